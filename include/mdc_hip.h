@@ -1,0 +1,162 @@
+/*
+ * mdc_hip.h -- C ABI of libmdc_hip.so: the MI355X (gfx950) implementation of the
+ * per-frame photometric + FOV undistortion hot path of tum-vision/mono_dataset_code.
+ *
+ * This is the drop-in boundary.  Everything above it (the C++ classes
+ * PhotometricUndistorter / UndistorterFOV in include/mono_dataset_code/, any
+ * ctypes / cgo / JNI binding) sees only plain pointers, sizes and status codes.
+ * Each entry point names the reference interface it replaces; paths are
+ * relative to the reference repository root.
+ *
+ * Conventions
+ *   - every function returns MDC_OK (0) or a negative mdc_status; the message
+ *     for the last failure on a context is mdc_last_error(ctx);
+ *   - *_host functions take host pointers, are synchronous and blocking, and
+ *     borrow the caller's buffers for the duration of the call only -- the
+ *     semantics of the reference methods they stand in for;
+ *   - *_device functions take device pointers valid on the context's GPU and
+ *     enqueue on `stream` (a hipStream_t passed as void*; NULL = the context's
+ *     own stream) without synchronising;
+ *   - a context is bound to one GPU; calls on one context are serialised by an
+ *     internal mutex, different contexts are independent; no global state.
+ */
+#ifndef MDC_HIP_H
+#define MDC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mdc_ctx mdc_ctx;
+
+typedef enum mdc_status {
+  MDC_OK = 0,
+  MDC_ERR_ARG = -1,       /* NULL / out-of-range argument */
+  MDC_ERR_STATE = -2,     /* a table the call needs was never set (cf. the reference's valid/validGamma/validVignette) */
+  MDC_ERR_SIZE = -3,      /* pixel count does not match the tables (cf. FOVUndistorter.cpp:327-338) */
+  MDC_ERR_HIP = -4,       /* a HIP runtime call failed */
+  MDC_ERR_NO_DEVICE = -5  /* no gfx950 device visible: there is NO CPU fallback */
+} mdc_status;
+
+/* Flag word of the per-frame calls: the four bools of
+ * DatasetReader::getImage(id, rectify, removeGamma, removeVignette, nanOverexposed)
+ * (src/BenchmarkDatasetReader.h:188) resp. the three of
+ * PhotometricUndistorter::unMapImage(..., undoGamma, undoVignette, killOverexposed)
+ * (src/PhotometricUndistorter.h:43).  Normalised inside the library exactly as
+ * src/PhotometricUndistorter.cpp:173-189 does. */
+enum {
+  MDC_GAMMA = 1u,    /* undoGamma / removeGamma          */
+  MDC_VIGNETTE = 2u, /* undoVignette / removeVignette    */
+  MDC_KILL_OVEREXPOSED = 4u, /* killOverexposed / nanOverexposed: raw 255 -> NaN */
+  MDC_RECTIFY = 8u   /* rectify (mdc_process_* only)     */
+};
+
+/* Pipeline selector for mdc_set_option(MDC_OPT_KERNEL) -- test/bench hook. */
+enum {
+  MDC_KERNEL_AUTO = 0,   /* LDS-tiled kernel when the remap allows it, else gather */
+  MDC_KERNEL_GATHER = 1, /* direct global gather (always legal)                    */
+  MDC_KERNEL_TILED = 2   /* LDS-staged source windows (fails if not plannable)     */
+};
+enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2 };
+
+typedef struct mdc_info {
+  int device;                /* HIP device ordinal                                  */
+  int in_w, in_h;            /* raw frame size (0 if unknown)                       */
+  int out_w, out_h;          /* rectified size (0 if no remap set)                  */
+  int valid_gamma;           /* GInv set     (PhotometricUndistorter::validGamma)   */
+  int valid_vignette;        /* vignette set (PhotometricUndistorter::validVignette)*/
+  int valid_remap;           /* remap set    (UndistorterFOV::valid)                */
+  int tiled;                 /* 1 if the LDS-tiled kernel is planned for the remap  */
+  int tile_w, tile_h;        /* output tile of the tiled kernel                     */
+  int n_tiles;
+  int lds_bytes;             /* dynamic LDS per workgroup of the tiled kernel       */
+  int src_bbox[4];           /* x0,y0,x1,y1 (inclusive) of source pixels any valid output taps */
+  int64_t src_bbox_bytes;    /* bbox area in bytes (u8 source)                      */
+  int64_t src_staged_bytes;  /* bytes the tiled kernel stages per frame (sum of windows) */
+  int64_t n_black;           /* outputs whose remap is the (-1,-1) sentinel         */
+} mdc_info;
+
+/* ---- lifetime -------------------------------------------------------------- */
+
+/* Creates a context on HIP device `device` (-1 = the calling thread's current
+ * device).  MDC_ERR_NO_DEVICE if no GPU is visible. */
+int mdc_create(int device, mdc_ctx** out);
+void mdc_destroy(mdc_ctx* ctx);
+const char* mdc_last_error(const mdc_ctx* ctx); /* never NULL; "" if no error; ctx may be NULL (creation errors) */
+int mdc_get_info(mdc_ctx* ctx, mdc_info* info);
+int mdc_set_option(mdc_ctx* ctx, int option, int value);
+
+/* ---- calibration tables (once per sequence) -------------------------------- */
+
+/* Uploads what PhotometricUndistorter's constructor builds
+ * (src/PhotometricUndistorter.cpp:42-157): ginv = GInv[256] (NULL = validGamma
+ * false), vignette_inv = vignetteMapInv[w*h] (NULL = validVignette false). */
+int mdc_set_photometric(mdc_ctx* ctx, const float* ginv, const float* vignette_inv, int w, int h);
+
+/* Uploads what UndistorterFOV's constructor builds (src/FOVUndistorter.cpp:223-251):
+ * remap_x/remap_y[out_w*out_h] in source pixels, (-1,-1) = black.  Plans the
+ * tiled kernel (source window per output tile).  NULL tables clear the remap. */
+int mdc_set_remap(mdc_ctx* ctx, const float* remap_x, const float* remap_y, int in_w, int in_h, int out_w, int out_h);
+
+/* ---- host-pointer, single-frame: under the reference's class methods -------- */
+
+/* PhotometricUndistorter::unMapImage(image_in, image_out, n, g, v, o)
+ * (src/PhotometricUndistorter.cpp:165-212). */
+int mdc_unmap_host(mdc_ctx* ctx, const uint8_t* image_in, float* image_out, int n, unsigned flags);
+
+/* UndistorterFOV::undistort<float> / <unsigned char>(input, output, nPixIn, nPixOut)
+ * (src/FOVUndistorter.cpp:322-370).  MDC_ERR_STATE without a remap (the reference
+ * returns silently, :325), MDC_ERR_SIZE on a pixel-count mismatch (:327-338);
+ * `output` is untouched in both cases. */
+int mdc_undistort_host_f32(mdc_ctx* ctx, const float* input, float* output, int n_in, int n_out);
+int mdc_undistort_host_u8(mdc_ctx* ctx, const uint8_t* input, float* output, int n_in, int n_out);
+
+/* The whole of DatasetReader::getImage after decode (src/BenchmarkDatasetReader.h:207-241)
+ * in one fused pass -- no W*H float intermediate (internalTempBuffer, :145,:222).
+ * `out` holds out_w*out_h floats with MDC_RECTIFY, else in_w*in_h. */
+int mdc_process_host(mdc_ctx* ctx, const uint8_t* raw, float* out, unsigned flags);
+
+/* ---- device-pointer, batched: the throughput path --------------------------- */
+
+/* unMapImage over nframes back-to-back frames (in: nframes*w*h u8; out: same count f32). */
+int mdc_unmap_batch_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags,
+                           void* stream);
+
+/* getImage over nframes frames, fused photometric + remap when MDC_RECTIFY is set
+ * (out: nframes*out_w*out_h f32), else identical to mdc_unmap_batch_device. */
+int mdc_process_batch_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags,
+                             void* stream);
+
+/* undistort<float> over nframes float frames (in: nframes*in_w*in_h f32). */
+int mdc_undistort_batch_device_f32(mdc_ctx* ctx, const float* d_in, float* d_out, int64_t nframes, void* stream);
+
+/* 2x2 box pyramid (BASELINE.json config 5; NOT in the reference -- definition in
+ * DESIGN.md): for each of nframes w*h f32 images writes levels 1..levels-1 into
+ * d_levels[l-1] (each nframes*(w>>l)*(h>>l) f32).  levels counts level 0. */
+int mdc_pyramid_batch_device(mdc_ctx* ctx, const float* d_base, int w, int h, int levels, float* const* d_levels,
+                             int64_t nframes, void* stream);
+
+/* Synthetic sequence generator (bench/test utility):
+ * byte i of frame f = fmix32(seed + (first_frame+f)*npix + i) >> 24. */
+int mdc_synth_frames_device(mdc_ctx* ctx, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix,
+                            uint32_t seed, void* stream);
+
+/* ---- calibration hand-over between ranks (multi-GPU) ------------------------ */
+
+/* Serialises every table of the context (header + GInv + vignetteInv + remapX/Y)
+ * into one flat blob so that rank 0 can broadcast it (RCCL / gloo -- the caller's
+ * collective) and the other ranks import it bit-identically.
+ * mdc_export_tables(ctx, NULL, 0, &n) returns the size. */
+int mdc_export_tables(mdc_ctx* ctx, void* blob, size_t cap, size_t* size);
+int mdc_import_tables(mdc_ctx* ctx, const void* blob, size_t size);
+
+/* Blocks until everything enqueued on the context's own stream has finished. */
+int mdc_synchronize(mdc_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDC_HIP_H */

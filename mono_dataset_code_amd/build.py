@@ -1,0 +1,92 @@
+"""Build recipe for the native libraries (in-tree, no install step).
+
+  libmdc_hip.so   hipcc, gfx950 only   HIP kernels + the C ABI (include/mdc_hip.h)
+  libmdc_host.so  g++                  drop-in C++ classes + C facade (include/mdc_host.h)
+
+Both land next to this file so they travel with the source tree to the GPU box.
+`python -m mono_dataset_code_amd.build` rebuilds whatever is out of date.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(CSRC, "host")
+INC = os.path.join(ROOT, "include")
+EIGEN_STUB = os.path.join(INC, "mono_dataset_code", "compat")  # only used when real Eigen is absent
+
+LIB_HIP = os.path.join(PKG, "libmdc_hip.so")
+LIB_HOST = os.path.join(PKG, "libmdc_host.so")
+
+HIP_SOURCES = [os.path.join(CSRC, f) for f in ("mdc_kernels.hip", "mdc_capi.hip")]
+HIP_DEPS = HIP_SOURCES + [os.path.join(CSRC, "mdc_internal.h"), os.path.join(INC, "mdc_hip.h")]
+HOST_SOURCES = [os.path.join(HOST, f) for f in (
+    "fov_undistorter.cpp", "photometric_undistorter.cpp", "gray_png.cpp", "host_device.cpp", "mdc_host_capi.cpp")]
+HOST_DEPS = HOST_SOURCES + [os.path.join(HOST, "gray_png.h"), os.path.join(HOST, "host_device.h"),
+                            os.path.join(INC, "mdc_hip.h"), os.path.join(INC, "mdc_host.h"),
+                            os.path.join(INC, "mono_dataset_code", "FOVUndistorter.h"),
+                            os.path.join(INC, "mono_dataset_code", "PhotometricUndistorter.h"),
+                            os.path.join(INC, "mono_dataset_code", "ExposureImage.h")]
+
+# -ffp-contract=off: the reference is built without FMA; contraction would break bit parity.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+             "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+HOST_FLAGS = ["-O2", "-std=c++11", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+    return r.stdout
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def eigen_include():
+    """Real Eigen if installed, else the few-type stand-in shipped for this image."""
+    for d in ("/usr/include/eigen3", "/usr/local/include/eigen3"):
+        if os.path.exists(os.path.join(d, "Eigen", "Core")):
+            return d
+    return EIGEN_STUB
+
+
+def build_hip(force=False):
+    if force or _stale(LIB_HIP, HIP_DEPS):
+        _run([hipcc()] + HIP_FLAGS + ["-I" + INC] + HIP_SOURCES + ["-o", LIB_HIP])
+    return LIB_HIP
+
+
+def build_host(force=False):
+    build_hip(force)
+    if force or _stale(LIB_HOST, HOST_DEPS + [LIB_HIP]):
+        _run(["g++"] + HOST_FLAGS + ["-I" + INC, "-I" + os.path.join(INC, "mono_dataset_code"), "-I" + HOST,
+                                     "-I" + eigen_include()] + HOST_SOURCES +
+             ["-L" + PKG, "-lmdc_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-o", LIB_HOST])
+    return LIB_HOST
+
+
+def build_all(force=False):
+    build_hip(force)
+    build_host(force)
+    return LIB_HIP, LIB_HOST
+
+
+if __name__ == "__main__":
+    print("\n".join(build_all(force="--force" in sys.argv)))

@@ -1,0 +1,343 @@
+"""ctypes bindings of include/mdc_hip.h (libmdc_hip.so) and include/mdc_host.h (libmdc_host.so).
+
+Thin, explicit, no logic: every Python method is one C call.  Device buffers are
+passed as integer addresses (e.g. torch.Tensor.data_ptr()), host buffers as numpy
+arrays.  Loading fails loudly (OSError) when the libraries have not been built --
+there is no Python or CPU fallback for the per-frame work.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_HIP_PATH = os.path.join(_PKG, "libmdc_hip.so")
+LIB_HOST_PATH = os.path.join(_PKG, "libmdc_host.so")
+
+# flag word (include/mdc_hip.h)
+GAMMA, VIGNETTE, KILL_OVEREXPOSED, RECTIFY = 1, 2, 4, 8
+KERNEL_AUTO, KERNEL_GATHER, KERNEL_TILED = 0, 1, 2
+OPT_KERNEL, OPT_FRAMES_PER_BLOCK = 1, 2
+OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
+
+# every symbol include/mdc_hip.h declares (checked by tests/test_abi.py)
+HIP_SYMBOLS = [
+    "mdc_create", "mdc_destroy", "mdc_last_error", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
+    "mdc_set_remap", "mdc_unmap_host", "mdc_undistort_host_f32", "mdc_undistort_host_u8", "mdc_process_host",
+    "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
+    "mdc_pyramid_batch_device", "mdc_synth_frames_device", "mdc_export_tables", "mdc_import_tables",
+    "mdc_synchronize",
+]
+HOST_SYMBOLS = [
+    "mdch_fov_create", "mdch_fov_destroy", "mdch_fov_valid", "mdch_fov_has_gpu", "mdch_fov_dims",
+    "mdch_fov_intrinsics", "mdch_fov_remap", "mdch_fov_distort", "mdch_fov_undistort_f32", "mdch_fov_undistort_u8",
+    "mdch_photo_create", "mdch_photo_destroy", "mdch_photo_valid", "mdch_photo_has_gpu", "mdch_photo_ginv",
+    "mdch_photo_g", "mdch_photo_vignette", "mdch_photo_unmap", "mdch_bind",
+]
+
+
+class MdcInfo(C.Structure):
+    _fields_ = [("device", C.c_int), ("in_w", C.c_int), ("in_h", C.c_int), ("out_w", C.c_int), ("out_h", C.c_int),
+                ("valid_gamma", C.c_int), ("valid_vignette", C.c_int), ("valid_remap", C.c_int), ("tiled", C.c_int),
+                ("tile_w", C.c_int), ("tile_h", C.c_int), ("n_tiles", C.c_int), ("lds_bytes", C.c_int),
+                ("src_bbox", C.c_int * 4), ("src_bbox_bytes", C.c_int64), ("src_staged_bytes", C.c_int64),
+                ("n_black", C.c_int64)]
+
+
+class MdcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mdc error %d: %s" % (code, msg))
+        self.code = code
+
+
+_hip = None
+_host = None
+_vp, _i, _i64, _u32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_size_t
+
+
+def hip_lib():
+    global _hip
+    if _hip is None:
+        if not os.path.exists(LIB_HIP_PATH):
+            raise OSError("%s not built: run `python -m mono_dataset_code_amd.build`" % LIB_HIP_PATH)
+        L = C.CDLL(LIB_HIP_PATH)
+        L.mdc_create.argtypes = [_i, C.POINTER(_vp)]
+        L.mdc_destroy.argtypes = [_vp]
+        L.mdc_destroy.restype = None
+        L.mdc_last_error.argtypes = [_vp]
+        L.mdc_last_error.restype = C.c_char_p
+        L.mdc_get_info.argtypes = [_vp, C.POINTER(MdcInfo)]
+        L.mdc_set_option.argtypes = [_vp, _i, _i]
+        L.mdc_set_photometric.argtypes = [_vp, _vp, _vp, _i, _i]
+        L.mdc_set_remap.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i]
+        L.mdc_unmap_host.argtypes = [_vp, _vp, _vp, _i, C.c_uint]
+        L.mdc_undistort_host_f32.argtypes = [_vp, _vp, _vp, _i, _i]
+        L.mdc_undistort_host_u8.argtypes = [_vp, _vp, _vp, _i, _i]
+        L.mdc_process_host.argtypes = [_vp, _vp, _vp, C.c_uint]
+        L.mdc_unmap_batch_device.argtypes = [_vp, _vp, _vp, _i64, C.c_uint, _vp]
+        L.mdc_process_batch_device.argtypes = [_vp, _vp, _vp, _i64, C.c_uint, _vp]
+        L.mdc_undistort_batch_device_f32.argtypes = [_vp, _vp, _vp, _i64, _vp]
+        L.mdc_pyramid_batch_device.argtypes = [_vp, _vp, _i, _i, _i, C.POINTER(_vp), _i64, _vp]
+        L.mdc_synth_frames_device.argtypes = [_vp, _vp, _i64, _i64, _i, _u32, _vp]
+        L.mdc_export_tables.argtypes = [_vp, _vp, _sz, C.POINTER(_sz)]
+        L.mdc_import_tables.argtypes = [_vp, _vp, _sz]
+        L.mdc_synchronize.argtypes = [_vp]
+        for n in HIP_SYMBOLS:
+            if n not in ("mdc_destroy", "mdc_last_error"):
+                getattr(L, n).restype = _i
+        _hip = L
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        hip_lib()
+        if not os.path.exists(LIB_HOST_PATH):
+            raise OSError("%s not built: run `python -m mono_dataset_code_amd.build`" % LIB_HOST_PATH)
+        L = C.CDLL(LIB_HOST_PATH)
+        L.mdch_fov_create.argtypes = [C.c_char_p]
+        L.mdch_fov_create.restype = _vp
+        L.mdch_fov_destroy.argtypes = [_vp]
+        L.mdch_fov_destroy.restype = None
+        for n in ("mdch_fov_valid", "mdch_fov_has_gpu"):
+            getattr(L, n).argtypes = [_vp]
+            getattr(L, n).restype = _i
+        L.mdch_fov_dims.argtypes = [_vp, _vp]
+        L.mdch_fov_dims.restype = None
+        L.mdch_fov_intrinsics.argtypes = [_vp, _vp]
+        L.mdch_fov_intrinsics.restype = None
+        L.mdch_fov_remap.argtypes = [_vp, _vp, _vp]
+        L.mdch_fov_remap.restype = _i
+        L.mdch_fov_distort.argtypes = [_vp, _vp, _vp, _i]
+        L.mdch_fov_distort.restype = None
+        L.mdch_fov_undistort_f32.argtypes = [_vp, _vp, _vp, _i, _i]
+        L.mdch_fov_undistort_f32.restype = None
+        L.mdch_fov_undistort_u8.argtypes = [_vp, _vp, _vp, _i, _i]
+        L.mdch_fov_undistort_u8.restype = None
+        L.mdch_photo_create.argtypes = [C.c_char_p, C.c_char_p, _i, _i]
+        L.mdch_photo_create.restype = _vp
+        L.mdch_photo_destroy.argtypes = [_vp]
+        L.mdch_photo_destroy.restype = None
+        for n in ("mdch_photo_valid", "mdch_photo_has_gpu"):
+            getattr(L, n).argtypes = [_vp]
+            getattr(L, n).restype = _i
+        L.mdch_photo_ginv.argtypes = [_vp, _vp]
+        L.mdch_photo_ginv.restype = _i
+        L.mdch_photo_g.argtypes = [_vp, _vp]
+        L.mdch_photo_g.restype = _i
+        L.mdch_photo_vignette.argtypes = [_vp, _vp, _vp]
+        L.mdch_photo_vignette.restype = _i
+        L.mdch_photo_unmap.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i]
+        L.mdch_photo_unmap.restype = None
+        L.mdch_bind.argtypes = [_vp, _vp, _vp]
+        L.mdch_bind.restype = _i
+        _host = L
+    return _host
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(_vp) if a is not None else None
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+class Context:
+    """One mdc_ctx (one GPU).  Methods map 1:1 onto include/mdc_hip.h."""
+
+    def __init__(self, device=0):
+        self._L = hip_lib()
+        h = _vp()
+        rc = self._L.mdc_create(int(device), C.byref(h))
+        if rc != OK:
+            raise MdcError(rc, self._L.mdc_last_error(None).decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mdc_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def handle(self):
+        return self._h
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise MdcError(rc, self._L.mdc_last_error(self._h).decode())
+
+    def last_error(self):
+        return self._L.mdc_last_error(self._h).decode()
+
+    def info(self):
+        i = MdcInfo()
+        self._chk(self._L.mdc_get_info(self._h, C.byref(i)))
+        return i
+
+    def set_option(self, opt, value):
+        self._chk(self._L.mdc_set_option(self._h, opt, value))
+
+    def set_photometric(self, ginv, vinv, w, h):
+        g = _f32(ginv) if ginv is not None else None
+        v = _f32(vinv) if vinv is not None else None
+        if g is not None:
+            assert g.size == 256
+        if v is not None:
+            assert v.size == w * h
+        self._chk(self._L.mdc_set_photometric(self._h, _np_ptr(g), _np_ptr(v), w, h))
+
+    def set_remap(self, rx, ry, in_w, in_h, out_w, out_h):
+        if rx is None:
+            self._chk(self._L.mdc_set_remap(self._h, None, None, 0, 0, 0, 0))
+            return
+        rx, ry = _f32(rx), _f32(ry)
+        assert rx.size == out_w * out_h and ry.size == out_w * out_h
+        self._chk(self._L.mdc_set_remap(self._h, _np_ptr(rx), _np_ptr(ry), in_w, in_h, out_w, out_h))
+
+    # host-pointer single-frame calls: return the status code, raise only if asked
+    def unmap_host(self, img_u8, out_f32, flags, check=True):
+        rc = self._L.mdc_unmap_host(self._h, _np_ptr(img_u8), _np_ptr(out_f32), img_u8.size, flags)
+        if check:
+            self._chk(rc)
+        return rc
+
+    def undistort_host(self, img, out_f32, check=True):
+        fn = self._L.mdc_undistort_host_f32 if img.dtype == np.float32 else self._L.mdc_undistort_host_u8
+        rc = fn(self._h, _np_ptr(img), _np_ptr(out_f32), img.size, out_f32.size)
+        if check:
+            self._chk(rc)
+        return rc
+
+    def process_host(self, raw_u8, out_f32, flags, check=True):
+        rc = self._L.mdc_process_host(self._h, _np_ptr(raw_u8), _np_ptr(out_f32), flags)
+        if check:
+            self._chk(rc)
+        return rc
+
+    # device-pointer batched calls (addresses as ints)
+    def unmap_batch(self, d_in, d_out, nframes, flags, stream=0):
+        self._chk(self._L.mdc_unmap_batch_device(self._h, d_in, d_out, nframes, flags, stream or None))
+
+    def process_batch(self, d_in, d_out, nframes, flags, stream=0):
+        self._chk(self._L.mdc_process_batch_device(self._h, d_in, d_out, nframes, flags, stream or None))
+
+    def undistort_batch_f32(self, d_in, d_out, nframes, stream=0):
+        self._chk(self._L.mdc_undistort_batch_device_f32(self._h, d_in, d_out, nframes, stream or None))
+
+    def pyramid_batch(self, d_base, w, h, levels, d_levels, nframes, stream=0):
+        arr = (_vp * max(1, len(d_levels)))(*d_levels)
+        self._chk(self._L.mdc_pyramid_batch_device(self._h, d_base, w, h, levels, arr, nframes, stream or None))
+
+    def synth_frames(self, d_out, first_frame, nframes, npix, seed, stream=0):
+        self._chk(self._L.mdc_synth_frames_device(self._h, d_out, first_frame, nframes, npix, seed, stream or None))
+
+    def export_tables(self):
+        n = _sz(0)
+        self._chk(self._L.mdc_export_tables(self._h, None, 0, C.byref(n)))
+        buf = np.zeros(n.value, dtype=np.uint8)
+        self._chk(self._L.mdc_export_tables(self._h, _np_ptr(buf), buf.size, C.byref(n)))
+        return buf
+
+    def import_tables(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self._chk(self._L.mdc_import_tables(self._h, _np_ptr(blob), blob.size))
+
+    def synchronize(self):
+        self._chk(self._L.mdc_synchronize(self._h))
+
+    def bind(self, fov=None, photo=None):
+        rc = host_lib().mdch_bind(self._h, fov._h if fov is not None else None, photo._h if photo is not None else None)
+        self._chk(rc)
+
+
+class UndistorterFOV:
+    """Handle on the C++ class UndistorterFOV (include/mono_dataset_code/FOVUndistorter.h)."""
+
+    def __init__(self, camera_txt):
+        self._L = host_lib()
+        self._h = self._L.mdch_fov_create(os.fsencode(camera_txt))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mdch_fov_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def is_valid(self):
+        return bool(self._L.mdch_fov_valid(self._h))
+
+    def has_gpu(self):
+        return bool(self._L.mdch_fov_has_gpu(self._h))
+
+    def dims(self):
+        d = np.zeros(4, dtype=np.int32)
+        self._L.mdch_fov_dims(self._h, _np_ptr(d))
+        return tuple(int(x) for x in d)
+
+    def intrinsics(self):
+        o = np.zeros(29, dtype=np.float32)
+        self._L.mdch_fov_intrinsics(self._h, _np_ptr(o))
+        return {"K_rect": o[0:9].reshape(3, 3).copy(), "K_org": o[9:18].reshape(3, 3).copy(),
+                "original": o[18:23].copy(), "omega": float(o[23]), "out_calib": o[24:29].copy()}
+
+    def remap(self):
+        _, _, ow, oh = self.dims()
+        if not self.is_valid():
+            return None
+        rx = np.zeros(ow * oh, dtype=np.float32)
+        ry = np.zeros(ow * oh, dtype=np.float32)
+        if not self._L.mdch_fov_remap(self._h, _np_ptr(rx), _np_ptr(ry)):
+            return None
+        return rx, ry
+
+    def distort_coordinates(self, x, y):
+        assert x.dtype == np.float32 and y.dtype == np.float32 and x.size == y.size
+        self._L.mdch_fov_distort(self._h, _np_ptr(x), _np_ptr(y), x.size)
+
+    def undistort(self, img, out):
+        fn = self._L.mdch_fov_undistort_f32 if img.dtype == np.float32 else self._L.mdch_fov_undistort_u8
+        fn(self._h, _np_ptr(img), _np_ptr(out), img.size, out.size)
+
+
+class PhotometricUndistorter:
+    """Handle on the C++ class PhotometricUndistorter (include/mono_dataset_code/PhotometricUndistorter.h)."""
+
+    def __init__(self, pcalib_txt, vignette_image, w, h):
+        self._L = host_lib()
+        self.w, self.h = w, h
+        self._h = self._L.mdch_photo_create(os.fsencode(pcalib_txt), os.fsencode(vignette_image), w, h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mdch_photo_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def valid(self):
+        return self._L.mdch_photo_valid(self._h)
+
+    def has_gpu(self):
+        return bool(self._L.mdch_photo_has_gpu(self._h))
+
+    def ginv(self):
+        o = np.zeros(256, dtype=np.float32)
+        return o if self._L.mdch_photo_ginv(self._h, _np_ptr(o)) else None
+
+    def g(self):
+        o = np.zeros(256, dtype=np.float32)
+        return o if self._L.mdch_photo_g(self._h, _np_ptr(o)) else None
+
+    def vignette(self):
+        m = np.zeros(self.w * self.h, dtype=np.float32)
+        i = np.zeros(self.w * self.h, dtype=np.float32)
+        return (m, i) if self._L.mdch_photo_vignette(self._h, _np_ptr(m), _np_ptr(i)) else None
+
+    def unmap(self, img_u8, out_f32, g, v, o):
+        self._L.mdch_photo_unmap(self._h, _np_ptr(img_u8), _np_ptr(out_f32), img_u8.size, int(g), int(v), int(o))

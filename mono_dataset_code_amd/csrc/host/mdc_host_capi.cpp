@@ -1,0 +1,132 @@
+// C facade over the drop-in classes -- see include/mdc_host.h.
+#include "mdc_host.h"
+
+#include <cstring>
+
+#include "FOVUndistorter.h"
+#include "PhotometricUndistorter.h"
+
+struct mdch_fov { UndistorterFOV* u; };
+struct mdch_photo { PhotometricUndistorter* p; };
+
+// Friend of both classes: read-only view of their tables for the facade.
+struct MdcHostAccess {
+  static const float* rx(const UndistorterFOV& u) { return u.remap_x_; }
+  static const float* ry(const UndistorterFOV& u) { return u.remap_y_; }
+  static const float* calib_out(const UndistorterFOV& u) { return u.calib_out_; }
+  static bool has_gpu(const UndistorterFOV& u) { return u.gpu_ != 0; }
+  static bool has_gpu(const PhotometricUndistorter& p) { return p.gpu_ != 0; }
+  static bool valid_gamma(const PhotometricUndistorter& p) { return p.valid_gamma_; }
+  static bool valid_vignette(const PhotometricUndistorter& p) { return p.valid_vignette_; }
+  static const float* vmap(const PhotometricUndistorter& p) { return p.vignette_; }
+  static const float* vinv(const PhotometricUndistorter& p) { return p.vignette_inv_; }
+  static const float* ginv(const PhotometricUndistorter& p) { return p.ginv_; }
+  static int w(const PhotometricUndistorter& p) { return p.w_; }
+  static int h(const PhotometricUndistorter& p) { return p.h_; }
+};
+
+extern "C" {
+
+mdch_fov* mdch_fov_create(const char* camera_txt) {
+  mdch_fov* h = new mdch_fov;
+  h->u = new UndistorterFOV(camera_txt);
+  return h;
+}
+void mdch_fov_destroy(mdch_fov* h) {
+  if (!h) return;
+  delete h->u;
+  delete h;
+}
+int mdch_fov_valid(const mdch_fov* h) { return h->u->isValid() ? 1 : 0; }
+int mdch_fov_has_gpu(const mdch_fov* h) { return MdcHostAccess::has_gpu(*h->u) ? 1 : 0; }
+void mdch_fov_dims(const mdch_fov* h, int d[4]) {
+  d[0] = h->u->getInputDims()[0];
+  d[1] = h->u->getInputDims()[1];
+  d[2] = h->u->getOutputDims()[0];
+  d[3] = h->u->getOutputDims()[1];
+}
+void mdch_fov_intrinsics(const mdch_fov* h, float* o) {
+  const Eigen::Matrix3f a = h->u->getK_rect(), b = h->u->getK_org();
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      o[r * 3 + c] = a(r, c);
+      o[9 + r * 3 + c] = b(r, c);
+    }
+  const Eigen::VectorXf v = h->u->getOriginalCalibration();
+  for (int i = 0; i < 5; i++) o[18 + i] = v[i];
+  o[23] = h->u->getOmega();
+  for (int i = 0; i < 5; i++) o[24 + i] = MdcHostAccess::calib_out(*h->u)[i];
+}
+int mdch_fov_remap(const mdch_fov* h, float* rx, float* ry) {
+  if (!h->u->isValid() || !MdcHostAccess::rx(*h->u)) return 0;
+  const size_t n = (size_t)h->u->getOutputDims()[0] * h->u->getOutputDims()[1];
+  memcpy(rx, MdcHostAccess::rx(*h->u), n * sizeof(float));
+  memcpy(ry, MdcHostAccess::ry(*h->u), n * sizeof(float));
+  return 1;
+}
+void mdch_fov_distort(mdch_fov* h, float* x, float* y, int n) { h->u->distortCoordinates(x, y, n); }
+void mdch_fov_undistort_f32(const mdch_fov* h, const float* in, float* out, int n_in, int n_out) {
+  h->u->undistort<float>(in, out, n_in, n_out);
+}
+void mdch_fov_undistort_u8(const mdch_fov* h, const unsigned char* in, float* out, int n_in, int n_out) {
+  h->u->undistort<unsigned char>(in, out, n_in, n_out);
+}
+
+mdch_photo* mdch_photo_create(const char* pcalib, const char* vignette, int w, int h) {
+  mdch_photo* p = new mdch_photo;
+  p->p = new PhotometricUndistorter(pcalib, vignette, w, h);
+  return p;
+}
+void mdch_photo_destroy(mdch_photo* p) {
+  if (!p) return;
+  delete p->p;
+  delete p;
+}
+int mdch_photo_valid(const mdch_photo* p) {
+  return (MdcHostAccess::valid_gamma(*p->p) ? 1 : 0) | (MdcHostAccess::valid_vignette(*p->p) ? 2 : 0);
+}
+int mdch_photo_has_gpu(const mdch_photo* p) { return MdcHostAccess::has_gpu(*p->p) ? 1 : 0; }
+int mdch_photo_ginv(mdch_photo* p, float* o) {
+  const float* g = p->p->getGInv();
+  if (!g) return 0;
+  memcpy(o, g, 256 * sizeof(float));
+  return 1;
+}
+int mdch_photo_g(mdch_photo* p, float* o) {
+  const float* g = p->p->getG();
+  if (!g) return 0;
+  memcpy(o, g, 256 * sizeof(float));
+  return 1;
+}
+int mdch_photo_vignette(const mdch_photo* p, float* map, float* inv) {
+  if (!MdcHostAccess::valid_vignette(*p->p)) return 0;
+  const size_t n = (size_t)MdcHostAccess::w(*p->p) * MdcHostAccess::h(*p->p);
+  if (map) memcpy(map, MdcHostAccess::vmap(*p->p), n * sizeof(float));
+  if (inv) memcpy(inv, MdcHostAccess::vinv(*p->p), n * sizeof(float));
+  return 1;
+}
+void mdch_photo_unmap(mdch_photo* p, unsigned char* in, float* out, int n, int g, int v, int o) {
+  p->p->unMapImage(in, out, n, g != 0, v != 0, o != 0);
+}
+
+int mdch_bind(mdc_ctx* ctx, const mdch_fov* fov, const mdch_photo* photo) {
+  if (!ctx) return MDC_ERR_ARG;
+  int rc = MDC_OK;
+  if (photo) {
+    const PhotometricUndistorter& p = *photo->p;
+    rc = mdc_set_photometric(ctx, MdcHostAccess::valid_gamma(p) ? MdcHostAccess::ginv(p) : 0,
+                             MdcHostAccess::valid_vignette(p) ? MdcHostAccess::vinv(p) : 0, MdcHostAccess::w(p),
+                             MdcHostAccess::h(p));
+    if (rc != MDC_OK) return rc;
+  }
+  if (fov) {
+    const UndistorterFOV& u = *fov->u;
+    if (u.isValid())
+      rc = mdc_set_remap(ctx, MdcHostAccess::rx(u), MdcHostAccess::ry(u), u.getInputDims()[0], u.getInputDims()[1],
+                         u.getOutputDims()[0], u.getOutputDims()[1]);
+    else rc = mdc_set_remap(ctx, 0, 0, 0, 0, 0, 0);
+  }
+  return rc;
+}
+
+}  // extern "C"

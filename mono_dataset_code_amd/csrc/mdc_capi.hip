@@ -1,0 +1,624 @@
+// libmdc_hip.so -- implementation of the C ABI in include/mdc_hip.h.
+//
+// Host-side responsibilities only: device copies of the calibration tables, the
+// tile plan of the LDS-staged remap kernel, flag normalisation exactly as
+// src/PhotometricUndistorter.cpp:173-189 (reference repo), staging for the
+// host-pointer calls.  There is NO CPU implementation of the per-frame maths in
+// this library: without a HIP device every entry point fails with
+// MDC_ERR_NO_DEVICE.
+#include "../../include/mdc_hip.h"
+#include "mdc_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace mdc;
+
+struct mdc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  std::string err;
+
+  // photometric tables
+  int in_w = 0, in_h = 0;
+  bool valid_gamma = false, valid_vignette = false;
+  std::vector<float> h_ginv;  // 256
+  std::vector<float> h_vinv;  // in_w*in_h
+  float* d_luts = nullptr;    // 4 x 256: [gamma | kill<<1]
+  float* d_vinv = nullptr;
+
+  // geometric tables
+  bool valid_remap = false;
+  int rm_in_w = 0, rm_in_h = 0, out_w = 0, out_h = 0;
+  std::vector<float> h_rx, h_ry;
+  float *d_rx = nullptr, *d_ry = nullptr;
+
+  // tile plan
+  bool tiled = false;
+  TileDesc* d_tiles = nullptr;
+  int n_tiles = 0, tiles_x = 0, win_bytes = 0;
+  int bbox[4] = {0, 0, -1, -1};
+  int64_t staged_bytes = 0, n_black = 0;
+
+  // options
+  int opt_kernel = MDC_KERNEL_AUTO;
+  int opt_fpb = 0;
+
+  // staging for the host-pointer calls
+  void* d_stage_in = nullptr;
+  size_t stage_in_cap = 0;
+  float* d_stage_out = nullptr;
+  size_t stage_out_cap = 0;
+};
+
+namespace {
+
+thread_local std::string g_create_err;
+
+int fail(mdc_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  else g_create_err = buf;
+  return code;
+}
+
+#define MDC_HIP(c, call)                                                                      \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) return fail((c), MDC_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+    else prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+// The reference's flag degradation, src/PhotometricUndistorter.cpp:173-189.
+void normalise(const mdc_ctx* c, unsigned flags, bool& g, bool& v, bool& o) {
+  g = (flags & MDC_GAMMA) != 0;
+  v = (flags & MDC_VIGNETTE) != 0;
+  o = (flags & MDC_KILL_OVEREXPOSED) != 0;
+  if (!c->valid_gamma && g) g = false;
+  if (!c->valid_vignette && v) v = false;
+  if (!g && v) {
+    v = false;
+    g = false;
+  }
+}
+
+const float* lut_for(const mdc_ctx* c, bool g, bool o) { return c->d_luts + 256 * ((g ? 1 : 0) | (o ? 2 : 0)); }
+
+int upload_luts(mdc_ctx* c) {
+  std::vector<float> l(4 * 256);
+  for (int var = 0; var < 4; var++)
+    for (int b = 0; b < 256; b++) {
+      float x = (var & 1) ? (c->valid_gamma ? c->h_ginv[b] : (float)b) : (float)b;
+      if ((var & 2) && b == 255) x = std::numeric_limits<float>::quiet_NaN();
+      l[var * 256 + b] = x;
+    }
+  if (!c->d_luts) MDC_HIP(c, hipMalloc(&c->d_luts, l.size() * sizeof(float)));
+  MDC_HIP(c, hipMemcpy(c->d_luts, l.data(), l.size() * sizeof(float), hipMemcpyHostToDevice));
+  return MDC_OK;
+}
+
+int frames_per_block(const mdc_ctx* c, int64_t nframes, int blocks_per_group) {
+  if (c->opt_fpb > 0) return (int)std::min<int64_t>(c->opt_fpb, std::max<int64_t>(nframes, 1));
+  // enough workgroups to fill 256 CUs several times over, yet tables amortised
+  int64_t groups = std::max<int64_t>(1, 4096 / std::max(1, blocks_per_group));
+  groups = std::min<int64_t>(groups, nframes);
+  return (int)((nframes + groups - 1) / groups);
+}
+
+// Source window of every output tile (see TileDesc).  Fails (tiled = false)
+// when rows of the frame are not whole 16-byte chunks or a window is too large.
+int plan_tiles(mdc_ctx* c) {
+  c->tiled = false;
+  c->n_tiles = 0;
+  c->staged_bytes = 0;
+  c->n_black = 0;
+  c->bbox[0] = c->bbox[1] = std::numeric_limits<int>::max();
+  c->bbox[2] = c->bbox[3] = -1;
+  const int ow = c->out_w, oh = c->out_h, iw = c->rm_in_w;
+  const int tx = (ow + kTileW - 1) / kTileW, ty = (oh + kTileH - 1) / kTileH;
+  std::vector<TileDesc> tiles((size_t)tx * ty);
+  bool ok = (iw % 16 == 0);
+  int win_max = 16;
+  for (int t = 0; t < tx * ty; t++) {
+    int x_lo = std::numeric_limits<int>::max(), y_lo = x_lo, x_hi = -1, y_hi = -1;
+    const int bx = (t % tx) * kTileW, by = (t / tx) * kTileH;
+    for (int y = by; y < std::min(by + kTileH, oh); y++)
+      for (int x = bx; x < std::min(bx + kTileW, ow); x++) {
+        const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
+        if (xx < 0) {
+          c->n_black++;
+          continue;
+        }
+        const int xi = (int)xx, yi = (int)yy;
+        x_lo = std::min(x_lo, xi);
+        x_hi = std::max(x_hi, xi + 1);
+        y_lo = std::min(y_lo, yi);
+        y_hi = std::max(y_hi, yi + 1);
+      }
+    TileDesc& d = tiles[t];
+    if (x_hi < 0) {
+      d = TileDesc{0, 0, 0, 1};
+      continue;
+    }
+    c->bbox[0] = std::min(c->bbox[0], x_lo);
+    c->bbox[1] = std::min(c->bbox[1], y_lo);
+    c->bbox[2] = std::max(c->bbox[2], x_hi);
+    c->bbox[3] = std::max(c->bbox[3], y_hi);
+    d.x0 = x_lo & ~15;
+    d.y0 = y_lo;
+    d.rows = y_hi - y_lo + 1;
+    d.cpr = (x_hi - d.x0) / 16 + 1;
+    const int nch = d.rows * d.cpr;
+    if (nch > kTileMaxChunks * kTileThreads) ok = false;
+    if (d.x0 + d.cpr * 16 > iw) ok = false;
+    win_max = std::max(win_max, nch * 16);
+    c->staged_bytes += (int64_t)nch * 16;
+  }
+  if (c->bbox[2] < 0) c->bbox[0] = c->bbox[1] = 0;
+  if (tiled_lds_bytes(win_max) > 64 * 1024) ok = false;
+  if (c->d_tiles) {
+    (void)hipFree(c->d_tiles);
+    c->d_tiles = nullptr;
+  }
+  if (!ok) return MDC_OK;
+  MDC_HIP(c, hipMalloc(&c->d_tiles, tiles.size() * sizeof(TileDesc)));
+  MDC_HIP(c, hipMemcpy(c->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+  c->n_tiles = tx * ty;
+  c->tiles_x = tx;
+  c->win_bytes = win_max;
+  c->tiled = true;
+  return MDC_OK;
+}
+
+int ensure_stage(mdc_ctx* c, size_t in_bytes, size_t out_bytes) {
+  if (in_bytes > c->stage_in_cap) {
+    if (c->d_stage_in) (void)hipFree(c->d_stage_in);
+    c->d_stage_in = nullptr;
+    c->stage_in_cap = 0;
+    MDC_HIP(c, hipMalloc(&c->d_stage_in, in_bytes));
+    c->stage_in_cap = in_bytes;
+  }
+  if (out_bytes > c->stage_out_cap) {
+    if (c->d_stage_out) (void)hipFree(c->d_stage_out);
+    c->d_stage_out = nullptr;
+    c->stage_out_cap = 0;
+    MDC_HIP(c, hipMalloc(&c->d_stage_out, out_bytes));
+    c->stage_out_cap = out_bytes;
+  }
+  return MDC_OK;
+}
+
+RemapArgs remap_args(const mdc_ctx* c, const float* lut, const float* vinv) {
+  RemapArgs a;
+  a.lut = lut;
+  a.vinv = vinv;
+  a.rx = c->d_rx;
+  a.ry = c->d_ry;
+  a.in_w = c->rm_in_w;
+  a.in_h = c->rm_in_h;
+  a.out_w = c->out_w;
+  a.out_h = c->out_h;
+  return a;
+}
+
+// Enqueue the fused / photometric-only pipeline on `s`.  Lock held by caller.
+int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, hipStream_t s) {
+  bool g, v, o;
+  normalise(c, flags, g, v, o);
+  const float* lut = lut_for(c, g, o);
+  const float* vinv = v ? c->d_vinv : nullptr;
+  if (!(flags & MDC_RECTIFY)) {
+    const int fw = c->in_w > 0 ? c->in_w : c->rm_in_w, fh = c->in_h > 0 ? c->in_h : c->rm_in_h;
+    if (fw <= 0 || fh <= 0) return fail(c, MDC_ERR_STATE, "frame size unknown: set the photometric tables or a remap first");
+    const int64_t npix = (int64_t)fw * fh;
+    const int fpb = frames_per_block(c, nframes, (int)((npix + 4095) / 4096));
+    MDC_HIP(c, launch_unmap(d_in, d_out, lut, vinv, npix, nframes, fpb, s));
+    return MDC_OK;
+  }
+  if (!c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
+  if (vinv && (c->in_w != c->rm_in_w || c->in_h != c->rm_in_h))
+    return fail(c, MDC_ERR_SIZE, "vignette is %dx%d but the remap expects %dx%d input", c->in_w, c->in_h, c->rm_in_w,
+                c->rm_in_h);
+  RemapArgs a = remap_args(c, lut, vinv);
+  const bool aligned = (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
+  bool use_tiled = c->tiled && aligned;
+  if (c->opt_kernel == MDC_KERNEL_GATHER) use_tiled = false;
+  if (c->opt_kernel == MDC_KERNEL_TILED && !use_tiled)
+    return fail(c, MDC_ERR_STATE, "tiled kernel requested but not plannable for this remap / alignment");
+  if (use_tiled) {
+    TilePlan p{c->d_tiles, c->n_tiles, c->tiles_x, c->win_bytes};
+    const int fpb = frames_per_block(c, nframes, (c->n_tiles + 7) & ~7);
+    MDC_HIP(c, launch_remap_tiled_u8(d_in, d_out, a, p, nframes, fpb, s));
+  } else {
+    const int fpb = frames_per_block(c, nframes, (c->out_w * c->out_h + 255) / 256);
+    MDC_HIP(c, launch_remap_gather_u8(d_in, d_out, a, nframes, fpb, s));
+  }
+  return MDC_OK;
+}
+
+struct BlobHeader {
+  uint32_t magic, version;
+  int32_t in_w, in_h, rm_in_w, rm_in_h, out_w, out_h;
+  int32_t valid_gamma, valid_vignette, valid_remap, pad;
+};
+constexpr uint32_t kMagic = 0x4d444331u;  // "MDC1"
+
+}  // namespace
+
+extern "C" {
+
+int mdc_create(int device, mdc_ctx** out) {
+  if (!out) return fail(nullptr, MDC_ERR_ARG, "mdc_create: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, MDC_ERR_NO_DEVICE, "no HIP device visible (%s); this library has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device == -1 && hipGetDevice(&device) != hipSuccess) device = 0;
+  if (device < 0 || device >= n) return fail(nullptr, MDC_ERR_ARG, "device %d out of range [0,%d)", device, n);
+  mdc_ctx* c = new mdc_ctx();
+  c->device = device;
+  DeviceGuard dg(device);
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    fail(nullptr, MDC_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    delete c;
+    return MDC_ERR_HIP;
+  }
+  c->h_ginv.assign(256, 0.f);
+  int rc = upload_luts(c);
+  if (rc != MDC_OK) {
+    g_create_err = c->err;
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return rc;
+  }
+  *out = c;
+  return MDC_OK;
+}
+
+void mdc_destroy(mdc_ctx* c) {
+  if (!c) return;
+  {
+    DeviceGuard dg(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_tiles, c->d_stage_in, c->d_stage_out};
+    for (void* p : ptrs)
+      if (p) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+
+const char* mdc_last_error(const mdc_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int mdc_set_option(mdc_ctx* c, int option, int value) {
+  if (!c) return MDC_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  switch (option) {
+    case MDC_OPT_KERNEL:
+      if (value < MDC_KERNEL_AUTO || value > MDC_KERNEL_TILED) return fail(c, MDC_ERR_ARG, "bad kernel selector %d", value);
+      c->opt_kernel = value;
+      return MDC_OK;
+    case MDC_OPT_FRAMES_PER_BLOCK:
+      if (value < 0) return fail(c, MDC_ERR_ARG, "bad frames-per-block %d", value);
+      c->opt_fpb = value;
+      return MDC_OK;
+  }
+  return fail(c, MDC_ERR_ARG, "unknown option %d", option);
+}
+
+int mdc_get_info(mdc_ctx* c, mdc_info* i) {
+  if (!c || !i) return MDC_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  memset(i, 0, sizeof *i);
+  i->device = c->device;
+  i->in_w = c->in_w ? c->in_w : c->rm_in_w;
+  i->in_h = c->in_h ? c->in_h : c->rm_in_h;
+  i->out_w = c->valid_remap ? c->out_w : 0;
+  i->out_h = c->valid_remap ? c->out_h : 0;
+  i->valid_gamma = c->valid_gamma;
+  i->valid_vignette = c->valid_vignette;
+  i->valid_remap = c->valid_remap;
+  i->tiled = c->valid_remap && c->tiled;
+  i->tile_w = kTileW;
+  i->tile_h = kTileH;
+  i->n_tiles = c->n_tiles;
+  i->lds_bytes = c->tiled ? (int)tiled_lds_bytes(c->win_bytes) : 0;
+  for (int k = 0; k < 4; k++) i->src_bbox[k] = c->bbox[k];
+  i->src_bbox_bytes = c->bbox[2] >= 0 ? (int64_t)(c->bbox[2] - c->bbox[0] + 1) * (c->bbox[3] - c->bbox[1] + 1) : 0;
+  i->src_staged_bytes = c->staged_bytes;
+  i->n_black = c->n_black;
+  return MDC_OK;
+}
+
+int mdc_set_photometric(mdc_ctx* c, const float* ginv, const float* vignette_inv, int w, int h) {
+  if (!c) return MDC_ERR_ARG;
+  if (w <= 0 || h <= 0) return fail(c, MDC_ERR_ARG, "bad frame size %dx%d", w, h);
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  MDC_HIP(c, hipStreamSynchronize(c->stream));
+  c->in_w = w;
+  c->in_h = h;
+  c->valid_gamma = ginv != nullptr;
+  if (ginv) c->h_ginv.assign(ginv, ginv + 256);
+  int rc = upload_luts(c);
+  if (rc != MDC_OK) return rc;
+  c->valid_vignette = vignette_inv != nullptr;
+  if (c->d_vinv) {
+    (void)hipFree(c->d_vinv);
+    c->d_vinv = nullptr;
+  }
+  c->h_vinv.clear();
+  if (vignette_inv) {
+    const size_t n = (size_t)w * h;
+    c->h_vinv.assign(vignette_inv, vignette_inv + n);
+    MDC_HIP(c, hipMalloc(&c->d_vinv, n * sizeof(float)));
+    MDC_HIP(c, hipMemcpy(c->d_vinv, vignette_inv, n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return MDC_OK;
+}
+
+int mdc_set_remap(mdc_ctx* c, const float* rx, const float* ry, int in_w, int in_h, int out_w, int out_h) {
+  if (!c) return MDC_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  MDC_HIP(c, hipStreamSynchronize(c->stream));
+  c->valid_remap = false;
+  c->tiled = false;
+  for (float** p : {&c->d_rx, &c->d_ry})
+    if (*p) {
+      (void)hipFree(*p);
+      *p = nullptr;
+    }
+  c->h_rx.clear();
+  c->h_ry.clear();
+  if (!rx || !ry) return MDC_OK;
+  if (in_w <= 1 || in_h <= 1 || out_w <= 0 || out_h <= 0)
+    return fail(c, MDC_ERR_ARG, "bad remap geometry %dx%d -> %dx%d", in_w, in_h, out_w, out_h);
+  const size_t n = (size_t)out_w * out_h;
+  // Defensive validation of what UndistorterFOV's constructor guarantees
+  // (src/FOVUndistorter.cpp:243): every non-black tap lies strictly inside the frame.
+  for (size_t i = 0; i < n; i++) {
+    if (rx[i] < 0) continue;
+    if (!(rx[i] > 0 && ry[i] > 0 && rx[i] < in_w - 1 && ry[i] < in_h - 1))
+      return fail(c, MDC_ERR_ARG, "remap entry %zu = (%g,%g) is outside (0,%d)x(0,%d)", i, rx[i], ry[i], in_w - 1,
+                  in_h - 1);
+  }
+  c->h_rx.assign(rx, rx + n);
+  c->h_ry.assign(ry, ry + n);
+  c->rm_in_w = in_w;
+  c->rm_in_h = in_h;
+  c->out_w = out_w;
+  c->out_h = out_h;
+  MDC_HIP(c, hipMalloc(&c->d_rx, n * sizeof(float)));
+  MDC_HIP(c, hipMalloc(&c->d_ry, n * sizeof(float)));
+  MDC_HIP(c, hipMemcpy(c->d_rx, rx, n * sizeof(float), hipMemcpyHostToDevice));
+  MDC_HIP(c, hipMemcpy(c->d_ry, ry, n * sizeof(float), hipMemcpyHostToDevice));
+  int rc = plan_tiles(c);
+  if (rc != MDC_OK) return rc;
+  c->valid_remap = true;
+  return MDC_OK;
+}
+
+int mdc_unmap_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (!d_in || !d_out || nframes < 0) return fail(c, MDC_ERR_ARG, "mdc_unmap_batch_device: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  return enqueue_process(c, d_in, d_out, nframes, flags & ~MDC_RECTIFY, stream ? (hipStream_t)stream : c->stream);
+}
+
+int mdc_process_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (!d_in || !d_out || nframes < 0) return fail(c, MDC_ERR_ARG, "mdc_process_batch_device: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  return enqueue_process(c, d_in, d_out, nframes, flags, stream ? (hipStream_t)stream : c->stream);
+}
+
+int mdc_undistort_batch_device_f32(mdc_ctx* c, const float* d_in, float* d_out, int64_t nframes, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (!d_in || !d_out || nframes < 0) return fail(c, MDC_ERR_ARG, "mdc_undistort_batch_device_f32: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  if (!c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
+  RemapArgs a = remap_args(c, nullptr, nullptr);
+  const int fpb = frames_per_block(c, nframes, (c->out_w * c->out_h + 255) / 256);
+  MDC_HIP(c, launch_remap_gather_f32(d_in, d_out, a, nframes, fpb, stream ? (hipStream_t)stream : c->stream));
+  return MDC_OK;
+}
+
+int mdc_pyramid_batch_device(mdc_ctx* c, const float* d_base, int w, int h, int levels, float* const* d_levels,
+                             int64_t nframes, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (!d_base || w <= 0 || h <= 0 || levels < 1 || nframes < 0 || (levels > 1 && !d_levels))
+    return fail(c, MDC_ERR_ARG, "mdc_pyramid_batch_device: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  const float* src = d_base;
+  for (int l = 1; l < levels; l++) {
+    if (!d_levels[l - 1]) return fail(c, MDC_ERR_ARG, "level %d buffer is NULL", l);
+    MDC_HIP(c, launch_pyramid_level(src, d_levels[l - 1], w >> (l - 1), h >> (l - 1), nframes, s));
+    src = d_levels[l - 1];
+  }
+  return MDC_OK;
+}
+
+int mdc_synth_frames_device(mdc_ctx* c, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix, uint32_t seed,
+                            void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (!d_out || nframes < 0 || npix <= 0) return fail(c, MDC_ERR_ARG, "mdc_synth_frames_device: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  MDC_HIP(c, launch_synth(d_out, first_frame, nframes, npix, seed, stream ? (hipStream_t)stream : c->stream));
+  return MDC_OK;
+}
+
+int mdc_synchronize(mdc_ctx* c) {
+  if (!c) return MDC_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  MDC_HIP(c, hipStreamSynchronize(c->stream));
+  return MDC_OK;
+}
+
+// ---- host-pointer single-frame calls ---------------------------------------------
+
+int mdc_unmap_host(mdc_ctx* c, const uint8_t* in, float* out, int n, unsigned flags) {
+  if (!c) return MDC_ERR_ARG;
+  if (!in || !out || n < 0) return fail(c, MDC_ERR_ARG, "mdc_unmap_host: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  if (n == 0) return MDC_OK;
+  bool g, v, o;
+  normalise(c, flags, g, v, o);
+  // The reference asserts n == w*h (compiled out under NDEBUG, :191) and would read
+  // vignetteMapInv[i] for i < n; with the vignette on we refuse a mismatching n.
+  if (v && (int64_t)n != (int64_t)c->in_w * c->in_h)
+    return fail(c, MDC_ERR_SIZE, "unMapImage: n = %d but the vignette holds %d pixels", n, c->in_w * c->in_h);
+  int rc = ensure_stage(c, (size_t)n, (size_t)n * sizeof(float));
+  if (rc != MDC_OK) return rc;
+  MDC_HIP(c, hipMemcpyAsync(c->d_stage_in, in, (size_t)n, hipMemcpyHostToDevice, c->stream));
+  MDC_HIP(c, launch_unmap((const uint8_t*)c->d_stage_in, c->d_stage_out, lut_for(c, g, o), v ? c->d_vinv : nullptr, n, 1,
+                          1, c->stream));
+  MDC_HIP(c, hipMemcpyAsync(out, c->d_stage_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  MDC_HIP(c, hipStreamSynchronize(c->stream));
+  return MDC_OK;
+}
+
+static int undistort_host(mdc_ctx* c, const void* in, bool is_f32, float* out, int n_in, int n_out) {
+  if (!c) return MDC_ERR_ARG;
+  if (!in || !out) return fail(c, MDC_ERR_ARG, "undistort: NULL buffer");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  if (!c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
+  if (n_in != c->rm_in_w * c->rm_in_h)
+    return fail(c, MDC_ERR_SIZE, "undistort called with wrong input image dimensions (expected %d pixel, got %d pixel)",
+                c->rm_in_w * c->rm_in_h, n_in);
+  if (n_out != c->out_w * c->out_h)
+    return fail(c, MDC_ERR_SIZE, "undistort called with wrong output image dimensions (expected %d pixel, got %d pixel)",
+                c->out_w * c->out_h, n_out);
+  const size_t in_bytes = (size_t)n_in * (is_f32 ? 4 : 1);
+  int rc = ensure_stage(c, in_bytes, (size_t)n_out * sizeof(float));
+  if (rc != MDC_OK) return rc;
+  MDC_HIP(c, hipMemcpyAsync(c->d_stage_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
+  if (is_f32) {
+    RemapArgs a = remap_args(c, nullptr, nullptr);
+    MDC_HIP(c, launch_remap_gather_f32((const float*)c->d_stage_in, c->d_stage_out, a, 1, 1, c->stream));
+  } else {
+    rc = enqueue_process(c, (const uint8_t*)c->d_stage_in, c->d_stage_out, 1, MDC_RECTIFY, c->stream);
+    if (rc != MDC_OK) return rc;
+  }
+  MDC_HIP(c, hipMemcpyAsync(out, c->d_stage_out, (size_t)n_out * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  MDC_HIP(c, hipStreamSynchronize(c->stream));
+  return MDC_OK;
+}
+
+int mdc_undistort_host_f32(mdc_ctx* c, const float* in, float* out, int n_in, int n_out) {
+  return undistort_host(c, in, true, out, n_in, n_out);
+}
+int mdc_undistort_host_u8(mdc_ctx* c, const uint8_t* in, float* out, int n_in, int n_out) {
+  return undistort_host(c, in, false, out, n_in, n_out);
+}
+
+int mdc_process_host(mdc_ctx* c, const uint8_t* raw, float* out, unsigned flags) {
+  if (!c) return MDC_ERR_ARG;
+  if (!raw || !out) return fail(c, MDC_ERR_ARG, "mdc_process_host: NULL buffer");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  const bool rect = (flags & MDC_RECTIFY) != 0;
+  if (rect && !c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
+  const int iw = (rect || c->in_w <= 0) ? c->rm_in_w : c->in_w, ih = (rect || c->in_h <= 0) ? c->rm_in_h : c->in_h;
+  if (iw <= 0 || ih <= 0) return fail(c, MDC_ERR_STATE, "frame size unknown");
+  const size_t n_in = (size_t)iw * ih;
+  const size_t n_out = rect ? (size_t)c->out_w * c->out_h : n_in;
+  int rc = ensure_stage(c, n_in, n_out * sizeof(float));
+  if (rc != MDC_OK) return rc;
+  MDC_HIP(c, hipMemcpyAsync(c->d_stage_in, raw, n_in, hipMemcpyHostToDevice, c->stream));
+  rc = enqueue_process(c, (const uint8_t*)c->d_stage_in, c->d_stage_out, 1, flags, c->stream);
+  if (rc != MDC_OK) return rc;
+  MDC_HIP(c, hipMemcpyAsync(out, c->d_stage_out, n_out * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  MDC_HIP(c, hipStreamSynchronize(c->stream));
+  return MDC_OK;
+}
+
+// ---- table hand-over ------------------------------------------------------------------
+
+int mdc_export_tables(mdc_ctx* c, void* blob, size_t cap, size_t* size) {
+  if (!c || !size) return MDC_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  const size_t nv = c->valid_vignette ? c->h_vinv.size() : 0;
+  const size_t nr = c->valid_remap ? c->h_rx.size() : 0;
+  const size_t need = sizeof(BlobHeader) + 256 * 4 + nv * 4 + 2 * nr * 4;
+  *size = need;
+  if (!blob) return MDC_OK;
+  if (cap < need) return fail(c, MDC_ERR_ARG, "export buffer too small (%zu < %zu)", cap, need);
+  BlobHeader h{kMagic, 1, c->in_w, c->in_h, c->rm_in_w, c->rm_in_h, c->out_w, c->out_h,
+               c->valid_gamma, c->valid_vignette, c->valid_remap, 0};
+  char* p = (char*)blob;
+  memcpy(p, &h, sizeof h);
+  p += sizeof h;
+  memcpy(p, c->h_ginv.data(), 256 * 4);
+  p += 256 * 4;
+  if (nv) memcpy(p, c->h_vinv.data(), nv * 4);
+  p += nv * 4;
+  if (nr) {
+    memcpy(p, c->h_rx.data(), nr * 4);
+    p += nr * 4;
+    memcpy(p, c->h_ry.data(), nr * 4);
+  }
+  return MDC_OK;
+}
+
+int mdc_import_tables(mdc_ctx* c, const void* blob, size_t size) {
+  if (!c || !blob) return MDC_ERR_ARG;
+  BlobHeader h;
+  if (size < sizeof h) return fail(c, MDC_ERR_ARG, "table blob truncated");
+  memcpy(&h, blob, sizeof h);
+  if (h.magic != kMagic || h.version != 1) return fail(c, MDC_ERR_ARG, "table blob has wrong magic/version");
+  const size_t nv = h.valid_vignette ? (size_t)h.in_w * h.in_h : 0;
+  const size_t nr = h.valid_remap ? (size_t)h.out_w * h.out_h : 0;
+  if (size != sizeof h + 256 * 4 + nv * 4 + 2 * nr * 4) return fail(c, MDC_ERR_ARG, "table blob has wrong size");
+  const char* p = (const char*)blob + sizeof h;
+  const float* ginv = (const float*)p;
+  p += 256 * 4;
+  const float* vinv = (const float*)p;
+  p += nv * 4;
+  const float* rx = (const float*)p;
+  const float* ry = rx + nr;
+  int rc = MDC_OK;
+  if (h.in_w > 0 && h.in_h > 0)
+    rc = mdc_set_photometric(c, h.valid_gamma ? ginv : nullptr, h.valid_vignette ? vinv : nullptr, h.in_w, h.in_h);
+  if (rc != MDC_OK) return rc;
+  if (h.valid_remap) rc = mdc_set_remap(c, rx, ry, h.rm_in_w, h.rm_in_h, h.out_w, h.out_h);
+  else rc = mdc_set_remap(c, nullptr, nullptr, 0, 0, 0, 0);
+  return rc;
+}
+
+}  // extern "C"

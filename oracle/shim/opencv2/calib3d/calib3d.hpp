@@ -1,0 +1,3 @@
+// TEST INFRASTRUCTURE ONLY -- forwards to the stub core header.
+#pragma once
+#include "opencv2/core/core.hpp"
