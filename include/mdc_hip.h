@@ -15,8 +15,8 @@
  *     borrow the caller's buffers for the duration of the call only -- the
  *     semantics of the reference methods they stand in for;
  *   - *_device functions take device pointers valid on the context's GPU and
- *     enqueue on `stream` (a hipStream_t passed as void*; NULL = the context's
- *     own stream) without synchronising;
+ *     enqueue on `stream` (a hipStream_t passed as void*; NULL = HIP's default
+ *     stream, as everywhere in HIP) without synchronising;
  *   - a context is bound to one GPU; calls on one context are serialised by an
  *     internal mutex, different contexts are independent; no global state.
  */
@@ -60,7 +60,8 @@ enum {
   MDC_KERNEL_GATHER = 1, /* direct global gather (always legal)                    */
   MDC_KERNEL_TILED = 2   /* LDS-staged source windows (fails if not plannable)     */
 };
-enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2 };
+enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2, MDC_OPT_LUT_REPLICAS = 3 /* tuning: 8, 16 or 32 */,
+       MDC_OPT_TAP_MODE = 4 /* tuning: LDS tap fetch 0 = u16, 1 = 2 x u8, 2 = aligned dword pair */ };
 
 typedef struct mdc_info {
   int device;                /* HIP device ordinal                                  */
@@ -153,7 +154,7 @@ int mdc_synth_frames_device(mdc_ctx* ctx, uint8_t* d_out, int64_t first_frame, i
 int mdc_export_tables(mdc_ctx* ctx, void* blob, size_t cap, size_t* size);
 int mdc_import_tables(mdc_ctx* ctx, const void* blob, size_t size);
 
-/* Blocks until everything enqueued on the context's own stream has finished. */
+/* Blocks until the context's own stream (used by the *_host calls) is idle. */
 int mdc_synchronize(mdc_ctx* ctx);
 
 #ifdef __cplusplus

@@ -17,7 +17,7 @@ LIB_HOST_PATH = os.path.join(_PKG, "libmdc_host.so")
 # flag word (include/mdc_hip.h)
 GAMMA, VIGNETTE, KILL_OVEREXPOSED, RECTIFY = 1, 2, 4, 8
 KERNEL_AUTO, KERNEL_GATHER, KERNEL_TILED = 0, 1, 2
-OPT_KERNEL, OPT_FRAMES_PER_BLOCK = 1, 2
+OPT_KERNEL, OPT_FRAMES_PER_BLOCK, OPT_LUT_REPLICAS, OPT_TAP_MODE = 1, 2, 3, 4
 OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 
 # every symbol include/mdc_hip.h declares (checked by tests/test_abi.py)
@@ -55,9 +55,22 @@ _host = None
 _vp, _i, _i64, _u32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_size_t
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 (same soname as /opt/rocm's).
+    Two HIP runtimes in one process cannot both own the GPU, so when torch is
+    installed it must be loaded FIRST: libmdc_hip.so's NEEDED libamdhip64.so.7 then
+    resolves to the copy torch already mapped.  Without torch the system runtime
+    (RUNPATH /opt/rocm) is used."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def hip_lib():
     global _hip
     if _hip is None:
+        _share_hip_runtime_with_torch()
         if not os.path.exists(LIB_HIP_PATH):
             raise OSError("%s not built: run `python -m mono_dataset_code_amd.build`" % LIB_HIP_PATH)
         L = C.CDLL(LIB_HIP_PATH)
@@ -221,20 +234,20 @@ class Context:
 
     # device-pointer batched calls (addresses as ints)
     def unmap_batch(self, d_in, d_out, nframes, flags, stream=0):
-        self._chk(self._L.mdc_unmap_batch_device(self._h, d_in, d_out, nframes, flags, stream or None))
+        self._chk(self._L.mdc_unmap_batch_device(self._h, d_in, d_out, nframes, flags, stream if stream else None))
 
     def process_batch(self, d_in, d_out, nframes, flags, stream=0):
-        self._chk(self._L.mdc_process_batch_device(self._h, d_in, d_out, nframes, flags, stream or None))
+        self._chk(self._L.mdc_process_batch_device(self._h, d_in, d_out, nframes, flags, stream if stream else None))
 
     def undistort_batch_f32(self, d_in, d_out, nframes, stream=0):
-        self._chk(self._L.mdc_undistort_batch_device_f32(self._h, d_in, d_out, nframes, stream or None))
+        self._chk(self._L.mdc_undistort_batch_device_f32(self._h, d_in, d_out, nframes, stream if stream else None))
 
     def pyramid_batch(self, d_base, w, h, levels, d_levels, nframes, stream=0):
         arr = (_vp * max(1, len(d_levels)))(*d_levels)
-        self._chk(self._L.mdc_pyramid_batch_device(self._h, d_base, w, h, levels, arr, nframes, stream or None))
+        self._chk(self._L.mdc_pyramid_batch_device(self._h, d_base, w, h, levels, arr, nframes, stream if stream else None))
 
     def synth_frames(self, d_out, first_frame, nframes, npix, seed, stream=0):
-        self._chk(self._L.mdc_synth_frames_device(self._h, d_out, first_frame, nframes, npix, seed, stream or None))
+        self._chk(self._L.mdc_synth_frames_device(self._h, d_out, first_frame, nframes, npix, seed, stream if stream else None))
 
     def export_tables(self):
         n = _sz(0)

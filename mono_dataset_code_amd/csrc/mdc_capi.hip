@@ -51,6 +51,8 @@ struct mdc_ctx {
   // options
   int opt_kernel = MDC_KERNEL_AUTO;
   int opt_fpb = 0;
+  int opt_lut_rep = 32;
+  int opt_taps = 1;
 
   // staging for the host-pointer calls
   void* d_stage_in = nullptr;
@@ -174,11 +176,11 @@ int plan_tiles(mdc_ctx* c) {
     const int nch = d.rows * d.cpr;
     if (nch > kTileMaxChunks * kTileThreads) ok = false;
     if (d.x0 + d.cpr * 16 > iw) ok = false;
-    win_max = std::max(win_max, nch * 16);
+    win_max = std::max(win_max, nch * 16 + 16);  // +16: the aligned dword pair of the last tap may reach past the window
     c->staged_bytes += (int64_t)nch * 16;
   }
   if (c->bbox[2] < 0) c->bbox[0] = c->bbox[1] = 0;
-  if (tiled_lds_bytes(win_max) > 64 * 1024) ok = false;
+  if (tiled_lds_bytes(win_max, kLutRep) > 64 * 1024) ok = false;
   if (c->d_tiles) {
     (void)hipFree(c->d_tiles);
     c->d_tiles = nullptr;
@@ -251,7 +253,7 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
   if (use_tiled) {
     TilePlan p{c->d_tiles, c->n_tiles, c->tiles_x, c->win_bytes};
     const int fpb = frames_per_block(c, nframes, (c->n_tiles + 7) & ~7);
-    MDC_HIP(c, launch_remap_tiled_u8(d_in, d_out, a, p, nframes, fpb, s));
+    MDC_HIP(c, launch_remap_tiled_u8(d_in, d_out, a, p, nframes, fpb, c->opt_lut_rep, c->opt_taps, s));
   } else {
     const int fpb = frames_per_block(c, nframes, (c->out_w * c->out_h + 255) / 256);
     MDC_HIP(c, launch_remap_gather_u8(d_in, d_out, a, nframes, fpb, s));
@@ -328,6 +330,14 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
       if (value < 0) return fail(c, MDC_ERR_ARG, "bad frames-per-block %d", value);
       c->opt_fpb = value;
       return MDC_OK;
+    case MDC_OPT_TAP_MODE:
+      if (value < 0 || value > 2) return fail(c, MDC_ERR_ARG, "tap mode must be 0, 1 or 2");
+      c->opt_taps = value;
+      return MDC_OK;
+    case MDC_OPT_LUT_REPLICAS:
+      if (value != 8 && value != 16 && value != 32) return fail(c, MDC_ERR_ARG, "LUT replicas must be 8, 16 or 32");
+      c->opt_lut_rep = value;
+      return MDC_OK;
   }
   return fail(c, MDC_ERR_ARG, "unknown option %d", option);
 }
@@ -348,7 +358,7 @@ int mdc_get_info(mdc_ctx* c, mdc_info* i) {
   i->tile_w = kTileW;
   i->tile_h = kTileH;
   i->n_tiles = c->n_tiles;
-  i->lds_bytes = c->tiled ? (int)tiled_lds_bytes(c->win_bytes) : 0;
+  i->lds_bytes = c->tiled ? (int)tiled_lds_bytes(c->win_bytes, c->opt_lut_rep) : 0;
   for (int k = 0; k < 4; k++) i->src_bbox[k] = c->bbox[k];
   i->src_bbox_bytes = c->bbox[2] >= 0 ? (int64_t)(c->bbox[2] - c->bbox[0] + 1) * (c->bbox[3] - c->bbox[1] + 1) : 0;
   i->src_staged_bytes = c->staged_bytes;
@@ -430,7 +440,7 @@ int mdc_unmap_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_
   if (!d_in || !d_out || nframes < 0) return fail(c, MDC_ERR_ARG, "mdc_unmap_batch_device: bad argument");
   std::lock_guard<std::mutex> lk(c->mu);
   DeviceGuard dg(c->device);
-  return enqueue_process(c, d_in, d_out, nframes, flags & ~MDC_RECTIFY, stream ? (hipStream_t)stream : c->stream);
+  return enqueue_process(c, d_in, d_out, nframes, flags & ~MDC_RECTIFY, (hipStream_t)stream);
 }
 
 int mdc_process_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, void* stream) {
@@ -438,7 +448,7 @@ int mdc_process_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int6
   if (!d_in || !d_out || nframes < 0) return fail(c, MDC_ERR_ARG, "mdc_process_batch_device: bad argument");
   std::lock_guard<std::mutex> lk(c->mu);
   DeviceGuard dg(c->device);
-  return enqueue_process(c, d_in, d_out, nframes, flags, stream ? (hipStream_t)stream : c->stream);
+  return enqueue_process(c, d_in, d_out, nframes, flags, (hipStream_t)stream);
 }
 
 int mdc_undistort_batch_device_f32(mdc_ctx* c, const float* d_in, float* d_out, int64_t nframes, void* stream) {
@@ -449,7 +459,7 @@ int mdc_undistort_batch_device_f32(mdc_ctx* c, const float* d_in, float* d_out, 
   if (!c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
   RemapArgs a = remap_args(c, nullptr, nullptr);
   const int fpb = frames_per_block(c, nframes, (c->out_w * c->out_h + 255) / 256);
-  MDC_HIP(c, launch_remap_gather_f32(d_in, d_out, a, nframes, fpb, stream ? (hipStream_t)stream : c->stream));
+  MDC_HIP(c, launch_remap_gather_f32(d_in, d_out, a, nframes, fpb, (hipStream_t)stream));
   return MDC_OK;
 }
 
@@ -460,7 +470,7 @@ int mdc_pyramid_batch_device(mdc_ctx* c, const float* d_base, int w, int h, int 
     return fail(c, MDC_ERR_ARG, "mdc_pyramid_batch_device: bad argument");
   std::lock_guard<std::mutex> lk(c->mu);
   DeviceGuard dg(c->device);
-  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  hipStream_t s = (hipStream_t)stream;
   const float* src = d_base;
   for (int l = 1; l < levels; l++) {
     if (!d_levels[l - 1]) return fail(c, MDC_ERR_ARG, "level %d buffer is NULL", l);
@@ -476,7 +486,7 @@ int mdc_synth_frames_device(mdc_ctx* c, uint8_t* d_out, int64_t first_frame, int
   if (!d_out || nframes < 0 || npix <= 0) return fail(c, MDC_ERR_ARG, "mdc_synth_frames_device: bad argument");
   std::lock_guard<std::mutex> lk(c->mu);
   DeviceGuard dg(c->device);
-  MDC_HIP(c, launch_synth(d_out, first_frame, nframes, npix, seed, stream ? (hipStream_t)stream : c->stream));
+  MDC_HIP(c, launch_synth(d_out, first_frame, nframes, npix, seed, (hipStream_t)stream));
   return MDC_OK;
 }
 

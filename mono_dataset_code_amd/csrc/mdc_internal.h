@@ -48,9 +48,10 @@ hipError_t launch_remap_gather_u8(const uint8_t* d_in, float* d_out, const Remap
 hipError_t launch_remap_gather_f32(const float* d_in, float* d_out, const RemapArgs& a, int64_t nframes, int fpb,
                                    hipStream_t s);
 // Fused LUT (* vignette) + bilinear remap, u8 frames, source windows staged in LDS.
+// lut_rep = LDS replicas of the response LUT (32 = conflict-free, 16/8 = smaller LDS footprint).
 hipError_t launch_remap_tiled_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
-                                 int64_t nframes, int fpb, hipStream_t s);
-size_t tiled_lds_bytes(int win_bytes);
+                                 int64_t nframes, int fpb, int lut_rep, int taps, hipStream_t s);
+size_t tiled_lds_bytes(int win_bytes, int lut_rep);
 
 // One 2x2 box level: dst (w/2 x h/2) from src (w x h), nframes images each.
 hipError_t launch_pyramid_level(const float* d_src, float* d_dst, int w, int h, int64_t nframes, hipStream_t s);

@@ -217,31 +217,141 @@ __global__ __launch_bounds__(256) void remap_gather_f32_kernel(const float* __re
 //                        HBM -> registers -> LDS in 16-byte chunks (each window row
 //                        is a run of aligned 16-byte pieces: coalesced, every byte
 //                        of the frame fetched by the workgroup at most once);
-//                        then per output 4 ds_read_u8 taps, 4 conflict-free LUT
-//                        reads, 4 (+4) multiplies, 3 adds, one coalesced store.
+//                        then per output 4 byte taps, 4 conflict-free LUT reads,
+//                        4 (+4) multiplies, 3 adds, one coalesced store.
 // Lane = output column, so the 32 lanes of an LDS access group read ~43
 // consecutive source bytes of one row: broadcast within a dword, distinct banks
-// across dwords.  Two LDS window buffers: the loads of frame f+1 are in flight
-// while frame f is computed; one barrier per frame.
+// across dwords.  Two LDS window buffers: the loads of frame f+1 are issued before
+// frame f is computed and land in the other buffer afterwards; one barrier per frame.
+// The staging loads are unconditional (chunk index clamped to the window, so a
+// surplus lane re-reads the last chunk) and the frame loop is instantiated per
+// number of staging rounds R: straight-line code keeps the loads in flight across
+// the compute phase instead of waiting at a divergent merge.
 //
 // XCD placement: the dispatcher deals workgroups round-robin over the 8 XCDs
 // (block b -> XCD b%8).  Tiles are re-indexed so that each XCD owns a contiguous
 // band of tiles; neighbouring tiles share source-window halo rows, which then hit
 // in the same L2.  Speed only -- correctness does not depend on placement.
 // ----------------------------------------------------------------------------
-template <bool VIG>
-__global__ __launch_bounds__(kTileThreads) void remap_tiled_u8_kernel(const uint8_t* __restrict__ in,
+struct TileThread {  // per-thread, frame-invariant
+  Bilin bl[4];
+  int off[4];    // LDS byte offset of tap (0,0) inside the window
+  int oidx[4];   // output index inside a frame
+  bool inside[4], black[4];
+  float v00[4], v10[4], v01[4], v11[4];
+};
+
+// EDGE = the tile sticks out of the output image: stores are predicated per output.
+// Interior tiles store unconditionally, which keeps the store count of a frame
+// known at compile time (exact s_waitcnt vmcnt(N) for the prefetched loads that
+// were issued before them -- vmcnt retires in order on gfx9).
+// TAPS selects how the two horizontally adjacent byte taps of a row are fetched from LDS:
+//   0  two byte loads as written (hipcc fuses them into one ds_read_u16 at an arbitrary,
+//      often odd, address)
+//   1  two separate ds_read_u8
+//   2  the two aligned dwords around the pair (ds_read2_b32) + v_alignbyte
+typedef const __attribute__((address_space(3))) unsigned char* lds_u8_ptr;
+typedef const volatile __attribute__((address_space(3))) unsigned char* lds_vu8_ptr;
+typedef const __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
+
+template <int TAPS>
+__device__ __forceinline__ void tap_pair(const unsigned char* p, int& a, int& b) {
+  if (TAPS == 0) {
+    lds_u8_ptr q = (lds_u8_ptr)p;
+    a = q[0];
+    b = q[1];
+  } else if (TAPS == 1) {
+    lds_vu8_ptr q = (lds_vu8_ptr)p;
+    a = q[0];
+    b = q[1];
+  } else {
+    lds_u8_ptr q8 = (lds_u8_ptr)p;
+    const uint32_t addr = (uint32_t)(uintptr_t)q8;  // LDS byte address (32-bit in address space 3)
+    lds_u32_ptr q = (lds_u32_ptr)(uintptr_t)(addr & ~3u);
+    const uint32_t lo = q[0], hi = q[1];
+    const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, addr & 3u);
+    a = w & 255u;
+    b = (w >> 8) & 255u;
+  }
+}
+
+template <bool VIG, int LUTREP, bool EDGE, int TAPS>
+__device__ __forceinline__ void tile_compute(const TileThread& t, const unsigned char* __restrict__ w, int pitch,
+                                             const float* __restrict__ my_lut, float* __restrict__ dst) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const unsigned char* p = w + t.off[j];
+    int b00, b10, b01, b11;
+    tap_pair<TAPS>(p, b00, b10);
+    tap_pair<TAPS>(p + pitch, b01, b11);
+    float t00 = my_lut[b00 * LUTREP];
+    float t10 = my_lut[b10 * LUTREP];
+    float t01 = my_lut[b01 * LUTREP];
+    float t11 = my_lut[b11 * LUTREP];
+    if (VIG) {
+      t00 = t00 * t.v00[j];
+      t10 = t10 * t.v10[j];
+      t01 = t01 * t.v01[j];
+      t11 = t11 * t.v11[j];
+    }
+    float r = bilin_sum(t.bl[j], t00, t10, t01, t11);
+    if (t.black[j]) r = 0.f;
+    if (!EDGE || t.inside[j]) __builtin_nontemporal_store(r, dst + t.oidx[j]);
+  }
+}
+
+template <bool VIG, int LUTREP, int R, bool EDGE, int TAPS>
+__device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* __restrict__ src,
+                                            float* __restrict__ dst, long long n_in, long long n_out, int nframes,
+                                            int nch, const TileDesc& td, int in_w, unsigned char* s_win,
+                                            int win_bytes, const float* my_lut, int tid) {
+  const int pitch = td.cpr * 16;
+  int goff[R], loff[R];
+#pragma unroll
+  for (int k = 0; k < R; k++) {
+    const int c = min(tid + k * kTileThreads, nch - 1);
+    const int r = c / td.cpr;
+    goff[k] = (td.y0 + r) * in_w + td.x0 + (c - r * td.cpr) * 16;
+    loff[k] = c * 16;
+  }
+  u32x4 stage[R];
+#pragma unroll
+  for (int k = 0; k < R; k++) stage[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + goff[k]));
+#pragma unroll
+  for (int k = 0; k < R; k++) *reinterpret_cast<u32x4*>(s_win + loff[k]) = stage[k];
+  __syncthreads();
+  int cur = 0;
+  for (int f = 0; f < nframes - 1; f++) {
+    src += n_in;
+#pragma unroll
+    for (int k = 0; k < R; k++) stage[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + goff[k]));
+    tile_compute<VIG, LUTREP, EDGE, TAPS>(t, s_win + cur * win_bytes, pitch, my_lut, dst);
+    dst += n_out;
+    unsigned char* wn = s_win + (cur ^ 1) * win_bytes;
+#pragma unroll
+    for (int k = 0; k < R; k++) *reinterpret_cast<u32x4*>(wn + loff[k]) = stage[k];
+    __syncthreads();
+    cur ^= 1;
+  }
+  tile_compute<VIG, LUTREP, EDGE, TAPS>(t, s_win + cur * win_bytes, pitch, my_lut, dst);
+}
+
+template <bool VIG, int LUTREP, int TAPS>
+__global__ __launch_bounds__(kTileThreads, 5) void remap_tiled_u8_kernel(const uint8_t* __restrict__ in,
                                                                       float* __restrict__ out, RemapArgs a,
                                                                       const TileDesc* __restrict__ tiles,
                                                                       int n_tiles, int tiles_x, int win_bytes,
                                                                       int nframes, int fpb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_lut = reinterpret_cast<float*>(smem);
-  unsigned char* s_win = smem + kLutBytes;
+  unsigned char* s_win = smem + 256 * LUTREP * 4;
 
   const int ntp = gridDim.x;  // padded to a multiple of 8
   const int tile = (blockIdx.x & 7) * (ntp >> 3) + (blockIdx.x >> 3);
   if (tile >= n_tiles) return;  // whole workgroup leaves before any barrier
+  const int f0 = blockIdx.y * fpb;
+  const int nf = min(nframes, f0 + fpb) - f0;
+  if (nf <= 0) return;
 
   const int tid = threadIdx.x;
   const int lane_x = tid % kTileW;
@@ -251,105 +361,60 @@ __global__ __launch_bounds__(kTileThreads) void remap_tiled_u8_kernel(const uint
   const int ox = (tile % tiles_x) * kTileW + lane_x;
   const int oy0 = (tile / tiles_x) * kTileH + row0;
 
-  fill_lut<kTileThreads>(s_lut, a.lut, tid);
-  const float* my_lut = s_lut + (tid & (kLutRep - 1));
+#pragma unroll 4
+  for (int i = tid; i < 256 * LUTREP; i += kTileThreads) s_lut[i] = a.lut[i / LUTREP];
+  const float* my_lut = s_lut + (tid & (LUTREP - 1));
 
-  // ---- per-output constants -------------------------------------------------
-  Bilin bl[4];
-  int off[4];
-  int oidx[4];
-  bool inside[4], black[4];
-  float v00[4], v10[4], v01[4], v11[4];
+  TileThread t;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int oy = oy0 + j;
-    inside[j] = (ox < a.out_w) && (oy < a.out_h);
-    oidx[j] = oy * a.out_w + ox;
+    t.inside[j] = (ox < a.out_w) && (oy < a.out_h);
+    t.oidx[j] = oy * a.out_w + ox;
     float xx = -1.f, yy = -1.f;
-    if (inside[j]) {
-      xx = a.rx[oidx[j]];
-      yy = a.ry[oidx[j]];
+    if (t.inside[j]) {
+      xx = a.rx[t.oidx[j]];
+      yy = a.ry[t.oidx[j]];
     }
-    black[j] = xx < 0;
-    bl[j] = bilin_of(black[j] ? 0.f : xx, black[j] ? 0.f : yy);
-    off[j] = black[j] ? 0 : (bl[j].yi - td.y0) * pitch + (bl[j].xi - td.x0);
-    v00[j] = v10[j] = v01[j] = v11[j] = 1.f;
-    if (VIG && !black[j]) {
-      const int s = bl[j].xi + bl[j].yi * a.in_w;
-      v00[j] = a.vinv[s];
-      v10[j] = a.vinv[s + 1];
-      v01[j] = a.vinv[s + a.in_w];
-      v11[j] = a.vinv[s + a.in_w + 1];
+    t.black[j] = xx < 0;
+    t.bl[j] = bilin_of(t.black[j] ? 0.f : xx, t.black[j] ? 0.f : yy);
+    t.off[j] = t.black[j] ? 0 : (t.bl[j].yi - td.y0) * pitch + (t.bl[j].xi - td.x0);
+    t.v00[j] = t.v10[j] = t.v01[j] = t.v11[j] = 1.f;
+    if (VIG && !t.black[j]) {
+      const int s = t.bl[j].xi + t.bl[j].yi * a.in_w;
+      t.v00[j] = a.vinv[s];
+      t.v10[j] = a.vinv[s + 1];
+      t.v01[j] = a.vinv[s + a.in_w];
+      t.v11[j] = a.vinv[s + a.in_w + 1];
     }
-  }
-
-  // ---- staging assignment: chunk c = tid + k*NT of the window -----------------
-  const int nch = td.rows * td.cpr;
-  int goff[kTileMaxChunks];
-  bool cok[kTileMaxChunks];
-#pragma unroll
-  for (int k = 0; k < kTileMaxChunks; k++) {
-    const int c = tid + k * kTileThreads;
-    cok[k] = c < nch;
-    const int r = cok[k] ? c / td.cpr : 0;
-    const int col = cok[k] ? c - r * td.cpr : 0;
-    goff[k] = (td.y0 + r) * a.in_w + td.x0 + col * 16;
   }
 
   const long long n_in = (long long)a.in_w * a.in_h;
   const long long n_out = (long long)a.out_w * a.out_h;
-  const int f0 = blockIdx.y * fpb;
-  const int f1 = min(nframes, f0 + fpb);
-  if (f0 >= f1) return;
   const uint8_t* src = in + (long long)f0 * n_in;
   float* dst = out + (long long)f0 * n_out;
-
-  u32x4 stage[kTileMaxChunks];
+  const int nch = td.rows * td.cpr;
+  if (nch == 0) {  // every output of the tile is black (or outside): zeros, no staging
+    for (int f = 0; f < nf; f++, dst += n_out)
 #pragma unroll
-  for (int k = 0; k < kTileMaxChunks; k++)
-    if (cok[k]) stage[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + goff[k]));
-#pragma unroll
-  for (int k = 0; k < kTileMaxChunks; k++)
-    if (cok[k]) *reinterpret_cast<u32x4*>(s_win + (tid + k * kTileThreads) * 16) = stage[k];
-  __syncthreads();
-
-  int cur = 0;
-  for (int f = f0; f < f1; f++) {
-    const bool more = (f + 1) < f1;
-    if (more) {
-      src += n_in;
-#pragma unroll
-      for (int k = 0; k < kTileMaxChunks; k++)
-        if (cok[k]) stage[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + goff[k]));
-    }
-    const unsigned char* w = s_win + cur * win_bytes;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const unsigned char* t = w + off[j];
-      float t00 = my_lut[(int)t[0] * kLutRep];
-      float t10 = my_lut[(int)t[1] * kLutRep];
-      float t01 = my_lut[(int)t[pitch] * kLutRep];
-      float t11 = my_lut[(int)t[pitch + 1] * kLutRep];
-      if (VIG) {
-        t00 = t00 * v00[j];
-        t10 = t10 * v10[j];
-        t01 = t01 * v01[j];
-        t11 = t11 * v11[j];
-      }
-      float r = bilin_sum(bl[j], t00, t10, t01, t11);
-      if (black[j]) r = 0.f;
-      if (inside[j]) __builtin_nontemporal_store(r, dst + oidx[j]);
-    }
-    dst += n_out;
-    if (more) {
-      unsigned char* wn = s_win + (cur ^ 1) * win_bytes;
-#pragma unroll
-      for (int k = 0; k < kTileMaxChunks; k++)
-        if (cok[k]) *reinterpret_cast<u32x4*>(wn + (tid + k * kTileThreads) * 16) = stage[k];
-    }
-    __syncthreads();
-    cur ^= 1;
+      for (int j = 0; j < 4; j++)
+        if (t.inside[j]) dst[t.oidx[j]] = 0.f;
+    return;
   }
+  const int rounds = (nch + kTileThreads - 1) / kTileThreads;  // workgroup-uniform
+  const bool edge = ((tile % tiles_x) + 1) * kTileW > a.out_w || ((tile / tiles_x) + 1) * kTileH > a.out_h;
+#define MDC_TILE_RUN(R_, E_) \
+  tile_frames<VIG, LUTREP, R_, E_, TAPS>(t, src, dst, n_in, n_out, nf, nch, td, a.in_w, s_win, win_bytes, my_lut, tid)
+  if (!edge) {
+    if (rounds == 1) MDC_TILE_RUN(1, false);
+    else if (rounds == 2) MDC_TILE_RUN(2, false);
+    else MDC_TILE_RUN(kTileMaxChunks, false);
+  } else {
+    if (rounds == 1) MDC_TILE_RUN(1, true);
+    else if (rounds == 2) MDC_TILE_RUN(2, true);
+    else MDC_TILE_RUN(kTileMaxChunks, true);
+  }
+#undef MDC_TILE_RUN
 }
 
 // ----------------------------------------------------------------------------
@@ -395,7 +460,7 @@ inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace
 
-size_t tiled_lds_bytes(int win_bytes) { return (size_t)kLutBytes + 2 * (size_t)win_bytes; }
+size_t tiled_lds_bytes(int win_bytes, int lut_rep) { return (size_t)256 * lut_rep * 4 + 2 * (size_t)win_bytes; }
 
 hipError_t launch_unmap(const uint8_t* d_in, float* d_out, const float* d_lut, const float* d_vinv, int64_t npix,
                         int64_t nframes, int fpb, hipStream_t s) {
@@ -433,19 +498,39 @@ hipError_t launch_remap_gather_f32(const float* d_in, float* d_out, const RemapA
   return hipGetLastError();
 }
 
-hipError_t launch_remap_tiled_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
-                                 int64_t nframes, int fpb, hipStream_t s) {
-  if (nframes <= 0) return hipSuccess;
+template <bool VIG, int LUTREP, int TAPS>
+static hipError_t launch_tiled_variant(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
+                                       int64_t nframes, int fpb, hipStream_t s) {
   const int ntp = (p.n_tiles + 7) & ~7;
   dim3 grid(ntp, ceil_div(nframes, fpb));
-  const size_t lds = tiled_lds_bytes(p.win_bytes);
-  if (a.vinv)
-    remap_tiled_u8_kernel<true><<<grid, kTileThreads, lds, s>>>(d_in, d_out, a, p.d_tiles, p.n_tiles, p.tiles_x,
-                                                                p.win_bytes, (int)nframes, fpb);
-  else
-    remap_tiled_u8_kernel<false><<<grid, kTileThreads, lds, s>>>(d_in, d_out, a, p.d_tiles, p.n_tiles, p.tiles_x,
-                                                                 p.win_bytes, (int)nframes, fpb);
+  const size_t lds = tiled_lds_bytes(p.win_bytes, LUTREP);
+  remap_tiled_u8_kernel<VIG, LUTREP, TAPS><<<grid, kTileThreads, lds, s>>>(
+      d_in, d_out, a, p.d_tiles, p.n_tiles, p.tiles_x, p.win_bytes, (int)nframes, fpb);
   return hipGetLastError();
+}
+
+template <bool VIG, int LUTREP>
+static hipError_t launch_tiled_taps(int taps, const uint8_t* d_in, float* d_out, const RemapArgs& a,
+                                    const TilePlan& p, int64_t nframes, int fpb, hipStream_t s) {
+  switch (taps) {
+    case 0: return launch_tiled_variant<VIG, LUTREP, 0>(d_in, d_out, a, p, nframes, fpb, s);
+    case 1: return launch_tiled_variant<VIG, LUTREP, 1>(d_in, d_out, a, p, nframes, fpb, s);
+    default: return launch_tiled_variant<VIG, LUTREP, 2>(d_in, d_out, a, p, nframes, fpb, s);
+  }
+}
+
+hipError_t launch_remap_tiled_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
+                                 int64_t nframes, int fpb, int lut_rep, int taps, hipStream_t s) {
+  if (nframes <= 0) return hipSuccess;
+  const bool v = a.vinv != nullptr;
+  switch (lut_rep) {
+    case 8: return v ? launch_tiled_taps<true, 8>(taps, d_in, d_out, a, p, nframes, fpb, s)
+                     : launch_tiled_taps<false, 8>(taps, d_in, d_out, a, p, nframes, fpb, s);
+    case 16: return v ? launch_tiled_taps<true, 16>(taps, d_in, d_out, a, p, nframes, fpb, s)
+                      : launch_tiled_taps<false, 16>(taps, d_in, d_out, a, p, nframes, fpb, s);
+    default: return v ? launch_tiled_taps<true, 32>(taps, d_in, d_out, a, p, nframes, fpb, s)
+                      : launch_tiled_taps<false, 32>(taps, d_in, d_out, a, p, nframes, fpb, s);
+  }
 }
 
 hipError_t launch_pyramid_level(const float* d_src, float* d_dst, int w, int h, int64_t nframes, hipStream_t s) {

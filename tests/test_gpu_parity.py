@@ -1,0 +1,265 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+The oracle is oracle/mdc_oracle.c (plain-C restatement of the reference, itself
+pinned bit-for-bit against the reference build in test_oracle_vs_ref.py).
+Tolerance: none -- values must be bit-identical, the NaN (overexposure) mask and
+the black-pixel zeros exact.  (BASELINE.json asks for <= 1e-4 relative.)
+"""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CAMERAS, bits_equal, test_frames as make_frames
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+class Setup:
+    def __init__(self, name, calib_dirs, oracle):
+        from mono_dataset_code_amd import capi
+
+        d = calib_dirs[name]
+        self.cam = oracle.parse_camera(os.path.join(d, "camera.txt"))
+        assert self.cam["valid"]
+        self.W, self.H, self.w, self.h = self.cam["in_w"], self.cam["in_h"], self.cam["out_w"], self.cam["out_h"]
+        self.fov = capi.UndistorterFOV(os.path.join(d, "camera.txt"))
+        self.photo = capi.PhotometricUndistorter(os.path.join(d, "pcalib.txt"), os.path.join(d, "vignette.png"), self.W, self.H)
+        assert self.fov.is_valid() and self.photo.valid() == 3
+        assert self.fov.has_gpu() and self.photo.has_gpu(), "native GPU context missing"
+        self.rx, self.ry = self.fov.remap()
+        self.ginv = self.photo.ginv()
+        self.vinv = self.photo.vignette()[1]
+        self.ctx = capi.Context(0)
+        self.ctx.bind(self.fov, self.photo)
+
+    def want(self, oracle, raw, rect, g, v, o):
+        return oracle.get_image(raw, self.W, self.H, self.w, self.h, self.ginv, self.vinv, True, True, self.rx, self.ry,
+                                rect, g, v, o)
+
+
+@pytest.fixture(scope="module")
+def setups(calib_dirs, oracle):
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = Setup(name, calib_dirs, oracle)
+        return cache[name]
+
+    return get
+
+
+SMALL = [n for n in CAMERAS if n != "full_1280_to_640"]
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_process_host_all_flags(name, setups, oracle):
+    """All 16 combinations of getImage's four bools x 5 frame kinds, fused host call."""
+    from mono_dataset_code_amd import capi
+
+    s = setups(name)
+    for raw in make_frames(s.W, s.H):
+        for rect, g, v, o in itertools.product((0, 1), repeat=4):
+            flags = (capi.RECTIFY * rect) | (capi.GAMMA * g) | (capi.VIGNETTE * v) | (capi.KILL_OVEREXPOSED * o)
+            out = np.full(s.w * s.h if rect else s.W * s.H, -7.0, np.float32)
+            s.ctx.process_host(raw, out, flags)
+            assert bits_equal(out, s.want(oracle, raw, rect, g, v, o)), (name, rect, g, v, o)
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_tiled_and_gather_kernels_agree(name, setups, oracle, torch_cuda):
+    """Device batch API, both kernels, ragged batch sizes (1, 3, 17 frames)."""
+    from mono_dataset_code_amd import capi
+
+    torch = torch_cuda
+    s = setups(name)
+    info = s.ctx.info()
+    frames = np.stack(make_frames(s.W, s.H, n_noise=14))  # 17 frames
+    assert len(frames) == 17
+    want = np.stack([s.want(oracle, f, 1, 1, 1, 1) for f in frames])
+    d_in = torch.from_numpy(frames).cuda()
+    flags = capi.RECTIFY | capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED
+    kernels = [capi.KERNEL_GATHER] + ([capi.KERNEL_TILED] if info.tiled else [])
+    if name not in ("ragged", "small_full_black"):  # width % 16 != 0 / windows too tall for LDS staging
+        assert info.tiled, "tiled kernel should be plannable for %s" % name
+    for k in kernels:
+        s.ctx.set_option(capi.OPT_KERNEL, k)
+        for taps, rep in ((2, 32), (0, 16), (1, 8)) if k == capi.KERNEL_TILED else ((2, 32),):
+          s.ctx.set_option(capi.OPT_TAP_MODE, taps)
+          s.ctx.set_option(capi.OPT_LUT_REPLICAS, rep)
+          for n, fpb in ((1, 0), (3, 2), (17, 0), (17, 5)):
+            s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, fpb)
+            d_out = torch.full((n, s.w * s.h), -7.0, dtype=torch.float32, device="cuda")
+            s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, flags, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert bits_equal(d_out.cpu().numpy(), want[:n]), (name, k, taps, rep, n, fpb)
+    s.ctx.set_option(capi.OPT_TAP_MODE, 2)
+    s.ctx.set_option(capi.OPT_LUT_REPLICAS, 32)
+    s.ctx.set_option(capi.OPT_KERNEL, capi.KERNEL_AUTO)
+    s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, 0)
+
+
+@pytest.mark.parametrize("name", ["small_explicit", "ragged"])
+def test_unmap_and_undistort_host(name, setups, oracle):
+    """The two reference methods separately, through the C ABI host calls."""
+    from mono_dataset_code_amd import capi
+
+    s = setups(name)
+    for raw in make_frames(s.W, s.H):
+        for g, v, o in itertools.product((0, 1), repeat=3):
+            out = np.full(s.W * s.H, -7.0, np.float32)
+            s.ctx.unmap_host(raw, out, (capi.GAMMA * g) | (capi.VIGNETTE * v) | (capi.KILL_OVEREXPOSED * o))
+            want = oracle.unmap(raw, s.ginv, s.vinv, True, True, g, v, o)
+            assert bits_equal(out, want), (name, g, v, o)
+        # undistort<unsigned char> and undistort<float> (float input = the unmapped frame incl. NaN/inf)
+        out = np.full(s.w * s.h, -7.0, np.float32)
+        s.ctx.undistort_host(raw, out)
+        assert bits_equal(out, oracle.undistort(raw, s.rx, s.ry, s.W))
+        fin = oracle.unmap(raw, s.ginv, s.vinv, True, True, 1, 1, 1)
+        s.ctx.undistort_host(fin, out)
+        assert bits_equal(out, oracle.undistort(fin, s.rx, s.ry, s.W))
+
+
+def test_cxx_classes_match_reference(calib_dirs, ref, oracle):
+    """The drop-in C++ classes against the reference's own classes, method by method."""
+    from mono_dataset_code_amd import capi
+
+    d = calib_dirs["small_full_black"]
+    cam = os.path.join(d, "camera.txt")
+    ours, theirs = capi.UndistorterFOV(cam), ref.fov(cam)
+    W, H, w, h = theirs.dims()
+    po = capi.PhotometricUndistorter(os.path.join(d, "pcalib.txt"), os.path.join(d, "vignette.png"), W, H)
+    pt = ref.photo(os.path.join(d, "pcalib.txt"), os.path.join(d, "vignette.png"), W, H)
+    assert ours.has_gpu() and po.has_gpu()
+    for raw in make_frames(W, H):
+        for g, v, o in itertools.product((0, 1), repeat=3):
+            a, b = np.zeros(W * H, np.float32), np.zeros(W * H, np.float32)
+            po.unmap(raw, a, g, v, o)
+            pt.unmap(raw.copy(), b, g, v, o)
+            assert bits_equal(a, b), (g, v, o)
+            a2, b2 = np.zeros(w * h, np.float32), np.zeros(w * h, np.float32)
+            ours.undistort(a, a2)
+            theirs.undistort(b, b2)
+            assert bits_equal(a2, b2), (g, v, o)
+        a2, b2 = np.zeros(w * h, np.float32), np.zeros(w * h, np.float32)
+        ours.undistort(raw, a2)
+        theirs.undistort(raw, b2)
+        assert bits_equal(a2, b2)
+    # wrong sizes: output untouched, like the reference (FOVUndistorter.cpp:327-338)
+    a2 = np.full(w * h, 5.0, np.float32)
+    ours.undistort(np.zeros(W * H - 1, np.uint8), a2)
+    assert np.all(a2 == 5.0)
+
+
+def test_full_size_config_and_properties(setups, oracle, torch_cuda):
+    """BASELINE.json configs[1]/[2] at full size: oracle on 3 frames, then
+    size-independent properties on a 64-frame batch."""
+    from mono_dataset_code_amd import capi, synth
+
+    torch = torch_cuda
+    s = setups("full_1280_to_640")
+    info = s.ctx.info()
+    assert info.tiled and info.in_w == 1280 and info.out_w == 640
+    n = 64
+    npix, nout = s.W * s.H, s.w * s.h
+    st = torch.cuda.current_stream().cuda_stream
+    d_in = torch.empty(n * npix, dtype=torch.uint8, device="cuda")
+    s.ctx.synth_frames(d_in.data_ptr(), 100, n, npix, synth.SEED, st)
+    flags = capi.RECTIFY | capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED
+    d_out = torch.empty(n * nout, dtype=torch.float32, device="cuda")
+    s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, flags, st)
+    torch.cuda.synchronize()
+    frames = d_in.view(n, npix).cpu().numpy()
+    assert np.array_equal(frames[:2], synth.noise_frames(100, 2, npix))  # HIP generator == numpy generator
+    got = d_out.view(n, nout).cpu().numpy()
+    for f in (0, 31, 63):
+        assert bits_equal(got[f], s.want(oracle, frames[f], 1, 1, 1, 1)), f
+    # property 1: batching is invisible -- frame-at-a-time launches give the same bytes
+    d_one = torch.empty(nout, dtype=torch.float32, device="cuda")
+    for f in (5, 40):
+        s.ctx.process_batch(d_in.data_ptr() + f * npix, d_one.data_ptr(), 1, flags, st)
+        torch.cuda.synchronize()
+        assert bits_equal(d_one.cpu().numpy(), got[f])
+    # property 2: gather and tiled kernels agree on the whole batch
+    s.ctx.set_option(capi.OPT_KERNEL, capi.KERNEL_GATHER)
+    d_g = torch.empty(n * nout, dtype=torch.float32, device="cuda")
+    s.ctx.process_batch(d_in.data_ptr(), d_g.data_ptr(), n, flags, st)
+    torch.cuda.synchronize()
+    s.ctx.set_option(capi.OPT_KERNEL, capi.KERNEL_AUTO)
+    assert bits_equal(d_g.cpu().numpy(), got)
+    # property 3: NaN rate of uniform noise = 1-(255/256)^4 of valid outputs
+    rate = np.isnan(got).mean()
+    assert abs(rate - (1 - (255 / 256) ** 4)) < 2e-4
+    # property 4: fused == unmap followed by undistort<float> (the reference's two-pass composition)
+    d_tmp = torch.empty(2 * npix, dtype=torch.float32, device="cuda")
+    d_two = torch.empty(2 * nout, dtype=torch.float32, device="cuda")
+    s.ctx.unmap_batch(d_in.data_ptr(), d_tmp.data_ptr(), 2, flags, st)
+    s.ctx.undistort_batch_f32(d_tmp.data_ptr(), d_two.data_ptr(), 2, st)
+    torch.cuda.synchronize()
+    assert bits_equal(d_two.cpu().numpy(), got[:2])
+    # config 2: unMapImage only, full size
+    want = oracle.unmap(frames[0], s.ginv, s.vinv, True, True, 1, 1, 1)
+    assert bits_equal(d_tmp[:npix].cpu().numpy(), want)
+
+
+def test_pyramid(torch_cuda, oracle):
+    """4-level box pyramid (own definition, parity unpinned by the reference)."""
+    from mono_dataset_code_amd import capi
+
+    torch = torch_cuda
+    ctx = capi.Context(0)
+    w, h, n = 96, 80, 3
+    rng = np.random.RandomState(1)
+    base = rng.rand(n, w * h).astype(np.float32) * 255
+    base[0, 100] = np.nan
+    d_base = torch.from_numpy(base).cuda()
+    lv = [torch.empty(n * (w >> l) * (h >> l), dtype=torch.float32, device="cuda") for l in (1, 2, 3)]
+    ctx.pyramid_batch(d_base.data_ptr(), w, h, 4, [t.data_ptr() for t in lv], n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for f in range(n):
+        src, cw, ch = base[f], w, h
+        for l in range(3):
+            want = oracle.pyramid_level(src, cw, ch)
+            got = lv[l].view(n, -1)[f].cpu().numpy()
+            assert bits_equal(got, want), (f, l)
+            src, cw, ch = want, cw // 2, ch // 2
+
+
+def test_table_blob_roundtrip(setups, oracle, torch_cuda):
+    """export -> import into a second context (what the RCCL broadcast carries)."""
+    from mono_dataset_code_amd import capi
+
+    s = setups("small_crop")
+    blob = s.ctx.export_tables()
+    c2 = capi.Context(0)
+    c2.import_tables(blob)
+    assert np.array_equal(c2.export_tables(), blob)
+    raw = make_frames(s.W, s.H)[0]
+    a, b = np.zeros(s.w * s.h, np.float32), np.zeros(s.w * s.h, np.float32)
+    s.ctx.process_host(raw, a, 15)
+    c2.process_host(raw, b, 15)
+    assert bits_equal(a, b)
+
+
+def test_error_codes(setups):
+    from mono_dataset_code_amd import capi
+
+    c = capi.Context(0)
+    out = np.zeros(10, np.float32)
+    assert c.undistort_host(np.zeros(10, np.uint8), out, check=False) == capi.ERR_STATE
+    assert c.process_host(np.zeros(10, np.uint8), out, capi.RECTIFY, check=False) == capi.ERR_STATE
+    s = setups("small_explicit")
+    assert s.ctx.undistort_host(np.zeros(10, np.uint8), out, check=False) == capi.ERR_SIZE
+    assert "wrong input image" in s.ctx.last_error()
+    with pytest.raises(capi.MdcError):
+        c.set_remap(np.array([5.0], np.float32), np.array([500.0], np.float32), 16, 16, 1, 1)
