@@ -60,8 +60,9 @@ enum {
   MDC_KERNEL_GATHER = 1, /* direct global gather (always legal)                    */
   MDC_KERNEL_TILED = 2   /* LDS-staged source windows (fails if not plannable)     */
 };
-enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2, MDC_OPT_LUT_REPLICAS = 3 /* tuning: 8, 16 or 32 */,
-       MDC_OPT_TAP_MODE = 4 /* tuning: LDS tap fetch 0 = u16, 1 = 2 x u8, 2 = aligned dword pair */ };
+enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2, MDC_OPT_LUT_REPLICAS = 3 /* tuning: 16 or 32 */,
+       MDC_OPT_TAP_MODE = 4 /* tuning: LDS tap fetch 1 = 2 x u8, 2 = aligned dword pair */,
+       MDC_OPT_TILE_ROWS = 5 /* tuning: output tile 64x16 (256 threads) or 64x32 (512 threads) */ };
 
 typedef struct mdc_info {
   int device;                /* HIP device ordinal                                  */

@@ -82,6 +82,16 @@ def build_host(force=False):
     return LIB_HOST
 
 
+def build_variant(name, defines):
+    """Experimental build of libmdc_hip with -D switches (see MDC_EXP_* in mdc_kernels.hip);
+    loaded by tools/sweep.py --lib.  Lands in mono_dataset_code_amd/variants/."""
+    d = os.path.join(PKG, "variants")
+    os.makedirs(d, exist_ok=True)
+    out = os.path.join(d, "libmdc_hip_%s.so" % name)
+    _run([hipcc()] + HIP_FLAGS + ["-I" + INC] + ["-D" + x for x in defines] + HIP_SOURCES + ["-o", out])
+    return out
+
+
 def build_all(force=False):
     build_hip(force)
     build_host(force)

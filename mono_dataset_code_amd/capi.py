@@ -11,13 +11,13 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_HIP_PATH = os.path.join(_PKG, "libmdc_hip.so")
+LIB_HIP_PATH = os.environ.get("MDC_LIB_HIP") or os.path.join(_PKG, "libmdc_hip.so")  # override: experiment builds
 LIB_HOST_PATH = os.path.join(_PKG, "libmdc_host.so")
 
 # flag word (include/mdc_hip.h)
 GAMMA, VIGNETTE, KILL_OVEREXPOSED, RECTIFY = 1, 2, 4, 8
 KERNEL_AUTO, KERNEL_GATHER, KERNEL_TILED = 0, 1, 2
-OPT_KERNEL, OPT_FRAMES_PER_BLOCK, OPT_LUT_REPLICAS, OPT_TAP_MODE = 1, 2, 3, 4
+OPT_KERNEL, OPT_FRAMES_PER_BLOCK, OPT_LUT_REPLICAS, OPT_TAP_MODE, OPT_TILE_ROWS = 1, 2, 3, 4, 5
 OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 
 # every symbol include/mdc_hip.h declares (checked by tests/test_abi.py)

@@ -44,7 +44,7 @@ struct mdc_ctx {
   // tile plan
   bool tiled = false;
   TileDesc* d_tiles = nullptr;
-  int n_tiles = 0, tiles_x = 0, win_bytes = 0;
+  int n_tiles = 0, tiles_x = 0, win_bytes = 0, tile_h = 0;
   int bbox[4] = {0, 0, -1, -1};
   int64_t staged_bytes = 0, n_black = 0;
 
@@ -53,6 +53,7 @@ struct mdc_ctx {
   int opt_fpb = 0;
   int opt_lut_rep = 32;
   int opt_taps = 1;
+  int opt_tile_h = 32;
 
   // staging for the host-pointer calls
   void* d_stage_in = nullptr;
@@ -140,6 +141,7 @@ int plan_tiles(mdc_ctx* c) {
   c->bbox[0] = c->bbox[1] = std::numeric_limits<int>::max();
   c->bbox[2] = c->bbox[3] = -1;
   const int ow = c->out_w, oh = c->out_h, iw = c->rm_in_w;
+  const int kTileH = c->opt_tile_h, kTileThreads = 16 * kTileH;
   const int tx = (ow + kTileW - 1) / kTileW, ty = (oh + kTileH - 1) / kTileH;
   std::vector<TileDesc> tiles((size_t)tx * ty);
   bool ok = (iw % 16 == 0);
@@ -190,6 +192,7 @@ int plan_tiles(mdc_ctx* c) {
   MDC_HIP(c, hipMemcpy(c->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
   c->n_tiles = tx * ty;
   c->tiles_x = tx;
+  c->tile_h = kTileH;
   c->win_bytes = win_max;
   c->tiled = true;
   return MDC_OK;
@@ -251,7 +254,7 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
   if (c->opt_kernel == MDC_KERNEL_TILED && !use_tiled)
     return fail(c, MDC_ERR_STATE, "tiled kernel requested but not plannable for this remap / alignment");
   if (use_tiled) {
-    TilePlan p{c->d_tiles, c->n_tiles, c->tiles_x, c->win_bytes};
+    TilePlan p{c->d_tiles, c->n_tiles, c->tiles_x, c->tile_h, c->win_bytes};
     const int fpb = frames_per_block(c, nframes, (c->n_tiles + 7) & ~7);
     MDC_HIP(c, launch_remap_tiled_u8(d_in, d_out, a, p, nframes, fpb, c->opt_lut_rep, c->opt_taps, s));
   } else {
@@ -330,12 +333,21 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
       if (value < 0) return fail(c, MDC_ERR_ARG, "bad frames-per-block %d", value);
       c->opt_fpb = value;
       return MDC_OK;
+    case MDC_OPT_TILE_ROWS: {
+      if (value != 16 && value != 32) return fail(c, MDC_ERR_ARG, "tile rows must be 16 or 32");
+      if (value == c->opt_tile_h) return MDC_OK;
+      c->opt_tile_h = value;
+      if (!c->valid_remap) return MDC_OK;
+      DeviceGuard dg(c->device);
+      MDC_HIP(c, hipDeviceSynchronize());
+      return plan_tiles(c);
+    }
     case MDC_OPT_TAP_MODE:
-      if (value < 0 || value > 2) return fail(c, MDC_ERR_ARG, "tap mode must be 0, 1 or 2");
+      if (value < 1 || value > 2) return fail(c, MDC_ERR_ARG, "tap mode must be 1 or 2");
       c->opt_taps = value;
       return MDC_OK;
     case MDC_OPT_LUT_REPLICAS:
-      if (value != 8 && value != 16 && value != 32) return fail(c, MDC_ERR_ARG, "LUT replicas must be 8, 16 or 32");
+      if (value != 16 && value != 32) return fail(c, MDC_ERR_ARG, "LUT replicas must be 16 or 32");
       c->opt_lut_rep = value;
       return MDC_OK;
   }
@@ -356,7 +368,7 @@ int mdc_get_info(mdc_ctx* c, mdc_info* i) {
   i->valid_remap = c->valid_remap;
   i->tiled = c->valid_remap && c->tiled;
   i->tile_w = kTileW;
-  i->tile_h = kTileH;
+  i->tile_h = c->opt_tile_h;
   i->n_tiles = c->n_tiles;
   i->lds_bytes = c->tiled ? (int)tiled_lds_bytes(c->win_bytes, c->opt_lut_rep) : 0;
   for (int k = 0; k < 4; k++) i->src_bbox[k] = c->bbox[k];

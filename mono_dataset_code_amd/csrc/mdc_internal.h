@@ -15,13 +15,12 @@ struct TileDesc {
   int cpr;     // 16-byte chunks per window row; LDS pitch = 16*cpr bytes
 };
 
-// Geometry of the tiled kernel: TW x TH outputs per workgroup, one lane per
-// output column, 4 output rows per thread  ->  TW*TH/4 threads.
+// Geometry of the tiled kernel: kTileW x tile_h outputs per workgroup, one lane per
+// output column, 4 output rows per thread  ->  16*tile_h threads
+// (tile_h = 16: 256 threads; tile_h = 32: 512 threads).
 constexpr int kTileW = 64;
-constexpr int kTileH = 16;
-constexpr int kTileThreads = kTileW * kTileH / 4;  // 256
-constexpr int kTileMaxChunks = 3;                  // 16-byte chunks a thread may stage per frame
-constexpr int kLutRep = 32;                        // LDS replicas of the 256-entry response LUT (one per bank)
+constexpr int kTileMaxChunks = 3;  // 16-byte chunks a thread may stage per frame
+constexpr int kLutRep = 32;        // LDS replicas of the 256-entry response LUT (one per bank)
 
 struct RemapArgs {
   const float* lut;    // 256 floats: response LUT variant (identity or GInv; [255] = NaN when killing overexposed)
@@ -34,6 +33,7 @@ struct RemapArgs {
 struct TilePlan {
   const TileDesc* d_tiles;
   int n_tiles, tiles_x;
+  int tile_h;     // 16 or 32 output rows per tile
   int win_bytes;  // LDS bytes of one staging buffer (max over tiles of rows*cpr*16)
 };
 

@@ -27,6 +27,23 @@ namespace mdc {
 namespace {
 
 constexpr int kLutBytes = 256 * kLutRep * 4;
+// Build-time experiment switches (tools/sweep.py --lib ...; defaults are the shipped configuration).
+#ifndef MDC_EXP_LOAD_NT
+#define MDC_EXP_LOAD_NT 0   // staging loads: plain (L2-allocating) -- neighbouring tiles re-use halo lines; nt measured slower
+#endif
+#ifndef MDC_EXP_STORE_NT
+#define MDC_EXP_STORE_NT 1  // output stores carry the nontemporal hint
+#endif
+#ifndef MDC_EXP_BATCHED
+#define MDC_EXP_BATCHED 0   // issue all 16 tap reads, then all 16 LUT reads, then the arithmetic
+#endif
+#ifndef MDC_EXP_WAVES
+#define MDC_EXP_WAVES 5     // __launch_bounds__ min waves per SIMD of the 256-thread tiled kernel
+#endif
+#ifndef MDC_EXP_WAVES_512
+#define MDC_EXP_WAVES_512 6 // same for the 512-thread (64x32 tile) kernel: 3 workgroups per CU
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -254,6 +271,23 @@ typedef const __attribute__((address_space(3))) unsigned char* lds_u8_ptr;
 typedef const volatile __attribute__((address_space(3))) unsigned char* lds_vu8_ptr;
 typedef const __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
 
+template <typename T>
+__device__ __forceinline__ T stream_load(const T* p) {
+#if MDC_EXP_LOAD_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void stream_store(T v, T* p) {
+#if MDC_EXP_STORE_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 template <int TAPS>
 __device__ __forceinline__ void tap_pair(const unsigned char* p, int& a, int& b) {
   if (TAPS == 0) {
@@ -278,6 +312,35 @@ __device__ __forceinline__ void tap_pair(const unsigned char* p, int& a, int& b)
 template <bool VIG, int LUTREP, bool EDGE, int TAPS>
 __device__ __forceinline__ void tile_compute(const TileThread& t, const unsigned char* __restrict__ w, int pitch,
                                              const float* __restrict__ my_lut, float* __restrict__ dst) {
+#if MDC_EXP_BATCHED
+  int b00[4], b10[4], b01[4], b11[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const unsigned char* p = w + t.off[j];
+    tap_pair<TAPS>(p, b00[j], b10[j]);
+    tap_pair<TAPS>(p + pitch, b01[j], b11[j]);
+  }
+  float t00[4], t10[4], t01[4], t11[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    t00[j] = my_lut[b00[j] * LUTREP];
+    t10[j] = my_lut[b10[j] * LUTREP];
+    t01[j] = my_lut[b01[j] * LUTREP];
+    t11[j] = my_lut[b11[j] * LUTREP];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (VIG) {
+      t00[j] = t00[j] * t.v00[j];
+      t10[j] = t10[j] * t.v10[j];
+      t01[j] = t01[j] * t.v01[j];
+      t11[j] = t11[j] * t.v11[j];
+    }
+    float r = bilin_sum(t.bl[j], t00[j], t10[j], t01[j], t11[j]);
+    if (t.black[j]) r = 0.f;
+    if (!EDGE || t.inside[j]) stream_store(r, dst + t.oidx[j]);
+  }
+#else
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const unsigned char* p = w + t.off[j];
@@ -296,11 +359,12 @@ __device__ __forceinline__ void tile_compute(const TileThread& t, const unsigned
     }
     float r = bilin_sum(t.bl[j], t00, t10, t01, t11);
     if (t.black[j]) r = 0.f;
-    if (!EDGE || t.inside[j]) __builtin_nontemporal_store(r, dst + t.oidx[j]);
+    if (!EDGE || t.inside[j]) stream_store(r, dst + t.oidx[j]);
   }
+#endif
 }
 
-template <bool VIG, int LUTREP, int R, bool EDGE, int TAPS>
+template <bool VIG, int LUTREP, int R, bool EDGE, int TAPS, int NT>
 __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* __restrict__ src,
                                             float* __restrict__ dst, long long n_in, long long n_out, int nframes,
                                             int nch, const TileDesc& td, int in_w, unsigned char* s_win,
@@ -309,14 +373,14 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
   int goff[R], loff[R];
 #pragma unroll
   for (int k = 0; k < R; k++) {
-    const int c = min(tid + k * kTileThreads, nch - 1);
+    const int c = min(tid + k * NT, nch - 1);
     const int r = c / td.cpr;
     goff[k] = (td.y0 + r) * in_w + td.x0 + (c - r * td.cpr) * 16;
     loff[k] = c * 16;
   }
   u32x4 stage[R];
 #pragma unroll
-  for (int k = 0; k < R; k++) stage[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + goff[k]));
+  for (int k = 0; k < R; k++) stage[k] = stream_load(reinterpret_cast<const u32x4*>(src + goff[k]));
 #pragma unroll
   for (int k = 0; k < R; k++) *reinterpret_cast<u32x4*>(s_win + loff[k]) = stage[k];
   __syncthreads();
@@ -324,7 +388,7 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
   for (int f = 0; f < nframes - 1; f++) {
     src += n_in;
 #pragma unroll
-    for (int k = 0; k < R; k++) stage[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + goff[k]));
+    for (int k = 0; k < R; k++) stage[k] = stream_load(reinterpret_cast<const u32x4*>(src + goff[k]));
     tile_compute<VIG, LUTREP, EDGE, TAPS>(t, s_win + cur * win_bytes, pitch, my_lut, dst);
     dst += n_out;
     unsigned char* wn = s_win + (cur ^ 1) * win_bytes;
@@ -336,8 +400,8 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
   tile_compute<VIG, LUTREP, EDGE, TAPS>(t, s_win + cur * win_bytes, pitch, my_lut, dst);
 }
 
-template <bool VIG, int LUTREP, int TAPS>
-__global__ __launch_bounds__(kTileThreads, 5) void remap_tiled_u8_kernel(const uint8_t* __restrict__ in,
+template <bool VIG, int LUTREP, int TAPS, int NT>
+__global__ __launch_bounds__(NT, (NT == 512 ? MDC_EXP_WAVES_512 : MDC_EXP_WAVES)) void remap_tiled_u8_kernel(const uint8_t* __restrict__ in,
                                                                       float* __restrict__ out, RemapArgs a,
                                                                       const TileDesc* __restrict__ tiles,
                                                                       int n_tiles, int tiles_x, int win_bytes,
@@ -359,10 +423,11 @@ __global__ __launch_bounds__(kTileThreads, 5) void remap_tiled_u8_kernel(const u
   const TileDesc td = tiles[tile];
   const int pitch = td.cpr * 16;
   const int ox = (tile % tiles_x) * kTileW + lane_x;
-  const int oy0 = (tile / tiles_x) * kTileH + row0;
+  constexpr int kTileRows = NT / 16;  // 4 output rows per thread, kTileW lanes per row
+  const int oy0 = (tile / tiles_x) * kTileRows + row0;
 
 #pragma unroll 4
-  for (int i = tid; i < 256 * LUTREP; i += kTileThreads) s_lut[i] = a.lut[i / LUTREP];
+  for (int i = tid; i < 256 * LUTREP; i += NT) s_lut[i] = a.lut[i / LUTREP];
   const float* my_lut = s_lut + (tid & (LUTREP - 1));
 
   TileThread t;
@@ -401,10 +466,10 @@ __global__ __launch_bounds__(kTileThreads, 5) void remap_tiled_u8_kernel(const u
         if (t.inside[j]) dst[t.oidx[j]] = 0.f;
     return;
   }
-  const int rounds = (nch + kTileThreads - 1) / kTileThreads;  // workgroup-uniform
-  const bool edge = ((tile % tiles_x) + 1) * kTileW > a.out_w || ((tile / tiles_x) + 1) * kTileH > a.out_h;
+  const int rounds = (nch + NT - 1) / NT;  // workgroup-uniform
+  const bool edge = ((tile % tiles_x) + 1) * kTileW > a.out_w || ((tile / tiles_x) + 1) * kTileRows > a.out_h;
 #define MDC_TILE_RUN(R_, E_) \
-  tile_frames<VIG, LUTREP, R_, E_, TAPS>(t, src, dst, n_in, n_out, nf, nch, td, a.in_w, s_win, win_bytes, my_lut, tid)
+  tile_frames<VIG, LUTREP, R_, E_, TAPS, NT>(t, src, dst, n_in, n_out, nf, nch, td, a.in_w, s_win, win_bytes, my_lut, tid)
   if (!edge) {
     if (rounds == 1) MDC_TILE_RUN(1, false);
     else if (rounds == 2) MDC_TILE_RUN(2, false);
@@ -498,39 +563,39 @@ hipError_t launch_remap_gather_f32(const float* d_in, float* d_out, const RemapA
   return hipGetLastError();
 }
 
-template <bool VIG, int LUTREP, int TAPS>
+template <bool VIG, int LUTREP, int TAPS, int NT>
 static hipError_t launch_tiled_variant(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
                                        int64_t nframes, int fpb, hipStream_t s) {
   const int ntp = (p.n_tiles + 7) & ~7;
   dim3 grid(ntp, ceil_div(nframes, fpb));
   const size_t lds = tiled_lds_bytes(p.win_bytes, LUTREP);
-  remap_tiled_u8_kernel<VIG, LUTREP, TAPS><<<grid, kTileThreads, lds, s>>>(
-      d_in, d_out, a, p.d_tiles, p.n_tiles, p.tiles_x, p.win_bytes, (int)nframes, fpb);
+  remap_tiled_u8_kernel<VIG, LUTREP, TAPS, NT><<<grid, NT, lds, s>>>(d_in, d_out, a, p.d_tiles, p.n_tiles, p.tiles_x,
+                                                                      p.win_bytes, (int)nframes, fpb);
   return hipGetLastError();
 }
 
-template <bool VIG, int LUTREP>
-static hipError_t launch_tiled_taps(int taps, const uint8_t* d_in, float* d_out, const RemapArgs& a,
-                                    const TilePlan& p, int64_t nframes, int fpb, hipStream_t s) {
-  switch (taps) {
-    case 0: return launch_tiled_variant<VIG, LUTREP, 0>(d_in, d_out, a, p, nframes, fpb, s);
-    case 1: return launch_tiled_variant<VIG, LUTREP, 1>(d_in, d_out, a, p, nframes, fpb, s);
-    default: return launch_tiled_variant<VIG, LUTREP, 2>(d_in, d_out, a, p, nframes, fpb, s);
-  }
+template <bool VIG, int LUTREP, int TAPS>
+static hipError_t launch_tiled_nt(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
+                                  int64_t nframes, int fpb, hipStream_t s) {
+  return p.tile_h == 32 ? launch_tiled_variant<VIG, LUTREP, TAPS, 512>(d_in, d_out, a, p, nframes, fpb, s)
+                        : launch_tiled_variant<VIG, LUTREP, TAPS, 256>(d_in, d_out, a, p, nframes, fpb, s);
+}
+
+template <bool VIG>
+static hipError_t launch_tiled_vig(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
+                                   int64_t nframes, int fpb, int lut_rep, int taps, hipStream_t s) {
+  if (lut_rep == 16)
+    return taps == 2 ? launch_tiled_nt<VIG, 16, 2>(d_in, d_out, a, p, nframes, fpb, s)
+                     : launch_tiled_nt<VIG, 16, 1>(d_in, d_out, a, p, nframes, fpb, s);
+  return taps == 2 ? launch_tiled_nt<VIG, 32, 2>(d_in, d_out, a, p, nframes, fpb, s)
+                   : launch_tiled_nt<VIG, 32, 1>(d_in, d_out, a, p, nframes, fpb, s);
 }
 
 hipError_t launch_remap_tiled_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
                                  int64_t nframes, int fpb, int lut_rep, int taps, hipStream_t s) {
   if (nframes <= 0) return hipSuccess;
-  const bool v = a.vinv != nullptr;
-  switch (lut_rep) {
-    case 8: return v ? launch_tiled_taps<true, 8>(taps, d_in, d_out, a, p, nframes, fpb, s)
-                     : launch_tiled_taps<false, 8>(taps, d_in, d_out, a, p, nframes, fpb, s);
-    case 16: return v ? launch_tiled_taps<true, 16>(taps, d_in, d_out, a, p, nframes, fpb, s)
-                      : launch_tiled_taps<false, 16>(taps, d_in, d_out, a, p, nframes, fpb, s);
-    default: return v ? launch_tiled_taps<true, 32>(taps, d_in, d_out, a, p, nframes, fpb, s)
-                      : launch_tiled_taps<false, 32>(taps, d_in, d_out, a, p, nframes, fpb, s);
-  }
+  return a.vinv ? launch_tiled_vig<true>(d_in, d_out, a, p, nframes, fpb, lut_rep, taps, s)
+                : launch_tiled_vig<false>(d_in, d_out, a, p, nframes, fpb, lut_rep, taps, s);
 }
 
 hipError_t launch_pyramid_level(const float* d_src, float* d_dst, int w, int h, int64_t nframes, hipStream_t s) {

@@ -89,12 +89,17 @@ def test_tiled_and_gather_kernels_agree(name, setups, oracle, torch_cuda):
     want = np.stack([s.want(oracle, f, 1, 1, 1, 1) for f in frames])
     d_in = torch.from_numpy(frames).cuda()
     flags = capi.RECTIFY | capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED
+    s.ctx.set_option(capi.OPT_TILE_ROWS, 16)
+    info = s.ctx.info()
     kernels = [capi.KERNEL_GATHER] + ([capi.KERNEL_TILED] if info.tiled else [])
     if name not in ("ragged", "small_full_black"):  # width % 16 != 0 / windows too tall for LDS staging
         assert info.tiled, "tiled kernel should be plannable for %s" % name
     for k in kernels:
         s.ctx.set_option(capi.OPT_KERNEL, k)
-        for taps, rep in ((2, 32), (0, 16), (1, 8)) if k == capi.KERNEL_TILED else ((2, 32),):
+        for taps, rep, rows in ((2, 32, 32), (1, 16, 16), (1, 32, 32), (2, 16, 16)) if k == capi.KERNEL_TILED else ((1, 32, 32),):
+          s.ctx.set_option(capi.OPT_TILE_ROWS, rows)
+          if k == capi.KERNEL_TILED and not s.ctx.info().tiled:
+              continue
           s.ctx.set_option(capi.OPT_TAP_MODE, taps)
           s.ctx.set_option(capi.OPT_LUT_REPLICAS, rep)
           for n, fpb in ((1, 0), (3, 2), (17, 0), (17, 5)):
@@ -102,9 +107,10 @@ def test_tiled_and_gather_kernels_agree(name, setups, oracle, torch_cuda):
             d_out = torch.full((n, s.w * s.h), -7.0, dtype=torch.float32, device="cuda")
             s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, flags, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-            assert bits_equal(d_out.cpu().numpy(), want[:n]), (name, k, taps, rep, n, fpb)
-    s.ctx.set_option(capi.OPT_TAP_MODE, 2)
+            assert bits_equal(d_out.cpu().numpy(), want[:n]), (name, k, taps, rep, rows, n, fpb)
+    s.ctx.set_option(capi.OPT_TAP_MODE, 1)
     s.ctx.set_option(capi.OPT_LUT_REPLICAS, 32)
+    s.ctx.set_option(capi.OPT_TILE_ROWS, 32)
     s.ctx.set_option(capi.OPT_KERNEL, capi.KERNEL_AUTO)
     s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, 0)
 

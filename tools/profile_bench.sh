@@ -1,0 +1,47 @@
+#!/bin/bash
+# Round profile of the bench command (run on the GPU box via gpurun):
+#   1. rocprofv3 --kernel-trace --stats            -> per-kernel average duration
+#   2. rocprofv3 --pmc FETCH_SIZE   (own pass)     -> HBM read bytes per launch
+#   3. rocprofv3 --pmc WRITE_SIZE   (own pass)     -> HBM write bytes per launch
+# and a summary JSON with the gfx950 corrections of MI355X_MICROARCH.md (section HBM), checked on
+# this box with tools/fetch_calib.hip: FETCH_SIZE counts KiB and reports exactly 1/2 of the bytes
+# read (all widths we use), WRITE_SIZE counts KiB and is exact.
+# usage: tools/profile_bench.sh <tag> [bench.py args...]
+set -u
+TAG=$1; shift
+OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/bench_under_profiler.json 2> $OUT/stats.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $BENCH > /dev/null 2> $OUT/fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $BENCH > /dev/null 2> $OUT/write.log
+python3 - "$OUT" "$TAG" "$*" <<'PY'
+import csv, glob, json, sys, collections
+out, tag, args = sys.argv[1], sys.argv[2], sys.argv[3]
+def short(k):
+    k = k.split("(")[0]
+    return k.split("::")[-1] if "::" in k else k
+stats = {}
+for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        stats[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
+                                   "total_ms": float(r["TotalDurationNs"]) / 1e6, "pct": float(r["Percentage"])}
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for which in ("fetch", "write"):
+    for f in glob.glob(out + "/%s/**/*counter_collection.csv" % which, recursive=True):
+        for r in csv.DictReader(open(f)):
+            pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {"tag": tag, "bench_args": args, "kernels": {}}
+for k, s in stats.items():
+    e = dict(s)
+    if k in pmc:
+        f = pmc[k].get("FETCH_SIZE", []); w = pmc[k].get("WRITE_SIZE", [])
+        # skip the warmup-free first dispatches? all launches are identical batches: plain mean
+        if f: e["FETCH_SIZE_KiB_raw_mean"] = sum(f) / len(f); e["hbm_read_bytes_per_launch"] = 2.0 * 1024 * sum(f) / len(f)
+        if w: e["WRITE_SIZE_KiB_raw_mean"] = sum(w) / len(w); e["hbm_write_bytes_per_launch"] = 1024.0 * sum(w) / len(w)
+        if f and w: e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+    res["kernels"][k] = e
+json.dump(res, open(out + "/summary.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
