@@ -49,14 +49,17 @@ def parse():
     return p.parse_args()
 
 
-def traffic_from_profiles(kernel_tag):
-    """HBM bytes per launch from the PMC passes (tools/pmc_traffic.py writes
-    profiles/hbm_traffic.json); None until that file exists."""
+def traffic_from_profiles(kernel_tag, frames_per_launch):
+    """Measured HBM bytes per launch of the dominant kernel, from the separate PMC passes
+    (tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, gfx950
+    corrections applied) recorded per frame in profiles/hbm_traffic.json.  PMC cannot be
+    collected inside this process, so the figure is the committed one; None if absent."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(kernel_tag)
-    except (OSError, ValueError):
+            e = json.load(f).get(kernel_tag)
+        return round(e["bytes_per_frame"] * frames_per_launch) if e else None
+    except (OSError, ValueError, KeyError):
         return None
 
 
@@ -237,7 +240,7 @@ def main():
             tag = "fused_tiled" if info.tiled and args.kernel != "gather" else "fused_gather"
         achieved = alg_frame * B / (kernel_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles(tag),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles(tag, B),
                 "kernel": tag, "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_frame": alg_frame,
                 "frames_per_launch": B, "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4)}
         out = {

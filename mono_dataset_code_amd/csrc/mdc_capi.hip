@@ -125,9 +125,10 @@ int upload_luts(mdc_ctx* c) {
 
 int frames_per_block(const mdc_ctx* c, int64_t nframes, int blocks_per_group) {
   if (c->opt_fpb > 0) return (int)std::min<int64_t>(c->opt_fpb, std::max<int64_t>(nframes, 1));
-  // enough workgroups to fill 256 CUs several times over, yet tables amortised
-  int64_t groups = std::max<int64_t>(1, 4096 / std::max(1, blocks_per_group));
-  groups = std::min<int64_t>(groups, nframes);
+  // enough workgroups to fill 256 CUs several times over (tail), yet >= 8 frames per
+  // workgroup so the per-workgroup table reads stay amortised
+  int64_t groups = std::max<int64_t>(1, (4800 + blocks_per_group - 1) / std::max(1, blocks_per_group));
+  groups = std::min<int64_t>(groups, std::max<int64_t>(1, nframes / 8));
   return (int)((nframes + groups - 1) / groups);
 }
 

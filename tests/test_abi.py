@@ -1,0 +1,82 @@
+"""The C-ABI shared libraries load and export every symbol their headers declare
+(no compute calls: this runs without a GPU), and without a GPU the product fails
+loudly instead of falling back to a CPU implementation."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header, prefix):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s\w+)\s*\(" % prefix, txt)))
+
+
+def test_libmdc_hip_exports_header():
+    from mono_dataset_code_amd import capi
+
+    names = declared("mdc_hip.h", "mdc_")
+    assert sorted(capi.HIP_SYMBOLS) == names
+    lib = ctypes.CDLL(capi.LIB_HIP_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_libmdc_host_exports_header():
+    from mono_dataset_code_amd import capi
+
+    names = declared("mdc_host.h", "mdch_")
+    assert sorted(capi.HOST_SYMBOLS) == names
+    lib = capi.host_lib()
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_signatures_have_no_torch_types():
+    for h in ("mdc_hip.h", "mdc_host.h"):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        assert "torch" not in txt and "at::" not in txt and "Tensor" not in txt
+
+
+def test_no_cpu_fallback_without_gpu(calib_dirs):
+    """On a box without a HIP device: context creation reports MDC_ERR_NO_DEVICE and the
+    C++ classes leave their output untouched (and complain) -- they never compute on the CPU."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from mono_dataset_code_amd import capi
+
+    with pytest.raises(capi.MdcError) as e:
+        capi.Context(0)
+    assert e.value.code == capi.ERR_NO_DEVICE
+    d = calib_dirs["small_explicit"]
+    fov = capi.UndistorterFOV(os.path.join(d, "camera.txt"))
+    assert fov.is_valid() and not fov.has_gpu()
+    W, H, w, h = fov.dims()
+    out = np.full(w * h, 123.0, np.float32)
+    fov.undistort(np.zeros(W * H, np.uint8), out)
+    assert np.all(out == 123.0)
+    ph = capi.PhotometricUndistorter(os.path.join(d, "pcalib.txt"), os.path.join(d, "vignette.png"), W, H)
+    out2 = np.full(W * H, 123.0, np.float32)
+    ph.unmap(np.zeros(W * H, np.uint8), out2, 1, 1, 1)
+    assert np.all(out2 == 123.0)
+
+
+def test_product_does_not_reference_the_oracle():
+    """Nothing under the package or include/ may import, link or name oracle/ (the only
+    shared piece is the Eigen stand-in, which lives on the product side)."""
+    bad = []
+    for base in ("mono_dataset_code_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".h", ".hip", ".cpp")) or f == "Core":
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"oracle[/.]|liboracle|libmdc_ref|orc_\w+\(|ref_\w+\(", txt) and "oracle/Makefile" not in txt.replace("oracle's", ""):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

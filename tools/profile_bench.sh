@@ -19,9 +19,11 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $
 python3 - "$OUT" "$TAG" "$*" <<'PY'
 import csv, glob, json, sys, collections
 out, tag, args = sys.argv[1], sys.argv[2], sys.argv[3]
+import re
 def short(k):
-    k = k.split("(")[0]
-    return k.split("::")[-1] if "::" in k else k
+    k = k.replace("(anonymous namespace)::", "").replace("void ", "")
+    m = re.match(r"([\w:]+(<[^()]*>)?)", k)
+    return (m.group(1) if m else k).replace("mdc::", "")
 stats = {}
 for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
