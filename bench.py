@@ -150,12 +150,10 @@ def main():
             os.dup2(saved, 1)
             os.close(devnull)
         assert fov.is_valid() and photo.valid() == 3
-        ctx.bind(fov, photo)
-        blob = ctx.export_tables()
+        blob = capi.pack_tables(fov, photo)  # host-side serialisation of GInv, vignetteInv, remapX/Y
     if world > 1:
-        blob = shard.broadcast_tables(blob, src=0, device=dev)
-        if rank != 0:
-            ctx.import_tables(blob)
+        blob = shard.broadcast_tables(blob, src=0, device=dev)  # the only collective: once, over RCCL
+    ctx.import_tables(blob)  # every rank (rank 0 included) uploads the same bytes
     ctx.set_option(capi.OPT_KERNEL, {"auto": capi.KERNEL_AUTO, "gather": capi.KERNEL_GATHER, "tiled": capi.KERNEL_TILED}[args.kernel])
     ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, args.fpb)
     if args.lut_rep:

@@ -46,6 +46,12 @@ void mdch_photo_unmap(mdch_photo*, unsigned char* in, float* out, int n, int g, 
  * context so the fused mdc_process_* entry points can be used. */
 int mdch_bind(mdc_ctx* ctx, const mdch_fov* fov, const mdch_photo* photo);
 
+/* Serialises the tables of the two objects (either may be NULL) on the host into the
+ * blob format of mdc_export_tables / mdc_import_tables -- what rank 0 broadcasts to the
+ * other ranks of a multi-GPU job.  Needs no GPU.  mdch_pack_tables(f, p, NULL, 0, &n)
+ * returns the size.  Returns MDC_OK or MDC_ERR_ARG (buffer too small). */
+int mdch_pack_tables(const mdch_fov* fov, const mdch_photo* photo, void* blob, size_t cap, size_t* size);
+
 #ifdef __cplusplus
 }
 #endif

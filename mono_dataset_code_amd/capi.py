@@ -32,7 +32,7 @@ HOST_SYMBOLS = [
     "mdch_fov_create", "mdch_fov_destroy", "mdch_fov_valid", "mdch_fov_has_gpu", "mdch_fov_dims",
     "mdch_fov_intrinsics", "mdch_fov_remap", "mdch_fov_distort", "mdch_fov_undistort_f32", "mdch_fov_undistort_u8",
     "mdch_photo_create", "mdch_photo_destroy", "mdch_photo_valid", "mdch_photo_has_gpu", "mdch_photo_ginv",
-    "mdch_photo_g", "mdch_photo_vignette", "mdch_photo_unmap", "mdch_bind",
+    "mdch_photo_g", "mdch_photo_vignette", "mdch_photo_unmap", "mdch_bind", "mdch_pack_tables",
 ]
 
 
@@ -145,6 +145,8 @@ def host_lib():
         L.mdch_photo_unmap.restype = None
         L.mdch_bind.argtypes = [_vp, _vp, _vp]
         L.mdch_bind.restype = _i
+        L.mdch_pack_tables.argtypes = [_vp, _vp, _vp, _sz, C.POINTER(_sz)]
+        L.mdch_pack_tables.restype = _i
         _host = L
     return _host
 
@@ -266,6 +268,20 @@ class Context:
     def bind(self, fov=None, photo=None):
         rc = host_lib().mdch_bind(self._h, fov._h if fov is not None else None, photo._h if photo is not None else None)
         self._chk(rc)
+
+
+def pack_tables(fov=None, photo=None):
+    """Host-side table blob (mdch_pack_tables): what rank 0 broadcasts; needs no GPU."""
+    L = host_lib()
+    n = _sz(0)
+    fh = fov._h if fov is not None else None
+    ph = photo._h if photo is not None else None
+    if L.mdch_pack_tables(fh, ph, None, 0, C.byref(n)) != OK:
+        raise MdcError(ERR_ARG, "mdch_pack_tables")
+    buf = np.zeros(n.value, dtype=np.uint8)
+    if L.mdch_pack_tables(fh, ph, _np_ptr(buf), buf.size, C.byref(n)) != OK:
+        raise MdcError(ERR_ARG, "mdch_pack_tables")
+    return buf
 
 
 class UndistorterFOV:

@@ -1,6 +1,7 @@
 // C facade over the drop-in classes -- see include/mdc_host.h.
 #include "mdc_host.h"
 
+#include <cstdint>
 #include <cstring>
 
 #include "FOVUndistorter.h"
@@ -127,6 +128,59 @@ int mdch_bind(mdc_ctx* ctx, const mdch_fov* fov, const mdch_photo* photo) {
     else rc = mdc_set_remap(ctx, 0, 0, 0, 0, 0, 0);
   }
   return rc;
+}
+
+// Must stay in step with BlobHeader in csrc/mdc_capi.hip (checked by tests/test_multi_gpu.py
+// on the GPU: pack == export after bind).
+namespace {
+struct PackedHeader {
+  uint32_t magic, version;
+  int32_t in_w, in_h, rm_in_w, rm_in_h, out_w, out_h;
+  int32_t valid_gamma, valid_vignette, valid_remap, pad;
+};
+}  // namespace
+
+int mdch_pack_tables(const mdch_fov* fov, const mdch_photo* photo, void* blob, size_t cap, size_t* size) {
+  if (!size) return MDC_ERR_ARG;
+  PackedHeader h;
+  memset(&h, 0, sizeof h);
+  h.magic = 0x4d444331u;
+  h.version = 1;
+  const PhotometricUndistorter* p = photo ? photo->p : 0;
+  const UndistorterFOV* u = fov ? fov->u : 0;
+  if (p) {
+    h.in_w = MdcHostAccess::w(*p);
+    h.in_h = MdcHostAccess::h(*p);
+    h.valid_gamma = MdcHostAccess::valid_gamma(*p);
+    h.valid_vignette = MdcHostAccess::valid_vignette(*p);
+  }
+  if (u && u->isValid()) {
+    h.valid_remap = 1;
+    h.rm_in_w = u->getInputDims()[0];
+    h.rm_in_h = u->getInputDims()[1];
+    h.out_w = u->getOutputDims()[0];
+    h.out_h = u->getOutputDims()[1];
+  }
+  const size_t nv = h.valid_vignette ? (size_t)h.in_w * h.in_h : 0;
+  const size_t nr = h.valid_remap ? (size_t)h.out_w * h.out_h : 0;
+  const size_t need = sizeof h + 256 * 4 + nv * 4 + 2 * nr * 4;
+  *size = need;
+  if (!blob) return MDC_OK;
+  if (cap < need) return MDC_ERR_ARG;
+  char* q = (char*)blob;
+  memcpy(q, &h, sizeof h);
+  q += sizeof h;
+  float zeros[256];
+  memset(zeros, 0, sizeof zeros);
+  memcpy(q, (p && h.valid_gamma) ? MdcHostAccess::ginv(*p) : zeros, 256 * 4);
+  q += 256 * 4;
+  if (nv) memcpy(q, MdcHostAccess::vinv(*p), nv * 4);
+  q += nv * 4;
+  if (nr) {
+    memcpy(q, MdcHostAccess::rx(*u), nr * 4);
+    memcpy(q + nr * 4, MdcHostAccess::ry(*u), nr * 4);
+  }
+  return MDC_OK;
 }
 
 }  // extern "C"

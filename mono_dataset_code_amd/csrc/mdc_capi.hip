@@ -607,7 +607,8 @@ int mdc_export_tables(mdc_ctx* c, void* blob, size_t cap, size_t* size) {
   char* p = (char*)blob;
   memcpy(p, &h, sizeof h);
   p += sizeof h;
-  memcpy(p, c->h_ginv.data(), 256 * 4);
+  if (c->valid_gamma) memcpy(p, c->h_ginv.data(), 256 * 4);
+  else memset(p, 0, 256 * 4);
   p += 256 * 4;
   if (nv) memcpy(p, c->h_vinv.data(), nv * 4);
   p += nv * 4;
