@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-pointer drop-in calls (never the bench `value`):
+single-frame, synchronous, pageable host buffers -- what a caller of the reference's
+classes gets without changing a line."""
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from mono_dataset_code_amd import capi, synth  # noqa: E402
+
+d = synth.write_sequence_calibration(tempfile.mkdtemp(prefix="mdc_host_"))
+fov = capi.UndistorterFOV(os.path.join(d, "camera.txt"))
+photo = capi.PhotometricUndistorter(os.path.join(d, "pcalib.txt"), os.path.join(d, "vignette.png"), 1280, 1024)
+ctx = capi.Context(0)
+ctx.bind(fov, photo)
+W, H, w, h = fov.dims()
+frames = synth.noise_frames(0, 8, W * H)
+tmp = np.zeros(W * H, np.float32)
+out = np.zeros(w * h, np.float32)
+N = 200
+
+
+def rate(fn):
+    fn(0)
+    t0 = time.perf_counter()
+    for i in range(N):
+        fn(i)
+    dt = time.perf_counter() - t0
+    return N / dt, N * W * H / dt / 1e6
+
+
+def two_calls(i):  # exactly what DatasetReader::getImage does with the drop-in classes
+    photo.unmap(frames[i % 8], tmp, 1, 1, 1)
+    fov.undistort(tmp, out)
+
+
+print("host path, 1280x1024 -> 640x480, g+v+o, %d frames each" % N, file=sys.stderr)
+for name, fn in (("unMapImage + undistort<float> (two class calls, W*H float round trip)", two_calls),
+                 ("mdc_process_host (fused, one call)", lambda i: ctx.process_host(frames[i % 8], out, 15))):
+    fps, mpix = rate(fn)
+    print("%-75s %8.1f frames/s  %9.1f Mpix/s" % (name, fps, mpix), file=sys.stderr)
