@@ -44,6 +44,8 @@ struct mdc_ctx {
   // tile plan
   bool tiled = false;
   TileDesc* d_tiles = nullptr;
+  int* d_order = nullptr;  // block -> tile placement table (XCD bands)
+  int n_blocks = 0;
   int n_tiles = 0, tiles_x = 0, win_bytes = 0, tile_h = 0;
   int bbox[4] = {0, 0, -1, -1};
   int64_t staged_bytes = 0, n_black = 0;
@@ -54,6 +56,7 @@ struct mdc_ctx {
   int opt_lut_rep = 32;
   int opt_taps = 1;
   int opt_tile_h = 32;
+  int opt_order = MDC_ORDER_BANDS;
 
   // staging for the host-pointer calls
   void* d_stage_in = nullptr;
@@ -132,6 +135,39 @@ int frames_per_block(const mdc_ctx* c, int64_t nframes, int blocks_per_group) {
   return (int)((nframes + groups - 1) / groups);
 }
 
+// Placement table of the tiled kernel: entry b = tile run by block b of a frame group, -1 = none.
+// The dispatcher deals blocks round-robin over the 8 XCDs (block b -> XCD b % 8, slot b / 8), so
+// XCD k runs the tiles of entries k, k+8, k+16, ...  Neighbouring tiles share source lines (halo
+// rows, 128-byte lines straddling a tile border); they should meet in ONE XCD's L2.
+//   MDC_ORDER_BANDS     row-major runs of ceil(n/8) tiles per XCD
+//   MDC_ORDER_ROWS      whole tile rows per XCD, as even as the row count allows (no horizontal
+//                       neighbours split; XCDs with a row less idle at the end of a frame group)
+//   MDC_ORDER_IDENTITY  block b = tile b: neighbours land on different XCDs (diagnosis: worst case)
+std::vector<int> tile_order(int tx, int ty, int mode) {
+  const int n = tx * ty;
+  std::vector<std::vector<int>> per_xcd(8);
+  if (mode == MDC_ORDER_IDENTITY) {
+    for (int t = 0; t < n; t++) per_xcd[t % 8].push_back(t);
+  } else if (mode == MDC_ORDER_ROWS && ty >= 8) {
+    int r = 0;
+    for (int k = 0; k < 8; k++) {
+      const int rows = ty / 8 + (k < ty % 8 ? 1 : 0);
+      for (int y = r; y < r + rows; y++)
+        for (int x = 0; x < tx; x++) per_xcd[k].push_back(y * tx + x);
+      r += rows;
+    }
+  } else {
+    const int per = (n + 7) / 8;
+    for (int t = 0; t < n; t++) per_xcd[t / per].push_back(t);
+  }
+  size_t slots = 0;
+  for (const auto& v : per_xcd) slots = std::max(slots, v.size());
+  std::vector<int> order(slots * 8, -1);
+  for (int k = 0; k < 8; k++)
+    for (size_t j = 0; j < per_xcd[k].size(); j++) order[j * 8 + k] = per_xcd[k][j];
+  return order;
+}
+
 // Source window of every output tile (see TileDesc).  Fails (tiled = false)
 // when rows of the frame are not whole 16-byte chunks or a window is too large.
 int plan_tiles(mdc_ctx* c) {
@@ -188,9 +224,17 @@ int plan_tiles(mdc_ctx* c) {
     (void)hipFree(c->d_tiles);
     c->d_tiles = nullptr;
   }
+  if (c->d_order) {
+    (void)hipFree(c->d_order);
+    c->d_order = nullptr;
+  }
   if (!ok) return MDC_OK;
+  const std::vector<int> order = tile_order(tx, ty, c->opt_order);
   MDC_HIP(c, hipMalloc(&c->d_tiles, tiles.size() * sizeof(TileDesc)));
   MDC_HIP(c, hipMemcpy(c->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+  MDC_HIP(c, hipMalloc(&c->d_order, order.size() * sizeof(int)));
+  MDC_HIP(c, hipMemcpy(c->d_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+  c->n_blocks = (int)order.size();
   c->n_tiles = tx * ty;
   c->tiles_x = tx;
   c->tile_h = kTileH;
@@ -255,8 +299,8 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
   if (c->opt_kernel == MDC_KERNEL_TILED && !use_tiled)
     return fail(c, MDC_ERR_STATE, "tiled kernel requested but not plannable for this remap / alignment");
   if (use_tiled) {
-    TilePlan p{c->d_tiles, c->n_tiles, c->tiles_x, c->tile_h, c->win_bytes};
-    const int fpb = frames_per_block(c, nframes, (c->n_tiles + 7) & ~7);
+    TilePlan p{c->d_tiles, c->d_order, c->n_blocks, c->n_tiles, c->tiles_x, c->tile_h, c->win_bytes};
+    const int fpb = frames_per_block(c, nframes, c->n_blocks);
     MDC_HIP(c, launch_remap_tiled_u8(d_in, d_out, a, p, nframes, fpb, c->opt_lut_rep, c->opt_taps, s));
   } else {
     const int fpb = frames_per_block(c, nframes, (c->out_w * c->out_h + 255) / 256);
@@ -312,7 +356,7 @@ void mdc_destroy(mdc_ctx* c) {
   {
     DeviceGuard dg(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_tiles, c->d_stage_in, c->d_stage_out};
+    void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_tiles, c->d_order, c->d_stage_in, c->d_stage_out};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -338,6 +382,15 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
       if (value != 16 && value != 32) return fail(c, MDC_ERR_ARG, "tile rows must be 16 or 32");
       if (value == c->opt_tile_h) return MDC_OK;
       c->opt_tile_h = value;
+      if (!c->valid_remap) return MDC_OK;
+      DeviceGuard dg(c->device);
+      MDC_HIP(c, hipDeviceSynchronize());
+      return plan_tiles(c);
+    }
+    case MDC_OPT_TILE_ORDER: {
+      if (value < MDC_ORDER_BANDS || value > MDC_ORDER_IDENTITY) return fail(c, MDC_ERR_ARG, "bad tile order %d", value);
+      if (value == c->opt_order) return MDC_OK;
+      c->opt_order = value;
       if (!c->valid_remap) return MDC_OK;
       DeviceGuard dg(c->device);
       MDC_HIP(c, hipDeviceSynchronize());

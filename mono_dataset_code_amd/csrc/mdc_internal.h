@@ -32,6 +32,8 @@ struct RemapArgs {
 
 struct TilePlan {
   const TileDesc* d_tiles;
+  const int* d_order;  // block -> tile (or -1), n_blocks entries, n_blocks % 8 == 0: block b runs on XCD b % 8
+  int n_blocks;
   int n_tiles, tiles_x;
   int tile_h;     // 16 or 32 output rows per tile
   int win_bytes;  // LDS bytes of one staging buffer (max over tiles of rows*cpr*16)

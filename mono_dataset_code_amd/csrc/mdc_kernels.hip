@@ -37,6 +37,15 @@ constexpr int kLutBytes = 256 * kLutRep * 4;
 #ifndef MDC_EXP_BATCHED
 #define MDC_EXP_BATCHED 0   // issue all 16 tap reads, then all 16 LUT reads, then the arithmetic
 #endif
+#ifndef MDC_EXP_SKIP_STORE
+#define MDC_EXP_SKIP_STORE 0  // diagnosis: outputs are computed but (practically) never stored -> read side alone
+#endif
+#ifndef MDC_EXP_SKIP_LOAD
+#define MDC_EXP_SKIP_LOAD 0   // diagnosis: every frame re-stages frame 0 (L2 hits) -> write side alone
+#endif
+#ifndef MDC_EXP_PF2
+#define MDC_EXP_PF2 0         // staging loads run TWO frames ahead (second stage in registers)
+#endif
 #ifndef MDC_EXP_WAVES
 #define MDC_EXP_WAVES 5     // __launch_bounds__ min waves per SIMD of the 256-thread tiled kernel
 #endif
@@ -246,14 +255,15 @@ __global__ __launch_bounds__(256) void remap_gather_f32_kernel(const float* __re
 // the compute phase instead of waiting at a divergent merge.
 //
 // XCD placement: the dispatcher deals workgroups round-robin over the 8 XCDs
-// (block b -> XCD b%8).  Tiles are re-indexed so that each XCD owns a contiguous
-// band of tiles; neighbouring tiles share source-window halo rows, which then hit
-// in the same L2.  Speed only -- correctness does not depend on placement.
+// (block b -> XCD b%8).  The host hands over a table block -> tile (TilePlan::d_order)
+// built so that each XCD owns a contiguous band of tiles; neighbouring tiles share
+// source-window halo lines, which then hit in the same L2.  Speed only --
+// correctness does not depend on placement.
 // ----------------------------------------------------------------------------
 struct TileThread {  // per-thread, frame-invariant
   Bilin bl[4];
-  int off[4];    // LDS byte offset of tap (0,0) inside the window
-  int oidx[4];   // output index inside a frame
+  int off[4];         // LDS byte offset of tap (0,0) inside the window
+  uint32_t obyte[4];  // byte offset of the output inside a frame (unsigned: scalar base + 32-bit lane offset addressing)
   bool inside[4], black[4];
   float v00[4], v10[4], v01[4], v11[4];
 };
@@ -281,6 +291,9 @@ __device__ __forceinline__ T stream_load(const T* p) {
 }
 template <typename T>
 __device__ __forceinline__ void stream_store(T v, T* p) {
+#if MDC_EXP_SKIP_STORE
+  if (v != (T)-1.2345e30f) return;
+#endif
 #if MDC_EXP_STORE_NT
   __builtin_nontemporal_store(v, p);
 #else
@@ -338,7 +351,7 @@ __device__ __forceinline__ void tile_compute(const TileThread& t, const unsigned
     }
     float r = bilin_sum(t.bl[j], t00[j], t10[j], t01[j], t11[j]);
     if (t.black[j]) r = 0.f;
-    if (!EDGE || t.inside[j]) stream_store(r, dst + t.oidx[j]);
+    if (!EDGE || t.inside[j]) stream_store(r, reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + t.obyte[j]));
   }
 #else
 #pragma unroll
@@ -359,7 +372,7 @@ __device__ __forceinline__ void tile_compute(const TileThread& t, const unsigned
     }
     float r = bilin_sum(t.bl[j], t00, t10, t01, t11);
     if (t.black[j]) r = 0.f;
-    if (!EDGE || t.inside[j]) stream_store(r, dst + t.oidx[j]);
+    if (!EDGE || t.inside[j]) stream_store(r, reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + t.obyte[j]));
   }
 #endif
 }
@@ -370,12 +383,13 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
                                             int nch, const TileDesc& td, int in_w, unsigned char* s_win,
                                             int win_bytes, const float* my_lut, int tid) {
   const int pitch = td.cpr * 16;
-  int goff[R], loff[R];
+  uint32_t goff[R];
+  int loff[R];
 #pragma unroll
   for (int k = 0; k < R; k++) {
     const int c = min(tid + k * NT, nch - 1);
     const int r = c / td.cpr;
-    goff[k] = (td.y0 + r) * in_w + td.x0 + (c - r * td.cpr) * 16;
+    goff[k] = (uint32_t)((td.y0 + r) * in_w + td.x0 + (c - r * td.cpr) * 16);
     loff[k] = c * 16;
   }
   u32x4 stage[R];
@@ -386,7 +400,9 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
   __syncthreads();
   int cur = 0;
   for (int f = 0; f < nframes - 1; f++) {
+#if !MDC_EXP_SKIP_LOAD
     src += n_in;
+#endif
 #pragma unroll
     for (int k = 0; k < R; k++) stage[k] = stream_load(reinterpret_cast<const u32x4*>(src + goff[k]));
     tile_compute<VIG, LUTREP, EDGE, TAPS>(t, s_win + cur * win_bytes, pitch, my_lut, dst);
@@ -400,19 +416,84 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
   tile_compute<VIG, LUTREP, EDGE, TAPS>(t, s_win + cur * win_bytes, pitch, my_lut, dst);
 }
 
+// Same, with the staging loads running two frames ahead: the chunks of frame f+2 are requested
+// before frame f is computed, those of frame f+1 (requested one iteration earlier) are written to
+// the other LDS buffer afterwards.  Unrolled by two so the two register stages need no moves.
+template <bool VIG, int LUTREP, int R, bool EDGE, int TAPS, int NT>
+__device__ __forceinline__ void tile_frames_pf2(const TileThread& t, const uint8_t* __restrict__ src,
+                                                float* __restrict__ dst, long long n_in, long long n_out, int nframes,
+                                                int nch, const TileDesc& td, int in_w, unsigned char* s_win,
+                                                int win_bytes, const float* my_lut, int tid) {
+  const int pitch = td.cpr * 16;
+  uint32_t goff[R];
+  int loff[R];
+#pragma unroll
+  for (int k = 0; k < R; k++) {
+    const int c = min(tid + k * NT, nch - 1);
+    const int r = c / td.cpr;
+    goff[k] = (uint32_t)((td.y0 + r) * in_w + td.x0 + (c - r * td.cpr) * 16);
+    loff[k] = c * 16;
+  }
+  u32x4 sa[R], sb[R];
+  const int last = nframes - 1;
+#pragma unroll
+  for (int k = 0; k < R; k++) sa[k] = stream_load(reinterpret_cast<const u32x4*>(src + goff[k]));
+#pragma unroll
+  for (int k = 0; k < R; k++) *reinterpret_cast<u32x4*>(s_win + loff[k]) = sa[k];
+  {
+    const uint8_t* p1 = src + (long long)min(1, last) * n_in;
+#pragma unroll
+    for (int k = 0; k < R; k++) sa[k] = stream_load(reinterpret_cast<const u32x4*>(p1 + goff[k]));
+  }
+  __syncthreads();
+  unsigned char* w0 = s_win;
+  unsigned char* w1 = s_win + win_bytes;
+  int f = 0;
+  for (; f + 2 <= last; f += 2) {
+    {  // frame f from w0; request f+2 -> sb; land f+1 (sa) in w1
+      const uint8_t* p = src + (long long)(f + 2) * n_in;
+#pragma unroll
+      for (int k = 0; k < R; k++) sb[k] = stream_load(reinterpret_cast<const u32x4*>(p + goff[k]));
+      tile_compute<VIG, LUTREP, EDGE, TAPS>(t, w0, pitch, my_lut, dst);
+      dst += n_out;
+#pragma unroll
+      for (int k = 0; k < R; k++) *reinterpret_cast<u32x4*>(w1 + loff[k]) = sa[k];
+      __syncthreads();
+    }
+    {  // frame f+1 from w1; request f+3 -> sa; land f+2 (sb) in w0
+      const uint8_t* p = src + (long long)min(f + 3, last) * n_in;
+#pragma unroll
+      for (int k = 0; k < R; k++) sa[k] = stream_load(reinterpret_cast<const u32x4*>(p + goff[k]));
+      tile_compute<VIG, LUTREP, EDGE, TAPS>(t, w1, pitch, my_lut, dst);
+      dst += n_out;
+#pragma unroll
+      for (int k = 0; k < R; k++) *reinterpret_cast<u32x4*>(w0 + loff[k]) = sb[k];
+      __syncthreads();
+    }
+  }
+  // here: w0 holds frame f, sa holds frame min(f+1, last); f == last or f == last-1
+  tile_compute<VIG, LUTREP, EDGE, TAPS>(t, w0, pitch, my_lut, dst);
+  if (f < last) {
+    dst += n_out;
+#pragma unroll
+    for (int k = 0; k < R; k++) *reinterpret_cast<u32x4*>(w1 + loff[k]) = sa[k];
+    __syncthreads();
+    tile_compute<VIG, LUTREP, EDGE, TAPS>(t, w1, pitch, my_lut, dst);
+  }
+}
+
 template <bool VIG, int LUTREP, int TAPS, int NT>
 __global__ __launch_bounds__(NT, (NT == 512 ? MDC_EXP_WAVES_512 : MDC_EXP_WAVES)) void remap_tiled_u8_kernel(const uint8_t* __restrict__ in,
                                                                       float* __restrict__ out, RemapArgs a,
                                                                       const TileDesc* __restrict__ tiles,
-                                                                      int n_tiles, int tiles_x, int win_bytes,
-                                                                      int nframes, int fpb) {
+                                                                      const int* __restrict__ order, int tiles_x,
+                                                                      int win_bytes, int nframes, int fpb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_lut = reinterpret_cast<float*>(smem);
   unsigned char* s_win = smem + 256 * LUTREP * 4;
 
-  const int ntp = gridDim.x;  // padded to a multiple of 8
-  const int tile = (blockIdx.x & 7) * (ntp >> 3) + (blockIdx.x >> 3);
-  if (tile >= n_tiles) return;  // whole workgroup leaves before any barrier
+  const int tile = order[blockIdx.x];  // host-made placement table (plan_tiles); -1 = padding slot
+  if (tile < 0) return;                // whole workgroup leaves before any barrier
   const int f0 = blockIdx.y * fpb;
   const int nf = min(nframes, f0 + fpb) - f0;
   if (nf <= 0) return;
@@ -435,11 +516,12 @@ __global__ __launch_bounds__(NT, (NT == 512 ? MDC_EXP_WAVES_512 : MDC_EXP_WAVES)
   for (int j = 0; j < 4; j++) {
     const int oy = oy0 + j;
     t.inside[j] = (ox < a.out_w) && (oy < a.out_h);
-    t.oidx[j] = oy * a.out_w + ox;
+    const int oidx = oy * a.out_w + ox;
+    t.obyte[j] = (uint32_t)oidx * 4u;
     float xx = -1.f, yy = -1.f;
     if (t.inside[j]) {
-      xx = a.rx[t.oidx[j]];
-      yy = a.ry[t.oidx[j]];
+      xx = a.rx[oidx];
+      yy = a.ry[oidx];
     }
     t.black[j] = xx < 0;
     t.bl[j] = bilin_of(t.black[j] ? 0.f : xx, t.black[j] ? 0.f : yy);
@@ -463,13 +545,18 @@ __global__ __launch_bounds__(NT, (NT == 512 ? MDC_EXP_WAVES_512 : MDC_EXP_WAVES)
     for (int f = 0; f < nf; f++, dst += n_out)
 #pragma unroll
       for (int j = 0; j < 4; j++)
-        if (t.inside[j]) dst[t.oidx[j]] = 0.f;
+        if (t.inside[j]) *reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + t.obyte[j]) = 0.f;
     return;
   }
   const int rounds = (nch + NT - 1) / NT;  // workgroup-uniform
   const bool edge = ((tile % tiles_x) + 1) * kTileW > a.out_w || ((tile / tiles_x) + 1) * kTileRows > a.out_h;
+#if MDC_EXP_PF2
+#define MDC_TILE_FRAMES tile_frames_pf2
+#else
+#define MDC_TILE_FRAMES tile_frames
+#endif
 #define MDC_TILE_RUN(R_, E_) \
-  tile_frames<VIG, LUTREP, R_, E_, TAPS, NT>(t, src, dst, n_in, n_out, nf, nch, td, a.in_w, s_win, win_bytes, my_lut, tid)
+  MDC_TILE_FRAMES<VIG, LUTREP, R_, E_, TAPS, NT>(t, src, dst, n_in, n_out, nf, nch, td, a.in_w, s_win, win_bytes, my_lut, tid)
   if (!edge) {
     if (rounds == 1) MDC_TILE_RUN(1, false);
     else if (rounds == 2) MDC_TILE_RUN(2, false);
@@ -566,10 +653,9 @@ hipError_t launch_remap_gather_f32(const float* d_in, float* d_out, const RemapA
 template <bool VIG, int LUTREP, int TAPS, int NT>
 static hipError_t launch_tiled_variant(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
                                        int64_t nframes, int fpb, hipStream_t s) {
-  const int ntp = (p.n_tiles + 7) & ~7;
-  dim3 grid(ntp, ceil_div(nframes, fpb));
+  dim3 grid(p.n_blocks, ceil_div(nframes, fpb));
   const size_t lds = tiled_lds_bytes(p.win_bytes, LUTREP);
-  remap_tiled_u8_kernel<VIG, LUTREP, TAPS, NT><<<grid, NT, lds, s>>>(d_in, d_out, a, p.d_tiles, p.n_tiles, p.tiles_x,
+  remap_tiled_u8_kernel<VIG, LUTREP, TAPS, NT><<<grid, NT, lds, s>>>(d_in, d_out, a, p.d_tiles, p.d_order, p.tiles_x,
                                                                       p.win_bytes, (int)nframes, fpb);
   return hipGetLastError();
 }
