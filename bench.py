@@ -43,7 +43,6 @@ def parse():
     p.add_argument("--workload", default="fused", choices=["fused", "unmap", "pyramid"])
     p.add_argument("--kernel", default="auto", choices=["auto", "gather", "tiled"])
     p.add_argument("--fpb", type=int, default=0, help="frames per workgroup (0 = library default)")
-    p.add_argument("--lut-rep", type=int, default=0, help="LDS replicas of the response LUT (0 = library default)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return p.parse_args()
@@ -156,8 +155,6 @@ def main():
     ctx.import_tables(blob)  # every rank (rank 0 included) uploads the same bytes
     ctx.set_option(capi.OPT_KERNEL, {"auto": capi.KERNEL_AUTO, "gather": capi.KERNEL_GATHER, "tiled": capi.KERNEL_TILED}[args.kernel])
     ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, args.fpb)
-    if args.lut_rep:
-        ctx.set_option(capi.OPT_LUT_REPLICAS, args.lut_rep)
     info = ctx.info()
     out_w, out_h = (info.out_w, info.out_h) if args.workload != "unmap" else (IN_W, IN_H)
 

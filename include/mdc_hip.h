@@ -60,9 +60,8 @@ enum {
   MDC_KERNEL_GATHER = 1, /* direct global gather (always legal)                    */
   MDC_KERNEL_TILED = 2   /* LDS-staged source windows (fails if not plannable)     */
 };
-enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2, MDC_OPT_LUT_REPLICAS = 3 /* tuning: 16 or 32 */,
-       MDC_OPT_TAP_MODE = 4 /* tuning: LDS tap fetch 1 = 2 x u8, 2 = aligned dword pair */,
-       MDC_OPT_TILE_ROWS = 5 /* tuning: output tile 64x16 (256 threads) or 64x32 (512 threads) */,
+enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2 /* frames a workgroup loops over; 0 = automatic */,
+       MDC_OPT_TILE_ROWS = 5 /* tuning: output tile 64 x {16, 32, 60, 64} (256 / 512 / 960 / 1024 threads) */,
        MDC_OPT_TILE_ORDER = 6 /* tuning: placement of output tiles on the 8 XCDs, MDC_ORDER_* */ };
 enum { MDC_ORDER_BANDS = 0 /* row-major runs of tiles per XCD */, MDC_ORDER_ROWS = 1 /* whole tile rows per XCD */,
        MDC_ORDER_IDENTITY = 2 /* block b = tile b (diagnosis) */ };

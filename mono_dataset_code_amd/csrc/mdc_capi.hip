@@ -43,18 +43,18 @@ struct mdc_ctx {
 
   // tile plan
   bool tiled = false;
-  TileDesc* d_tiles = nullptr;
+  uint32_t* d_chunks = nullptr;  // tile plan, see TilePlan (mdc_internal.h)
+  int* d_nch = nullptr;
+  uint32_t* d_taps = nullptr;
   int* d_order = nullptr;  // block -> tile placement table (XCD bands)
   int n_blocks = 0;
-  int n_tiles = 0, tiles_x = 0, win_bytes = 0, tile_h = 0;
+  int n_tiles = 0, tiles_x = 0, chunk_cap = 0, tile_h = 0;
   int bbox[4] = {0, 0, -1, -1};
   int64_t staged_bytes = 0, n_black = 0;
 
   // options
   int opt_kernel = MDC_KERNEL_AUTO;
   int opt_fpb = 0;
-  int opt_lut_rep = 32;
-  int opt_taps = 1;
   int opt_tile_h = 32;
   int opt_order = MDC_ORDER_BANDS;
 
@@ -168,8 +168,24 @@ std::vector<int> tile_order(int tx, int ty, int mode) {
   return order;
 }
 
-// Source window of every output tile (see TileDesc).  Fails (tiled = false)
-// when rows of the frame are not whole 16-byte chunks or a window is too large.
+// Plan of the tiled kernel (see TilePlan): per tile the exact source window as a list of
+// 16-byte chunks, per output the LDS offsets of its two tap rows.  Fails (tiled = false)
+// when rows of the frame are not whole 16-byte chunks or a window is too large for LDS.
+void free_plan(mdc_ctx* c) {
+  for (void** p : {(void**)&c->d_chunks, (void**)&c->d_nch, (void**)&c->d_taps, (void**)&c->d_order})
+    if (*p) {
+      (void)hipFree(*p);
+      *p = nullptr;
+    }
+}
+
+template <typename T>
+int upload(mdc_ctx* c, T** dst, const std::vector<T>& v) {
+  MDC_HIP(c, hipMalloc(dst, std::max<size_t>(v.size(), 1) * sizeof(T)));
+  if (!v.empty()) MDC_HIP(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return MDC_OK;
+}
+
 int plan_tiles(mdc_ctx* c) {
   c->tiled = false;
   c->n_tiles = 0;
@@ -177,68 +193,87 @@ int plan_tiles(mdc_ctx* c) {
   c->n_black = 0;
   c->bbox[0] = c->bbox[1] = std::numeric_limits<int>::max();
   c->bbox[2] = c->bbox[3] = -1;
+  free_plan(c);
   const int ow = c->out_w, oh = c->out_h, iw = c->rm_in_w;
   const int kTileH = c->opt_tile_h, kTileThreads = 16 * kTileH;
   const int tx = (ow + kTileW - 1) / kTileW, ty = (oh + kTileH - 1) / kTileH;
-  std::vector<TileDesc> tiles((size_t)tx * ty);
+  const int n_tiles = tx * ty;
   bool ok = (iw % 16 == 0);
-  int win_max = 16;
-  for (int t = 0; t < tx * ty; t++) {
-    int x_lo = std::numeric_limits<int>::max(), y_lo = x_lo, x_hi = -1, y_hi = -1;
+  std::vector<std::vector<uint32_t>> chunks(n_tiles);
+  std::vector<int> nch(n_tiles, 0);
+  std::vector<uint32_t> taps((size_t)ow * oh, 0u);
+  struct Row {
+    int lo = std::numeric_limits<int>::max(), hi = -1, x0 = 0, lds = 0;
+  };
+  for (int t = 0; t < n_tiles && ok; t++) {
     const int bx = (t % tx) * kTileW, by = (t / tx) * kTileH;
-    for (int y = by; y < std::min(by + kTileH, oh); y++)
-      for (int x = bx; x < std::min(bx + kTileW, ow); x++) {
+    const int x1 = std::min(bx + kTileW, ow), y1 = std::min(by + kTileH, oh);
+    int y_lo = std::numeric_limits<int>::max(), y_hi = -1;
+    for (int y = by; y < y1; y++)
+      for (int x = bx; x < x1; x++) {
         const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
         if (xx < 0) {
           c->n_black++;
           continue;
         }
-        const int xi = (int)xx, yi = (int)yy;
-        x_lo = std::min(x_lo, xi);
-        x_hi = std::max(x_hi, xi + 1);
-        y_lo = std::min(y_lo, yi);
-        y_hi = std::max(y_hi, yi + 1);
+        y_lo = std::min(y_lo, (int)yy);
+        y_hi = std::max(y_hi, (int)yy + 1);
       }
-    TileDesc& d = tiles[t];
-    if (x_hi < 0) {
-      d = TileDesc{0, 0, 0, 1};
-      continue;
-    }
-    c->bbox[0] = std::min(c->bbox[0], x_lo);
+    if (y_hi < 0) continue;  // every output black: no window
+    std::vector<Row> rows(y_hi - y_lo + 1);
+    for (int y = by; y < y1; y++)
+      for (int x = bx; x < x1; x++) {
+        const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
+        if (xx < 0) continue;
+        const int xi = (int)xx, yi = (int)yy;
+        for (int dy = 0; dy < 2; dy++) {
+          Row& r = rows[yi + dy - y_lo];
+          r.lo = std::min(r.lo, xi);
+          r.hi = std::max(r.hi, xi + 1);
+        }
+        c->bbox[0] = std::min(c->bbox[0], xi);
+        c->bbox[2] = std::max(c->bbox[2], xi + 1);
+      }
     c->bbox[1] = std::min(c->bbox[1], y_lo);
-    c->bbox[2] = std::max(c->bbox[2], x_hi);
     c->bbox[3] = std::max(c->bbox[3], y_hi);
-    d.x0 = x_lo & ~15;
-    d.y0 = y_lo;
-    d.rows = y_hi - y_lo + 1;
-    d.cpr = (x_hi - d.x0) / 16 + 1;
-    const int nch = d.rows * d.cpr;
-    if (nch > kTileMaxChunks * kTileThreads) ok = false;
-    if (d.x0 + d.cpr * 16 > iw) ok = false;
-    win_max = std::max(win_max, nch * 16 + 16);  // +16: the aligned dword pair of the last tap may reach past the window
-    c->staged_bytes += (int64_t)nch * 16;
+    for (size_t k = 0; k < rows.size(); k++) {
+      Row& r = rows[k];
+      if (r.hi < 0) continue;  // no tap in this row (cannot happen between two used rows, harmless if it does)
+      r.x0 = r.lo & ~15;
+      r.lds = (int)chunks[t].size() * 16;
+      const int n = (r.hi - r.x0) / 16 + 1;
+      if (r.x0 + n * 16 > iw) ok = false;
+      for (int j = 0; j < n; j++) chunks[t].push_back((uint32_t)((y_lo + (int)k) * iw + r.x0 + j * 16));
+    }
+    nch[t] = (int)chunks[t].size();
+    if (nch[t] > kTileMaxChunks * kTileThreads || nch[t] * 16 > 65535) ok = false;
+    c->staged_bytes += (int64_t)nch[t] * 16;
+    for (int y = by; y < y1 && ok; y++)
+      for (int x = bx; x < x1; x++) {
+        const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
+        if (xx < 0) continue;
+        const int xi = (int)xx, yi = (int)yy;
+        const Row &r0 = rows[yi - y_lo], &r1 = rows[yi + 1 - y_lo];
+        taps[(size_t)y * ow + x] = (uint32_t)(r0.lds + xi - r0.x0) | ((uint32_t)(r1.lds + xi - r1.x0) << 16);
+      }
   }
   if (c->bbox[2] < 0) c->bbox[0] = c->bbox[1] = 0;
-  if (tiled_lds_bytes(win_max, kLutRep) > 64 * 1024) ok = false;
-  if (c->d_tiles) {
-    (void)hipFree(c->d_tiles);
-    c->d_tiles = nullptr;
-  }
-  if (c->d_order) {
-    (void)hipFree(c->d_order);
-    c->d_order = nullptr;
-  }
+  int cap = kTileThreads;
+  for (int t = 0; t < n_tiles; t++) cap = std::max(cap, (nch[t] + kTileThreads - 1) / kTileThreads * kTileThreads);
+  if (tiled_lds_bytes(cap) > kLdsPerCU) ok = false;
   if (!ok) return MDC_OK;
+  std::vector<uint32_t> flat((size_t)n_tiles * cap, kOutside);
+  for (int t = 0; t < n_tiles; t++) std::copy(chunks[t].begin(), chunks[t].end(), flat.begin() + (size_t)t * cap);
   const std::vector<int> order = tile_order(tx, ty, c->opt_order);
-  MDC_HIP(c, hipMalloc(&c->d_tiles, tiles.size() * sizeof(TileDesc)));
-  MDC_HIP(c, hipMemcpy(c->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
-  MDC_HIP(c, hipMalloc(&c->d_order, order.size() * sizeof(int)));
-  MDC_HIP(c, hipMemcpy(c->d_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+  int rc;
+  if ((rc = upload(c, &c->d_chunks, flat)) != MDC_OK || (rc = upload(c, &c->d_nch, nch)) != MDC_OK ||
+      (rc = upload(c, &c->d_taps, taps)) != MDC_OK || (rc = upload(c, &c->d_order, order)) != MDC_OK)
+    return rc;
   c->n_blocks = (int)order.size();
-  c->n_tiles = tx * ty;
+  c->n_tiles = n_tiles;
   c->tiles_x = tx;
   c->tile_h = kTileH;
-  c->win_bytes = win_max;
+  c->chunk_cap = cap;
   c->tiled = true;
   return MDC_OK;
 }
@@ -299,9 +334,10 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
   if (c->opt_kernel == MDC_KERNEL_TILED && !use_tiled)
     return fail(c, MDC_ERR_STATE, "tiled kernel requested but not plannable for this remap / alignment");
   if (use_tiled) {
-    TilePlan p{c->d_tiles, c->d_order, c->n_blocks, c->n_tiles, c->tiles_x, c->tile_h, c->win_bytes};
+    TilePlan p{c->d_chunks, c->d_nch, c->d_taps, c->d_order, c->n_blocks, c->n_tiles, c->tiles_x, c->tile_h, c->chunk_cap,
+               c->n_black > 0};
     const int fpb = frames_per_block(c, nframes, c->n_blocks);
-    MDC_HIP(c, launch_remap_tiled_u8(d_in, d_out, a, p, nframes, fpb, c->opt_lut_rep, c->opt_taps, s));
+    MDC_HIP(c, launch_remap_tiled_u8(d_in, d_out, a, p, nframes, fpb, s));
   } else {
     const int fpb = frames_per_block(c, nframes, (c->out_w * c->out_h + 255) / 256);
     MDC_HIP(c, launch_remap_gather_u8(d_in, d_out, a, nframes, fpb, s));
@@ -356,7 +392,8 @@ void mdc_destroy(mdc_ctx* c) {
   {
     DeviceGuard dg(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_tiles, c->d_order, c->d_stage_in, c->d_stage_out};
+    free_plan(c);
+    void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_stage_in, c->d_stage_out};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -379,7 +416,7 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
       c->opt_fpb = value;
       return MDC_OK;
     case MDC_OPT_TILE_ROWS: {
-      if (value != 16 && value != 32) return fail(c, MDC_ERR_ARG, "tile rows must be 16 or 32");
+      if (value != 16 && value != 32 && value != 60 && value != 64) return fail(c, MDC_ERR_ARG, "tile rows must be 16, 32, 60 or 64");
       if (value == c->opt_tile_h) return MDC_OK;
       c->opt_tile_h = value;
       if (!c->valid_remap) return MDC_OK;
@@ -396,14 +433,6 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
       MDC_HIP(c, hipDeviceSynchronize());
       return plan_tiles(c);
     }
-    case MDC_OPT_TAP_MODE:
-      if (value < 1 || value > 2) return fail(c, MDC_ERR_ARG, "tap mode must be 1 or 2");
-      c->opt_taps = value;
-      return MDC_OK;
-    case MDC_OPT_LUT_REPLICAS:
-      if (value != 16 && value != 32) return fail(c, MDC_ERR_ARG, "LUT replicas must be 16 or 32");
-      c->opt_lut_rep = value;
-      return MDC_OK;
   }
   return fail(c, MDC_ERR_ARG, "unknown option %d", option);
 }
@@ -424,7 +453,7 @@ int mdc_get_info(mdc_ctx* c, mdc_info* i) {
   i->tile_w = kTileW;
   i->tile_h = c->opt_tile_h;
   i->n_tiles = c->n_tiles;
-  i->lds_bytes = c->tiled ? (int)tiled_lds_bytes(c->win_bytes, c->opt_lut_rep) : 0;
+  i->lds_bytes = c->tiled ? (int)tiled_lds_bytes(c->chunk_cap) : 0;
   for (int k = 0; k < 4; k++) i->src_bbox[k] = c->bbox[k];
   i->src_bbox_bytes = c->bbox[2] >= 0 ? (int64_t)(c->bbox[2] - c->bbox[0] + 1) * (c->bbox[3] - c->bbox[1] + 1) : 0;
   i->src_staged_bytes = c->staged_bytes;

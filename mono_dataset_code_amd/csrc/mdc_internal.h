@@ -6,21 +6,13 @@
 
 namespace mdc {
 
-// Source window of one output tile of the LDS-tiled kernel.  The window is the
-// set of raw-frame bytes [y0, y0+rows) x [x0, x0 + 16*cpr): x0 is 16-byte
-// aligned so every row is a whole number of 16-byte chunks of the frame.
-struct TileDesc {
-  int x0, y0;  // top-left source pixel of the window
-  int rows;    // window height (0 = every output of the tile is black)
-  int cpr;     // 16-byte chunks per window row; LDS pitch = 16*cpr bytes
-};
-
 // Geometry of the tiled kernel: kTileW x tile_h outputs per workgroup, one lane per
 // output column, 4 output rows per thread  ->  16*tile_h threads
-// (tile_h = 16: 256 threads; tile_h = 32: 512 threads).
+// (tile_h = 16: 256 threads; 32: 512; 60: 960; 64: 1024).
 constexpr int kTileW = 64;
 constexpr int kTileMaxChunks = 3;  // 16-byte chunks a thread may stage per frame
 constexpr int kLutRep = 32;        // LDS replicas of the 256-entry response LUT (one per bank)
+constexpr uint32_t kOutside = 0xfffffff0u;  // buffer offset beyond any frame: the access is dropped by the range check
 
 struct RemapArgs {
   const float* lut;    // 256 floats: response LUT variant (identity or GInv; [255] = NaN when killing overexposed)
@@ -30,13 +22,21 @@ struct RemapArgs {
   int in_w, in_h, out_w, out_h;
 };
 
+// Plan of the tiled kernel for one remap (built on the host by plan_tiles, mdc_capi.hip).
+// The source window of an output tile is the exact set of raw-frame bytes its bilinear taps
+// touch, row by row: for every source row the run [x0, x0 + 16 n) of aligned 16-byte chunks
+// covering the taps of that row (x0 % 16 == 0).  Chunks are numbered row by row; chunk c is
+// staged at LDS byte 16 c of the window buffer.
 struct TilePlan {
-  const TileDesc* d_tiles;
-  const int* d_order;  // block -> tile (or -1), n_blocks entries, n_blocks % 8 == 0: block b runs on XCD b % 8
+  const uint32_t* d_chunks;  // [n_tiles][chunk_cap] byte offset of chunk c inside a frame, kOutside for c >= nch
+  const int* d_nch;          // [n_tiles] chunks of the tile's window (0 = every output black / outside)
+  const uint32_t* d_taps;    // [out_w*out_h] LDS byte offset of tap (xi,yi) | offset of tap (xi,yi+1) << 16
+  const int* d_order;        // block -> tile (or -1), n_blocks entries, n_blocks % 8 == 0: block b runs on XCD b % 8
   int n_blocks;
   int n_tiles, tiles_x;
-  int tile_h;     // 16 or 32 output rows per tile
-  int win_bytes;  // LDS bytes of one staging buffer (max over tiles of rows*cpr*16)
+  int tile_h;      // output rows per tile: 16, 32, 60 or 64
+  int chunk_cap;   // whole staging rounds: max over tiles of ceil(nch / threads) * threads
+  bool has_black;  // some output carries the (-1,-1) sentinel
 };
 
 // out[f][i] = lut[in[f][i]] (* vinv[i]) over nframes frames of npix pixels.
@@ -50,10 +50,10 @@ hipError_t launch_remap_gather_u8(const uint8_t* d_in, float* d_out, const Remap
 hipError_t launch_remap_gather_f32(const float* d_in, float* d_out, const RemapArgs& a, int64_t nframes, int fpb,
                                    hipStream_t s);
 // Fused LUT (* vignette) + bilinear remap, u8 frames, source windows staged in LDS.
-// lut_rep = LDS replicas of the response LUT (32 = conflict-free, 16/8 = smaller LDS footprint).
 hipError_t launch_remap_tiled_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
-                                 int64_t nframes, int fpb, int lut_rep, int taps, hipStream_t s);
-size_t tiled_lds_bytes(int win_bytes, int lut_rep);
+                                 int64_t nframes, int fpb, hipStream_t s);
+size_t tiled_lds_bytes(int chunk_cap);  // LUT replicas + two window buffers of chunk_cap chunks
+constexpr size_t kLdsPerCU = 160 * 1024;
 
 // One 2x2 box level: dst (w/2 x h/2) from src (w x h), nframes images each.
 hipError_t launch_pyramid_level(const float* d_src, float* d_dst, int w, int h, int64_t nframes, hipStream_t s);

@@ -34,23 +34,11 @@ constexpr int kLutBytes = 256 * kLutRep * 4;
 #ifndef MDC_EXP_STORE_NT
 #define MDC_EXP_STORE_NT 1  // output stores carry the nontemporal hint
 #endif
-#ifndef MDC_EXP_BATCHED
-#define MDC_EXP_BATCHED 0   // issue all 16 tap reads, then all 16 LUT reads, then the arithmetic
-#endif
 #ifndef MDC_EXP_SKIP_STORE
 #define MDC_EXP_SKIP_STORE 0  // diagnosis: outputs are computed but (practically) never stored -> read side alone
 #endif
 #ifndef MDC_EXP_SKIP_LOAD
 #define MDC_EXP_SKIP_LOAD 0   // diagnosis: every frame re-stages frame 0 (L2 hits) -> write side alone
-#endif
-#ifndef MDC_EXP_PF2
-#define MDC_EXP_PF2 0         // staging loads run TWO frames ahead (second stage in registers)
-#endif
-#ifndef MDC_EXP_WAVES
-#define MDC_EXP_WAVES 5     // __launch_bounds__ min waves per SIMD of the 256-thread tiled kernel
-#endif
-#ifndef MDC_EXP_WAVES_512
-#define MDC_EXP_WAVES_512 6 // same for the 512-thread (64x32 tile) kernel: 3 workgroups per CU
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -236,23 +224,29 @@ __global__ __launch_bounds__(256) void remap_gather_f32_kernel(const float* __re
 // ----------------------------------------------------------------------------
 // Tiled fused kernel (the headline path).
 //
-// Workgroup = one kTileW x kTileH output tile, looping over `fpb` frames.
+// Workgroup = one kTileW x (NT/16) output tile, looping over `fpb` frames.
 //   once per workgroup : remap -> LDS byte offset + 4 weights per output, the 4
 //                        vignette factors of its taps (registers), LUT replicas (LDS);
-//   once per frame     : the tile's source window of the raw u8 frame is copied
-//                        HBM -> registers -> LDS in 16-byte chunks (each window row
-//                        is a run of aligned 16-byte pieces: coalesced, every byte
-//                        of the frame fetched by the workgroup at most once);
+//   once per frame     : the tile's source window of the raw u8 frame goes HBM -> LDS
+//                        directly (buffer_load_dwordx4 ... lds, no VGPR staging, no
+//                        ds_write).  The window is the exact footprint of the tile's taps:
+//                        per source row the run of aligned 16-byte chunks that covers them
+//                        (TilePlan::d_chunks, made on the host); chunk c lands at LDS byte
+//                        16*c -- a wave's 64 chunks are 1 KiB contiguous in LDS, as the
+//                        LDS-DMA path needs; every byte is fetched by the workgroup once;
 //                        then per output 4 byte taps, 4 conflict-free LUT reads,
 //                        4 (+4) multiplies, 3 adds, one coalesced store.
 // Lane = output column, so the 32 lanes of an LDS access group read ~43
 // consecutive source bytes of one row: broadcast within a dword, distinct banks
-// across dwords.  Two LDS window buffers: the loads of frame f+1 are issued before
-// frame f is computed and land in the other buffer afterwards; one barrier per frame.
-// The staging loads are unconditional (chunk index clamped to the window, so a
-// surplus lane re-reads the last chunk) and the frame loop is instantiated per
-// number of staging rounds R: straight-line code keeps the loads in flight across
-// the compute phase instead of waiting at a divergent merge.
+// across dwords.  Two LDS window buffers: the DMA of frame f+1 is issued before
+// frame f is computed; `s_waitcnt vmcnt(#stores)` + one barrier per frame.
+//
+// Addressing.  Frames and outputs are reached through raw buffer descriptors
+// (scalar base, advanced per frame by scalar adds) + a frame-invariant 32-bit
+// lane offset: no per-access address arithmetic on the VALU.  The descriptors
+// cover exactly one frame, so the hardware range check drops the stores of
+// outputs outside the image (their offset is kOutside) and surplus lanes of the
+// last staging round read nothing.
 //
 // XCD placement: the dispatcher deals workgroups round-robin over the 8 XCDs
 // (block b -> XCD b%8).  The host hands over a table block -> tile (TilePlan::d_order)
@@ -260,110 +254,50 @@ __global__ __launch_bounds__(256) void remap_gather_f32_kernel(const float* __re
 // source-window halo lines, which then hit in the same L2.  Speed only --
 // correctness does not depend on placement.
 // ----------------------------------------------------------------------------
+typedef const __attribute__((address_space(3))) unsigned char* lds_u8_ptr;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+constexpr uint32_t kRsrcWord3 = 0x00020000u;  // gfx9 raw buffer: 32-bit data format, no swizzle
+#if MDC_EXP_STORE_NT
+constexpr int kStoreAux = 2;  // nt
+#else
+constexpr int kStoreAux = 0;
+#endif
+#if MDC_EXP_LOAD_NT
+constexpr int kLoadAux = 2;
+#else
+constexpr int kLoadAux = 0;
+#endif
+
+// (a macro, not a function: the descriptor type is only known to the device pass)
+#define MDC_FRAME_RSRC(base, bytes) \
+  __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(base)), 0, (int)(bytes), (int)kRsrcWord3)
+
 struct TileThread {  // per-thread, frame-invariant
   Bilin bl[4];
-  int off[4];         // LDS byte offset of tap (0,0) inside the window
-  uint32_t obyte[4];  // byte offset of the output inside a frame (unsigned: scalar base + 32-bit lane offset addressing)
-  bool inside[4], black[4];
+  int off0[4], off1[4];  // LDS byte offsets of taps (xi,yi) and (xi,yi+1) inside the window
+  uint32_t obyte[4];     // byte offset of the output inside a frame, kOutside if not in the image
+  bool black[4];
   float v00[4], v10[4], v01[4], v11[4];
 };
 
-// EDGE = the tile sticks out of the output image: stores are predicated per output.
-// Interior tiles store unconditionally, which keeps the store count of a frame
-// known at compile time (exact s_waitcnt vmcnt(N) for the prefetched loads that
-// were issued before them -- vmcnt retires in order on gfx9).
-// TAPS selects how the two horizontally adjacent byte taps of a row are fetched from LDS:
-//   0  two byte loads as written (hipcc fuses them into one ds_read_u16 at an arbitrary,
-//      often odd, address)
-//   1  two separate ds_read_u8
-//   2  the two aligned dwords around the pair (ds_read2_b32) + v_alignbyte
-typedef const __attribute__((address_space(3))) unsigned char* lds_u8_ptr;
-typedef const volatile __attribute__((address_space(3))) unsigned char* lds_vu8_ptr;
-typedef const __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
-
-template <typename T>
-__device__ __forceinline__ T stream_load(const T* p) {
-#if MDC_EXP_LOAD_NT
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-}
-template <typename T>
-__device__ __forceinline__ void stream_store(T v, T* p) {
-#if MDC_EXP_SKIP_STORE
-  if (v != (T)-1.2345e30f) return;
-#endif
-#if MDC_EXP_STORE_NT
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
-
-template <int TAPS>
-__device__ __forceinline__ void tap_pair(const unsigned char* p, int& a, int& b) {
-  if (TAPS == 0) {
-    lds_u8_ptr q = (lds_u8_ptr)p;
-    a = q[0];
-    b = q[1];
-  } else if (TAPS == 1) {
-    lds_vu8_ptr q = (lds_vu8_ptr)p;
-    a = q[0];
-    b = q[1];
-  } else {
-    lds_u8_ptr q8 = (lds_u8_ptr)p;
-    const uint32_t addr = (uint32_t)(uintptr_t)q8;  // LDS byte address (32-bit in address space 3)
-    lds_u32_ptr q = (lds_u32_ptr)(uintptr_t)(addr & ~3u);
-    const uint32_t lo = q[0], hi = q[1];
-    const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, addr & 3u);
-    a = w & 255u;
-    b = (w >> 8) & 255u;
-  }
-}
-
-template <bool VIG, int LUTREP, bool EDGE, int TAPS>
-__device__ __forceinline__ void tile_compute(const TileThread& t, const unsigned char* __restrict__ w, int pitch,
-                                             const float* __restrict__ my_lut, float* __restrict__ dst) {
-#if MDC_EXP_BATCHED
-  int b00[4], b10[4], b01[4], b11[4];
+template <bool VIG, bool BLACK>
+__device__ __forceinline__ void tile_compute(const TileThread& t, const unsigned char* __restrict__ w,
+                                             const float* __restrict__ my_lut, float* dst, uint32_t out_bytes) {
+#if __HIP_DEVICE_COMPILE__  // buffer / LDS-DMA builtins exist in the device pass only
+  const auto ro = MDC_FRAME_RSRC(dst, out_bytes);
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const unsigned char* p = w + t.off[j];
-    tap_pair<TAPS>(p, b00[j], b10[j]);
-    tap_pair<TAPS>(p + pitch, b01[j], b11[j]);
-  }
-  float t00[4], t10[4], t01[4], t11[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    t00[j] = my_lut[b00[j] * LUTREP];
-    t10[j] = my_lut[b10[j] * LUTREP];
-    t01[j] = my_lut[b01[j] * LUTREP];
-    t11[j] = my_lut[b11[j] * LUTREP];
-  }
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    if (VIG) {
-      t00[j] = t00[j] * t.v00[j];
-      t10[j] = t10[j] * t.v10[j];
-      t01[j] = t01[j] * t.v01[j];
-      t11[j] = t11[j] * t.v11[j];
-    }
-    float r = bilin_sum(t.bl[j], t00[j], t10[j], t01[j], t11[j]);
-    if (t.black[j]) r = 0.f;
-    if (!EDGE || t.inside[j]) stream_store(r, reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + t.obyte[j]));
-  }
-#else
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const unsigned char* p = w + t.off[j];
-    int b00, b10, b01, b11;
-    tap_pair<TAPS>(p, b00, b10);
-    tap_pair<TAPS>(p + pitch, b01, b11);
-    float t00 = my_lut[b00 * LUTREP];
-    float t10 = my_lut[b10 * LUTREP];
-    float t01 = my_lut[b01 * LUTREP];
-    float t11 = my_lut[b11 * LUTREP];
+    // explicit byte loads: two adjacent byte loads fused into one ds_read_u16 at an odd
+    // address are replayed by the LDS (SQ_LDS_UNALIGNED_STALL), hence volatile
+    typedef const volatile __attribute__((address_space(3))) unsigned char* tap_ptr;
+    tap_ptr p = (tap_ptr)(w + t.off0[j]);
+    tap_ptr q = (tap_ptr)(w + t.off1[j]);
+    const int b00 = p[0], b10 = p[1], b01 = q[0], b11 = q[1];
+    float t00 = my_lut[b00 * kLutRep];
+    float t10 = my_lut[b10 * kLutRep];
+    float t01 = my_lut[b01 * kLutRep];
+    float t11 = my_lut[b11 * kLutRep];
     if (VIG) {
       t00 = t00 * t.v00[j];
       t10 = t10 * t.v10[j];
@@ -371,129 +305,67 @@ __device__ __forceinline__ void tile_compute(const TileThread& t, const unsigned
       t11 = t11 * t.v11[j];
     }
     float r = bilin_sum(t.bl[j], t00, t10, t01, t11);
-    if (t.black[j]) r = 0.f;
-    if (!EDGE || t.inside[j]) stream_store(r, reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + t.obyte[j]));
+    if (BLACK && t.black[j]) r = 0.f;
+#if MDC_EXP_SKIP_STORE
+    if (r != -1.2345e30f) continue;
+#endif
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, t.obyte[j], 0, kStoreAux);
   }
 #endif
 }
 
-template <bool VIG, int LUTREP, int R, bool EDGE, int TAPS, int NT>
+// One staging pass: the window of the frame at `ri` -> LDS buffer `win`.  R = rounds of NT chunks.
+template <int R, int NT>
+__device__ __forceinline__ void stage_window(const uint8_t* src, uint32_t in_bytes, unsigned char* win,
+                                             const uint32_t (&goff)[R], int wave) {
+#if __HIP_DEVICE_COMPILE__
+  const auto ri = MDC_FRAME_RSRC(src, in_bytes);
+#pragma unroll
+  for (int k = 0; k < R; k++)  // lanes past the window carry kOutside: nothing is fetched, zeros land in LDS
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (lds_void_ptr)(win + (k * NT + wave * 64) * 16), 16, goff[k], 0, 0,
+                                             kLoadAux);
+#endif
+}
+
+template <bool VIG, bool BLACK, int R, int NT>
 __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* __restrict__ src,
-                                            float* __restrict__ dst, long long n_in, long long n_out, int nframes,
-                                            int nch, const TileDesc& td, int in_w, unsigned char* s_win,
+                                            float* __restrict__ dst, uint32_t in_bytes, uint32_t out_bytes,
+                                            int nframes, const uint32_t* __restrict__ chunks, unsigned char* s_win,
                                             int win_bytes, const float* my_lut, int tid) {
-  const int pitch = td.cpr * 16;
   uint32_t goff[R];
-  int loff[R];
 #pragma unroll
-  for (int k = 0; k < R; k++) {
-    const int c = min(tid + k * NT, nch - 1);
-    const int r = c / td.cpr;
-    goff[k] = (uint32_t)((td.y0 + r) * in_w + td.x0 + (c - r * td.cpr) * 16);
-    loff[k] = c * 16;
-  }
-  u32x4 stage[R];
-#pragma unroll
-  for (int k = 0; k < R; k++) stage[k] = stream_load(reinterpret_cast<const u32x4*>(src + goff[k]));
-#pragma unroll
-  for (int k = 0; k < R; k++) *reinterpret_cast<u32x4*>(s_win + loff[k]) = stage[k];
-  __syncthreads();
-  int cur = 0;
-  for (int f = 0; f < nframes - 1; f++) {
-#if !MDC_EXP_SKIP_LOAD
-    src += n_in;
-#endif
-#pragma unroll
-    for (int k = 0; k < R; k++) stage[k] = stream_load(reinterpret_cast<const u32x4*>(src + goff[k]));
-    tile_compute<VIG, LUTREP, EDGE, TAPS>(t, s_win + cur * win_bytes, pitch, my_lut, dst);
-    dst += n_out;
-    unsigned char* wn = s_win + (cur ^ 1) * win_bytes;
-#pragma unroll
-    for (int k = 0; k < R; k++) *reinterpret_cast<u32x4*>(wn + loff[k]) = stage[k];
-    __syncthreads();
-    cur ^= 1;
-  }
-  tile_compute<VIG, LUTREP, EDGE, TAPS>(t, s_win + cur * win_bytes, pitch, my_lut, dst);
-}
-
-// Same, with the staging loads running two frames ahead: the chunks of frame f+2 are requested
-// before frame f is computed, those of frame f+1 (requested one iteration earlier) are written to
-// the other LDS buffer afterwards.  Unrolled by two so the two register stages need no moves.
-template <bool VIG, int LUTREP, int R, bool EDGE, int TAPS, int NT>
-__device__ __forceinline__ void tile_frames_pf2(const TileThread& t, const uint8_t* __restrict__ src,
-                                                float* __restrict__ dst, long long n_in, long long n_out, int nframes,
-                                                int nch, const TileDesc& td, int in_w, unsigned char* s_win,
-                                                int win_bytes, const float* my_lut, int tid) {
-  const int pitch = td.cpr * 16;
-  uint32_t goff[R];
-  int loff[R];
-#pragma unroll
-  for (int k = 0; k < R; k++) {
-    const int c = min(tid + k * NT, nch - 1);
-    const int r = c / td.cpr;
-    goff[k] = (uint32_t)((td.y0 + r) * in_w + td.x0 + (c - r * td.cpr) * 16);
-    loff[k] = c * 16;
-  }
-  u32x4 sa[R], sb[R];
-  const int last = nframes - 1;
-#pragma unroll
-  for (int k = 0; k < R; k++) sa[k] = stream_load(reinterpret_cast<const u32x4*>(src + goff[k]));
-#pragma unroll
-  for (int k = 0; k < R; k++) *reinterpret_cast<u32x4*>(s_win + loff[k]) = sa[k];
-  {
-    const uint8_t* p1 = src + (long long)min(1, last) * n_in;
-#pragma unroll
-    for (int k = 0; k < R; k++) sa[k] = stream_load(reinterpret_cast<const u32x4*>(p1 + goff[k]));
-  }
-  __syncthreads();
+  for (int k = 0; k < R; k++) goff[k] = chunks[tid + k * NT];  // kOutside past the window
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned char* w0 = s_win;
   unsigned char* w1 = s_win + win_bytes;
-  int f = 0;
-  for (; f + 2 <= last; f += 2) {
-    {  // frame f from w0; request f+2 -> sb; land f+1 (sa) in w1
-      const uint8_t* p = src + (long long)(f + 2) * n_in;
-#pragma unroll
-      for (int k = 0; k < R; k++) sb[k] = stream_load(reinterpret_cast<const u32x4*>(p + goff[k]));
-      tile_compute<VIG, LUTREP, EDGE, TAPS>(t, w0, pitch, my_lut, dst);
-      dst += n_out;
-#pragma unroll
-      for (int k = 0; k < R; k++) *reinterpret_cast<u32x4*>(w1 + loff[k]) = sa[k];
-      __syncthreads();
-    }
-    {  // frame f+1 from w1; request f+3 -> sa; land f+2 (sb) in w0
-      const uint8_t* p = src + (long long)min(f + 3, last) * n_in;
-#pragma unroll
-      for (int k = 0; k < R; k++) sa[k] = stream_load(reinterpret_cast<const u32x4*>(p + goff[k]));
-      tile_compute<VIG, LUTREP, EDGE, TAPS>(t, w1, pitch, my_lut, dst);
-      dst += n_out;
-#pragma unroll
-      for (int k = 0; k < R; k++) *reinterpret_cast<u32x4*>(w0 + loff[k]) = sb[k];
-      __syncthreads();
-    }
+  stage_window<R, NT>(src, in_bytes, w0, goff, wave);
+  __syncthreads();
+  for (int f = 0; f < nframes - 1; f++) {
+#if !MDC_EXP_SKIP_LOAD
+    src += in_bytes;
+#endif
+    stage_window<R, NT>(src, in_bytes, w1, goff, wave);
+    tile_compute<VIG, BLACK>(t, w0, my_lut, dst, out_bytes);
+    dst += out_bytes / 4;
+    __syncthreads();  // DMA of frame f+1 landed (vmcnt) and every wave is done reading w0
+    unsigned char* x = w0;
+    w0 = w1;
+    w1 = x;
   }
-  // here: w0 holds frame f, sa holds frame min(f+1, last); f == last or f == last-1
-  tile_compute<VIG, LUTREP, EDGE, TAPS>(t, w0, pitch, my_lut, dst);
-  if (f < last) {
-    dst += n_out;
-#pragma unroll
-    for (int k = 0; k < R; k++) *reinterpret_cast<u32x4*>(w1 + loff[k]) = sa[k];
-    __syncthreads();
-    tile_compute<VIG, LUTREP, EDGE, TAPS>(t, w1, pitch, my_lut, dst);
-  }
+  tile_compute<VIG, BLACK>(t, w0, my_lut, dst, out_bytes);
 }
 
-template <bool VIG, int LUTREP, int TAPS, int NT>
-__global__ __launch_bounds__(NT, (NT == 512 ? MDC_EXP_WAVES_512 : MDC_EXP_WAVES)) void remap_tiled_u8_kernel(const uint8_t* __restrict__ in,
-                                                                      float* __restrict__ out, RemapArgs a,
-                                                                      const TileDesc* __restrict__ tiles,
-                                                                      const int* __restrict__ order, int tiles_x,
-                                                                      int win_bytes, int nframes, int fpb) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// Occupancy is set by LDS (LUT replicas + two window buffers): 3 workgroups of 512 threads or 2 of
+// 960/1024 per CU; the register budget follows from that.
+template <bool VIG, bool BLACK, int NT>
+__global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap_tiled_u8_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,
+                                                            RemapArgs a, TilePlan p, int nframes, int fpb) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   float* s_lut = reinterpret_cast<float*>(smem);
-  unsigned char* s_win = smem + 256 * LUTREP * 4;
+  unsigned char* s_win = smem + kLutBytes;
 
-  const int tile = order[blockIdx.x];  // host-made placement table (plan_tiles); -1 = padding slot
-  if (tile < 0) return;                // whole workgroup leaves before any barrier
+  const int tile = p.d_order[blockIdx.x];  // host-made placement table (plan_tiles); -1 = padding slot
+  if (tile < 0) return;                    // whole workgroup leaves before any barrier
   const int f0 = blockIdx.y * fpb;
   const int nf = min(nframes, f0 + fpb) - f0;
   if (nf <= 0) return;
@@ -501,31 +373,35 @@ __global__ __launch_bounds__(NT, (NT == 512 ? MDC_EXP_WAVES_512 : MDC_EXP_WAVES)
   const int tid = threadIdx.x;
   const int lane_x = tid % kTileW;
   const int row0 = (tid / kTileW) * 4;
-  const TileDesc td = tiles[tile];
-  const int pitch = td.cpr * 16;
-  const int ox = (tile % tiles_x) * kTileW + lane_x;
+  const int ox = (tile % p.tiles_x) * kTileW + lane_x;
   constexpr int kTileRows = NT / 16;  // 4 output rows per thread, kTileW lanes per row
-  const int oy0 = (tile / tiles_x) * kTileRows + row0;
+  const int oy0 = (tile / p.tiles_x) * kTileRows + row0;
 
-#pragma unroll 4
-  for (int i = tid; i < 256 * LUTREP; i += NT) s_lut[i] = a.lut[i / LUTREP];
-  const float* my_lut = s_lut + (tid & (LUTREP - 1));
+  // LUT replicas: entry e occupies words [32e, 32e+32) -- eight 16-byte stores of (v,v,v,v)
+  for (int i = tid; i < 256 * (kLutRep / 4); i += NT) {
+    const float v = a.lut[i / (kLutRep / 4)];
+    reinterpret_cast<f32x4*>(s_lut)[i] = f32x4{v, v, v, v};
+  }
+  const float* my_lut = s_lut + (tid & (kLutRep - 1));
 
   TileThread t;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int oy = oy0 + j;
-    t.inside[j] = (ox < a.out_w) && (oy < a.out_h);
+    const bool inside = (ox < a.out_w) && (oy < a.out_h);
     const int oidx = oy * a.out_w + ox;
-    t.obyte[j] = (uint32_t)oidx * 4u;
+    t.obyte[j] = inside ? (uint32_t)oidx * 4u : kOutside;
     float xx = -1.f, yy = -1.f;
-    if (t.inside[j]) {
+    uint32_t tp = 0;
+    if (inside) {
       xx = a.rx[oidx];
       yy = a.ry[oidx];
+      tp = p.d_taps[oidx];
     }
-    t.black[j] = xx < 0;
+    t.black[j] = xx < 0;  // outputs outside the image count as black: their taps read window byte 0, their store is dropped
     t.bl[j] = bilin_of(t.black[j] ? 0.f : xx, t.black[j] ? 0.f : yy);
-    t.off[j] = t.black[j] ? 0 : (t.bl[j].yi - td.y0) * pitch + (t.bl[j].xi - td.x0);
+    t.off0[j] = (int)(tp & 0xffffu);
+    t.off1[j] = (int)(tp >> 16);
     t.v00[j] = t.v10[j] = t.v01[j] = t.v11[j] = 1.f;
     if (VIG && !t.black[j]) {
       const int s = t.bl[j].xi + t.bl[j].yi * a.in_w;
@@ -536,36 +412,29 @@ __global__ __launch_bounds__(NT, (NT == 512 ? MDC_EXP_WAVES_512 : MDC_EXP_WAVES)
     }
   }
 
-  const long long n_in = (long long)a.in_w * a.in_h;
-  const long long n_out = (long long)a.out_w * a.out_h;
-  const uint8_t* src = in + (long long)f0 * n_in;
-  float* dst = out + (long long)f0 * n_out;
-  const int nch = td.rows * td.cpr;
+  const uint32_t in_bytes = (uint32_t)a.in_w * (uint32_t)a.in_h;
+  const uint32_t out_bytes = (uint32_t)a.out_w * (uint32_t)a.out_h * 4u;
+  const uint8_t* src = in + (long long)f0 * in_bytes;
+  float* dst = out + (long long)f0 * (out_bytes / 4);
+  const int nch = p.d_nch[tile];
   if (nch == 0) {  // every output of the tile is black (or outside): zeros, no staging
-    for (int f = 0; f < nf; f++, dst += n_out)
+#if __HIP_DEVICE_COMPILE__
+    for (int f = 0; f < nf; f++, dst += out_bytes / 4) {
+      const auto ro = MDC_FRAME_RSRC(dst, out_bytes);
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (t.inside[j]) *reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + t.obyte[j]) = 0.f;
+      for (int j = 0; j < 4; j++) __builtin_amdgcn_raw_buffer_store_b32(0u, ro, t.obyte[j], 0, 0);
+    }
+#endif
     return;
   }
   const int rounds = (nch + NT - 1) / NT;  // workgroup-uniform
-  const bool edge = ((tile % tiles_x) + 1) * kTileW > a.out_w || ((tile / tiles_x) + 1) * kTileRows > a.out_h;
-#if MDC_EXP_PF2
-#define MDC_TILE_FRAMES tile_frames_pf2
-#else
-#define MDC_TILE_FRAMES tile_frames
-#endif
-#define MDC_TILE_RUN(R_, E_) \
-  MDC_TILE_FRAMES<VIG, LUTREP, R_, E_, TAPS, NT>(t, src, dst, n_in, n_out, nf, nch, td, a.in_w, s_win, win_bytes, my_lut, tid)
-  if (!edge) {
-    if (rounds == 1) MDC_TILE_RUN(1, false);
-    else if (rounds == 2) MDC_TILE_RUN(2, false);
-    else MDC_TILE_RUN(kTileMaxChunks, false);
-  } else {
-    if (rounds == 1) MDC_TILE_RUN(1, true);
-    else if (rounds == 2) MDC_TILE_RUN(2, true);
-    else MDC_TILE_RUN(kTileMaxChunks, true);
-  }
+  const uint32_t* chunks = p.d_chunks + (size_t)tile * p.chunk_cap;
+  const int win_bytes = p.chunk_cap * 16;
+#define MDC_TILE_RUN(R_) \
+  tile_frames<VIG, BLACK, R_, NT>(t, src, dst, in_bytes, out_bytes, nf, chunks, s_win, win_bytes, my_lut, tid)
+  if (rounds == 1) MDC_TILE_RUN(1);
+  else if (rounds == 2) MDC_TILE_RUN(2);
+  else MDC_TILE_RUN(kTileMaxChunks);
 #undef MDC_TILE_RUN
 }
 
@@ -612,7 +481,7 @@ inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace
 
-size_t tiled_lds_bytes(int win_bytes, int lut_rep) { return (size_t)256 * lut_rep * 4 + 2 * (size_t)win_bytes; }
+size_t tiled_lds_bytes(int chunk_cap) { return (size_t)kLutBytes + 2 * (size_t)chunk_cap * 16; }
 
 hipError_t launch_unmap(const uint8_t* d_in, float* d_out, const float* d_lut, const float* d_vinv, int64_t npix,
                         int64_t nframes, int fpb, hipStream_t s) {
@@ -650,38 +519,43 @@ hipError_t launch_remap_gather_f32(const float* d_in, float* d_out, const RemapA
   return hipGetLastError();
 }
 
-template <bool VIG, int LUTREP, int TAPS, int NT>
+template <bool VIG, bool BLACK, int NT>
 static hipError_t launch_tiled_variant(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
                                        int64_t nframes, int fpb, hipStream_t s) {
   dim3 grid(p.n_blocks, ceil_div(nframes, fpb));
-  const size_t lds = tiled_lds_bytes(p.win_bytes, LUTREP);
-  remap_tiled_u8_kernel<VIG, LUTREP, TAPS, NT><<<grid, NT, lds, s>>>(d_in, d_out, a, p.d_tiles, p.d_order, p.tiles_x,
-                                                                      p.win_bytes, (int)nframes, fpb);
+  const size_t lds = tiled_lds_bytes(p.chunk_cap);
+  if (lds > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in (64x60 / 64x64 tiles)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&remap_tiled_u8_kernel<VIG, BLACK, NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  remap_tiled_u8_kernel<VIG, BLACK, NT><<<grid, NT, lds, s>>>(d_in, d_out, a, p, (int)nframes, fpb);
   return hipGetLastError();
 }
 
-template <bool VIG, int LUTREP, int TAPS>
+template <bool VIG, bool BLACK>
 static hipError_t launch_tiled_nt(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
                                   int64_t nframes, int fpb, hipStream_t s) {
-  return p.tile_h == 32 ? launch_tiled_variant<VIG, LUTREP, TAPS, 512>(d_in, d_out, a, p, nframes, fpb, s)
-                        : launch_tiled_variant<VIG, LUTREP, TAPS, 256>(d_in, d_out, a, p, nframes, fpb, s);
-}
-
-template <bool VIG>
-static hipError_t launch_tiled_vig(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
-                                   int64_t nframes, int fpb, int lut_rep, int taps, hipStream_t s) {
-  if (lut_rep == 16)
-    return taps == 2 ? launch_tiled_nt<VIG, 16, 2>(d_in, d_out, a, p, nframes, fpb, s)
-                     : launch_tiled_nt<VIG, 16, 1>(d_in, d_out, a, p, nframes, fpb, s);
-  return taps == 2 ? launch_tiled_nt<VIG, 32, 2>(d_in, d_out, a, p, nframes, fpb, s)
-                   : launch_tiled_nt<VIG, 32, 1>(d_in, d_out, a, p, nframes, fpb, s);
+  switch (p.tile_h) {
+    case 16: return launch_tiled_variant<VIG, BLACK, 256>(d_in, d_out, a, p, nframes, fpb, s);
+    case 32: return launch_tiled_variant<VIG, BLACK, 512>(d_in, d_out, a, p, nframes, fpb, s);
+    case 60: return launch_tiled_variant<VIG, BLACK, 960>(d_in, d_out, a, p, nframes, fpb, s);
+    case 64: return launch_tiled_variant<VIG, BLACK, 1024>(d_in, d_out, a, p, nframes, fpb, s);
+  }
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_remap_tiled_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
-                                 int64_t nframes, int fpb, int lut_rep, int taps, hipStream_t s) {
+                                 int64_t nframes, int fpb, hipStream_t s) {
   if (nframes <= 0) return hipSuccess;
-  return a.vinv ? launch_tiled_vig<true>(d_in, d_out, a, p, nframes, fpb, lut_rep, taps, s)
-                : launch_tiled_vig<false>(d_in, d_out, a, p, nframes, fpb, lut_rep, taps, s);
+  // frames are addressed through 32-bit buffer offsets
+  if ((int64_t)a.in_w * a.in_h >= (int64_t)kOutside || (int64_t)a.out_w * a.out_h * 4 >= (int64_t)kOutside)
+    return hipErrorInvalidValue;
+  if (a.vinv)
+    return p.has_black ? launch_tiled_nt<true, true>(d_in, d_out, a, p, nframes, fpb, s)
+                       : launch_tiled_nt<true, false>(d_in, d_out, a, p, nframes, fpb, s);
+  return p.has_black ? launch_tiled_nt<false, true>(d_in, d_out, a, p, nframes, fpb, s)
+                     : launch_tiled_nt<false, false>(d_in, d_out, a, p, nframes, fpb, s);
 }
 
 hipError_t launch_pyramid_level(const float* d_src, float* d_dst, int w, int h, int64_t nframes, hipStream_t s) {

@@ -96,24 +96,20 @@ def test_tiled_and_gather_kernels_agree(name, setups, oracle, torch_cuda):
         assert info.tiled, "tiled kernel should be plannable for %s" % name
     for k in kernels:
         s.ctx.set_option(capi.OPT_KERNEL, k)
-        for taps, rep, rows, order in (((2, 32, 32, capi.ORDER_BANDS), (1, 16, 16, capi.ORDER_ROWS), (1, 32, 32, capi.ORDER_IDENTITY),
-                                        (2, 16, 16, capi.ORDER_BANDS), (1, 32, 32, capi.ORDER_ROWS))
-                                       if k == capi.KERNEL_TILED else ((1, 32, 32, capi.ORDER_BANDS),)):
+        for rows, order in (((32, capi.ORDER_BANDS), (16, capi.ORDER_ROWS), (32, capi.ORDER_IDENTITY), (60, capi.ORDER_BANDS),
+                             (64, capi.ORDER_ROWS), (16, capi.ORDER_BANDS), (32, capi.ORDER_ROWS))
+                            if k == capi.KERNEL_TILED else ((32, capi.ORDER_BANDS),)):
           s.ctx.set_option(capi.OPT_TILE_ROWS, rows)
           s.ctx.set_option(capi.OPT_TILE_ORDER, order)
           if k == capi.KERNEL_TILED and not s.ctx.info().tiled:
               continue
-          s.ctx.set_option(capi.OPT_TAP_MODE, taps)
-          s.ctx.set_option(capi.OPT_LUT_REPLICAS, rep)
           for n, fpb in ((1, 0), (3, 2), (17, 0), (17, 5)):
             s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, fpb)
             d_out = torch.full((n, s.w * s.h), -7.0, dtype=torch.float32, device="cuda")
             s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, flags, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-            assert bits_equal(d_out.cpu().numpy(), want[:n]), (name, k, taps, rep, rows, order, n, fpb)
+            assert bits_equal(d_out.cpu().numpy(), want[:n]), (name, k, rows, order, n, fpb)
     s.ctx.set_option(capi.OPT_TILE_ORDER, capi.ORDER_BANDS)
-    s.ctx.set_option(capi.OPT_TAP_MODE, 1)
-    s.ctx.set_option(capi.OPT_LUT_REPLICAS, 32)
     s.ctx.set_option(capi.OPT_TILE_ROWS, 32)
     s.ctx.set_option(capi.OPT_KERNEL, capi.KERNEL_AUTO)
     s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, 0)

@@ -4,7 +4,7 @@
 Variants are interleaved over several rounds in ONE process (cross-process noise
 looks like a kernel property otherwise); reports median and min ms per launch and
 the implied algorithmic GB/s.  Usage:
-  python tools/sweep.py --frames 1024 --rounds 5 --fpb 0,16,32,64 --lut-rep 32,16,8 --kernel tiled,gather
+  python tools/sweep.py --frames 1024 --rounds 5 --fpb 0,16,32,64 --rows 32,60 --order 0,1 --kernel tiled,gather
 """
 import argparse
 import itertools
@@ -29,9 +29,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--fpb", default="0")
-    ap.add_argument("--lut-rep", default="32")
     ap.add_argument("--kernel", default="tiled")
-    ap.add_argument("--taps", default="1")
     ap.add_argument("--lib", default="")
     ap.add_argument("--rows", default="32")
     ap.add_argument("--order", default="0", help="tile placement: 0 bands, 1 whole rows per XCD, 2 identity")
@@ -61,18 +59,15 @@ def main():
     flags = 7 | (8 if a.workload == "fused" else 0)
     alg = (int(info.src_bbox_bytes) + npo * 4) if a.workload == "fused" else npi * 5
     kmap = {"tiled": capi.KERNEL_TILED, "gather": capi.KERNEL_GATHER, "auto": capi.KERNEL_AUTO}
-    variants = list(itertools.product(a.kernel.split(","), [int(x) for x in a.fpb.split(",")],
-                                      [int(x) for x in a.lut_rep.split(",")], [int(x) for x in a.taps.split(",")], [int(x) for x in a.rows.split(",")],
+    variants = list(itertools.product(a.kernel.split(","), [int(x) for x in a.fpb.split(",")], [int(x) for x in a.rows.split(",")],
                                       [int(x) for x in a.order.split(",")]))
     times = {v: [] for v in variants}
     for r in range(a.rounds + 1):
         for v in variants:
             ctx.set_option(capi.OPT_KERNEL, kmap[v[0]])
             ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, v[1])
-            ctx.set_option(capi.OPT_LUT_REPLICAS, v[2])
-            ctx.set_option(capi.OPT_TAP_MODE, v[3])
-            ctx.set_option(capi.OPT_TILE_ROWS, v[4])
-            ctx.set_option(capi.OPT_TILE_ORDER, v[5])
+            ctx.set_option(capi.OPT_TILE_ROWS, v[2])
+            ctx.set_option(capi.OPT_TILE_ORDER, v[3])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), B, flags, s)
             e0.record()
@@ -82,11 +77,11 @@ def main():
             torch.cuda.synchronize()
             if r:
                 times[v].append(e0.elapsed_time(e1) / a.iters)
-    print("%-8s %5s %4s %4s %4s %3s %10s %10s %9s %7s" % ("kernel", "fpb", "rep", "taps", "rows", "ord", "median_ms", "min_ms", "GB/s", "frac8T"))
+    print("%-8s %5s %4s %3s %10s %10s %9s %7s" % ("kernel", "fpb", "rows", "ord", "median_ms", "min_ms", "GB/s", "frac8T"))
     for v in variants:
         med, mn = float(np.median(times[v])), float(np.min(times[v]))
         gbs = alg * B / (med * 1e-3) / 1e9
-        print("%-8s %5d %4d %4d %4d %3d %10.4f %10.4f %9.1f %7.3f" % (v[0], v[1], v[2], v[3], v[4], v[5], med, mn, gbs, gbs / 8000), flush=True)
+        print("%-8s %5d %4d %3d %10.4f %10.4f %9.1f %7.3f" % (v[0], v[1], v[2], v[3], med, mn, gbs, gbs / 8000), flush=True)
 
 
 if __name__ == "__main__":
