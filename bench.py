@@ -37,8 +37,11 @@ IN_W, IN_H, OUT_W, OUT_H = 1280, 1024, 640, 480
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--preroll-s", type=float, default=0.3,
+                   help="untimed clock ramp before the warmup steps: the first ~30 ms after an idle period run ~15 %% "
+                        "slow (DVFS, profiles/r01_dvfs_warmup_curve.txt)")
     p.add_argument("--frames", type=int, default=1024, help="frames per GPU per step (batch of one launch)")
     p.add_argument("--workload", default="fused", choices=["fused", "unmap", "pyramid"])
     p.add_argument("--kernel", default="auto", choices=["auto", "gather", "tiled"])
@@ -178,6 +181,11 @@ def main():
         if args.workload == "pyramid":
             ctx.pyramid_batch(d_out.data_ptr(), out_w, out_h, levels, [t.data_ptr() for t in d_levels], B, stream)
 
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.preroll_s:  # untimed: bring the clocks to their steady state
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -246,7 +254,7 @@ def main():
             "config": {"workload": {"fused": "configs[2]: fused photometric(g+v+o) + FOV bilinear remap 1280x1024 u8 -> 640x480 f32",
                                     "unmap": "configs[1]: unMapImage only (g+v+o) 1280x1024 u8 -> f32",
                                     "pyramid": "configs[4]: fused photometric + remap 1280x1024 -> 1280x1024 + 4-level box pyramid"}[args.workload],
-                       "frames_per_gpu_per_step": B, "sharding": "round-robin frame f -> rank f %% %d" % world,
+                       "frames_per_gpu_per_step": B, "preroll_s": args.preroll_s, "sharding": "round-robin frame f -> rank f %% %d" % world,
                        "tables": "rank-0 build + one RCCL broadcast" if world > 1 else "local build",
                        "frames_per_s": round(frames_total / elapsed, 1),
                        "out_mpix_per_s": round(frames_total * npix_out / 1e6 / elapsed, 1)},

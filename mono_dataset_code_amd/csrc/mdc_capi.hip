@@ -48,7 +48,7 @@ struct mdc_ctx {
   uint32_t* d_taps = nullptr;
   int* d_order = nullptr;  // block -> tile placement table (XCD bands)
   int n_blocks = 0;
-  int n_tiles = 0, tiles_x = 0, chunk_cap = 0, tile_h = 0;
+  int n_tiles = 0, tiles_x = 0, chunk_cap = 0, win_bytes = 0, nbuf = 2, tile_h = 0;
   int bbox[4] = {0, 0, -1, -1};
   int64_t staged_bytes = 0, n_black = 0;
 
@@ -57,6 +57,7 @@ struct mdc_ctx {
   int opt_fpb = 0;
   int opt_tile_h = 32;
   int opt_order = MDC_ORDER_BANDS;
+  int opt_nbuf = 0;  // 0 = automatic
 
   // staging for the host-pointer calls
   void* d_stage_in = nullptr;
@@ -126,11 +127,11 @@ int upload_luts(mdc_ctx* c) {
   return MDC_OK;
 }
 
-int frames_per_block(const mdc_ctx* c, int64_t nframes, int blocks_per_group) {
+int frames_per_block(const mdc_ctx* c, int64_t nframes, int blocks_per_group, int target_wgs = 4800) {
   if (c->opt_fpb > 0) return (int)std::min<int64_t>(c->opt_fpb, std::max<int64_t>(nframes, 1));
   // enough workgroups to fill 256 CUs several times over (tail), yet >= 8 frames per
   // workgroup so the per-workgroup table reads stay amortised
-  int64_t groups = std::max<int64_t>(1, (4800 + blocks_per_group - 1) / std::max(1, blocks_per_group));
+  int64_t groups = std::max<int64_t>(1, (target_wgs + blocks_per_group - 1) / std::max(1, blocks_per_group));
   groups = std::min<int64_t>(groups, std::max<int64_t>(1, nframes / 8));
   return (int)((nframes + groups - 1) / groups);
 }
@@ -258,9 +259,19 @@ int plan_tiles(mdc_ctx* c) {
       }
   }
   if (c->bbox[2] < 0) c->bbox[0] = c->bbox[1] = 0;
-  int cap = kTileThreads;
-  for (int t = 0; t < n_tiles; t++) cap = std::max(cap, (nch[t] + kTileThreads - 1) / kTileThreads * kTileThreads);
-  if (tiled_lds_bytes(cap) > kLdsPerCU) ok = false;
+  int cap = kTileThreads, nch_max = 1;
+  for (int t = 0; t < n_tiles; t++) {
+    cap = std::max(cap, (nch[t] + kTileThreads - 1) / kTileThreads * kTileThreads);
+    nch_max = std::max(nch_max, nch[t]);
+  }
+  const int win_bytes = (nch_max * 16 + 1023) & ~1023;  // a wave's DMA destination is 1 KiB aligned
+  // Window buffers: as many frames staged ahead as LDS allows WITHOUT lowering the number of
+  // workgroups per CU that two buffers permit (occupancy first, then depth), at most 4.
+  const int wg_per_cu = std::max<int>(1, std::min<size_t>(kLdsPerCU / tiled_lds_bytes(win_bytes, 2), 2048 / kTileThreads));
+  int nbuf = 2;
+  while (nbuf < 4 && tiled_lds_bytes(win_bytes, nbuf + 1) * wg_per_cu <= kLdsPerCU) nbuf++;
+  if (c->opt_nbuf) nbuf = c->opt_nbuf;
+  if (tiled_lds_bytes(win_bytes, nbuf) > kLdsPerCU) ok = false;
   if (!ok) return MDC_OK;
   std::vector<uint32_t> flat((size_t)n_tiles * cap, kOutside);
   for (int t = 0; t < n_tiles; t++) std::copy(chunks[t].begin(), chunks[t].end(), flat.begin() + (size_t)t * cap);
@@ -274,6 +285,8 @@ int plan_tiles(mdc_ctx* c) {
   c->tiles_x = tx;
   c->tile_h = kTileH;
   c->chunk_cap = cap;
+  c->win_bytes = win_bytes;
+  c->nbuf = nbuf;
   c->tiled = true;
   return MDC_OK;
 }
@@ -319,7 +332,7 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
     const int fw = c->in_w > 0 ? c->in_w : c->rm_in_w, fh = c->in_h > 0 ? c->in_h : c->rm_in_h;
     if (fw <= 0 || fh <= 0) return fail(c, MDC_ERR_STATE, "frame size unknown: set the photometric tables or a remap first");
     const int64_t npix = (int64_t)fw * fh;
-    const int fpb = frames_per_block(c, nframes, (int)((npix + 4095) / 4096));
+    const int fpb = frames_per_block(c, nframes, (int)((npix + 4095) / 4096), 20000);  // measured best at ~8 frames per workgroup
     MDC_HIP(c, launch_unmap(d_in, d_out, lut, vinv, npix, nframes, fpb, s));
     return MDC_OK;
   }
@@ -335,7 +348,7 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
     return fail(c, MDC_ERR_STATE, "tiled kernel requested but not plannable for this remap / alignment");
   if (use_tiled) {
     TilePlan p{c->d_chunks, c->d_nch, c->d_taps, c->d_order, c->n_blocks, c->n_tiles, c->tiles_x, c->tile_h, c->chunk_cap,
-               c->n_black > 0};
+               c->win_bytes, c->nbuf, c->n_black > 0};
     const int fpb = frames_per_block(c, nframes, c->n_blocks);
     MDC_HIP(c, launch_remap_tiled_u8(d_in, d_out, a, p, nframes, fpb, s));
   } else {
@@ -424,6 +437,15 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
       MDC_HIP(c, hipDeviceSynchronize());
       return plan_tiles(c);
     }
+    case MDC_OPT_WINDOW_BUFFERS: {
+      if (value != 0 && (value < 2 || value > 4)) return fail(c, MDC_ERR_ARG, "window buffers must be 0 (auto) or 2..4");
+      if (value == c->opt_nbuf) return MDC_OK;
+      c->opt_nbuf = value;
+      if (!c->valid_remap) return MDC_OK;
+      DeviceGuard dg(c->device);
+      MDC_HIP(c, hipDeviceSynchronize());
+      return plan_tiles(c);
+    }
     case MDC_OPT_TILE_ORDER: {
       if (value < MDC_ORDER_BANDS || value > MDC_ORDER_IDENTITY) return fail(c, MDC_ERR_ARG, "bad tile order %d", value);
       if (value == c->opt_order) return MDC_OK;
@@ -453,7 +475,7 @@ int mdc_get_info(mdc_ctx* c, mdc_info* i) {
   i->tile_w = kTileW;
   i->tile_h = c->opt_tile_h;
   i->n_tiles = c->n_tiles;
-  i->lds_bytes = c->tiled ? (int)tiled_lds_bytes(c->chunk_cap) : 0;
+  i->lds_bytes = c->tiled ? (int)tiled_lds_bytes(c->win_bytes, c->nbuf) : 0;
   for (int k = 0; k < 4; k++) i->src_bbox[k] = c->bbox[k];
   i->src_bbox_bytes = c->bbox[2] >= 0 ? (int64_t)(c->bbox[2] - c->bbox[0] + 1) * (c->bbox[3] - c->bbox[1] + 1) : 0;
   i->src_staged_bytes = c->staged_bytes;

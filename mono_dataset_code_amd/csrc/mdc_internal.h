@@ -35,7 +35,9 @@ struct TilePlan {
   int n_blocks;
   int n_tiles, tiles_x;
   int tile_h;      // output rows per tile: 16, 32, 60 or 64
-  int chunk_cap;   // whole staging rounds: max over tiles of ceil(nch / threads) * threads
+  int chunk_cap;   // row length of d_chunks: max over tiles of ceil(nch / threads) * threads
+  int win_bytes;   // LDS bytes of one window buffer: 16 * max nch, rounded up to 1 KiB
+  int nbuf;        // window buffers per workgroup (2..4): nbuf-1 frames are staged ahead
   bool has_black;  // some output carries the (-1,-1) sentinel
 };
 
@@ -52,7 +54,7 @@ hipError_t launch_remap_gather_f32(const float* d_in, float* d_out, const RemapA
 // Fused LUT (* vignette) + bilinear remap, u8 frames, source windows staged in LDS.
 hipError_t launch_remap_tiled_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
                                  int64_t nframes, int fpb, hipStream_t s);
-size_t tiled_lds_bytes(int chunk_cap);  // LUT replicas + two window buffers of chunk_cap chunks
+size_t tiled_lds_bytes(int win_bytes, int nbuf);  // LUT replicas + nbuf window buffers
 constexpr size_t kLdsPerCU = 160 * 1024;
 
 // One 2x2 box level: dst (w/2 x h/2) from src (w x h), nframes images each.

@@ -54,55 +54,61 @@ __device__ __forceinline__ void fill_lut(float* s_lut, const float* __restrict__
 }
 
 // ----------------------------------------------------------------------------
-// unMapImage, vector path: npix % 4 == 0, 16-byte aligned bases.
-// A workgroup owns 4096 consecutive pixels and loops over its frames.  Access
-// k of thread t touches pixels 4*(k*256+t) .. +3: each wave-instruction loads
-// 256 contiguous bytes of the raw frame and stores 1 KiB contiguous floats.
+// unMapImage, vector path: npix % 4 == 0, 4-byte aligned bases.
+// A workgroup owns 4096 consecutive pixels and loops over its frames.
 // ----------------------------------------------------------------------------
+// unMapImage with wave-contiguous dword stores (dword stores reach a higher write rate on this
+// memory system than 16-byte ones, tools/hbm_mix.hip).  The raw frame is still read 4 pixels per
+// lane (one u32, 256 contiguous bytes per wave-instruction); a wave-private 256-byte LDS scratch
+// per access turns "lane t holds pixels 4t..4t+3" into "lane t holds pixels t, t+64, t+128, t+192"
+// of the same 256-pixel run, so every store instruction of a wave writes 256 contiguous bytes.
 template <bool VIG>
-__global__ __launch_bounds__(256) void unmap_vec_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,
-                                                        const float* __restrict__ lut,
-                                                        const float* __restrict__ vinv, long long npix, int nframes,
-                                                        int fpb) {
+__global__ __launch_bounds__(256) void unmap_xpose_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,
+                                                          const float* __restrict__ lut,
+                                                          const float* __restrict__ vinv, long long npix, int nframes,
+                                                          int fpb) {
   __shared__ float s_lut[256 * kLutRep];
-  const int tid = threadIdx.x;
+  __shared__ uint32_t s_raw[4][4][64];  // [wave][access][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   fill_lut<256>(s_lut, lut, tid);
   __syncthreads();
   const float* my_lut = s_lut + (tid & (kLutRep - 1));
-
-  const long long base = (long long)blockIdx.x * 4096;
-  long long p[4];
-  bool ok[4];
-  f32x4 v[4];
+  const long long blk = (long long)blockIdx.x * 4096;
+  long long run[4];  // first pixel of the 256-pixel run of access k of this wave
+  float v[4][4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    p[k] = base + (long long)(k * 256 + tid) * 4;
-    ok[k] = p[k] < npix;
-    v[k] = (f32x4)(1.f);
-    if (VIG && ok[k]) v[k] = *reinterpret_cast<const f32x4*>(vinv + p[k]);
+    run[k] = blk + k * 1024 + wave * 256;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const long long i = run[k] + j * 64 + lane;
+      v[k][j] = (VIG && i < npix) ? vinv[i] : 1.f;
+    }
   }
   const int f0 = blockIdx.y * fpb;
   const int f1 = min(nframes, f0 + fpb);
   const uint8_t* src = in + (long long)f0 * npix;
   float* dst = out + (long long)f0 * npix;
+  typedef const volatile __attribute__((address_space(3))) unsigned char* lds_byte_ptr;
   for (int f = f0; f < f1; f++, src += npix, dst += npix) {
     uint32_t raw[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) raw[k] = ok[k] ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src + p[k])) : 0u;
+    for (int k = 0; k < 4; k++) {
+      const long long i = run[k] + 4 * lane;
+      raw[k] = i < npix ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src + i)) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_raw[wave][k][lane] = raw[k];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      f32x4 r;
-      r.x = my_lut[((raw[k]) & 255u) * kLutRep];
-      r.y = my_lut[((raw[k] >> 8) & 255u) * kLutRep];
-      r.z = my_lut[((raw[k] >> 16) & 255u) * kLutRep];
-      r.w = my_lut[(raw[k] >> 24) * kLutRep];
-      if (VIG) {
-        r.x = r.x * v[k].x;
-        r.y = r.y * v[k].y;
-        r.z = r.z * v[k].z;
-        r.w = r.w * v[k].w;
+      lds_byte_ptr b = (lds_byte_ptr)&s_raw[wave][k][0];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float r = my_lut[(int)b[j * 64 + lane] * kLutRep];
+        if (VIG) r = r * v[k][j];
+        const long long i = run[k] + j * 64 + lane;
+        if (i < npix) __builtin_nontemporal_store(r, dst + i);
       }
-      if (ok[k]) __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(dst + p[k]));
     }
   }
 }
@@ -258,7 +264,9 @@ typedef const __attribute__((address_space(3))) unsigned char* lds_u8_ptr;
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 constexpr uint32_t kRsrcWord3 = 0x00020000u;  // gfx9 raw buffer: 32-bit data format, no swizzle
-#if MDC_EXP_STORE_NT
+#ifdef MDC_EXP_STORE_AUX
+constexpr int kStoreAux = MDC_EXP_STORE_AUX;  // gfx94x/gfx950 cache-policy bits: 1 = sc0, 2 = nt, 16 = sc1
+#elif MDC_EXP_STORE_NT
 constexpr int kStoreAux = 2;  // nt
 #else
 constexpr int kStoreAux = 0;
@@ -314,50 +322,92 @@ __device__ __forceinline__ void tile_compute(const TileThread& t, const unsigned
 #endif
 }
 
-// One staging pass: the window of the frame at `ri` -> LDS buffer `win`.  R = rounds of NT chunks.
+// One staging pass: the window of the frame at `src` -> LDS buffer `win`.  R = rounds of NT chunks.
+// Lanes past the window (goff == kOutside) are masked off: they neither fetch nor write LDS, so a
+// buffer holds exactly the tile's chunks.
 template <int R, int NT>
 __device__ __forceinline__ void stage_window(const uint8_t* src, uint32_t in_bytes, unsigned char* win,
                                              const uint32_t (&goff)[R], int wave) {
 #if __HIP_DEVICE_COMPILE__
   const auto ri = MDC_FRAME_RSRC(src, in_bytes);
 #pragma unroll
-  for (int k = 0; k < R; k++)  // lanes past the window carry kOutside: nothing is fetched, zeros land in LDS
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (lds_void_ptr)(win + (k * NT + wave * 64) * 16), 16, goff[k], 0, 0,
-                                             kLoadAux);
+  for (int k = 0; k < R; k++)
+    if (goff[k] != kOutside)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (lds_void_ptr)(win + (k * NT + wave * 64) * 16), 16, goff[k], 0,
+                                               0, kLoadAux);
 #endif
 }
 
-template <bool VIG, bool BLACK, int R, int NT>
+// s_waitcnt vmcnt(N) ; s_barrier -- hand-placed: the compiler's own barrier (a workgroup fence)
+// would wait for EVERY outstanding LDS-DMA, i.e. also for the frames staged ahead.  vmcnt retires
+// in issue order on gfx9, loads and stores alike (the compiler's own counting relies on that).
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+// A = allowance of the per-frame wait for a wave that issues `rw` DMA instructions per frame with
+// D frames staged ahead: everything issued after the DMA of frame f+1 may stay in flight, which is
+// at least (D-1) later DMA groups and the 4 stores of frame f  ->  (D-1)*rw + 4.
+template <int D, int R>
+__device__ __forceinline__ void frame_barrier(int rw) {
+  if (R >= 3 && rw >= 3) wait_vm_barrier<(D - 1) * 3 + 4>();
+  else if (R >= 2 && rw == 2) wait_vm_barrier<(D - 1) * 2 + 4>();
+  else if (rw == 1) wait_vm_barrier<(D - 1) * 1 + 4>();
+  else wait_vm_barrier<4>();
+}
+
+// Frames [0, nframes) of one tile.  NBUF window buffers, D = NBUF-1 frames staged ahead: the DMA
+// of frame f+D is issued before frame f is computed; one barrier per frame.
+template <bool VIG, bool BLACK, int R, int NT, int NBUF>
 __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* __restrict__ src,
                                             float* __restrict__ dst, uint32_t in_bytes, uint32_t out_bytes,
-                                            int nframes, const uint32_t* __restrict__ chunks, unsigned char* s_win,
-                                            int win_bytes, const float* my_lut, int tid) {
+                                            int nframes, int nch, const uint32_t* __restrict__ chunks,
+                                            unsigned char* s_win, int win_bytes, const float* my_lut, int tid) {
+  constexpr int D = NBUF - 1;
   uint32_t goff[R];
 #pragma unroll
   for (int k = 0; k < R; k++) goff[k] = chunks[tid + k * NT];  // kOutside past the window
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  unsigned char* w0 = s_win;
-  unsigned char* w1 = s_win + win_bytes;
-  stage_window<R, NT>(src, in_bytes, w0, goff, wave);
-  __syncthreads();
-  for (int f = 0; f < nframes - 1; f++) {
-#if !MDC_EXP_SKIP_LOAD
-    src += in_bytes;
+  int rw = 0;  // DMA instructions this wave issues per frame (rounds in which its first lane has a chunk)
+#pragma unroll
+  for (int k = 0; k < R; k++) rw += (wave * 64 + k * NT < nch) ? 1 : 0;
+  unsigned char* w[NBUF];
+#pragma unroll
+  for (int i = 0; i < NBUF; i++) w[i] = s_win + i * win_bytes;
+  const int last = nframes - 1;
+#pragma unroll
+  for (int d = 0; d < D; d++) {
+#if MDC_EXP_SKIP_LOAD
+    stage_window<R, NT>(src, in_bytes, w[d], goff, wave);
+#else
+    stage_window<R, NT>(src + (long long)min(d, last) * in_bytes, in_bytes, w[d], goff, wave);
 #endif
-    stage_window<R, NT>(src, in_bytes, w1, goff, wave);
-    tile_compute<VIG, BLACK>(t, w0, my_lut, dst, out_bytes);
-    dst += out_bytes / 4;
-    __syncthreads();  // DMA of frame f+1 landed (vmcnt) and every wave is done reading w0
-    unsigned char* x = w0;
-    w0 = w1;
-    w1 = x;
   }
-  tile_compute<VIG, BLACK>(t, w0, my_lut, dst, out_bytes);
+  // frame 0 landed: only the D-1 later DMA groups may still be in flight
+  if (R >= 3 && rw >= 3) wait_vm_barrier<(D - 1) * 3>();
+  else if (R >= 2 && rw == 2) wait_vm_barrier<(D - 1) * 2>();
+  else if (rw == 1) wait_vm_barrier<(D - 1) * 1>();
+  else wait_vm_barrier<0>();
+  for (int f = 0; f <= last; f++) {
+#if MDC_EXP_SKIP_LOAD
+    stage_window<R, NT>(src, in_bytes, w[D], goff, wave);
+#else
+    stage_window<R, NT>(src + (long long)min(f + D, last) * in_bytes, in_bytes, w[D], goff, wave);
+#endif
+    tile_compute<VIG, BLACK>(t, w[0], my_lut, dst, out_bytes);
+    dst += out_bytes / 4;
+    frame_barrier<D, R>(rw);  // frame f+1 landed in every wave's part of w[1]; everyone is done reading w[0]
+    unsigned char* x = w[0];
+#pragma unroll
+    for (int i = 0; i < D; i++) w[i] = w[i + 1];
+    w[D] = x;
+  }
 }
 
 // Occupancy is set by LDS (LUT replicas + two window buffers): 3 workgroups of 512 threads or 2 of
 // 960/1024 per CU; the register budget follows from that.
-template <bool VIG, bool BLACK, int NT>
+template <bool VIG, bool BLACK, int NT, int NBUF>
 __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap_tiled_u8_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,
                                                             RemapArgs a, TilePlan p, int nframes, int fpb) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -429,9 +479,8 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap
   }
   const int rounds = (nch + NT - 1) / NT;  // workgroup-uniform
   const uint32_t* chunks = p.d_chunks + (size_t)tile * p.chunk_cap;
-  const int win_bytes = p.chunk_cap * 16;
 #define MDC_TILE_RUN(R_) \
-  tile_frames<VIG, BLACK, R_, NT>(t, src, dst, in_bytes, out_bytes, nf, chunks, s_win, win_bytes, my_lut, tid)
+  tile_frames<VIG, BLACK, R_, NT, NBUF>(t, src, dst, in_bytes, out_bytes, nf, nch, chunks, s_win, p.win_bytes, my_lut, tid)
   if (rounds == 1) MDC_TILE_RUN(1);
   else if (rounds == 2) MDC_TILE_RUN(2);
   else MDC_TILE_RUN(kTileMaxChunks);
@@ -481,19 +530,17 @@ inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace
 
-size_t tiled_lds_bytes(int chunk_cap) { return (size_t)kLutBytes + 2 * (size_t)chunk_cap * 16; }
+size_t tiled_lds_bytes(int win_bytes, int nbuf) { return (size_t)kLutBytes + (size_t)nbuf * win_bytes; }
 
 hipError_t launch_unmap(const uint8_t* d_in, float* d_out, const float* d_lut, const float* d_vinv, int64_t npix,
                         int64_t nframes, int fpb, hipStream_t s) {
   if (nframes <= 0 || npix <= 0) return hipSuccess;
   const int groups = ceil_div(nframes, fpb);
-  const bool vec = (npix % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_in) & 3) == 0) &&
-                   ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0) &&
-                   (!d_vinv || (reinterpret_cast<uintptr_t>(d_vinv) & 15) == 0);
+  const bool vec = (npix % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_in) & 3) == 0);
   if (vec) {
     dim3 grid(ceil_div(npix, 4096), groups);
-    if (d_vinv) unmap_vec_kernel<true><<<grid, 256, 0, s>>>(d_in, d_out, d_lut, d_vinv, npix, (int)nframes, fpb);
-    else unmap_vec_kernel<false><<<grid, 256, 0, s>>>(d_in, d_out, d_lut, d_vinv, npix, (int)nframes, fpb);
+    if (d_vinv) unmap_xpose_kernel<true><<<grid, 256, 0, s>>>(d_in, d_out, d_lut, d_vinv, npix, (int)nframes, fpb);
+    else unmap_xpose_kernel<false><<<grid, 256, 0, s>>>(d_in, d_out, d_lut, d_vinv, npix, (int)nframes, fpb);
   } else {
     dim3 grid(ceil_div(npix, 256), groups);
     if (d_vinv) unmap_scalar_kernel<true><<<grid, 256, 0, s>>>(d_in, d_out, d_lut, d_vinv, npix, (int)nframes, fpb);
@@ -519,28 +566,39 @@ hipError_t launch_remap_gather_f32(const float* d_in, float* d_out, const RemapA
   return hipGetLastError();
 }
 
-template <bool VIG, bool BLACK, int NT>
+template <bool VIG, bool BLACK, int NT, int NBUF>
 static hipError_t launch_tiled_variant(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
                                        int64_t nframes, int fpb, hipStream_t s) {
   dim3 grid(p.n_blocks, ceil_div(nframes, fpb));
-  const size_t lds = tiled_lds_bytes(p.chunk_cap);
-  if (lds > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in (64x60 / 64x64 tiles)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&remap_tiled_u8_kernel<VIG, BLACK, NT>),
+  const size_t lds = tiled_lds_bytes(p.win_bytes, NBUF);
+  if (lds > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&remap_tiled_u8_kernel<VIG, BLACK, NT, NBUF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  remap_tiled_u8_kernel<VIG, BLACK, NT><<<grid, NT, lds, s>>>(d_in, d_out, a, p, (int)nframes, fpb);
+  remap_tiled_u8_kernel<VIG, BLACK, NT, NBUF><<<grid, NT, lds, s>>>(d_in, d_out, a, p, (int)nframes, fpb);
   return hipGetLastError();
+}
+
+template <bool VIG, bool BLACK, int NT>
+static hipError_t launch_tiled_buf(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
+                                   int64_t nframes, int fpb, hipStream_t s) {
+  switch (p.nbuf) {
+    case 2: return launch_tiled_variant<VIG, BLACK, NT, 2>(d_in, d_out, a, p, nframes, fpb, s);
+    case 3: return launch_tiled_variant<VIG, BLACK, NT, 3>(d_in, d_out, a, p, nframes, fpb, s);
+    case 4: return launch_tiled_variant<VIG, BLACK, NT, 4>(d_in, d_out, a, p, nframes, fpb, s);
+  }
+  return hipErrorInvalidValue;
 }
 
 template <bool VIG, bool BLACK>
 static hipError_t launch_tiled_nt(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
                                   int64_t nframes, int fpb, hipStream_t s) {
   switch (p.tile_h) {
-    case 16: return launch_tiled_variant<VIG, BLACK, 256>(d_in, d_out, a, p, nframes, fpb, s);
-    case 32: return launch_tiled_variant<VIG, BLACK, 512>(d_in, d_out, a, p, nframes, fpb, s);
-    case 60: return launch_tiled_variant<VIG, BLACK, 960>(d_in, d_out, a, p, nframes, fpb, s);
-    case 64: return launch_tiled_variant<VIG, BLACK, 1024>(d_in, d_out, a, p, nframes, fpb, s);
+    case 16: return launch_tiled_buf<VIG, BLACK, 256>(d_in, d_out, a, p, nframes, fpb, s);
+    case 32: return launch_tiled_buf<VIG, BLACK, 512>(d_in, d_out, a, p, nframes, fpb, s);
+    case 60: return launch_tiled_buf<VIG, BLACK, 960>(d_in, d_out, a, p, nframes, fpb, s);
+    case 64: return launch_tiled_buf<VIG, BLACK, 1024>(d_in, d_out, a, p, nframes, fpb, s);
   }
   return hipErrorInvalidValue;
 }

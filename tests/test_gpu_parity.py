@@ -96,11 +96,12 @@ def test_tiled_and_gather_kernels_agree(name, setups, oracle, torch_cuda):
         assert info.tiled, "tiled kernel should be plannable for %s" % name
     for k in kernels:
         s.ctx.set_option(capi.OPT_KERNEL, k)
-        for rows, order in (((32, capi.ORDER_BANDS), (16, capi.ORDER_ROWS), (32, capi.ORDER_IDENTITY), (60, capi.ORDER_BANDS),
-                             (64, capi.ORDER_ROWS), (16, capi.ORDER_BANDS), (32, capi.ORDER_ROWS))
-                            if k == capi.KERNEL_TILED else ((32, capi.ORDER_BANDS),)):
+        for rows, order, nbuf in (((32, capi.ORDER_BANDS, 0), (16, capi.ORDER_ROWS, 4), (32, capi.ORDER_IDENTITY, 3), (60, capi.ORDER_BANDS, 0),
+                                   (64, capi.ORDER_ROWS, 2), (16, capi.ORDER_BANDS, 2), (32, capi.ORDER_ROWS, 4), (60, capi.ORDER_ROWS, 2))
+                                  if k == capi.KERNEL_TILED else ((32, capi.ORDER_BANDS, 0),)):
           s.ctx.set_option(capi.OPT_TILE_ROWS, rows)
           s.ctx.set_option(capi.OPT_TILE_ORDER, order)
+          s.ctx.set_option(capi.OPT_WINDOW_BUFFERS, nbuf)
           if k == capi.KERNEL_TILED and not s.ctx.info().tiled:
               continue
           for n, fpb in ((1, 0), (3, 2), (17, 0), (17, 5)):
@@ -108,8 +109,9 @@ def test_tiled_and_gather_kernels_agree(name, setups, oracle, torch_cuda):
             d_out = torch.full((n, s.w * s.h), -7.0, dtype=torch.float32, device="cuda")
             s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, flags, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-            assert bits_equal(d_out.cpu().numpy(), want[:n]), (name, k, rows, order, n, fpb)
+            assert bits_equal(d_out.cpu().numpy(), want[:n]), (name, k, rows, order, nbuf, n, fpb)
     s.ctx.set_option(capi.OPT_TILE_ORDER, capi.ORDER_BANDS)
+    s.ctx.set_option(capi.OPT_WINDOW_BUFFERS, 0)
     s.ctx.set_option(capi.OPT_TILE_ROWS, 32)
     s.ctx.set_option(capi.OPT_KERNEL, capi.KERNEL_AUTO)
     s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, 0)

@@ -1,19 +1,20 @@
 #!/usr/bin/env python3
-"""Within-process A/B of kernel variants / tuning knobs on the bench workload.
+"""Within-process A/B of kernel builds / tuning knobs on the bench workload.
 
-Variants are interleaved over several rounds in ONE process (cross-process noise
-looks like a kernel property otherwise); reports median and min ms per launch and
-the implied algorithmic GB/s.  Usage:
+Variants are interleaved over several rounds in ONE process on ONE GPU (different boxes and
+different processes differ by +-5 %, more than most effects of interest); reports median and
+min ms per launch and the implied algorithmic GB/s.  Usage:
   python tools/sweep.py --frames 1024 --rounds 5 --fpb 0,16,32,64 --rows 32,60 --order 0,1 --kernel tiled,gather
+  python tools/sweep.py --libs default,mono_dataset_code_amd/variants/libmdc_hip_v1.so   # builds side by side
+Every lib is an independent ctypes binding of include/mdc_hip.h (same HIP runtime); the
+calibration tables are built once on the host and imported into each as the broadcast blob.
 """
 import argparse
+import importlib.util
 import itertools
 import os
 import sys
 import tempfile
-
-if "--lib" in sys.argv:  # experiment build of libmdc_hip (mono_dataset_code_amd/build.py:build_variant)
-    os.environ["MDC_LIB_HIP"] = sys.argv[sys.argv.index("--lib") + 1]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,18 +24,47 @@ import torch  # noqa: E402
 from mono_dataset_code_amd import capi, synth  # noqa: E402
 
 
+def binding(path):
+    """A second, independent instance of the capi module bound to another libmdc_hip build."""
+    if path in ("default", "-", ""):
+        return capi
+    spec = importlib.util.spec_from_file_location("capi_" + os.path.basename(path).replace(".", "_"),
+                                                  os.path.join(ROOT, "mono_dataset_code_amd", "capi.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    m.LIB_HIP_PATH = path if os.path.isabs(path) else os.path.join(ROOT, path)
+    return m
+
+
+def try_set(m, ctx, name, value):
+    opt = getattr(m, name, None)
+    if opt is None:
+        return
+    try:
+        ctx.set_option(opt, value)
+    except Exception:  # older builds do not know newer options / values
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--fpb", default="0")
     ap.add_argument("--kernel", default="tiled")
-    ap.add_argument("--lib", default="")
+    ap.add_argument("--libs", default="default", help="comma list of libmdc_hip builds ('default' = the in-tree one)")
+    ap.add_argument("--lib", default="", help="(compat) single alternative build")
     ap.add_argument("--rows", default="32")
     ap.add_argument("--order", default="0", help="tile placement: 0 bands, 1 whole rows per XCD, 2 identity")
+    ap.add_argument("--sched", default="-1", help="frame scheduling: -1 library default, 0 static groups, 1 persistent")
+    ap.add_argument("--nbuf", default="0", help="LDS window buffers (0 = automatic)")
+    ap.add_argument("--remap", default="fov", choices=["fov", "affine", "affine128"],
+                    help="diagnosis: replace the FOV remap by a distortion-free one of the same scale (no window overlap "
+                         "from the bow); affine128 = output tile columns map to whole 128-byte source lines")
     ap.add_argument("--workload", default="fused", choices=["fused", "unmap"])
     a = ap.parse_args()
+    libs = [a.lib] if a.lib else a.libs.split(",")
     dev = torch.device("cuda", 0)
     d = synth.write_sequence_calibration(tempfile.mkdtemp(prefix="mdc_sweep_"))
     sys.stdout.flush()
@@ -45,9 +75,22 @@ def main():
     import ctypes
     ctypes.CDLL(None).fflush(None)
     os.dup2(so, 1)
-    ctx = capi.Context(0)
-    ctx.bind(fov, photo)
-    info = ctx.info()
+    blob = capi.pack_tables(fov, photo)
+    ctxs = {}
+    for l in libs:
+        m = binding(l)
+        c = m.Context(0)
+        c.import_tables(blob)
+        if a.remap != "fov":
+            sx = 1.345 if a.remap == "affine" else 2.0  # 64 outputs -> 86 or exactly 128 source bytes
+            x0 = 200.3 if a.remap == "affine" else 0.3
+            xs = (x0 + sx * np.arange(640, dtype=np.float64)).astype(np.float32)
+            ys = (146.9 + 1.515 * np.arange(480, dtype=np.float64)).astype(np.float32)
+            rx = np.broadcast_to(xs[None, :], (480, 640)).copy()
+            ry = np.broadcast_to(ys[:, None], (480, 640)).copy()
+            c.set_remap(rx, ry, 1280, 1024, 640, 480)
+        ctxs[l] = (m, c)
+    info = ctxs[libs[0]][1].info()
     B, npi = a.frames, 1280 * 1024
     npo = 640 * 480 if a.workload == "fused" else npi
     st = torch.cuda.Stream(device=dev)
@@ -55,19 +98,28 @@ def main():
     s = st.cuda_stream
     d_in = torch.empty(B * npi, dtype=torch.uint8, device=dev)
     d_out = torch.empty(B * npo, dtype=torch.float32, device=dev)
-    ctx.synth_frames(d_in.data_ptr(), 0, B, npi, synth.SEED, s)
+    ctxs[libs[0]][1].synth_frames(d_in.data_ptr(), 0, B, npi, synth.SEED, s)
     flags = 7 | (8 if a.workload == "fused" else 0)
     alg = (int(info.src_bbox_bytes) + npo * 4) if a.workload == "fused" else npi * 5
     kmap = {"tiled": capi.KERNEL_TILED, "gather": capi.KERNEL_GATHER, "auto": capi.KERNEL_AUTO}
-    variants = list(itertools.product(a.kernel.split(","), [int(x) for x in a.fpb.split(",")], [int(x) for x in a.rows.split(",")],
-                                      [int(x) for x in a.order.split(",")]))
+    ints = lambda x: [int(v) for v in x.split(",")]  # noqa: E731
+    variants = list(itertools.product(libs, a.kernel.split(","), ints(a.fpb), ints(a.rows), ints(a.order), ints(a.sched), ints(a.nbuf)))
     times = {v: [] for v in variants}
+    # DVFS: the first ~30 ms after an idle period run ~15 % slow (profiles/r01_dvfs_warmup_curve.txt)
+    m0, c0 = ctxs[libs[0]]
+    for _ in range(200):
+        c0.process_batch(d_in.data_ptr(), d_out.data_ptr(), B, flags, s)
+    torch.cuda.synchronize()
     for r in range(a.rounds + 1):
         for v in variants:
-            ctx.set_option(capi.OPT_KERNEL, kmap[v[0]])
-            ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, v[1])
-            ctx.set_option(capi.OPT_TILE_ROWS, v[2])
-            ctx.set_option(capi.OPT_TILE_ORDER, v[3])
+            m, ctx = ctxs[v[0]]
+            ctx.set_option(m.OPT_KERNEL, kmap[v[1]])
+            ctx.set_option(m.OPT_FRAMES_PER_BLOCK, v[2])
+            try_set(m, ctx, "OPT_TILE_ROWS", v[3])
+            try_set(m, ctx, "OPT_TILE_ORDER", v[4])
+            if v[5] >= 0:
+                try_set(m, ctx, "OPT_SCHEDULE", v[5])
+            try_set(m, ctx, "OPT_WINDOW_BUFFERS", v[6])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), B, flags, s)
             e0.record()
@@ -77,11 +129,11 @@ def main():
             torch.cuda.synchronize()
             if r:
                 times[v].append(e0.elapsed_time(e1) / a.iters)
-    print("%-8s %5s %4s %3s %10s %10s %9s %7s" % ("kernel", "fpb", "rows", "ord", "median_ms", "min_ms", "GB/s", "frac8T"))
+    print("%-28s %-7s %5s %4s %3s %3s %3s %10s %10s %9s %7s" % ("lib", "kernel", "fpb", "rows", "ord", "sch", "buf", "median_ms", "min_ms", "GB/s", "frac8T"))
     for v in variants:
         med, mn = float(np.median(times[v])), float(np.min(times[v]))
         gbs = alg * B / (med * 1e-3) / 1e9
-        print("%-8s %5d %4d %3d %10.4f %10.4f %9.1f %7.3f" % (v[0], v[1], v[2], v[3], med, mn, gbs, gbs / 8000), flush=True)
+        print("%-28s %-7s %5d %4d %3d %3d %3d %10.4f %10.4f %9.1f %7.3f" % (os.path.basename(v[0])[-28:], v[1], v[2], v[3], v[4], v[5], v[6], med, mn, gbs, gbs / 8000), flush=True)
 
 
 if __name__ == "__main__":
