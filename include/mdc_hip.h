@@ -144,6 +144,14 @@ int mdc_undistort_batch_device_f32(mdc_ctx* ctx, const float* d_in, float* d_out
 int mdc_pyramid_batch_device(mdc_ctx* ctx, const float* d_base, int w, int h, int levels, float* const* d_levels,
                              int64_t nframes, void* stream);
 
+/* getImage + box pyramid in ONE pass over the raw frames (config 5, the DSO-style preprocessing path):
+ * d_base as mdc_process_batch_device writes it, plus levels 1..levels-1 as mdc_pyramid_batch_device
+ * would derive them from d_base -- bit-identical results.  With MDC_RECTIFY and an output made of whole
+ * tiles (out_w % 64 == 0, out_h % tile rows == 0) levels 1..3 come out of the remap kernel's registers
+ * (no re-read of the base); other geometries and levels >= 4 fall back to one pass per level. */
+int mdc_process_pyramid_batch_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_base, int levels,
+                                     float* const* d_levels, int64_t nframes, unsigned flags, void* stream);
+
 /* Synthetic sequence generator (bench/test utility):
  * byte i of frame f = fmix32(seed + (first_frame+f)*npix + i) >> 24. */
 int mdc_synth_frames_device(mdc_ctx* ctx, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix,

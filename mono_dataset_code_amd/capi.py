@@ -26,7 +26,7 @@ HIP_SYMBOLS = [
     "mdc_create", "mdc_destroy", "mdc_last_error", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
     "mdc_set_remap", "mdc_unmap_host", "mdc_undistort_host_f32", "mdc_undistort_host_u8", "mdc_process_host",
     "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
-    "mdc_pyramid_batch_device", "mdc_synth_frames_device", "mdc_export_tables", "mdc_import_tables",
+    "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device", "mdc_synth_frames_device", "mdc_export_tables", "mdc_import_tables",
     "mdc_synchronize",
 ]
 HOST_SYMBOLS = [
@@ -92,6 +92,7 @@ def hip_lib():
         L.mdc_process_batch_device.argtypes = [_vp, _vp, _vp, _i64, C.c_uint, _vp]
         L.mdc_undistort_batch_device_f32.argtypes = [_vp, _vp, _vp, _i64, _vp]
         L.mdc_pyramid_batch_device.argtypes = [_vp, _vp, _i, _i, _i, C.POINTER(_vp), _i64, _vp]
+        L.mdc_process_pyramid_batch_device.argtypes = [_vp, _vp, _vp, _i, C.POINTER(_vp), _i64, C.c_uint, _vp]
         L.mdc_synth_frames_device.argtypes = [_vp, _vp, _i64, _i64, _i, _u32, _vp]
         L.mdc_export_tables.argtypes = [_vp, _vp, _sz, C.POINTER(_sz)]
         L.mdc_import_tables.argtypes = [_vp, _vp, _sz]
@@ -248,6 +249,11 @@ class Context:
     def pyramid_batch(self, d_base, w, h, levels, d_levels, nframes, stream=0):
         arr = (_vp * max(1, len(d_levels)))(*d_levels)
         self._chk(self._L.mdc_pyramid_batch_device(self._h, d_base, w, h, levels, arr, nframes, stream if stream else None))
+
+    def process_pyramid_batch(self, d_in, d_base, levels, d_levels, nframes, flags, stream=0):
+        arr = (_vp * max(1, len(d_levels)))(*d_levels)
+        self._chk(self._L.mdc_process_pyramid_batch_device(self._h, d_in, d_base, levels, arr, nframes, flags,
+                                                           stream if stream else None))
 
     def synth_frames(self, d_out, first_frame, nframes, npix, seed, stream=0):
         self._chk(self._L.mdc_synth_frames_device(self._h, d_out, first_frame, nframes, npix, seed, stream if stream else None))

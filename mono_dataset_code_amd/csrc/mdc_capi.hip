@@ -200,6 +200,7 @@ int plan_tiles(mdc_ctx* c) {
   const int tx = (ow + kTileW - 1) / kTileW, ty = (oh + kTileH - 1) / kTileH;
   const int n_tiles = tx * ty;
   bool ok = (iw % 16 == 0);
+  for (size_t i = 0; i < (size_t)ow * oh; i++) c->n_black += c->h_rx[i] < 0;
   std::vector<std::vector<uint32_t>> chunks(n_tiles);
   std::vector<int> nch(n_tiles, 0);
   std::vector<uint32_t> taps((size_t)ow * oh, 0u);
@@ -213,10 +214,7 @@ int plan_tiles(mdc_ctx* c) {
     for (int y = by; y < y1; y++)
       for (int x = bx; x < x1; x++) {
         const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
-        if (xx < 0) {
-          c->n_black++;
-          continue;
-        }
+        if (xx < 0) continue;
         y_lo = std::min(y_lo, (int)yy);
         y_hi = std::max(y_hi, (int)yy + 1);
       }
@@ -323,7 +321,10 @@ RemapArgs remap_args(const mdc_ctx* c, const float* lut, const float* vinv) {
 }
 
 // Enqueue the fused / photometric-only pipeline on `s`.  Lock held by caller.
-int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, hipStream_t s) {
+// pyr (optional): levels 1..3 of the box pyramid; *pyr_done tells whether the launch wrote them.
+int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, hipStream_t s,
+                    float* const* pyr = nullptr, bool* pyr_done = nullptr) {
+  if (pyr_done) *pyr_done = false;
   bool g, v, o;
   normalise(c, flags, g, v, o);
   const float* lut = lut_for(c, g, o);
@@ -350,7 +351,10 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
     TilePlan p{c->d_chunks, c->d_nch, c->d_taps, c->d_order, c->n_blocks, c->n_tiles, c->tiles_x, c->tile_h, c->chunk_cap,
                c->win_bytes, c->nbuf, c->n_black > 0};
     const int fpb = frames_per_block(c, nframes, c->n_blocks);
-    MDC_HIP(c, launch_remap_tiled_u8(d_in, d_out, a, p, nframes, fpb, s));
+    const bool fuse_pyr = pyr && c->tile_h != 60 && c->out_w % kTileW == 0 && c->out_h % c->tile_h == 0;
+    MDC_HIP(c, launch_remap_tiled_u8(d_in, d_out, a, p, nframes, fpb, s, fuse_pyr ? pyr[0] : nullptr,
+                                     fuse_pyr ? pyr[1] : nullptr, fuse_pyr ? pyr[2] : nullptr));
+    if (pyr_done) *pyr_done = fuse_pyr;
   } else {
     const int fpb = frames_per_block(c, nframes, (c->out_w * c->out_h + 255) / 256);
     MDC_HIP(c, launch_remap_gather_u8(d_in, d_out, a, nframes, fpb, s));
@@ -591,6 +595,32 @@ int mdc_pyramid_batch_device(mdc_ctx* c, const float* d_base, int w, int h, int 
   const float* src = d_base;
   for (int l = 1; l < levels; l++) {
     if (!d_levels[l - 1]) return fail(c, MDC_ERR_ARG, "level %d buffer is NULL", l);
+    MDC_HIP(c, launch_pyramid_level(src, d_levels[l - 1], w >> (l - 1), h >> (l - 1), nframes, s));
+    src = d_levels[l - 1];
+  }
+  return MDC_OK;
+}
+
+int mdc_process_pyramid_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_base, int levels, float* const* d_levels,
+                                     int64_t nframes, unsigned flags, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (!d_in || !d_base || nframes < 0 || levels < 1 || (levels > 1 && !d_levels))
+    return fail(c, MDC_ERR_ARG, "mdc_process_pyramid_batch_device: bad argument");
+  for (int l = 1; l < levels; l++)
+    if (!d_levels[l - 1]) return fail(c, MDC_ERR_ARG, "level %d buffer is NULL", l);
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  hipStream_t s = (hipStream_t)stream;
+  const bool rect = (flags & MDC_RECTIFY) != 0;
+  const int w = rect ? c->out_w : (c->in_w > 0 ? c->in_w : c->rm_in_w), h = rect ? c->out_h : (c->in_h > 0 ? c->in_h : c->rm_in_h);
+  float* pyr[3] = {levels > 1 ? d_levels[0] : nullptr, levels > 2 ? d_levels[1] : nullptr, levels > 3 ? d_levels[2] : nullptr};
+  bool fused = false;
+  int rc = enqueue_process(c, d_in, d_base, nframes, flags, s, levels > 1 ? pyr : nullptr, &fused);
+  if (rc != MDC_OK) return rc;
+  // levels the launch did not write (no fused path for this geometry, or more than 4 levels)
+  const int first = fused ? std::min(levels, 4) : 1;
+  const float* src = first == 1 ? d_base : d_levels[first - 2];
+  for (int l = first; l < levels; l++) {
     MDC_HIP(c, launch_pyramid_level(src, d_levels[l - 1], w >> (l - 1), h >> (l - 1), nframes, s));
     src = d_levels[l - 1];
   }

@@ -52,9 +52,13 @@ hipError_t launch_remap_gather_u8(const uint8_t* d_in, float* d_out, const Remap
 hipError_t launch_remap_gather_f32(const float* d_in, float* d_out, const RemapArgs& a, int64_t nframes, int fpb,
                                    hipStream_t s);
 // Fused LUT (* vignette) + bilinear remap, u8 frames, source windows staged in LDS.
+// d_l1..d_l3 (optional): levels 1..3 of the 2x2 box pyramid of every output frame, written by the same
+// launch (needs whole tiles: out_w % 64 == 0, out_h % tile_h == 0, tile_h in {16, 32, 64}).
 hipError_t launch_remap_tiled_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
-                                 int64_t nframes, int fpb, hipStream_t s);
+                                 int64_t nframes, int fpb, hipStream_t s, float* d_l1 = nullptr, float* d_l2 = nullptr,
+                                 float* d_l3 = nullptr);
 size_t tiled_lds_bytes(int win_bytes, int nbuf);  // LUT replicas + nbuf window buffers
+size_t tiled_pyramid_lds_bytes(int tile_h);       // + level-2 hand-over rows of the fused pyramid
 constexpr size_t kLdsPerCU = 160 * 1024;
 
 // One 2x2 box level: dst (w/2 x h/2) from src (w x h), nframes images each.

@@ -287,11 +287,13 @@ struct TileThread {  // per-thread, frame-invariant
   uint32_t obyte[4];     // byte offset of the output inside a frame, kOutside if not in the image
   bool black[4];
   float v00[4], v10[4], v01[4], v11[4];
+  uint32_t p1byte[2], p2byte;  // fused pyramid: byte offsets of this lane's level-1 / level-2 outputs (kOutside if none)
 };
 
 template <bool VIG, bool BLACK>
 __device__ __forceinline__ void tile_compute(const TileThread& t, const unsigned char* __restrict__ w,
-                                             const float* __restrict__ my_lut, float* dst, uint32_t out_bytes) {
+                                             const float* __restrict__ my_lut, float* dst, uint32_t out_bytes,
+                                             float (&res)[4]) {
 #if __HIP_DEVICE_COMPILE__  // buffer / LDS-DMA builtins exist in the device pass only
   const auto ro = MDC_FRAME_RSRC(dst, out_bytes);
 #pragma unroll
@@ -314,10 +316,75 @@ __device__ __forceinline__ void tile_compute(const TileThread& t, const unsigned
     }
     float r = bilin_sum(t.bl[j], t00, t10, t01, t11);
     if (BLACK && t.black[j]) r = 0.f;
+    res[j] = r;
 #if MDC_EXP_SKIP_STORE
     if (r != -1.2345e30f) continue;
 #endif
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, t.obyte[j], 0, kStoreAux);
+  }
+#endif
+}
+
+// ----------------------------------------------------------------------------
+// Fused box pyramid (BASELINE.json config 5; not in the reference, definition in DESIGN.md):
+// level l+1 pixel = 0.25f*(((a+b)+c)+d), a=(2x,2y) b=(2x+1,2y) c=(2x,2y+1) d=(2x+1,2y+1).
+// A thread holds 4 vertically consecutive outputs of one column, the right neighbour column sits
+// in the next lane: levels 1 and 2 come out of registers with two DPP quad permutes; level 3
+// pairs row groups of different waves and goes through a 16-float LDS row per wave, one frame
+// later (the per-frame barrier doubles as its hand-over).
+// ----------------------------------------------------------------------------
+struct PyramidOut {
+  float* l1;  // nframes * (w/2)*(h/2), or nullptr
+  float* l2;  // nframes * (w/4)*(h/4), or nullptr
+  float* l3;  // nframes * (w/8)*(h/8), or nullptr
+};
+
+__device__ __forceinline__ float box4(float a, float b, float c, float d) { return 0.25f * (((a + b) + c) + d); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// levels 1 and 2 of frame `f` from this thread's four outputs; this wave's level-2 row -> s_row
+__device__ __forceinline__ void pyramid_levels12(const TileThread& t, const float (&r)[4], const PyramidOut& py,
+                                                 long long f, uint32_t l1_bytes, uint32_t l2_bytes, float* s_row,
+                                                 int lane) {
+#if __HIP_DEVICE_COMPILE__
+  float v1[2];
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    const float b = dpp_quad<0xF5>(r[2 * p]);      // quad_perm [1,1,3,3]: even lanes read their right neighbour
+    const float d = dpp_quad<0xF5>(r[2 * p + 1]);
+    v1[p] = box4(r[2 * p], b, r[2 * p + 1], d);
+  }
+  if (py.l1) {
+    const auto r1 = MDC_FRAME_RSRC(py.l1 + f * (l1_bytes / 4), l1_bytes);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1[0]), r1, t.p1byte[0], 0, kStoreAux);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1[1]), r1, t.p1byte[1], 0, kStoreAux);
+  }
+  const float b2 = dpp_quad<0xAA>(v1[0]);  // quad_perm [2,2,2,2]: lane 4k reads lane 4k+2
+  const float d2 = dpp_quad<0xAA>(v1[1]);
+  const float v2 = box4(v1[0], b2, v1[1], d2);
+  if (py.l2) {
+    const auto r2 = MDC_FRAME_RSRC(py.l2 + f * (l2_bytes / 4), l2_bytes);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v2), r2, t.p2byte, 0, kStoreAux);
+  }
+  if ((lane & 3) == 0) s_row[lane >> 2] = v2;
+#endif
+}
+
+// level 3 of frame `f` of this tile from the level-2 rows the waves left in LDS (G = row groups = waves)
+template <int G>
+__device__ __forceinline__ void pyramid_level3(const PyramidOut& py, long long f, uint32_t l3_bytes, const float* s_rows,
+                                               uint32_t p3byte, int tid) {
+#if __HIP_DEVICE_COMPILE__
+  if (py.l3 && tid < 8 * (G / 2)) {
+    const int m = tid >> 3, k = tid & 7;
+    const float* top = s_rows + (2 * m) * 16 + 2 * k;
+    const float* bot = s_rows + (2 * m + 1) * 16 + 2 * k;
+    const float v3 = box4(top[0], top[1], bot[0], bot[1]);
+    const auto r3 = MDC_FRAME_RSRC(py.l3 + f * (l3_bytes / 4), l3_bytes);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v3), r3, p3byte, 0, kStoreAux);
   }
 #endif
 }
@@ -359,11 +426,12 @@ __device__ __forceinline__ void frame_barrier(int rw) {
 
 // Frames [0, nframes) of one tile.  NBUF window buffers, D = NBUF-1 frames staged ahead: the DMA
 // of frame f+D is issued before frame f is computed; one barrier per frame.
-template <bool VIG, bool BLACK, int R, int NT, int NBUF>
+template <bool VIG, bool BLACK, bool PYR, int R, int NT, int NBUF>
 __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* __restrict__ src,
                                             float* __restrict__ dst, uint32_t in_bytes, uint32_t out_bytes,
                                             int nframes, int nch, const uint32_t* __restrict__ chunks,
-                                            unsigned char* s_win, int win_bytes, const float* my_lut, int tid) {
+                                            unsigned char* s_win, int win_bytes, const float* my_lut, int tid,
+                                            const PyramidOut& py, long long f_first, uint32_t p3byte) {
   constexpr int D = NBUF - 1;
   uint32_t goff[R];
 #pragma unroll
@@ -389,13 +457,19 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
   else if (R >= 2 && rw == 2) wait_vm_barrier<(D - 1) * 2>();
   else if (rw == 1) wait_vm_barrier<(D - 1) * 1>();
   else wait_vm_barrier<0>();
+  constexpr int G = NT / 64;  // row groups of the tile = waves
+  float* s_pyr = reinterpret_cast<float*>(s_win + NBUF * win_bytes);  // [2][G][16] level-2 rows (PYR only)
+  const uint32_t l1_bytes = out_bytes / 4, l2_bytes = out_bytes / 16, l3_bytes = out_bytes / 64;
   for (int f = 0; f <= last; f++) {
+    if (PYR && f > 0) pyramid_level3<G>(py, f_first + f - 1, l3_bytes, s_pyr + ((f - 1) & 1) * G * 16, p3byte, tid);
 #if MDC_EXP_SKIP_LOAD
     stage_window<R, NT>(src, in_bytes, w[D], goff, wave);
 #else
     stage_window<R, NT>(src + (long long)min(f + D, last) * in_bytes, in_bytes, w[D], goff, wave);
 #endif
-    tile_compute<VIG, BLACK>(t, w[0], my_lut, dst, out_bytes);
+    float res[4];
+    tile_compute<VIG, BLACK>(t, w[0], my_lut, dst, out_bytes, res);
+    if (PYR) pyramid_levels12(t, res, py, f_first + f, l1_bytes, l2_bytes, s_pyr + ((f & 1) * G + wave) * 16, tid & 63);
     dst += out_bytes / 4;
     frame_barrier<D, R>(rw);  // frame f+1 landed in every wave's part of w[1]; everyone is done reading w[0]
     unsigned char* x = w[0];
@@ -403,13 +477,14 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
     for (int i = 0; i < D; i++) w[i] = w[i + 1];
     w[D] = x;
   }
+  if (PYR) pyramid_level3<G>(py, f_first + last, l3_bytes, s_pyr + (last & 1) * G * 16, p3byte, tid);
 }
 
 // Occupancy is set by LDS (LUT replicas + two window buffers): 3 workgroups of 512 threads or 2 of
 // 960/1024 per CU; the register budget follows from that.
-template <bool VIG, bool BLACK, int NT, int NBUF>
-__global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap_tiled_u8_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,
-                                                            RemapArgs a, TilePlan p, int nframes, int fpb) {
+template <bool VIG, bool BLACK, bool PYR, int NT, int NBUF>
+__global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap_tiled_u8_kernel(
+    const uint8_t* __restrict__ in, float* __restrict__ out, RemapArgs a, TilePlan p, PyramidOut py, int nframes, int fpb) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   float* s_lut = reinterpret_cast<float*>(smem);
   unsigned char* s_win = smem + kLutBytes;
@@ -448,6 +523,9 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap
       yy = a.ry[oidx];
       tp = p.d_taps[oidx];
     }
+    if (PYR && (j & 1) == 0)  // level 1: even lanes, rows oy/2; (whole tiles only, so `inside` holds)
+      t.p1byte[j >> 1] = (lane_x & 1) ? kOutside : (uint32_t)((oy >> 1) * (a.out_w >> 1) + (ox >> 1)) * 4u;
+    if (PYR && j == 0) t.p2byte = (lane_x & 3) ? kOutside : (uint32_t)((oy >> 2) * (a.out_w >> 2) + (ox >> 2)) * 4u;
     t.black[j] = xx < 0;  // outputs outside the image count as black: their taps read window byte 0, their store is dropped
     t.bl[j] = bilin_of(t.black[j] ? 0.f : xx, t.black[j] ? 0.f : yy);
     t.off0[j] = (int)(tp & 0xffffu);
@@ -467,20 +545,34 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap
   const uint8_t* src = in + (long long)f0 * in_bytes;
   float* dst = out + (long long)f0 * (out_bytes / 4);
   const int nch = p.d_nch[tile];
-  if (nch == 0) {  // every output of the tile is black (or outside): zeros, no staging
+  uint32_t p3byte = kOutside;  // level 3: thread u < 8*(rows/8) owns pixel (u%8, u/8) of the tile's 8 x rows/8 block
+  if (PYR && tid < 8 * (NT / 128))
+    p3byte = (uint32_t)(((tile / p.tiles_x) * (NT / 128) + (tid >> 3)) * (a.out_w >> 3) + (tile % p.tiles_x) * 8 + (tid & 7)) * 4u;
+  if (nch == 0) {  // every output of the tile is black (or outside): zeros (on every level), no staging
 #if __HIP_DEVICE_COMPILE__
     for (int f = 0; f < nf; f++, dst += out_bytes / 4) {
       const auto ro = MDC_FRAME_RSRC(dst, out_bytes);
 #pragma unroll
       for (int j = 0; j < 4; j++) __builtin_amdgcn_raw_buffer_store_b32(0u, ro, t.obyte[j], 0, 0);
+      if (PYR) {
+        const long long fa = (long long)f0 + f;
+        if (py.l1) {
+          const auto r1 = MDC_FRAME_RSRC(py.l1 + fa * (out_bytes / 16), out_bytes / 4);
+          __builtin_amdgcn_raw_buffer_store_b32(0u, r1, t.p1byte[0], 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(0u, r1, t.p1byte[1], 0, 0);
+        }
+        if (py.l2) __builtin_amdgcn_raw_buffer_store_b32(0u, MDC_FRAME_RSRC(py.l2 + fa * (out_bytes / 64), out_bytes / 16), t.p2byte, 0, 0);
+        if (py.l3) __builtin_amdgcn_raw_buffer_store_b32(0u, MDC_FRAME_RSRC(py.l3 + fa * (out_bytes / 256), out_bytes / 64), p3byte, 0, 0);
+      }
     }
 #endif
     return;
   }
   const int rounds = (nch + NT - 1) / NT;  // workgroup-uniform
   const uint32_t* chunks = p.d_chunks + (size_t)tile * p.chunk_cap;
-#define MDC_TILE_RUN(R_) \
-  tile_frames<VIG, BLACK, R_, NT, NBUF>(t, src, dst, in_bytes, out_bytes, nf, nch, chunks, s_win, p.win_bytes, my_lut, tid)
+#define MDC_TILE_RUN(R_)                                                                                              \
+  tile_frames<VIG, BLACK, PYR, R_, NT, NBUF>(t, src, dst, in_bytes, out_bytes, nf, nch, chunks, s_win, p.win_bytes, \
+                                             my_lut, tid, py, (long long)f0, p3byte)
   if (rounds == 1) MDC_TILE_RUN(1);
   else if (rounds == 2) MDC_TILE_RUN(2);
   else MDC_TILE_RUN(kTileMaxChunks);
@@ -531,6 +623,7 @@ inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 }  // namespace
 
 size_t tiled_lds_bytes(int win_bytes, int nbuf) { return (size_t)kLutBytes + (size_t)nbuf * win_bytes; }
+size_t tiled_pyramid_lds_bytes(int tile_h) { return (size_t)2 * (tile_h / 4) * 16 * sizeof(float); }
 
 hipError_t launch_unmap(const uint8_t* d_in, float* d_out, const float* d_lut, const float* d_vinv, int64_t npix,
                         int64_t nframes, int fpb, hipStream_t s) {
@@ -566,54 +659,61 @@ hipError_t launch_remap_gather_f32(const float* d_in, float* d_out, const RemapA
   return hipGetLastError();
 }
 
-template <bool VIG, bool BLACK, int NT, int NBUF>
-static hipError_t launch_tiled_variant(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
-                                       int64_t nframes, int fpb, hipStream_t s) {
-  dim3 grid(p.n_blocks, ceil_div(nframes, fpb));
-  const size_t lds = tiled_lds_bytes(p.win_bytes, NBUF);
+struct TiledLaunch {
+  const uint8_t* d_in;
+  float* d_out;
+  RemapArgs a;
+  TilePlan p;
+  PyramidOut py;
+  int64_t nframes;
+  int fpb;
+  hipStream_t s;
+};
+
+template <bool VIG, bool BLACK, bool PYR, int NT, int NBUF>
+static hipError_t launch_tiled_variant(const TiledLaunch& l) {
+  dim3 grid(l.p.n_blocks, ceil_div(l.nframes, l.fpb));
+  const size_t lds = tiled_lds_bytes(l.p.win_bytes, NBUF) + (PYR ? tiled_pyramid_lds_bytes(l.p.tile_h) : 0);
   if (lds > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&remap_tiled_u8_kernel<VIG, BLACK, NT, NBUF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&remap_tiled_u8_kernel<VIG, BLACK, PYR, NT, NBUF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  remap_tiled_u8_kernel<VIG, BLACK, NT, NBUF><<<grid, NT, lds, s>>>(d_in, d_out, a, p, (int)nframes, fpb);
+  remap_tiled_u8_kernel<VIG, BLACK, PYR, NT, NBUF><<<grid, NT, lds, l.s>>>(l.d_in, l.d_out, l.a, l.p, l.py, (int)l.nframes, l.fpb);
   return hipGetLastError();
 }
 
-template <bool VIG, bool BLACK, int NT>
-static hipError_t launch_tiled_buf(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
-                                   int64_t nframes, int fpb, hipStream_t s) {
-  switch (p.nbuf) {
-    case 2: return launch_tiled_variant<VIG, BLACK, NT, 2>(d_in, d_out, a, p, nframes, fpb, s);
-    case 3: return launch_tiled_variant<VIG, BLACK, NT, 3>(d_in, d_out, a, p, nframes, fpb, s);
-    case 4: return launch_tiled_variant<VIG, BLACK, NT, 4>(d_in, d_out, a, p, nframes, fpb, s);
+template <bool VIG, bool BLACK, bool PYR, int NT>
+static hipError_t launch_tiled_buf(const TiledLaunch& l) {
+  switch (l.p.nbuf) {
+    case 2: return launch_tiled_variant<VIG, BLACK, PYR, NT, 2>(l);
+    case 3: return launch_tiled_variant<VIG, BLACK, PYR, NT, 3>(l);
+    case 4: return launch_tiled_variant<VIG, BLACK, PYR, NT, 4>(l);
   }
   return hipErrorInvalidValue;
 }
 
 template <bool VIG, bool BLACK>
-static hipError_t launch_tiled_nt(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
-                                  int64_t nframes, int fpb, hipStream_t s) {
-  switch (p.tile_h) {
-    case 16: return launch_tiled_buf<VIG, BLACK, 256>(d_in, d_out, a, p, nframes, fpb, s);
-    case 32: return launch_tiled_buf<VIG, BLACK, 512>(d_in, d_out, a, p, nframes, fpb, s);
-    case 60: return launch_tiled_buf<VIG, BLACK, 960>(d_in, d_out, a, p, nframes, fpb, s);
-    case 64: return launch_tiled_buf<VIG, BLACK, 1024>(d_in, d_out, a, p, nframes, fpb, s);
+static hipError_t launch_tiled_nt(const TiledLaunch& l) {
+  const bool pyr = l.py.l1 || l.py.l2 || l.py.l3;
+  switch (l.p.tile_h) {
+    case 16: return pyr ? launch_tiled_buf<VIG, BLACK, true, 256>(l) : launch_tiled_buf<VIG, BLACK, false, 256>(l);
+    case 32: return pyr ? launch_tiled_buf<VIG, BLACK, true, 512>(l) : launch_tiled_buf<VIG, BLACK, false, 512>(l);
+    case 60: return pyr ? hipErrorInvalidValue : launch_tiled_buf<VIG, BLACK, false, 960>(l);  // 15 row groups: no level-3 pairs
+    case 64: return pyr ? launch_tiled_buf<VIG, BLACK, true, 1024>(l) : launch_tiled_buf<VIG, BLACK, false, 1024>(l);
   }
   return hipErrorInvalidValue;
 }
 
 hipError_t launch_remap_tiled_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
-                                 int64_t nframes, int fpb, hipStream_t s) {
+                                 int64_t nframes, int fpb, hipStream_t s, float* d_l1, float* d_l2, float* d_l3) {
   if (nframes <= 0) return hipSuccess;
   // frames are addressed through 32-bit buffer offsets
   if ((int64_t)a.in_w * a.in_h >= (int64_t)kOutside || (int64_t)a.out_w * a.out_h * 4 >= (int64_t)kOutside)
     return hipErrorInvalidValue;
-  if (a.vinv)
-    return p.has_black ? launch_tiled_nt<true, true>(d_in, d_out, a, p, nframes, fpb, s)
-                       : launch_tiled_nt<true, false>(d_in, d_out, a, p, nframes, fpb, s);
-  return p.has_black ? launch_tiled_nt<false, true>(d_in, d_out, a, p, nframes, fpb, s)
-                     : launch_tiled_nt<false, false>(d_in, d_out, a, p, nframes, fpb, s);
+  const TiledLaunch l{d_in, d_out, a, p, PyramidOut{d_l1, d_l2, d_l3}, nframes, fpb, s};
+  if (a.vinv) return p.has_black ? launch_tiled_nt<true, true>(l) : launch_tiled_nt<true, false>(l);
+  return p.has_black ? launch_tiled_nt<false, true>(l) : launch_tiled_nt<false, false>(l);
 }
 
 hipError_t launch_pyramid_level(const float* d_src, float* d_dst, int w, int h, int64_t nframes, hipStream_t s) {

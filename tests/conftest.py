@@ -52,6 +52,8 @@ CAMERAS = {
     "small_pinhole": (("0.5 0.6 0.5 0.5 0", "320 256", "crop", "130 70"), 16),
     # ragged: input width not a multiple of 16 (gather kernel), odd output size
     "ragged": (("0.349153 0.436593 0.493140 0.499021 0.933271", "322 250", "0.4 0.53 0.5 0.5 0", "157 93"), 16),
+    # output made of whole 64 x {16,32,64} tiles (fused pyramid path), black border pixels
+    "pyr_whole_black": (("0.349153 0.436593 0.493140 0.499021 0.933271", "320 256", "full", "192 128"), 16),
     # magnifying remap (output larger than input)
     "upsample": (("0.349153 0.436593 0.493140 0.499021 0.5", "160 128", "crop", "320 256"), 16),
 }

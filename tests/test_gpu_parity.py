@@ -92,7 +92,7 @@ def test_tiled_and_gather_kernels_agree(name, setups, oracle, torch_cuda):
     s.ctx.set_option(capi.OPT_TILE_ROWS, 16)
     info = s.ctx.info()
     kernels = [capi.KERNEL_GATHER] + ([capi.KERNEL_TILED] if info.tiled else [])
-    if name not in ("ragged", "small_full_black"):  # width % 16 != 0 / windows too tall for LDS staging
+    if name not in ("ragged", "small_full_black", "pyr_whole_black"):  # width % 16 != 0 / windows too large for 64x16 tiles
         assert info.tiled, "tiled kernel should be plannable for %s" % name
     for k in kernels:
         s.ctx.set_option(capi.OPT_KERNEL, k)
@@ -241,6 +241,38 @@ def test_pyramid(torch_cuda, oracle):
             got = lv[l].view(n, -1)[f].cpu().numpy()
             assert bits_equal(got, want), (f, l)
             src, cw, ch = want, cw // 2, ch // 2
+
+
+@pytest.mark.parametrize("name", ["pyr_whole_black", "upsample", "small_explicit"])
+def test_process_pyramid_fused(name, setups, oracle, torch_cuda):
+    """getImage + pyramid in one call (config 5): levels 1..3 out of the remap kernel where the output is
+    made of whole tiles, one pass per level otherwise; both must equal the oracle's level chain bit for bit."""
+    from mono_dataset_code_amd import capi
+
+    torch = torch_cuda
+    s = setups(name)
+    frames = np.stack(make_frames(s.W, s.H, n_noise=4))  # incl. saturated blobs -> NaN regions
+    n = len(frames)
+    flags = capi.RECTIFY | capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED
+    base_want = [s.want(oracle, f, 1, 1, 1, 1) for f in frames]
+    d_in = torch.from_numpy(frames).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    for rows, levels, fpb in ((32, 4, 0), (16, 4, 3), (64, 3, 0), (60, 4, 0), (32, 5, 2), (32, 1, 0)):
+        s.ctx.set_option(capi.OPT_TILE_ROWS, rows)
+        s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, fpb)
+        d_base = torch.full((n, s.w * s.h), -7.0, dtype=torch.float32, device="cuda")
+        lv = [torch.full((n * (s.w >> l) * (s.h >> l),), -7.0, dtype=torch.float32, device="cuda") for l in range(1, levels)]
+        s.ctx.process_pyramid_batch(d_in.data_ptr(), d_base.data_ptr(), levels, [t.data_ptr() for t in lv], n, flags, st)
+        torch.cuda.synchronize()
+        for f in range(n):
+            assert bits_equal(d_base[f].cpu().numpy(), base_want[f]), (name, rows, levels, f)
+            src, cw, ch = base_want[f], s.w, s.h
+            for l in range(levels - 1):
+                want = oracle.pyramid_level(src, cw, ch)
+                assert bits_equal(lv[l].view(n, -1)[f].cpu().numpy(), want), (name, rows, levels, f, l + 1)
+                src, cw, ch = want, cw // 2, ch // 2
+    s.ctx.set_option(capi.OPT_TILE_ROWS, 32)
+    s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, 0)
 
 
 def test_table_blob_roundtrip(setups, oracle, torch_cuda):

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Copy the judged artefacts of tools/profile_bench.sh runs from gpurun_out/ (scratch) into
+profiles/ (tracked) and refresh profiles/hbm_traffic.json, which bench.py reads for
+roofline.traffic.  usage: tools/collect_profiles.py <round-tag, e.g. r01b>"""
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+KERNEL_OF = {"fused": ("fused_tiled", "remap_tiled_u8_kernel", 1024), "unmap": ("unmap", "unmap_xpose_kernel", 512),
+             "pyramid": ("pyramid_remap", "remap_tiled_u8_kernel", 256)}
+traffic_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
+for wl, (key, kname, frames) in KERNEL_OF.items():
+    d = os.path.join(ROOT, "gpurun_out", "profile_%s_%s" % (tag, wl))
+    if not os.path.isdir(d):
+        continue
+    shutil.copy(os.path.join(d, "summary.json"), os.path.join(ROOT, "profiles", "%s_%s_summary.json" % (tag, wl)))
+    for f in glob.glob(d + "/stats/**/*kernel_stats.csv", recursive=True):
+        shutil.copy(f, os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, wl)))
+    s = json.load(open(os.path.join(d, "summary.json")))
+    args = s.get("bench_args", "").split()
+    if "--frames" in args:
+        frames = int(args[args.index("--frames") + 1])
+    for k, v in s["kernels"].items():
+        if k.startswith(kname) and "hbm_bytes_per_launch" in v:
+            traffic[key] = {
+                "bytes_per_frame": v["hbm_bytes_per_launch"] / frames,
+                "read_bytes_per_frame": v["hbm_read_bytes_per_launch"] / frames,
+                "write_bytes_per_frame": v["hbm_write_bytes_per_launch"] / frames,
+                "kernel": k, "avg_us_under_profiler": v["avg_us"], "frames_per_launch": frames,
+                "source": "profiles/%s_%s_summary.json" % (tag, wl),
+                "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 half-count, verified profiles/r01_fetch_calibration.txt) + WRITE_SIZE KiB x1024",
+            }
+json.dump(traffic, open(traffic_path, "w"), indent=1)
+print(json.dumps(traffic, indent=1))
