@@ -124,6 +124,23 @@ int mdc_undistort_host_u8(mdc_ctx* ctx, const uint8_t* input, float* output, int
  * `out` holds out_w*out_h floats with MDC_RECTIFY, else in_w*in_h. */
 int mdc_process_host(mdc_ctx* ctx, const uint8_t* raw, float* out, unsigned flags);
 
+/* ---- host-pointer, many frames: a sequence through PCIe ---------------------- */
+
+/* Page-locked host memory for frames and results (hipHostMalloc / hipHostFree): copies from and
+ * to it run asynchronously at PCIe rate, so a reader that keeps its decoded frames and its
+ * ExposureImage::image buffers (src/ExposureImage.h:45) in such memory overlaps transfers with
+ * the kernels.  NULL on failure. */
+void* mdc_host_alloc(size_t bytes);
+void mdc_host_free(void* p);
+
+/* DatasetReader::getImage (src/BenchmarkDatasetReader.h:207-241, after decode) for nframes frames
+ * in one call: raw[i] -> out[i], results identical to nframes mdc_process_host calls.  Frames go
+ * through the GPU in chunks on two streams, so the upload of one chunk, the kernel of the next and
+ * the download of the previous one overlap.  Any host memory works; pageable buffers make the HIP
+ * runtime stage every copy (a few GB/s), mdc_host_alloc'ed ones reach the PCIe rate.  Blocking. */
+int mdc_process_frames_host(mdc_ctx* ctx, const uint8_t* const* raw, float* const* out, int64_t nframes,
+                            unsigned flags);
+
 /* ---- device-pointer, batched: the throughput path --------------------------- */
 
 /* unMapImage over nframes back-to-back frames (in: nframes*w*h u8; out: same count f32). */

@@ -25,6 +25,7 @@ OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 HIP_SYMBOLS = [
     "mdc_create", "mdc_destroy", "mdc_last_error", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
     "mdc_set_remap", "mdc_unmap_host", "mdc_undistort_host_f32", "mdc_undistort_host_u8", "mdc_process_host",
+    "mdc_host_alloc", "mdc_host_free", "mdc_process_frames_host",
     "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
     "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device", "mdc_synth_frames_device", "mdc_export_tables", "mdc_import_tables",
     "mdc_synchronize",
@@ -88,6 +89,11 @@ def hip_lib():
         L.mdc_undistort_host_f32.argtypes = [_vp, _vp, _vp, _i, _i]
         L.mdc_undistort_host_u8.argtypes = [_vp, _vp, _vp, _i, _i]
         L.mdc_process_host.argtypes = [_vp, _vp, _vp, C.c_uint]
+        L.mdc_host_alloc.argtypes = [_sz]
+        L.mdc_host_alloc.restype = _vp
+        L.mdc_host_free.argtypes = [_vp]
+        L.mdc_host_free.restype = None
+        L.mdc_process_frames_host.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), _i64, C.c_uint]
         L.mdc_unmap_batch_device.argtypes = [_vp, _vp, _vp, _i64, C.c_uint, _vp]
         L.mdc_process_batch_device.argtypes = [_vp, _vp, _vp, _i64, C.c_uint, _vp]
         L.mdc_undistort_batch_device_f32.argtypes = [_vp, _vp, _vp, _i64, _vp]
@@ -98,7 +104,7 @@ def hip_lib():
         L.mdc_import_tables.argtypes = [_vp, _vp, _sz]
         L.mdc_synchronize.argtypes = [_vp]
         for n in HIP_SYMBOLS:
-            if n not in ("mdc_destroy", "mdc_last_error"):
+            if n not in ("mdc_destroy", "mdc_last_error", "mdc_host_alloc", "mdc_host_free"):
                 getattr(L, n).restype = _i
         _hip = L
     return _hip
@@ -160,6 +166,25 @@ def _np_ptr(a):
 def _f32(a):
     a = np.ascontiguousarray(a, dtype=np.float32)
     return a
+
+
+class PinnedArray:
+    """A numpy view of page-locked host memory (mdc_host_alloc); keep the object alive while the view is used."""
+
+    def __init__(self, shape, dtype):
+        self._L = hip_lib()
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = self._L.mdc_host_alloc(self.nbytes)
+        if not self._p:
+            raise MemoryError("mdc_host_alloc(%d) failed" % self.nbytes)
+        buf = (C.c_char * self.nbytes).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self._L.mdc_host_free(self._p)
+            self._p = None
 
 
 class Context:
@@ -235,6 +260,14 @@ class Context:
         if check:
             self._chk(rc)
         return rc
+
+    def process_frames_host(self, raws, outs, flags):
+        """raws / outs: sequences of numpy arrays (u8 frames, f32 results), one pair per frame."""
+        n = len(raws)
+        assert len(outs) == n
+        a = (_vp * max(1, n))(*[_np_ptr(r) for r in raws])
+        b = (_vp * max(1, n))(*[_np_ptr(o) for o in outs])
+        self._chk(self._L.mdc_process_frames_host(self._h, a, b, n, flags))
 
     # device-pointer batched calls (addresses as ints)
     def unmap_batch(self, d_in, d_out, nframes, flags, stream=0):

@@ -59,6 +59,13 @@ struct mdc_ctx {
   int opt_order = MDC_ORDER_BANDS;
   int opt_nbuf = 0;  // 0 = automatic
 
+  // pipelined host-frame path (mdc_process_frames_host): two chunk slots, each with its own stream
+  hipStream_t pipe_stream[2] = {nullptr, nullptr};
+  hipEvent_t pipe_done[2] = {nullptr, nullptr};
+  uint8_t* d_pipe_in[2] = {nullptr, nullptr};
+  float* d_pipe_out[2] = {nullptr, nullptr};
+  size_t pipe_in_cap = 0, pipe_out_cap = 0;
+
   // staging for the host-pointer calls
   void* d_stage_in = nullptr;
   size_t stage_in_cap = 0;
@@ -410,9 +417,14 @@ void mdc_destroy(mdc_ctx* c) {
     DeviceGuard dg(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_plan(c);
-    void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_stage_in, c->d_stage_out};
+    void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_stage_in, c->d_stage_out,
+                    c->d_pipe_in[0], c->d_pipe_in[1], c->d_pipe_out[0], c->d_pipe_out[1]};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
+    for (int k = 0; k < 2; k++) {
+      if (c->pipe_done[k]) (void)hipEventDestroy(c->pipe_done[k]);
+      if (c->pipe_stream[k]) (void)hipStreamDestroy(c->pipe_stream[k]);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
   }
   delete c;
@@ -723,6 +735,67 @@ int mdc_process_host(mdc_ctx* c, const uint8_t* raw, float* out, unsigned flags)
   MDC_HIP(c, hipMemcpyAsync(out, c->d_stage_out, n_out * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   MDC_HIP(c, hipStreamSynchronize(c->stream));
   return MDC_OK;
+}
+
+// ---- host-pointer, many frames: copies and kernels overlapped ------------------------------
+
+void* mdc_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void mdc_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
+int mdc_process_frames_host(mdc_ctx* c, const uint8_t* const* raw, float* const* out, int64_t nframes, unsigned flags) {
+  if (!c) return MDC_ERR_ARG;
+  if (nframes < 0 || (nframes > 0 && (!raw || !out))) return fail(c, MDC_ERR_ARG, "mdc_process_frames_host: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  const bool rect = (flags & MDC_RECTIFY) != 0;
+  if (rect && !c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
+  const int iw = (rect || c->in_w <= 0) ? c->rm_in_w : c->in_w, ih = (rect || c->in_h <= 0) ? c->rm_in_h : c->in_h;
+  if (iw <= 0 || ih <= 0) return fail(c, MDC_ERR_STATE, "frame size unknown");
+  const size_t n_in = (size_t)iw * ih;
+  const size_t n_out = rect ? (size_t)c->out_w * c->out_h : n_in;
+  for (int64_t i = 0; i < nframes; i++)
+    if (!raw[i] || !out[i]) return fail(c, MDC_ERR_ARG, "mdc_process_frames_host: frame %lld has a NULL buffer", (long long)i);
+  constexpr int kChunk = 16;  // frames per slot: one kernel launch, 2 x 16 async copies
+  if (c->pipe_in_cap < kChunk * n_in || c->pipe_out_cap < kChunk * n_out * sizeof(float) || !c->pipe_stream[0]) {
+    for (int k = 0; k < 2; k++) {
+      if (c->pipe_stream[k]) MDC_HIP(c, hipStreamSynchronize(c->pipe_stream[k]));
+      if (!c->pipe_stream[k]) MDC_HIP(c, hipStreamCreateWithFlags(&c->pipe_stream[k], hipStreamNonBlocking));
+      if (!c->pipe_done[k]) MDC_HIP(c, hipEventCreateWithFlags(&c->pipe_done[k], hipEventDisableTiming));
+      if (c->d_pipe_in[k]) (void)hipFree(c->d_pipe_in[k]);
+      if (c->d_pipe_out[k]) (void)hipFree(c->d_pipe_out[k]);
+      c->d_pipe_in[k] = nullptr;
+      c->d_pipe_out[k] = nullptr;
+      MDC_HIP(c, hipMalloc(&c->d_pipe_in[k], kChunk * n_in));
+      MDC_HIP(c, hipMalloc(&c->d_pipe_out[k], kChunk * n_out * sizeof(float)));
+    }
+    c->pipe_in_cap = kChunk * n_in;
+    c->pipe_out_cap = kChunk * n_out * sizeof(float);
+  }
+  // chunk k runs entirely on stream k%2 (H2D, kernel, D2H in order); the two streams overlap one
+  // chunk's copies with the other's kernel.  Re-using a slot waits for its previous chunk.
+  int rc = MDC_OK;
+  for (int64_t f0 = 0, k = 0; f0 < nframes && rc == MDC_OK; f0 += kChunk, k++) {
+    const int slot = (int)(k & 1);
+    hipStream_t s = c->pipe_stream[slot];
+    const int n = (int)std::min<int64_t>(kChunk, nframes - f0);
+    if (k >= 2) MDC_HIP(c, hipEventSynchronize(c->pipe_done[slot]));
+    for (int i = 0; i < n; i++)
+      MDC_HIP(c, hipMemcpyAsync(c->d_pipe_in[slot] + (size_t)i * n_in, raw[f0 + i], n_in, hipMemcpyHostToDevice, s));
+    rc = enqueue_process(c, c->d_pipe_in[slot], c->d_pipe_out[slot], n, flags, s);
+    if (rc != MDC_OK) break;
+    for (int i = 0; i < n; i++)
+      MDC_HIP(c, hipMemcpyAsync(out[f0 + i], c->d_pipe_out[slot] + (size_t)i * n_out, n_out * sizeof(float),
+                                hipMemcpyDeviceToHost, s));
+    MDC_HIP(c, hipEventRecord(c->pipe_done[slot], s));
+  }
+  for (int k = 0; k < 2; k++) MDC_HIP(c, hipStreamSynchronize(c->pipe_stream[k]));
+  return rc;
 }
 
 // ---- table hand-over ------------------------------------------------------------------

@@ -275,6 +275,37 @@ def test_process_pyramid_fused(name, setups, oracle, torch_cuda):
     s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, 0)
 
 
+@pytest.mark.parametrize("name", ["small_crop", "ragged"])
+def test_process_frames_host_pipeline(name, setups, oracle):
+    """Many host frames in one call (chunks on two streams): equal to the oracle frame by frame, with
+    pageable and with page-locked buffers, for counts around the chunk size and all flag modes that matter."""
+    from mono_dataset_code_amd import capi
+
+    s = setups(name)
+    base = make_frames(s.W, s.H, n_noise=5)
+    frames = [base[i % len(base)] for i in range(37)]
+    for rect, g, v, o in ((1, 1, 1, 1), (0, 1, 1, 0), (1, 0, 0, 0)):
+        flags = (capi.RECTIFY * rect) | (capi.GAMMA * g) | (capi.VIGNETTE * v) | (capi.KILL_OVEREXPOSED * o)
+        n_out = s.w * s.h if rect else s.W * s.H
+        want = [s.want(oracle, f, rect, g, v, o) for f in base]
+        for n in (0, 1, 16, 17, 37):
+            outs = [np.full(n_out, -7.0, np.float32) for _ in range(n)]
+            s.ctx.process_frames_host(frames[:n], outs, flags)
+            for i in range(n):
+                assert bits_equal(outs[i], want[i % len(base)]), (name, rect, g, v, o, n, i)
+    # page-locked buffers from the library's allocator
+    n = 20
+    pin_in = capi.PinnedArray((n, s.W * s.H), np.uint8)
+    pin_out = capi.PinnedArray((n, s.w * s.h), np.float32)
+    for i in range(n):
+        pin_in.array[i] = frames[i]
+    pin_out.array[:] = -7.0
+    s.ctx.process_frames_host([pin_in.array[i] for i in range(n)], [pin_out.array[i] for i in range(n)], 15)
+    want = [s.want(oracle, f, 1, 1, 1, 1) for f in base]
+    for i in range(n):
+        assert bits_equal(pin_out.array[i], want[i % len(base)]), (name, "pinned", i)
+
+
 def test_table_blob_roundtrip(setups, oracle, torch_cuda):
     """export -> import into a second context (what the RCCL broadcast carries)."""
     from mono_dataset_code_amd import capi

@@ -39,8 +39,31 @@ def two_calls(i):  # exactly what DatasetReader::getImage does with the drop-in 
     fov.undistort(tmp, out)
 
 
+M = 256  # frames per mdc_process_frames_host call
+page_in = [frames[i % 8].copy() for i in range(M)]
+page_out = [np.zeros(w * h, np.float32) for _ in range(M)]
+pin_in = capi.PinnedArray((M, W * H), np.uint8)
+pin_out = capi.PinnedArray((M, w * h), np.float32)
+for i in range(M):
+    pin_in.array[i] = frames[i % 8]
+
+
+def many(raws, outs):
+    ctx.process_frames_host(raws, outs, 15)  # warm
+    t0 = time.perf_counter()
+    for _ in range(4):
+        ctx.process_frames_host(raws, outs, 15)
+    dt = time.perf_counter() - t0
+    return 4 * M / dt, 4 * M * W * H / dt / 1e6
+
+
 print("host path, 1280x1024 -> 640x480, g+v+o, %d frames each" % N, file=sys.stderr)
 for name, fn in (("unMapImage + undistort<float> (two class calls, W*H float round trip)", two_calls),
                  ("mdc_process_host (fused, one call)", lambda i: ctx.process_host(frames[i % 8], out, 15))):
     fps, mpix = rate(fn)
+    print("%-75s %8.1f frames/s  %9.1f Mpix/s" % (name, fps, mpix), file=sys.stderr)
+for name, (raws, outs) in (("mdc_process_frames_host, %d frames per call, pageable buffers" % M, (page_in, page_out)),
+                           ("mdc_process_frames_host, %d frames per call, mdc_host_alloc buffers" % M,
+                            ([pin_in.array[i] for i in range(M)], [pin_out.array[i] for i in range(M)]))):
+    fps, mpix = many(raws, outs)
     print("%-75s %8.1f frames/s  %9.1f Mpix/s" % (name, fps, mpix), file=sys.stderr)
