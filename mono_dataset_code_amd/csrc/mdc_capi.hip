@@ -58,6 +58,7 @@ struct mdc_ctx {
   int opt_tile_h = 32;
   int opt_order = MDC_ORDER_BANDS;
   int opt_nbuf = 0;  // 0 = automatic
+  int opt_interleave = 0;
 
   // pipelined host-frame path (mdc_process_frames_host): two chunk slots, each with its own stream
   hipStream_t pipe_stream[2] = {nullptr, nullptr};
@@ -356,7 +357,7 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
     return fail(c, MDC_ERR_STATE, "tiled kernel requested but not plannable for this remap / alignment");
   if (use_tiled) {
     TilePlan p{c->d_chunks, c->d_nch, c->d_taps, c->d_order, c->n_blocks, c->n_tiles, c->tiles_x, c->tile_h, c->chunk_cap,
-               c->win_bytes, c->nbuf, c->n_black > 0};
+               c->win_bytes, c->nbuf, c->n_black > 0, c->opt_interleave != 0};
     const int fpb = frames_per_block(c, nframes, c->n_blocks);
     const bool fuse_pyr = pyr && c->tile_h != 60 && c->out_w % kTileW == 0 && c->out_h % c->tile_h == 0;
     MDC_HIP(c, launch_remap_tiled_u8(d_in, d_out, a, p, nframes, fpb, s, fuse_pyr ? pyr[0] : nullptr,
@@ -453,6 +454,9 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
       MDC_HIP(c, hipDeviceSynchronize());
       return plan_tiles(c);
     }
+    case MDC_OPT_FRAME_INTERLEAVE:
+      c->opt_interleave = value != 0;
+      return MDC_OK;
     case MDC_OPT_WINDOW_BUFFERS: {
       if (value != 0 && (value < 2 || value > 4)) return fail(c, MDC_ERR_ARG, "window buffers must be 0 (auto) or 2..4");
       if (value == c->opt_nbuf) return MDC_OK;

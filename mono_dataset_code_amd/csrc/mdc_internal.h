@@ -39,6 +39,7 @@ struct TilePlan {
   int win_bytes;   // LDS bytes of one window buffer: 16 * max nch, rounded up to 1 KiB
   int nbuf;        // window buffers per workgroup (2..4): nbuf-1 frames are staged ahead
   bool has_black;  // some output carries the (-1,-1) sentinel
+  bool interleave; // frame groups take every G-th frame instead of fpb consecutive ones
 };
 
 // out[f][i] = lut[in[f][i]] (* vinv[i]) over nframes frames of npix pixels.

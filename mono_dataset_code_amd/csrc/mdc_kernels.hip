@@ -27,7 +27,8 @@ namespace mdc {
 namespace {
 
 constexpr int kLutBytes = 256 * kLutRep * 4;
-// Build-time experiment switches (tools/sweep.py --lib ...; defaults are the shipped configuration).
+// Build-time experiment switches (mono_dataset_code_amd/build.py:build_variant + tools/sweep.py --libs for an
+// in-process A/B; defaults are the shipped configuration).
 #ifndef MDC_EXP_LOAD_NT
 #define MDC_EXP_LOAD_NT 0   // staging loads: plain (L2-allocating) -- neighbouring tiles re-use halo lines; nt measured slower
 #endif
@@ -42,22 +43,24 @@ constexpr int kLutBytes = 256 * kLutRep * 4;
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // Replicate the 256-entry LUT kLutRep times so that lane l reads replica l%32:
 // word address b*32 + (l&31) lies in bank l&31 for every byte value b, i.e. a
-// data-dependent table lookup with zero LDS bank conflicts.
+// data-dependent table lookup with zero LDS bank conflicts.  Entry e occupies words
+// [32e, 32e+32): eight 16-byte stores of (v,v,v,v).
 template <int NT>
 __device__ __forceinline__ void fill_lut(float* s_lut, const float* __restrict__ lut, int tid) {
-#pragma unroll 4
-  for (int i = tid; i < 256 * kLutRep; i += NT) s_lut[i] = lut[i / kLutRep];
+  for (int i = tid; i < 256 * (kLutRep / 4); i += NT) {
+    const float v = lut[i / (kLutRep / 4)];
+    reinterpret_cast<f32x4*>(s_lut)[i] = f32x4{v, v, v, v};
+  }
 }
 
 // ----------------------------------------------------------------------------
 // unMapImage, vector path: npix % 4 == 0, 4-byte aligned bases.
 // A workgroup owns 4096 consecutive pixels and loops over its frames.
 // ----------------------------------------------------------------------------
-// unMapImage with wave-contiguous dword stores (dword stores reach a higher write rate on this
+// Wave-contiguous dword stores (dword stores reach a higher write rate on this
 // memory system than 16-byte ones, tools/hbm_mix.hip).  The raw frame is still read 4 pixels per
 // lane (one u32, 256 contiguous bytes per wave-instruction); a wave-private 256-byte LDS scratch
 // per access turns "lane t holds pixels 4t..4t+3" into "lane t holds pixels t, t+64, t+128, t+192"
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void unmap_xpose_kernel(const uint8_t* __restr
                                                           const float* __restrict__ lut,
                                                           const float* __restrict__ vinv, long long npix, int nframes,
                                                           int fpb) {
-  __shared__ float s_lut[256 * kLutRep];
+  __shared__ __attribute__((aligned(16))) float s_lut[256 * kLutRep];
   __shared__ uint32_t s_raw[4][4][64];  // [wave][access][lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   fill_lut<256>(s_lut, lut, tid);
@@ -260,7 +263,6 @@ __global__ __launch_bounds__(256) void remap_gather_f32_kernel(const float* __re
 // source-window halo lines, which then hit in the same L2.  Speed only --
 // correctness does not depend on placement.
 // ----------------------------------------------------------------------------
-typedef const __attribute__((address_space(3))) unsigned char* lds_u8_ptr;
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 constexpr uint32_t kRsrcWord3 = 0x00020000u;  // gfx9 raw buffer: 32-bit data format, no swizzle
@@ -431,8 +433,11 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
                                             float* __restrict__ dst, uint32_t in_bytes, uint32_t out_bytes,
                                             int nframes, int nch, const uint32_t* __restrict__ chunks,
                                             unsigned char* s_win, int win_bytes, const float* my_lut, int tid,
-                                            const PyramidOut& py, long long f_first, uint32_t p3byte) {
+                                            const PyramidOut& py, long long f_first, int fstep, uint32_t p3byte) {
+  // iteration i works on frame f_first + i*fstep; src / dst point at that workgroup's first frame
   constexpr int D = NBUF - 1;
+  const long long in_step = (long long)fstep * in_bytes;
+  const long long out_step = (long long)fstep * (out_bytes / 4);
   uint32_t goff[R];
 #pragma unroll
   for (int k = 0; k < R; k++) goff[k] = chunks[tid + k * NT];  // kOutside past the window
@@ -449,7 +454,7 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
 #if MDC_EXP_SKIP_LOAD
     stage_window<R, NT>(src, in_bytes, w[d], goff, wave);
 #else
-    stage_window<R, NT>(src + (long long)min(d, last) * in_bytes, in_bytes, w[d], goff, wave);
+    stage_window<R, NT>(src + min(d, last) * in_step, in_bytes, w[d], goff, wave);
 #endif
   }
   // frame 0 landed: only the D-1 later DMA groups may still be in flight
@@ -461,38 +466,47 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
   float* s_pyr = reinterpret_cast<float*>(s_win + NBUF * win_bytes);  // [2][G][16] level-2 rows (PYR only)
   const uint32_t l1_bytes = out_bytes / 4, l2_bytes = out_bytes / 16, l3_bytes = out_bytes / 64;
   for (int f = 0; f <= last; f++) {
-    if (PYR && f > 0) pyramid_level3<G>(py, f_first + f - 1, l3_bytes, s_pyr + ((f - 1) & 1) * G * 16, p3byte, tid);
+    if (PYR && f > 0)
+      pyramid_level3<G>(py, f_first + (long long)(f - 1) * fstep, l3_bytes, s_pyr + ((f - 1) & 1) * G * 16, p3byte, tid);
 #if MDC_EXP_SKIP_LOAD
     stage_window<R, NT>(src, in_bytes, w[D], goff, wave);
 #else
-    stage_window<R, NT>(src + (long long)min(f + D, last) * in_bytes, in_bytes, w[D], goff, wave);
+    stage_window<R, NT>(src + min(f + D, last) * in_step, in_bytes, w[D], goff, wave);
 #endif
     float res[4];
     tile_compute<VIG, BLACK>(t, w[0], my_lut, dst, out_bytes, res);
-    if (PYR) pyramid_levels12(t, res, py, f_first + f, l1_bytes, l2_bytes, s_pyr + ((f & 1) * G + wave) * 16, tid & 63);
-    dst += out_bytes / 4;
+    if (PYR)
+      pyramid_levels12(t, res, py, f_first + (long long)f * fstep, l1_bytes, l2_bytes, s_pyr + ((f & 1) * G + wave) * 16,
+                       tid & 63);
+    dst += out_step;
     frame_barrier<D, R>(rw);  // frame f+1 landed in every wave's part of w[1]; everyone is done reading w[0]
     unsigned char* x = w[0];
 #pragma unroll
     for (int i = 0; i < D; i++) w[i] = w[i + 1];
     w[D] = x;
   }
-  if (PYR) pyramid_level3<G>(py, f_first + last, l3_bytes, s_pyr + (last & 1) * G * 16, p3byte, tid);
+  if (PYR) pyramid_level3<G>(py, f_first + (long long)last * fstep, l3_bytes, s_pyr + (last & 1) * G * 16, p3byte, tid);
 }
 
 // Occupancy is set by LDS (LUT replicas + two window buffers): 3 workgroups of 512 threads or 2 of
 // 960/1024 per CU; the register budget follows from that.
 template <bool VIG, bool BLACK, bool PYR, int NT, int NBUF>
 __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap_tiled_u8_kernel(
-    const uint8_t* __restrict__ in, float* __restrict__ out, RemapArgs a, TilePlan p, PyramidOut py, int nframes, int fpb) {
+    const uint8_t* __restrict__ in, float* __restrict__ out, RemapArgs a, TilePlan p, PyramidOut py, int nframes, int fpb,
+    int interleave) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   float* s_lut = reinterpret_cast<float*>(smem);
   unsigned char* s_win = smem + kLutBytes;
 
   const int tile = p.d_order[blockIdx.x];  // host-made placement table (plan_tiles); -1 = padding slot
   if (tile < 0) return;                    // whole workgroup leaves before any barrier
-  const int f0 = blockIdx.y * fpb;
-  const int nf = min(nframes, f0 + fpb) - f0;
+  // Frames of this workgroup: group g of G takes frames [g*fpb, (g+1)*fpb), or -- interleaved --
+  // frames g, g+G, g+2G, ...  Interleaved, the groups resident at one time (dispatched in order)
+  // walk through ADJACENT frames side by side, so the chip's aggregate traffic sweeps the batch
+  // linearly instead of touching a few frames each fpb frames apart.
+  const int fstep = interleave ? (int)gridDim.y : 1;
+  const int f0 = interleave ? (int)blockIdx.y : (int)blockIdx.y * fpb;
+  const int nf = interleave ? (nframes - f0 + fstep - 1) / fstep : min(nframes, f0 + fpb) - f0;
   if (nf <= 0) return;
 
   const int tid = threadIdx.x;
@@ -502,11 +516,7 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap
   constexpr int kTileRows = NT / 16;  // 4 output rows per thread, kTileW lanes per row
   const int oy0 = (tile / p.tiles_x) * kTileRows + row0;
 
-  // LUT replicas: entry e occupies words [32e, 32e+32) -- eight 16-byte stores of (v,v,v,v)
-  for (int i = tid; i < 256 * (kLutRep / 4); i += NT) {
-    const float v = a.lut[i / (kLutRep / 4)];
-    reinterpret_cast<f32x4*>(s_lut)[i] = f32x4{v, v, v, v};
-  }
+  fill_lut<NT>(s_lut, a.lut, tid);
   const float* my_lut = s_lut + (tid & (kLutRep - 1));
 
   TileThread t;
@@ -550,12 +560,12 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap
     p3byte = (uint32_t)(((tile / p.tiles_x) * (NT / 128) + (tid >> 3)) * (a.out_w >> 3) + (tile % p.tiles_x) * 8 + (tid & 7)) * 4u;
   if (nch == 0) {  // every output of the tile is black (or outside): zeros (on every level), no staging
 #if __HIP_DEVICE_COMPILE__
-    for (int f = 0; f < nf; f++, dst += out_bytes / 4) {
+    for (int f = 0; f < nf; f++, dst += (long long)fstep * (out_bytes / 4)) {
       const auto ro = MDC_FRAME_RSRC(dst, out_bytes);
 #pragma unroll
       for (int j = 0; j < 4; j++) __builtin_amdgcn_raw_buffer_store_b32(0u, ro, t.obyte[j], 0, 0);
       if (PYR) {
-        const long long fa = (long long)f0 + f;
+        const long long fa = (long long)f0 + (long long)f * fstep;
         if (py.l1) {
           const auto r1 = MDC_FRAME_RSRC(py.l1 + fa * (out_bytes / 16), out_bytes / 4);
           __builtin_amdgcn_raw_buffer_store_b32(0u, r1, t.p1byte[0], 0, 0);
@@ -572,7 +582,7 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap
   const uint32_t* chunks = p.d_chunks + (size_t)tile * p.chunk_cap;
 #define MDC_TILE_RUN(R_)                                                                                              \
   tile_frames<VIG, BLACK, PYR, R_, NT, NBUF>(t, src, dst, in_bytes, out_bytes, nf, nch, chunks, s_win, p.win_bytes, \
-                                             my_lut, tid, py, (long long)f0, p3byte)
+                                             my_lut, tid, py, (long long)f0, fstep, p3byte)
   if (rounds == 1) MDC_TILE_RUN(1);
   else if (rounds == 2) MDC_TILE_RUN(2);
   else MDC_TILE_RUN(kTileMaxChunks);
@@ -679,7 +689,8 @@ static hipError_t launch_tiled_variant(const TiledLaunch& l) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  remap_tiled_u8_kernel<VIG, BLACK, PYR, NT, NBUF><<<grid, NT, lds, l.s>>>(l.d_in, l.d_out, l.a, l.p, l.py, (int)l.nframes, l.fpb);
+  remap_tiled_u8_kernel<VIG, BLACK, PYR, NT, NBUF><<<grid, NT, lds, l.s>>>(l.d_in, l.d_out, l.a, l.p, l.py, (int)l.nframes,
+                                                                           l.fpb, l.p.interleave ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -104,14 +104,16 @@ def test_tiled_and_gather_kernels_agree(name, setups, oracle, torch_cuda):
           s.ctx.set_option(capi.OPT_WINDOW_BUFFERS, nbuf)
           if k == capi.KERNEL_TILED and not s.ctx.info().tiled:
               continue
-          for n, fpb in ((1, 0), (3, 2), (17, 0), (17, 5)):
+          for n, fpb, il in ((1, 0, 0), (3, 2, 1), (17, 0, 0), (17, 5, 1), (17, 5, 0), (17, 0, 1)):
             s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, fpb)
+            s.ctx.set_option(capi.OPT_FRAME_INTERLEAVE, il)
             d_out = torch.full((n, s.w * s.h), -7.0, dtype=torch.float32, device="cuda")
             s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, flags, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-            assert bits_equal(d_out.cpu().numpy(), want[:n]), (name, k, rows, order, nbuf, n, fpb)
+            assert bits_equal(d_out.cpu().numpy(), want[:n]), (name, k, rows, order, nbuf, n, fpb, il)
     s.ctx.set_option(capi.OPT_TILE_ORDER, capi.ORDER_BANDS)
     s.ctx.set_option(capi.OPT_WINDOW_BUFFERS, 0)
+    s.ctx.set_option(capi.OPT_FRAME_INTERLEAVE, 0)
     s.ctx.set_option(capi.OPT_TILE_ROWS, 32)
     s.ctx.set_option(capi.OPT_KERNEL, capi.KERNEL_AUTO)
     s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, 0)
@@ -257,9 +259,10 @@ def test_process_pyramid_fused(name, setups, oracle, torch_cuda):
     base_want = [s.want(oracle, f, 1, 1, 1, 1) for f in frames]
     d_in = torch.from_numpy(frames).cuda()
     st = torch.cuda.current_stream().cuda_stream
-    for rows, levels, fpb in ((32, 4, 0), (16, 4, 3), (64, 3, 0), (60, 4, 0), (32, 5, 2), (32, 1, 0)):
+    for rows, levels, fpb, il in ((32, 4, 0, 0), (16, 4, 3, 1), (64, 3, 0, 0), (60, 4, 0, 0), (32, 5, 2, 1), (32, 1, 0, 0), (64, 4, 2, 1)):
         s.ctx.set_option(capi.OPT_TILE_ROWS, rows)
         s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, fpb)
+        s.ctx.set_option(capi.OPT_FRAME_INTERLEAVE, il)
         d_base = torch.full((n, s.w * s.h), -7.0, dtype=torch.float32, device="cuda")
         lv = [torch.full((n * (s.w >> l) * (s.h >> l),), -7.0, dtype=torch.float32, device="cuda") for l in range(1, levels)]
         s.ctx.process_pyramid_batch(d_in.data_ptr(), d_base.data_ptr(), levels, [t.data_ptr() for t in lv], n, flags, st)

@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--lib", default="", help="(compat) single alternative build")
     ap.add_argument("--rows", default="32")
     ap.add_argument("--order", default="0", help="tile placement: 0 bands, 1 whole rows per XCD, 2 identity")
-    ap.add_argument("--sched", default="-1", help="frame scheduling: -1 library default, 0 static groups, 1 persistent")
+    ap.add_argument("--sched", default="-1", help="frame assignment: -1 library default, 0 consecutive runs, 1 interleaved")
     ap.add_argument("--nbuf", default="0", help="LDS window buffers (0 = automatic)")
     ap.add_argument("--remap", default="fov", choices=["fov", "affine", "affine128"],
                     help="diagnosis: replace the FOV remap by a distortion-free one of the same scale (no window overlap "
@@ -118,7 +118,7 @@ def main():
             try_set(m, ctx, "OPT_TILE_ROWS", v[3])
             try_set(m, ctx, "OPT_TILE_ORDER", v[4])
             if v[5] >= 0:
-                try_set(m, ctx, "OPT_SCHEDULE", v[5])
+                try_set(m, ctx, "OPT_FRAME_INTERLEAVE", v[5])
             try_set(m, ctx, "OPT_WINDOW_BUFFERS", v[6])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), B, flags, s)
