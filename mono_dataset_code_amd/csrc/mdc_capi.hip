@@ -207,7 +207,8 @@ int plan_tiles(mdc_ctx* c) {
   const int kTileH = c->opt_tile_h, kTileThreads = 16 * kTileH;
   const int tx = (ow + kTileW - 1) / kTileW, ty = (oh + kTileH - 1) / kTileH;
   const int n_tiles = tx * ty;
-  bool ok = (iw % 16 == 0);
+  // whole 16-byte chunks per frame row; one frame within the 32-bit lane offsets of the buffer descriptors
+  bool ok = (iw % 16 == 0) && (int64_t)iw * c->rm_in_h < (int64_t)kOutside && (int64_t)ow * oh * 4 < (int64_t)kOutside;
   for (size_t i = 0; i < (size_t)ow * oh; i++) c->n_black += c->h_rx[i] < 0;
   std::vector<std::vector<uint32_t>> chunks(n_tiles);
   std::vector<int> nch(n_tiles, 0);

@@ -222,6 +222,40 @@ def test_full_size_config_and_properties(setups, oracle, torch_cuda):
     assert bits_equal(d_tmp[:npix].cpu().numpy(), want)
 
 
+def test_batch_beyond_4gib(setups, oracle, torch_cuda):
+    """A batch whose frames lie beyond 4 GiB from the base pointers (3400 frames: 4.46 GB in, 4.18 GB out):
+    the per-frame buffer descriptors take a 48-bit base, lane offsets stay 32-bit.  Checked against the
+    oracle on both sides of the 4 GiB line, for the fused and the unMapImage kernels."""
+    from mono_dataset_code_amd import capi, synth
+
+    torch = torch_cuda
+    s = setups("full_1280_to_640")
+    n = 3400
+    npix, nout = s.W * s.H, s.w * s.h
+    st = torch.cuda.current_stream().cuda_stream
+    d_in = torch.empty(n * npix, dtype=torch.uint8, device="cuda")
+    s.ctx.synth_frames(d_in.data_ptr(), 7, n, npix, synth.SEED, st)
+    flags = capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED
+    d_out = torch.zeros(n * nout, dtype=torch.float32, device="cuda")
+    s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, flags | capi.RECTIFY, st)
+    torch.cuda.synchronize()
+    line_in, line_out = (1 << 32) // npix, (1 << 32) // (nout * 4)  # first frame past 4 GiB: input 3276, output 3495 (> n)
+    picks = (0, line_in - 1, line_in, line_in + 1, n - 1)
+    for f in picks:
+        raw = synth.noise_frames(7 + f, 1, npix)[0]
+        assert np.array_equal(d_in[f * npix:(f + 1) * npix].cpu().numpy(), raw), f
+        assert bits_equal(d_out[f * nout:(f + 1) * nout].cpu().numpy(), s.want(oracle, raw, 1, 1, 1, 1)), f
+    del d_out
+    # unMapImage: 5.24 MB of output per frame -> the output crosses 4 GiB at frame 819
+    m = 900
+    d_un = torch.zeros(m * npix, dtype=torch.float32, device="cuda")
+    s.ctx.process_batch(d_in.data_ptr(), d_un.data_ptr(), m, flags, st)
+    torch.cuda.synchronize()
+    for f in (0, 818, 819, 820, m - 1):
+        raw = synth.noise_frames(7 + f, 1, npix)[0]
+        assert bits_equal(d_un[f * npix:(f + 1) * npix].cpu().numpy(), oracle.unmap(raw, s.ginv, s.vinv, True, True, 1, 1, 1)), f
+
+
 def test_pyramid(torch_cuda, oracle):
     """4-level box pyramid (own definition, parity unpinned by the reference)."""
     from mono_dataset_code_amd import capi
