@@ -43,12 +43,18 @@ struct mdc_ctx {
 
   // tile plan
   bool tiled = false;
-  uint32_t* d_chunks = nullptr;  // tile plan, see TilePlan (mdc_internal.h)
-  int* d_nch = nullptr;
-  uint32_t* d_taps = nullptr;
+  // tile plans, see TilePlan (mdc_internal.h): [0] raw u8 frames (fused path), [1] float frames (undistort<float>)
+  struct SrcPlan {
+    uint32_t* d_chunks = nullptr;
+    int* d_nch = nullptr;
+    uint32_t* d_taps = nullptr;
+    int chunk_cap = 0, win_bytes = 0, nbuf = 2;
+    bool tiled = false;
+    int64_t staged_bytes = 0;
+  } plan[2];
   int* d_order = nullptr;  // block -> tile placement table (XCD bands)
   int n_blocks = 0;
-  int n_tiles = 0, tiles_x = 0, chunk_cap = 0, win_bytes = 0, nbuf = 2, tile_h = 0;
+  int n_tiles = 0, tiles_x = 0, tile_h = 0;
   int bbox[4] = {0, 0, -1, -1};
   int64_t staged_bytes = 0, n_black = 0;
 
@@ -181,11 +187,19 @@ std::vector<int> tile_order(int tx, int ty, int mode) {
 // 16-byte chunks, per output the LDS offsets of its two tap rows.  Fails (tiled = false)
 // when rows of the frame are not whole 16-byte chunks or a window is too large for LDS.
 void free_plan(mdc_ctx* c) {
-  for (void** p : {(void**)&c->d_chunks, (void**)&c->d_nch, (void**)&c->d_taps, (void**)&c->d_order})
-    if (*p) {
-      (void)hipFree(*p);
-      *p = nullptr;
-    }
+  for (auto& pl : c->plan) {
+    for (void** p : {(void**)&pl.d_chunks, (void**)&pl.d_nch, (void**)&pl.d_taps})
+      if (*p) {
+        (void)hipFree(*p);
+        *p = nullptr;
+      }
+    pl.tiled = false;
+    pl.staged_bytes = 0;
+  }
+  if (c->d_order) {
+    (void)hipFree(c->d_order);
+    c->d_order = nullptr;
+  }
 }
 
 template <typename T>
@@ -195,21 +209,18 @@ int upload(mdc_ctx* c, T** dst, const std::vector<T>& v) {
   return MDC_OK;
 }
 
-int plan_tiles(mdc_ctx* c) {
-  c->tiled = false;
-  c->n_tiles = 0;
-  c->staged_bytes = 0;
-  c->n_black = 0;
-  c->bbox[0] = c->bbox[1] = std::numeric_limits<int>::max();
-  c->bbox[2] = c->bbox[3] = -1;
-  free_plan(c);
+// The plan for source pixels of `es` bytes (1 = raw u8 frames with the LUT replicas in LDS,
+// 4 = float frames, no LUT): a 16-byte chunk holds 16 / es pixels.  Leaves pl.tiled = false when
+// frame rows are not whole chunks or a window is too large.
+int plan_source(mdc_ctx* c, int es, mdc_ctx::SrcPlan& pl) {
   const int ow = c->out_w, oh = c->out_h, iw = c->rm_in_w;
   const int kTileH = c->opt_tile_h, kTileThreads = 16 * kTileH;
   const int tx = (ow + kTileW - 1) / kTileW, ty = (oh + kTileH - 1) / kTileH;
   const int n_tiles = tx * ty;
+  const int ppc = 16 / es;  // pixels per chunk
+  const bool lut = es == 1;
   // whole 16-byte chunks per frame row; one frame within the 32-bit lane offsets of the buffer descriptors
-  bool ok = (iw % 16 == 0) && (int64_t)iw * c->rm_in_h < (int64_t)kOutside && (int64_t)ow * oh * 4 < (int64_t)kOutside;
-  for (size_t i = 0; i < (size_t)ow * oh; i++) c->n_black += c->h_rx[i] < 0;
+  bool ok = (iw % ppc == 0) && (int64_t)iw * c->rm_in_h * es < (int64_t)kOutside && (int64_t)ow * oh * 4 < (int64_t)kOutside;
   std::vector<std::vector<uint32_t>> chunks(n_tiles);
   std::vector<int> nch(n_tiles, 0);
   std::vector<uint32_t> taps((size_t)ow * oh, 0u);
@@ -239,33 +250,28 @@ int plan_tiles(mdc_ctx* c) {
           r.lo = std::min(r.lo, xi);
           r.hi = std::max(r.hi, xi + 1);
         }
-        c->bbox[0] = std::min(c->bbox[0], xi);
-        c->bbox[2] = std::max(c->bbox[2], xi + 1);
       }
-    c->bbox[1] = std::min(c->bbox[1], y_lo);
-    c->bbox[3] = std::max(c->bbox[3], y_hi);
     for (size_t k = 0; k < rows.size(); k++) {
       Row& r = rows[k];
       if (r.hi < 0) continue;  // no tap in this row (cannot happen between two used rows, harmless if it does)
-      r.x0 = r.lo & ~15;
+      r.x0 = r.lo - r.lo % ppc;
       r.lds = (int)chunks[t].size() * 16;
-      const int n = (r.hi - r.x0) / 16 + 1;
-      if (r.x0 + n * 16 > iw) ok = false;
-      for (int j = 0; j < n; j++) chunks[t].push_back((uint32_t)((y_lo + (int)k) * iw + r.x0 + j * 16));
+      const int n = (r.hi - r.x0) / ppc + 1;
+      if (r.x0 + n * ppc > iw) ok = false;
+      for (int j = 0; j < n; j++) chunks[t].push_back((uint32_t)(((y_lo + (int)k) * iw + r.x0 + j * ppc) * es));
     }
     nch[t] = (int)chunks[t].size();
-    if (nch[t] > kTileMaxChunks * kTileThreads || nch[t] * 16 > 65535) ok = false;
-    c->staged_bytes += (int64_t)nch[t] * 16;
+    if (nch[t] > (lut ? kTileMaxChunks : kTileMaxChunksF32) * kTileThreads || nch[t] * 16 > 65535) ok = false;
+    pl.staged_bytes += (int64_t)nch[t] * 16;
     for (int y = by; y < y1 && ok; y++)
       for (int x = bx; x < x1; x++) {
         const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
         if (xx < 0) continue;
         const int xi = (int)xx, yi = (int)yy;
         const Row &r0 = rows[yi - y_lo], &r1 = rows[yi + 1 - y_lo];
-        taps[(size_t)y * ow + x] = (uint32_t)(r0.lds + xi - r0.x0) | ((uint32_t)(r1.lds + xi - r1.x0) << 16);
+        taps[(size_t)y * ow + x] = (uint32_t)(r0.lds + (xi - r0.x0) * es) | ((uint32_t)(r1.lds + (xi - r1.x0) * es) << 16);
       }
   }
-  if (c->bbox[2] < 0) c->bbox[0] = c->bbox[1] = 0;
   int cap = kTileThreads, nch_max = 1;
   for (int t = 0; t < n_tiles; t++) {
     cap = std::max(cap, (nch[t] + kTileThreads - 1) / kTileThreads * kTileThreads);
@@ -274,27 +280,62 @@ int plan_tiles(mdc_ctx* c) {
   const int win_bytes = (nch_max * 16 + 1023) & ~1023;  // a wave's DMA destination is 1 KiB aligned
   // Window buffers: as many frames staged ahead as LDS allows WITHOUT lowering the number of
   // workgroups per CU that two buffers permit (occupancy first, then depth), at most 4.
-  const int wg_per_cu = std::max<int>(1, std::min<size_t>(kLdsPerCU / tiled_lds_bytes(win_bytes, 2), 2048 / kTileThreads));
+  const int wg_per_cu =
+      std::max<int>(1, std::min<size_t>(kLdsPerCU / tiled_lds_bytes(win_bytes, 2, lut), 2048 / kTileThreads));
   int nbuf = 2;
-  while (nbuf < 4 && tiled_lds_bytes(win_bytes, nbuf + 1) * wg_per_cu <= kLdsPerCU) nbuf++;
+  while (nbuf < 4 && tiled_lds_bytes(win_bytes, nbuf + 1, lut) * wg_per_cu <= kLdsPerCU) nbuf++;
   if (c->opt_nbuf) nbuf = c->opt_nbuf;
-  if (tiled_lds_bytes(win_bytes, nbuf) > kLdsPerCU) ok = false;
+  if (tiled_lds_bytes(win_bytes, nbuf, lut) > kLdsPerCU) ok = false;
   if (!ok) return MDC_OK;
   std::vector<uint32_t> flat((size_t)n_tiles * cap, kOutside);
   for (int t = 0; t < n_tiles; t++) std::copy(chunks[t].begin(), chunks[t].end(), flat.begin() + (size_t)t * cap);
-  const std::vector<int> order = tile_order(tx, ty, c->opt_order);
   int rc;
-  if ((rc = upload(c, &c->d_chunks, flat)) != MDC_OK || (rc = upload(c, &c->d_nch, nch)) != MDC_OK ||
-      (rc = upload(c, &c->d_taps, taps)) != MDC_OK || (rc = upload(c, &c->d_order, order)) != MDC_OK)
+  if ((rc = upload(c, &pl.d_chunks, flat)) != MDC_OK || (rc = upload(c, &pl.d_nch, nch)) != MDC_OK ||
+      (rc = upload(c, &pl.d_taps, taps)) != MDC_OK)
     return rc;
+  pl.chunk_cap = cap;
+  pl.win_bytes = win_bytes;
+  pl.nbuf = nbuf;
+  pl.tiled = true;
+  return MDC_OK;
+}
+
+// Plans of the tiled kernels for the current remap: tile grid, XCD placement, source bounding
+// box, one SrcPlan per source pixel type.
+int plan_tiles(mdc_ctx* c) {
+  c->tiled = false;
+  c->n_tiles = 0;
+  c->staged_bytes = 0;
+  c->n_black = 0;
+  c->bbox[0] = c->bbox[1] = std::numeric_limits<int>::max();
+  c->bbox[2] = c->bbox[3] = -1;
+  free_plan(c);
+  const int ow = c->out_w, oh = c->out_h;
+  const int kTileH = c->opt_tile_h;
+  const int tx = (ow + kTileW - 1) / kTileW, ty = (oh + kTileH - 1) / kTileH;
+  for (size_t i = 0; i < (size_t)ow * oh; i++) {
+    const float xx = c->h_rx[i], yy = c->h_ry[i];
+    if (xx < 0) {
+      c->n_black++;
+      continue;
+    }
+    c->bbox[0] = std::min(c->bbox[0], (int)xx);
+    c->bbox[2] = std::max(c->bbox[2], (int)xx + 1);
+    c->bbox[1] = std::min(c->bbox[1], (int)yy);
+    c->bbox[3] = std::max(c->bbox[3], (int)yy + 1);
+  }
+  if (c->bbox[2] < 0) c->bbox[0] = c->bbox[1] = 0;
+  int rc;
+  if ((rc = plan_source(c, 1, c->plan[0])) != MDC_OK || (rc = plan_source(c, 4, c->plan[1])) != MDC_OK) return rc;
+  if (!c->plan[0].tiled && !c->plan[1].tiled) return MDC_OK;
+  const std::vector<int> order = tile_order(tx, ty, c->opt_order);
+  if ((rc = upload(c, &c->d_order, order)) != MDC_OK) return rc;
   c->n_blocks = (int)order.size();
-  c->n_tiles = n_tiles;
+  c->n_tiles = tx * ty;
   c->tiles_x = tx;
   c->tile_h = kTileH;
-  c->chunk_cap = cap;
-  c->win_bytes = win_bytes;
-  c->nbuf = nbuf;
-  c->tiled = true;
+  c->tiled = c->plan[0].tiled;
+  c->staged_bytes = c->plan[0].staged_bytes;
   return MDC_OK;
 }
 
@@ -316,6 +357,12 @@ int ensure_stage(mdc_ctx* c, size_t in_bytes, size_t out_bytes) {
   return MDC_OK;
 }
 
+TilePlan tile_plan(const mdc_ctx* c, int which) {
+  const mdc_ctx::SrcPlan& pl = c->plan[which];
+  return TilePlan{pl.d_chunks, pl.d_nch, pl.d_taps, c->d_order, c->n_blocks, c->n_tiles, c->tiles_x, c->tile_h,
+                  pl.chunk_cap, pl.win_bytes, pl.nbuf, c->n_black > 0, c->opt_interleave != 0};
+}
+
 RemapArgs remap_args(const mdc_ctx* c, const float* lut, const float* vinv) {
   RemapArgs a;
   a.lut = lut;
@@ -327,6 +374,20 @@ RemapArgs remap_args(const mdc_ctx* c, const float* lut, const float* vinv) {
   a.out_w = c->out_w;
   a.out_h = c->out_h;
   return a;
+}
+
+// UndistorterFOV::undistort<float> over float frames: LDS-tiled kernel when planned, else the gather kernel.
+int enqueue_undistort_f32(mdc_ctx* c, const float* d_in, float* d_out, int64_t nframes, hipStream_t s) {
+  RemapArgs a = remap_args(c, nullptr, nullptr);
+  const bool aligned = (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
+  if (c->plan[1].tiled && aligned && c->opt_kernel != MDC_KERNEL_GATHER) {
+    const int fpb = frames_per_block(c, nframes, c->n_blocks);
+    MDC_HIP(c, launch_remap_tiled_f32(d_in, d_out, a, tile_plan(c, 1), nframes, fpb, s));
+  } else {
+    const int fpb = frames_per_block(c, nframes, (c->out_w * c->out_h + 255) / 256);
+    MDC_HIP(c, launch_remap_gather_f32(d_in, d_out, a, nframes, fpb, s));
+  }
+  return MDC_OK;
 }
 
 // Enqueue the fused / photometric-only pipeline on `s`.  Lock held by caller.
@@ -357,8 +418,7 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
   if (c->opt_kernel == MDC_KERNEL_TILED && !use_tiled)
     return fail(c, MDC_ERR_STATE, "tiled kernel requested but not plannable for this remap / alignment");
   if (use_tiled) {
-    TilePlan p{c->d_chunks, c->d_nch, c->d_taps, c->d_order, c->n_blocks, c->n_tiles, c->tiles_x, c->tile_h, c->chunk_cap,
-               c->win_bytes, c->nbuf, c->n_black > 0, c->opt_interleave != 0};
+    const TilePlan p = tile_plan(c, 0);
     const int fpb = frames_per_block(c, nframes, c->n_blocks);
     const bool fuse_pyr = pyr && c->tile_h != 60 && c->out_w % kTileW == 0 && c->out_h % c->tile_h == 0;
     MDC_HIP(c, launch_remap_tiled_u8(d_in, d_out, a, p, nframes, fpb, s, fuse_pyr ? pyr[0] : nullptr,
@@ -496,7 +556,7 @@ int mdc_get_info(mdc_ctx* c, mdc_info* i) {
   i->tile_w = kTileW;
   i->tile_h = c->opt_tile_h;
   i->n_tiles = c->n_tiles;
-  i->lds_bytes = c->tiled ? (int)tiled_lds_bytes(c->win_bytes, c->nbuf) : 0;
+  i->lds_bytes = c->tiled ? (int)tiled_lds_bytes(c->plan[0].win_bytes, c->plan[0].nbuf, true) : 0;
   for (int k = 0; k < 4; k++) i->src_bbox[k] = c->bbox[k];
   i->src_bbox_bytes = c->bbox[2] >= 0 ? (int64_t)(c->bbox[2] - c->bbox[0] + 1) * (c->bbox[3] - c->bbox[1] + 1) : 0;
   i->src_staged_bytes = c->staged_bytes;
@@ -595,10 +655,7 @@ int mdc_undistort_batch_device_f32(mdc_ctx* c, const float* d_in, float* d_out, 
   std::lock_guard<std::mutex> lk(c->mu);
   DeviceGuard dg(c->device);
   if (!c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
-  RemapArgs a = remap_args(c, nullptr, nullptr);
-  const int fpb = frames_per_block(c, nframes, (c->out_w * c->out_h + 255) / 256);
-  MDC_HIP(c, launch_remap_gather_f32(d_in, d_out, a, nframes, fpb, (hipStream_t)stream));
-  return MDC_OK;
+  return enqueue_undistort_f32(c, d_in, d_out, nframes, (hipStream_t)stream);
 }
 
 int mdc_pyramid_batch_device(mdc_ctx* c, const float* d_base, int w, int h, int levels, float* const* d_levels,
@@ -703,8 +760,8 @@ static int undistort_host(mdc_ctx* c, const void* in, bool is_f32, float* out, i
   if (rc != MDC_OK) return rc;
   MDC_HIP(c, hipMemcpyAsync(c->d_stage_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
   if (is_f32) {
-    RemapArgs a = remap_args(c, nullptr, nullptr);
-    MDC_HIP(c, launch_remap_gather_f32((const float*)c->d_stage_in, c->d_stage_out, a, 1, 1, c->stream));
+    rc = enqueue_undistort_f32(c, (const float*)c->d_stage_in, c->d_stage_out, 1, c->stream);
+    if (rc != MDC_OK) return rc;
   } else {
     rc = enqueue_process(c, (const uint8_t*)c->d_stage_in, c->d_stage_out, 1, MDC_RECTIFY, c->stream);
     if (rc != MDC_OK) return rc;

@@ -10,7 +10,8 @@ namespace mdc {
 // output column, 4 output rows per thread  ->  16*tile_h threads
 // (tile_h = 16: 256 threads; 32: 512; 60: 960; 64: 1024).
 constexpr int kTileW = 64;
-constexpr int kTileMaxChunks = 3;  // 16-byte chunks a thread may stage per frame
+constexpr int kTileMaxChunks = 3;     // 16-byte chunks a thread may stage per frame (raw u8 frames)
+constexpr int kTileMaxChunksF32 = 4;  // same for float frames (a window holds 4x the bytes)
 constexpr int kLutRep = 32;        // LDS replicas of the 256-entry response LUT (one per bank)
 constexpr uint32_t kOutside = 0xfffffff0u;  // buffer offset beyond any frame: the access is dropped by the range check
 
@@ -58,7 +59,10 @@ hipError_t launch_remap_gather_f32(const float* d_in, float* d_out, const RemapA
 hipError_t launch_remap_tiled_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
                                  int64_t nframes, int fpb, hipStream_t s, float* d_l1 = nullptr, float* d_l2 = nullptr,
                                  float* d_l3 = nullptr);
-size_t tiled_lds_bytes(int win_bytes, int nbuf);  // LUT replicas + nbuf window buffers
+// undistort<float>: the same tiled kernel on float frames (16-byte chunks of 4 pixels, no LUT).
+hipError_t launch_remap_tiled_f32(const float* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
+                                  int64_t nframes, int fpb, hipStream_t s);
+size_t tiled_lds_bytes(int win_bytes, int nbuf, bool lut = true);  // (LUT replicas +) nbuf window buffers
 size_t tiled_pyramid_lds_bytes(int tile_h);       // + level-2 hand-over rows of the fused pyramid
 constexpr size_t kLdsPerCU = 160 * 1024;
 

@@ -292,7 +292,7 @@ struct TileThread {  // per-thread, frame-invariant
   uint32_t p1byte[2], p2byte;  // fused pyramid: byte offsets of this lane's level-1 / level-2 outputs (kOutside if none)
 };
 
-template <bool VIG, bool BLACK>
+template <bool VIG, bool BLACK, bool F32>
 __device__ __forceinline__ void tile_compute(const TileThread& t, const unsigned char* __restrict__ w,
                                              const float* __restrict__ my_lut, float* dst, uint32_t out_bytes,
                                              float (&res)[4]) {
@@ -300,6 +300,15 @@ __device__ __forceinline__ void tile_compute(const TileThread& t, const unsigned
   const auto ro = MDC_FRAME_RSRC(dst, out_bytes);
 #pragma unroll
   for (int j = 0; j < 4; j++) {
+    if (F32) {  // float frames (undistort<float>): the taps are the staged floats themselves
+      const float* p = reinterpret_cast<const float*>(w + t.off0[j]);
+      const float* q = reinterpret_cast<const float*>(w + t.off1[j]);
+      float r = bilin_sum(t.bl[j], p[0], p[1], q[0], q[1]);
+      if (BLACK && t.black[j]) r = 0.f;
+      res[j] = r;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, t.obyte[j], 0, kStoreAux);
+      continue;
+    }
     // explicit byte loads: two adjacent byte loads fused into one ds_read_u16 at an odd
     // address are replayed by the LDS (SQ_LDS_UNALIGNED_STALL), hence volatile
     typedef const volatile __attribute__((address_space(3))) unsigned char* tap_ptr;
@@ -420,7 +429,8 @@ __device__ __forceinline__ void wait_vm_barrier() {
 // at least (D-1) later DMA groups and the 4 stores of frame f  ->  (D-1)*rw + 4.
 template <int D, int R>
 __device__ __forceinline__ void frame_barrier(int rw) {
-  if (R >= 3 && rw >= 3) wait_vm_barrier<(D - 1) * 3 + 4>();
+  if (R >= 4 && rw >= 4) wait_vm_barrier<(D - 1) * 4 + 4>();
+  else if (R >= 3 && rw == 3) wait_vm_barrier<(D - 1) * 3 + 4>();
   else if (R >= 2 && rw == 2) wait_vm_barrier<(D - 1) * 2 + 4>();
   else if (rw == 1) wait_vm_barrier<(D - 1) * 1 + 4>();
   else wait_vm_barrier<4>();
@@ -428,7 +438,7 @@ __device__ __forceinline__ void frame_barrier(int rw) {
 
 // Frames [0, nframes) of one tile.  NBUF window buffers, D = NBUF-1 frames staged ahead: the DMA
 // of frame f+D is issued before frame f is computed; one barrier per frame.
-template <bool VIG, bool BLACK, bool PYR, int R, int NT, int NBUF>
+template <bool VIG, bool BLACK, bool PYR, bool F32, int R, int NT, int NBUF>
 __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* __restrict__ src,
                                             float* __restrict__ dst, uint32_t in_bytes, uint32_t out_bytes,
                                             int nframes, int nch, const uint32_t* __restrict__ chunks,
@@ -458,7 +468,8 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
 #endif
   }
   // frame 0 landed: only the D-1 later DMA groups may still be in flight
-  if (R >= 3 && rw >= 3) wait_vm_barrier<(D - 1) * 3>();
+  if (R >= 4 && rw >= 4) wait_vm_barrier<(D - 1) * 4>();
+  else if (R >= 3 && rw == 3) wait_vm_barrier<(D - 1) * 3>();
   else if (R >= 2 && rw == 2) wait_vm_barrier<(D - 1) * 2>();
   else if (rw == 1) wait_vm_barrier<(D - 1) * 1>();
   else wait_vm_barrier<0>();
@@ -474,7 +485,7 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
     stage_window<R, NT>(src + min(f + D, last) * in_step, in_bytes, w[D], goff, wave);
 #endif
     float res[4];
-    tile_compute<VIG, BLACK>(t, w[0], my_lut, dst, out_bytes, res);
+    tile_compute<VIG, BLACK, F32>(t, w[0], my_lut, dst, out_bytes, res);
     if (PYR)
       pyramid_levels12(t, res, py, f_first + (long long)f * fstep, l1_bytes, l2_bytes, s_pyr + ((f & 1) * G + wave) * 16,
                        tid & 63);
@@ -490,13 +501,14 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
 
 // Occupancy is set by LDS (LUT replicas + two window buffers): 3 workgroups of 512 threads or 2 of
 // 960/1024 per CU; the register budget follows from that.
-template <bool VIG, bool BLACK, bool PYR, int NT, int NBUF>
-__global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap_tiled_u8_kernel(
+// F32: the frames are floats (UndistorterFOV::undistort<float>, no LUT, no vignette); else raw u8.
+template <bool VIG, bool BLACK, bool PYR, bool F32, int NT, int NBUF>
+__global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap_tiled_kernel(
     const uint8_t* __restrict__ in, float* __restrict__ out, RemapArgs a, TilePlan p, PyramidOut py, int nframes, int fpb,
     int interleave) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   float* s_lut = reinterpret_cast<float*>(smem);
-  unsigned char* s_win = smem + kLutBytes;
+  unsigned char* s_win = smem + (F32 ? 0 : kLutBytes);
 
   const int tile = p.d_order[blockIdx.x];  // host-made placement table (plan_tiles); -1 = padding slot
   if (tile < 0) return;                    // whole workgroup leaves before any barrier
@@ -516,7 +528,7 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap
   constexpr int kTileRows = NT / 16;  // 4 output rows per thread, kTileW lanes per row
   const int oy0 = (tile / p.tiles_x) * kTileRows + row0;
 
-  fill_lut<NT>(s_lut, a.lut, tid);
+  if (!F32) fill_lut<NT>(s_lut, a.lut, tid);
   const float* my_lut = s_lut + (tid & (kLutRep - 1));
 
   TileThread t;
@@ -550,7 +562,7 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap
     }
   }
 
-  const uint32_t in_bytes = (uint32_t)a.in_w * (uint32_t)a.in_h;
+  const uint32_t in_bytes = (uint32_t)a.in_w * (uint32_t)a.in_h * (F32 ? 4u : 1u);
   const uint32_t out_bytes = (uint32_t)a.out_w * (uint32_t)a.out_h * 4u;
   const uint8_t* src = in + (long long)f0 * in_bytes;
   float* dst = out + (long long)f0 * (out_bytes / 4);
@@ -581,11 +593,12 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap
   const int rounds = (nch + NT - 1) / NT;  // workgroup-uniform
   const uint32_t* chunks = p.d_chunks + (size_t)tile * p.chunk_cap;
 #define MDC_TILE_RUN(R_)                                                                                              \
-  tile_frames<VIG, BLACK, PYR, R_, NT, NBUF>(t, src, dst, in_bytes, out_bytes, nf, nch, chunks, s_win, p.win_bytes, \
+  tile_frames<VIG, BLACK, PYR, F32, R_, NT, NBUF>(t, src, dst, in_bytes, out_bytes, nf, nch, chunks, s_win, p.win_bytes, \
                                              my_lut, tid, py, (long long)f0, fstep, p3byte)
   if (rounds == 1) MDC_TILE_RUN(1);
   else if (rounds == 2) MDC_TILE_RUN(2);
-  else MDC_TILE_RUN(kTileMaxChunks);
+  else if (rounds == 3 || !F32) MDC_TILE_RUN(3);
+  else if constexpr (F32) MDC_TILE_RUN(4);  // float windows are 4x the bytes: up to kTileMaxChunksF32 rounds
 #undef MDC_TILE_RUN
 }
 
@@ -632,7 +645,7 @@ inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace
 
-size_t tiled_lds_bytes(int win_bytes, int nbuf) { return (size_t)kLutBytes + (size_t)nbuf * win_bytes; }
+size_t tiled_lds_bytes(int win_bytes, int nbuf, bool lut) { return (lut ? (size_t)kLutBytes : 0) + (size_t)nbuf * win_bytes; }
 size_t tiled_pyramid_lds_bytes(int tile_h) { return (size_t)2 * (tile_h / 4) * 16 * sizeof(float); }
 
 hipError_t launch_unmap(const uint8_t* d_in, float* d_out, const float* d_lut, const float* d_vinv, int64_t npix,
@@ -680,26 +693,37 @@ struct TiledLaunch {
   hipStream_t s;
 };
 
-template <bool VIG, bool BLACK, bool PYR, int NT, int NBUF>
+template <bool VIG, bool BLACK, bool PYR, bool F32, int NT, int NBUF>
 static hipError_t launch_tiled_variant(const TiledLaunch& l) {
   dim3 grid(l.p.n_blocks, ceil_div(l.nframes, l.fpb));
-  const size_t lds = tiled_lds_bytes(l.p.win_bytes, NBUF) + (PYR ? tiled_pyramid_lds_bytes(l.p.tile_h) : 0);
+  const size_t lds = tiled_lds_bytes(l.p.win_bytes, NBUF, !F32) + (PYR ? tiled_pyramid_lds_bytes(l.p.tile_h) : 0);
   if (lds > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&remap_tiled_u8_kernel<VIG, BLACK, PYR, NT, NBUF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&remap_tiled_kernel<VIG, BLACK, PYR, F32, NT, NBUF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  remap_tiled_u8_kernel<VIG, BLACK, PYR, NT, NBUF><<<grid, NT, lds, l.s>>>(l.d_in, l.d_out, l.a, l.p, l.py, (int)l.nframes,
-                                                                           l.fpb, l.p.interleave ? 1 : 0);
+  remap_tiled_kernel<VIG, BLACK, PYR, F32, NT, NBUF><<<grid, NT, lds, l.s>>>(l.d_in, l.d_out, l.a, l.p, l.py,
+                                                                             (int)l.nframes, l.fpb, l.p.interleave ? 1 : 0);
   return hipGetLastError();
 }
 
-template <bool VIG, bool BLACK, bool PYR, int NT>
+template <bool VIG, bool BLACK, bool PYR, int NT, bool F32 = false>
 static hipError_t launch_tiled_buf(const TiledLaunch& l) {
   switch (l.p.nbuf) {
-    case 2: return launch_tiled_variant<VIG, BLACK, PYR, NT, 2>(l);
-    case 3: return launch_tiled_variant<VIG, BLACK, PYR, NT, 3>(l);
-    case 4: return launch_tiled_variant<VIG, BLACK, PYR, NT, 4>(l);
+    case 2: return launch_tiled_variant<VIG, BLACK, PYR, F32, NT, 2>(l);
+    case 3: return launch_tiled_variant<VIG, BLACK, PYR, F32, NT, 3>(l);
+    case 4: return launch_tiled_variant<VIG, BLACK, PYR, F32, NT, 4>(l);
+  }
+  return hipErrorInvalidValue;
+}
+
+template <bool BLACK>
+static hipError_t launch_tiled_f32_nt(const TiledLaunch& l) {
+  switch (l.p.tile_h) {
+    case 16: return launch_tiled_buf<false, BLACK, false, 256, true>(l);
+    case 32: return launch_tiled_buf<false, BLACK, false, 512, true>(l);
+    case 60: return launch_tiled_buf<false, BLACK, false, 960, true>(l);
+    case 64: return launch_tiled_buf<false, BLACK, false, 1024, true>(l);
   }
   return hipErrorInvalidValue;
 }
@@ -725,6 +749,15 @@ hipError_t launch_remap_tiled_u8(const uint8_t* d_in, float* d_out, const RemapA
   const TiledLaunch l{d_in, d_out, a, p, PyramidOut{d_l1, d_l2, d_l3}, nframes, fpb, s};
   if (a.vinv) return p.has_black ? launch_tiled_nt<true, true>(l) : launch_tiled_nt<true, false>(l);
   return p.has_black ? launch_tiled_nt<false, true>(l) : launch_tiled_nt<false, false>(l);
+}
+
+hipError_t launch_remap_tiled_f32(const float* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
+                                  int64_t nframes, int fpb, hipStream_t s) {
+  if (nframes <= 0) return hipSuccess;
+  if ((int64_t)a.in_w * a.in_h * 4 >= (int64_t)kOutside || (int64_t)a.out_w * a.out_h * 4 >= (int64_t)kOutside)
+    return hipErrorInvalidValue;
+  const TiledLaunch l{reinterpret_cast<const uint8_t*>(d_in), d_out, a, p, PyramidOut{nullptr, nullptr, nullptr}, nframes, fpb, s};
+  return p.has_black ? launch_tiled_f32_nt<true>(l) : launch_tiled_f32_nt<false>(l);
 }
 
 hipError_t launch_pyramid_level(const float* d_src, float* d_dst, int w, int h, int64_t nframes, hipStream_t s) {

@@ -140,6 +140,36 @@ def test_unmap_and_undistort_host(name, setups, oracle):
         assert bits_equal(out, oracle.undistort(fin, s.rx, s.ry, s.W))
 
 
+@pytest.mark.parametrize("name", ["small_explicit", "small_full_black", "upsample", "ragged"])
+def test_undistort_f32_batch_tiled_and_gather(name, setups, oracle, torch_cuda):
+    """UndistorterFOV::undistort<float> on device batches: the LDS-tiled float kernel (every tile shape and
+    buffer count) and the gather kernel against the oracle, inputs with NaN / inf (unmapped frames)."""
+    from mono_dataset_code_amd import capi
+
+    torch = torch_cuda
+    s = setups(name)
+    raws = make_frames(s.W, s.H, n_noise=4)
+    fins = np.stack([oracle.unmap(r, s.ginv, s.vinv, True, True, 1, 1, 1) for r in raws])
+    want = np.stack([oracle.undistort(f, s.rx, s.ry, s.W) for f in fins])
+    n = len(fins)
+    d_in = torch.from_numpy(fins).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    for kernel, rows, nbuf, fpb in ((capi.KERNEL_GATHER, 32, 0, 0), (capi.KERNEL_AUTO, 32, 0, 0), (capi.KERNEL_AUTO, 16, 3, 2),
+                                    (capi.KERNEL_AUTO, 60, 2, 0), (capi.KERNEL_AUTO, 64, 0, 3), (capi.KERNEL_AUTO, 32, 4, 1)):
+        s.ctx.set_option(capi.OPT_KERNEL, kernel)
+        s.ctx.set_option(capi.OPT_TILE_ROWS, rows)
+        s.ctx.set_option(capi.OPT_WINDOW_BUFFERS, nbuf)
+        s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, fpb)
+        d_out = torch.full((n, s.w * s.h), -7.0, dtype=torch.float32, device="cuda")
+        s.ctx.undistort_batch_f32(d_in.data_ptr(), d_out.data_ptr(), n, st)
+        torch.cuda.synchronize()
+        assert bits_equal(d_out.cpu().numpy(), want), (name, kernel, rows, nbuf, fpb)
+    s.ctx.set_option(capi.OPT_KERNEL, capi.KERNEL_AUTO)
+    s.ctx.set_option(capi.OPT_TILE_ROWS, 32)
+    s.ctx.set_option(capi.OPT_WINDOW_BUFFERS, 0)
+    s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, 0)
+
+
 def test_cxx_classes_match_reference(calib_dirs, ref, oracle):
     """The drop-in C++ classes against the reference's own classes, method by method."""
     from mono_dataset_code_amd import capi

@@ -10,8 +10,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-KERNEL_OF = {"fused": ("fused_tiled", "remap_tiled_u8_kernel", 1024), "unmap": ("unmap", "unmap_xpose_kernel", 512),
-             "pyramid": ("pyramid_fused", "remap_tiled_u8_kernel", 256)}
+KERNEL_OF = {"fused": ("fused_tiled", "remap_tiled_kernel", 1024), "unmap": ("unmap", "unmap_xpose_kernel", 512),
+             "pyramid": ("pyramid_fused", "remap_tiled_kernel", 256)}
 traffic_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
 for wl, (key, kname, frames) in KERNEL_OF.items():

@@ -1,6 +1,6 @@
 // HBM ceilings of this box for the traffic MIX and the ACCESS PATTERNS of the fused
 // photometric + remap kernel (reads of u8 source windows, writes of f32 output tiles),
-// stripped of all arithmetic.  Tells how far remap_tiled_u8_kernel is from what the
+// stripped of all arithmetic.  Tells how far remap_tiled_kernel is from what the
 // memory system can deliver for its pattern, and which pattern changes would pay.
 //   hipcc --offload-arch=gfx950 -O3 tools/hbm_mix.hip -o /tmp/hbm_mix && /tmp/hbm_mix
 // Geometry = bench workload: 1024 frames, 1280x1024 u8 in, 640x480 f32 out.
