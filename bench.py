@@ -34,6 +34,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s
 IN_W, IN_H, OUT_W, OUT_H = 1280, 1024, 640, 480
 
 
+def _flush_c_stdio():
+    import ctypes
+
+    ctypes.CDLL(None).fflush(None)
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -46,6 +52,8 @@ def parse():
     p.add_argument("--workload", default="fused", choices=["fused", "unmap", "pyramid"])
     p.add_argument("--kernel", default="auto", choices=["auto", "gather", "tiled"])
     p.add_argument("--fpb", type=int, default=0, help="frames per workgroup (0 = library default)")
+    p.add_argument("--tile-rows", type=int, default=0, help="output tile rows of the tiled kernel (0 = library default)")
+    p.add_argument("--nbuf", type=int, default=0, help="LDS window buffers (0 = automatic)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return p.parse_args()
@@ -86,6 +94,7 @@ def cpu_baseline(args, calib_dir, flags_gvo):
             fov = R.fov(os.path.join(calib_dir, "camera.txt"))
             photo = R.photo(os.path.join(calib_dir, "pcalib.txt"), os.path.join(calib_dir, "vignette.png"), IN_W, IN_H)
         finally:
+            _flush_c_stdio()  # the chatter sits in libc's buffer; drop it into /dev/null, not after our JSON line
             os.dup2(saved, 1)
             os.close(devnull)
 
@@ -149,6 +158,7 @@ def main():
             photo = capi.PhotometricUndistorter(os.path.join(calib_dir, "pcalib.txt"),
                                                 os.path.join(calib_dir, "vignette.png"), IN_W, IN_H)
         finally:
+            _flush_c_stdio()  # the chatter sits in libc's buffer; drop it into /dev/null, not after our JSON line
             os.dup2(saved, 1)
             os.close(devnull)
         assert fov.is_valid() and photo.valid() == 3
@@ -158,6 +168,10 @@ def main():
     ctx.import_tables(blob)  # every rank (rank 0 included) uploads the same bytes
     ctx.set_option(capi.OPT_KERNEL, {"auto": capi.KERNEL_AUTO, "gather": capi.KERNEL_GATHER, "tiled": capi.KERNEL_TILED}[args.kernel])
     ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, args.fpb)
+    if args.tile_rows:
+        ctx.set_option(capi.OPT_TILE_ROWS, args.tile_rows)
+    if args.nbuf:
+        ctx.set_option(capi.OPT_WINDOW_BUFFERS, args.nbuf)
     info = ctx.info()
     out_w, out_h = (info.out_w, info.out_h) if args.workload != "unmap" else (IN_W, IN_H)
 
