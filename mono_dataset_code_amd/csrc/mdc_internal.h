@@ -12,7 +12,10 @@ namespace mdc {
 constexpr int kTileW = 64;
 constexpr int kTileMaxChunks = 3;     // 16-byte chunks a thread may stage per frame (raw u8 frames)
 constexpr int kTileMaxChunksF32 = 4;  // same for float frames (a window holds 4x the bytes)
-constexpr int kLutRep = 32;        // LDS replicas of the 256-entry response LUT (one per bank)
+#ifndef MDC_EXP_LUT_REP
+#define MDC_EXP_LUT_REP 32
+#endif
+constexpr int kLutRep = MDC_EXP_LUT_REP;  // LDS replicas of the 256-entry response LUT (32 = one per bank, conflict-free)
 constexpr uint32_t kOutside = 0xfffffff0u;  // buffer offset beyond any frame: the access is dropped by the range check
 
 struct RemapArgs {

@@ -503,7 +503,7 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
 // 960/1024 per CU; the register budget follows from that.
 // F32: the frames are floats (UndistorterFOV::undistort<float>, no LUT, no vignette); else raw u8.
 template <bool VIG, bool BLACK, bool PYR, bool F32, int NT, int NBUF>
-__global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? 6 : 4)) void remap_tiled_kernel(
+__global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 : 6) : 4)) void remap_tiled_kernel(
     const uint8_t* __restrict__ in, float* __restrict__ out, RemapArgs a, TilePlan p, PyramidOut py, int nframes, int fpb,
     int interleave) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
