@@ -286,6 +286,35 @@ def test_batch_beyond_4gib(setups, oracle, torch_cuda):
         assert bits_equal(d_un[f * npix:(f + 1) * npix].cpu().numpy(), oracle.unmap(raw, s.ginv, s.vinv, True, True, 1, 1, 1)), f
 
 
+def test_batch_launch_is_graph_capturable(setups, oracle, torch_cuda):
+    """mdc_process_batch_device does no allocation / synchronisation: it can be captured into a HIP graph on
+    the caller's stream and replayed (a reader that re-uses its buffers pays one graph launch per batch)."""
+    from mono_dataset_code_amd import capi
+
+    torch = torch_cuda
+    s = setups("small_crop")
+    frames = np.stack(make_frames(s.W, s.H, n_noise=3))
+    n = len(frames)
+    flags = capi.RECTIFY | capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED
+    d_in = torch.from_numpy(frames).cuda()
+    d_out = torch.zeros((n, s.w * s.h), dtype=torch.float32, device="cuda")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, flags, st.cuda_stream)  # warm (module load)
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, flags, torch.cuda.current_stream().cuda_stream)
+        for rep in range(3):
+            d_in.copy_(torch.from_numpy(np.roll(frames, rep, axis=0)))
+            d_out.fill_(-7.0)
+            g.replay()
+            st.synchronize()
+            got = d_out.cpu().numpy()
+            for i in range(n):
+                assert bits_equal(got[i], s.want(oracle, np.roll(frames, rep, axis=0)[i], 1, 1, 1, 1)), (rep, i)
+
+
 def test_pyramid(torch_cuda, oracle):
     """4-level box pyramid (own definition, parity unpinned by the reference)."""
     from mono_dataset_code_amd import capi
