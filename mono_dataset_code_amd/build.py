@@ -29,7 +29,8 @@ HOST_DEPS = HOST_SOURCES + [os.path.join(HOST, "gray_png.h"), os.path.join(HOST,
                             os.path.join(INC, "mdc_hip.h"), os.path.join(INC, "mdc_host.h"),
                             os.path.join(INC, "mono_dataset_code", "FOVUndistorter.h"),
                             os.path.join(INC, "mono_dataset_code", "PhotometricUndistorter.h"),
-                            os.path.join(INC, "mono_dataset_code", "ExposureImage.h")]
+                            os.path.join(INC, "mono_dataset_code", "ExposureImage.h"),
+                            os.path.join(INC, "mono_dataset_code", "MdcBind.h")]
 
 # -ffp-contract=off: the reference is built without FMA; contraction would break bit parity.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",

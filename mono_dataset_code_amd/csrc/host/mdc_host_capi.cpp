@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "FOVUndistorter.h"
+#include "MdcBind.h"
 #include "PhotometricUndistorter.h"
 
 struct mdch_fov { UndistorterFOV* u; };
@@ -25,6 +26,26 @@ struct MdcHostAccess {
   static int w(const PhotometricUndistorter& p) { return p.w_; }
   static int h(const PhotometricUndistorter& p) { return p.h_; }
 };
+
+int mdc_bind_objects(mdc_ctx* ctx, const UndistorterFOV* fov, const PhotometricUndistorter* photo) {
+  if (!ctx) return MDC_ERR_ARG;
+  int rc = MDC_OK;
+  if (photo) {
+    const PhotometricUndistorter& p = *photo;
+    rc = mdc_set_photometric(ctx, MdcHostAccess::valid_gamma(p) ? MdcHostAccess::ginv(p) : 0,
+                             MdcHostAccess::valid_vignette(p) ? MdcHostAccess::vinv(p) : 0, MdcHostAccess::w(p),
+                             MdcHostAccess::h(p));
+    if (rc != MDC_OK) return rc;
+  }
+  if (fov) {
+    const UndistorterFOV& u = *fov;
+    if (u.isValid())
+      rc = mdc_set_remap(ctx, MdcHostAccess::rx(u), MdcHostAccess::ry(u), u.getInputDims()[0], u.getInputDims()[1],
+                         u.getOutputDims()[0], u.getOutputDims()[1]);
+    else rc = mdc_set_remap(ctx, 0, 0, 0, 0, 0, 0);
+  }
+  return rc;
+}
 
 extern "C" {
 
@@ -111,23 +132,7 @@ void mdch_photo_unmap(mdch_photo* p, unsigned char* in, float* out, int n, int g
 }
 
 int mdch_bind(mdc_ctx* ctx, const mdch_fov* fov, const mdch_photo* photo) {
-  if (!ctx) return MDC_ERR_ARG;
-  int rc = MDC_OK;
-  if (photo) {
-    const PhotometricUndistorter& p = *photo->p;
-    rc = mdc_set_photometric(ctx, MdcHostAccess::valid_gamma(p) ? MdcHostAccess::ginv(p) : 0,
-                             MdcHostAccess::valid_vignette(p) ? MdcHostAccess::vinv(p) : 0, MdcHostAccess::w(p),
-                             MdcHostAccess::h(p));
-    if (rc != MDC_OK) return rc;
-  }
-  if (fov) {
-    const UndistorterFOV& u = *fov->u;
-    if (u.isValid())
-      rc = mdc_set_remap(ctx, MdcHostAccess::rx(u), MdcHostAccess::ry(u), u.getInputDims()[0], u.getInputDims()[1],
-                         u.getOutputDims()[0], u.getOutputDims()[1]);
-    else rc = mdc_set_remap(ctx, 0, 0, 0, 0, 0, 0);
-  }
-  return rc;
+  return mdc_bind_objects(ctx, fov ? fov->u : 0, photo ? photo->p : 0);
 }
 
 // Must stay in step with BlobHeader in csrc/mdc_capi.hip (checked by tests/test_multi_gpu.py

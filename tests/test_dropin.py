@@ -18,6 +18,7 @@ from conftest import bits_equal
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "playback_ref")
 MDC_BIN = os.path.join(ROOT, "oracle", "_ref", "playback_mdc")
+FAST_BIN = os.path.join(ROOT, "oracle", "_ref", "sequence_fast")
 FLAGS = ["1111", "0111", "1000", "0000", "1110", "1010", "0001", "1100"]
 N_FRAMES = 3
 CAM = ("0.349153 0.436593 0.493140 0.499021 0.933271", "320 256", "crop", "192 144")
@@ -98,3 +99,22 @@ def test_dropin_classes_under_unmodified_reader_match_reference(sequence, tmp_pa
     # same chatter on stdout (the classes print the reference's messages)
     keep = lambda s: [l for l in s.splitlines() if l.startswith(("PLAYBACK", "Input resolution", "Output resolution", "Out:", "new K", "old K", "Successfully"))]
     assert keep(log_ref) == keep(log_mdc)
+
+
+@pytest.mark.gpu
+def test_fused_sequence_program_matches_reference_getimage(sequence, tmp_path):
+    """INTEGRATION.md section B compiled as C++ (tests/dropin/sequence_fast.cpp): the unmodified reader decodes,
+    mdc_bind_objects + one mdc_process_frames_host call per flag set produce every getImage() result of the
+    reference, byte for byte, from page-locked buffers."""
+    need(REF_BIN)
+    need(FAST_BIN)
+    d, _ = sequence
+    a, b = str(tmp_path / "ref.bin"), str(tmp_path / "fast.bin")
+    run_playback(REF_BIN, d, a)
+    log = run_playback(FAST_BIN, d, b)
+    assert "SEQUENCE_FAST 3 images, 320x256 -> 192x144" in log
+    ra, rb = parse(a), parse(b)
+    assert len(ra) == len(rb) == len(FLAGS) * N_FRAMES
+    for x, y in zip(ra, rb):
+        assert x[:6] == y[:6]
+        assert bits_equal(x[6], y[6]), x[:4]
