@@ -170,6 +170,28 @@ int mdc_pyramid_batch_device(mdc_ctx* ctx, const float* d_base, int w, int h, in
 int mdc_process_pyramid_batch_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_base, int levels,
                                      float* const* d_levels, int64_t nframes, unsigned flags, void* stream);
 
+/* ---- lens model on many points ------------------------------------------------ */
+
+/* The FOV camera of one UndistorterFOV object: camera.txt line 1 (fx fy cx cy omega, relative to the
+ * input size), the input size, and the NORMALISED output calibration its constructor leaves behind
+ * (src/FOVUndistorter.cpp:214-218) with the output size.  mdc_fov_model_of (MdcBind.h) / mdch_fov_model
+ * (mdc_host.h) fill it from an object. */
+typedef struct mdc_fov_model {
+  float in_calib[5];
+  int in_w, in_h;
+  float out_calib[5];
+  int out_w, out_h;
+} mdc_fov_model;
+
+/* UndistorterFOV::distortCoordinates(in_x, in_y, n) (src/FOVUndistorter.cpp:280-319): rectified pixel
+ * coordinates -> raw pixel coordinates, in place, n points -- for callers that warp many points per
+ * frame (vignetteCalib: 10^6 per image, src/main_vignetteCalib.cpp:284).  Bit-identical to the
+ * reference built against glibc's libm: the kernel restates that library's fdlibm atanf, it does not
+ * call the GPU math library's (which differs in the last bit).  The class method itself keeps running
+ * on the host (it builds the remap tables); this entry point is the opt-in. */
+int mdc_distort_points_device(mdc_ctx* ctx, const mdc_fov_model* model, float* d_x, float* d_y, int64_t n, void* stream);
+int mdc_distort_points_host(mdc_ctx* ctx, const mdc_fov_model* model, float* x, float* y, int64_t n);
+
 /* Synthetic sequence generator (bench/test utility):
  * byte i of frame f = fmix32(seed + (first_frame+f)*npix + i) >> 24. */
 int mdc_synth_frames_device(mdc_ctx* ctx, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix,

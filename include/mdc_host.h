@@ -32,6 +32,8 @@ void mdch_fov_distort(mdch_fov*, float* x, float* y, int n);         /* distortC
 void mdch_fov_undistort_f32(const mdch_fov*, const float* in, float* out, int n_in, int n_out); /* undistort<float> */
 void mdch_fov_undistort_u8(const mdch_fov*, const unsigned char* in, float* out, int n_in, int n_out);
 
+void mdch_fov_model(const mdch_fov*, mdc_fov_model* model);           /* lens model for mdc_distort_points_* */
+
 /* PhotometricUndistorter(std::string file, std::string vignetteImage, int w, int h) */
 mdch_photo* mdch_photo_create(const char* pcalib_txt, const char* vignette_image, int w, int h);
 void mdch_photo_destroy(mdch_photo*);

@@ -27,15 +27,21 @@ HIP_SYMBOLS = [
     "mdc_set_remap", "mdc_unmap_host", "mdc_undistort_host_f32", "mdc_undistort_host_u8", "mdc_process_host",
     "mdc_host_alloc", "mdc_host_free", "mdc_process_frames_host",
     "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
-    "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device", "mdc_synth_frames_device", "mdc_export_tables", "mdc_import_tables",
+    "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device", "mdc_synth_frames_device",
+    "mdc_distort_points_device", "mdc_distort_points_host", "mdc_export_tables", "mdc_import_tables",
     "mdc_synchronize",
 ]
 HOST_SYMBOLS = [
     "mdch_fov_create", "mdch_fov_destroy", "mdch_fov_valid", "mdch_fov_has_gpu", "mdch_fov_dims",
-    "mdch_fov_intrinsics", "mdch_fov_remap", "mdch_fov_distort", "mdch_fov_undistort_f32", "mdch_fov_undistort_u8",
+    "mdch_fov_intrinsics", "mdch_fov_model", "mdch_fov_remap", "mdch_fov_distort", "mdch_fov_undistort_f32", "mdch_fov_undistort_u8",
     "mdch_photo_create", "mdch_photo_destroy", "mdch_photo_valid", "mdch_photo_has_gpu", "mdch_photo_ginv",
     "mdch_photo_g", "mdch_photo_vignette", "mdch_photo_unmap", "mdch_bind", "mdch_pack_tables",
 ]
+
+
+class FovModel(C.Structure):
+    _fields_ = [("in_calib", C.c_float * 5), ("in_w", C.c_int), ("in_h", C.c_int), ("out_calib", C.c_float * 5),
+                ("out_w", C.c_int), ("out_h", C.c_int)]
 
 
 class MdcInfo(C.Structure):
@@ -100,6 +106,8 @@ def hip_lib():
         L.mdc_pyramid_batch_device.argtypes = [_vp, _vp, _i, _i, _i, C.POINTER(_vp), _i64, _vp]
         L.mdc_process_pyramid_batch_device.argtypes = [_vp, _vp, _vp, _i, C.POINTER(_vp), _i64, C.c_uint, _vp]
         L.mdc_synth_frames_device.argtypes = [_vp, _vp, _i64, _i64, _i, _u32, _vp]
+        L.mdc_distort_points_device.argtypes = [_vp, C.POINTER(FovModel), _vp, _vp, _i64, _vp]
+        L.mdc_distort_points_host.argtypes = [_vp, C.POINTER(FovModel), _vp, _vp, _i64]
         L.mdc_export_tables.argtypes = [_vp, _vp, _sz, C.POINTER(_sz)]
         L.mdc_import_tables.argtypes = [_vp, _vp, _sz]
         L.mdc_synchronize.argtypes = [_vp]
@@ -128,6 +136,8 @@ def host_lib():
         L.mdch_fov_dims.restype = None
         L.mdch_fov_intrinsics.argtypes = [_vp, _vp]
         L.mdch_fov_intrinsics.restype = None
+        L.mdch_fov_model.argtypes = [_vp, C.POINTER(FovModel)]
+        L.mdch_fov_model.restype = None
         L.mdch_fov_remap.argtypes = [_vp, _vp, _vp]
         L.mdch_fov_remap.restype = _i
         L.mdch_fov_distort.argtypes = [_vp, _vp, _vp, _i]
@@ -288,6 +298,13 @@ class Context:
         self._chk(self._L.mdc_process_pyramid_batch_device(self._h, d_in, d_base, levels, arr, nframes, flags,
                                                            stream if stream else None))
 
+    def distort_points_host(self, model, x, y):
+        assert x.dtype == np.float32 and y.dtype == np.float32 and x.size == y.size
+        self._chk(self._L.mdc_distort_points_host(self._h, C.byref(model), _np_ptr(x), _np_ptr(y), x.size))
+
+    def distort_points_device(self, model, d_x, d_y, n, stream=0):
+        self._chk(self._L.mdc_distort_points_device(self._h, C.byref(model), d_x, d_y, n, stream if stream else None))
+
     def synth_frames(self, d_out, first_frame, nframes, npix, seed, stream=0):
         self._chk(self._L.mdc_synth_frames_device(self._h, d_out, first_frame, nframes, npix, seed, stream if stream else None))
 
@@ -364,6 +381,11 @@ class UndistorterFOV:
         if not self._L.mdch_fov_remap(self._h, _np_ptr(rx), _np_ptr(ry)):
             return None
         return rx, ry
+
+    def model(self):
+        m = FovModel()
+        self._L.mdch_fov_model(self._h, C.byref(m))
+        return m
 
     def distort_coordinates(self, x, y):
         assert x.dtype == np.float32 and y.dtype == np.float32 and x.size == y.size

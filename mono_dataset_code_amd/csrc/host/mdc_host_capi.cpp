@@ -16,6 +16,7 @@ struct MdcHostAccess {
   static const float* rx(const UndistorterFOV& u) { return u.remap_x_; }
   static const float* ry(const UndistorterFOV& u) { return u.remap_y_; }
   static const float* calib_out(const UndistorterFOV& u) { return u.calib_out_; }
+  static const float* calib_in(const UndistorterFOV& u) { return u.calib_in_; }
   static bool has_gpu(const UndistorterFOV& u) { return u.gpu_ != 0; }
   static bool has_gpu(const PhotometricUndistorter& p) { return p.gpu_ != 0; }
   static bool valid_gamma(const PhotometricUndistorter& p) { return p.valid_gamma_; }
@@ -47,7 +48,20 @@ int mdc_bind_objects(mdc_ctx* ctx, const UndistorterFOV* fov, const PhotometricU
   return rc;
 }
 
+void mdc_fov_model_of(const UndistorterFOV& u, mdc_fov_model* m) {
+  for (int i = 0; i < 5; i++) {
+    m->in_calib[i] = MdcHostAccess::calib_in(u)[i];
+    m->out_calib[i] = MdcHostAccess::calib_out(u)[i];
+  }
+  m->in_w = u.getInputDims()[0];
+  m->in_h = u.getInputDims()[1];
+  m->out_w = u.getOutputDims()[0];
+  m->out_h = u.getOutputDims()[1];
+}
+
 extern "C" {
+
+void mdch_fov_model(const mdch_fov* h, mdc_fov_model* m) { mdc_fov_model_of(*h->u, m); }
 
 mdch_fov* mdch_fov_create(const char* camera_txt) {
   mdch_fov* h = new mdch_fov;

@@ -701,6 +701,54 @@ int mdc_process_pyramid_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_b
   return MDC_OK;
 }
 
+// mdc_fov_model -> pixel-unit lens model, operation for operation as src/FOVUndistorter.cpp:289-301
+// (float products, `- 0.5` in double for the input camera, `- 0.5f`-equivalent narrowing for the output one,
+// double tan narrowed to float -- see DESIGN.md section 2).
+static DistortModel distort_model(const mdc_fov_model* f) {
+  DistortModel m;
+  const float dist = f->in_calib[4];
+  m.omega = dist;
+  m.d2t = 2.0f * ::tan((double)(dist / 2.0f));
+  m.fx = f->in_calib[0] * f->in_w;
+  m.fy = f->in_calib[1] * f->in_h;
+  m.cx = f->in_calib[2] * f->in_w - 0.5;
+  m.cy = f->in_calib[3] * f->in_h - 0.5;
+  m.ofx = f->out_calib[0] * f->out_w;
+  m.ofy = f->out_calib[1] * f->out_h;
+  m.ocx = f->out_calib[2] * f->out_w - 0.5f;
+  m.ocy = f->out_calib[3] * f->out_h - 0.5f;
+  return m;
+}
+
+int mdc_distort_points_device(mdc_ctx* c, const mdc_fov_model* model, float* d_x, float* d_y, int64_t n, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (!model || n < 0 || (n > 0 && (!d_x || !d_y))) return fail(c, MDC_ERR_ARG, "mdc_distort_points_device: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  MDC_HIP(c, launch_distort_points(d_x, d_y, n, distort_model(model), (hipStream_t)stream));
+  return MDC_OK;
+}
+
+int mdc_distort_points_host(mdc_ctx* c, const mdc_fov_model* model, float* x, float* y, int64_t n) {
+  if (!c) return MDC_ERR_ARG;
+  if (!model || n < 0 || (n > 0 && (!x || !y))) return fail(c, MDC_ERR_ARG, "mdc_distort_points_host: bad argument");
+  if (n == 0) return MDC_OK;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  const size_t bytes = (size_t)n * sizeof(float);
+  int rc = ensure_stage(c, bytes, bytes);
+  if (rc != MDC_OK) return rc;
+  float* dx = (float*)c->d_stage_in;
+  float* dy = c->d_stage_out;
+  MDC_HIP(c, hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, c->stream));
+  MDC_HIP(c, hipMemcpyAsync(dy, y, bytes, hipMemcpyHostToDevice, c->stream));
+  MDC_HIP(c, launch_distort_points(dx, dy, n, distort_model(model), c->stream));
+  MDC_HIP(c, hipMemcpyAsync(x, dx, bytes, hipMemcpyDeviceToHost, c->stream));
+  MDC_HIP(c, hipMemcpyAsync(y, dy, bytes, hipMemcpyDeviceToHost, c->stream));
+  MDC_HIP(c, hipStreamSynchronize(c->stream));
+  return MDC_OK;
+}
+
 int mdc_synth_frames_device(mdc_ctx* c, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix, uint32_t seed,
                             void* stream) {
   if (!c) return MDC_ERR_ARG;

@@ -72,6 +72,14 @@ constexpr size_t kLdsPerCU = 160 * 1024;
 // One 2x2 box level: dst (w/2 x h/2) from src (w x h), nframes images each.
 hipError_t launch_pyramid_level(const float* d_src, float* d_dst, int w, int h, int64_t nframes, hipStream_t s);
 
+// FOV lens model in pixel units, derived on the host exactly as src/FOVUndistorter.cpp:289-301 does.
+struct DistortModel {
+  float fx, fy, cx, cy, omega, d2t;  // input camera; d2t = 2 tan(omega / 2)
+  float ofx, ofy, ocx, ocy;          // rectified (output) camera
+};
+// (x, y) rectified pixel -> raw pixel, in place (UndistorterFOV::distortCoordinates).
+hipError_t launch_distort_points(float* d_x, float* d_y, int64_t n, const DistortModel& m, hipStream_t s);
+
 hipError_t launch_synth(uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix, uint32_t seed, hipStream_t s);
 
 }  // namespace mdc

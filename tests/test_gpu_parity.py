@@ -315,6 +315,40 @@ def test_batch_launch_is_graph_capturable(setups, oracle, torch_cuda):
                 assert bits_equal(got[i], s.want(oracle, np.roll(frames, rep, axis=0)[i], 1, 1, 1, 1)), (rep, i)
 
 
+@pytest.mark.parametrize("name", ["small_explicit", "small_crop", "small_full_black", "small_pinhole", "upsample", "full_1280_to_640"])
+def test_distort_points_on_gpu_equals_host_libm(name, setups, oracle, calib_dirs, torch_cuda):
+    """distortCoordinates on the GPU (fdlibm atanf restated in the kernel) against the oracle and against the
+    class method (both on the host libm): bit for bit on 2*10^6 points that sweep every branch of atanf
+    (inside the image, far outside, tiny radii, the exact centre)."""
+    from mono_dataset_code_amd import capi
+
+    s = setups(name)
+    m = s.fov.model()
+    rng = np.random.RandomState(5)
+    n = 2_000_000
+    x = (rng.rand(n).astype(np.float32) * 3 - 1) * np.float32(s.w)  # -w .. 2w
+    y = (rng.rand(n).astype(np.float32) * 3 - 1) * np.float32(s.h)
+    x[:1000] = np.float32(m.out_calib[2] * m.out_w) - np.float32(0.5) + (rng.rand(1000).astype(np.float32) - 0.5) * np.float32(1e-3)  # r ~ 0
+    y[:1000] = np.float32(m.out_calib[3] * m.out_h) - np.float32(0.5) + (rng.rand(1000).astype(np.float32) - 0.5) * np.float32(1e-3)
+    x[1000:2000] *= np.float32(1e4)  # huge radii: atanf's far branch
+    want_x, want_y = x.copy(), y.copy()
+    oracle.distort(s.cam, np.array(list(m.out_calib), np.float32), want_x, want_y)
+    cls_x, cls_y = x.copy(), y.copy()
+    s.fov.distort_coordinates(cls_x, cls_y)  # the drop-in class method (host)
+    assert np.array_equal(cls_x.view(np.uint32), want_x.view(np.uint32)) and np.array_equal(cls_y.view(np.uint32), want_y.view(np.uint32))
+    got_x, got_y = x.copy(), y.copy()
+    s.ctx.distort_points_host(m, got_x, got_y)
+    bad = int((got_x.view(np.uint32) != want_x.view(np.uint32)).sum() + (got_y.view(np.uint32) != want_y.view(np.uint32)).sum())
+    assert bad == 0, (name, bad)
+    # device-pointer flavour
+    torch = torch_cuda
+    d_x, d_y = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    s.ctx.distort_points_device(m, d_x.data_ptr(), d_y.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_x.cpu().numpy().view(np.uint32), want_x.view(np.uint32))
+    assert np.array_equal(d_y.cpu().numpy().view(np.uint32), want_y.view(np.uint32))
+
+
 def test_pyramid(torch_cuda, oracle):
     """4-level box pyramid (own definition, parity unpinned by the reference)."""
     from mono_dataset_code_amd import capi
