@@ -132,18 +132,25 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; MDC_BENCH_BACKEND=gloo lets the tests run several ranks on ONE GPU (RCCL refuses that)
+    backend = os.environ.get("MDC_BENCH_BACKEND", "nccl")
+    gpu = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mono_dataset_code_amd import capi, shard, synth
 
     # ---- calibration: rank 0 builds (host C++ classes), everyone imports the blob ----
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(gpu)
     calib_dir = None
     blob = None
     if rank == 0:
@@ -164,7 +171,7 @@ def main():
         assert fov.is_valid() and photo.valid() == 3
         blob = capi.pack_tables(fov, photo)  # host-side serialisation of GInv, vignetteInv, remapX/Y
     if world > 1:
-        blob = shard.broadcast_tables(blob, src=0, device=dev)  # the only collective: once, over RCCL
+        blob = shard.broadcast_tables(blob, src=0, device=coll_dev)  # the only collective: once, over RCCL
     ctx.import_tables(blob)  # every rank (rank 0 included) uploads the same bytes
     ctx.set_option(capi.OPT_KERNEL, {"auto": capi.KERNEL_AUTO, "gather": capi.KERNEL_GATHER, "tiled": capi.KERNEL_TILED}[args.kernel])
     ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, args.fpb)
@@ -221,7 +228,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))

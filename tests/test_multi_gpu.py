@@ -91,3 +91,25 @@ def test_packed_blob_equals_exported_blob(calib_dirs):
     assert np.array_equal(c2.export_tables(), packed)
     i1, i2 = ctx.info(), c2.info()
     assert (i1.in_w, i1.out_w, i1.tiled, i1.n_tiles, i1.src_bbox_bytes) == (i2.in_w, i2.out_w, i2.tiled, i2.n_tiles, i2.src_bbox_bytes)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N>1 path end to end (rank-0 table build, broadcast, import on every rank, round-robin
+    shard, barrier + max-over-ranks timing, one JSON line from rank 0) with two ranks sharing the one GPU
+    of the test box: gloo carries the collectives there (RCCL wants one device per rank)."""
+    import json
+
+    env = dict(os.environ, MDC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--frames", "64", "--preroll-s", "0.05"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("[Gloo]")]  # gloo announces itself on stdout
+    assert len(lines) == 1, r.stdout  # exactly one JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 5
+    assert out["config"]["frames_per_gpu_per_step"] == 64 and "cpu_baseline" not in out
+    assert out["parity"]["mismatching_pixels"] == 0
+    assert out["config"]["tables"].startswith("rank-0 build")
