@@ -81,7 +81,7 @@ typedef struct mdc_info {
   int lds_bytes;             /* dynamic LDS per workgroup of the tiled kernel       */
   int src_bbox[4];           /* x0,y0,x1,y1 (inclusive) of source pixels any valid output taps */
   int64_t src_bbox_bytes;    /* bbox area in bytes (u8 source)                      */
-  int64_t src_staged_bytes;  /* bytes the tiled kernel stages per frame (sum of windows) */
+  int64_t src_staged_bytes;  /* bytes the tiled kernel stages per frame (sum of the exact per-row windows) */
   int64_t n_black;           /* outputs whose remap is the (-1,-1) sentinel         */
 } mdc_info;
 
