@@ -37,6 +37,19 @@ def test_libmdc_host_exports_header():
         assert hasattr(lib, n), n
 
 
+def test_headers_compile_as_plain_c_and_cxx(tmp_path):
+    """include/mdc_hip.h and mdc_host.h are a C ABI: they must parse as C99 and as C++ with nothing but libc headers."""
+    import subprocess
+
+    src = tmp_path / "abi.c"
+    src.write_text('#include "mdc_host.h"\nint main(void){ mdc_info i; mdc_fov_model m; (void)i; (void)m; return MDC_OK; }\n')
+    inc = os.path.join(ROOT, "include")
+    for cmd in (["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I" + inc, str(src)],
+                ["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I" + inc, str(src)]):
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+
+
 def test_signatures_have_no_torch_types():
     for h in ("mdc_hip.h", "mdc_host.h"):
         txt = open(os.path.join(ROOT, "include", h)).read()
