@@ -61,7 +61,7 @@ enum {
   MDC_KERNEL_TILED = 2   /* LDS-staged source windows (fails if not plannable)     */
 };
 enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2 /* frames a workgroup loops over; 0 = automatic */,
-       MDC_OPT_TILE_ROWS = 5 /* tuning: output tile 64 x {16, 32, 60, 64} (256 / 512 / 960 / 1024 threads) */,
+       MDC_OPT_TILE_ROWS = 5 /* tuning: output tile 64 x {16, 32, 60, 64} (256 / 512 / 960 / 1024 threads); 0 = automatic */,
        MDC_OPT_TILE_ORDER = 6 /* tuning: placement of output tiles on the 8 XCDs, MDC_ORDER_* */,
        MDC_OPT_WINDOW_BUFFERS = 7 /* tuning: LDS window buffers per workgroup, 2..4 (frames staged ahead + 1); 0 = automatic */,
        MDC_OPT_FRAME_INTERLEAVE = 8 /* tuning: a workgroup takes every G-th frame (1) or a run of consecutive frames (0) */ };

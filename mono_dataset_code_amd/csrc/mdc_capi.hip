@@ -61,7 +61,7 @@ struct mdc_ctx {
   // options
   int opt_kernel = MDC_KERNEL_AUTO;
   int opt_fpb = 0;
-  int opt_tile_h = 32;
+  int opt_tile_h = 0;  // 0 = automatic: the first of 32, 64, 60, 16 whose windows fit
   int opt_order = MDC_ORDER_BANDS;
   int opt_nbuf = 0;  // 0 = automatic
   int opt_interleave = 0;
@@ -212,9 +212,9 @@ int upload(mdc_ctx* c, T** dst, const std::vector<T>& v) {
 // The plan for source pixels of `es` bytes (1 = raw u8 frames with the LUT replicas in LDS,
 // 4 = float frames, no LUT): a 16-byte chunk holds 16 / es pixels.  Leaves pl.tiled = false when
 // frame rows are not whole chunks or a window is too large.
-int plan_source(mdc_ctx* c, int es, mdc_ctx::SrcPlan& pl) {
+int plan_source(mdc_ctx* c, int es, int kTileH, mdc_ctx::SrcPlan& pl) {
   const int ow = c->out_w, oh = c->out_h, iw = c->rm_in_w;
-  const int kTileH = c->opt_tile_h, kTileThreads = 16 * kTileH;
+  const int kTileThreads = 16 * kTileH;
   const int tx = (ow + kTileW - 1) / kTileW, ty = (oh + kTileH - 1) / kTileH;
   const int n_tiles = tx * ty;
   const int ppc = 16 / es;  // pixels per chunk
@@ -311,8 +311,6 @@ int plan_tiles(mdc_ctx* c) {
   c->bbox[2] = c->bbox[3] = -1;
   free_plan(c);
   const int ow = c->out_w, oh = c->out_h;
-  const int kTileH = c->opt_tile_h;
-  const int tx = (ow + kTileW - 1) / kTileW, ty = (oh + kTileH - 1) / kTileH;
   for (size_t i = 0; i < (size_t)ow * oh; i++) {
     const float xx = c->h_rx[i], yy = c->h_ry[i];
     if (xx < 0) {
@@ -325,9 +323,18 @@ int plan_tiles(mdc_ctx* c) {
     c->bbox[3] = std::max(c->bbox[3], (int)yy + 1);
   }
   if (c->bbox[2] < 0) c->bbox[0] = c->bbox[1] = 0;
-  int rc;
-  if ((rc = plan_source(c, 1, c->plan[0])) != MDC_OK || (rc = plan_source(c, 4, c->plan[1])) != MDC_OK) return rc;
+  // Tile height: the requested one, or the first candidate whose raw-frame windows fit (strongly
+  // distorting cameras need the taller tiles: their windows are too wide for 3 staging rounds of 512 threads).
+  int rc, kTileH = 0;
+  const int candidates[4] = {32, 64, 60, 16};
+  for (int k = 0; k < (c->opt_tile_h ? 1 : 4); k++) {
+    kTileH = c->opt_tile_h ? c->opt_tile_h : candidates[k];
+    free_plan(c);
+    if ((rc = plan_source(c, 1, kTileH, c->plan[0])) != MDC_OK || (rc = plan_source(c, 4, kTileH, c->plan[1])) != MDC_OK) return rc;
+    if (c->plan[0].tiled) break;
+  }
   if (!c->plan[0].tiled && !c->plan[1].tiled) return MDC_OK;
+  const int tx = (ow + kTileW - 1) / kTileW, ty = (oh + kTileH - 1) / kTileH;
   const std::vector<int> order = tile_order(tx, ty, c->opt_order);
   if ((rc = upload(c, &c->d_order, order)) != MDC_OK) return rc;
   c->n_blocks = (int)order.size();
@@ -507,7 +514,8 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
       c->opt_fpb = value;
       return MDC_OK;
     case MDC_OPT_TILE_ROWS: {
-      if (value != 16 && value != 32 && value != 60 && value != 64) return fail(c, MDC_ERR_ARG, "tile rows must be 16, 32, 60 or 64");
+      if (value != 0 && value != 16 && value != 32 && value != 60 && value != 64)
+        return fail(c, MDC_ERR_ARG, "tile rows must be 0 (automatic), 16, 32, 60 or 64");
       if (value == c->opt_tile_h) return MDC_OK;
       c->opt_tile_h = value;
       if (!c->valid_remap) return MDC_OK;
@@ -554,7 +562,7 @@ int mdc_get_info(mdc_ctx* c, mdc_info* i) {
   i->valid_remap = c->valid_remap;
   i->tiled = c->valid_remap && c->tiled;
   i->tile_w = kTileW;
-  i->tile_h = c->opt_tile_h;
+  i->tile_h = c->tiled ? c->tile_h : c->opt_tile_h;
   i->n_tiles = c->n_tiles;
   i->lds_bytes = c->tiled ? (int)tiled_lds_bytes(c->plan[0].win_bytes, c->plan[0].nbuf, true) : 0;
   for (int k = 0; k < 4; k++) i->src_bbox[k] = c->bbox[k];

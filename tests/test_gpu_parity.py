@@ -114,7 +114,7 @@ def test_tiled_and_gather_kernels_agree(name, setups, oracle, torch_cuda):
     s.ctx.set_option(capi.OPT_TILE_ORDER, capi.ORDER_BANDS)
     s.ctx.set_option(capi.OPT_WINDOW_BUFFERS, 0)
     s.ctx.set_option(capi.OPT_FRAME_INTERLEAVE, 0)
-    s.ctx.set_option(capi.OPT_TILE_ROWS, 32)
+    s.ctx.set_option(capi.OPT_TILE_ROWS, 0)
     s.ctx.set_option(capi.OPT_KERNEL, capi.KERNEL_AUTO)
     s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, 0)
 
@@ -165,7 +165,7 @@ def test_undistort_f32_batch_tiled_and_gather(name, setups, oracle, torch_cuda):
         torch.cuda.synchronize()
         assert bits_equal(d_out.cpu().numpy(), want), (name, kernel, rows, nbuf, fpb)
     s.ctx.set_option(capi.OPT_KERNEL, capi.KERNEL_AUTO)
-    s.ctx.set_option(capi.OPT_TILE_ROWS, 32)
+    s.ctx.set_option(capi.OPT_TILE_ROWS, 0)
     s.ctx.set_option(capi.OPT_WINDOW_BUFFERS, 0)
     s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, 0)
 
@@ -250,6 +250,21 @@ def test_full_size_config_and_properties(setups, oracle, torch_cuda):
     # config 2: unMapImage only, full size
     want = oracle.unmap(frames[0], s.ginv, s.vinv, True, True, 1, 1, 1)
     assert bits_equal(d_tmp[:npix].cpu().numpy(), want)
+
+
+def test_automatic_tile_height_keeps_strong_distortion_on_the_tiled_kernel(setups):
+    """'full' cameras have source windows too wide for 64x32 tiles; the automatic choice moves to taller tiles
+    instead of dropping to the gather kernel."""
+    from mono_dataset_code_amd import capi
+
+    for name, expect in (("small_explicit", 32), ("small_full_black", 64), ("pyr_whole_black", 64)):
+        s = setups(name)
+        s.ctx.set_option(capi.OPT_TILE_ROWS, 0)
+        info = s.ctx.info()
+        assert info.tiled and info.tile_h == expect, (name, info.tiled, info.tile_h)
+        s.ctx.set_option(capi.OPT_TILE_ROWS, 32)
+        assert s.ctx.info().tiled == (expect == 32)
+        s.ctx.set_option(capi.OPT_TILE_ROWS, 0)
 
 
 def test_batch_beyond_4gib(setups, oracle, torch_cuda):
@@ -401,7 +416,7 @@ def test_process_pyramid_fused(name, setups, oracle, torch_cuda):
                 want = oracle.pyramid_level(src, cw, ch)
                 assert bits_equal(lv[l].view(n, -1)[f].cpu().numpy(), want), (name, rows, levels, f, l + 1)
                 src, cw, ch = want, cw // 2, ch // 2
-    s.ctx.set_option(capi.OPT_TILE_ROWS, 32)
+    s.ctx.set_option(capi.OPT_TILE_ROWS, 0)
     s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, 0)
 
 
