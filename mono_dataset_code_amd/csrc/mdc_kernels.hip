@@ -38,6 +38,9 @@ constexpr int kLutBytes = 256 * kLutRep * 4;
 #ifndef MDC_EXP_SKIP_STORE
 #define MDC_EXP_SKIP_STORE 0  // diagnosis: outputs are computed but (practically) never stored -> read side alone
 #endif
+#ifndef MDC_EXP_FAKE_COMPUTE
+#define MDC_EXP_FAKE_COMPUTE 0  // diagnosis (wrong results): 1 = one tap + one LUT read per output instead of 4 + 4, 2 = no LDS reads
+#endif
 #ifndef MDC_EXP_SKIP_LOAD
 #define MDC_EXP_SKIP_LOAD 0   // diagnosis: every frame re-stages frame 0 (L2 hits) -> write side alone
 #endif
@@ -311,6 +314,17 @@ __device__ __forceinline__ void tile_compute(const TileThread& t, const unsigned
     }
     // explicit byte loads: two adjacent byte loads fused into one ds_read_u16 at an odd
     // address are replayed by the LDS (SQ_LDS_UNALIGNED_STALL), hence volatile
+#if MDC_EXP_FAKE_COMPUTE
+    {
+      float r = t.bl[j].w00;
+#if MDC_EXP_FAKE_COMPUTE == 1
+      r = r * my_lut[(int)((const volatile __attribute__((address_space(3))) unsigned char*)(w + t.off0[j]))[0] * kLutRep];
+#endif
+      res[j] = r;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, t.obyte[j], 0, kStoreAux);
+      continue;
+    }
+#endif
     typedef const volatile __attribute__((address_space(3))) unsigned char* tap_ptr;
     tap_ptr p = (tap_ptr)(w + t.off0[j]);
     tap_ptr q = (tap_ptr)(w + t.off1[j]);
