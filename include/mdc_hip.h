@@ -61,12 +61,14 @@ enum {
   MDC_KERNEL_TILED = 2   /* LDS-staged source windows (fails if not plannable)     */
 };
 enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2 /* frames a workgroup loops over; 0 = automatic */,
-       MDC_OPT_TILE_ROWS = 5 /* tuning: output tile 64 x {16, 32, 60, 64} (256 / 512 / 960 / 1024 threads); 0 = automatic */,
+       MDC_OPT_TILE_ROWS = 5 /* tuning: output tile rows {16, 32, 60, 64} (64 columns: 256 / 512 / 960 / 1024 threads); 0 = automatic */,
        MDC_OPT_TILE_ORDER = 6 /* tuning: placement of output tiles on the 8 XCDs, MDC_ORDER_* */,
        MDC_OPT_WINDOW_BUFFERS = 7 /* tuning: LDS window buffers per workgroup, 2..4 (frames staged ahead + 1); 0 = automatic */,
-       MDC_OPT_FRAME_INTERLEAVE = 8 /* tuning: a workgroup takes every G-th frame (1) or a run of consecutive frames (0) */ };
+       MDC_OPT_FRAME_INTERLEAVE = 8 /* tuning: a workgroup takes every G-th frame (1) or a run of consecutive frames (0) */,
+       MDC_OPT_TILE_COLS = 9 /* tuning: output tile {64, 128} x rows (128 x {16, 32}: 512 / 1024 threads); 0 = automatic */ };
 enum { MDC_ORDER_BANDS = 0 /* row-major runs of tiles per XCD */, MDC_ORDER_ROWS = 1 /* whole tile rows per XCD */,
-       MDC_ORDER_IDENTITY = 2 /* block b = tile b (diagnosis) */ };
+       MDC_ORDER_IDENTITY = 2 /* block b = tile b (diagnosis) */,
+       MDC_ORDER_BLOCKS2D = 3 /* the tile grid cut into 8 rectangles, one per XCD */ };
 
 typedef struct mdc_info {
   int device;                /* HIP device ordinal                                  */
@@ -79,6 +81,9 @@ typedef struct mdc_info {
   int tile_w, tile_h;        /* output tile of the tiled kernel                     */
   int n_tiles;
   int lds_bytes;             /* dynamic LDS per workgroup of the tiled kernel       */
+  int window_buffers;        /* LDS window buffers of the tiled kernel (frames staged ahead + 1) */
+  int f32_tiled;             /* 1 if undistort<float> runs on the LDS-tiled kernel; it has its own tile shape: */
+  int f32_tile_w, f32_tile_h;
   int src_bbox[4];           /* x0,y0,x1,y1 (inclusive) of source pixels any valid output taps */
   int64_t src_bbox_bytes;    /* bbox area in bytes (u8 source)                      */
   int64_t src_staged_bytes;  /* bytes the tiled kernel stages per frame (sum of the exact per-row windows) */
@@ -196,6 +201,18 @@ int mdc_distort_points_host(mdc_ctx* ctx, const mdc_fov_model* model, float* x, 
  * byte i of frame f = fmix32(seed + (first_frame+f)*npix + i) >> 24. */
 int mdc_synth_frames_device(mdc_ctx* ctx, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix,
                             uint32_t seed, void* stream);
+
+/* Measurement utilities (bench.py; nothing of the reference corresponds to them).
+ * mdc_describe_launch: the kernel instantiation mdc_process_batch_device (pyramid_levels <= 1) or
+ * mdc_process_pyramid_batch_device (pyramid_levels = its `levels`) launches for `flags` with the current tables
+ * and options, spelt as rocprofv3 prints it without namespaces -- so a recorded PMC figure can be matched to
+ * the kernel that actually ran.
+ * mdc_ceiling_mix_device: a linear, arithmetic-free stream reading read_bytes from d_read (16-byte aligned)
+ * while writing write_bytes to d_write with `blocks` workgroups of 256 -- the rate the memory system of THIS
+ * box gives to a kernel's traffic mix, to normalise the kernel's own rate against. */
+int mdc_describe_launch(mdc_ctx* ctx, unsigned flags, int pyramid_levels, char* buf, size_t cap);
+int mdc_ceiling_mix_device(mdc_ctx* ctx, const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes,
+                           int blocks, void* stream);
 
 /* ---- calibration hand-over between ranks (multi-GPU) ------------------------ */
 

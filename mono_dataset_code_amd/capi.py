@@ -17,8 +17,8 @@ LIB_HOST_PATH = os.path.join(_PKG, "libmdc_host.so")
 # flag word (include/mdc_hip.h)
 GAMMA, VIGNETTE, KILL_OVEREXPOSED, RECTIFY = 1, 2, 4, 8
 KERNEL_AUTO, KERNEL_GATHER, KERNEL_TILED = 0, 1, 2
-OPT_KERNEL, OPT_FRAMES_PER_BLOCK, OPT_TILE_ROWS, OPT_TILE_ORDER, OPT_WINDOW_BUFFERS, OPT_FRAME_INTERLEAVE = 1, 2, 5, 6, 7, 8
-ORDER_BANDS, ORDER_ROWS, ORDER_IDENTITY = 0, 1, 2
+OPT_KERNEL, OPT_FRAMES_PER_BLOCK, OPT_TILE_ROWS, OPT_TILE_ORDER, OPT_WINDOW_BUFFERS, OPT_FRAME_INTERLEAVE, OPT_TILE_COLS = 1, 2, 5, 6, 7, 8, 9
+ORDER_BANDS, ORDER_ROWS, ORDER_IDENTITY, ORDER_BLOCKS2D = 0, 1, 2, 3
 OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 
 # every symbol include/mdc_hip.h declares (checked by tests/test_abi.py)
@@ -29,7 +29,7 @@ HIP_SYMBOLS = [
     "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
     "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device", "mdc_synth_frames_device",
     "mdc_distort_points_device", "mdc_distort_points_host", "mdc_export_tables", "mdc_import_tables",
-    "mdc_synchronize",
+    "mdc_synchronize", "mdc_describe_launch", "mdc_ceiling_mix_device",
 ]
 HOST_SYMBOLS = [
     "mdch_fov_create", "mdch_fov_destroy", "mdch_fov_valid", "mdch_fov_has_gpu", "mdch_fov_dims",
@@ -48,6 +48,7 @@ class MdcInfo(C.Structure):
     _fields_ = [("device", C.c_int), ("in_w", C.c_int), ("in_h", C.c_int), ("out_w", C.c_int), ("out_h", C.c_int),
                 ("valid_gamma", C.c_int), ("valid_vignette", C.c_int), ("valid_remap", C.c_int), ("tiled", C.c_int),
                 ("tile_w", C.c_int), ("tile_h", C.c_int), ("n_tiles", C.c_int), ("lds_bytes", C.c_int),
+                ("window_buffers", C.c_int), ("f32_tiled", C.c_int), ("f32_tile_w", C.c_int), ("f32_tile_h", C.c_int),
                 ("src_bbox", C.c_int * 4), ("src_bbox_bytes", C.c_int64), ("src_staged_bytes", C.c_int64),
                 ("n_black", C.c_int64)]
 
@@ -111,7 +112,13 @@ def hip_lib():
         L.mdc_export_tables.argtypes = [_vp, _vp, _sz, C.POINTER(_sz)]
         L.mdc_import_tables.argtypes = [_vp, _vp, _sz]
         L.mdc_synchronize.argtypes = [_vp]
+        old_build = LIB_HIP_PATH != os.path.join(_PKG, "libmdc_hip.so")  # tools/sweep.py --libs: A/B against earlier builds
+        if not old_build or hasattr(L, "mdc_describe_launch"):
+            L.mdc_describe_launch.argtypes = [_vp, C.c_uint, _i, C.c_char_p, _sz]
+            L.mdc_ceiling_mix_device.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int64, _i, _vp]
         for n in HIP_SYMBOLS:
+            if old_build and not hasattr(L, n):
+                continue
             if n not in ("mdc_destroy", "mdc_last_error", "mdc_host_alloc", "mdc_host_free"):
                 getattr(L, n).restype = _i
         _hip = L
@@ -321,6 +328,14 @@ class Context:
 
     def synchronize(self):
         self._chk(self._L.mdc_synchronize(self._h))
+
+    def describe_launch(self, flags, pyramid_levels=0):
+        buf = C.create_string_buffer(256)
+        self._chk(self._L.mdc_describe_launch(self._h, flags, pyramid_levels, buf, 256))
+        return buf.value.decode()
+
+    def ceiling_mix(self, d_read, read_bytes, d_write, write_bytes, blocks=16384, stream=0):
+        self._chk(self._L.mdc_ceiling_mix_device(self._h, d_read, read_bytes, d_write, write_bytes, blocks, stream if stream else None))
 
     def bind(self, fov=None, photo=None):
         rc = host_lib().mdch_bind(self._h, fov._h if fov is not None else None, photo._h if photo is not None else None)

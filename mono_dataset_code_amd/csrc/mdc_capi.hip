@@ -41,27 +41,26 @@ struct mdc_ctx {
   std::vector<float> h_rx, h_ry;
   float *d_rx = nullptr, *d_ry = nullptr;
 
-  // tile plan
-  bool tiled = false;
-  // tile plans, see TilePlan (mdc_internal.h): [0] raw u8 frames (fused path), [1] float frames (undistort<float>)
+  // tile plans, see TilePlan (mdc_internal.h): [0] raw u8 frames (fused path), [1] float frames
+  // (undistort<float>).  Each source type has its own tile shape and XCD placement table.
   struct SrcPlan {
     uint32_t* d_chunks = nullptr;
     int* d_nch = nullptr;
     uint32_t* d_taps = nullptr;
+    int* d_order = nullptr;  // block -> tile placement table (XCD bands)
     int chunk_cap = 0, win_bytes = 0, nbuf = 2;
+    int tile_w = 0, tile_h = 0, n_tiles = 0, tiles_x = 0, n_blocks = 0;
     bool tiled = false;
     int64_t staged_bytes = 0;
   } plan[2];
-  int* d_order = nullptr;  // block -> tile placement table (XCD bands)
-  int n_blocks = 0;
-  int n_tiles = 0, tiles_x = 0, tile_h = 0;
   int bbox[4] = {0, 0, -1, -1};
-  int64_t staged_bytes = 0, n_black = 0;
+  int64_t n_black = 0;
 
   // options
   int opt_kernel = MDC_KERNEL_AUTO;
   int opt_fpb = 0;
-  int opt_tile_h = 0;  // 0 = automatic: the first of 32, 64, 60, 16 whose windows fit
+  int opt_tile_h = 0;  // 0 = automatic: the first shape of the candidate list whose windows fit
+  int opt_tile_w = 0;  // 0 = automatic
   int opt_order = MDC_ORDER_BANDS;
   int opt_nbuf = 0;  // 0 = automatic
   int opt_interleave = 0;
@@ -147,7 +146,11 @@ int frames_per_block(const mdc_ctx* c, int64_t nframes, int blocks_per_group, in
   // workgroup so the per-workgroup table reads stay amortised
   int64_t groups = std::max<int64_t>(1, (target_wgs + blocks_per_group - 1) / std::max(1, blocks_per_group));
   groups = std::min<int64_t>(groups, std::max<int64_t>(1, nframes / 8));
-  return (int)((nframes + groups - 1) / groups);
+  int64_t fpb = (nframes + groups - 1) / groups;
+  // few, large tiles (128 x 32: 80 blocks per frame group): not below 32 frames per workgroup as long as
+  // that still leaves >= 2048 workgroups -- the per-workgroup prologue costs about two frames' time
+  if (fpb < 32 && (int64_t)blocks_per_group * ((nframes + 31) / 32) >= 2048) fpb = 32;
+  return (int)fpb;
 }
 
 // Placement table of the tiled kernel: entry b = tile run by block b of a frame group, -1 = none.
@@ -158,10 +161,35 @@ int frames_per_block(const mdc_ctx* c, int64_t nframes, int blocks_per_group, in
 //   MDC_ORDER_ROWS      whole tile rows per XCD, as even as the row count allows (no horizontal
 //                       neighbours split; XCDs with a row less idle at the end of a frame group)
 //   MDC_ORDER_IDENTITY  block b = tile b: neighbours land on different XCDs (diagnosis: worst case)
+//   MDC_ORDER_BLOCKS2D  the tile grid cut into 8 rectangles by recursive bisection of the longer side
+//                       (least shared halo perimeter between XCDs; the rectangles differ in size by up to
+//                       one row / column, XCDs with fewer tiles get padding slots)
+static void bisect(int x0, int y0, int x1, int y1, int parts, int tx, std::vector<std::vector<int>>& out) {
+  if (parts == 1) {
+    std::vector<int> v;
+    for (int y = y0; y < y1; y++)
+      for (int x = x0; x < x1; x++) v.push_back(y * tx + x);
+    out.push_back(v);
+    return;
+  }
+  if (x1 - x0 > y1 - y0) {
+    const int xm = x0 + (x1 - x0 + 1) / 2;
+    bisect(x0, y0, xm, y1, parts / 2, tx, out);
+    bisect(xm, y0, x1, y1, parts / 2, tx, out);
+  } else {
+    const int ym = y0 + (y1 - y0 + 1) / 2;
+    bisect(x0, y0, x1, ym, parts / 2, tx, out);
+    bisect(x0, ym, x1, y1, parts / 2, tx, out);
+  }
+}
+
 std::vector<int> tile_order(int tx, int ty, int mode) {
   const int n = tx * ty;
   std::vector<std::vector<int>> per_xcd(8);
-  if (mode == MDC_ORDER_IDENTITY) {
+  if (mode == MDC_ORDER_BLOCKS2D && tx * ty >= 8) {
+    per_xcd.clear();
+    bisect(0, 0, tx, ty, 8, tx, per_xcd);
+  } else if (mode == MDC_ORDER_IDENTITY) {
     for (int t = 0; t < n; t++) per_xcd[t % 8].push_back(t);
   } else if (mode == MDC_ORDER_ROWS && ty >= 8) {
     int r = 0;
@@ -186,19 +214,19 @@ std::vector<int> tile_order(int tx, int ty, int mode) {
 // Plan of the tiled kernel (see TilePlan): per tile the exact source window as a list of
 // 16-byte chunks, per output the LDS offsets of its two tap rows.  Fails (tiled = false)
 // when rows of the frame are not whole 16-byte chunks or a window is too large for LDS.
+void free_src_plan(mdc_ctx::SrcPlan& pl) {
+  for (void** p : {(void**)&pl.d_chunks, (void**)&pl.d_nch, (void**)&pl.d_taps, (void**)&pl.d_order})
+    if (*p) {
+      (void)hipFree(*p);
+      *p = nullptr;
+    }
+  pl.tiled = false;
+  pl.staged_bytes = 0;
+  pl.n_tiles = pl.tiles_x = pl.n_blocks = 0;
+}
 void free_plan(mdc_ctx* c) {
   for (auto& pl : c->plan) {
-    for (void** p : {(void**)&pl.d_chunks, (void**)&pl.d_nch, (void**)&pl.d_taps})
-      if (*p) {
-        (void)hipFree(*p);
-        *p = nullptr;
-      }
-    pl.tiled = false;
-    pl.staged_bytes = 0;
-  }
-  if (c->d_order) {
-    (void)hipFree(c->d_order);
-    c->d_order = nullptr;
+    free_src_plan(pl);
   }
 }
 
@@ -212,15 +240,18 @@ int upload(mdc_ctx* c, T** dst, const std::vector<T>& v) {
 // The plan for source pixels of `es` bytes (1 = raw u8 frames with the LUT replicas in LDS,
 // 4 = float frames, no LUT): a 16-byte chunk holds 16 / es pixels.  Leaves pl.tiled = false when
 // frame rows are not whole chunks or a window is too large.
-int plan_source(mdc_ctx* c, int es, int kTileH, mdc_ctx::SrcPlan& pl) {
+int plan_source(mdc_ctx* c, int es, int kTileW, int kTileH, mdc_ctx::SrcPlan& pl) {
   const int ow = c->out_w, oh = c->out_h, iw = c->rm_in_w;
-  const int kTileThreads = 16 * kTileH;
+  const int kTileThreads = kTileW * kTileH / 4;
+  pl.staged_bytes = 0;
   const int tx = (ow + kTileW - 1) / kTileW, ty = (oh + kTileH - 1) / kTileH;
   const int n_tiles = tx * ty;
   const int ppc = 16 / es;  // pixels per chunk
   const bool lut = es == 1;
   // whole 16-byte chunks per frame row; one frame within the 32-bit lane offsets of the buffer descriptors
   bool ok = (iw % ppc == 0) && (int64_t)iw * c->rm_in_h * es < (int64_t)kOutside && (int64_t)ow * oh * 4 < (int64_t)kOutside;
+  // the 960-/1024-thread tiles derive the output offsets of rows 1..3 from row 0 (kOutsideLean, mdc_kernels.hip)
+  if (kTileThreads >= 960 && (int64_t)ow * (oh + kTileH) * 4 >= 0xc0000000ll) ok = false;
   std::vector<std::vector<uint32_t>> chunks(n_tiles);
   std::vector<int> nch(n_tiles, 0);
   std::vector<uint32_t> taps((size_t)ow * oh, 0u);
@@ -272,19 +303,20 @@ int plan_source(mdc_ctx* c, int es, int kTileH, mdc_ctx::SrcPlan& pl) {
         taps[(size_t)y * ow + x] = (uint32_t)(r0.lds + (xi - r0.x0) * es) | ((uint32_t)(r1.lds + (xi - r1.x0) * es) << 16);
       }
   }
-  int cap = kTileThreads, nch_max = 1;
-  for (int t = 0; t < n_tiles; t++) {
-    cap = std::max(cap, (nch[t] + kTileThreads - 1) / kTileThreads * kTileThreads);
-    nch_max = std::max(nch_max, nch[t]);
-  }
+  // every tile's chunk list is padded (kOutside) to the kernel's maximum of staging rounds: the kernel loads
+  // all of them unconditionally, first thing, before it knows the tile's chunk count
+  const int cap = (lut ? kTileMaxChunks : kTileMaxChunksF32) * kTileThreads;
+  int nch_max = 1;
+  for (int t = 0; t < n_tiles; t++) nch_max = std::max(nch_max, nch[t]);
   const int win_bytes = (nch_max * 16 + 1023) & ~1023;  // a wave's DMA destination is 1 KiB aligned
   // Window buffers: as many frames staged ahead as LDS allows WITHOUT lowering the number of
   // workgroups per CU that two buffers permit (occupancy first, then depth), at most 4.
   const int wg_per_cu =
       std::max<int>(1, std::min<size_t>(kLdsPerCU / tiled_lds_bytes(win_bytes, 2, lut), 2048 / kTileThreads));
+  const int nbuf_max = kTileThreads > 512 ? 3 : 4;
   int nbuf = 2;
-  while (nbuf < 4 && tiled_lds_bytes(win_bytes, nbuf + 1, lut) * wg_per_cu <= kLdsPerCU) nbuf++;
-  if (c->opt_nbuf) nbuf = c->opt_nbuf;
+  while (nbuf < nbuf_max && tiled_lds_bytes(win_bytes, nbuf + 1, lut) * wg_per_cu <= kLdsPerCU) nbuf++;
+  if (c->opt_nbuf) nbuf = std::min(c->opt_nbuf, nbuf_max);
   if (tiled_lds_bytes(win_bytes, nbuf, lut) > kLdsPerCU) ok = false;
   if (!ok) return MDC_OK;
   std::vector<uint32_t> flat((size_t)n_tiles * cap, kOutside);
@@ -293,6 +325,13 @@ int plan_source(mdc_ctx* c, int es, int kTileH, mdc_ctx::SrcPlan& pl) {
   if ((rc = upload(c, &pl.d_chunks, flat)) != MDC_OK || (rc = upload(c, &pl.d_nch, nch)) != MDC_OK ||
       (rc = upload(c, &pl.d_taps, taps)) != MDC_OK)
     return rc;
+  const std::vector<int> order = tile_order(tx, ty, c->opt_order);
+  if ((rc = upload(c, &pl.d_order, order)) != MDC_OK) return rc;
+  pl.n_blocks = (int)order.size();
+  pl.n_tiles = n_tiles;
+  pl.tiles_x = tx;
+  pl.tile_w = kTileW;
+  pl.tile_h = kTileH;
   pl.chunk_cap = cap;
   pl.win_bytes = win_bytes;
   pl.nbuf = nbuf;
@@ -303,9 +342,6 @@ int plan_source(mdc_ctx* c, int es, int kTileH, mdc_ctx::SrcPlan& pl) {
 // Plans of the tiled kernels for the current remap: tile grid, XCD placement, source bounding
 // box, one SrcPlan per source pixel type.
 int plan_tiles(mdc_ctx* c) {
-  c->tiled = false;
-  c->n_tiles = 0;
-  c->staged_bytes = 0;
   c->n_black = 0;
   c->bbox[0] = c->bbox[1] = std::numeric_limits<int>::max();
   c->bbox[2] = c->bbox[3] = -1;
@@ -323,26 +359,27 @@ int plan_tiles(mdc_ctx* c) {
     c->bbox[3] = std::max(c->bbox[3], (int)yy + 1);
   }
   if (c->bbox[2] < 0) c->bbox[0] = c->bbox[1] = 0;
-  // Tile height: the requested one, or the first candidate whose raw-frame windows fit (strongly
-  // distorting cameras need the taller tiles: their windows are too wide for 3 staging rounds of 512 threads).
-  int rc, kTileH = 0;
-  const int candidates[4] = {32, 64, 60, 16};
-  for (int k = 0; k < (c->opt_tile_h ? 1 : 4); k++) {
-    kTileH = c->opt_tile_h ? c->opt_tile_h : candidates[k];
-    free_plan(c);
-    if ((rc = plan_source(c, 1, kTileH, c->plan[0])) != MDC_OK || (rc = plan_source(c, 4, kTileH, c->plan[1])) != MDC_OK) return rc;
-    if (c->plan[0].tiled) break;
+  // Tile shape per source type: the requested one, or the first candidate whose windows fit (strongly
+  // distorting cameras need the taller tiles: their windows are too wide for the staging rounds of the
+  // smaller workgroups).  Both lists are in order of measured speed on the bench camera (tools/sweep.py,
+  // tools/rate_undistort_f32.py).
+  // (128 x 16 first: measured 5-7 % faster than 64 x 32 on the bench camera -- a 64-wide tile spans ~86 source
+  // bytes, less than one 128-byte line, so nearly every line is fetched by two workgroups; at 128 columns far
+  // fewer are.  profiles/r02_experiments/)
+  static const TileShape cand_u8[] = {{128, 16}, {64, 32}, {128, 32}, {64, 64}, {64, 60}, {64, 16}};
+  static const TileShape cand_f32[] = {{128, 16}, {64, 32}, {64, 16}, {128, 32}, {64, 64}, {64, 60}};  // 0.66 / 0.63 / 0.60 / 0.60 / 0.54 of 8 TB/s
+  for (int which = 0; which < 2; which++) {
+    const TileShape* cand = which == 0 ? cand_u8 : cand_f32;
+    const bool forced = c->opt_tile_h != 0 || c->opt_tile_w != 0;
+    for (int k = 0; k < 6; k++) {
+      const int tw = c->opt_tile_w ? c->opt_tile_w : cand[k].w, th = c->opt_tile_h ? c->opt_tile_h : cand[k].h;
+      if (forced && (tw != cand[k].w || th != cand[k].h)) continue;  // a forced dimension filters the list
+      free_src_plan(c->plan[which]);
+      const int rc = plan_source(c, which == 0 ? 1 : 4, tw, th, c->plan[which]);
+      if (rc != MDC_OK) return rc;
+      if (c->plan[which].tiled) break;
+    }
   }
-  if (!c->plan[0].tiled && !c->plan[1].tiled) return MDC_OK;
-  const int tx = (ow + kTileW - 1) / kTileW, ty = (oh + kTileH - 1) / kTileH;
-  const std::vector<int> order = tile_order(tx, ty, c->opt_order);
-  if ((rc = upload(c, &c->d_order, order)) != MDC_OK) return rc;
-  c->n_blocks = (int)order.size();
-  c->n_tiles = tx * ty;
-  c->tiles_x = tx;
-  c->tile_h = kTileH;
-  c->tiled = c->plan[0].tiled;
-  c->staged_bytes = c->plan[0].staged_bytes;
   return MDC_OK;
 }
 
@@ -366,7 +403,7 @@ int ensure_stage(mdc_ctx* c, size_t in_bytes, size_t out_bytes) {
 
 TilePlan tile_plan(const mdc_ctx* c, int which) {
   const mdc_ctx::SrcPlan& pl = c->plan[which];
-  return TilePlan{pl.d_chunks, pl.d_nch, pl.d_taps, c->d_order, c->n_blocks, c->n_tiles, c->tiles_x, c->tile_h,
+  return TilePlan{pl.d_chunks, pl.d_nch, pl.d_taps, pl.d_order, pl.n_blocks, pl.n_tiles, pl.tiles_x, pl.tile_w, pl.tile_h,
                   pl.chunk_cap, pl.win_bytes, pl.nbuf, c->n_black > 0, c->opt_interleave != 0};
 }
 
@@ -388,7 +425,7 @@ int enqueue_undistort_f32(mdc_ctx* c, const float* d_in, float* d_out, int64_t n
   RemapArgs a = remap_args(c, nullptr, nullptr);
   const bool aligned = (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
   if (c->plan[1].tiled && aligned && c->opt_kernel != MDC_KERNEL_GATHER) {
-    const int fpb = frames_per_block(c, nframes, c->n_blocks);
+    const int fpb = frames_per_block(c, nframes, c->plan[1].n_blocks);
     MDC_HIP(c, launch_remap_tiled_f32(d_in, d_out, a, tile_plan(c, 1), nframes, fpb, s));
   } else {
     const int fpb = frames_per_block(c, nframes, (c->out_w * c->out_h + 255) / 256);
@@ -420,14 +457,17 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
                 c->rm_in_h);
   RemapArgs a = remap_args(c, lut, vinv);
   const bool aligned = (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
-  bool use_tiled = c->tiled && aligned;
+  bool use_tiled = c->plan[0].tiled && aligned;
   if (c->opt_kernel == MDC_KERNEL_GATHER) use_tiled = false;
   if (c->opt_kernel == MDC_KERNEL_TILED && !use_tiled)
     return fail(c, MDC_ERR_STATE, "tiled kernel requested but not plannable for this remap / alignment");
   if (use_tiled) {
     const TilePlan p = tile_plan(c, 0);
-    const int fpb = frames_per_block(c, nframes, c->n_blocks);
-    const bool fuse_pyr = pyr && c->tile_h != 60 && c->out_w % kTileW == 0 && c->out_h % c->tile_h == 0;
+    const int fpb = frames_per_block(c, nframes, p.n_blocks);
+    // the fused pyramid adds level-2 hand-over rows to the workgroup's LDS: without room for them the
+    // per-level passes run instead
+    const bool fuse_pyr = pyr && p.tile_h % 8 == 0 && c->out_w % p.tile_w == 0 && c->out_h % p.tile_h == 0 &&
+                          tiled_lds_bytes(p.win_bytes, p.nbuf, true) + tiled_pyramid_lds_bytes(p.tile_w, p.tile_h) <= kLdsPerCU;
     MDC_HIP(c, launch_remap_tiled_u8(d_in, d_out, a, p, nframes, fpb, s, fuse_pyr ? pyr[0] : nullptr,
                                      fuse_pyr ? pyr[1] : nullptr, fuse_pyr ? pyr[2] : nullptr));
     if (pyr_done) *pyr_done = fuse_pyr;
@@ -446,6 +486,9 @@ struct BlobHeader {
 constexpr uint32_t kMagic = 0x4d444331u;  // "MDC1"
 
 }  // namespace
+
+static int set_photometric_locked(mdc_ctx* c, const float* ginv, const float* vignette_inv, int w, int h);
+static int set_remap_locked(mdc_ctx* c, const float* rx, const float* ry, int in_w, int in_h, int out_w, int out_h);
 
 extern "C" {
 
@@ -523,6 +566,15 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
       MDC_HIP(c, hipDeviceSynchronize());
       return plan_tiles(c);
     }
+    case MDC_OPT_TILE_COLS: {
+      if (value != 0 && value != 64 && value != 128) return fail(c, MDC_ERR_ARG, "tile columns must be 0 (automatic), 64 or 128");
+      if (value == c->opt_tile_w) return MDC_OK;
+      c->opt_tile_w = value;
+      if (!c->valid_remap) return MDC_OK;
+      DeviceGuard dg(c->device);
+      MDC_HIP(c, hipDeviceSynchronize());
+      return plan_tiles(c);
+    }
     case MDC_OPT_FRAME_INTERLEAVE:
       c->opt_interleave = value != 0;
       return MDC_OK;
@@ -536,7 +588,7 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
       return plan_tiles(c);
     }
     case MDC_OPT_TILE_ORDER: {
-      if (value < MDC_ORDER_BANDS || value > MDC_ORDER_IDENTITY) return fail(c, MDC_ERR_ARG, "bad tile order %d", value);
+      if (value < MDC_ORDER_BANDS || value > MDC_ORDER_BLOCKS2D) return fail(c, MDC_ERR_ARG, "bad tile order %d", value);
       if (value == c->opt_order) return MDC_OK;
       c->opt_order = value;
       if (!c->valid_remap) return MDC_OK;
@@ -560,14 +612,19 @@ int mdc_get_info(mdc_ctx* c, mdc_info* i) {
   i->valid_gamma = c->valid_gamma;
   i->valid_vignette = c->valid_vignette;
   i->valid_remap = c->valid_remap;
-  i->tiled = c->valid_remap && c->tiled;
-  i->tile_w = kTileW;
-  i->tile_h = c->tiled ? c->tile_h : c->opt_tile_h;
-  i->n_tiles = c->n_tiles;
-  i->lds_bytes = c->tiled ? (int)tiled_lds_bytes(c->plan[0].win_bytes, c->plan[0].nbuf, true) : 0;
+  const mdc_ctx::SrcPlan& p0 = c->plan[0];
+  i->tiled = c->valid_remap && p0.tiled;
+  i->tile_w = p0.tiled ? p0.tile_w : c->opt_tile_w;
+  i->tile_h = p0.tiled ? p0.tile_h : c->opt_tile_h;
+  i->n_tiles = p0.n_tiles;
+  i->lds_bytes = p0.tiled ? (int)tiled_lds_bytes(p0.win_bytes, p0.nbuf, true) : 0;
+  i->window_buffers = p0.tiled ? p0.nbuf : 0;
+  i->f32_tiled = c->valid_remap && c->plan[1].tiled;
+  i->f32_tile_w = c->plan[1].tiled ? c->plan[1].tile_w : 0;
+  i->f32_tile_h = c->plan[1].tiled ? c->plan[1].tile_h : 0;
   for (int k = 0; k < 4; k++) i->src_bbox[k] = c->bbox[k];
   i->src_bbox_bytes = c->bbox[2] >= 0 ? (int64_t)(c->bbox[2] - c->bbox[0] + 1) * (c->bbox[3] - c->bbox[1] + 1) : 0;
-  i->src_staged_bytes = c->staged_bytes;
+  i->src_staged_bytes = p0.staged_bytes;
   i->n_black = c->n_black;
   return MDC_OK;
 }
@@ -576,8 +633,14 @@ int mdc_set_photometric(mdc_ctx* c, const float* ginv, const float* vignette_inv
   if (!c) return MDC_ERR_ARG;
   if (w <= 0 || h <= 0) return fail(c, MDC_ERR_ARG, "bad frame size %dx%d", w, h);
   std::lock_guard<std::mutex> lk(c->mu);
+  return set_photometric_locked(c, ginv, vignette_inv, w, h);
+}
+
+// (lock held) The tables are replaced in place: every kernel that may still read them -- also those the
+// *_device entry points put on caller streams -- has to be done first, hence the device-wide wait.
+static int set_photometric_locked(mdc_ctx* c, const float* ginv, const float* vignette_inv, int w, int h) {
   DeviceGuard dg(c->device);
-  MDC_HIP(c, hipStreamSynchronize(c->stream));
+  MDC_HIP(c, hipDeviceSynchronize());
   c->in_w = w;
   c->in_h = h;
   c->valid_gamma = ginv != nullptr;
@@ -602,10 +665,14 @@ int mdc_set_photometric(mdc_ctx* c, const float* ginv, const float* vignette_inv
 int mdc_set_remap(mdc_ctx* c, const float* rx, const float* ry, int in_w, int in_h, int out_w, int out_h) {
   if (!c) return MDC_ERR_ARG;
   std::lock_guard<std::mutex> lk(c->mu);
+  return set_remap_locked(c, rx, ry, in_w, in_h, out_w, out_h);
+}
+
+static int set_remap_locked(mdc_ctx* c, const float* rx, const float* ry, int in_w, int in_h, int out_w, int out_h) {
   DeviceGuard dg(c->device);
-  MDC_HIP(c, hipStreamSynchronize(c->stream));
+  MDC_HIP(c, hipDeviceSynchronize());
   c->valid_remap = false;
-  c->tiled = false;
+  free_plan(c);
   for (float** p : {&c->d_rx, &c->d_ry})
     if (*p) {
       (void)hipFree(*p);
@@ -767,6 +834,43 @@ int mdc_synth_frames_device(mdc_ctx* c, uint8_t* d_out, int64_t first_frame, int
   return MDC_OK;
 }
 
+int mdc_describe_launch(mdc_ctx* c, unsigned flags, int pyramid_levels, char* buf, size_t cap) {
+  if (!c || !buf || cap == 0) return MDC_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  bool g, v, o;
+  normalise(c, flags, g, v, o);
+  char tmp[160];
+  if (!(flags & MDC_RECTIFY)) {
+    const int fw = c->in_w > 0 ? c->in_w : c->rm_in_w, fh = c->in_h > 0 ? c->in_h : c->rm_in_h;
+    snprintf(tmp, sizeof tmp, "%s<%s>", ((int64_t)fw * fh) % 4 == 0 ? "unmap_xpose_kernel" : "unmap_scalar_kernel", v ? "true" : "false");
+  } else if (!c->valid_remap) {
+    return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
+  } else if (c->plan[0].tiled && c->opt_kernel != MDC_KERNEL_GATHER) {
+    const mdc_ctx::SrcPlan& p = c->plan[0];
+    const bool pyr = pyramid_levels > 1 && p.tile_h % 8 == 0 && c->out_w % p.tile_w == 0 && c->out_h % p.tile_h == 0 &&
+                     tiled_lds_bytes(p.win_bytes, p.nbuf, true) + tiled_pyramid_lds_bytes(p.tile_w, p.tile_h) <= kLdsPerCU;
+    snprintf(tmp, sizeof tmp, "remap_tiled_kernel<%s, %s, %s, false, %d, %d, %d>", v ? "true" : "false",
+             c->n_black > 0 ? "true" : "false", pyr ? "true" : "false", p.tile_w, p.tile_w * p.tile_h / 4, p.nbuf);
+  } else {
+    snprintf(tmp, sizeof tmp, "remap_gather_u8_kernel<%s>", v ? "true" : "false");
+  }
+  if (strlen(tmp) + 1 > cap) return fail(c, MDC_ERR_ARG, "mdc_describe_launch: buffer too small");
+  memcpy(buf, tmp, strlen(tmp) + 1);
+  return MDC_OK;
+}
+
+int mdc_ceiling_mix_device(mdc_ctx* c, const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes,
+                           int blocks, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (read_bytes < 0 || write_bytes < 0 || (read_bytes > 0 && !d_read) || (write_bytes > 0 && !d_write) || blocks <= 0 ||
+      (reinterpret_cast<uintptr_t>(d_read) & 15) != 0)
+    return fail(c, MDC_ERR_ARG, "mdc_ceiling_mix_device: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  MDC_HIP(c, launch_mix_ceiling(d_read, read_bytes, d_write, write_bytes, blocks, (hipStream_t)stream));
+  return MDC_OK;
+}
+
 int mdc_synchronize(mdc_ctx* c) {
   if (!c) return MDC_ERR_ARG;
   std::lock_guard<std::mutex> lk(c->mu);
@@ -880,7 +984,9 @@ int mdc_process_frames_host(mdc_ctx* c, const uint8_t* const* raw, float* const*
   for (int64_t i = 0; i < nframes; i++)
     if (!raw[i] || !out[i]) return fail(c, MDC_ERR_ARG, "mdc_process_frames_host: frame %lld has a NULL buffer", (long long)i);
   constexpr int kChunk = 16;  // frames per slot: one kernel launch, 2 x 16 async copies
-  if (c->pipe_in_cap < kChunk * n_in || c->pipe_out_cap < kChunk * n_out * sizeof(float) || !c->pipe_stream[0]) {
+  if (c->pipe_in_cap < kChunk * n_in || c->pipe_out_cap < kChunk * n_out * sizeof(float) || !c->pipe_stream[0] ||
+      !c->pipe_stream[1]) {
+    c->pipe_in_cap = c->pipe_out_cap = 0;  // a failure part-way leaves "no slots", not stale capacities
     for (int k = 0; k < 2; k++) {
       if (c->pipe_stream[k]) MDC_HIP(c, hipStreamSynchronize(c->pipe_stream[k]));
       if (!c->pipe_stream[k]) MDC_HIP(c, hipStreamCreateWithFlags(&c->pipe_stream[k], hipStreamNonBlocking));
@@ -897,23 +1003,42 @@ int mdc_process_frames_host(mdc_ctx* c, const uint8_t* const* raw, float* const*
   }
   // chunk k runs entirely on stream k%2 (H2D, kernel, D2H in order); the two streams overlap one
   // chunk's copies with the other's kernel.  Re-using a slot waits for its previous chunk.
+  // On a failure the loop stops, BOTH streams are drained (asynchronous copies into the caller's buffers
+  // may still be in flight) and only then the error is returned.
   int rc = MDC_OK;
-  for (int64_t f0 = 0, k = 0; f0 < nframes && rc == MDC_OK; f0 += kChunk, k++) {
+  hipError_t he = hipSuccess;
+  const char* what = "";
+#define MDC_PIPE(call)              \
+  if (he == hipSuccess) {           \
+    he = (call);                    \
+    if (he != hipSuccess) what = #call; \
+  }
+  for (int64_t f0 = 0, k = 0; f0 < nframes && rc == MDC_OK && he == hipSuccess; f0 += kChunk, k++) {
     const int slot = (int)(k & 1);
     hipStream_t s = c->pipe_stream[slot];
     const int n = (int)std::min<int64_t>(kChunk, nframes - f0);
-    if (k >= 2) MDC_HIP(c, hipEventSynchronize(c->pipe_done[slot]));
+    if (k >= 2) MDC_PIPE(hipEventSynchronize(c->pipe_done[slot]));
     for (int i = 0; i < n; i++)
-      MDC_HIP(c, hipMemcpyAsync(c->d_pipe_in[slot] + (size_t)i * n_in, raw[f0 + i], n_in, hipMemcpyHostToDevice, s));
+      MDC_PIPE(hipMemcpyAsync(c->d_pipe_in[slot] + (size_t)i * n_in, raw[f0 + i], n_in, hipMemcpyHostToDevice, s));
+    if (he != hipSuccess) break;
     rc = enqueue_process(c, c->d_pipe_in[slot], c->d_pipe_out[slot], n, flags, s);
     if (rc != MDC_OK) break;
     for (int i = 0; i < n; i++)
-      MDC_HIP(c, hipMemcpyAsync(out[f0 + i], c->d_pipe_out[slot] + (size_t)i * n_out, n_out * sizeof(float),
-                                hipMemcpyDeviceToHost, s));
-    MDC_HIP(c, hipEventRecord(c->pipe_done[slot], s));
+      MDC_PIPE(hipMemcpyAsync(out[f0 + i], c->d_pipe_out[slot] + (size_t)i * n_out, n_out * sizeof(float),
+                              hipMemcpyDeviceToHost, s));
+    MDC_PIPE(hipEventRecord(c->pipe_done[slot], s));
   }
-  for (int k = 0; k < 2; k++) MDC_HIP(c, hipStreamSynchronize(c->pipe_stream[k]));
-  return rc;
+  for (int k = 0; k < 2; k++) {
+    const hipError_t e = hipStreamSynchronize(c->pipe_stream[k]);
+    if (he == hipSuccess && e != hipSuccess) {
+      he = e;
+      what = "hipStreamSynchronize(pipe_stream)";
+    }
+  }
+#undef MDC_PIPE
+  if (rc != MDC_OK) return rc;
+  if (he != hipSuccess) return fail(c, MDC_ERR_HIP, "%s: %s", what, hipGetErrorString(he));
+  return MDC_OK;
 }
 
 // ---- table hand-over ------------------------------------------------------------------
@@ -961,12 +1086,26 @@ int mdc_import_tables(mdc_ctx* c, const void* blob, size_t size) {
   p += nv * 4;
   const float* rx = (const float*)p;
   const float* ry = rx + nr;
+  // one critical section: no other thread may see the new photometric tables next to the old remap
+  std::lock_guard<std::mutex> lk(c->mu);
   int rc = MDC_OK;
-  if (h.in_w > 0 && h.in_h > 0)
-    rc = mdc_set_photometric(c, h.valid_gamma ? ginv : nullptr, h.valid_vignette ? vinv : nullptr, h.in_w, h.in_h);
+  if (h.in_w > 0 && h.in_h > 0) {
+    rc = set_photometric_locked(c, h.valid_gamma ? ginv : nullptr, h.valid_vignette ? vinv : nullptr, h.in_w, h.in_h);
+  } else {  // the blob carries no photometric calibration: neither does the context afterwards
+    DeviceGuard dg(c->device);
+    MDC_HIP(c, hipDeviceSynchronize());
+    c->in_w = c->in_h = 0;
+    c->valid_gamma = c->valid_vignette = false;
+    c->h_vinv.clear();
+    if (c->d_vinv) {
+      (void)hipFree(c->d_vinv);
+      c->d_vinv = nullptr;
+    }
+    rc = upload_luts(c);
+  }
   if (rc != MDC_OK) return rc;
-  if (h.valid_remap) rc = mdc_set_remap(c, rx, ry, h.rm_in_w, h.rm_in_h, h.out_w, h.out_h);
-  else rc = mdc_set_remap(c, nullptr, nullptr, 0, 0, 0, 0);
+  if (h.valid_remap) rc = set_remap_locked(c, rx, ry, h.rm_in_w, h.rm_in_h, h.out_w, h.out_h);
+  else rc = set_remap_locked(c, nullptr, nullptr, 0, 0, 0, 0);
   return rc;
 }
 

@@ -6,10 +6,18 @@
 
 namespace mdc {
 
-// Geometry of the tiled kernel: kTileW x tile_h outputs per workgroup, one lane per
-// output column, 4 output rows per thread  ->  16*tile_h threads
-// (tile_h = 16: 256 threads; 32: 512; 60: 960; 64: 1024).
-constexpr int kTileW = 64;
+// Geometry of the tiled kernel: tile_w x tile_h outputs per workgroup, one lane per output column
+// (tile_w / 64 waves side by side), 4 output rows per thread  ->  tile_w * tile_h / 4 threads.
+// Legal shapes: 64 x {16, 32, 60, 64} (256 / 512 / 960 / 1024 threads), 128 x {16, 32} (512 / 1024).
+struct TileShape {
+  int w, h;
+};
+constexpr TileShape kTileShapes[] = {{64, 16}, {64, 32}, {64, 60}, {64, 64}, {128, 16}, {128, 32}};
+constexpr bool tile_shape_ok(int w, int h) {
+  for (const TileShape& t : kTileShapes)
+    if (t.w == w && t.h == h) return true;
+  return false;
+}
 constexpr int kTileMaxChunks = 3;     // 16-byte chunks a thread may stage per frame (raw u8 frames)
 constexpr int kTileMaxChunksF32 = 4;  // same for float frames (a window holds 4x the bytes)
 #ifndef MDC_EXP_LUT_REP
@@ -38,8 +46,9 @@ struct TilePlan {
   const int* d_order;        // block -> tile (or -1), n_blocks entries, n_blocks % 8 == 0: block b runs on XCD b % 8
   int n_blocks;
   int n_tiles, tiles_x;
-  int tile_h;      // output rows per tile: 16, 32, 60 or 64
-  int chunk_cap;   // row length of d_chunks: max over tiles of ceil(nch / threads) * threads
+  int tile_w;      // output columns per tile: 64 or 128
+  int tile_h;      // output rows per tile: 16, 32, 60 or 64 (see kTileShapes)
+  int chunk_cap;   // row length of d_chunks: kTileMaxChunks (F32: kTileMaxChunksF32) x threads, padded with kOutside
   int win_bytes;   // LDS bytes of one window buffer: 16 * max nch, rounded up to 1 KiB
   int nbuf;        // window buffers per workgroup (2..4): nbuf-1 frames are staged ahead
   bool has_black;  // some output carries the (-1,-1) sentinel
@@ -58,7 +67,7 @@ hipError_t launch_remap_gather_f32(const float* d_in, float* d_out, const RemapA
                                    hipStream_t s);
 // Fused LUT (* vignette) + bilinear remap, u8 frames, source windows staged in LDS.
 // d_l1..d_l3 (optional): levels 1..3 of the 2x2 box pyramid of every output frame, written by the same
-// launch (needs whole tiles: out_w % 64 == 0, out_h % tile_h == 0, tile_h in {16, 32, 64}).
+// launch (needs whole tiles: out_w % tile_w == 0, out_h % tile_h == 0, tile_h % 8 == 0).
 hipError_t launch_remap_tiled_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
                                  int64_t nframes, int fpb, hipStream_t s, float* d_l1 = nullptr, float* d_l2 = nullptr,
                                  float* d_l3 = nullptr);
@@ -66,7 +75,7 @@ hipError_t launch_remap_tiled_u8(const uint8_t* d_in, float* d_out, const RemapA
 hipError_t launch_remap_tiled_f32(const float* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
                                   int64_t nframes, int fpb, hipStream_t s);
 size_t tiled_lds_bytes(int win_bytes, int nbuf, bool lut = true);  // (LUT replicas +) nbuf window buffers
-size_t tiled_pyramid_lds_bytes(int tile_h);       // + level-2 hand-over rows of the fused pyramid
+size_t tiled_pyramid_lds_bytes(int tile_w, int tile_h);  // + level-2 hand-over rows of the fused pyramid
 constexpr size_t kLdsPerCU = 160 * 1024;
 
 // One 2x2 box level: dst (w/2 x h/2) from src (w x h), nframes images each.
@@ -79,6 +88,10 @@ struct DistortModel {
 };
 // (x, y) rectified pixel -> raw pixel, in place (UndistorterFOV::distortCoordinates).
 hipError_t launch_distort_points(float* d_x, float* d_y, int64_t n, const DistortModel& m, hipStream_t s);
+
+// Bench utility: linear read of read_bytes interleaved with a linear write of write_bytes (no arithmetic).
+hipError_t launch_mix_ceiling(const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes, int blocks,
+                              hipStream_t s);
 
 hipError_t launch_synth(uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix, uint32_t seed, hipStream_t s);
 

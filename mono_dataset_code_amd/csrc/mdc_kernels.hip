@@ -53,10 +53,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // [32e, 32e+32): eight 16-byte stores of (v,v,v,v).
 template <int NT>
 __device__ __forceinline__ void fill_lut(float* s_lut, const float* __restrict__ lut, int tid) {
-  for (int i = tid; i < 256 * (kLutRep / 4); i += NT) {
-    const float v = lut[i / (kLutRep / 4)];
-    reinterpret_cast<f32x4*>(s_lut)[i] = f32x4{v, v, v, v};
-  }
+  constexpr int N = 256 * (kLutRep / 4);  // 16-byte stores in total
+  constexpr int IT = (N + NT - 1) / NT;
+  float v[IT];  // every load issued before the first store waits for its value: one memory round trip, not IT
+#pragma unroll
+  for (int k = 0; k < IT; k++) v[k] = lut[min(tid + k * NT, N - 1) / (kLutRep / 4)];
+#pragma unroll
+  for (int k = 0; k < IT; k++)
+    if (IT * NT == N || tid + k * NT < N) reinterpret_cast<f32x4*>(s_lut)[tid + k * NT] = f32x4{v[k], v[k], v[k], v[k]};
 }
 
 // ----------------------------------------------------------------------------
@@ -148,17 +152,21 @@ struct Bilin {
   int xi, yi;
   float w11, w01, w10, w00;
 };
+// the four weights from the fractional parts, src/FOVUndistorter.cpp:356,362-365
+__device__ __forceinline__ void bilin_weights(Bilin& b, float fx, float fy) {
+  const float xxyy = fx * fy;
+  b.w11 = xxyy;
+  b.w01 = fy - xxyy;
+  b.w10 = fx - xxyy;
+  b.w00 = ((1.f - fx) - fy) + xxyy;
+}
 __device__ __forceinline__ Bilin bilin_of(float xx, float yy) {
   Bilin b;
   b.xi = (int)xx;
   b.yi = (int)yy;
   xx -= (float)b.xi;
   yy -= (float)b.yi;
-  const float xxyy = xx * yy;
-  b.w11 = xxyy;
-  b.w01 = yy - xxyy;
-  b.w10 = xx - xxyy;
-  b.w00 = ((1.f - xx) - yy) + xxyy;
+  bilin_weights(b, xx, yy);
   return b;
 }
 __device__ __forceinline__ float bilin_sum(const Bilin& b, float t00, float t10, float t01, float t11) {
@@ -267,6 +275,11 @@ __global__ __launch_bounds__(256) void remap_gather_f32_kernel(const float* __re
 // correctness does not depend on placement.
 // ----------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
+// Window buffers are handled as LDS-address-space (32-bit) pointers throughout: a generic pointer would cost a
+// 64-bit add, a null compare and a select per tap row to get back to an LDS address.
+typedef __attribute__((address_space(3))) unsigned char* lds_u8_ptr;
+typedef const volatile __attribute__((address_space(3))) unsigned char* lds_tap_ptr;
+typedef const __attribute__((address_space(3))) float* lds_f32_ptr;
 
 constexpr uint32_t kRsrcWord3 = 0x00020000u;  // gfx9 raw buffer: 32-bit data format, no swizzle
 #ifdef MDC_EXP_STORE_AUX
@@ -286,66 +299,101 @@ constexpr int kLoadAux = 0;
 #define MDC_FRAME_RSRC(base, bytes) \
   __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(base)), 0, (int)(bytes), (int)kRsrcWord3)
 
-struct TileThread {  // per-thread, frame-invariant
-  Bilin bl[4];
-  int off0[4], off1[4];  // LDS byte offsets of taps (xi,yi) and (xi,yi+1) inside the window
-  uint32_t obyte[4];     // byte offset of the output inside a frame, kOutside if not in the image
+// Per-thread, frame-invariant state.  The 1024-/960-thread tiles must fit 64 VGPRs (two workgroups per
+// CU): their instantiations are LEAN -- the two tap offsets stay packed in one register (unpacked per
+// frame, +2 VALU per output) and only the first row's output offset is kept, rows 1..3 add the row pitch
+// (rows below the image then lie beyond the frame's descriptor range and are dropped like kOutside).
+constexpr uint32_t kOutsideLean = 0xc0000000u;  // + 3 row pitches still beyond any frame the plan accepts
+struct TileThread {
+  Bilin bl[4];           // (!LEAN) weights kept; (LEAN) only the fractional parts are, the weights are redone per frame
+  float fx[4], fy[4];    //  -- the same four IEEE operations either way, so the same bits
+  int off0[4], off1[4];  // LDS byte offsets of taps (xi,yi) and (xi,yi+1) inside the window  (!LEAN)
+  uint32_t tap[4];       // off0 | off1 << 16                                                  (LEAN)
+  uint32_t obyte[4];     // byte offset of the output inside a frame, kOutside if not in the image (LEAN: [0] only)
   bool black[4];
   float v00[4], v10[4], v01[4], v11[4];
   uint32_t p1byte[2], p2byte;  // fused pyramid: byte offsets of this lane's level-1 / level-2 outputs (kOutside if none)
 };
 
-template <bool VIG, bool BLACK, bool F32>
-__device__ __forceinline__ void tile_compute(const TileThread& t, const unsigned char* __restrict__ w,
-                                             const float* __restrict__ my_lut, float* dst, uint32_t out_bytes,
-                                             float (&res)[4]) {
+template <bool VIG, bool BLACK, bool F32, bool LEAN, int B>
+__device__ __forceinline__ void tile_compute(const TileThread& t, lds_u8_ptr w, lds_f32_ptr my_lut, float* dst,
+                                             uint32_t out_bytes, uint32_t row_bytes, float (&res)[4]) {
 #if __HIP_DEVICE_COMPILE__  // buffer / LDS-DMA builtins exist in the device pass only
   const auto ro = MDC_FRAME_RSRC(dst, out_bytes);
+  // Outputs are processed B at a time: all their byte taps are issued, then all their LUT reads, then the
+  // arithmetic -- two LDS latencies per batch instead of two per output.  (B = 2 where registers are short:
+  // the 64-VGPR LEAN tiles and the fused pyramid.)
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j0 = 0; j0 < 4; j0 += B) {
+    int off0[B], off1[B];
+    Bilin bw[B];
+#pragma unroll
+    for (int u = 0; u < B; u++) {
+      const int j = j0 + u;
+      // LEAN: the derived values must be REDONE every frame (that is the point: fewer live registers), but they are
+      // loop-invariant and the optimiser would hoist them right back -- the empty asm makes the sources opaque.
+      uint32_t tap = t.tap[j];
+      float fx = t.fx[j], fy = t.fy[j];
+      if (LEAN) asm volatile("" : "+v"(tap), "+v"(fx), "+v"(fy));
+      off0[u] = LEAN ? (int)(tap & 0xffffu) : t.off0[j];
+      off1[u] = LEAN ? (int)(tap >> 16) : t.off1[j];
+      bw[u] = t.bl[j];
+      if (LEAN) bilin_weights(bw[u], fx, fy);
+    }
+    float tv[B][4];  // t00 t10 t01 t11
     if (F32) {  // float frames (undistort<float>): the taps are the staged floats themselves
-      const float* p = reinterpret_cast<const float*>(w + t.off0[j]);
-      const float* q = reinterpret_cast<const float*>(w + t.off1[j]);
-      float r = bilin_sum(t.bl[j], p[0], p[1], q[0], q[1]);
+#pragma unroll
+      for (int u = 0; u < B; u++) {
+        lds_f32_ptr p = reinterpret_cast<lds_f32_ptr>(w + off0[u]);
+        lds_f32_ptr q = reinterpret_cast<lds_f32_ptr>(w + off1[u]);
+        tv[u][0] = p[0];
+        tv[u][1] = p[1];
+        tv[u][2] = q[0];
+        tv[u][3] = q[1];
+      }
+    } else {
+      // explicit byte loads: two adjacent byte loads fused into one ds_read_u16 at an odd
+      // address are replayed by the LDS (SQ_LDS_UNALIGNED_STALL), hence volatile
+      int b[B][4];
+#pragma unroll
+      for (int u = 0; u < B; u++) {
+        lds_tap_ptr p = (lds_tap_ptr)(w + off0[u]);
+        lds_tap_ptr q = (lds_tap_ptr)(w + off1[u]);
+        b[u][0] = p[0];
+        b[u][1] = p[1];
+        b[u][2] = q[0];
+        b[u][3] = q[1];
+      }
+#if MDC_EXP_FAKE_COMPUTE == 2
+#pragma unroll
+      for (int u = 0; u < B; u++)
+        for (int k = 0; k < 4; k++) tv[u][k] = bw[u].w00;
+#else
+#pragma unroll
+      for (int u = 0; u < B; u++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) tv[u][k] = my_lut[b[u][k] * kLutRep];
+#endif
+    }
+#pragma unroll
+    for (int u = 0; u < B; u++) {
+      const int j = j0 + u;
+      float t00 = tv[u][0], t10 = tv[u][1], t01 = tv[u][2], t11 = tv[u][3];
+      if (VIG && !F32) {
+        t00 = t00 * t.v00[j];
+        t10 = t10 * t.v10[j];
+        t01 = t01 * t.v01[j];
+        t11 = t11 * t.v11[j];
+      }
+      float r = bilin_sum(bw[u], t00, t10, t01, t11);
       if (BLACK && t.black[j]) r = 0.f;
       res[j] = r;
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, t.obyte[j], 0, kStoreAux);
-      continue;
-    }
-    // explicit byte loads: two adjacent byte loads fused into one ds_read_u16 at an odd
-    // address are replayed by the LDS (SQ_LDS_UNALIGNED_STALL), hence volatile
-#if MDC_EXP_FAKE_COMPUTE
-    {
-      float r = t.bl[j].w00;
-#if MDC_EXP_FAKE_COMPUTE == 1
-      r = r * my_lut[(int)((const volatile __attribute__((address_space(3))) unsigned char*)(w + t.off0[j]))[0] * kLutRep];
-#endif
-      res[j] = r;
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, t.obyte[j], 0, kStoreAux);
-      continue;
-    }
-#endif
-    typedef const volatile __attribute__((address_space(3))) unsigned char* tap_ptr;
-    tap_ptr p = (tap_ptr)(w + t.off0[j]);
-    tap_ptr q = (tap_ptr)(w + t.off1[j]);
-    const int b00 = p[0], b10 = p[1], b01 = q[0], b11 = q[1];
-    float t00 = my_lut[b00 * kLutRep];
-    float t10 = my_lut[b10 * kLutRep];
-    float t01 = my_lut[b01 * kLutRep];
-    float t11 = my_lut[b11 * kLutRep];
-    if (VIG) {
-      t00 = t00 * t.v00[j];
-      t10 = t10 * t.v10[j];
-      t01 = t01 * t.v01[j];
-      t11 = t11 * t.v11[j];
-    }
-    float r = bilin_sum(t.bl[j], t00, t10, t01, t11);
-    if (BLACK && t.black[j]) r = 0.f;
-    res[j] = r;
 #if MDC_EXP_SKIP_STORE
-    if (r != -1.2345e30f) continue;
+      if (r != -1.2345e30f) continue;
 #endif
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, t.obyte[j], 0, kStoreAux);
+      const uint32_t obyte = LEAN ? t.obyte[0] + (uint32_t)j * row_bytes : t.obyte[j];
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), ro, obyte, 0, kStoreAux);
+    }
   }
 #endif
 }
@@ -398,15 +446,17 @@ __device__ __forceinline__ void pyramid_levels12(const TileThread& t, const floa
 #endif
 }
 
-// level 3 of frame `f` of this tile from the level-2 rows the waves left in LDS (G = row groups = waves)
-template <int G>
+// level 3 of frame `f` of this tile from the level-2 rows the waves left in LDS
+// (RG = row groups of 4 output rows, each leaving one level-2 row of TW/4 floats)
+template <int RG, int TW>
 __device__ __forceinline__ void pyramid_level3(const PyramidOut& py, long long f, uint32_t l3_bytes, const float* s_rows,
                                                uint32_t p3byte, int tid) {
 #if __HIP_DEVICE_COMPILE__
-  if (py.l3 && tid < 8 * (G / 2)) {
-    const int m = tid >> 3, k = tid & 7;
-    const float* top = s_rows + (2 * m) * 16 + 2 * k;
-    const float* bot = s_rows + (2 * m + 1) * 16 + 2 * k;
+  constexpr int L2W = TW / 4, L3W = TW / 8;
+  if (py.l3 && tid < L3W * (RG / 2)) {
+    const int m = tid / L3W, k = tid % L3W;
+    const float* top = s_rows + (2 * m) * L2W + 2 * k;
+    const float* bot = s_rows + (2 * m + 1) * L2W + 2 * k;
     const float v3 = box4(top[0], top[1], bot[0], bot[1]);
     const auto r3 = MDC_FRAME_RSRC(py.l3 + f * (l3_bytes / 4), l3_bytes);
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v3), r3, p3byte, 0, kStoreAux);
@@ -418,7 +468,7 @@ __device__ __forceinline__ void pyramid_level3(const PyramidOut& py, long long f
 // Lanes past the window (goff == kOutside) are masked off: they neither fetch nor write LDS, so a
 // buffer holds exactly the tile's chunks.
 template <int R, int NT>
-__device__ __forceinline__ void stage_window(const uint8_t* src, uint32_t in_bytes, unsigned char* win,
+__device__ __forceinline__ void stage_window(const uint8_t* src, uint32_t in_bytes, lds_u8_ptr win,
                                              const uint32_t (&goff)[R], int wave) {
 #if __HIP_DEVICE_COMPILE__
   const auto ri = MDC_FRAME_RSRC(src, in_bytes);
@@ -427,16 +477,24 @@ __device__ __forceinline__ void stage_window(const uint8_t* src, uint32_t in_byt
     if (goff[k] != kOutside)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (lds_void_ptr)(win + (k * NT + wave * 64) * 16), 16, goff[k], 0,
                                                0, kLoadAux);
+  // The hand-counted vmcnt allowances below rely on the issue order "DMA group, then the frame's
+  // stores": nothing may be scheduled across this point (the DMA and the stores use different
+  // descriptors, so the compiler sees no dependence of its own).
+  __builtin_amdgcn_sched_barrier(0);
 #endif
 }
 
 // s_waitcnt vmcnt(N) ; s_barrier -- hand-placed: the compiler's own barrier (a workgroup fence)
 // would wait for EVERY outstanding LDS-DMA, i.e. also for the frames staged ahead.  vmcnt retires
 // in issue order on gfx9, loads and stores alike (the compiler's own counting relies on that).
+// lgkmcnt(0) rides along: the fused pyramid hands its level-2 row to other waves through LDS
+// (ds_write just before this point), and a ds_write must have COMPLETED before the barrier for the
+// readers behind it to see it; every other LDS operation of the frame has been consumed by then, so
+// the extra wait is free.
 template <int N>
 __device__ __forceinline__ void wait_vm_barrier() {
   static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 // A = allowance of the per-frame wait for a wave that issues `rw` DMA instructions per frame with
 // D frames staged ahead: everything issued after the DMA of frame f+1 may stay in flight, which is
@@ -452,24 +510,25 @@ __device__ __forceinline__ void frame_barrier(int rw) {
 
 // Frames [0, nframes) of one tile.  NBUF window buffers, D = NBUF-1 frames staged ahead: the DMA
 // of frame f+D is issued before frame f is computed; one barrier per frame.
-template <bool VIG, bool BLACK, bool PYR, bool F32, int R, int NT, int NBUF>
+template <bool VIG, bool BLACK, bool PYR, bool F32, int R, int TW, int NT, int NBUF>
 __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* __restrict__ src,
                                             float* __restrict__ dst, uint32_t in_bytes, uint32_t out_bytes,
-                                            int nframes, int nch, const uint32_t* __restrict__ chunks,
-                                            unsigned char* s_win, int win_bytes, const float* my_lut, int tid,
-                                            const PyramidOut& py, long long f_first, int fstep, uint32_t p3byte) {
+                                            int nframes, int nch, const uint32_t (&goff_all)[F32 ? kTileMaxChunksF32 : kTileMaxChunks],
+                                            lds_u8_ptr s_win, int win_bytes, lds_f32_ptr my_lut, int tid,
+                                            const PyramidOut& py, long long f_first, int fstep, uint32_t p3byte,
+                                            uint32_t row_bytes) {
   // iteration i works on frame f_first + i*fstep; src / dst point at that workgroup's first frame
   constexpr int D = NBUF - 1;
   const long long in_step = (long long)fstep * in_bytes;
   const long long out_step = (long long)fstep * (out_bytes / 4);
   uint32_t goff[R];
 #pragma unroll
-  for (int k = 0; k < R; k++) goff[k] = chunks[tid + k * NT];  // kOutside past the window
+  for (int k = 0; k < R; k++) goff[k] = goff_all[k];  // kOutside past the window
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int rw = 0;  // DMA instructions this wave issues per frame (rounds in which its first lane has a chunk)
 #pragma unroll
   for (int k = 0; k < R; k++) rw += (wave * 64 + k * NT < nch) ? 1 : 0;
-  unsigned char* w[NBUF];
+  lds_u8_ptr w[NBUF];
 #pragma unroll
   for (int i = 0; i < NBUF; i++) w[i] = s_win + i * win_bytes;
   const int last = nframes - 1;
@@ -487,42 +546,44 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
   else if (R >= 2 && rw == 2) wait_vm_barrier<(D - 1) * 2>();
   else if (rw == 1) wait_vm_barrier<(D - 1) * 1>();
   else wait_vm_barrier<0>();
-  constexpr int G = NT / 64;  // row groups of the tile = waves
-  float* s_pyr = reinterpret_cast<float*>(s_win + NBUF * win_bytes);  // [2][G][16] level-2 rows (PYR only)
+  constexpr int G = NT / TW;        // row groups of the tile (4 output rows each; TW/64 waves side by side)
+  constexpr int L2W = TW / 4;       // level-2 pixels per tile row
+  float* s_pyr = (float*)(s_win + NBUF * win_bytes);  // [2][G][L2W] level-2 rows (PYR only)
+  const int pyr_slot = (wave / (TW / 64)) * L2W + (wave % (TW / 64)) * 16;  // this wave's 16 floats inside one [G][L2W] set
   const uint32_t l1_bytes = out_bytes / 4, l2_bytes = out_bytes / 16, l3_bytes = out_bytes / 64;
   for (int f = 0; f <= last; f++) {
     if (PYR && f > 0)
-      pyramid_level3<G>(py, f_first + (long long)(f - 1) * fstep, l3_bytes, s_pyr + ((f - 1) & 1) * G * 16, p3byte, tid);
+      pyramid_level3<G, TW>(py, f_first + (long long)(f - 1) * fstep, l3_bytes, s_pyr + ((f - 1) & 1) * G * L2W, p3byte, tid);
 #if MDC_EXP_SKIP_LOAD
     stage_window<R, NT>(src, in_bytes, w[D], goff, wave);
 #else
     stage_window<R, NT>(src + min(f + D, last) * in_step, in_bytes, w[D], goff, wave);
 #endif
     float res[4];
-    tile_compute<VIG, BLACK, F32>(t, w[0], my_lut, dst, out_bytes, res);
+    tile_compute<VIG, BLACK, F32, (NT >= 960), ((NT >= 960 || PYR) ? 2 : 4)>(t, w[0], my_lut, dst, out_bytes, row_bytes, res);
     if (PYR)
-      pyramid_levels12(t, res, py, f_first + (long long)f * fstep, l1_bytes, l2_bytes, s_pyr + ((f & 1) * G + wave) * 16,
+      pyramid_levels12(t, res, py, f_first + (long long)f * fstep, l1_bytes, l2_bytes, s_pyr + (f & 1) * G * L2W + pyr_slot,
                        tid & 63);
     dst += out_step;
     frame_barrier<D, R>(rw);  // frame f+1 landed in every wave's part of w[1]; everyone is done reading w[0]
-    unsigned char* x = w[0];
+    lds_u8_ptr x = w[0];
 #pragma unroll
     for (int i = 0; i < D; i++) w[i] = w[i + 1];
     w[D] = x;
   }
-  if (PYR) pyramid_level3<G>(py, f_first + (long long)last * fstep, l3_bytes, s_pyr + (last & 1) * G * 16, p3byte, tid);
+  if (PYR) pyramid_level3<G, TW>(py, f_first + (long long)last * fstep, l3_bytes, s_pyr + (last & 1) * G * L2W, p3byte, tid);
 }
 
 // Occupancy is set by LDS (LUT replicas + two window buffers): 3 workgroups of 512 threads or 2 of
 // 960/1024 per CU; the register budget follows from that.
 // F32: the frames are floats (UndistorterFOV::undistort<float>, no LUT, no vignette); else raw u8.
-template <bool VIG, bool BLACK, bool PYR, bool F32, int NT, int NBUF>
+template <bool VIG, bool BLACK, bool PYR, bool F32, int TW, int NT, int NBUF>
 __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 : 6) : 4)) void remap_tiled_kernel(
     const uint8_t* __restrict__ in, float* __restrict__ out, RemapArgs a, TilePlan p, PyramidOut py, int nframes, int fpb,
     int interleave) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   float* s_lut = reinterpret_cast<float*>(smem);
-  unsigned char* s_win = smem + (F32 ? 0 : kLutBytes);
+  lds_u8_ptr s_win = (lds_u8_ptr)smem + (F32 ? 0 : kLutBytes);
 
   const int tile = p.d_order[blockIdx.x];  // host-made placement table (plan_tiles); -1 = padding slot
   if (tile < 0) return;                    // whole workgroup leaves before any barrier
@@ -536,14 +597,36 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
   if (nf <= 0) return;
 
   const int tid = threadIdx.x;
-  const int lane_x = tid % kTileW;
-  const int row0 = (tid / kTileW) * 4;
-  const int ox = (tile % p.tiles_x) * kTileW + lane_x;
-  constexpr int kTileRows = NT / 16;  // 4 output rows per thread, kTileW lanes per row
+  const int lane_x = tid % TW;
+  const int row0 = (tid / TW) * 4;
+  const int ox = (tile % p.tiles_x) * TW + lane_x;
+  constexpr int kTileRows = NT * 4 / TW;  // 4 output rows per thread, TW lanes per row
+  constexpr bool LEAN = NT >= 960;
   const int oy0 = (tile / p.tiles_x) * kTileRows + row0;
 
+  // Prologue, ordered for memory-level parallelism: the workgroup's whole start-up is three dependent
+  // round trips -- (1) tile id -> (2) chunk list + remap + tap offsets + LUT, all in flight together ->
+  // (3) first frames' LDS-DMA + vignette factors -- instead of one round trip per table and output row
+  // (a workgroup lives for ~32 frames of ~2 us; a serial prologue was ~7 % of the kernel).
+  const int nch = p.d_nch[tile];
+  constexpr int RMAX = F32 ? kTileMaxChunksF32 : kTileMaxChunks;
+  const uint32_t* chunks = p.d_chunks + (size_t)tile * (RMAX * NT);  // rows are padded with kOutside to RMAX rounds
+  uint32_t goff[RMAX];
+#pragma unroll
+  for (int k = 0; k < RMAX; k++) goff[k] = chunks[tid + k * NT];
+
+  float xx[4], yy[4];
+  uint32_t tp[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {  // unconditional loads (index 0 stands in for outputs outside the image): no branches
+    const bool inside = (ox < a.out_w) && (oy0 + j < a.out_h);
+    const int oidx = inside ? (oy0 + j) * a.out_w + ox : 0;
+    xx[j] = a.rx[oidx];
+    yy[j] = a.ry[oidx];
+    tp[j] = p.d_taps[oidx];
+  }
   if (!F32) fill_lut<NT>(s_lut, a.lut, tid);
-  const float* my_lut = s_lut + (tid & (kLutRep - 1));
+  lds_f32_ptr my_lut = (lds_f32_ptr)s_lut + (tid & (kLutRep - 1));
 
   TileThread t;
 #pragma unroll
@@ -551,24 +634,31 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
     const int oy = oy0 + j;
     const bool inside = (ox < a.out_w) && (oy < a.out_h);
     const int oidx = oy * a.out_w + ox;
-    t.obyte[j] = inside ? (uint32_t)oidx * 4u : kOutside;
-    float xx = -1.f, yy = -1.f;
-    uint32_t tp = 0;
-    if (inside) {
-      xx = a.rx[oidx];
-      yy = a.ry[oidx];
-      tp = p.d_taps[oidx];
+    if (LEAN) {  // row j = row 0 + j row pitches; rows below the image fall outside the frame descriptor
+      if (j == 0) t.obyte[0] = ox < a.out_w ? (uint32_t)oidx * 4u : kOutsideLean;
+    } else {
+      t.obyte[j] = inside ? (uint32_t)oidx * 4u : kOutside;
+    }
+    if (!inside) {
+      xx[j] = yy[j] = -1.f;
+      tp[j] = 0;
     }
     if (PYR && (j & 1) == 0)  // level 1: even lanes, rows oy/2; (whole tiles only, so `inside` holds)
       t.p1byte[j >> 1] = (lane_x & 1) ? kOutside : (uint32_t)((oy >> 1) * (a.out_w >> 1) + (ox >> 1)) * 4u;
     if (PYR && j == 0) t.p2byte = (lane_x & 3) ? kOutside : (uint32_t)((oy >> 2) * (a.out_w >> 2) + (ox >> 2)) * 4u;
-    t.black[j] = xx < 0;  // outputs outside the image count as black: their taps read window byte 0, their store is dropped
-    t.bl[j] = bilin_of(t.black[j] ? 0.f : xx, t.black[j] ? 0.f : yy);
-    t.off0[j] = (int)(tp & 0xffffu);
-    t.off1[j] = (int)(tp >> 16);
+    t.black[j] = xx[j] < 0;  // outputs outside the image count as black: their taps read window byte 0, their store is dropped
+    t.bl[j] = bilin_of(t.black[j] ? 0.f : xx[j], t.black[j] ? 0.f : yy[j]);
+    t.fx[j] = (t.black[j] ? 0.f : xx[j]) - (float)t.bl[j].xi;
+    t.fy[j] = (t.black[j] ? 0.f : yy[j]) - (float)t.bl[j].yi;
+    t.tap[j] = tp[j];
+    t.off0[j] = (int)(tp[j] & 0xffffu);
+    t.off1[j] = (int)(tp[j] >> 16);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
     t.v00[j] = t.v10[j] = t.v01[j] = t.v11[j] = 1.f;
-    if (VIG && !t.black[j]) {
-      const int s = t.bl[j].xi + t.bl[j].yi * a.in_w;
+    if (VIG) {  // unconditional gathers: a black output's factors are never used (its result is forced or dropped)
+      const int s = t.black[j] ? 0 : t.bl[j].xi + t.bl[j].yi * a.in_w;
       t.v00[j] = a.vinv[s];
       t.v10[j] = a.vinv[s + 1];
       t.v01[j] = a.vinv[s + a.in_w];
@@ -580,16 +670,17 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
   const uint32_t out_bytes = (uint32_t)a.out_w * (uint32_t)a.out_h * 4u;
   const uint8_t* src = in + (long long)f0 * in_bytes;
   float* dst = out + (long long)f0 * (out_bytes / 4);
-  const int nch = p.d_nch[tile];
-  uint32_t p3byte = kOutside;  // level 3: thread u < 8*(rows/8) owns pixel (u%8, u/8) of the tile's 8 x rows/8 block
-  if (PYR && tid < 8 * (NT / 128))
-    p3byte = (uint32_t)(((tile / p.tiles_x) * (NT / 128) + (tid >> 3)) * (a.out_w >> 3) + (tile % p.tiles_x) * 8 + (tid & 7)) * 4u;
+  uint32_t p3byte = kOutside;  // level 3: thread u < (TW/8)*(rows/8) owns pixel (u % (TW/8), u / (TW/8)) of the tile's level-3 block
+  if (PYR && tid < (TW / 8) * (kTileRows / 8))
+    p3byte = (uint32_t)(((tile / p.tiles_x) * (kTileRows / 8) + tid / (TW / 8)) * (a.out_w >> 3) + (tile % p.tiles_x) * (TW / 8) +
+                        tid % (TW / 8)) * 4u;
   if (nch == 0) {  // every output of the tile is black (or outside): zeros (on every level), no staging
 #if __HIP_DEVICE_COMPILE__
     for (int f = 0; f < nf; f++, dst += (long long)fstep * (out_bytes / 4)) {
       const auto ro = MDC_FRAME_RSRC(dst, out_bytes);
 #pragma unroll
-      for (int j = 0; j < 4; j++) __builtin_amdgcn_raw_buffer_store_b32(0u, ro, t.obyte[j], 0, 0);
+      for (int j = 0; j < 4; j++)
+        __builtin_amdgcn_raw_buffer_store_b32(0u, ro, LEAN ? t.obyte[0] + (uint32_t)j * (uint32_t)a.out_w * 4u : t.obyte[j], 0, 0);
       if (PYR) {
         const long long fa = (long long)f0 + (long long)f * fstep;
         if (py.l1) {
@@ -605,10 +696,9 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
     return;
   }
   const int rounds = (nch + NT - 1) / NT;  // workgroup-uniform
-  const uint32_t* chunks = p.d_chunks + (size_t)tile * p.chunk_cap;
 #define MDC_TILE_RUN(R_)                                                                                              \
-  tile_frames<VIG, BLACK, PYR, F32, R_, NT, NBUF>(t, src, dst, in_bytes, out_bytes, nf, nch, chunks, s_win, p.win_bytes, \
-                                             my_lut, tid, py, (long long)f0, fstep, p3byte)
+  tile_frames<VIG, BLACK, PYR, F32, R_, TW, NT, NBUF>(t, src, dst, in_bytes, out_bytes, nf, nch, goff, s_win, p.win_bytes, \
+                                             my_lut, tid, py, (long long)f0, fstep, p3byte, (uint32_t)a.out_w * 4u)
   if (rounds == 1) MDC_TILE_RUN(1);
   else if (rounds == 2) MDC_TILE_RUN(2);
   else if (rounds == 3 || !F32) MDC_TILE_RUN(3);
@@ -720,12 +810,40 @@ __global__ __launch_bounds__(256) void synth_kernel(uint8_t* __restrict__ out, l
     for (int k = 0; k < 4 && i + k < n; k++) out[i + k] = (uint8_t)(word >> (8 * k));
 }
 
+// Bench utility (no arithmetic of the path): a LINEAR stream that reads n_r 16-byte chunks and writes n_w
+// dwords, interleaved at that ratio -- the memory system's rate for the traffic MIX of a kernel without
+// its access pattern.  bench.py runs it with the algorithmic byte counts of the benchmarked launch, in
+// the same process on the same box, and reports the kernel's rate as a fraction of it.
+// Stores are wave-contiguous dwords with the nontemporal hint (the fastest store form measured on this
+// memory system, tools/hbm_mix.hip), loads wave-contiguous 16-byte.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mix_ceiling_kernel(const u32x4* __restrict__ a, float* __restrict__ b,
+                                                          unsigned long long n_r, unsigned long long n_w) {
+  const unsigned long long tid = (unsigned long long)blockIdx.x * 256 + threadIdx.x, T = (unsigned long long)gridDim.x * 256;
+  const unsigned long long iters = (n_w + T - 1) / T;
+  unsigned long long racc = 0, rk = tid;
+  uint32_t x = 0;
+  for (unsigned long long it = 0; it < iters; it++) {
+    racc += n_r;  // one chunk is read every n_w / n_r stores, the same iteration for every thread
+    if (racc >= n_w) {
+      racc -= n_w;
+      if (rk < n_r) {
+        const u32x4 v = a[rk];
+        x ^= v.x ^ v.y ^ v.z ^ v.w;
+      }
+      rk += T;
+    }
+    const unsigned long long i = it * T + tid;
+    if (i < n_w) __builtin_nontemporal_store(__uint_as_float(x & 0x3fffffffu), b + i);
+  }
+}
+
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace
 
 size_t tiled_lds_bytes(int win_bytes, int nbuf, bool lut) { return (lut ? (size_t)kLutBytes : 0) + (size_t)nbuf * win_bytes; }
-size_t tiled_pyramid_lds_bytes(int tile_h) { return (size_t)2 * (tile_h / 4) * 16 * sizeof(float); }
+size_t tiled_pyramid_lds_bytes(int tile_w, int tile_h) { return (size_t)2 * (tile_h / 4) * (tile_w / 4) * sizeof(float); }
 
 hipError_t launch_unmap(const uint8_t* d_in, float* d_out, const float* d_lut, const float* d_vinv, int64_t npix,
                         int64_t nframes, int fpb, hipStream_t s) {
@@ -772,37 +890,44 @@ struct TiledLaunch {
   hipStream_t s;
 };
 
-template <bool VIG, bool BLACK, bool PYR, bool F32, int NT, int NBUF>
+template <bool VIG, bool BLACK, bool PYR, bool F32, int TW, int NT, int NBUF>
 static hipError_t launch_tiled_variant(const TiledLaunch& l) {
   dim3 grid(l.p.n_blocks, ceil_div(l.nframes, l.fpb));
-  const size_t lds = tiled_lds_bytes(l.p.win_bytes, NBUF, !F32) + (PYR ? tiled_pyramid_lds_bytes(l.p.tile_h) : 0);
+  const size_t lds = tiled_lds_bytes(l.p.win_bytes, NBUF, !F32) + (PYR ? tiled_pyramid_lds_bytes(l.p.tile_w, l.p.tile_h) : 0);
   if (lds > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&remap_tiled_kernel<VIG, BLACK, PYR, F32, NT, NBUF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&remap_tiled_kernel<VIG, BLACK, PYR, F32, TW, NT, NBUF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  remap_tiled_kernel<VIG, BLACK, PYR, F32, NT, NBUF><<<grid, NT, lds, l.s>>>(l.d_in, l.d_out, l.a, l.p, l.py,
-                                                                             (int)l.nframes, l.fpb, l.p.interleave ? 1 : 0);
+  remap_tiled_kernel<VIG, BLACK, PYR, F32, TW, NT, NBUF><<<grid, NT, lds, l.s>>>(l.d_in, l.d_out, l.a, l.p, l.py,
+                                                                                 (int)l.nframes, l.fpb, l.p.interleave ? 1 : 0);
   return hipGetLastError();
 }
 
-template <bool VIG, bool BLACK, bool PYR, int NT, bool F32 = false>
+template <bool VIG, bool BLACK, bool PYR, bool F32, int TW, int NT>
 static hipError_t launch_tiled_buf(const TiledLaunch& l) {
   switch (l.p.nbuf) {
-    case 2: return launch_tiled_variant<VIG, BLACK, PYR, F32, NT, 2>(l);
-    case 3: return launch_tiled_variant<VIG, BLACK, PYR, F32, NT, 3>(l);
-    case 4: return launch_tiled_variant<VIG, BLACK, PYR, F32, NT, 4>(l);
+    case 2: return launch_tiled_variant<VIG, BLACK, PYR, F32, TW, NT, 2>(l);
+    case 3: return launch_tiled_variant<VIG, BLACK, PYR, F32, TW, NT, 3>(l);
+    case 4:
+      if constexpr (NT <= 512) return launch_tiled_variant<VIG, BLACK, PYR, F32, TW, NT, 4>(l);  // 4 buffers of a 1024-thread tile never fit
+      break;
   }
   return hipErrorInvalidValue;
 }
 
-template <bool BLACK>
-static hipError_t launch_tiled_f32_nt(const TiledLaunch& l) {
-  switch (l.p.tile_h) {
-    case 16: return launch_tiled_buf<false, BLACK, false, 256, true>(l);
-    case 32: return launch_tiled_buf<false, BLACK, false, 512, true>(l);
-    case 60: return launch_tiled_buf<false, BLACK, false, 960, true>(l);
-    case 64: return launch_tiled_buf<false, BLACK, false, 1024, true>(l);
+// tile shape -> instantiation.  kTileShapes (mdc_internal.h) lists the legal (tile_w, tile_h) pairs.
+template <bool VIG, bool BLACK, bool PYR, bool F32>
+static hipError_t launch_tiled_shape(const TiledLaunch& l) {
+  switch (l.p.tile_w * 1000 + l.p.tile_h) {
+    case 64016: return launch_tiled_buf<VIG, BLACK, PYR, F32, 64, 256>(l);
+    case 64032: return launch_tiled_buf<VIG, BLACK, PYR, F32, 64, 512>(l);
+    case 64060:  // 15 row groups: no level-3 pairs
+      if constexpr (!PYR) return launch_tiled_buf<VIG, BLACK, false, F32, 64, 960>(l);
+      break;
+    case 64064: return launch_tiled_buf<VIG, BLACK, PYR, F32, 64, 1024>(l);
+    case 128016: return launch_tiled_buf<VIG, BLACK, PYR, F32, 128, 512>(l);
+    case 128032: return launch_tiled_buf<VIG, BLACK, PYR, F32, 128, 1024>(l);
   }
   return hipErrorInvalidValue;
 }
@@ -810,13 +935,7 @@ static hipError_t launch_tiled_f32_nt(const TiledLaunch& l) {
 template <bool VIG, bool BLACK>
 static hipError_t launch_tiled_nt(const TiledLaunch& l) {
   const bool pyr = l.py.l1 || l.py.l2 || l.py.l3;
-  switch (l.p.tile_h) {
-    case 16: return pyr ? launch_tiled_buf<VIG, BLACK, true, 256>(l) : launch_tiled_buf<VIG, BLACK, false, 256>(l);
-    case 32: return pyr ? launch_tiled_buf<VIG, BLACK, true, 512>(l) : launch_tiled_buf<VIG, BLACK, false, 512>(l);
-    case 60: return pyr ? hipErrorInvalidValue : launch_tiled_buf<VIG, BLACK, false, 960>(l);  // 15 row groups: no level-3 pairs
-    case 64: return pyr ? launch_tiled_buf<VIG, BLACK, true, 1024>(l) : launch_tiled_buf<VIG, BLACK, false, 1024>(l);
-  }
-  return hipErrorInvalidValue;
+  return pyr ? launch_tiled_shape<VIG, BLACK, true, false>(l) : launch_tiled_shape<VIG, BLACK, false, false>(l);
 }
 
 hipError_t launch_remap_tiled_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,
@@ -836,7 +955,7 @@ hipError_t launch_remap_tiled_f32(const float* d_in, float* d_out, const RemapAr
   if ((int64_t)a.in_w * a.in_h * 4 >= (int64_t)kOutside || (int64_t)a.out_w * a.out_h * 4 >= (int64_t)kOutside)
     return hipErrorInvalidValue;
   const TiledLaunch l{reinterpret_cast<const uint8_t*>(d_in), d_out, a, p, PyramidOut{nullptr, nullptr, nullptr}, nframes, fpb, s};
-  return p.has_black ? launch_tiled_f32_nt<true>(l) : launch_tiled_f32_nt<false>(l);
+  return p.has_black ? launch_tiled_shape<false, true, false, true>(l) : launch_tiled_shape<false, false, false, true>(l);
 }
 
 hipError_t launch_pyramid_level(const float* d_src, float* d_dst, int w, int h, int64_t nframes, hipStream_t s) {
@@ -849,6 +968,14 @@ hipError_t launch_pyramid_level(const float* d_src, float* d_dst, int w, int h, 
 hipError_t launch_distort_points(float* d_x, float* d_y, int64_t n, const DistortModel& m, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   distort_points_kernel<<<ceil_div(n, 256), 256, 0, s>>>(d_x, d_y, n, m);
+  return hipGetLastError();
+}
+
+hipError_t launch_mix_ceiling(const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes, int blocks,
+                              hipStream_t s) {
+  if (write_bytes <= 0) return hipSuccess;
+  mix_ceiling_kernel<<<blocks, 256, 0, s>>>(reinterpret_cast<const u32x4*>(d_read), d_write,
+                                            (unsigned long long)(read_bytes / 16), (unsigned long long)(write_bytes / 4));
   return hipGetLastError();
 }
 

@@ -54,6 +54,8 @@ CAMERAS = {
     "ragged": (("0.349153 0.436593 0.493140 0.499021 0.933271", "322 250", "0.4 0.53 0.5 0.5 0", "157 93"), 16),
     # output made of whole 64 x {16,32,64} tiles (fused pyramid path), black border pixels
     "pyr_whole_black": (("0.349153 0.436593 0.493140 0.499021 0.933271", "320 256", "full", "192 128"), 16),
+    # BASELINE.json configs[4]: rectify 1280x1024 -> 1280x1024, the base of the 4-level pyramid (bench.py --workload pyramid)
+    "full_1280_to_1280": (("0.349153 0.436593 0.493140 0.499021 0.933271", "1280 1024", "0.4 0.53 0.5 0.5 0", "1280 1024"), 16),
     # magnifying remap (output larger than input)
     "upsample": (("0.349153 0.436593 0.493140 0.499021 0.5", "160 128", "crop", "320 256"), 16),
 }

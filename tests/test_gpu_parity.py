@@ -59,7 +59,7 @@ def setups(calib_dirs, oracle):
     return get
 
 
-SMALL = [n for n in CAMERAS if n != "full_1280_to_640"]
+SMALL = [n for n in CAMERAS if not n.startswith("full_1280")]
 
 
 @pytest.mark.parametrize("name", SMALL)
@@ -96,9 +96,12 @@ def test_tiled_and_gather_kernels_agree(name, setups, oracle, torch_cuda):
         assert info.tiled, "tiled kernel should be plannable for %s" % name
     for k in kernels:
         s.ctx.set_option(capi.OPT_KERNEL, k)
-        for rows, order, nbuf in (((32, capi.ORDER_BANDS, 0), (16, capi.ORDER_ROWS, 4), (32, capi.ORDER_IDENTITY, 3), (60, capi.ORDER_BANDS, 0),
-                                   (64, capi.ORDER_ROWS, 2), (16, capi.ORDER_BANDS, 2), (32, capi.ORDER_ROWS, 4), (60, capi.ORDER_ROWS, 2))
-                                  if k == capi.KERNEL_TILED else ((32, capi.ORDER_BANDS, 0),)):
+        for rows, order, nbuf, cols in (((32, capi.ORDER_BANDS, 0, 64), (16, capi.ORDER_ROWS, 4, 64), (32, capi.ORDER_IDENTITY, 3, 64), (60, capi.ORDER_BANDS, 0, 64),
+                                   (64, capi.ORDER_ROWS, 2, 64), (16, capi.ORDER_BANDS, 2, 64), (32, capi.ORDER_ROWS, 4, 64), (60, capi.ORDER_ROWS, 2, 64),
+                                   (32, capi.ORDER_BLOCKS2D, 0, 128), (16, capi.ORDER_BANDS, 4, 128), (32, capi.ORDER_ROWS, 3, 128), (16, capi.ORDER_BLOCKS2D, 2, 128),
+                                   (32, capi.ORDER_BLOCKS2D, 2, 64))
+                                  if k == capi.KERNEL_TILED else ((32, capi.ORDER_BANDS, 0, 64),)):
+          s.ctx.set_option(capi.OPT_TILE_COLS, cols)
           s.ctx.set_option(capi.OPT_TILE_ROWS, rows)
           s.ctx.set_option(capi.OPT_TILE_ORDER, order)
           s.ctx.set_option(capi.OPT_WINDOW_BUFFERS, nbuf)
@@ -110,7 +113,8 @@ def test_tiled_and_gather_kernels_agree(name, setups, oracle, torch_cuda):
             d_out = torch.full((n, s.w * s.h), -7.0, dtype=torch.float32, device="cuda")
             s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, flags, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-            assert bits_equal(d_out.cpu().numpy(), want[:n]), (name, k, rows, order, nbuf, n, fpb, il)
+            assert bits_equal(d_out.cpu().numpy(), want[:n]), (name, k, rows, cols, order, nbuf, n, fpb, il)
+    s.ctx.set_option(capi.OPT_TILE_COLS, 0)
     s.ctx.set_option(capi.OPT_TILE_ORDER, capi.ORDER_BANDS)
     s.ctx.set_option(capi.OPT_WINDOW_BUFFERS, 0)
     s.ctx.set_option(capi.OPT_FRAME_INTERLEAVE, 0)
@@ -252,19 +256,30 @@ def test_full_size_config_and_properties(setups, oracle, torch_cuda):
     assert bits_equal(d_tmp[:npix].cpu().numpy(), want)
 
 
-def test_automatic_tile_height_keeps_strong_distortion_on_the_tiled_kernel(setups):
-    """'full' cameras have source windows too wide for 64x32 tiles; the automatic choice moves to taller tiles
-    instead of dropping to the gather kernel."""
+def test_automatic_tile_shape_keeps_strong_distortion_on_the_tiled_kernel(setups):
+    """'full' cameras have source windows too wide for the small tiles; the automatic choice walks down the candidate
+    list to a shape whose windows fit instead of dropping to the gather kernel."""
     from mono_dataset_code_amd import capi
 
-    for name, expect in (("small_explicit", 32), ("small_full_black", 64), ("pyr_whole_black", 64)):
+    legal = {(64, 16), (64, 32), (64, 60), (64, 64), (128, 16), (128, 32)}
+    for name, fits_64x32 in (("small_explicit", True), ("small_full_black", False), ("pyr_whole_black", False)):
         s = setups(name)
+        s.ctx.set_option(capi.OPT_TILE_COLS, 0)
         s.ctx.set_option(capi.OPT_TILE_ROWS, 0)
         info = s.ctx.info()
-        assert info.tiled and info.tile_h == expect, (name, info.tiled, info.tile_h)
+        assert info.tiled and (info.tile_w, info.tile_h) in legal, (name, info.tiled, info.tile_w, info.tile_h)
+        assert info.window_buffers in (2, 3, 4) and info.lds_bytes <= 160 * 1024
+        if fits_64x32:
+            assert (info.tile_w, info.tile_h) == (128, 16)  # the first candidate
+        s.ctx.set_option(capi.OPT_TILE_COLS, 64)
         s.ctx.set_option(capi.OPT_TILE_ROWS, 32)
-        assert s.ctx.info().tiled == (expect == 32)
+        assert s.ctx.info().tiled == fits_64x32
+        s.ctx.set_option(capi.OPT_TILE_COLS, 0)  # rows forced, columns free: 128 x 32 takes the wide windows
+        assert s.ctx.info().tiled and s.ctx.info().tile_h == 32
         s.ctx.set_option(capi.OPT_TILE_ROWS, 0)
+    # undistort<float> has its own plan and shape
+    i = setups("small_explicit").ctx.info()
+    assert i.f32_tiled and (i.f32_tile_w, i.f32_tile_h) == (128, 16)
 
 
 def test_batch_beyond_4gib(setups, oracle, torch_cuda):
@@ -401,7 +416,9 @@ def test_process_pyramid_fused(name, setups, oracle, torch_cuda):
     base_want = [s.want(oracle, f, 1, 1, 1, 1) for f in frames]
     d_in = torch.from_numpy(frames).cuda()
     st = torch.cuda.current_stream().cuda_stream
-    for rows, levels, fpb, il in ((32, 4, 0, 0), (16, 4, 3, 1), (64, 3, 0, 0), (60, 4, 0, 0), (32, 5, 2, 1), (32, 1, 0, 0), (64, 4, 2, 1)):
+    for rows, levels, fpb, il, cols in ((32, 4, 0, 0, 64), (16, 4, 3, 1, 64), (64, 3, 0, 0, 64), (60, 4, 0, 0, 64), (32, 5, 2, 1, 64), (32, 1, 0, 0, 64),
+                                        (64, 4, 2, 1, 64), (32, 4, 0, 0, 128), (16, 4, 2, 1, 128), (32, 3, 3, 0, 128)):
+        s.ctx.set_option(capi.OPT_TILE_COLS, cols)
         s.ctx.set_option(capi.OPT_TILE_ROWS, rows)
         s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, fpb)
         s.ctx.set_option(capi.OPT_FRAME_INTERLEAVE, il)
@@ -414,10 +431,51 @@ def test_process_pyramid_fused(name, setups, oracle, torch_cuda):
             src, cw, ch = base_want[f], s.w, s.h
             for l in range(levels - 1):
                 want = oracle.pyramid_level(src, cw, ch)
-                assert bits_equal(lv[l].view(n, -1)[f].cpu().numpy(), want), (name, rows, levels, f, l + 1)
+                assert bits_equal(lv[l].view(n, -1)[f].cpu().numpy(), want), (name, rows, cols, levels, f, l + 1)
                 src, cw, ch = want, cw // 2, ch // 2
+    s.ctx.set_option(capi.OPT_TILE_COLS, 0)
     s.ctx.set_option(capi.OPT_TILE_ROWS, 0)
     s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, 0)
+
+
+def test_pyramid_config5_full_size(setups, oracle, torch_cuda):
+    """BASELINE.json configs[4] at its real geometry: 1280x1024 raw -> 1280x1024 rectified base + levels 1..3
+    (640x512, 320x256, 160x128) out of ONE launch, every level of every checked frame bit-equal to the oracle's
+    chain; then the stand-alone level passes on the same base must reproduce the fused levels on the whole batch."""
+    from mono_dataset_code_amd import capi, synth
+
+    torch = torch_cuda
+    s = setups("full_1280_to_1280")
+    info = s.ctx.info()
+    assert info.tiled and (info.out_w, info.out_h) == (1280, 1024)
+    n, levels = 12, 4
+    npix, nout = s.W * s.H, s.w * s.h
+    st = torch.cuda.current_stream().cuda_stream
+    d_in = torch.empty(n * npix, dtype=torch.uint8, device="cuda")
+    s.ctx.synth_frames(d_in.data_ptr(), 7, n, npix, synth.SEED, st)
+    torch.cuda.synchronize()
+    frames = d_in.view(n, npix).cpu().numpy().copy()
+    frames[3] = synth.smooth_frame(s.W, s.H, 0.4)  # saturated blobs: contiguous NaN regions through every level
+    d_in.copy_(torch.from_numpy(frames).reshape(-1))
+    flags = capi.RECTIFY | capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED
+    d_base = torch.full((n, nout), -7.0, dtype=torch.float32, device="cuda")
+    lv = [torch.full((n, (s.w >> l) * (s.h >> l)), -7.0, dtype=torch.float32, device="cuda") for l in range(1, levels)]
+    s.ctx.process_pyramid_batch(d_in.data_ptr(), d_base.data_ptr(), levels, [t.data_ptr() for t in lv], n, flags, st)
+    torch.cuda.synchronize()
+    for f in (0, 3, n - 1):
+        src, cw, ch = s.want(oracle, frames[f], 1, 1, 1, 1), s.w, s.h
+        assert bits_equal(d_base[f].cpu().numpy(), src), f
+        for l in range(levels - 1):
+            src = oracle.pyramid_level(src, cw, ch)
+            cw, ch = cw // 2, ch // 2
+            assert src.size == cw * ch == lv[l].shape[1]
+            assert bits_equal(lv[l][f].cpu().numpy(), src), (f, l + 1)
+    # whole batch: per-level passes over the fused base == the fused levels
+    lv2 = [torch.full_like(t, -9.0) for t in lv]
+    s.ctx.pyramid_batch(d_base.data_ptr(), s.w, s.h, levels, [t.data_ptr() for t in lv2], n, st)
+    torch.cuda.synchronize()
+    for a, b in zip(lv, lv2):
+        assert bits_equal(a.cpu().numpy(), b.cpu().numpy())
 
 
 @pytest.mark.parametrize("name", ["small_crop", "ragged"])

@@ -51,9 +51,11 @@ def test_random_camera_random_options(seed, tmp_path, oracle):
     want = {}
     for trial in range(6):
         rows = int(rng.choice([16, 32, 60, 64]))
+        cols = int(rng.choice([64, 128])) if rows in (16, 32) else 64
+        ctx.set_option(capi.OPT_TILE_COLS, cols)
         ctx.set_option(capi.OPT_TILE_ROWS, rows)
         ctx.set_option(capi.OPT_WINDOW_BUFFERS, int(rng.choice([0, 2, 3, 4])))
-        ctx.set_option(capi.OPT_TILE_ORDER, int(rng.integers(0, 3)))
+        ctx.set_option(capi.OPT_TILE_ORDER, int(rng.integers(0, 4)))
         ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, int(rng.choice([0, 1, 2, 3, 5])))
         ctx.set_option(capi.OPT_FRAME_INTERLEAVE, int(rng.integers(0, 2)))
         g, v, o = (int(x) for x in rng.integers(0, 2, 3))
@@ -66,7 +68,7 @@ def test_random_camera_random_options(seed, tmp_path, oracle):
         ctx.process_pyramid_batch(d_in.data_ptr(), d_out.data_ptr(), levels, [t.data_ptr() for t in lv], n, flags, st)
         torch.cuda.synchronize()
         info = ctx.info()
-        tag = (seed, lines, trial, rows, info.tiled, g, v, o, levels)
+        tag = (seed, lines, trial, rows, cols, info.tiled, g, v, o, levels)
         assert bits_equal(d_out.cpu().numpy(), want[(g, v, o)]), tag
         for f in range(n):
             src, cw, ch = want[(g, v, o)][f], w, h

@@ -106,7 +106,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
            "--frames", "64", "--preroll-s", "0.05"]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("[Gloo]")]  # gloo announces itself on stdout
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]  # gloo announces itself on stdout, ranks interleaved
     assert len(lines) == 1, r.stdout  # exactly one JSON line, from rank 0
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 5

@@ -109,6 +109,148 @@ __global__ __launch_bounds__(TW* TH / 4) void tile_rw(const uint8_t* __restrict_
   }
 }
 
+// Wave-private variant of the tile skeleton: the 8 waves of a 64x32 tile each own a 64x4 output strip and
+// read their OWN window (128 B x 8 rows = one 16-byte load per lane), so nothing is shared between the
+// waves of a workgroup and no barrier is needed.  PF = loads of frame f+1 issued before frame f is
+// stored; BAR = keep a workgroup barrier per frame anyway (isolates what the barrier costs).
+template <int PF, bool BAR, int SMODE>
+__global__ __launch_bounds__(512) void strip_rw(const uint8_t* __restrict__ in, float* __restrict__ out, int nframes,
+                                                int fpb, int band) {
+  constexpr int TW = 64, TH = 32, TX = OW / TW, TY = OH / TH, NTILES = TX * TY;
+  __shared__ u32x4 sink[512];
+  const int ntp = gridDim.x;
+  int tile = band ? (blockIdx.x & 7) * (ntp >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  if (tile >= NTILES) return;
+  const int tx = tile % TX, ty = tile / TX;
+  const int f0 = blockIdx.y * fpb, f1 = min(nframes, f0 + fpb);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cx = (int)(640.f + (tx * TW + TW / 2 - 320) * 1.345f);
+  const int cy = (int)(512.f + (ty * TH + wave * 4 + 2 - 240) * 1.52f);
+  const int x0 = max(0, (cx - 64)) & ~15, y0 = max(0, cy - 4);
+  const long long soff = (long long)(y0 + (lane >> 3)) * IW + x0 + (lane & 7) * 16;
+  const long long obase = (long long)(ty * TH + wave * 4) * OW + tx * TW + lane;
+  u32x4 cur = *reinterpret_cast<const u32x4*>(in + (long long)f0 * NIN + soff);
+  for (int f = f0; f < f1; f++) {
+    u32x4 nxt = cur;
+    if (PF) {
+      if (f + 1 < f1) nxt = *reinterpret_cast<const u32x4*>(in + (long long)(f + 1) * NIN + soff);
+    } else if (f > f0) {
+      cur = *reinterpret_cast<const u32x4*>(in + (long long)f * NIN + soff);
+    }
+    const uint32_t acc = cur.x ^ cur.y ^ cur.z ^ cur.w;
+    if (BAR) {
+      sink[tid] = cur;
+      __syncthreads();
+    }
+    float* dst = out + (long long)f * NOUT + obase;
+    const float x = __uint_as_float(acc & 0x3fffffffu);
+#pragma unroll
+    for (int j = 0; j < 4; j++) st<SMODE>(x, dst + j * OW);
+    if (PF) cur = nxt;
+  }
+}
+
+// tile skeleton with the loads of frame f+1 issued before frame f is written (software prefetch), barrier kept
+// il != 0: group g of G = gridDim.y takes frames g, g+G, g+2G, ... (all resident workgroups sweep the batch side
+// by side) instead of fpb consecutive frames.  Dynamic LDS passed at launch is unused: it only lowers occupancy.
+template <int TW, int TH, int SMODE, bool BAR>
+__global__ __launch_bounds__(TW* TH / 4) void tile_rw_pf(const uint8_t* __restrict__ in, float* __restrict__ out,
+                                                          int nframes, int fpb, int winw, int winh, int band, int il = 0) {
+  constexpr int NT = TW * TH / 4;
+  constexpr int TX = OW / TW, TY = OH / TH, NTILES = TX * TY;
+  __shared__ u32x4 sink[NT];
+  const int ntp = gridDim.x;
+  int tile = band ? (blockIdx.x & 7) * (ntp >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  if (tile >= NTILES) return;
+  const int tx = tile % TX, ty = tile / TX;
+  const int fs = il ? (int)gridDim.y : 1;
+  const int f0 = il ? (int)blockIdx.y : blockIdx.y * fpb, f1 = il ? nframes : min(nframes, f0 + fpb);
+  const int tid = threadIdx.x;
+  const int cx = (int)(640.f + (tx * TW + TW / 2 - 320) * 1.345f), cy = (int)(512.f + (ty * TH + TH / 2 - 240) * 1.52f);
+  const int x0 = max(0, (cx - winw / 2)) & ~15, y0 = max(0, cy - winh / 2);
+  const int cpr = winw / 16, nch = cpr * winh;
+  const int lane_x = tid % TW, row0 = (tid / TW) * 4;
+  const long long obase = (long long)(ty * TH + row0) * OW + tx * TW + lane_x;
+  // at most 2 chunks per thread (nch <= 2 NT)
+  long long so[2];
+  bool has[2];
+  for (int k = 0; k < 2; k++) {
+    const int c = tid + k * NT;
+    has[k] = c < nch;
+    const int r = has[k] ? c / cpr : 0;
+    so[k] = (long long)(y0 + r) * IW + x0 + (c - r * cpr) * 16;
+  }
+  u32x4 cur[2] = {}, nxt[2] = {};
+  for (int k = 0; k < 2; k++)
+    if (has[k]) cur[k] = *reinterpret_cast<const u32x4*>(in + (long long)f0 * NIN + so[k]);
+  for (int f = f0; f < f1; f += fs) {
+    if (f + fs < f1)
+      for (int k = 0; k < 2; k++)
+        if (has[k]) nxt[k] = *reinterpret_cast<const u32x4*>(in + (long long)(f + fs) * NIN + so[k]);
+    uint32_t acc = 0;
+    for (int k = 0; k < 2; k++) acc ^= cur[k].x ^ cur[k].y ^ cur[k].z ^ cur[k].w;
+    if (BAR) {
+      sink[tid] = cur[0];
+      __syncthreads();
+    }
+    float* dst = out + (long long)f * NOUT + obase;
+    const float x = __uint_as_float(acc & 0x3fffffffu);
+#pragma unroll
+    for (int j = 0; j < 4; j++) st<SMODE>(x, dst + j * OW);
+    for (int k = 0; k < 2; k++) cur[k] = nxt[k];
+  }
+}
+
+// The tile skeleton with a workgroup's fpb frames taken as chunks of `chunk` consecutive frames, the chunks
+// of the G = gridDim.y groups interleaved: iteration i of group y works on frame ((i / chunk) * G + y) * chunk
+// + i % chunk.  The groups resident at one time then cover a COMPACT range of frames (like a small fpb), while
+// every workgroup still lives for fpb frames (one prologue).  chunk = fpb is the plain consecutive assignment.
+template <int TW, int TH, int SMODE>
+__global__ __launch_bounds__(TW* TH / 4) void tile_rw_chunked(const uint8_t* __restrict__ in, float* __restrict__ out,
+                                                               int nframes, int fpb, int winw, int winh, int chunk) {
+  constexpr int NT = TW * TH / 4;
+  constexpr int TX = OW / TW, TY = OH / TH, NTILES = TX * TY;
+  __shared__ u32x4 sink[NT];
+  const int ntp = gridDim.x;
+  int tile = (blockIdx.x & 7) * (ntp >> 3) + (blockIdx.x >> 3);
+  if (tile >= NTILES) return;
+  const int tx = tile % TX, ty = tile / TX;
+  const int G = gridDim.y, y = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int cx = (int)(640.f + (tx * TW + TW / 2 - 320) * 1.345f), cy = (int)(512.f + (ty * TH + TH / 2 - 240) * 1.52f);
+  const int x0 = max(0, (cx - winw / 2)) & ~15, y0 = max(0, cy - winh / 2);
+  const int cpr = winw / 16, nch = cpr * winh;
+  const int lane_x = tid % TW, row0 = (tid / TW) * 4;
+  const long long obase = (long long)(ty * TH + row0) * OW + tx * TW + lane_x;
+  long long so[2];
+  bool has[2];
+  for (int k = 0; k < 2; k++) {
+    const int c = tid + k * NT;
+    has[k] = c < nch;
+    const int r = has[k] ? c / cpr : 0;
+    so[k] = (long long)(y0 + r) * IW + x0 + (c - r * cpr) * 16;
+  }
+  auto frame_of = [&](int i) { return ((i / chunk) * G + y) * chunk + i % chunk; };
+  u32x4 cur[2] = {}, nxt[2] = {};
+  for (int k = 0; k < 2; k++)
+    if (has[k]) cur[k] = *reinterpret_cast<const u32x4*>(in + (long long)frame_of(0) * NIN + so[k]);
+  for (int i = 0; i < fpb; i++) {
+    const int f = frame_of(i);
+    if (i + 1 < fpb)
+      for (int k = 0; k < 2; k++)
+        if (has[k]) nxt[k] = *reinterpret_cast<const u32x4*>(in + (long long)frame_of(i + 1) * NIN + so[k]);
+    uint32_t acc = 0;
+    for (int k = 0; k < 2; k++) acc ^= cur[k].x ^ cur[k].y ^ cur[k].z ^ cur[k].w;
+    sink[tid] = cur[0];
+    __syncthreads();
+    float* dst = out + (long long)f * NOUT + obase;
+    const float x = __uint_as_float(acc & 0x3fffffffu);
+#pragma unroll
+    for (int j = 0; j < 4; j++) st<SMODE>(x, dst + j * OW);
+    for (int k = 0; k < 2; k++) cur[k] = nxt[k];
+  }
+}
+
 // read-only "pieces": a workgroup reads 7168 bytes of each of its frames as rows of L contiguous bytes
 // (stride = one image row); the 104 workgroups of a frame group tile a 1024 x 728 byte region without
 // overlap.  Same bytes for every L -- isolates how the piece length affects the achieved read rate.
@@ -225,6 +367,42 @@ int main() {
     report("tile64x32 read+write plain-ld nt-st", rb + wb, time_ms([&] { tile_rw<64, 32, ST_PLAIN, ST_NT, true, true><<<g64, 512>>>(d_in, d_out, F, fpb, 128, 56, 1); }));
     report("tile64x32 read+write nt-ld nt-st", rb + wb, time_ms([&] { tile_rw<64, 32, ST_NT, ST_NT, true, true><<<g64, 512>>>(d_in, d_out, F, fpb, 128, 56, 1); }));
     report("tile64x32 read+write plain-ld plain-st", rb + wb, time_ms([&] { tile_rw<64, 32, ST_PLAIN, ST_PLAIN, true, true><<<g64, 512>>>(d_in, d_out, F, fpb, 128, 56, 1); }));
+    // structure experiments (round 2): what do the per-frame barrier and a prefetch cost / buy in the skeleton?
+    const double rbs = 150.0 * 8 * 1024 * F;  // strips: 8 waves x 1 KiB per tile and frame
+    report("tile64x32 r+w prefetch, barrier", rb + wb, time_ms([&] { tile_rw_pf<64, 32, ST_NT, true><<<g64, 512>>>(d_in, d_out, F, fpb, 128, 56, 1); }));
+    report("tile64x32 r+w prefetch, NO barrier", rb + wb, time_ms([&] { tile_rw_pf<64, 32, ST_NT, false><<<g64, 512>>>(d_in, d_out, F, fpb, 128, 56, 1); }));
+    report("tile128x16 r+w prefetch, barrier (192x40 win)", 150.0 * 192 * 40 * F + wb, time_ms([&] { tile_rw_pf<128, 16, ST_NT, true><<<dim3(152, groups), 512>>>(d_in, d_out, F, fpb, 192, 40, 1); }));
+    report("tile128x32 r+w prefetch, barrier (192x56 win)", 75.0 * 192 * 56 * F + wb, time_ms([&] { tile_rw_pf<128, 32, ST_NT, true><<<dim3(80, groups), 1024>>>(d_in, d_out, F, fpb, 192, 56, 1); }));
+    report("strips 64x4 per wave, no prefetch, no barrier", rbs + wb, time_ms([&] { strip_rw<0, false, ST_NT><<<g64, 512>>>(d_in, d_out, F, fpb, 1); }));
+    report("strips 64x4 per wave, prefetch, no barrier", rbs + wb, time_ms([&] { strip_rw<1, false, ST_NT><<<g64, 512>>>(d_in, d_out, F, fpb, 1); }));
+    report("strips 64x4 per wave, prefetch, barrier", rbs + wb, time_ms([&] { strip_rw<1, true, ST_NT><<<g64, 512>>>(d_in, d_out, F, fpb, 1); }));
+    // compact in-flight frame set without a short workgroup life: chunks of c frames, groups interleaved
+    for (int lds : {0, 52 * 1024})
+      for (int fp : {32, 64, 128})
+        for (int ck : {1, 4, 8, 16, 32}) {
+          if (ck > fp) continue;
+          char nm[96];
+          snprintf(nm, sizeof nm, "tile64x32 chunked fpb %d chunk %d %s", fp, ck, lds ? "3WG/CU" : "4WG/CU");
+          report(nm, rb + wb, time_ms([&] { tile_rw_chunked<64, 32, ST_NT><<<dim3(152, F / fp), 512, lds>>>(d_in, d_out, F, fp, 128, 56, ck); }));
+        }
+    // occupancy: the real kernel runs 3 workgroups of 512 per CU (LDS), this skeleton 4
+    report("tile64x32 pf barrier, 3 WG/CU (52 KiB dummy LDS)", rb + wb, time_ms([&] { tile_rw_pf<64, 32, ST_NT, true><<<g64, 512, 52 * 1024>>>(d_in, d_out, F, fpb, 128, 56, 1); }));
+    report("tile64x32 pf barrier, 2 WG/CU (70 KiB dummy LDS)", rb + wb, time_ms([&] { tile_rw_pf<64, 32, ST_NT, true><<<g64, 512, 64 * 1024>>>(d_in, d_out, F, fpb, 128, 56, 1); }));
+    // one round of persistent workgroups sweeping the batch side by side (G groups, frames g, g+G, ...)
+    for (int G : {5, 4, 10, 32}) {
+      char nm[96];
+      snprintf(nm, sizeof nm, "tile64x32 pf barrier, interleaved G=%d", G);
+      report(nm, rb + wb, time_ms([&] { tile_rw_pf<64, 32, ST_NT, true><<<dim3(152, G), 512>>>(d_in, d_out, F, 0, 128, 56, 1, 1); }));
+      snprintf(nm, sizeof nm, "tile64x32 pf barrier, interleaved G=%d 3WG/CU", G);
+      report(nm, rb + wb, time_ms([&] { tile_rw_pf<64, 32, ST_NT, true><<<dim3(152, G), 512, 52 * 1024>>>(d_in, d_out, F, 0, 128, 56, 1, 1); }));
+    }
+    for (int fp : {8, 64}) {
+      char nm[96];
+      snprintf(nm, sizeof nm, "strips prefetch no barrier fpb %d", fp);
+      report(nm, rbs + wb, time_ms([&] { strip_rw<1, false, ST_NT><<<dim3(152, (F + fp - 1) / fp), 512>>>(d_in, d_out, F, fp, 1); }));
+      snprintf(nm, sizeof nm, "tile64x32 prefetch barrier fpb %d", fp);
+      report(nm, rb + wb, time_ms([&] { tile_rw_pf<64, 32, ST_NT, true><<<dim3(152, (F + fp - 1) / fp), 512>>>(d_in, d_out, F, fp, 128, 56, 1); }));
+    }
     for (int fp : {8, 16, 64, 205}) {
       char nm[96];
       snprintf(nm, sizeof nm, "tile64x32 read+write plain-ld nt-st fpb %d", fp);

@@ -32,10 +32,17 @@ d_out = torch.empty(B * npo, dtype=torch.float32, device="cuda")
 ctx.synth_frames(d_raw.data_ptr(), 0, B, npi, synth.SEED, s)
 ctx.unmap_batch(d_raw.data_ptr(), d_f.data_ptr(), B, 7, s)
 alg = int(info.src_bbox_bytes) * 4 + npo * 4
-for label, kernel, rows in (("gather", capi.KERNEL_GATHER, 32), ("tiled 64x32", capi.KERNEL_AUTO, 32), ("tiled 64x16", capi.KERNEL_AUTO, 16),
-                            ("tiled 64x64", capi.KERNEL_AUTO, 64)):
+for label, kernel, cols, rows, nbuf in (("gather", capi.KERNEL_GATHER, 64, 32, 0), ("tiled auto", capi.KERNEL_AUTO, 0, 0, 0),
+                                        ("tiled 64x32", capi.KERNEL_AUTO, 64, 32, 0), ("tiled 64x16", capi.KERNEL_AUTO, 64, 16, 0),
+                                        ("tiled 64x64", capi.KERNEL_AUTO, 64, 64, 0), ("tiled 128x16", capi.KERNEL_AUTO, 128, 16, 0),
+                                        ("tiled 128x32", capi.KERNEL_AUTO, 128, 32, 0), ("tiled 64x32 b3", capi.KERNEL_AUTO, 64, 32, 3),
+                                        ("tiled 64x16 b2", capi.KERNEL_AUTO, 64, 16, 2), ("tiled 128x16 b3", capi.KERNEL_AUTO, 128, 16, 3)):
     ctx.set_option(capi.OPT_KERNEL, kernel)
+    ctx.set_option(capi.OPT_TILE_COLS, cols)
     ctx.set_option(capi.OPT_TILE_ROWS, rows)
+    ctx.set_option(capi.OPT_WINDOW_BUFFERS, nbuf)
+    i = ctx.info()
+    label += " [%dx%d %s]" % (i.f32_tile_w, i.f32_tile_h, "tiled" if i.f32_tiled else "gather")
     for _ in range(100):
         ctx.undistort_batch_f32(d_f.data_ptr(), d_out.data_ptr(), B, s)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -45,5 +52,5 @@ for label, kernel, rows in (("gather", capi.KERNEL_GATHER, 32), ("tiled 64x32", 
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 50
-    print("undistort<float> %-12s: %.4f ms / %d frames, algorithmic %.2f MB/frame (bbox x 4 B + output) -> %.0f GB/s = %.3f of 8 TB/s"
+    print("undistort<float> %-32s: %.4f ms / %d frames, algorithmic %.2f MB/frame (bbox x 4 B + output) -> %.0f GB/s = %.3f of 8 TB/s"
           % (label, ms, B, alg / 1e6, alg * B / ms / 1e6, alg * B / ms / 1e6 / 8000))
