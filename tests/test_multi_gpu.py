@@ -5,6 +5,7 @@ caller's torch.distributed backend -- RCCL ("nccl") on GPUs, gloo here: world_si
 import os
 import subprocess
 import sys
+import tempfile
 
 import numpy as np
 import pytest
@@ -93,23 +94,88 @@ def test_packed_blob_equals_exported_blob(calib_dirs):
     assert (i1.in_w, i1.out_w, i1.tiled, i1.n_tiles, i1.src_bbox_bytes) == (i2.in_w, i2.out_w, i2.tiled, i2.n_tiles, i2.src_bbox_bytes)
 
 
-@pytest.mark.gpu
-def test_bench_two_ranks_on_one_gpu(tmp_path):
-    """bench.py's N>1 path end to end (rank-0 table build, broadcast, import on every rank, round-robin
-    shard, barrier + max-over-ranks timing, one JSON line from rank 0) with two ranks sharing the one GPU
-    of the test box: gloo carries the collectives there (RCCL wants one device per rank)."""
+def _bench(args, env=None, nproc=0, port=29533, timeout=900):
     import json
 
-    env = dict(os.environ, MDC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
-           "--frames", "64", "--preroll-s", "0.05"]
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT)
+    e = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    e.update(env or {})
+    if nproc:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]  # gloo announces itself on stdout, ranks interleaved
     assert len(lines) == 1, r.stdout  # exactly one JSON line, from rank 0
-    out = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def _check_rank_dumps(dump_dir, world, n, oracle):
+    """Every rank's first n outputs against the oracle for the GLOBAL frame index rank + i * world, recomputed here
+    from the frame generator: the frame -> rank mapping is checked on bytes, not on arithmetic."""
+    from conftest import bits_equal
+    from mono_dataset_code_amd import capi, synth
+
+    d = synth.write_sequence_calibration(tempfile.mkdtemp(prefix="mdc_dump_"))
+    fov = capi.UndistorterFOV(os.path.join(d, "camera.txt"))
+    photo = capi.PhotometricUndistorter(os.path.join(d, "pcalib.txt"), os.path.join(d, "vignette.png"), 1280, 1024)
+    rx, ry = fov.remap()
+    ginv, vinv = photo.ginv(), photo.vignette()[1]
+    for r in range(world):
+        out = np.load(os.path.join(dump_dir, "rank%d_out.npy" % r))
+        idx = np.load(os.path.join(dump_dir, "rank%d_idx.npy" % r))
+        head = np.load(os.path.join(dump_dir, "rank%d_in_head.npy" % r)).reshape(n, 64)
+        assert out.shape == (n, 640 * 480) and list(idx) == [r + i * world for i in range(n)]
+        for i in range(n):
+            raw = synth.noise_frames(int(idx[i]), 1, 1280 * 1024)[0]
+            assert np.array_equal(head[i], raw[:64]), "rank %d local frame %d does not hold global frame %d" % (r, i, idx[i])
+            want = oracle.get_image(raw, 1280, 1024, 640, 480, ginv, vinv, True, True, rx, ry, 1, 1, 1, 1)
+            assert bits_equal(out[i], want), (r, i, int(idx[i]))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu(tmp_path, oracle):
+    """bench.py's N>1 path end to end (rank-0 table build, broadcast, import on every rank, round-robin
+    shard, barrier + max-over-ranks timing, one JSON line from rank 0) with two ranks sharing the one GPU
+    of the test box: gloo carries the collectives there (RCCL wants one device per rank).  EVERY rank's first
+    three outputs are compared with the oracle for their global frame indices."""
+    out = _bench(["--gpus", "2", "--steps", "5", "--warmup", "2", "--frames", "64", "--preroll-s", "0.05",
+                  "--dump-dir", str(tmp_path), "--dump-frames", "3"], env={"MDC_BENCH_BACKEND": "gloo"}, nproc=2)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 5
     assert out["config"]["frames_per_gpu_per_step"] == 64 and "cpu_baseline" not in out
     assert out["parity"]["mismatching_pixels"] == 0
-    assert out["config"]["tables"].startswith("rank-0 build")
+    assert out["config"]["tables"].startswith("rank-0 build") and out["config"]["collective_backend"] == "gloo"
+    assert len(out["roofline"]["per_rank_kernel_ms_mean_median_min"]) == 2
+    _check_rank_dumps(str(tmp_path), 2, 3, oracle)
+
+
+@pytest.mark.gpu
+def test_bench_seq50k_sharding_two_ranks(tmp_path, oracle):
+    """BASELINE.json configs[3] (one sequence, frame f on GPU f % N), shrunk to 2 x 40 frames: strong scaling line,
+    per-rank outputs equal to the oracle for the global indices."""
+    out = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "seq50k", "--frames", "40", "--preroll-s", "0.05",
+                  "--dump-dir", str(tmp_path), "--dump-frames", "2", "--no-ceiling"], env={"MDC_BENCH_BACKEND": "gloo"}, nproc=2, port=29537)
+    assert out["scaling"] == "strong" and out["config"]["sequence_frames"] == 80 and out["config"]["frames_per_gpu_per_step"] == 40
+    assert out["parity"]["mismatching_pixels"] == 0
+    _check_rank_dumps(str(tmp_path), 2, 2, oracle)
+
+
+@pytest.mark.gpu
+def test_bench_rccl_branch_executes_with_a_world_of_one(tmp_path):
+    """The "nccl" (= RCCL) branch of bench.py on the one GPU of the test box: process-group init on the device, the
+    table broadcast, the barriers and the all-reduce / all-gather all run through RCCL with world size 1."""
+    out = _bench(["--gpus", "1", "--steps", "4", "--warmup", "1", "--frames", "128", "--preroll-s", "0.05", "--no-cpu-baseline"],
+                 env={"MDC_BENCH_FORCE_DIST": "1", "MDC_BENCH_BACKEND": "nccl", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
+                      "MASTER_PORT": "29539"})
+    assert out["n_gpus"] == 1 and out["config"]["collective_backend"] == "nccl"
+    assert out["config"]["tables"] == "rank-0 build + one RCCL broadcast"
+    assert out["parity"]["mismatching_pixels"] == 0
+    assert out["roofline"]["frac_of_same_box_mix_ceiling"] > 0.3 and out["roofline"]["kernel"].startswith("remap_tiled_kernel<")
+
+
+@pytest.mark.gpu
+def test_bench_pyramid_checks_every_level():
+    out = _bench(["--steps", "3", "--warmup", "1", "--workload", "pyramid", "--frames", "16", "--preroll-s", "0.05", "--no-cpu-baseline"])
+    assert out["parity"] == {"frames_checked": 2, "levels_checked": 4, "mismatching_pixels": 0}
+    assert ", true, false, " in out["roofline"]["kernel"]  # the fused-pyramid instantiation ran

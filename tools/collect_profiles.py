@@ -10,11 +10,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-KERNEL_OF = {"fused": ("fused_tiled", "remap_tiled_kernel", 1024), "unmap": ("unmap", "unmap_xpose_kernel", 512),
-             "pyramid": ("pyramid_fused", "remap_tiled_kernel", 256)}
+WORKLOADS = {"fused": "remap_tiled_kernel", "unmap": "unmap_xpose_kernel", "pyramid": "remap_tiled_kernel", "seq50k": "remap_tiled_kernel"}
 traffic_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
-for wl, (key, kname, frames) in KERNEL_OF.items():
+for wl, kname in WORKLOADS.items():
     d = os.path.join(ROOT, "gpurun_out", "profile_%s_%s" % (tag, wl))
     if not os.path.isdir(d):
         continue
@@ -22,12 +21,19 @@ for wl, (key, kname, frames) in KERNEL_OF.items():
     for f in glob.glob(d + "/stats/**/*kernel_stats.csv", recursive=True):
         shutil.copy(f, os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, wl)))
     s = json.load(open(os.path.join(d, "summary.json")))
-    args = s.get("bench_args", "").split()
-    if "--frames" in args:
-        frames = int(args[args.index("--frames") + 1])
+    # frames per launch: what bench.py said under the profiler (its JSON line is kept next to the stats)
+    frames = None
+    try:
+        line = [l for l in open(os.path.join(d, "bench_under_profiler.json")) if l.startswith("{")][-1]
+        frames = json.loads(line)["roofline"]["frames_per_launch"]
+    except (OSError, IndexError, KeyError, ValueError):
+        pass
+    if not frames:
+        continue
     for k, v in s["kernels"].items():
         if k.startswith(kname) and "hbm_bytes_per_launch" in v:
-            traffic[key] = {
+            # one entry per kernel INSTANTIATION: bench.py only quotes a figure measured on the instantiation it launched
+            traffic["%s:%s" % (wl, k)] = {
                 "bytes_per_frame": v["hbm_bytes_per_launch"] / frames,
                 "read_bytes_per_frame": v["hbm_read_bytes_per_launch"] / frames,
                 "write_bytes_per_frame": v["hbm_write_bytes_per_launch"] / frames,
