@@ -65,7 +65,14 @@ enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2 /* frames a workgroup lo
        MDC_OPT_TILE_ORDER = 6 /* tuning: placement of output tiles on the 8 XCDs, MDC_ORDER_* */,
        MDC_OPT_WINDOW_BUFFERS = 7 /* tuning: LDS window buffers per workgroup, 2..4 (frames staged ahead + 1); 0 = automatic */,
        MDC_OPT_FRAME_INTERLEAVE = 8 /* tuning: a workgroup takes every G-th frame (1) or a run of consecutive frames (0) */,
-       MDC_OPT_TILE_COLS = 9 /* tuning: output tile {64, 128} x rows (128 x {16, 32}: 512 / 1024 threads); 0 = automatic */ };
+       MDC_OPT_TILE_COLS = 9 /* tuning: output tile {64, 128} x rows (128 x {16, 32}: 512 / 1024 threads); 0 = automatic */,
+       MDC_OPT_PIN_CALLER_BUFFERS = 10 /* 1: page-lock, in place, the W*H float buffer a caller passes repeatedly as
+          image_out of mdc_unmap_host / input of mdc_undistort_host_f32 (hipHostRegister on the second consecutive
+          sighting of the same pointer + size; released by mdc_destroy or when the option is cleared), so that the
+          reference's two-call composition (unMapImage -> internalTempBuffer -> undistort<float>,
+          src/BenchmarkDatasetReader.h:222-223) copies at PCIe rate.  OFF by default -- the caller promises that such a
+          buffer stays allocated for as long as the context lives.  Also switched on by the environment variable
+          MDC_PIN_CALLER_BUFFERS=1, for callers that cannot be recompiled. */ };
 enum { MDC_ORDER_BANDS = 0 /* row-major runs of tiles per XCD */, MDC_ORDER_ROWS = 1 /* whole tile rows per XCD */,
        MDC_ORDER_IDENTITY = 2 /* block b = tile b (diagnosis) */,
        MDC_ORDER_BLOCKS2D = 3 /* the tile grid cut into 8 rectangles, one per XCD */ };

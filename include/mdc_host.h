@@ -54,6 +54,41 @@ int mdch_bind(mdc_ctx* ctx, const mdch_fov* fov, const mdch_photo* photo);
  * returns the size.  Returns MDC_OK or MDC_ERR_ARG (buffer too small). */
 int mdch_pack_tables(const mdch_fov* fov, const mdch_photo* photo, void* blob, size_t cap, size_t* size);
 
+/* ---- class DatasetReader (include/mono_dataset_code/BenchmarkDatasetReader.h; reference
+ * src/BenchmarkDatasetReader.h:83-345) ------------------------------------------------------------ */
+typedef struct mdch_reader mdch_reader;
+mdch_reader* mdch_reader_create(const char* folder);   /* DatasetReader(std::string folder) */
+void mdch_reader_destroy(mdch_reader*);
+int mdch_reader_num_images(mdch_reader*);                /* getNumImages() */
+double mdch_reader_timestamp(mdch_reader*, int id);      /* getTimestamp() */
+float mdch_reader_exposure(mdch_reader*, int id);        /* getExposure() */
+void mdch_reader_dims(mdch_reader*, int d4[4]);          /* in_w in_h out_w out_h of its UndistorterFOV */
+/* getImage(id, rectify, removeGamma, removeVignette, nanOverexposed): copies ExposureImage::image into out
+ * (cap floats) and the other public fields into meta = {w, h, id}, stamp, exposure; 1 on success, 0 if getImage
+ * returned 0 or cap is too small. */
+int mdch_reader_get_image(mdch_reader*, int id, int rectify, int g, int v, int o, float* out, long cap, int meta3[3],
+                          double* stamp, float* exposure);
+/* getImages(first, count, ...): image i into out + i * frame_floats; ok[i] = 1 where an image was produced.
+ * Returns the number produced. */
+int mdch_reader_get_images(mdch_reader*, int first, int count, int rectify, int g, int v, int o, float* out,
+                           long frame_floats, unsigned char* ok);
+int mdch_reader_get_raw(mdch_reader*, int id, unsigned char* out, long cap, int wh[2]); /* getImageRaw(); 1 / 0 */
+void mdch_reader_set_threads(mdch_reader*, int n);       /* setDecodeThreads() */
+void mdch_reader_set_prefetch(mdch_reader*, int frames); /* setPrefetch() */
+const char* mdch_reader_last_error(mdch_reader*);
+void mdch_reader_prefetch_stats(mdch_reader*, long hits_misses[2]); /* getPrefetchStats() */
+
+/* The reader's frame decoders on a byte string (8-bit gray PNG, PGM P5, baseline JPEG): 1 on success, else 0
+ * with the reason in err (errcap bytes).  wh = decoded size (also set when only cap was too small). */
+int mdch_decode_gray8(const unsigned char* data, size_t n, unsigned char* out, size_t cap, int wh[2], char* err,
+                      size_t errcap);
+
+/* ExposureImage's pixel pool (include/mono_dataset_code/ExposureImage.h). */
+float* mdch_image_alloc(unsigned long nfloats);
+void mdch_image_free(float* block);
+void mdch_image_pool_trim(void);
+unsigned long mdch_image_pool_idle_bytes(void);
+
 #ifdef __cplusplus
 }
 #endif

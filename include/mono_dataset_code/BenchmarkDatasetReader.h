@@ -1,0 +1,72 @@
+// class DatasetReader with the public interface of the reference's reader
+// (src/BenchmarkDatasetReader.h:83-345): same constructor, same getters, same
+// getImage(id, rectify, removeGamma, removeVignette, nanOverexposed) returning a caller-owned
+// ExposureImage*.  playDataset (src/main_playbackDataset.cpp:56-116) and DSO-style front ends
+// compile against it unchanged; what changes is behind the interface:
+//
+//   * getImage is ONE fused GPU pass (mdc_process_host: response LUT x vignette + bilinear remap,
+//     include/mdc_hip.h) from a page-locked decode buffer into a pooled page-locked ExposureImage --
+//     no W*H float intermediate (the reference's internalTempBuffer, :145,:222), no per-frame
+//     `new float[]`;
+//   * frames are decoded by the library's own PNG / PGM / baseline-JPEG decoders, from the images/
+//     folder or straight out of images.zip (own zip reader) -- no OpenCV, no libzip;
+//   * the multi-threaded loader the reference's comment announces (:81) exists: a pool of decode
+//     threads prefetches the frames after the one just asked for, and getImages() runs a whole range
+//     through decode pool -> page-locked ring -> pipelined GPU chunks (mdc_process_frames_host).
+//
+// Results are the reference's, bit for bit (tests/test_reader.py against the reference's own reader).
+// Like the reference's, an object is NOT re-entrant: one thread calls into it at a time.
+#pragma once
+#include <string>
+
+#include "ExposureImage.h"
+#include "FOVUndistorter.h"
+#include "PhotometricUndistorter.h"
+
+class DatasetReader {
+ public:
+  // `folder` with trailing slash, holding camera.txt, pcalib.txt, vignette.png, times.txt and either
+  // images/ or images.zip (reference :86-148).  Prints the reference's log lines.
+  DatasetReader(std::string folder);
+  ~DatasetReader();
+
+  UndistorterFOV* getUndistorter();
+  PhotometricUndistorter* getPhotoUndistorter();
+  int getNumImages();
+  double getTimestamp(int id);  // 0 outside the sequence
+  float getExposure(int id);    // 0 outside the sequence
+
+  // The frame `id`, processed as the four switches say (reference :188-243).  Caller owns the result.
+  // 0 if the frame has the wrong size / cannot be decoded / the GPU pass fails (message on stdout /
+  // stderr); there is no CPU fallback.
+  ExposureImage* getImage(int id, bool rectify, bool removeGamma, bool removeVignette, bool nanOverexposed);
+
+  // ---- beyond the reference's interface ----------------------------------------------------------
+  // Frames first .. first+count-1 in one go: out[i] = what getImage(first+i, ...) returns (0 for a
+  // frame that fails).  Decoding runs on the thread pool while earlier chunks are on the GPU.
+  // Returns the number of images produced.
+  int getImages(int first, int count, bool rectify, bool removeGamma, bool removeVignette, bool nanOverexposed,
+                ExposureImage** out);
+
+  // The decoded 8-bit frame (what cv::imread / cv::imdecode give the reference, :247-276); the
+  // pointer stays valid until the next call on this object.  0 on failure.
+  const unsigned char* getImageRaw(int id, int* width, int* height);
+#ifdef CV_8U  // a translation unit that has OpenCV (or the test shim) also gets the reference's accessor
+  cv::Mat getImageRaw_internal(int id) {
+    int w = 0, h = 0;
+    const unsigned char* p = getImageRaw(id, &w, &h);
+    return p ? cv::Mat(h, w, CV_8U, const_cast<unsigned char*>(p)) : cv::Mat();
+  }
+#endif
+
+  void setDecodeThreads(int n);  // worker threads of the decode pool; 0 = automatic (default)
+  void setPrefetch(int frames);  // frames decoded ahead after a getImage (default 16, 0 = off)
+  const char* lastError() const; // why the last getImage / getImages / getImageRaw returned 0 / fewer images
+  void getPrefetchStats(long* hits, long* misses) const;  // frames found decoded ahead / decoded by the calling thread
+
+ private:
+  DatasetReader(const DatasetReader&);
+  DatasetReader& operator=(const DatasetReader&);
+  struct State;
+  State* s_;
+};

@@ -1,8 +1,20 @@
 // Drop-in for the reference's src/ExposureImage.h:33-51 -- the frame container
 // DatasetReader::getImage returns (src/BenchmarkDatasetReader.h:221).  Field
 // names, order and the constructor signature are the public API that callers
-// (main_playbackDataset.cpp:82,116, DSO-style consumers) rely on.
+// (main_playbackDataset.cpp:82,116, DSO-style consumers) rely on: `new ExposureImage(...)`
+// by the reader, `delete img` by the caller.
+//
+// The pixel block comes from a recycling pool of PAGE-LOCKED host memory (libmdc_host.so,
+// csrc/host/image_pool.cpp) instead of a fresh `new float[w*h]` per frame: the GPU writes results
+// into it at PCIe rate, and a caller that deletes each image after use (as playDataset does) gets
+// the same block back for the next frame -- no page faults, no re-pinning.  Without a GPU the pool
+// hands out ordinary heap memory.
 #pragma once
+
+extern "C" {
+float* mdch_image_alloc(unsigned long nfloats);
+void mdch_image_free(float* block);
+}
 
 class ExposureImage {
  public:
@@ -13,9 +25,9 @@ class ExposureImage {
   int id;               // frame index in the sequence
 
   ExposureImage(int width, int height, double stamp, float exposure, int frame_id)
-      : image(new float[static_cast<unsigned long>(width) * static_cast<unsigned long>(height)]),
+      : image(mdch_image_alloc(static_cast<unsigned long>(width) * static_cast<unsigned long>(height))),
         timestamp(stamp), w(width), h(height), exposure_time(exposure), id(frame_id) {}
-  ~ExposureImage() { delete[] image; }
+  ~ExposureImage() { mdch_image_free(image); }
 
   // the reference type is used through pointers only; copying would double-free
   ExposureImage(const ExposureImage&) = delete;

@@ -24,8 +24,11 @@ LIB_HOST = os.path.join(PKG, "libmdc_host.so")
 HIP_SOURCES = [os.path.join(CSRC, f) for f in ("mdc_kernels.hip", "mdc_capi.hip")]
 HIP_DEPS = HIP_SOURCES + [os.path.join(CSRC, "mdc_internal.h"), os.path.join(INC, "mdc_hip.h")]
 HOST_SOURCES = [os.path.join(HOST, f) for f in (
-    "fov_undistorter.cpp", "photometric_undistorter.cpp", "gray_png.cpp", "host_device.cpp", "mdc_host_capi.cpp")]
+    "fov_undistorter.cpp", "photometric_undistorter.cpp", "gray_png.cpp", "host_device.cpp", "mdc_host_capi.cpp",
+    "image_codecs.cpp", "zip_reader.cpp", "image_pool.cpp", "dataset_reader.cpp")]
 HOST_DEPS = HOST_SOURCES + [os.path.join(HOST, "gray_png.h"), os.path.join(HOST, "host_device.h"),
+                            os.path.join(HOST, "image_codecs.h"), os.path.join(HOST, "zip_reader.h"),
+                            os.path.join(INC, "mono_dataset_code", "BenchmarkDatasetReader.h"),
                             os.path.join(INC, "mdc_hip.h"), os.path.join(INC, "mdc_host.h"),
                             os.path.join(INC, "mono_dataset_code", "FOVUndistorter.h"),
                             os.path.join(INC, "mono_dataset_code", "PhotometricUndistorter.h"),
@@ -79,7 +82,7 @@ def build_host(force=False):
     if force or _stale(LIB_HOST, HOST_DEPS + [LIB_HIP]):
         _run(["g++"] + HOST_FLAGS + ["-I" + INC, "-I" + os.path.join(INC, "mono_dataset_code"), "-I" + HOST,
                                      "-I" + eigen_include()] + HOST_SOURCES +
-             ["-L" + PKG, "-lmdc_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-o", LIB_HOST])
+             ["-L" + PKG, "-lmdc_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-lpthread", "-o", LIB_HOST])
     return LIB_HOST
 
 

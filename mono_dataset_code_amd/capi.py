@@ -17,7 +17,7 @@ LIB_HOST_PATH = os.path.join(_PKG, "libmdc_host.so")
 # flag word (include/mdc_hip.h)
 GAMMA, VIGNETTE, KILL_OVEREXPOSED, RECTIFY = 1, 2, 4, 8
 KERNEL_AUTO, KERNEL_GATHER, KERNEL_TILED = 0, 1, 2
-OPT_KERNEL, OPT_FRAMES_PER_BLOCK, OPT_TILE_ROWS, OPT_TILE_ORDER, OPT_WINDOW_BUFFERS, OPT_FRAME_INTERLEAVE, OPT_TILE_COLS = 1, 2, 5, 6, 7, 8, 9
+OPT_KERNEL, OPT_FRAMES_PER_BLOCK, OPT_TILE_ROWS, OPT_TILE_ORDER, OPT_WINDOW_BUFFERS, OPT_FRAME_INTERLEAVE, OPT_TILE_COLS, OPT_PIN_CALLER_BUFFERS = 1, 2, 5, 6, 7, 8, 9, 10
 ORDER_BANDS, ORDER_ROWS, ORDER_IDENTITY, ORDER_BLOCKS2D = 0, 1, 2, 3
 OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 
@@ -36,6 +36,10 @@ HOST_SYMBOLS = [
     "mdch_fov_intrinsics", "mdch_fov_model", "mdch_fov_remap", "mdch_fov_distort", "mdch_fov_undistort_f32", "mdch_fov_undistort_u8",
     "mdch_photo_create", "mdch_photo_destroy", "mdch_photo_valid", "mdch_photo_has_gpu", "mdch_photo_ginv",
     "mdch_photo_g", "mdch_photo_vignette", "mdch_photo_unmap", "mdch_bind", "mdch_pack_tables",
+    "mdch_reader_create", "mdch_reader_destroy", "mdch_reader_num_images", "mdch_reader_timestamp", "mdch_reader_exposure",
+    "mdch_reader_dims", "mdch_reader_get_image", "mdch_reader_get_images", "mdch_reader_get_raw", "mdch_reader_set_threads",
+    "mdch_reader_set_prefetch", "mdch_reader_last_error", "mdch_reader_prefetch_stats", "mdch_decode_gray8", "mdch_image_alloc", "mdch_image_free",
+    "mdch_image_pool_trim", "mdch_image_pool_idle_bytes",
 ]
 
 
@@ -172,6 +176,35 @@ def host_lib():
         L.mdch_bind.restype = _i
         L.mdch_pack_tables.argtypes = [_vp, _vp, _vp, _sz, C.POINTER(_sz)]
         L.mdch_pack_tables.restype = _i
+        L.mdch_reader_create.argtypes = [C.c_char_p]
+        L.mdch_reader_create.restype = _vp
+        L.mdch_reader_destroy.argtypes = [_vp]
+        L.mdch_reader_destroy.restype = None
+        L.mdch_reader_num_images.argtypes = [_vp]
+        L.mdch_reader_timestamp.argtypes = [_vp, _i]
+        L.mdch_reader_timestamp.restype = C.c_double
+        L.mdch_reader_exposure.argtypes = [_vp, _i]
+        L.mdch_reader_exposure.restype = C.c_float
+        L.mdch_reader_dims.argtypes = [_vp, _vp]
+        L.mdch_reader_dims.restype = None
+        L.mdch_reader_get_image.argtypes = [_vp, _i, _i, _i, _i, _i, _vp, C.c_long, _vp, C.POINTER(C.c_double), C.POINTER(C.c_float)]
+        L.mdch_reader_get_images.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, C.c_long, _vp]
+        L.mdch_reader_get_raw.argtypes = [_vp, _i, _vp, C.c_long, _vp]
+        L.mdch_reader_set_threads.argtypes = [_vp, _i]
+        L.mdch_reader_set_threads.restype = None
+        L.mdch_reader_set_prefetch.argtypes = [_vp, _i]
+        L.mdch_reader_set_prefetch.restype = None
+        L.mdch_reader_last_error.argtypes = [_vp]
+        L.mdch_reader_last_error.restype = C.c_char_p
+        L.mdch_reader_prefetch_stats.argtypes = [_vp, _vp]
+        L.mdch_reader_prefetch_stats.restype = None
+        L.mdch_decode_gray8.argtypes = [_vp, _sz, _vp, _sz, _vp, C.c_char_p, _sz]
+        L.mdch_image_alloc.argtypes = [C.c_ulong]
+        L.mdch_image_alloc.restype = _vp
+        L.mdch_image_free.argtypes = [_vp]
+        L.mdch_image_free.restype = None
+        L.mdch_image_pool_trim.restype = None
+        L.mdch_image_pool_idle_bytes.restype = C.c_ulong
         _host = L
     return _host
 
@@ -447,3 +480,89 @@ class PhotometricUndistorter:
 
     def unmap(self, img_u8, out_f32, g, v, o):
         self._L.mdch_photo_unmap(self._h, _np_ptr(img_u8), _np_ptr(out_f32), img_u8.size, int(g), int(v), int(o))
+
+
+def decode_gray8(data):
+    """The reader's frame decoders (8-bit gray PNG, PGM P5, baseline JPEG) on a byte string -> (h, w) uint8 array;
+    raises ValueError with the decoder's message."""
+    L = host_lib()
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    wh = np.zeros(2, np.int32)
+    err = C.create_string_buffer(256)
+    out = np.zeros(1, np.uint8)
+    if not L.mdch_decode_gray8(_np_ptr(buf), buf.size, _np_ptr(out), 0, _np_ptr(wh), err, 256) and (wh[0] <= 0 or wh[1] <= 0):
+        raise ValueError(err.value.decode())
+    out = np.zeros(int(wh[0]) * int(wh[1]), np.uint8)
+    if not L.mdch_decode_gray8(_np_ptr(buf), buf.size, _np_ptr(out), out.size, _np_ptr(wh), err, 256):
+        raise ValueError(err.value.decode())
+    return out.reshape(int(wh[1]), int(wh[0]))
+
+
+class DatasetReader:
+    """class DatasetReader (include/mono_dataset_code/BenchmarkDatasetReader.h) through the C facade."""
+
+    def __init__(self, folder):
+        if not folder.endswith("/"):
+            folder += "/"
+        self._L = host_lib()
+        self._h = self._L.mdch_reader_create(os.fsencode(folder))
+        d = np.zeros(4, np.int32)
+        self._L.mdch_reader_dims(self._h, _np_ptr(d))
+        self.in_w, self.in_h, self.out_w, self.out_h = (int(x) for x in d)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mdch_reader_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __len__(self):
+        return self._L.mdch_reader_num_images(self._h)
+
+    def timestamp(self, i):
+        return self._L.mdch_reader_timestamp(self._h, i)
+
+    def exposure(self, i):
+        return self._L.mdch_reader_exposure(self._h, i)
+
+    def last_error(self):
+        return self._L.mdch_reader_last_error(self._h).decode()
+
+    def prefetch_stats(self):
+        hm = np.zeros(2, np.int64)
+        self._L.mdch_reader_prefetch_stats(self._h, _np_ptr(hm))
+        return int(hm[0]), int(hm[1])
+
+    def set_threads(self, n):
+        self._L.mdch_reader_set_threads(self._h, n)
+
+    def set_prefetch(self, n):
+        self._L.mdch_reader_set_prefetch(self._h, n)
+
+    def get_image(self, i, rectify, g, v, o):
+        """-> (image (h, w) float32, timestamp, exposure, id) or None (getImage returned 0)."""
+        n = max(self.in_w * self.in_h, self.out_w * self.out_h)
+        out = np.empty(n, np.float32)
+        meta = np.zeros(3, np.int32)
+        ts, ex = C.c_double(0), C.c_float(0)
+        if not self._L.mdch_reader_get_image(self._h, i, int(rectify), int(g), int(v), int(o), _np_ptr(out), n, _np_ptr(meta),
+                                             C.byref(ts), C.byref(ex)):
+            return None
+        w, h = int(meta[0]), int(meta[1])
+        return out[: w * h].reshape(h, w).copy(), ts.value, ex.value, int(meta[2])
+
+    def get_images(self, first, count, rectify, g, v, o):
+        """-> (images (count, h*w) float32, ok mask, number produced)."""
+        n = self.out_w * self.out_h if rectify else self.in_w * self.in_h
+        out = np.zeros((count, n), np.float32)
+        ok = np.zeros(count, np.uint8)
+        got = self._L.mdch_reader_get_images(self._h, first, count, int(rectify), int(g), int(v), int(o), _np_ptr(out), n, _np_ptr(ok))
+        return out, ok.astype(bool), got
+
+    def get_raw(self, i):
+        out = np.empty(self.in_w * self.in_h * 4 + 16, np.uint8)
+        wh = np.zeros(2, np.int32)
+        if not self._L.mdch_reader_get_raw(self._h, i, _np_ptr(out), out.size, _np_ptr(wh)):
+            return None
+        return out[: int(wh[0]) * int(wh[1])].reshape(int(wh[1]), int(wh[0])).copy()

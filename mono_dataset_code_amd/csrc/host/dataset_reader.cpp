@@ -1,0 +1,513 @@
+// class DatasetReader (include/mono_dataset_code/BenchmarkDatasetReader.h): the reference's sequence
+// reader (src/BenchmarkDatasetReader.h:83-345) re-built around the fused GPU pass.
+//
+//   listing / times.txt / log lines : as the reference (:86-148, :282-324)
+//   decode                          : own decoders (image_codecs.cpp), folder or images.zip (zip_reader.cpp),
+//                                     on a pool of worker threads, into page-locked buffers
+//   getImage                        : one mdc_process_host call into a pooled page-locked ExposureImage
+//   getImages                       : decode pool -> two page-locked half-rings -> mdc_process_frames_host
+//                                     per chunk; the pool decodes chunk k+1 while chunk k is on the GPU
+#include "BenchmarkDatasetReader.h"
+
+#include <dirent.h>
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "MdcBind.h"
+#include "host_device.h"
+#include "image_codecs.h"
+#include "mdc_hip.h"
+#include "zip_reader.h"
+
+namespace {
+
+// One decode request: frame `id` into `dst`.  Filled in by whoever decodes it (a pool worker or the
+// calling thread); `done` is published under State::mu.
+struct Decode {
+  int id = -1;
+  unsigned char* dst = 0;
+  size_t cap = 0;
+  int w = 0, h = 0;
+  bool ok = false, done = true, busy = false;  // busy: queued or being decoded
+  bool consumed = true;                        // prefetch cache: already handed to the caller (or never filled)
+  std::string err;
+  unsigned long stamp = 0;  // prefetch cache: age
+};
+
+struct HostBuffer {  // page-locked when a GPU is there, plain otherwise (decode works without a GPU)
+  unsigned char* p = 0;
+  bool pinned = false;
+  void alloc(size_t n) {
+    p = static_cast<unsigned char*>(mdc_host_alloc(n));
+    pinned = p != 0;
+    if (!p) p = static_cast<unsigned char*>(std::malloc(n));
+  }
+  void release() {
+    if (!p) return;
+    if (pinned) mdc_host_free(p);
+    else std::free(p);
+    p = 0;
+  }
+};
+
+unsigned flag_word(bool rectify, bool g, bool v, bool o) {
+  return (rectify ? MDC_RECTIFY : 0u) | (g ? MDC_GAMMA : 0u) | (v ? MDC_VIGNETTE : 0u) | (o ? MDC_KILL_OVEREXPOSED : 0u);
+}
+
+}  // namespace
+
+struct DatasetReader::State {
+  std::string path;
+  bool zipped = false;
+  mdc_host::ZipArchive zip;
+  std::vector<std::string> files;
+  std::vector<int> zip_index;
+  std::vector<double> timestamps;
+  std::vector<float> exposures;
+
+  UndistorterFOV* fov = 0;
+  PhotometricUndistorter* photo = 0;
+  mdc_ctx* gpu = 0;
+  int W = 0, H = 0, w = 0, h = 0;
+  std::string err;
+
+  // decode pool
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  std::deque<Decode*> jobs;
+  bool stop = false;
+  int want_threads = 0;
+
+  // prefetch cache of getImage / getImageRaw
+  int prefetch = 16;
+  std::vector<Decode> slots;
+  std::vector<HostBuffer> slot_mem;
+  int in_use = -1;  // slot whose buffer the caller holds (getImageRaw's promise)
+  unsigned long clock = 0;
+  long cache_hits = 0, cache_misses = 0;  // frames found decoded (or being decoded) ahead / decoded by the caller itself
+
+  // ring of getImages
+  static const int kChunk = 64;  // frames per GPU chunk = decode jobs in flight per half-ring
+  std::vector<HostBuffer> ring;  // 2 * kChunk frames (168 MB at 1280x1024, allocated on the first getImages)
+
+  size_t frame_bytes() const { return (size_t)W * H; }
+
+  // ---- decoding (any thread) ------------------------------------------------------------------
+  void decode_now(Decode& d) const {
+    static thread_local std::vector<unsigned char> bytes;  // per-thread scratch, keeps its capacity between frames
+    d.ok = false;
+    d.w = d.h = 0;
+    if (d.id < 0 || d.id >= (int)files.size()) {
+      d.err = "frame index out of range";
+      return;
+    }
+    if (zipped) {
+      if (!zip.read(zip_index[(size_t)d.id], bytes, &d.err)) return;
+    } else if (!mdc_host::read_file(files[(size_t)d.id], bytes)) {
+      d.err = "cannot read " + files[(size_t)d.id];
+      return;
+    }
+    d.ok = mdc_host::decode_gray8(bytes.data(), bytes.size(), d.dst, d.cap, &d.w, &d.h, &d.err);
+    if (!d.ok) d.err = files[(size_t)d.id] + ": " + d.err;
+  }
+
+  void worker() {
+    for (;;) {
+      Decode* d = 0;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_job.wait(lk, [&] { return stop || !jobs.empty(); });
+        if (stop && jobs.empty()) return;
+        d = jobs.front();
+        jobs.pop_front();
+      }
+      decode_now(*d);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        d->busy = false;
+        d->done = true;
+      }
+      cv_done.notify_all();
+    }
+  }
+
+  int thread_count() const {
+    if (want_threads > 0) return want_threads;
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(hw ? hw : 4u, 64u));
+  }
+  void start_pool() {
+    if (!workers.empty()) return;
+    const int n = thread_count();
+    for (int i = 0; i < n; i++) workers.emplace_back(&State::worker, this);
+  }
+  void stop_pool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_job.notify_all();
+    for (auto& t : workers) t.join();
+    workers.clear();
+    stop = false;
+  }
+  void submit(Decode* d) {  // mu held by the caller
+    d->busy = true;
+    d->done = false;
+    jobs.push_back(d);
+  }
+
+  // ---- prefetch cache ---------------------------------------------------------------------------
+  void ensure_slots() {
+    const size_t want = (size_t)std::max(prefetch, 0) + 2;
+    if (slots.size() == want) return;
+    drain();
+    for (auto& m : slot_mem) m.release();
+    slots.assign(want, Decode());
+    slot_mem.assign(want, HostBuffer());
+    for (size_t i = 0; i < want; i++) {
+      slot_mem[i].alloc(frame_bytes());
+      slots[i].dst = slot_mem[i].p;
+      slots[i].cap = frame_bytes();
+    }
+    in_use = -1;
+  }
+  void drain() {  // wait for every queued decode
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] {
+      for (auto& s : slots)
+        if (s.busy) return false;
+      return jobs.empty();
+    });
+  }
+  // mu held: a slot that is neither being decoded nor lent to the caller and holds nothing of value -- empty, or a
+  // frame the caller has already had (oldest first).  Frames decoded ahead and not yet asked for are never
+  // evicted for another prefetch (force: the caller itself needs a slot -- then the one farthest ahead goes).
+  int free_slot(bool force = false) {
+    int best = -1;
+    for (size_t i = 0; i < slots.size(); i++) {
+      if (slots[i].busy || (int)i == in_use) continue;
+      if (slots[i].id < 0) return (int)i;
+      if (!slots[i].consumed) continue;
+      if (best < 0 || slots[i].stamp < slots[(size_t)best].stamp) best = (int)i;
+    }
+    if (best < 0 && force)
+      for (size_t i = 0; i < slots.size(); i++)
+        if (!slots[i].busy && (int)i != in_use && (best < 0 || slots[i].id > slots[(size_t)best].id)) best = (int)i;
+    return best;
+  }
+  // The decoded frame `id` (from the cache, or decoded here), then the next frames are queued.
+  Decode* fetch(int id) {
+    ensure_slots();
+    int k = -1;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      for (size_t i = 0; i < slots.size(); i++)
+        if (slots[i].id == id) k = (int)i;
+      if (k >= 0) {
+        cache_hits++;
+        cv_done.wait(lk, [&] { return slots[(size_t)k].done; });
+      } else {
+        cache_misses++;
+        in_use = -1;
+        k = free_slot(true);
+        if (k < 0) {  // every other slot is being decoded into: wait for one
+          cv_done.wait(lk, [&] { return (k = free_slot(true)) >= 0; });
+        }
+        slots[(size_t)k].id = id;
+        slots[(size_t)k].done = false;
+      }
+      in_use = k;
+      slots[(size_t)k].consumed = true;
+      slots[(size_t)k].stamp = ++clock;
+    }
+    Decode& d = slots[(size_t)k];
+    if (!d.done) {  // not in the cache: decode in this thread
+      decode_now(d);
+      std::lock_guard<std::mutex> lk(mu);
+      d.done = true;
+    }
+    if (prefetch > 0 && (int)files.size() > 1) {
+      start_pool();
+      std::lock_guard<std::mutex> lk(mu);
+      for (int a = 1; a <= prefetch && id + a < (int)files.size(); a++) {
+        bool have = false;
+        for (auto& s : slots)
+          if (s.id == id + a) have = true;
+        if (have) continue;
+        const int f = free_slot();
+        if (f < 0) break;
+        slots[(size_t)f].id = id + a;
+        slots[(size_t)f].consumed = false;
+        slots[(size_t)f].stamp = ++clock;
+        submit(&slots[(size_t)f]);
+      }
+      cv_job.notify_all();
+    }
+    return &d;
+  }
+};
+
+namespace {
+
+// name-sorted directory listing, full paths (reference getdir, :44-72)
+void list_folder(const std::string& dir, std::vector<std::string>& files) {
+  DIR* dp = opendir(dir.c_str());
+  if (!dp) return;
+  while (struct dirent* e = readdir(dp)) {
+    const std::string name = e->d_name;
+    if (name != "." && name != "..") files.push_back(name);
+  }
+  closedir(dp);
+  std::sort(files.begin(), files.end());
+  for (auto& f : files) f = dir + f;
+}
+
+}  // namespace
+
+DatasetReader::DatasetReader(std::string folder) : s_(new State()) {
+  State& s = *s_;
+  s.path = folder;
+  list_folder(s.path + "images/", s.files);
+  if (!s.files.empty()) {
+    std::printf("Load Dataset %s: found %d files in folder /images; assuming that all images are there.\n", s.path.c_str(),
+                (int)s.files.size());
+  } else {
+    std::printf("Load Dataset %s: found no in folder /images; assuming that images are zipped.\n", s.path.c_str());
+    s.zipped = true;
+    std::string zerr;
+    if (!s.zip.open(s.path + "images.zip", &zerr)) {
+      std::printf("ERROR %d reading archive %s!\n", 1, (s.path + "images.zip").c_str());
+      std::fprintf(stderr, "DatasetReader: %s\n", zerr.c_str());
+      std::exit(1);  // as the reference (:111-115): callers rely on never seeing a reader without frames
+    }
+    std::vector<std::pair<std::string, int>> named;
+    for (int k = 0; k < s.zip.entries(); k++) {
+      const std::string& n = s.zip.name(k);
+      if (n == "." || n == "..") continue;
+      named.push_back(std::make_pair(n, k));
+    }
+    std::printf("got %d entries and %d files from zipfile!\n", s.zip.entries(), (int)named.size());
+    std::sort(named.begin(), named.end());
+    for (auto& nk : named) {
+      s.files.push_back(nk.first);
+      s.zip_index.push_back(nk.second);
+    }
+  }
+
+  // times.txt: "id stamp exposure" or "id stamp" per line (:282-324)
+  {
+    std::ifstream tr((s.path + "times.txt").c_str());
+    std::string line;
+    while (tr.good() && std::getline(tr, line)) {
+      int id;
+      double stamp;
+      float exposure = 0;
+      if (3 == std::sscanf(line.c_str(), "%d %lf %f", &id, &stamp, &exposure)) {
+        s.timestamps.push_back(stamp);
+        s.exposures.push_back(exposure);
+      } else if (2 == std::sscanf(line.c_str(), "%d %lf", &id, &stamp)) {
+        s.timestamps.push_back(stamp);
+        s.exposures.push_back(0);
+      }
+    }
+    if (s.exposures.size() != s.files.size()) {
+      std::printf("DatasetReader: Mismatch between number of images and number of timestamps / exposure times. Set all to zero.");
+      s.timestamps.assign(s.files.size(), 0.0);
+      s.exposures.assign(s.files.size(), 0.f);
+    }
+  }
+
+  s.fov = new UndistorterFOV((s.path + "camera.txt").c_str());
+  s.photo = new PhotometricUndistorter(s.path + "pcalib.txt", s.path + "vignette.png", s.fov->getInputDims()[0], s.fov->getInputDims()[1]);
+  s.W = s.fov->getInputDims()[0];
+  s.H = s.fov->getInputDims()[1];
+  s.w = s.fov->getOutputDims()[0];
+  s.h = s.fov->getOutputDims()[1];
+
+  // one context holding BOTH objects' tables: the fused pass needs them together
+  s.gpu = mdc_host::open_device_context("DatasetReader");
+  if (s.gpu && mdc_bind_objects(s.gpu, s.fov, s.photo) != MDC_OK) {
+    std::fprintf(stderr, "DatasetReader: table upload failed: %s\n", mdc_last_error(s.gpu));
+    mdc_destroy(s.gpu);
+    s.gpu = 0;
+  }
+  std::printf("Dataset %s: Got %d files!\n", s.path.c_str(), getNumImages());
+}
+
+DatasetReader::~DatasetReader() {
+  State& s = *s_;
+  s.stop_pool();
+  for (auto& m : s.slot_mem) m.release();
+  for (auto& m : s.ring) m.release();
+  if (s.gpu) mdc_destroy(s.gpu);
+  delete s.fov;
+  delete s.photo;
+  delete s_;
+}
+
+UndistorterFOV* DatasetReader::getUndistorter() { return s_->fov; }
+PhotometricUndistorter* DatasetReader::getPhotoUndistorter() { return s_->photo; }
+int DatasetReader::getNumImages() { return (int)s_->files.size(); }
+double DatasetReader::getTimestamp(int id) { return (id < 0 || id >= (int)s_->timestamps.size()) ? 0 : s_->timestamps[(size_t)id]; }
+float DatasetReader::getExposure(int id) { return (id < 0 || id >= (int)s_->exposures.size()) ? 0 : s_->exposures[(size_t)id]; }
+const char* DatasetReader::lastError() const { return s_->err.c_str(); }
+void DatasetReader::getPrefetchStats(long* hits, long* misses) const {
+  if (hits) *hits = s_->cache_hits;
+  if (misses) *misses = s_->cache_misses;
+}
+
+void DatasetReader::setDecodeThreads(int n) {
+  State& s = *s_;
+  if (n < 0) n = 0;
+  if (n == s.want_threads) return;
+  if (!s.slots.empty()) s.drain();
+  s.stop_pool();
+  s.want_threads = n;
+}
+
+void DatasetReader::setPrefetch(int frames) {
+  State& s = *s_;
+  s.prefetch = std::max(0, std::min(frames, 64));
+}
+
+const unsigned char* DatasetReader::getImageRaw(int id, int* width, int* height) {
+  State& s = *s_;
+  s.err.clear();
+  if (id < 0 || id >= (int)s.files.size()) {
+    s.err = "frame index out of range";
+    return 0;
+  }
+  Decode* d = s.fetch(id);
+  if (width) *width = d->w;
+  if (height) *height = d->h;
+  if (!d->ok) {
+    s.err = d->err;
+    return 0;
+  }
+  return d->dst;
+}
+
+ExposureImage* DatasetReader::getImage(int id, bool rectify, bool removeGamma, bool removeVignette, bool nanOverexposed) {
+  State& s = *s_;
+  int fw = 0, fh = 0;
+  const unsigned char* raw = getImageRaw(id, &fw, &fh);
+  if (id < 0 || id >= (int)s.files.size()) return 0;
+  if (fh != s.H || fw != s.W) {  // also what an undecodable file leads to in the reference: an empty cv::Mat (:194-199)
+    std::printf("ERROR: expected cv-mat to have dimensions %d x %d; found %d x %d (image %s)!\n", s.W, s.H, fw, fh,
+                s.files[(size_t)id].c_str());
+    if (!raw && !s.err.empty()) std::fprintf(stderr, "DatasetReader: %s\n", s.err.c_str());
+    return 0;
+  }
+  if (!raw) {
+    std::fprintf(stderr, "DatasetReader: %s\n", s.err.c_str());
+    return 0;
+  }
+  if (!s.gpu) {
+    s.err = "no GPU context: the per-frame pass has no CPU fallback";
+    std::fprintf(stderr, "DatasetReader::getImage: %s\n", s.err.c_str());
+    return 0;
+  }
+  ExposureImage* ret = rectify ? new ExposureImage(s.w, s.h, s.timestamps[(size_t)id], s.exposures[(size_t)id], id)
+                               : new ExposureImage(s.W, s.H, s.timestamps[(size_t)id], s.exposures[(size_t)id], id);
+  // the four switches are the library's flag word; every combination -- also "none" (plain cast, :234-240)
+  // and "rectify only" (undistort<unsigned char>, :228-233) -- is one pass of the same kernel family
+  if (mdc_process_host(s.gpu, raw, ret->image, flag_word(rectify, removeGamma, removeVignette, nanOverexposed)) != MDC_OK) {
+    s.err = mdc_last_error(s.gpu);
+    std::fprintf(stderr, "DatasetReader::getImage: %s\n", s.err.c_str());
+    delete ret;
+    return 0;
+  }
+  return ret;
+}
+
+int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamma, bool removeVignette, bool nanOverexposed,
+                             ExposureImage** out) {
+  State& s = *s_;
+  s.err.clear();
+  if (!out || count <= 0) return 0;
+  for (int i = 0; i < count; i++) out[i] = 0;
+  if (first < 0 || first + count > (int)s.files.size()) {
+    s.err = "frame range outside the sequence";
+    return 0;
+  }
+  if (!s.gpu) {
+    s.err = "no GPU context: the per-frame pass has no CPU fallback";
+    std::fprintf(stderr, "DatasetReader::getImages: %s\n", s.err.c_str());
+    return 0;
+  }
+  const int C = State::kChunk;
+  if (s.ring.empty()) {
+    s.ring.assign(2 * (size_t)C, HostBuffer());
+    for (auto& m : s.ring) m.alloc(s.frame_bytes());
+  }
+  s.start_pool();
+  std::vector<Decode> rec((size_t)count);
+  const int nchunks = (count + C - 1) / C;
+  auto submit_chunk = [&](int k) {
+    std::lock_guard<std::mutex> lk(s.mu);
+    for (int i = k * C; i < std::min(count, (k + 1) * C); i++) {
+      Decode& d = rec[(size_t)i];
+      d.id = first + i;
+      d.dst = s.ring[(size_t)((k & 1) * C + (i - k * C))].p;
+      d.cap = s.frame_bytes();
+      s.submit(&d);
+    }
+    s.cv_job.notify_all();
+  };
+  submit_chunk(0);
+  if (nchunks > 1) submit_chunk(1);
+  const unsigned flags = flag_word(rectify, removeGamma, removeVignette, nanOverexposed);
+  int produced = 0;
+  std::vector<const uint8_t*> src;
+  std::vector<float*> dst;
+  for (int k = 0; k < nchunks; k++) {
+    const int i0 = k * C, i1 = std::min(count, (k + 1) * C);
+    {
+      std::unique_lock<std::mutex> lk(s.mu);
+      s.cv_done.wait(lk, [&] {
+        for (int i = i0; i < i1; i++)
+          if (!rec[(size_t)i].done) return false;
+        return true;
+      });
+    }
+    src.clear();
+    dst.clear();
+    for (int i = i0; i < i1; i++) {
+      const Decode& d = rec[(size_t)i];
+      const int id = first + i;
+      if (!d.ok || d.w != s.W || d.h != s.H) {
+        std::printf("ERROR: expected cv-mat to have dimensions %d x %d; found %d x %d (image %s)!\n", s.W, s.H, d.w, d.h,
+                    s.files[(size_t)id].c_str());
+        if (!d.ok) s.err = d.err;
+        continue;
+      }
+      out[i] = rectify ? new ExposureImage(s.w, s.h, s.timestamps[(size_t)id], s.exposures[(size_t)id], id)
+                       : new ExposureImage(s.W, s.H, s.timestamps[(size_t)id], s.exposures[(size_t)id], id);
+      src.push_back(d.dst);
+      dst.push_back(out[i]->image);
+    }
+    // chunk k on the GPU (uploads, kernels and downloads pipelined inside the call) while the pool decodes chunk k+1
+    if (!src.empty() && mdc_process_frames_host(s.gpu, src.data(), dst.data(), (int64_t)src.size(), flags) != MDC_OK) {
+      s.err = mdc_last_error(s.gpu);
+      std::fprintf(stderr, "DatasetReader::getImages: %s\n", s.err.c_str());
+      for (int i = i0; i < i1; i++) {
+        delete out[i];
+        out[i] = 0;
+      }
+    } else {
+      produced += (int)src.size();
+    }
+    if (k + 2 < nchunks) submit_chunk(k + 2);  // its half of the ring is free again
+  }
+  return produced;
+}

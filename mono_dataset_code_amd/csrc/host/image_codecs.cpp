@@ -1,0 +1,493 @@
+#include "image_codecs.h"
+
+#include <zlib.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace mdc_host {
+
+bool read_file(const std::string& path, std::vector<unsigned char>& buf) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  if (n < 0) {
+    fclose(f);
+    return false;
+  }
+  buf.resize((size_t)n);
+  const bool ok = n == 0 || fread(buf.data(), 1, (size_t)n, f) == (size_t)n;
+  fclose(f);
+  return ok;
+}
+
+namespace {
+
+bool fail(std::string* err, const char* msg) {
+  if (err) *err = msg;
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PNG: 8-bit grayscale, non-interlaced (what the dataset's lossless frames are)
+// ---------------------------------------------------------------------------------------------
+unsigned be32(const unsigned char* p) { return (unsigned)p[0] << 24 | (unsigned)p[1] << 16 | (unsigned)p[2] << 8 | p[3]; }
+
+int paeth(int a, int b, int c) {
+  const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+  return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+bool png_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap, int* w, int* h, std::string* err) {
+  size_t pos = 8;
+  unsigned W = 0, H = 0;
+  int depth = 0, ctype = -1, interlace = 0;
+  // scratch that survives between frames of one thread: fresh multi-megabyte vectors per frame mean an mmap, page
+  // faults and an munmap each, and the kernel's address-space lock then serialises the decode threads
+  static thread_local std::vector<unsigned char> idat, raw;
+  idat.clear();
+  while (pos + 12 <= n) {
+    const unsigned len = be32(d + pos);
+    const unsigned char* tag = d + pos + 4;
+    if (pos + 12 + (size_t)len > n) return fail(err, "PNG: truncated chunk");
+    const unsigned char* body = d + pos + 8;
+    if (!memcmp(tag, "IHDR", 4) && len >= 13) {
+      W = be32(body);
+      H = be32(body + 4);
+      depth = body[8];
+      ctype = body[9];
+      interlace = body[12];
+    } else if (!memcmp(tag, "IDAT", 4)) {
+      idat.insert(idat.end(), body, body + len);
+    } else if (!memcmp(tag, "IEND", 4)) {
+      break;
+    }
+    pos += 12 + (size_t)len;
+  }
+  if (W == 0 || H == 0 || W > 65535 || H > 65535) return fail(err, "PNG: no IHDR");
+  *w = (int)W;
+  *h = (int)H;
+  if (ctype != 0 || depth != 8 || interlace != 0) return fail(err, "PNG: only 8-bit grayscale, non-interlaced frames are supported");
+  if ((size_t)W * H > cap) return fail(err, "frame larger than the buffer");
+  const size_t stride = W;
+  raw.resize((stride + 1) * H);
+  uLongf got = (uLongf)raw.size();
+  if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw.size()) return fail(err, "PNG: bad IDAT stream");
+  const unsigned char* prev = nullptr;
+  for (unsigned y = 0; y < H; y++) {
+    const unsigned char* line = &raw[(stride + 1) * y];
+    unsigned char* cur = out + (size_t)y * W;
+    const int ft = line[0];
+    for (size_t i = 0; i < stride; i++) {
+      const int a = i ? cur[i - 1] : 0, b = prev ? prev[i] : 0, c = (i && prev) ? prev[i - 1] : 0, x = line[1 + i];
+      int v;
+      switch (ft) {
+        case 0: v = x; break;
+        case 1: v = x + a; break;
+        case 2: v = x + b; break;
+        case 3: v = x + ((a + b) >> 1); break;
+        case 4: v = x + paeth(a, b, c); break;
+        default: return fail(err, "PNG: bad filter type");
+      }
+      cur[i] = (unsigned char)v;
+    }
+    prev = cur;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PGM (P5, maxval <= 255)
+// ---------------------------------------------------------------------------------------------
+bool pgm_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap, int* w, int* h, std::string* err) {
+  // header: "P5" ws width ws height ws maxval single-ws, '#' comments allowed between tokens
+  size_t p = 2;
+  int vals[3] = {0, 0, 0};
+  for (int k = 0; k < 3; k++) {
+    for (;;) {
+      while (p < n && (d[p] == ' ' || d[p] == '\t' || d[p] == '\r' || d[p] == '\n')) p++;
+      if (p < n && d[p] == '#') {
+        while (p < n && d[p] != '\n') p++;
+        continue;
+      }
+      break;
+    }
+    if (p >= n || d[p] < '0' || d[p] > '9') return fail(err, "PGM: bad header");
+    long v = 0;
+    while (p < n && d[p] >= '0' && d[p] <= '9' && v < 100000000) v = v * 10 + (d[p++] - '0');
+    vals[k] = (int)v;
+  }
+  p++;  // the single whitespace byte after maxval
+  if (vals[0] <= 0 || vals[1] <= 0) return fail(err, "PGM: bad size");
+  *w = vals[0];
+  *h = vals[1];
+  if (vals[2] > 255 || vals[2] <= 0) return fail(err, "PGM: only maxval <= 255 is supported");
+  const size_t px = (size_t)vals[0] * vals[1];
+  if (px > cap) return fail(err, "frame larger than the buffer");
+  if (p + px > n) return fail(err, "PGM: truncated");
+  memcpy(out, d + p, px);
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Baseline JPEG
+// ---------------------------------------------------------------------------------------------
+const unsigned char kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                   41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                   30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct Huff {
+  bool present = false;
+  unsigned char vals[256];
+  uint16_t look[512];  // codes of <= 9 bits: (length << 8) | symbol, 0 = longer code
+  int maxcode[18];     // largest code of length l (or -1), maxcode[17] = sentinel
+  int valoff[17];      // vals index of the first code of length l minus that code
+};
+
+bool build_huff(Huff& t, const unsigned char* bits /*[1..16] at bits[0..15]*/, const unsigned char* vals, int nvals) {
+  memset(t.look, 0, sizeof t.look);
+  memcpy(t.vals, vals, (size_t)nvals);
+  int code = 0, k = 0;
+  for (int l = 1; l <= 16; l++) {
+    t.valoff[l] = k - code;
+    const int cnt = bits[l - 1];
+    if (k + cnt > 256 || code + cnt > (1 << l)) return false;
+    for (int i = 0; i < cnt; i++, k++, code++)
+      if (l <= 9) {
+        const int first = code << (9 - l);
+        for (int f = 0; f < (1 << (9 - l)); f++) t.look[first + f] = (uint16_t)(l << 8 | vals[k]);
+      }
+    t.maxcode[l] = cnt ? code - 1 : -1;
+    code <<= 1;
+  }
+  t.maxcode[17] = 0x7fffffff;
+  t.present = k == nvals;
+  return t.present;
+}
+
+struct Bits {  // entropy-coded segment reader: FF00 unstuffing, stops (feeding zeros) at a marker
+  const unsigned char* p;
+  const unsigned char* end;
+  uint64_t acc = 0;
+  int cnt = 0;
+  bool hit_marker = false;
+  void fill() {
+    while (cnt <= 56) {
+      unsigned b = 0;
+      if (!hit_marker && p < end) {
+        b = *p;
+        if (b == 0xff) {
+          if (p + 1 < end && p[1] == 0) p += 2;
+          else {
+            hit_marker = true;
+            b = 0;
+          }
+        } else p++;
+      }
+      acc |= (uint64_t)b << (56 - cnt);
+      cnt += 8;
+    }
+  }
+  int peek(int n) { return (int)(acc >> (64 - n)); }
+  void skip(int n) {
+    acc <<= n;
+    cnt -= n;
+  }
+  int get(int n) {
+    if (n == 0) return 0;
+    if (cnt < n) fill();
+    const int v = peek(n);
+    skip(n);
+    return v;
+  }
+  void reset_at(const unsigned char* q) {
+    p = q;
+    acc = 0;
+    cnt = 0;
+    hit_marker = false;
+  }
+};
+
+inline int decode_sym(Bits& b, const Huff& t) {
+  if (b.cnt < 16) b.fill();
+  const int e = t.look[b.peek(9)];
+  if (e) {
+    b.skip(e >> 8);
+    return e & 255;
+  }
+  int code = b.peek(10), l = 10;
+  while (code > t.maxcode[l]) {
+    if (++l > 16) return -1;
+    code = b.peek(l);
+  }
+  b.skip(l);
+  const int idx = code + t.valoff[l];
+  return (idx >= 0 && idx < 256) ? t.vals[idx] : -1;
+}
+
+inline int extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
+
+// libjpeg's jidctint.c ("islow"), 8x8: the accurate integer inverse DCT every libjpeg / libjpeg-turbo
+// build uses by default -- same constants, same two passes, same rounding, so the samples agree bit for bit.
+inline int descale(long x, int n) { return (int)((x + (1L << (n - 1))) >> n); }
+inline unsigned char clamp_sample(int x) {
+  x += 128;
+  return (unsigned char)(x < 0 ? 0 : (x > 255 ? 255 : x));
+}
+void idct_islow(const int* coef /* dequantised, natural order */, unsigned char* out, size_t stride) {
+  const long F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299,
+             F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
+  const int CB = 13, P1 = 2;
+  int ws[64];
+  for (int c = 0; c < 8; c++) {
+    const int* in = coef + c;
+    if (!(in[8] | in[16] | in[24] | in[32] | in[40] | in[48] | in[56])) {
+      const int dc = in[0] * (1 << P1);
+      for (int r = 0; r < 8; r++) ws[r * 8 + c] = dc;
+      continue;
+    }
+    long z2 = in[16], z3 = in[48];
+    long z1 = (z2 + z3) * F0_541;
+    long tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
+    z2 = in[0];
+    z3 = in[32];
+    long tmp0 = (z2 + z3) * (1L << CB), tmp1 = (z2 - z3) * (1L << CB);
+    const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = in[56];
+    tmp1 = in[40];
+    tmp2 = in[24];
+    tmp3 = in[8];
+    z1 = tmp0 + tmp3;
+    z2 = tmp1 + tmp2;
+    z3 = tmp0 + tmp2;
+    long z4 = tmp1 + tmp3;
+    const long z5 = (z3 + z4) * F1_175;
+    tmp0 *= F0_298;
+    tmp1 *= F2_053;
+    tmp2 *= F3_072;
+    tmp3 *= F1_501;
+    z1 *= -F0_899;
+    z2 *= -F2_562;
+    z3 *= -F1_961;
+    z4 *= -F0_390;
+    z3 += z5;
+    z4 += z5;
+    tmp0 += z1 + z3;
+    tmp1 += z2 + z4;
+    tmp2 += z2 + z3;
+    tmp3 += z1 + z4;
+    ws[0 * 8 + c] = descale(tmp10 + tmp3, CB - P1);
+    ws[7 * 8 + c] = descale(tmp10 - tmp3, CB - P1);
+    ws[1 * 8 + c] = descale(tmp11 + tmp2, CB - P1);
+    ws[6 * 8 + c] = descale(tmp11 - tmp2, CB - P1);
+    ws[2 * 8 + c] = descale(tmp12 + tmp1, CB - P1);
+    ws[5 * 8 + c] = descale(tmp12 - tmp1, CB - P1);
+    ws[3 * 8 + c] = descale(tmp13 + tmp0, CB - P1);
+    ws[4 * 8 + c] = descale(tmp13 - tmp0, CB - P1);
+  }
+  for (int r = 0; r < 8; r++) {
+    const int* w = ws + r * 8;
+    unsigned char* o = out + (size_t)r * stride;
+    long z2 = w[2], z3 = w[6];
+    long z1 = (z2 + z3) * F0_541;
+    long tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
+    long tmp0 = ((long)w[0] + w[4]) * (1L << CB), tmp1 = ((long)w[0] - w[4]) * (1L << CB);
+    const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = w[7];
+    tmp1 = w[5];
+    tmp2 = w[3];
+    tmp3 = w[1];
+    z1 = tmp0 + tmp3;
+    z2 = tmp1 + tmp2;
+    z3 = tmp0 + tmp2;
+    long z4 = tmp1 + tmp3;
+    const long z5 = (z3 + z4) * F1_175;
+    tmp0 *= F0_298;
+    tmp1 *= F2_053;
+    tmp2 *= F3_072;
+    tmp3 *= F1_501;
+    z1 *= -F0_899;
+    z2 *= -F2_562;
+    z3 *= -F1_961;
+    z4 *= -F0_390;
+    z3 += z5;
+    z4 += z5;
+    tmp0 += z1 + z3;
+    tmp1 += z2 + z4;
+    tmp2 += z2 + z3;
+    tmp3 += z1 + z4;
+    const int S = CB + P1 + 3;
+    o[0] = clamp_sample(descale(tmp10 + tmp3, S));
+    o[7] = clamp_sample(descale(tmp10 - tmp3, S));
+    o[1] = clamp_sample(descale(tmp11 + tmp2, S));
+    o[6] = clamp_sample(descale(tmp11 - tmp2, S));
+    o[2] = clamp_sample(descale(tmp12 + tmp1, S));
+    o[5] = clamp_sample(descale(tmp12 - tmp1, S));
+    o[3] = clamp_sample(descale(tmp13 + tmp0, S));
+    o[4] = clamp_sample(descale(tmp13 - tmp0, S));
+  }
+}
+
+struct Comp {
+  int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0;
+};
+
+bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap, int* w, int* h, std::string* err) {
+  uint16_t qt[4][64];
+  bool have_qt[4] = {false, false, false, false};
+  Huff dc[4], ac[4];
+  Comp comp[4];
+  int ncomp = 0, W = 0, H = 0, restart = 0;
+  size_t p = 2;
+  bool have_sof = false;
+  while (p + 4 <= n) {
+    if (d[p] != 0xff) return fail(err, "JPEG: marker expected");
+    while (p < n && d[p] == 0xff) p++;  // fill bytes
+    if (p >= n) break;
+    const int m = d[p++];
+    if (m == 0xd8 || (m >= 0xd0 && m <= 0xd7) || m == 0x01) continue;
+    if (m == 0xd9) break;
+    if (p + 2 > n) return fail(err, "JPEG: truncated");
+    const size_t len = (size_t)d[p] << 8 | d[p + 1];
+    if (len < 2 || p + len > n) return fail(err, "JPEG: bad segment length");
+    const unsigned char* s = d + p + 2;
+    const size_t sl = len - 2;
+    if (m == 0xdb) {  // DQT
+      size_t q = 0;
+      while (q < sl) {
+        const int pq = s[q] >> 4, tq = s[q] & 15;
+        q++;
+        if (tq > 3 || q + (pq ? 128 : 64) > sl) return fail(err, "JPEG: bad DQT");
+        for (int i = 0; i < 64; i++, q += pq ? 2 : 1) qt[tq][kZigzag[i]] = pq ? (uint16_t)(s[q] << 8 | s[q + 1]) : s[q];
+        have_qt[tq] = true;
+      }
+    } else if (m == 0xc4) {  // DHT
+      size_t q = 0;
+      while (q + 17 <= sl) {
+        const int tc = s[q] >> 4, th = s[q] & 15;
+        int cnt = 0;
+        for (int i = 0; i < 16; i++) cnt += s[q + 1 + i];
+        if (th > 3 || tc > 1 || cnt > 256 || q + 17 + (size_t)cnt > sl) return fail(err, "JPEG: bad DHT");
+        if (!build_huff(tc ? ac[th] : dc[th], s + q + 1, s + q + 17, cnt)) return fail(err, "JPEG: bad Huffman table");
+        q += 17 + (size_t)cnt;
+      }
+    } else if (m == 0xc0 || m == 0xc1) {  // SOF0 / SOF1: sequential, Huffman
+      if (sl < 6 || s[0] != 8) return fail(err, "JPEG: only 8-bit samples are supported");
+      H = s[1] << 8 | s[2];
+      W = s[3] << 8 | s[4];
+      ncomp = s[5];
+      if ((ncomp != 1 && ncomp != 3) || sl < 6 + 3 * (size_t)ncomp || W <= 0 || H <= 0) return fail(err, "JPEG: unsupported frame header");
+      for (int i = 0; i < ncomp; i++) {
+        comp[i].id = s[6 + 3 * i];
+        comp[i].h = s[7 + 3 * i] >> 4;
+        comp[i].v = s[7 + 3 * i] & 15;
+        comp[i].tq = s[8 + 3 * i] & 3;
+        if (comp[i].h < 1 || comp[i].h > 4 || comp[i].v < 1 || comp[i].v > 4) return fail(err, "JPEG: bad sampling factors");
+      }
+      have_sof = true;
+      *w = W;
+      *h = H;
+    } else if (m == 0xc2 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
+      return fail(err, "JPEG: only baseline (sequential Huffman) files are supported");
+    } else if (m == 0xdd) {  // DRI
+      if (sl >= 2) restart = s[0] << 8 | s[1];
+    } else if (m == 0xda) {  // SOS: the one scan of a baseline file
+      if (!have_sof) return fail(err, "JPEG: scan before frame header");
+      if ((size_t)W * H > cap) return fail(err, "frame larger than the buffer");
+      const int ns = s[0];
+      if (ns != ncomp || sl < 1 + 2 * (size_t)ns + 3) return fail(err, "JPEG: only single-scan files are supported");
+      for (int i = 0; i < ns; i++) {
+        int k = -1;
+        for (int c = 0; c < ncomp; c++)
+          if (comp[c].id == s[1 + 2 * i]) k = c;
+        if (k != i) return fail(err, "JPEG: unexpected component order");
+        comp[k].td = s[2 + 2 * i] >> 4;
+        comp[k].ta = s[2 + 2 * i] & 15;
+        if (comp[k].td > 3 || comp[k].ta > 3 || !dc[comp[k].td].present || !ac[comp[k].ta].present || !have_qt[comp[k].tq])
+          return fail(err, "JPEG: scan refers to a missing table");
+        comp[k].pred = 0;
+      }
+      // geometry: a single-component scan is non-interleaved (one block per MCU)
+      const int hmax = ncomp == 1 ? 1 : std::max(comp[0].h, std::max(comp[1].h, comp[2].h));
+      const int vmax = ncomp == 1 ? 1 : std::max(comp[0].v, std::max(comp[1].v, comp[2].v));
+      const int yh = ncomp == 1 ? 1 : comp[0].h, yv = ncomp == 1 ? 1 : comp[0].v;
+      if (ncomp == 3 && (yh != hmax || yv != vmax)) return fail(err, "JPEG: luma is subsampled; unsupported");
+      const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
+      const int mx = (W + mcu_w - 1) / mcu_w, my = (H + mcu_h - 1) / mcu_h;
+      const size_t pw = (size_t)mx * mcu_w;  // padded luma row (luma has the full resolution)
+      static thread_local std::vector<unsigned char> rows;
+      rows.resize(pw * mcu_h);
+      Bits b;
+      b.p = d + p + len;
+      b.end = d + n;
+      int coef[64];
+      int to_restart = restart;
+      for (int y = 0; y < my; y++) {
+        for (int x = 0; x < mx; x++) {
+          if (restart && to_restart == 0) {  // RSTn: byte-align, skip the marker, reset predictions
+            const unsigned char* q = b.p;
+            while (q + 1 < b.end && !(q[0] == 0xff && q[1] >= 0xd0 && q[1] <= 0xd7)) q++;
+            if (q + 1 >= b.end) return fail(err, "JPEG: missing restart marker");
+            b.reset_at(q + 2);
+            for (int c = 0; c < ncomp; c++) comp[c].pred = 0;
+            to_restart = restart;
+          }
+          for (int c = 0; c < ncomp; c++) {
+            const int nb = ncomp == 1 ? 1 : comp[c].h * comp[c].v;
+            for (int k = 0; k < nb; k++) {
+              const bool luma = c == 0;
+              if (luma) memset(coef, 0, sizeof coef);
+              const uint16_t* q = qt[comp[c].tq];
+              int t = decode_sym(b, dc[comp[c].td]);
+              if (t < 0 || t > 11) return fail(err, "JPEG: bad DC code");
+              comp[c].pred += t ? extend(b.get(t), t) : 0;
+              if (luma) coef[0] = comp[c].pred * q[0];
+              for (int i = 1; i < 64;) {
+                const int rs = decode_sym(b, ac[comp[c].ta]);
+                if (rs < 0) return fail(err, "JPEG: bad AC code");
+                const int r = rs >> 4, sz = rs & 15;
+                if (sz == 0) {
+                  if (r != 15) break;  // EOB
+                  i += 16;
+                  continue;
+                }
+                i += r;
+                if (i > 63) return fail(err, "JPEG: coefficient index out of range");
+                const int v = extend(b.get(sz), sz);
+                if (luma) coef[kZigzag[i]] = v * q[kZigzag[i]];
+                i++;
+              }
+              if (luma) {
+                const int bx = ncomp == 1 ? 0 : k % comp[c].h, by = ncomp == 1 ? 0 : k / comp[c].h;
+                idct_islow(coef, rows.data() + (size_t)by * 8 * pw + (size_t)x * mcu_w + (size_t)bx * 8, pw);
+              }
+            }
+          }
+          if (restart) to_restart--;
+        }
+        const int y0 = y * mcu_h, ny = std::min(mcu_h, H - y0);
+        for (int r = 0; r < ny; r++) memcpy(out + (size_t)(y0 + r) * W, rows.data() + (size_t)r * pw, (size_t)W);
+      }
+      return true;
+    }
+    p += len;
+  }
+  return fail(err, "JPEG: no scan found");
+}
+
+}  // namespace
+
+bool decode_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap, int* w, int* h, std::string* err) {
+  *w = *h = 0;
+  static const unsigned char png_sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  if (n >= 16 && !memcmp(d, png_sig, 8)) return png_gray8(d, n, out, cap, w, h, err);
+  if (n >= 4 && d[0] == 0xff && d[1] == 0xd8) return jpeg_gray8(d, n, out, cap, w, h, err);
+  if (n >= 8 && d[0] == 'P' && d[1] == '5') return pgm_gray8(d, n, out, cap, w, h, err);
+  return fail(err, "unknown image format (PNG, PGM P5 and baseline JPEG are supported)");
+}
+
+}  // namespace mdc_host

@@ -4,7 +4,9 @@
 #include <cstdint>
 #include <cstring>
 
+#include "BenchmarkDatasetReader.h"
 #include "FOVUndistorter.h"
+#include "image_codecs.h"
 #include "MdcBind.h"
 #include "PhotometricUndistorter.h"
 
@@ -200,6 +202,82 @@ int mdch_pack_tables(const mdch_fov* fov, const mdch_photo* photo, void* blob, s
     memcpy(q + nr * 4, MdcHostAccess::ry(*u), nr * 4);
   }
   return MDC_OK;
+}
+
+
+// ---- DatasetReader ---------------------------------------------------------------------------------
+struct mdch_reader { DatasetReader* r; };
+
+mdch_reader* mdch_reader_create(const char* folder) {
+  mdch_reader* h = new mdch_reader;
+  h->r = new DatasetReader(folder);
+  return h;
+}
+void mdch_reader_destroy(mdch_reader* h) {
+  if (!h) return;
+  delete h->r;
+  delete h;
+}
+int mdch_reader_num_images(mdch_reader* h) { return h->r->getNumImages(); }
+double mdch_reader_timestamp(mdch_reader* h, int id) { return h->r->getTimestamp(id); }
+float mdch_reader_exposure(mdch_reader* h, int id) { return h->r->getExposure(id); }
+void mdch_reader_dims(mdch_reader* h, int d[4]) {
+  d[0] = h->r->getUndistorter()->getInputDims()[0];
+  d[1] = h->r->getUndistorter()->getInputDims()[1];
+  d[2] = h->r->getUndistorter()->getOutputDims()[0];
+  d[3] = h->r->getUndistorter()->getOutputDims()[1];
+}
+int mdch_reader_get_image(mdch_reader* h, int id, int rectify, int g, int v, int o, float* out, long cap, int meta[3],
+                          double* stamp, float* exposure) {
+  ExposureImage* img = h->r->getImage(id, rectify != 0, g != 0, v != 0, o != 0);
+  if (!img) return 0;
+  const long n = (long)img->w * img->h;
+  const int ok = n <= cap;
+  if (ok) memcpy(out, img->image, (size_t)n * sizeof(float));
+  meta[0] = img->w;
+  meta[1] = img->h;
+  meta[2] = img->id;
+  *stamp = img->timestamp;
+  *exposure = img->exposure_time;
+  delete img;  // caller owns the ExposureImage (main_playbackDataset.cpp:82,116)
+  return ok;
+}
+int mdch_reader_get_images(mdch_reader* h, int first, int count, int rectify, int g, int v, int o, float* out,
+                           long frame_floats, unsigned char* ok) {
+  if (count <= 0) return 0;
+  ExposureImage** imgs = new ExposureImage*[count];
+  const int n = h->r->getImages(first, count, rectify != 0, g != 0, v != 0, o != 0, imgs);
+  for (int i = 0; i < count; i++) {
+    ok[i] = 0;
+    if (!imgs[i]) continue;
+    if ((long)imgs[i]->w * imgs[i]->h <= frame_floats && imgs[i]->id == first + i) {
+      memcpy(out + (size_t)i * frame_floats, imgs[i]->image, (size_t)imgs[i]->w * imgs[i]->h * sizeof(float));
+      ok[i] = 1;
+    }
+    delete imgs[i];
+  }
+  delete[] imgs;
+  return n;
+}
+int mdch_reader_get_raw(mdch_reader* h, int id, unsigned char* out, long cap, int wh[2]) {
+  const unsigned char* p = h->r->getImageRaw(id, &wh[0], &wh[1]);
+  if (!p || (long)wh[0] * wh[1] > cap) return 0;
+  memcpy(out, p, (size_t)wh[0] * wh[1]);
+  return 1;
+}
+void mdch_reader_set_threads(mdch_reader* h, int n) { h->r->setDecodeThreads(n); }
+void mdch_reader_set_prefetch(mdch_reader* h, int n) { h->r->setPrefetch(n); }
+const char* mdch_reader_last_error(mdch_reader* h) { return h->r->lastError(); }
+void mdch_reader_prefetch_stats(mdch_reader* h, long hm[2]) { h->r->getPrefetchStats(&hm[0], &hm[1]); }
+
+int mdch_decode_gray8(const unsigned char* data, size_t n, unsigned char* out, size_t cap, int wh[2], char* err, size_t errcap) {
+  std::string e;
+  const bool ok = mdc_host::decode_gray8(data, n, out, cap, &wh[0], &wh[1], &e);
+  if (err && errcap) {
+    strncpy(err, e.c_str(), errcap - 1);
+    err[errcap - 1] = 0;
+  }
+  return ok ? 1 : 0;
 }
 
 }  // extern "C"

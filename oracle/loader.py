@@ -39,6 +39,12 @@ def build_ref(force=False):
     return REF_SO
 
 
+def build_dropin():
+    """The playDataset-style test drivers on this repo's own DatasetReader (tests/dropin/*.cpp against
+    include/mono_dataset_code/BenchmarkDatasetReader.h): need no reference sources."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "dropin"])
+
+
 def have_ref():
     return os.path.exists(REF_SO)
 

@@ -1,0 +1,63 @@
+// End-to-end rate of a sequence reader: decode + photometric + rectify, frames/s.  ONE source, three builds
+// (oracle/Makefile):
+//   reader_rate_ref  : the reference's reader + the reference's classes           (CPU, single-threaded as shipped)
+//   reader_rate_mdc  : the reference's UNMODIFIED reader + this repo's drop-in classes (two GPU calls per frame)
+//   reader_rate_fast : this repo's reader (fused getImage; with "batch" as 4th argument: getImages)
+//
+//   reader_rate_X <sequence folder> <rgvo flags> <passes> [batch]
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "BenchmarkDatasetReader.h"
+
+int main(int argc, char** argv) {
+  if (argc < 4) return 2;
+  std::string folder = argv[1];
+  if (folder.empty() || folder[folder.size() - 1] != '/') folder += "/";
+  const char* f = argv[2];
+  const int passes = std::atoi(argv[3]);
+  const bool batch = argc > 4 && !std::strcmp(argv[4], "batch");
+  DatasetReader* reader = new DatasetReader(folder);
+  const int n = reader->getNumImages();
+  double checksum = 0;
+  auto run = [&](int reps) {
+    for (int p = 0; p < reps; p++) {
+#ifdef MDC_OWN_READER
+      if (batch) {
+        std::vector<ExposureImage*> imgs((size_t)n);
+        reader->getImages(0, n, f[0] == '1', f[1] == '1', f[2] == '1', f[3] == '1', imgs.data());
+        for (int i = 0; i < n; i++)
+          if (imgs[(size_t)i]) {
+            const float x = imgs[(size_t)i]->image[(size_t)(i * 7919) % ((size_t)imgs[(size_t)i]->w * imgs[(size_t)i]->h)];
+            if (x == x) checksum += x;
+            delete imgs[(size_t)i];
+          }
+        continue;
+      }
+#endif
+      for (int i = 0; i < n; i++) {
+        ExposureImage* img = reader->getImage(i, f[0] == '1', f[1] == '1', f[2] == '1', f[3] == '1');
+        if (!img) continue;
+        const float x = img->image[(size_t)(i * 7919) % ((size_t)img->w * img->h)];
+        if (x == x) checksum += x;
+        delete img;
+      }
+    }
+  };
+  run(1);  // warm: page cache, GPU context, pools
+  const auto t0 = std::chrono::steady_clock::now();
+  run(passes);
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::printf("READER_RATE %s%s flags %s: %d frames x %d passes in %.3f s = %.1f frames/s (checksum %.6g)\n", argv[0],
+              batch ? " batch" : "", f, n, passes, dt, n * passes / dt, checksum);
+#ifdef MDC_OWN_READER
+  long hits = 0, misses = 0;
+  reader->getPrefetchStats(&hits, &misses);
+  std::printf("READER_RATE prefetch: %ld frames found decoded ahead, %ld decoded by the calling thread\n", hits, misses);
+#endif
+  delete reader;
+  return 0;
+}

@@ -1,0 +1,130 @@
+"""class DatasetReader (include/mono_dataset_code/BenchmarkDatasetReader.h) on the GPU: the reference's reader
+interface with the fused pass behind it.
+
+  * getImage / getImages for every switch combination == the CPU oracle, bit for bit, from an images/ folder and
+    from images.zip;
+  * the playDataset-style driver compiled against OUR reader header (same source file as for the reference's
+    reader) == the reference's own reader + classes end to end (playback_ref), byte for byte;
+  * JPEG frames: identical to the oracle on the libjpeg-decoded bytes.
+"""
+import io
+import itertools
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from conftest import bits_equal
+from test_reader_cpu import make_sequence, textured
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = {k: os.path.join(ROOT, "oracle", "_ref", k) for k in ("playback_ref", "playback_fast", "playback_batch")}
+FLAGS = ["1111", "0111", "1000", "0000", "1110", "1010", "0001", "1100"]
+
+
+def oracle_tables(d, oracle, w, h):
+    from mono_dataset_code_amd import synth
+
+    cam = oracle.parse_camera(os.path.join(d, "camera.txt"))
+    t = oracle.fov_setup(cam)
+    ginv, _ = oracle.photo_gamma(oracle.parse_pcalib(os.path.join(d, "pcalib.txt")))
+    vinv = oracle.photo_vignette(synth.vignette_image(w, h, 16))[1]
+    return cam, t, ginv, vinv
+
+
+def frames_for(n, h, w):
+    from mono_dataset_code_amd import synth
+
+    fr = [textured(h, w, s) for s in range(n - 2)]
+    fr.append(synth.smooth_frame(w, h, 0.7).reshape(h, w))  # saturated blobs -> NaN regions
+    fr.append(np.full((h, w), 255, np.uint8))
+    return fr
+
+
+@pytest.mark.parametrize("zipped,fmt", [(False, "png"), (True, "png"), (True, "jpg"), (False, "pgm")])
+def test_get_image_and_get_images_equal_the_oracle(tmp_path, oracle, zipped, fmt):
+    from mono_dataset_code_amd import capi
+
+    h, w = 256, 320
+    frames = frames_for(9, h, w)
+    names, blobs = make_sequence(str(tmp_path), frames, zipped, fmt)
+    raw = frames if fmt != "jpg" else [np.asarray(Image.open(io.BytesIO(b))) for b in blobs]
+    cam, t, ginv, vinv = oracle_tables(str(tmp_path), oracle, w, h)
+    ow, oh = cam["out_w"], cam["out_h"]
+    r = capi.DatasetReader(str(tmp_path))
+    assert len(r) == 9
+    for fl in itertools.product((0, 1), repeat=4):
+        want = [oracle.get_image(f.reshape(-1), w, h, ow, oh, ginv, vinv, True, True, t["remap_x"], t["remap_y"], *fl) for f in raw]
+        for i in (0, 8, 7, 3):
+            img, ts, ex, idx = r.get_image(i, *fl)
+            assert idx == i and abs(ts - (1000.0 + i / 20.0)) < 1e-9 and abs(ex - (1.0 + 0.01 * i)) < 1e-6
+            assert img.shape == ((oh, ow) if fl[0] else (h, w))
+            assert bits_equal(img, want[i]), (fl, i)
+        out, ok, got = r.get_images(0, 9, *fl)
+        assert got == 9 and ok.all()
+        for i in range(9):
+            assert bits_equal(out[i], want[i]), (fl, i, "getImages")
+    out, ok, got = r.get_images(2, 5, 1, 1, 1, 1)  # a sub-range
+    assert got == 5 and bits_equal(out[0], oracle.get_image(raw[2].reshape(-1), w, h, ow, oh, ginv, vinv, True, True, t["remap_x"], t["remap_y"], 1, 1, 1, 1))
+    out, ok, got = r.get_images(5, 9, 1, 1, 1, 1)  # runs past the end: refused as a whole
+    assert got == 0 and "outside the sequence" in r.last_error()
+    r.close()
+
+
+def test_get_images_longer_than_the_ring(tmp_path, oracle):
+    """More frames than two chunks of the page-locked ring (2 x 64): chunk k+2 re-uses chunk k's half while the pool decodes."""
+    from mono_dataset_code_amd import capi
+
+    h, w = 64, 80
+    frames = [textured(h, w, s) for s in range(300)]
+    make_sequence(str(tmp_path), frames, True, "png")
+    cam, t, ginv, vinv = oracle_tables(str(tmp_path), oracle, w, h)
+    r = capi.DatasetReader(str(tmp_path))
+    for threads in (0, 2):
+        r.set_threads(threads)
+        out, ok, got = r.get_images(0, 300, 1, 1, 1, 0)
+        assert got == 300 and ok.all()
+        for i in (0, 63, 64, 127, 128, 129, 200, 299):
+            want = oracle.get_image(frames[i].reshape(-1), w, h, cam["out_w"], cam["out_h"], ginv, vinv, True, True, t["remap_x"], t["remap_y"], 1, 1, 1, 0)
+            assert bits_equal(out[i], want), (threads, i)
+    r.close()
+
+
+def parse(path):
+    raw = open(path, "rb").read()
+    pos, recs = 0, []
+    while pos < len(raw):
+        w, h, idx, a = np.frombuffer(raw, np.int32, 4, pos)
+        ts = np.frombuffer(raw, np.float64, 1, pos + 16)[0]
+        ex = np.frombuffer(raw, np.float32, 1, pos + 24)[0]
+        recs.append((int(w), int(h), int(idx), int(a), float(ts), float(ex), np.frombuffer(raw, np.float32, w * h, pos + 28)))
+        pos += 28 + 4 * w * h
+    return recs
+
+
+@pytest.mark.parametrize("which", ["playback_fast", "playback_batch"])
+def test_playdataset_driver_on_our_reader_equals_the_reference_reader(tmp_path, which):
+    """tests/dropin/playback_headless.cpp is ONE source file: compiled against the reference's BenchmarkDatasetReader.h +
+    classes (playback_ref, CPU) and against this repo's reader header (playback_fast, GPU); playback_batch drives
+    getImages().  Same bytes out."""
+    for b in ("playback_ref", which):
+        if not os.path.exists(BIN[b]):
+            pytest.skip("%s not built" % b)
+    h, w = 256, 320
+    frames = frames_for(5, h, w)
+    d = str(tmp_path / "seq")
+    os.makedirs(d)
+    make_sequence(d, frames, False, "png")
+    outs = {}
+    for b in ("playback_ref", which):
+        out = str(tmp_path / (b + ".bin"))
+        r = subprocess.run([BIN[b], d, out] + FLAGS, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-3000:]
+        outs[b] = parse(out)
+    assert len(outs["playback_ref"]) == len(outs[which]) == len(FLAGS) * 5
+    for x, y in zip(outs["playback_ref"], outs[which]):
+        assert x[:6] == y[:6]
+        assert bits_equal(x[6], y[6]), x[:4]

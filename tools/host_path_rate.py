@@ -57,13 +57,37 @@ def many(raws, outs):
     return 4 * M / dt, 4 * M * W * H / dt / 1e6
 
 
+# the same two class calls with the opt-in page-locking of the repeated W*H float buffer (what
+# `MDC_PIN_CALLER_BUFFERS=1 playDataset ...` gives an unmodified reader)
+os.environ["MDC_PIN_CALLER_BUFFERS"] = "1"
+fov_p = capi.UndistorterFOV(os.path.join(d, "camera.txt"))
+photo_p = capi.PhotometricUndistorter(os.path.join(d, "pcalib.txt"), os.path.join(d, "vignette.png"), 1280, 1024)
+del os.environ["MDC_PIN_CALLER_BUFFERS"]
+pin_out1 = capi.PinnedArray((w * h,), np.float32)  # a pooled ExposureImage::image is page-locked already
+
+
+def two_calls_pinned(i):
+    photo_p.unmap(frames[i % 8], tmp, 1, 1, 1)
+    fov_p.undistort(tmp, pin_out1.array)
+
+
+pin_in1 = capi.PinnedArray((8, W * H), np.uint8)
+pin_in1.array[:] = frames
+
+
+def fused_pinned(i):  # what this repo's DatasetReader::getImage does after decoding: page-locked frame -> pooled image
+    ctx.process_host(pin_in1.array[i % 8], pin_out1.array, 15)
+
+
 print("host path, 1280x1024 -> 640x480, g+v+o, %d frames each" % N, file=sys.stderr)
 for name, fn in (("unMapImage + undistort<float> (two class calls, W*H float round trip)", two_calls),
-                 ("mdc_process_host (fused, one call)", lambda i: ctx.process_host(frames[i % 8], out, 15))):
+                 ("  the same with MDC_PIN_CALLER_BUFFERS=1 and a pooled (page-locked) ExposureImage", two_calls_pinned),
+                 ("mdc_process_host (fused, one call, pageable buffers)", lambda i: ctx.process_host(frames[i % 8], out, 15)),
+                 ("mdc_process_host from / to page-locked buffers (the reader's getImage after decode)", fused_pinned)):
     fps, mpix = rate(fn)
-    print("%-75s %8.1f frames/s  %9.1f Mpix/s" % (name, fps, mpix), file=sys.stderr)
+    print("%-90s %8.1f frames/s  %9.1f Mpix/s" % (name, fps, mpix), file=sys.stderr)
 for name, (raws, outs) in (("mdc_process_frames_host, %d frames per call, pageable buffers" % M, (page_in, page_out)),
                            ("mdc_process_frames_host, %d frames per call, mdc_host_alloc buffers" % M,
                             ([pin_in.array[i] for i in range(M)], [pin_out.array[i] for i in range(M)]))):
     fps, mpix = many(raws, outs)
-    print("%-75s %8.1f frames/s  %9.1f Mpix/s" % (name, fps, mpix), file=sys.stderr)
+    print("%-90s %8.1f frames/s  %9.1f Mpix/s" % (name, fps, mpix), file=sys.stderr)
