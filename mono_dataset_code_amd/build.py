@@ -86,6 +86,21 @@ def build_host(force=False):
     return LIB_HOST
 
 
+LIB_MULTI = os.path.join(PKG, "libmdc_multi.so")
+MULTI_SOURCE = os.path.join(CSRC, "mdc_multi.hip")
+
+
+def build_multi(force=False):
+    """libmdc_multi.so: one process, N GPUs, RCCL table broadcast (include/mdc_multi.h)."""
+    build_hip(force)
+    if force or _stale(LIB_MULTI, [MULTI_SOURCE, os.path.join(INC, "mdc_multi.h"), os.path.join(INC, "mdc_hip.h"), LIB_HIP]):
+        rocm = os.path.dirname(os.path.dirname(os.path.realpath(hipcc())))
+        _run([hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + INC, MULTI_SOURCE,
+              "-L" + PKG, "-lmdc_hip", "-L" + os.path.join(rocm, "lib"), "-lrccl", "-lpthread",
+              "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", LIB_MULTI])
+    return LIB_MULTI
+
+
 def build_variant(name, defines):
     """Experimental build of libmdc_hip with -D switches (see MDC_EXP_* in mdc_kernels.hip);
     loaded by tools/sweep.py --lib.  Lands in mono_dataset_code_amd/variants/."""
@@ -99,7 +114,8 @@ def build_variant(name, defines):
 def build_all(force=False):
     build_hip(force)
     build_host(force)
-    return LIB_HIP, LIB_HOST
+    build_multi(force)
+    return LIB_HIP, LIB_HOST, LIB_MULTI
 
 
 if __name__ == "__main__":
