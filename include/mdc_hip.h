@@ -204,6 +204,25 @@ typedef struct mdc_fov_model {
 int mdc_distort_points_device(mdc_ctx* ctx, const mdc_fov_model* model, float* d_x, float* d_y, int64_t n, void* stream);
 int mdc_distort_points_host(mdc_ctx* ctx, const mdc_fov_model* model, float* x, float* y, int64_t n);
 
+/* ---- vignetteCalib solver (src/main_vignetteCalib.cpp:395-527) ----------------------------------- */
+
+/* One "optimize planeColor" half-iteration (:400-448) over n_images images of w x h floats (stacked in d_images,
+ * NaN = masked pixel, :294-300) seen through the plane -> image coordinates d_p2x / d_p2y (n_images x n_plane, NaN =
+ * plane point outside that image, after distortCoordinates, :284): for every plane point the sums FF, FC over the
+ * images (d_ff, d_fc: n_plane floats, overwritten) and the new colour FC / FF (NaN where FF < 1) in d_plane_color,
+ * which is read first for the residual test against oth2 (the reference's int, :397-398).  d_er receives
+ * {E, R} of the reference's printf (:449).  FF, FC and the colours are bit-identical to the reference. */
+int mdc_vcal_plane_step_device(mdc_ctx* ctx, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
+                               int n_plane, float* d_plane_color, const float* d_vignette_factor, int oth2, float* d_ff,
+                               float* d_fc, double* d_er, void* stream);
+/* One "optimize vignette" half-iteration (:455-527): bilinear scatter of the plane colours into the image grid
+ * (d_tt, d_ct: w*h floats, overwritten), new factor CT / TT (NaN where TT < 1) normalised to a maximum of 1 in
+ * d_vignette_factor (read first for the residual test).  A scatter-add by concurrent float atomics: equal to the
+ * reference to ~1e-6 relative, not bitwise (the reference sums sequentially). */
+int mdc_vcal_vignette_step_device(mdc_ctx* ctx, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w,
+                                  int h, int n_plane, const float* d_plane_color, float* d_vignette_factor, int oth2, float* d_tt,
+                                  float* d_ct, double* d_er, void* stream);
+
 /* Synthetic sequence generator (bench/test utility):
  * byte i of frame f = fmix32(seed + (first_frame+f)*npix + i) >> 24. */
 int mdc_synth_frames_device(mdc_ctx* ctx, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix,

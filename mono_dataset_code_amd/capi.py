@@ -29,7 +29,8 @@ HIP_SYMBOLS = [
     "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
     "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device", "mdc_synth_frames_device",
     "mdc_distort_points_device", "mdc_distort_points_host", "mdc_export_tables", "mdc_import_tables",
-    "mdc_synchronize", "mdc_describe_launch", "mdc_ceiling_mix_device",
+    "mdc_synchronize", "mdc_describe_launch", "mdc_ceiling_mix_device", "mdc_vcal_plane_step_device",
+    "mdc_vcal_vignette_step_device",
 ]
 HOST_SYMBOLS = [
     "mdch_fov_create", "mdch_fov_destroy", "mdch_fov_valid", "mdch_fov_has_gpu", "mdch_fov_dims",
@@ -120,6 +121,8 @@ def hip_lib():
         if not old_build or hasattr(L, "mdc_describe_launch"):
             L.mdc_describe_launch.argtypes = [_vp, C.c_uint, _i, C.c_char_p, _sz]
             L.mdc_ceiling_mix_device.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int64, _i, _vp]
+            L.mdc_vcal_plane_step_device.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]
+            L.mdc_vcal_vignette_step_device.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]
         for n in HIP_SYMBOLS:
             if old_build and not hasattr(L, n):
                 continue
@@ -369,6 +372,36 @@ class Context:
 
     def ceiling_mix(self, d_read, read_bytes, d_write, write_bytes, blocks=16384, stream=0):
         self._chk(self._L.mdc_ceiling_mix_device(self._h, d_read, read_bytes, d_write, write_bytes, blocks, stream if stream else None))
+
+    def vcal_plane_step(self, d_images, d_p2x, d_p2y, d_plane_color, d_vig, oth2, stream=0):
+        """torch tensors on the device; d_plane_color is updated in place -> (FF, FC, E, R)."""
+        import torch
+
+        n, h, w = d_images.shape
+        npnt = d_p2x.shape[1]
+        ff = torch.empty(npnt, dtype=torch.float32, device=d_images.device)
+        fc = torch.empty_like(ff)
+        er = torch.zeros(2, dtype=torch.float64, device=d_images.device)
+        self._chk(self._L.mdc_vcal_plane_step_device(self._h, d_images.data_ptr(), d_p2x.data_ptr(), d_p2y.data_ptr(), n, w, h, npnt,
+                                                     d_plane_color.data_ptr(), d_vig.data_ptr(), int(oth2), ff.data_ptr(), fc.data_ptr(),
+                                                     er.data_ptr(), stream if stream else None))
+        e, r = er.cpu().tolist()
+        return ff, fc, e, r
+
+    def vcal_vignette_step(self, d_images, d_p2x, d_p2y, d_plane_color, d_vig, oth2, stream=0):
+        """d_vig is updated in place -> (TT, CT, E, R)."""
+        import torch
+
+        n, h, w = d_images.shape
+        npnt = d_p2x.shape[1]
+        tt = torch.empty(h * w, dtype=torch.float32, device=d_images.device)
+        ct = torch.empty_like(tt)
+        er = torch.zeros(2, dtype=torch.float64, device=d_images.device)
+        self._chk(self._L.mdc_vcal_vignette_step_device(self._h, d_images.data_ptr(), d_p2x.data_ptr(), d_p2y.data_ptr(), n, w, h, npnt,
+                                                        d_plane_color.data_ptr(), d_vig.data_ptr(), int(oth2), tt.data_ptr(), ct.data_ptr(),
+                                                        er.data_ptr(), stream if stream else None))
+        e, r = er.cpu().tolist()
+        return tt, ct, e, r
 
     def bind(self, fov=None, photo=None):
         rc = host_lib().mdch_bind(self._h, fov._h if fov is not None else None, photo._h if photo is not None else None)

@@ -88,6 +88,8 @@ struct mdc_ctx {
   float* d_pipe_out[2] = {nullptr, nullptr};
   size_t pipe_in_cap = 0, pipe_out_cap = 0;
 
+  unsigned* d_vcal_max = nullptr;  // vignetteCalib: bit pattern of the largest new vignette factor
+
   // staging for the host-pointer calls
   void* d_stage_in = nullptr;
   size_t stage_in_cap = 0;
@@ -591,7 +593,7 @@ void mdc_destroy(mdc_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     unpin_all(c);
     free_plan(c);
-    void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_stage_in, c->d_stage_out,
+    void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_stage_in, c->d_stage_out, c->d_vcal_max,
                     c->d_pipe_in[0], c->d_pipe_in[1], c->d_pipe_out[0], c->d_pipe_out[1]};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
@@ -892,6 +894,35 @@ int mdc_distort_points_host(mdc_ctx* c, const mdc_fov_model* model, float* x, fl
   MDC_HIP(c, hipMemcpyAsync(x, dx, bytes, hipMemcpyDeviceToHost, c->stream));
   MDC_HIP(c, hipMemcpyAsync(y, dy, bytes, hipMemcpyDeviceToHost, c->stream));
   MDC_HIP(c, hipStreamSynchronize(c->stream));
+  return MDC_OK;
+}
+
+int mdc_vcal_plane_step_device(mdc_ctx* c, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
+                               int n_plane, float* d_plane_color, const float* d_vignette_factor, int oth2, float* d_ff,
+                               float* d_fc, double* d_er, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (!d_images || !d_p2x || !d_p2y || !d_plane_color || !d_vignette_factor || !d_ff || !d_fc || !d_er || n_images < 0 || w < 2 ||
+      h < 2 || n_plane < 0)
+    return fail(c, MDC_ERR_ARG, "mdc_vcal_plane_step_device: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  MDC_HIP(c, launch_vcal_plane_step(d_images, d_p2x, d_p2y, n_images, w, h, n_plane, d_plane_color, d_vignette_factor, oth2, d_ff,
+                                    d_fc, d_er, (hipStream_t)stream));
+  return MDC_OK;
+}
+
+int mdc_vcal_vignette_step_device(mdc_ctx* c, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w,
+                                  int h, int n_plane, const float* d_plane_color, float* d_vignette_factor, int oth2, float* d_tt,
+                                  float* d_ct, double* d_er, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (!d_images || !d_p2x || !d_p2y || !d_plane_color || !d_vignette_factor || !d_tt || !d_ct || !d_er || n_images < 0 || w < 2 ||
+      h < 2 || n_plane < 0)
+    return fail(c, MDC_ERR_ARG, "mdc_vcal_vignette_step_device: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  if (!c->d_vcal_max) MDC_HIP(c, hipMalloc(&c->d_vcal_max, sizeof(unsigned)));
+  MDC_HIP(c, launch_vcal_vignette_step(d_images, d_p2x, d_p2y, n_images, w, h, n_plane, d_plane_color, d_vignette_factor, oth2,
+                                       d_tt, d_ct, d_er, c->d_vcal_max, (hipStream_t)stream));
   return MDC_OK;
 }
 

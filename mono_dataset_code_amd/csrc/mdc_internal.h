@@ -93,6 +93,14 @@ hipError_t launch_distort_points(float* d_x, float* d_y, int64_t n, const Distor
 hipError_t launch_mix_ceiling(const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes, int blocks,
                               hipStream_t s);
 
+// vignetteCalib solver half-iterations (src/main_vignetteCalib.cpp:400-448, :455-527); d_er = {E, R}
+hipError_t launch_vcal_plane_step(const float* d_images, const float* d_p2x, const float* d_p2y, int n, int wI, int hI, int np,
+                                  float* d_plane_color, const float* d_vig, int oth2, float* d_ff, float* d_fc, double* d_er,
+                                  hipStream_t s);
+hipError_t launch_vcal_vignette_step(const float* d_images, const float* d_p2x, const float* d_p2y, int n, int wI, int hI, int np,
+                                     const float* d_plane_color, float* d_vig, int oth2, float* d_tt, float* d_ct, double* d_er,
+                                     unsigned* d_max_bits, hipStream_t s);
+
 hipError_t launch_synth(uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix, uint32_t seed, hipStream_t s);
 
 }  // namespace mdc

@@ -64,6 +64,10 @@ class Oracle:
         L.orc_undistort_u8.argtypes = [_vp, _vp, _vp, _vp, _i, _i]
         L.orc_get_image.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i]
         L.orc_pyramid_level.argtypes = [_vp, _i, _i, _vp]
+        L.orc_vcal_plane_step.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]
+        L.orc_vcal_plane_step.restype = None
+        L.orc_vcal_vignette_step.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]
+        L.orc_vcal_vignette_step.restype = None
         L.orc_synth_frames.argtypes = [_vp, C.c_longlong, C.c_longlong, _i, C.c_uint]
         L.orc_time_path.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(C.c_double)]
         L.orc_time_path.restype = C.c_double
@@ -146,6 +150,28 @@ class Oracle:
         out = np.zeros((n, npix), np.uint8)
         self.L.orc_synth_frames(_p(out), first, n, npix, seed)
         return out
+
+    def vcal_plane_step(self, images, p2x, p2y, plane_color, vig, oth2):
+        """src/main_vignetteCalib.cpp:400-448 -> (new planeColor, FF, FC, E, R); images (n, hI, wI), p2x/p2y (n, np)."""
+        n, hI, wI = images.shape
+        npnt = p2x.shape[1]
+        pc = np.array(plane_color, np.float32, copy=True)
+        ff, fc = np.zeros(npnt, np.float32), np.zeros(npnt, np.float32)
+        er = np.zeros(2, np.float64)
+        self.L.orc_vcal_plane_step(_p(images), _p(p2x), _p(p2y), n, wI, hI, npnt, _p(pc), _p(ff), _p(fc), _p(vig), int(oth2),
+                                   er.ctypes.data, er.ctypes.data + 8)
+        return pc, ff, fc, float(er[0]), float(er[1])
+
+    def vcal_vignette_step(self, images, p2x, p2y, plane_color, vig, oth2):
+        """src/main_vignetteCalib.cpp:455-527 -> (new vignetteFactor, TT, CT, E, R)."""
+        n, hI, wI = images.shape
+        npnt = p2x.shape[1]
+        vf = np.array(vig, np.float32, copy=True)
+        tt, ct = np.zeros(hI * wI, np.float32), np.zeros(hI * wI, np.float32)
+        er = np.zeros(2, np.float64)
+        self.L.orc_vcal_vignette_step(_p(images), _p(p2x), _p(p2y), n, wI, hI, npnt, _p(plane_color), _p(vf), _p(tt), _p(ct), int(oth2),
+                                      er.ctypes.data, er.ctypes.data + 8)
+        return vf, tt, ct, float(er[0]), float(er[1])
 
     def time_path(self, frames, passes, in_w, in_h, out_w, out_h, ginv, vinv, rx, ry, rectify, g, v, o):
         cs = C.c_double(0)
@@ -271,3 +297,40 @@ class RefPhoto:
 
     def unmap(self, img, out, g, v, o):
         self.L.ref_photo_unmap(self.h, _p(img), _p(out), img.size, int(g), int(v), int(o))
+
+
+VCAL_REF_SO = os.path.join(HERE, "_ref", "libvcal_ref.so")
+
+
+class VcalRef:
+    """The reference's own vignetteCalib solver loops (oracle/vcal_extract.py + oracle/vcal_ref_wrapper.cpp)."""
+
+    def __init__(self):
+        build_ref()
+        if not os.path.exists(VCAL_REF_SO):
+            raise OSError("oracle/_ref/libvcal_ref.so is not built and /root/reference is not mounted")
+        self.L = C.CDLL(VCAL_REF_SO)
+
+    @staticmethod
+    def _rows(a):
+        return (C.c_void_p * a.shape[0])(*[a[i].ctypes.data for i in range(a.shape[0])])
+
+    def plane_step(self, images, p2x, p2y, gw, gh, plane_color, vig, oth2):
+        n, hI, wI = images.shape
+        pc = np.array(plane_color, np.float32, copy=True)
+        ff, fc = np.zeros(gw * gh, np.float32), np.zeros(gw * gh, np.float32)
+        vf = np.array(vig, np.float32, copy=True)
+        e, r = C.c_double(0), C.c_double(0)
+        self.L.ref_vcal_plane_step(n, self._rows(p2x), self._rows(p2y), self._rows(images.reshape(n, -1)), gw, gh, wI, hI, _p(pc), _p(ff),
+                                   _p(fc), _p(vf), int(oth2), C.byref(e), C.byref(r))
+        return pc, ff, fc, e.value, r.value
+
+    def vignette_step(self, images, p2x, p2y, gw, gh, plane_color, vig, oth2):
+        n, hI, wI = images.shape
+        pc = np.array(plane_color, np.float32, copy=True)
+        vf = np.array(vig, np.float32, copy=True)
+        tt, ct = np.zeros(hI * wI, np.float32), np.zeros(hI * wI, np.float32)
+        e, r = C.c_double(0), C.c_double(0)
+        self.L.ref_vcal_vignette_step(n, self._rows(p2x), self._rows(p2y), self._rows(images.reshape(n, -1)), gw, gh, wI, hI, _p(pc),
+                                      _p(vf), _p(tt), _p(ct), int(oth2), C.byref(e), C.byref(r))
+        return vf, tt, ct, e.value, r.value

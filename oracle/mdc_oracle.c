@@ -429,3 +429,119 @@ double orc_time_path(const unsigned char* frames, int nframes, int passes, int i
   if (checksum) *checksum = s;
   return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * vignetteCalib solver: the two accumulate half-iterations of src/main_vignetteCalib.cpp:395-527
+ * (alternating least squares for the plane's colour and the per-pixel vignette factor).
+ * Pinned bit for bit against the reference's own loop text (oracle/vcal_extract.py ->
+ * oracle/_ref/libvcal_ref.so) in tests/test_vcal.py.
+ * Images, plane->image coordinates and factors are stacked: images[img*wI*hI + ..],
+ * p2x/p2y[img*np + pi], np = gw*gh plane points.  oth2 is the reference's int (:397-398).
+ * ------------------------------------------------------------------------------------------- */
+/* getInterpolatedElement, src/main_vignetteCalib.cpp:52-70 */
+static float orc_interp(const float* mat, float x, float y, int width) {
+  int ix = (int)x;
+  int iy = (int)y;
+  float dx = x - ix;
+  float dy = y - iy;
+  float dxdy = dx * dy;
+  const float* bp = mat + ix + iy * width;
+  float res = dxdy * bp[1 + width] + (dy - dxdy) * bp[width] + (dx - dxdy) * bp[1] + (1 - dx - dy + dxdy) * bp[0];
+  return res;
+}
+
+/* "optimize planeColor", :400-448: FF/FC are rebuilt, planeColor is read (residuals) and then replaced. */
+void orc_vcal_plane_step(const float* images, const float* p2x, const float* p2y, int n, int wI, int hI, int np,
+                         float* planeColor, float* planeColorFF, float* planeColorFC, const float* vignetteFactor,
+                         int oth2, double* E_out, double* R_out) {
+  double E = 0, R = 0;
+  memset(planeColorFF, 0, (size_t)np * sizeof(float)); /* :401-402 */
+  memset(planeColorFC, 0, (size_t)np * sizeof(float));
+  for (int img = 0; img < n; img++) { /* :406 */
+    const float* plane2imgX = p2x + (size_t)img * np;
+    const float* plane2imgY = p2y + (size_t)img * np;
+    const float* image = images + (size_t)img * wI * hI;
+    for (int pi = 0; pi < np; pi++) { /* :412 */
+      if (isnan(plane2imgX[pi])) continue;
+      float color = orc_interp(image, plane2imgX[pi], plane2imgY[pi], wI); /* :417-418 */
+      float fac = orc_interp(vignetteFactor, plane2imgX[pi], plane2imgY[pi], wI);
+      if (isnan(fac)) continue;
+      if (isnan(color)) continue;
+      double residual = (double)((color - planeColor[pi] * fac) * (color - planeColor[pi] * fac)); /* :423, float product */
+      if (fabs(residual) > oth2) { /* :424-429 (abs resolves to the double overload in the reference build) */
+        E += oth2;
+        R++;
+        continue;
+      }
+      planeColorFF[pi] += fac * fac; /* :432-433 */
+      planeColorFC[pi] += color * fac;
+      if (isnan(planeColor[pi])) continue; /* :435 */
+      E += residual;
+      R++;
+    }
+  }
+  for (int pi = 0; pi < np; pi++) { /* :441-447 */
+    if (planeColorFF[pi] < 1) planeColor[pi] = NAN;
+    else planeColor[pi] = planeColorFC[pi] / planeColorFF[pi];
+  }
+  *E_out = E;
+  *R_out = R;
+}
+
+/* "optimize vignette", :455-527: TT/CT are rebuilt by bilinear scatter, vignetteFactor is read and then
+ * replaced and normalised to a maximum of 1. */
+void orc_vcal_vignette_step(const float* images, const float* p2x, const float* p2y, int n, int wI, int hI, int np,
+                            const float* planeColor, float* vignetteFactor, float* vignetteFactorTT,
+                            float* vignetteFactorCT, int oth2, double* E_out, double* R_out) {
+  double E = 0, R = 0;
+  memset(vignetteFactorTT, 0, (size_t)hI * wI * sizeof(float)); /* :457-458 */
+  memset(vignetteFactorCT, 0, (size_t)hI * wI * sizeof(float));
+  for (int img = 0; img < n; img++) { /* :461 */
+    const float* plane2imgX = p2x + (size_t)img * np;
+    const float* plane2imgY = p2y + (size_t)img * np;
+    const float* image = images + (size_t)img * wI * hI;
+    for (int pi = 0; pi < np; pi++) { /* :467 */
+      if (isnan(plane2imgX[pi])) continue;
+      float x = plane2imgX[pi];
+      float y = plane2imgY[pi];
+      float colorImage = orc_interp(image, x, y, wI); /* :473-475 */
+      float fac = orc_interp(vignetteFactor, x, y, wI);
+      float colorPlane = planeColor[pi];
+      if (isnan(colorPlane)) continue;
+      if (isnan(colorImage)) continue;
+      double residual = (double)((colorImage - colorPlane * fac) * (colorImage - colorPlane * fac)); /* :480 */
+      if (fabs(residual) > oth2) { /* :481-486 */
+        E += oth2;
+        R++;
+        continue;
+      }
+      int ix = (int)x; /* :489-493 */
+      int iy = (int)y;
+      float dx = x - ix;
+      float dy = y - iy;
+      float dxdy = dx * dy;
+      vignetteFactorTT[ix + iy * wI + 0] += (1 - dx - dy + dxdy) * colorPlane * colorPlane; /* :495-498 */
+      vignetteFactorTT[ix + iy * wI + 1] += (dx - dxdy) * colorPlane * colorPlane;
+      vignetteFactorTT[ix + iy * wI + wI] += (dy - dxdy) * colorPlane * colorPlane;
+      vignetteFactorTT[ix + iy * wI + 1 + wI] += dxdy * colorPlane * colorPlane;
+      vignetteFactorCT[ix + iy * wI + 0] += (1 - dx - dy + dxdy) * colorImage * colorPlane; /* :500-503 */
+      vignetteFactorCT[ix + iy * wI + 1] += (dx - dxdy) * colorImage * colorPlane;
+      vignetteFactorCT[ix + iy * wI + wI] += (dy - dxdy) * colorImage * colorPlane;
+      vignetteFactorCT[ix + iy * wI + 1 + wI] += dxdy * colorImage * colorPlane;
+      if (isnan(fac)) continue; /* :505 */
+      E += residual;
+      R++;
+    }
+  }
+  float maxFac = 0; /* :511-521 */
+  for (int pi = 0; pi < hI * wI; pi++) {
+    if (vignetteFactorTT[pi] < 1) vignetteFactor[pi] = NAN;
+    else {
+      vignetteFactor[pi] = vignetteFactorCT[pi] / vignetteFactorTT[pi];
+      if (vignetteFactor[pi] > maxFac) maxFac = vignetteFactor[pi];
+    }
+  }
+  for (int pi = 0; pi < hI * wI; pi++) vignetteFactor[pi] /= maxFac; /* :526-527 */
+  *E_out = E;
+  *R_out = R;
+}

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE.  The vignetteCalib solver's accumulate loops live inside main() of the reference's
+src/main_vignetteCalib.cpp (:395-527) -- they cannot be linked, and the file as a whole needs aruco + OpenCV.
+This script cuts the loop bodies (and getInterpolatedElement, :52-70) out of the reference file WHERE IT LIES,
+by their comment anchors, into oracle/_ref/*.inc (git-ignored, never committed); oracle/vcal_ref_wrapper.cpp wraps
+them into two functions and oracle/Makefile compiles that into oracle/_ref/libvcal_ref.so -- the pin for
+oracle/mdc_oracle.c's restatement (tests/test_vcal.py).  usage: vcal_extract.py <reference src dir> <out dir>"""
+import os
+import sys
+
+src, out = sys.argv[1], sys.argv[2]
+lines = open(os.path.join(src, "main_vignetteCalib.cpp")).read().split("\n")
+
+
+def find(sub, start=0):
+    for i in range(start, len(lines)):
+        if sub in lines[i]:
+            return i
+    raise SystemExit("anchor %r not found in main_vignetteCalib.cpp" % sub)
+
+
+i0 = find("float getInterpolatedElement(")
+i1 = next(i for i in range(i0, len(lines)) if lines[i].rstrip() == "}")
+a0 = find("optimize planeColor")
+b0 = find("optimize vignette", a0)
+b1 = find("vignetteFactor[pi] /= maxFac;", b0)
+os.makedirs(out, exist_ok=True)
+open(os.path.join(out, "vcal_interp.inc"), "w").write("\n".join(lines[i0:i1 + 1]) + "\n")
+open(os.path.join(out, "vcal_body_plane.inc"), "w").write("\n".join(lines[a0 + 1:b0]) + "\n")
+open(os.path.join(out, "vcal_body_vignette.inc"), "w").write("\n".join(lines[b0 + 1:b1 + 1]) + "\n")
+print("vcal: interp %d-%d, plane step %d-%d, vignette step %d-%d" % (i0 + 1, i1 + 1, a0 + 2, b0, b0 + 2, b1 + 1))

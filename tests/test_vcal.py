@@ -1,0 +1,102 @@
+"""vignetteCalib solver loops (reference src/main_vignetteCalib.cpp:395-527).
+
+CPU : oracle/mdc_oracle.c's restatement == the reference's own loop text (cut out of its main() at build time,
+      oracle/vcal_extract.py -> oracle/_ref/libvcal_ref.so), bit for bit, over several alternating iterations.
+GPU : mdc_vcal_plane_step == oracle bit for bit (each plane point sums over the images in the reference's order);
+      mdc_vcal_vignette_step within 1e-5 relative (a scatter-add: the summation ORDER of the reference's sequential
+      loop cannot be kept by concurrent atomics; float sums of positive terms differ in the last bits only)."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+
+def problem(seed=0, n=6, wI=48, hI=40, gw=36, gh=30):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:hI, 0:wI].astype(np.float32)
+    r2 = ((x - wI / 2) ** 2 + (y - hI / 2) ** 2) / (wI * hI / 4.0)
+    vig_true = (1.0 - 0.5 * r2).astype(np.float32)
+    gy, gx = np.mgrid[0:gh, 0:gw].astype(np.float32)
+    plane_true = (60 + 40 * np.sin(0.4 * gx) * np.cos(0.3 * gy)).astype(np.float32)
+    images = np.zeros((n, hI, wI), np.float32)
+    p2x = np.zeros((n, gw * gh), np.float32)
+    p2y = np.zeros((n, gw * gh), np.float32)
+    for i in range(n):
+        # an affine view of the plane that stays inside [1, w-2] x [1, h-2], different per image
+        sx, sy = rng.uniform(0.8, 1.15), rng.uniform(0.8, 1.15)
+        ox, oy = rng.uniform(1.5, 4.0), rng.uniform(1.5, 4.0)
+        px = (ox + sx * gx + 0.05 * gy).astype(np.float32)
+        py = (oy + sy * gy - 0.04 * gx).astype(np.float32)
+        bad = (px < 1) | (py < 1) | (px > wI - 2.5) | (py > hI - 2.5) | (rng.random((gh, gw)) < 0.03)
+        px[bad] = np.nan
+        py[bad] = np.nan
+        p2x[i], p2y[i] = px.reshape(-1), py.reshape(-1)
+        # the image: plane colour seen through the vignette (nearest plane point per pixel, good enough for a test)
+        ix = np.clip(np.round((x - ox) / sx), 0, gw - 1).astype(int)
+        iy = np.clip(np.round((y - oy) / sy), 0, gh - 1).astype(int)
+        img = plane_true[iy, ix] * vig_true + rng.normal(0, 0.5, (hI, wI)).astype(np.float32)
+        img[rng.random((hI, wI)) < 0.01] = np.nan  # masked gradients (:294-300)
+        images[i] = img
+    return images, p2x, p2y, gw, gh
+
+
+def test_oracle_equals_reference_loops_bit_for_bit(oracle):
+    from oracle import loader
+
+    try:
+        ref = loader.VcalRef()
+    except OSError as e:
+        pytest.skip(str(e))
+    for seed in range(3):
+        images, p2x, p2y, gw, gh = problem(seed)
+        n, hI, wI = images.shape
+        pc_o = np.zeros(gw * gh, np.float32)  # the reference's `new float[]` is uninitialised; any start value is legal
+        pc_r = pc_o.copy()
+        vf_o = np.ones(hI * wI, np.float32)
+        vf_r = vf_o.copy()
+        for it in range(6):
+            oth2 = 10000 * 10000 if it < 3 else 15 * 15  # :397-398
+            pc_o, ff_o, fc_o, e_o, r_o = oracle.vcal_plane_step(images, p2x, p2y, pc_o, vf_o, oth2)
+            pc_r, ff_r, fc_r, e_r, r_r = ref.plane_step(images, p2x, p2y, gw, gh, pc_r, vf_r, oth2)
+            assert bits_equal(ff_o, ff_r) and bits_equal(fc_o, fc_r) and bits_equal(pc_o, pc_r), (seed, it, "plane")
+            assert e_o == e_r and r_o == r_r and r_o > 100
+            vf_o, tt_o, ct_o, e_o, r_o = oracle.vcal_vignette_step(images, p2x, p2y, pc_o, vf_o, oth2)
+            vf_r, tt_r, ct_r, e_r, r_r = ref.vignette_step(images, p2x, p2y, gw, gh, pc_r, vf_r, oth2)
+            assert bits_equal(tt_o, tt_r) and bits_equal(ct_o, ct_r) and bits_equal(vf_o, vf_r), (seed, it, "vignette")
+            assert e_o == e_r and r_o == r_r
+        assert np.nanmax(vf_o) == 1.0 and np.isnan(pc_o).sum() < gw * gh // 2
+
+
+@pytest.mark.gpu
+def test_gpu_steps_against_oracle(oracle):
+    import torch
+
+    from mono_dataset_code_amd import capi
+
+    ctx = capi.Context(0)
+    st = torch.cuda.current_stream().cuda_stream
+    for seed, shape in ((0, {}), (1, dict(n=9, wI=160, hI=120, gw=140, gh=110))):
+        images, p2x, p2y, gw, gh = problem(seed, **shape)
+        n, hI, wI = images.shape
+        d_img, d_x, d_y = (torch.from_numpy(a).cuda() for a in (images, p2x, p2y))
+        pc = np.zeros(gw * gh, np.float32)
+        vf = np.ones(hI * wI, np.float32)
+        d_pc, d_vf = torch.from_numpy(pc).cuda(), torch.from_numpy(vf).cuda()
+        for it in range(6):
+            oth2 = 10000 * 10000 if it < 3 else 15 * 15
+            pc_o, ff_o, fc_o, e_o, r_o = oracle.vcal_plane_step(images, p2x, p2y, pc, vf, oth2)
+            ff, fc, e, r = ctx.vcal_plane_step(d_img, d_x, d_y, d_pc, d_vf, oth2, st)
+            torch.cuda.synchronize()
+            assert bits_equal(ff.cpu().numpy(), ff_o) and bits_equal(fc.cpu().numpy(), fc_o), (seed, it)
+            assert bits_equal(d_pc.cpu().numpy(), pc_o) and r == r_o and abs(e - e_o) <= 1e-9 * abs(e_o)
+            pc = pc_o
+            vf_o, tt_o, ct_o, e_o, r_o = oracle.vcal_vignette_step(images, p2x, p2y, pc, vf, oth2)
+            tt, ct, e, r = ctx.vcal_vignette_step(d_img, d_x, d_y, d_pc, d_vf, oth2, st)
+            torch.cuda.synchronize()
+            for got, want in ((tt.cpu().numpy(), tt_o), (ct.cpu().numpy(), ct_o), (d_vf.cpu().numpy(), vf_o)):
+                assert np.array_equal(np.isnan(got), np.isnan(want))
+                m = ~np.isnan(want)
+                assert np.allclose(got[m], want[m], rtol=1e-5, atol=1e-6), (seed, it, np.abs(got[m] - want[m]).max())
+            assert r == r_o and abs(e - e_o) <= 1e-6 * abs(e_o) + 1e-6
+            # the next iteration continues from the GPU's own (tolerance-equal) factors on both sides
+            vf = d_vf.cpu().numpy().copy()
