@@ -101,20 +101,38 @@ def build_multi(force=False):
     return LIB_MULTI
 
 
+def build_host_sanitize(out):
+    """tests/native/host_sanitize.cpp + the host sources under AddressSanitizer and UndefinedBehaviorSanitizer
+    (tests/test_sanitize.py).  The HIP side is the normal libmdc_hip.so, not instrumented."""
+    build_hip()
+    src = [os.path.join(ROOT, "tests", "native", "host_sanitize.cpp")] + HOST_SOURCES
+    _run(["g++", "-O1", "-g", "-std=c++11", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+          "-fno-omit-frame-pointer", "-Wall", "-I" + INC, "-I" + os.path.join(INC, "mono_dataset_code"), "-I" + HOST,
+          "-I" + eigen_include()] + src + ["-L" + PKG, "-lmdc_hip", "-Wl,-rpath," + PKG, "-lz", "-lpthread", "-o", out])
+    return out
+
+
 def build_variant(name, defines):
     """Experimental build of libmdc_hip with -D switches (see MDC_EXP_* in mdc_kernels.hip);
     loaded by tools/sweep.py --lib.  Lands in mono_dataset_code_amd/variants/."""
     d = os.path.join(PKG, "variants")
     os.makedirs(d, exist_ok=True)
     out = os.path.join(d, "libmdc_hip_%s.so" % name)
-    _run([hipcc()] + HIP_FLAGS + ["-I" + INC] + ["-D" + x for x in defines] + HIP_SOURCES + ["-o", out])
+    if _stale(out, HIP_DEPS):
+        _run([hipcc()] + HIP_FLAGS + ["-I" + INC] + ["-D" + x for x in defines] + HIP_SOURCES + ["-o", out])
     return out
+
+
+def build_debug():
+    """The bounds-checking build of the kernels (tests/test_gpu_debug.py); travels to the GPU box like the product build."""
+    return build_variant("debug", ["MDC_DEBUG_BOUNDS=1"])
 
 
 def build_all(force=False):
     build_hip(force)
     build_host(force)
     build_multi(force)
+    build_debug()
     return LIB_HIP, LIB_HOST, LIB_MULTI
 
 

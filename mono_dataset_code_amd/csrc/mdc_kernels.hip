@@ -45,6 +45,23 @@ constexpr int kLutBytes = 256 * kLutRep * 4;
 #define MDC_EXP_SKIP_LOAD 0   // diagnosis: every frame re-stages frame 0 (L2 hits) -> write side alone
 #endif
 
+// Debug build (mono_dataset_code_amd/build.py:build_variant("debug", ["MDC_DEBUG_BOUNDS=1"]), tests/test_gpu_debug.py):
+// every tap, staging destination and gather index is checked against its buffer; a violation traps the kernel
+// (the launch then fails with a HIP error instead of reading or writing out of bounds silently).
+#ifndef MDC_DEBUG_BOUNDS
+#define MDC_DEBUG_BOUNDS 0
+#endif
+#if MDC_DEBUG_BOUNDS
+#define MDC_CHECK(cond)               \
+  do {                                \
+    if (!(cond)) __builtin_trap();    \
+  } while (0)
+#else
+#define MDC_CHECK(cond) \
+  do {                  \
+  } while (0)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Replicate the 256-entry LUT kLutRep times so that lane l reads replica l%32:
@@ -193,6 +210,7 @@ __global__ __launch_bounds__(256) void remap_gather_u8_kernel(const uint8_t* __r
   const bool black = xx < 0;
   Bilin b = bilin_of(black ? 0.f : xx, black ? 0.f : yy);
   const int s = b.xi + b.yi * a.in_w;
+  MDC_CHECK(black || (b.xi >= 0 && b.yi >= 0 && b.xi + 1 < a.in_w && b.yi + 1 < a.in_h));
   float v00 = 1.f, v10 = 1.f, v01 = 1.f, v11 = 1.f;
   if (VIG && !black) {
     v00 = a.vinv[s];
@@ -229,6 +247,7 @@ __global__ __launch_bounds__(256) void remap_gather_f32_kernel(const float* __re
   const bool black = xx < 0;
   Bilin b = bilin_of(black ? 0.f : xx, black ? 0.f : yy);
   const int s = b.xi + b.yi * a.in_w;
+  MDC_CHECK(black || (b.xi >= 0 && b.yi >= 0 && b.xi + 1 < a.in_w && b.yi + 1 < a.in_h));
   const int f0 = blockIdx.y * fpb;
   const int f1 = min(nframes, f0 + fpb);
   for (int f = f0; f < f1; f++) {
@@ -317,7 +336,7 @@ struct TileThread {
 
 template <bool VIG, bool BLACK, bool F32, bool LEAN, int B>
 __device__ __forceinline__ void tile_compute(const TileThread& t, lds_u8_ptr w, lds_f32_ptr my_lut, float* dst,
-                                             uint32_t out_bytes, uint32_t row_bytes, float (&res)[4]) {
+                                             uint32_t out_bytes, uint32_t row_bytes, float (&res)[4], int win_bytes) {
 #if __HIP_DEVICE_COMPILE__  // buffer / LDS-DMA builtins exist in the device pass only
   const auto ro = MDC_FRAME_RSRC(dst, out_bytes);
   // Outputs are processed B at a time: all their byte taps are issued, then all their LUT reads, then the
@@ -339,6 +358,9 @@ __device__ __forceinline__ void tile_compute(const TileThread& t, lds_u8_ptr w, 
       off1[u] = LEAN ? (int)(tap >> 16) : t.off1[j];
       bw[u] = t.bl[j];
       if (LEAN) bilin_weights(bw[u], fx, fy);
+      // both tap pairs lie inside the window buffer (the host plan's promise)
+      MDC_CHECK(off0[u] >= 0 && off1[u] >= 0 && off0[u] + (F32 ? 8 : 2) <= win_bytes && off1[u] + (F32 ? 8 : 2) <= win_bytes);
+      MDC_CHECK(!F32 || ((off0[u] | off1[u]) & 3) == 0);
     }
     float tv[B][4];  // t00 t10 t01 t11
     if (F32) {  // float frames (undistort<float>): the taps are the staged floats themselves
@@ -474,9 +496,11 @@ __device__ __forceinline__ void stage_window(const uint8_t* src, uint32_t in_byt
   const auto ri = MDC_FRAME_RSRC(src, in_bytes);
 #pragma unroll
   for (int k = 0; k < R; k++)
-    if (goff[k] != kOutside)
+    if (goff[k] != kOutside) {
+      MDC_CHECK(goff[k] + 16u <= in_bytes && (goff[k] & 15u) == 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (lds_void_ptr)(win + (k * NT + wave * 64) * 16), 16, goff[k], 0,
                                                0, kLoadAux);
+    }
   // The hand-counted vmcnt allowances below rely on the issue order "DMA group, then the frame's
   // stores": nothing may be scheduled across this point (the DMA and the stores use different
   // descriptors, so the compiler sees no dependence of its own).
@@ -560,7 +584,7 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
     stage_window<R, NT>(src + min(f + D, last) * in_step, in_bytes, w[D], goff, wave);
 #endif
     float res[4];
-    tile_compute<VIG, BLACK, F32, (NT >= 960), ((NT >= 960 || PYR) ? 2 : 4)>(t, w[0], my_lut, dst, out_bytes, row_bytes, res);
+    tile_compute<VIG, BLACK, F32, (NT >= 960), ((NT >= 960 || PYR) ? 2 : 4)>(t, w[0], my_lut, dst, out_bytes, row_bytes, res, win_bytes);
     if (PYR)
       pyramid_levels12(t, res, py, f_first + (long long)f * fstep, l1_bytes, l2_bytes, s_pyr + (f & 1) * G * L2W + pyr_slot,
                        tid & 63);
@@ -696,6 +720,7 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
     return;
   }
   const int rounds = (nch + NT - 1) / NT;  // workgroup-uniform
+  MDC_CHECK(nch * 16 <= p.win_bytes && rounds <= RMAX && (goff[0] == kOutside) == (tid >= nch));
 #define MDC_TILE_RUN(R_)                                                                                              \
   tile_frames<VIG, BLACK, PYR, F32, R_, TW, NT, NBUF>(t, src, dst, in_bytes, out_bytes, nf, nch, goff, s_win, p.win_bytes, \
                                              my_lut, tid, py, (long long)f0, fstep, p3byte, (uint32_t)a.out_w * 4u)

@@ -1,0 +1,80 @@
+"""ASan + UBSan over the host layer: tests/native/host_sanitize.cpp is compiled together with
+the host sources under -fsanitize=address,undefined and run on valid, malformed, truncated and bit-flipped
+calibration files, images and zip archives, plus the reader's decode pool.  No GPU involved."""
+import io
+import os
+import subprocess
+import zipfile
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from test_reader_cpu import make_sequence, textured
+
+
+def test_host_layer_under_asan_ubsan(tmp_path):
+    from mono_dataset_code_amd import build, synth
+
+    exe = str(tmp_path / "host_sanitize")
+    try:
+        build.build_host_sanitize(exe)
+    except RuntimeError as e:
+        pytest.skip("sanitizer build unavailable: %s" % e)
+    root = tmp_path / "fix"
+    for d in ("images_any", "calib", "vignettes", "zips", "sequences"):
+        (root / d).mkdir(parents=True)
+    img = textured(70, 90, 1)
+    Image.fromarray(img).save(root / "images_any" / "a.png")
+    Image.fromarray(img).save(root / "images_any" / "b.jpg", quality=85)
+    Image.fromarray(img).save(root / "images_any" / "c_opt.jpg", quality=40, optimize=True)
+    Image.fromarray(img).save(root / "images_any" / "d_rst.jpg", quality=90, restart_marker_blocks=5)
+    Image.fromarray(np.stack([img, img[::-1], 255 - img], -1)).save(root / "images_any" / "e_color420.jpg", quality=80, subsampling=2)
+    Image.fromarray(img).save(root / "images_any" / "f_prog.jpg", progressive=True)
+    Image.fromarray(img.astype(np.uint16) << 8).save(root / "images_any" / "g16.png")
+    open(root / "images_any" / "h.pgm", "wb").write(b"P5\n# c\n90 70\n255\n" + img.tobytes())
+    open(root / "images_any" / "i.pgm", "wb").write(b"P5 99999 99999 255\n" + bytes(100))
+    open(root / "images_any" / "j.bin", "wb").write(os.urandom(3000))
+    # calibration files: valid variants + malformed ones (as tests/test_tables_vs_ref.py uses)
+    cams = {"camera_ok.txt": "0.349153 0.436593 0.493140 0.499021 0.933271\n48 32\ncrop\n30 20\n",
+            "camera_full.txt": "0.349153 0.436593 0.493140 0.499021 0.933271\n48 32\nfull\n30 20\n",
+            "camera_none.txt": "0.349153 0.436593 0.493140 0.499021 0.933271\n48 32\nnone\n30 20\n",
+            "camera_explicit.txt": "0.5 0.6 0.5 0.5 0\n48 32\n0.4 0.53 0.5 0.5 0\n31 21\n",
+            "camera_short.txt": "0.349153 0.436593\n", "camera_empty.txt": "", "camera_words.txt": "a b c d e\nx y\ncrop\n1 1\n",
+            "camera_huge.txt": "0.3 0.4 0.5 0.5 0.9\n48 32\ncrop\n0 0\n", "camera_neg.txt": "0.3 0.4 0.5 0.5 0.9\n-5 32\ncrop\n30 20\n"}
+    for k, v in cams.items():
+        open(root / "calib" / k, "w").write(v)
+    good = " ".join("%.6f" % (255.0 * (i / 255.0) ** 2.2 + 0.01 * i) for i in range(256))
+    for k, v in {"pcalib_ok.txt": good + "\n", "pcalib_255.txt": " ".join(good.split()[:255]) + "\n", "pcalib_flat.txt": " ".join(["1.0"] * 256) + "\n",
+                 "pcalib_empty.txt": "", "pcalib_text.txt": "hello world\n"}.items():
+        open(root / "calib" / k, "w").write(v)
+    v16 = np.asarray(synth.vignette_image(48, 32, 16)).reshape(32, 48).astype(np.uint16)
+    synth.write_png_gray(str(root / "vignettes" / "v16.png"), v16)
+    synth.write_png_gray(str(root / "vignettes" / "v8.png"), (v16 >> 8).astype(np.uint8))
+    synth.write_png_gray(str(root / "vignettes" / "wrong_size.png"), np.asarray(synth.vignette_image(40, 32, 16)).reshape(32, 40).astype(np.uint16))
+    open(root / "vignettes" / "garbage.png", "wb").write(b"\x89PNG\r\n\x1a\n" + os.urandom(200))
+    # zips
+    blobs = [open(root / "images_any" / n, "rb").read() for n in ("a.png", "b.jpg")]
+    for name, method in (("stored.zip", zipfile.ZIP_STORED), ("deflated.zip", zipfile.ZIP_DEFLATED)):
+        with zipfile.ZipFile(root / "zips" / name, "w", method) as z:
+            for i, b in enumerate(blobs):
+                z.writestr("%02d.bin" % i, b)
+    whole = open(root / "zips" / "deflated.zip", "rb").read()
+    open(root / "zips" / "truncated.zip", "wb").write(whole[: len(whole) * 2 // 3])
+    open(root / "zips" / "tail_only.zip", "wb").write(whole[-60:])
+    flipped = bytearray(whole)
+    flipped[len(whole) // 3] ^= 0xFF
+    open(root / "zips" / "flipped.zip", "wb").write(bytes(flipped))
+    open(root / "zips" / "garbage.zip", "wb").write(os.urandom(500))
+    # sequences (folder + zip), one with a corrupt frame
+    frames = [textured(32, 48, s) for s in range(6)]
+    for name, zipped, fmt in (("seq_png", False, "png"), ("seq_zip_jpg", True, "jpg")):
+        (root / "sequences" / name).mkdir()
+        make_sequence(str(root / "sequences" / name), frames, zipped, fmt)
+    open(root / "sequences" / "seq_png" / "images" / "00003.png", "wb").write(b"\x89PNG\r\n\x1a\n" + os.urandom(64))
+
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, str(root)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
+    tail = r.stdout[-4000:]
+    assert "AddressSanitizer" not in r.stdout and "runtime error" not in r.stdout, tail
+    assert r.returncode == 0 and "HOST_SANITIZE_OK" in r.stdout, tail
