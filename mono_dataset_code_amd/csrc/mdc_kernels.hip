@@ -720,7 +720,7 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
     return;
   }
   const int rounds = (nch + NT - 1) / NT;  // workgroup-uniform
-  MDC_CHECK(nch * 16 <= p.win_bytes && rounds <= RMAX && (goff[0] == kOutside) == (tid >= nch));
+  MDC_CHECK(nch * 16 <= p.win_bytes && rounds <= RMAX && (tid < nch || goff[0] == kOutside));
 #define MDC_TILE_RUN(R_)                                                                                              \
   tile_frames<VIG, BLACK, PYR, F32, R_, TW, NT, NBUF>(t, src, dst, in_bytes, out_bytes, nf, nch, goff, s_win, p.win_bytes, \
                                              my_lut, tid, py, (long long)f0, fstep, p3byte, (uint32_t)a.out_w * 4u)

@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--lib", default="", help="(compat) single alternative build")
     ap.add_argument("--rows", default="32")
     ap.add_argument("--cols", default="64", help="output tile columns: 64 or 128")
+    ap.add_argument("--pad", default="0", help="LDS row pitch padded to 128 bytes: 0 / 1")
     ap.add_argument("--order", default="0", help="tile placement: 0 bands, 1 whole rows per XCD, 2 identity")
     ap.add_argument("--sched", default="-1", help="frame assignment: -1 library default, 0 consecutive runs, 1 interleaved")
     ap.add_argument("--nbuf", default="0", help="LDS window buffers (0 = automatic)")
@@ -104,7 +105,7 @@ def main():
     alg = (int(info.src_bbox_bytes) + npo * 4) if a.workload == "fused" else npi * 5
     kmap = {"tiled": capi.KERNEL_TILED, "gather": capi.KERNEL_GATHER, "auto": capi.KERNEL_AUTO}
     ints = lambda x: [int(v) for v in x.split(",")]  # noqa: E731
-    variants = list(itertools.product(libs, a.kernel.split(","), ints(a.fpb), ints(a.rows), ints(a.order), ints(a.sched), ints(a.nbuf), ints(a.cols)))
+    variants = list(itertools.product(libs, a.kernel.split(","), ints(a.fpb), ints(a.rows), ints(a.order), ints(a.sched), ints(a.nbuf), ints(a.cols), ints(a.pad)))
     times = {v: [] for v in variants}
     # DVFS: the first ~30 ms after an idle period run ~15 % slow (profiles/r01_dvfs_warmup_curve.txt)
     m0, c0 = ctxs[libs[0]]
@@ -116,6 +117,7 @@ def main():
             m, ctx = ctxs[v[0]]
             ctx.set_option(m.OPT_KERNEL, kmap[v[1]])
             ctx.set_option(m.OPT_FRAMES_PER_BLOCK, v[2])
+            try_set(m, ctx, "OPT_LDS_ROW_PAD", v[8])
             try_set(m, ctx, "OPT_TILE_COLS", v[7])
             try_set(m, ctx, "OPT_TILE_ROWS", v[3])
             try_set(m, ctx, "OPT_TILE_ORDER", v[4])
@@ -131,11 +133,11 @@ def main():
             torch.cuda.synchronize()
             if r:
                 times[v].append(e0.elapsed_time(e1) / a.iters)
-    print("%-28s %-7s %5s %4s %4s %3s %3s %3s %10s %10s %9s %7s" % ("lib", "kernel", "fpb", "cols", "rows", "ord", "sch", "buf", "median_ms", "min_ms", "GB/s", "frac8T"))
+    print("%-28s %-7s %5s %4s %4s %3s %3s %3s %3s %10s %10s %9s %7s" % ("lib", "kernel", "fpb", "cols", "rows", "ord", "sch", "buf", "pad", "median_ms", "min_ms", "GB/s", "frac8T"))
     for v in variants:
         med, mn = float(np.median(times[v])), float(np.min(times[v]))
         gbs = alg * B / (med * 1e-3) / 1e9
-        print("%-28s %-7s %5d %4d %4d %3d %3d %3d %10.4f %10.4f %9.1f %7.3f" % (os.path.basename(v[0])[-28:], v[1], v[2], v[7], v[3], v[4], v[5], v[6], med, mn, gbs, gbs / 8000), flush=True)
+        print("%-28s %-7s %5d %4d %4d %3d %3d %3d %3d %10.4f %10.4f %9.1f %7.3f" % (os.path.basename(v[0])[-28:], v[1], v[2], v[7], v[3], v[4], v[5], v[6], v[8], med, mn, gbs, gbs / 8000), flush=True)
 
 
 if __name__ == "__main__":
