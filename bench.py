@@ -333,23 +333,29 @@ def main():
     if rank == 0 and not args.no_ceiling:
         wbytes = min(alg_write * B, d_out.numel() * 4)
         rbytes = min(alg_read * B, d_in.numel()) // 16 * 16
-        reps = 30
-        cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for _ in range(5):
-            ctx.ceiling_mix(d_in.data_ptr(), rbytes, d_out.data_ptr(), wbytes, 16384, stream)
-        for a, b in cev:
-            a.record()
-            ctx.ceiling_mix(d_in.data_ptr(), rbytes, d_out.data_ptr(), wbytes, 16384, stream)
-            b.record()
-        torch.cuda.synchronize()
-        cms = np.array([a.elapsed_time(b) for a, b in cev])
+        reps = 12
+        best = None
+        for blocks, span in ((4096, 0), (16384, 0), (65536, 0), (4096, 1), (16384, 1), (65536, 1)):
+            cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for _ in range(3):
+                ctx.ceiling_mix(d_in.data_ptr(), rbytes, d_out.data_ptr(), wbytes, blocks, span, stream)
+            for a, b in cev:
+                a.record()
+                ctx.ceiling_mix(d_in.data_ptr(), rbytes, d_out.data_ptr(), wbytes, blocks, span, stream)
+                b.record()
+            torch.cuda.synchronize()
+            c = np.array([a.elapsed_time(b) for a, b in cev])
+            if best is None or np.median(c) < np.median(best[0]):
+                best = (c, blocks, span)
+        cms, cblocks, cspan = best
         # the ceiling kernel wrote over the outputs: redo the step so that parity below checks real results
         step()
         torch.cuda.synchronize()
         scale = (alg_read * B + alg_write * B) / float(rbytes + wbytes)  # pyramid: levels are separate buffers, the stream writes d_out only
         ceiling = {"ms_median": round(float(np.median(cms)) * scale, 4), "ms_min": round(float(cms.min()) * scale, 4),
                    "read_bytes": alg_read * B, "write_bytes": alg_write * B,
-                   "what": "linear 16-B reads + wave-contiguous nt dword writes of the launch's ALGORITHMIC bytes, 16384 workgroups, same process"}
+                   "what": "linear 16-B reads + wave-contiguous nt dword writes of the launch's ALGORITHMIC bytes, same process; "
+                           "fastest of 6 launch shapes: %d workgroups, %s" % (cblocks, "contiguous span per workgroup" if cspan else "grid-stride")}
 
     if rank == 0:
         # spot parity of the benchmarked launch against the C oracle (2 frames; pyramid: every level)

@@ -235,11 +235,12 @@ int mdc_synth_frames_device(mdc_ctx* ctx, uint8_t* d_out, int64_t first_frame, i
  * and options, spelt as rocprofv3 prints it without namespaces -- so a recorded PMC figure can be matched to
  * the kernel that actually ran.
  * mdc_ceiling_mix_device: a linear, arithmetic-free stream reading read_bytes from d_read (16-byte aligned)
- * while writing write_bytes to d_write with `blocks` workgroups of 256 -- the rate the memory system of THIS
- * box gives to a kernel's traffic mix, to normalise the kernel's own rate against. */
+ * while writing write_bytes to d_write with `blocks` workgroups of 256 (span = 0: grid-stride; 1: each workgroup
+ * walks its own contiguous span) -- the rate the memory system of THIS box gives to a kernel's traffic mix, to
+ * normalise the kernel's own rate against; bench.py takes the fastest of several (blocks, span) settings. */
 int mdc_describe_launch(mdc_ctx* ctx, unsigned flags, int pyramid_levels, char* buf, size_t cap);
 int mdc_ceiling_mix_device(mdc_ctx* ctx, const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes,
-                           int blocks, void* stream);
+                           int blocks, int span, void* stream);
 
 /* ---- calibration hand-over between ranks (multi-GPU) ------------------------ */
 

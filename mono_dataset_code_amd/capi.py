@@ -120,7 +120,7 @@ def hip_lib():
         old_build = LIB_HIP_PATH != os.path.join(_PKG, "libmdc_hip.so")  # tools/sweep.py --libs: A/B against earlier builds
         if not old_build or hasattr(L, "mdc_describe_launch"):
             L.mdc_describe_launch.argtypes = [_vp, C.c_uint, _i, C.c_char_p, _sz]
-            L.mdc_ceiling_mix_device.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int64, _i, _vp]
+            L.mdc_ceiling_mix_device.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int64, _i, _i, _vp]
             L.mdc_vcal_plane_step_device.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]
             L.mdc_vcal_vignette_step_device.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]
         for n in HIP_SYMBOLS:
@@ -370,8 +370,8 @@ class Context:
         self._chk(self._L.mdc_describe_launch(self._h, flags, pyramid_levels, buf, 256))
         return buf.value.decode()
 
-    def ceiling_mix(self, d_read, read_bytes, d_write, write_bytes, blocks=16384, stream=0):
-        self._chk(self._L.mdc_ceiling_mix_device(self._h, d_read, read_bytes, d_write, write_bytes, blocks, stream if stream else None))
+    def ceiling_mix(self, d_read, read_bytes, d_write, write_bytes, blocks=16384, span=0, stream=0):
+        self._chk(self._L.mdc_ceiling_mix_device(self._h, d_read, read_bytes, d_write, write_bytes, blocks, span, stream if stream else None))
 
     def vcal_plane_step(self, d_images, d_p2x, d_p2y, d_plane_color, d_vig, oth2, stream=0):
         """torch tensors on the device; d_plane_color is updated in place -> (FF, FC, E, R)."""

@@ -515,7 +515,8 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
     const int fw = c->in_w > 0 ? c->in_w : c->rm_in_w, fh = c->in_h > 0 ? c->in_h : c->rm_in_h;
     if (fw <= 0 || fh <= 0) return fail(c, MDC_ERR_STATE, "frame size unknown: set the photometric tables or a remap first");
     const int64_t npix = (int64_t)fw * fh;
-    const int fpb = frames_per_block(c, nframes, (int)((npix + 4095) / 4096), 20000);  // measured best at ~8 frames per workgroup
+    int fpb = frames_per_block(c, nframes, (int)((npix + 4095) / 4096), 20000);  // measured best at 8 frames per workgroup,
+    if (!c->opt_fpb) fpb = std::min(fpb, 8);                                       // also for launches of thousands of frames
     MDC_HIP(c, launch_unmap(d_in, d_out, lut, vinv, npix, nframes, fpb, s));
     return MDC_OK;
   }
@@ -976,14 +977,14 @@ int mdc_describe_launch(mdc_ctx* c, unsigned flags, int pyramid_levels, char* bu
 }
 
 int mdc_ceiling_mix_device(mdc_ctx* c, const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes,
-                           int blocks, void* stream) {
+                           int blocks, int span, void* stream) {
   if (!c) return MDC_ERR_ARG;
   if (read_bytes < 0 || write_bytes < 0 || (read_bytes > 0 && !d_read) || (write_bytes > 0 && !d_write) || blocks <= 0 ||
       (reinterpret_cast<uintptr_t>(d_read) & 15) != 0)
     return fail(c, MDC_ERR_ARG, "mdc_ceiling_mix_device: bad argument");
   std::lock_guard<std::mutex> lk(c->mu);
   DeviceGuard dg(c->device);
-  MDC_HIP(c, launch_mix_ceiling(d_read, read_bytes, d_write, write_bytes, blocks, (hipStream_t)stream));
+  MDC_HIP(c, launch_mix_ceiling(d_read, read_bytes, d_write, write_bytes, blocks, span, (hipStream_t)stream));
   return MDC_OK;
 }
 

@@ -91,7 +91,7 @@ hipError_t launch_distort_points(float* d_x, float* d_y, int64_t n, const Distor
 
 // Bench utility: linear read of read_bytes interleaved with a linear write of write_bytes (no arithmetic).
 hipError_t launch_mix_ceiling(const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes, int blocks,
-                              hipStream_t s);
+                              int span, hipStream_t s);
 
 // vignetteCalib solver half-iterations (src/main_vignetteCalib.cpp:400-448, :455-527); d_er = {E, R}
 hipError_t launch_vcal_plane_step(const float* d_images, const float* d_p2x, const float* d_p2y, int n, int wI, int hI, int np,

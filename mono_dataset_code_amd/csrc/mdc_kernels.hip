@@ -842,23 +842,32 @@ __global__ __launch_bounds__(256) void synth_kernel(uint8_t* __restrict__ out, l
 // Stores are wave-contiguous dwords with the nontemporal hint (the fastest store form measured on this
 // memory system, tools/hbm_mix.hip), loads wave-contiguous 16-byte.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// SPAN = false: grid-stride (thread t touches element t, t+T, ...); SPAN = true: every workgroup walks its own
+// contiguous span of the write range (and of the read range), as a tiled kernel's workgroups do.
+template <bool SPAN>
 __global__ __launch_bounds__(256) void mix_ceiling_kernel(const u32x4* __restrict__ a, float* __restrict__ b,
                                                           unsigned long long n_r, unsigned long long n_w) {
-  const unsigned long long tid = (unsigned long long)blockIdx.x * 256 + threadIdx.x, T = (unsigned long long)gridDim.x * 256;
-  const unsigned long long iters = (n_w + T - 1) / T;
-  unsigned long long racc = 0, rk = tid;
+  const unsigned long long G = gridDim.x, T = G * 256;
+  const unsigned long long iters = SPAN ? (n_w + T - 1) / T : (n_w + T - 1) / T;
+  // SPAN: block g owns writes [g*iters*256, (g+1)*iters*256) and reads [g*riters*256, ...)
+  const unsigned long long riters = (n_r + T - 1) / T;
+  const unsigned long long w0 = SPAN ? (unsigned long long)blockIdx.x * iters * 256 + threadIdx.x : (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long r0 = SPAN ? (unsigned long long)blockIdx.x * riters * 256 + threadIdx.x : (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long step = SPAN ? 256 : T;
+  unsigned long long racc = 0, rk = r0, rdone = 0;
   uint32_t x = 0;
   for (unsigned long long it = 0; it < iters; it++) {
     racc += n_r;  // one chunk is read every n_w / n_r stores, the same iteration for every thread
     if (racc >= n_w) {
       racc -= n_w;
-      if (rk < n_r) {
-        const u32x4 v = a[rk];
+      if (rk < n_r && rdone < riters) {
+        const u32x4 v = __builtin_nontemporal_load(a + rk);  // streamed once: the faster load form (tools/hbm_mix.hip)
         x ^= v.x ^ v.y ^ v.z ^ v.w;
       }
-      rk += T;
+      rk += step;
+      rdone++;
     }
-    const unsigned long long i = it * T + tid;
+    const unsigned long long i = w0 + it * step;
     if (i < n_w) __builtin_nontemporal_store(__uint_as_float(x & 0x3fffffffu), b + i);
   }
 }
@@ -997,10 +1006,11 @@ hipError_t launch_distort_points(float* d_x, float* d_y, int64_t n, const Distor
 }
 
 hipError_t launch_mix_ceiling(const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes, int blocks,
-                              hipStream_t s) {
+                              int span, hipStream_t s) {
   if (write_bytes <= 0) return hipSuccess;
-  mix_ceiling_kernel<<<blocks, 256, 0, s>>>(reinterpret_cast<const u32x4*>(d_read), d_write,
-                                            (unsigned long long)(read_bytes / 16), (unsigned long long)(write_bytes / 4));
+  const unsigned long long n_r = (unsigned long long)(read_bytes / 16), n_w = (unsigned long long)(write_bytes / 4);
+  if (span) mix_ceiling_kernel<true><<<blocks, 256, 0, s>>>(reinterpret_cast<const u32x4*>(d_read), d_write, n_r, n_w);
+  else mix_ceiling_kernel<false><<<blocks, 256, 0, s>>>(reinterpret_cast<const u32x4*>(d_read), d_write, n_r, n_w);
   return hipGetLastError();
 }
 
