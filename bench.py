@@ -109,6 +109,25 @@ def traffic_from_profiles(kernel_name, frames_per_launch):
     return None, None
 
 
+def usable_cpus():
+    """Hardware threads, cut down to the container's CFS quota (cgroup v2 cpu.max / v1 cfs_quota_us): more busy
+    threads than that are throttled, so this is the honest "cores" of the CPU baseline."""
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(round(float(q) / float(p)))))
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, int(round(q / p))))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def host_description():
     model = platform.processor() or "unknown"
     try:
@@ -133,9 +152,10 @@ def cpu_baseline(args, calib_dir, rect):
     from mono_dataset_code_amd import synth
     from oracle import loader
 
-    cores = os.cpu_count() or 1
+    hw_threads = os.cpu_count() or 1
+    cores = usable_cpus()  # = hardware threads unless the container has a CPU quota
     npix = IN_W * IN_H
-    nframes = 2 * cores
+    nframes = max(512, 2 * cores)  # 670 MB of raw frames: beyond the host's last-level cache (2 x 256 MB), as a sequence is
     frames = synth.noise_frames(0, nframes, npix)
     if loader.have_ref() or os.path.isdir(loader.REFERENCE_ROOT):
         kind = "reference"
@@ -170,14 +190,27 @@ def cpu_baseline(args, calib_dir, rect):
 
     allc = rate(nframes, cores, rect, args.cpu_seconds)
     model, cc = host_description()
-    out = {"value": allc["value"], "unit": "Mpix/s", "cores": cores, "kind": kind,
-           "sample": "%s, %d threads, flags g+v+o%s" % (allc["sample"], cores, "+rectify" if rect else ""),
-           "fps": allc["fps"], "cpu_model": model, "compiler": cc + " -O3 -DNDEBUG -std=c++0x (no -march, no FMA)"}
+    if kind == "reference" and hw_threads > cores:  # also with every hardware thread busy (the quota throttles them): report the better
+        over = rate(nframes, hw_threads, rect, 3.0)
+        over["note"] = "%d threads on %d hardware threads under a %d-CPU cgroup quota" % (hw_threads, hw_threads, cores)
+        if over["value"] > allc["value"]:
+            allc, over = over, allc
+            cores_used = hw_threads
+        else:
+            cores_used = cores
+    else:
+        over, cores_used = None, cores
+    out = {"value": allc["value"], "unit": "Mpix/s", "cores": cores_used, "kind": kind,
+           "sample": "%s, %d threads, flags g+v+o%s" % (allc["sample"], allc["threads"], "+rectify" if rect else ""),
+           "fps": allc["fps"], "cpu_model": model, "compiler": cc + " -O3 -DNDEBUG -std=c++0x (no -march, no FMA)",
+           "hardware_threads": hw_threads, "cpu_quota": cores if cores < hw_threads else None}
+    if over is not None:
+        out["other_thread_count"] = {"value": over["value"], "fps": over["fps"], "threads": over["threads"], "sample": over["sample"]}
     if kind == "reference":
         one = rate(16, 1, rect, 3.0)
         out["one_thread_as_shipped"] = {"value": one["value"], "unit": "Mpix/s", "fps": one["fps"], "sample": one["sample"]}
         if rect:  # configs[1]'s CPU analogue: unMapImage only, full-size float output
-            ua = rate(nframes, cores, False, 3.0)
+            ua = rate(nframes, allc["threads"], False, 3.0)
             u1 = rate(16, 1, False, 2.0)
             out["unmap_only"] = {"all_cores": {"value": ua["value"], "fps": ua["fps"], "sample": ua["sample"]},
                                  "one_thread": {"value": u1["value"], "fps": u1["fps"], "sample": u1["sample"]}, "unit": "Mpix/s"}

@@ -12,7 +12,7 @@
 //     folder or straight out of images.zip (own zip reader) -- no OpenCV, no libzip;
 //   * the multi-threaded loader the reference's comment announces (:81) exists: a pool of decode
 //     threads prefetches the frames after the one just asked for, and getImages() runs a whole range
-//     through decode pool -> page-locked ring -> pipelined GPU chunks (mdc_process_frames_host).
+//     through decode pool -> ring of page-locked chunks -> pipelined GPU chunks (mdc_process_frames_host).
 //
 // Results are the reference's, bit for bit (tests/test_reader.py against the reference's own reader).
 // Like the reference's, an object is NOT re-entrant: one thread calls into it at a time.

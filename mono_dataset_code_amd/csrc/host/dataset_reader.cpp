@@ -5,12 +5,13 @@
 //   decode                          : own decoders (image_codecs.cpp), folder or images.zip (zip_reader.cpp),
 //                                     on a pool of worker threads, into page-locked buffers
 //   getImage                        : one mdc_process_host call into a pooled page-locked ExposureImage
-//   getImages                       : decode pool -> two page-locked half-rings -> mdc_process_frames_host
-//                                     per chunk; the pool decodes chunk k+1 while chunk k is on the GPU
+//   getImages                       : decode pool -> ring of page-locked chunks -> mdc_process_frames_host per chunk;
+//                                     the pool decodes the next chunks while chunk k is on the GPU
 #include "BenchmarkDatasetReader.h"
 
 #include <dirent.h>
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -96,8 +97,11 @@ struct DatasetReader::State {
   long cache_hits = 0, cache_misses = 0;  // frames found decoded (or being decoded) ahead / decoded by the caller itself
 
   // ring of getImages
-  static const int kChunk = 64;  // frames per GPU chunk = decode jobs in flight per half-ring
-  std::vector<HostBuffer> ring;  // 2 * kChunk frames (168 MB at 1280x1024, allocated on the first getImages)
+  // ring of getImages: kRing chunks of kChunk page-locked frame buffers.  Chunk k is on the GPU while the pool decodes
+  // chunks k+1 .. k+kRing-1 (up to 160 frames in flight): a decode thread that is slow on one frame delays only the
+  // chunk that frame is in, not the pipeline (two half-rings of 64 stalled on every straggler: 2.5-2.9 k frames/s)
+  static const int kChunk = 32, kRing = 6;
+  std::vector<HostBuffer> ring;  // kRing * kChunk frames (250 MB at 1280x1024, allocated on the first getImages)
 
   size_t frame_bytes() const { return (size_t)W * H; }
 
@@ -140,10 +144,31 @@ struct DatasetReader::State {
     }
   }
 
+  // CPUs this process may actually use: the hardware threads, cut down to the container's CFS quota if there is one
+  // (cgroup v2 cpu.max / v1 cpu.cfs_quota_us).  More decode threads than that only get throttled -- together with the
+  // HIP runtime's own threads (a box with 256 hardware threads and a 16-CPU quota decodes fastest with 16).
+  static int usable_cpus() {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (!hw) hw = 4;
+    double quota = 0, period = 0;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[64];
+      if (std::fscanf(f, "%63s %lf", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atof(q);
+      std::fclose(f);
+    } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+      if (std::fscanf(g, "%lf", &quota) != 1) quota = 0;
+      std::fclose(g);
+      if (FILE* h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (std::fscanf(h, "%lf", &period) != 1) period = 0;
+        std::fclose(h);
+      }
+    }
+    if (quota > 0 && period > 0) hw = std::min<unsigned>(hw, std::max(1u, (unsigned)(quota / period + 0.5)));
+    return (int)hw;
+  }
   int thread_count() const {
     if (want_threads > 0) return want_threads;
-    const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(hw ? hw : 4u, 64u));
+    return std::max(1, std::min(usable_cpus(), 64));
   }
   void start_pool() {
     if (!workers.empty()) return;
@@ -445,9 +470,9 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
     std::fprintf(stderr, "DatasetReader::getImages: %s\n", s.err.c_str());
     return 0;
   }
-  const int C = State::kChunk;
+  const int C = State::kChunk, RG = State::kRing;
   if (s.ring.empty()) {
-    s.ring.assign(2 * (size_t)C, HostBuffer());
+    s.ring.assign((size_t)RG * C, HostBuffer());
     for (auto& m : s.ring) m.alloc(s.frame_bytes());
   }
   s.start_pool();
@@ -458,20 +483,23 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
     for (int i = k * C; i < std::min(count, (k + 1) * C); i++) {
       Decode& d = rec[(size_t)i];
       d.id = first + i;
-      d.dst = s.ring[(size_t)((k & 1) * C + (i - k * C))].p;
+      d.dst = s.ring[(size_t)((k % RG) * C + (i - k * C))].p;
       d.cap = s.frame_bytes();
       s.submit(&d);
     }
     s.cv_job.notify_all();
   };
-  submit_chunk(0);
-  if (nchunks > 1) submit_chunk(1);
+  for (int k = 0; k < std::min(nchunks, RG); k++) submit_chunk(k);
   const unsigned flags = flag_word(rectify, removeGamma, removeVignette, nanOverexposed);
+  const bool trace = std::getenv("MDC_READER_TRACE") != 0;  // where a getImages call spends its time (stderr)
+  double t_wait = 0, t_gpu = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   int produced = 0;
   std::vector<const uint8_t*> src;
   std::vector<float*> dst;
   for (int k = 0; k < nchunks; k++) {
     const int i0 = k * C, i1 = std::min(count, (k + 1) * C);
+    const double tw = now();
     {
       std::unique_lock<std::mutex> lk(s.mu);
       s.cv_done.wait(lk, [&] {
@@ -480,6 +508,7 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
         return true;
       });
     }
+    t_wait += now() - tw;
     src.clear();
     dst.clear();
     for (int i = i0; i < i1; i++) {
@@ -497,7 +526,10 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
       dst.push_back(out[i]->image);
     }
     // chunk k on the GPU (uploads, kernels and downloads pipelined inside the call) while the pool decodes chunk k+1
-    if (!src.empty() && mdc_process_frames_host(s.gpu, src.data(), dst.data(), (int64_t)src.size(), flags) != MDC_OK) {
+    const double tg = now();
+    const int grc = src.empty() ? MDC_OK : mdc_process_frames_host(s.gpu, src.data(), dst.data(), (int64_t)src.size(), flags);
+    t_gpu += now() - tg;
+    if (grc != MDC_OK) {
       s.err = mdc_last_error(s.gpu);
       std::fprintf(stderr, "DatasetReader::getImages: %s\n", s.err.c_str());
       for (int i = i0; i < i1; i++) {
@@ -507,7 +539,10 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
     } else {
       produced += (int)src.size();
     }
-    if (k + 2 < nchunks) submit_chunk(k + 2);  // its half of the ring is free again
+    if (k + RG < nchunks) submit_chunk(k + RG);  // chunk k's buffers are free again
   }
+  if (trace)
+    std::fprintf(stderr, "DatasetReader::getImages: %d frames, %d threads: waited %.1f ms for the decoders, %.1f ms in the GPU calls\n",
+                 count, (int)s.workers.size(), t_wait * 1e3, t_gpu * 1e3);
   return produced;
 }

@@ -7,6 +7,7 @@
 //   reader_rate_X <sequence folder> <rgvo flags> <passes> [batch]
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -22,6 +23,9 @@ int main(int argc, char** argv) {
   const bool batch = argc > 4 && !std::strcmp(argv[4], "batch");
   DatasetReader* reader = new DatasetReader(folder);
   const int n = reader->getNumImages();
+#ifdef MDC_OWN_READER
+  if (const char* t = std::getenv("MDC_READER_THREADS")) reader->setDecodeThreads(std::atoi(t));
+#endif
   double checksum = 0;
   auto run = [&](int reps) {
     for (int p = 0; p < reps; p++) {
