@@ -2,6 +2,9 @@
 """Soak test of the tiled kernel's hand-placed vmcnt barriers: many launches on fresh data, every
 tile shape / window-buffer count, compared bit for bit with the gather kernel (which has no LDS
 staging and no barrier).  Any race between the LDS-DMA and the tap reads shows up as a mismatch.
+Every third iteration runs the FUSED PYRAMID on a 1280x1024 -> 1280x1024 remap and compares its levels with
+the stand-alone level passes over the same base (the level-3 hand-over goes through LDS across the per-frame
+barrier: a missing wait there shows up as a wrong level-3 pixel).
 usage: python tools/soak.py [iterations]"""
 import os
 import sys
@@ -14,31 +17,67 @@ import torch  # noqa: E402
 from mono_dataset_code_amd import capi, synth  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-d = synth.write_sequence_calibration(tempfile.mkdtemp(prefix="mdc_soak_"))
 so = os.dup(1)
 os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+d = synth.write_sequence_calibration(tempfile.mkdtemp(prefix="mdc_soak_"))
 fov = capi.UndistorterFOV(os.path.join(d, "camera.txt"))
 photo = capi.PhotometricUndistorter(os.path.join(d, "pcalib.txt"), os.path.join(d, "vignette.png"), 1280, 1024)
+d2 = synth.write_sequence_calibration(tempfile.mkdtemp(prefix="mdc_soak_pyr_"), synth.camera_lines(1280, 1024, 1280, 1024))
+fov2 = capi.UndistorterFOV(os.path.join(d2, "camera.txt"))
 import ctypes  # noqa: E402
 ctypes.CDLL(None).fflush(None)
 os.dup2(so, 1)
 ctx = capi.Context(0)
 ctx.bind(fov, photo)
+pyr = capi.Context(0)
+pyr.bind(fov2, photo)
 B, npi, npo = 512, 1280 * 1024, 640 * 480
+PB = 96  # frames of a pyramid launch (base 5.2 MB each)
 st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
 s = st.cuda_stream
 d_in = torch.empty(B * npi, dtype=torch.uint8, device="cuda")
 d_ref = torch.empty(B * npo, dtype=torch.float32, device="cuda")
 d_out = torch.empty(B * npo, dtype=torch.float32, device="cuda")
-configs = [(32, 2), (32, 3), (32, 4), (60, 2), (60, 3), (64, 2), (64, 3), (16, 2), (16, 4)]
+p_base = torch.empty(PB * npi, dtype=torch.float32, device="cuda")
+p_lv = [torch.empty(PB * (1280 >> l) * (1024 >> l), dtype=torch.float32, device="cuda") for l in (1, 2, 3)]
+p_ref = [torch.empty_like(t) for t in p_lv]
+configs = [(64, 32, 2), (64, 32, 3), (128, 16, 2), (64, 60, 2), (128, 32, 2), (64, 64, 2), (128, 16, 4), (64, 16, 2), (128, 32, 3), (64, 16, 4)]
+pyr_configs = [(128, 16, 0), (64, 32, 2), (128, 32, 2), (64, 64, 3), (64, 16, 4), (128, 16, 2)]
+
+
+def same(a, b):
+    if torch.equal(a.view(torch.int32), b.view(torch.int32)):
+        return True
+    return torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+
+
 bad = 0
 for it in range(iters):
     ctx.synth_frames(d_in.data_ptr(), it * B, B, npi, synth.SEED + it, s)
+    if it % 3 == 2:
+        cols, rows, nbuf = pyr_configs[(it // 3) % len(pyr_configs)]
+        pyr.set_option(capi.OPT_TILE_COLS, cols)
+        pyr.set_option(capi.OPT_TILE_ROWS, rows)
+        pyr.set_option(capi.OPT_WINDOW_BUFFERS, nbuf)
+        pyr.set_option(capi.OPT_FRAMES_PER_BLOCK, (0, 5, 12)[it % 3])
+        assert ", true, false," in pyr.describe_launch(15, 4), "the fused-pyramid instantiation must be the one that runs"
+        for rep in range(3):
+            for t in p_lv:
+                t.fill_(-7.0)
+            pyr.process_pyramid_batch(d_in.data_ptr(), p_base.data_ptr(), 4, [t.data_ptr() for t in p_lv], PB, 15, s)
+            pyr.pyramid_batch(p_base.data_ptr(), 1280, 1024, 4, [t.data_ptr() for t in p_ref], PB, s)
+            torch.cuda.synchronize()
+            for l, (a, b) in enumerate(zip(p_lv, p_ref)):
+                if not same(a, b):
+                    bad += 1
+                    print("PYRAMID MISMATCH iteration", it, "tile", cols, rows, "nbuf", nbuf, "level", l + 1, "rep", rep, flush=True)
+        continue
     ctx.set_option(capi.OPT_KERNEL, capi.KERNEL_GATHER)
     ctx.process_batch(d_in.data_ptr(), d_ref.data_ptr(), B, 15, s)
     ctx.set_option(capi.OPT_KERNEL, capi.KERNEL_TILED)
-    rows, nbuf = configs[it % len(configs)]
+    cols, rows, nbuf = configs[it % len(configs)]
+    ctx.set_option(capi.OPT_TILE_COLS, cols)
     ctx.set_option(capi.OPT_TILE_ROWS, rows)
     ctx.set_option(capi.OPT_WINDOW_BUFFERS, nbuf)
     ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, (0, 7, 33)[it % 3])
@@ -46,10 +85,9 @@ for it in range(iters):
         d_out.fill_(-7.0)
         ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), B, 15, s)
         torch.cuda.synchronize()
-        if not torch.equal(d_out.view(torch.int32), d_ref.view(torch.int32)):
-            nan_ok = torch.equal(torch.isnan(d_out), torch.isnan(d_ref)) and torch.equal(torch.nan_to_num(d_out), torch.nan_to_num(d_ref))
-            if not nan_ok:
-                bad += 1
-                print("MISMATCH iteration", it, "rows", rows, "nbuf", nbuf, "rep", rep, flush=True)
-print("soak: %d iterations x 4 launches x %d frames, %d mismatching launches" % (iters, B, bad))
+        if not same(d_out, d_ref):
+            bad += 1
+            print("MISMATCH iteration", it, "tile", cols, rows, "nbuf", nbuf, "rep", rep, flush=True)
+print("soak: %d iterations (2/3 fused x 4 launches x %d frames, 1/3 fused pyramid x 3 launches x %d frames), %d mismatching launches"
+      % (iters, B, PB, bad))
 sys.exit(1 if bad else 0)
