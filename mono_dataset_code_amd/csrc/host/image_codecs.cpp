@@ -146,6 +146,9 @@ struct Huff {
   uint16_t look[512];  // codes of <= 9 bits: (length << 8) | symbol, 0 = longer code
   int maxcode[18];     // largest code of length l (or -1), maxcode[17] = sentinel
   int valoff[17];      // vals index of the first code of length l minus that code
+  // AC tables only: for a 9-bit window that holds a whole (code, magnitude bits) pair: value << 8 | run << 4 | bits used;
+  // 0 = not such a window (long code, long magnitude, EOB or ZRL)
+  int16_t fast_ac[512];
 };
 
 bool build_huff(Huff& t, const unsigned char* bits /*[1..16] at bits[0..15]*/, const unsigned char* vals, int nvals) {
@@ -166,6 +169,16 @@ bool build_huff(Huff& t, const unsigned char* bits /*[1..16] at bits[0..15]*/, c
   }
   t.maxcode[17] = 0x7fffffff;
   t.present = k == nvals;
+  for (int w = 0; w < 512; w++) {
+    t.fast_ac[w] = 0;
+    const int e = t.look[w];
+    if (!e) continue;
+    const int len = e >> 8, rs = e & 255, run = rs >> 4, sz = rs & 15;
+    if (sz == 0 || len + sz > 9) continue;
+    int v = (w >> (9 - len - sz)) & ((1 << sz) - 1);  // the magnitude bits that follow the code inside the window
+    if (v < (1 << (sz - 1))) v += (int)((~0u) << sz) + 1;  // EXTEND
+    if (v >= -128 && v <= 127) t.fast_ac[w] = (int16_t)(v * 256 + run * 16 + (len + sz));
+  }
   return t.present;
 }
 
@@ -238,7 +251,12 @@ inline unsigned char clamp_sample(int x) {
   x += 128;
   return (unsigned char)(x < 0 ? 0 : (x > 255 ? 255 : x));
 }
-void idct_islow(const int* coef /* dequantised, natural order */, unsigned char* out, size_t stride) {
+void idct_islow(const int* coef /* dequantised, natural order */, unsigned char* out, size_t stride, bool dc_only) {
+  if (dc_only) {  // both passes collapse: DESCALE(dc << 2, 5) everywhere (the shortcuts of jidctint.c applied twice)
+    const unsigned char v = clamp_sample(descale((long)coef[0] * 4, 5));
+    for (int r = 0; r < 8; r++) memset(out + (size_t)r * stride, v, 8);
+    return;
+  }
   const long F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299,
              F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
   const int CB = 13, P1 = 2;
@@ -292,6 +310,10 @@ void idct_islow(const int* coef /* dequantised, natural order */, unsigned char*
   for (int r = 0; r < 8; r++) {
     const int* w = ws + r * 8;
     unsigned char* o = out + (size_t)r * stride;
+    if (!(w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7])) {  // jidctint.c's row shortcut: same value as the full pass
+      memset(o, clamp_sample(descale(w[0], 5)), 8);
+      continue;
+    }
     long z2 = w[2], z3 = w[6];
     long z1 = (z2 + z3) * F0_541;
     long tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
@@ -446,8 +468,21 @@ bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap
               if (t < 0 || t > 11) return fail(err, "JPEG: bad DC code");
               comp[c].pred += t ? extend(b.get(t), t) : 0;
               if (luma) coef[0] = comp[c].pred * q[0];
+              bool dc_only = true;
+              const Huff& act = ac[comp[c].ta];
               for (int i = 1; i < 64;) {
-                const int rs = decode_sym(b, ac[comp[c].ta]);
+                if (b.cnt < 16) b.fill();
+                const int fa = act.fast_ac[b.peek(9)];
+                if (fa) {  // code + magnitude in one lookup
+                  i += (fa >> 4) & 15;
+                  if (i > 63) return fail(err, "JPEG: coefficient index out of range");
+                  b.skip(fa & 15);
+                  if (luma) coef[kZigzag[i]] = (fa >> 8) * q[kZigzag[i]];
+                  dc_only = false;
+                  i++;
+                  continue;
+                }
+                const int rs = decode_sym(b, act);
                 if (rs < 0) return fail(err, "JPEG: bad AC code");
                 const int r = rs >> 4, sz = rs & 15;
                 if (sz == 0) {
@@ -459,11 +494,12 @@ bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap
                 if (i > 63) return fail(err, "JPEG: coefficient index out of range");
                 const int v = extend(b.get(sz), sz);
                 if (luma) coef[kZigzag[i]] = v * q[kZigzag[i]];
+                dc_only = false;
                 i++;
               }
               if (luma) {
                 const int bx = ncomp == 1 ? 0 : k % comp[c].h, by = ncomp == 1 ? 0 : k / comp[c].h;
-                idct_islow(coef, rows.data() + (size_t)by * 8 * pw + (size_t)x * mcu_w + (size_t)bx * 8, pw);
+                idct_islow(coef, rows.data() + (size_t)by * 8 * pw + (size_t)x * mcu_w + (size_t)bx * 8, pw, dc_only);
               }
             }
           }
