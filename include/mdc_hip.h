@@ -183,6 +183,15 @@ int mdc_pyramid_batch_device(mdc_ctx* ctx, const float* d_base, int w, int h, in
 int mdc_process_pyramid_batch_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_base, int levels,
                                      float* const* d_levels, int64_t nframes, unsigned flags, void* stream);
 
+/* DSO hand-off of one pyramid level (NOT in the reference: the per-level loop of DSO's
+ * FrameHessian::makeImages, definition in DESIGN.md section 5.5): for nframes images of w x h floats (level 0 = the
+ * output of mdc_process_batch_device, levels 1.. = mdc_process_pyramid_batch_device's) writes
+ *   d_dI                : nframes*w*h triples (I, dx, dy), dx = 0.5f*(I[i+1]-I[i-1]), dy = 0.5f*(I[i+w]-I[i-w]) over
+ *                         the linear index range [w, w*(h-1)), non-finite differences -> 0, first / last row -> 0;
+ *   d_abs_squared_grad  : nframes*w*h floats dx*dx + dy*dy. */
+int mdc_gradients_batch_device(mdc_ctx* ctx, const float* d_level, int w, int h, float* d_dI, float* d_abs_squared_grad,
+                               int64_t nframes, void* stream);
+
 /* ---- lens model on many points ------------------------------------------------ */
 
 /* The FOV camera of one UndistorterFOV object: camera.txt line 1 (fx fy cx cy omega, relative to the

@@ -30,7 +30,7 @@ HIP_SYMBOLS = [
     "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device", "mdc_synth_frames_device",
     "mdc_distort_points_device", "mdc_distort_points_host", "mdc_export_tables", "mdc_import_tables",
     "mdc_synchronize", "mdc_describe_launch", "mdc_ceiling_mix_device", "mdc_vcal_plane_step_device",
-    "mdc_vcal_vignette_step_device",
+    "mdc_vcal_vignette_step_device", "mdc_gradients_batch_device",
 ]
 HOST_SYMBOLS = [
     "mdch_fov_create", "mdch_fov_destroy", "mdch_fov_valid", "mdch_fov_has_gpu", "mdch_fov_dims",
@@ -122,6 +122,7 @@ def hip_lib():
             L.mdc_describe_launch.argtypes = [_vp, C.c_uint, _i, C.c_char_p, _sz]
             L.mdc_ceiling_mix_device.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int64, _i, _i, _vp]
             L.mdc_vcal_plane_step_device.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]
+            L.mdc_gradients_batch_device.argtypes = [_vp, _vp, _i, _i, _vp, _vp, C.c_int64, _vp]
             L.mdc_vcal_vignette_step_device.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]
         for n in HIP_SYMBOLS:
             if old_build and not hasattr(L, n):
@@ -372,6 +373,9 @@ class Context:
 
     def ceiling_mix(self, d_read, read_bytes, d_write, write_bytes, blocks=16384, span=0, stream=0):
         self._chk(self._L.mdc_ceiling_mix_device(self._h, d_read, read_bytes, d_write, write_bytes, blocks, span, stream if stream else None))
+
+    def gradients_batch(self, d_level, w, h, d_dI, d_abs, nframes, stream=0):
+        self._chk(self._L.mdc_gradients_batch_device(self._h, d_level, w, h, d_dI, d_abs, nframes, stream if stream else None))
 
     def vcal_plane_step(self, d_images, d_p2x, d_p2y, d_plane_color, d_vig, oth2, stream=0):
         """torch tensors on the device; d_plane_color is updated in place -> (FF, FC, E, R)."""

@@ -912,6 +912,17 @@ int mdc_distort_points_host(mdc_ctx* c, const mdc_fov_model* model, float* x, fl
   return MDC_OK;
 }
 
+int mdc_gradients_batch_device(mdc_ctx* c, const float* d_level, int w, int h, float* d_dI, float* d_abs_squared_grad,
+                               int64_t nframes, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (!d_level || !d_dI || !d_abs_squared_grad || w < 1 || h < 1 || nframes < 0 || (int64_t)w * h >= (1ll << 31))
+    return fail(c, MDC_ERR_ARG, "mdc_gradients_batch_device: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  MDC_HIP(c, launch_gradients(d_level, d_dI, d_abs_squared_grad, w, h, nframes, (hipStream_t)stream));
+  return MDC_OK;
+}
+
 int mdc_vcal_plane_step_device(mdc_ctx* c, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
                                int n_plane, float* d_plane_color, const float* d_vignette_factor, int oth2, float* d_ff,
                                float* d_fc, double* d_er, void* stream) {

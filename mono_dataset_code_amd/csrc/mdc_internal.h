@@ -101,6 +101,9 @@ hipError_t launch_vcal_vignette_step(const float* d_images, const float* d_p2x, 
                                      const float* d_plane_color, float* d_vig, int oth2, float* d_tt, float* d_ct, double* d_er,
                                      unsigned* d_max_bits, hipStream_t s);
 
+// DSO hand-off of one pyramid level: (I, dx, dy) triples + absSquaredGrad (see mdc_vcal.hip)
+hipError_t launch_gradients(const float* d_level, float* d_dI, float* d_abs2, int w, int h, int64_t nframes, hipStream_t s);
+
 hipError_t launch_synth(uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix, uint32_t seed, hipStream_t s);
 
 }  // namespace mdc

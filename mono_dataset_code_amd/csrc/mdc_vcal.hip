@@ -158,6 +158,51 @@ __global__ __launch_bounds__(256) void vcal_vignette_normalise_kernel(float* __r
   if (i < npix) vig[i] = vig[i] / __uint_as_float(*max_bits);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// DSO hand-off (NOT in the reference -- DSO's FrameHessian::makeImages, definition in
+// DESIGN.md section 5.5): for one pyramid level, per pixel the triple (I, dx, dy) with central differences
+// dx = 0.5f*(I[idx+1] - I[idx-1]), dy = 0.5f*(I[idx+w] - I[idx-w]) over the LINEAR index range [w, w*(h-1)) -- rows
+// 1 .. h-2, all columns, so the first and last column difference across the row boundary exactly as DSO's loop
+// does --, non-finite differences replaced by 0, and absSquaredGrad = dx*dx + dy*dy.  First and last row: 0.
+// A wave handles 64 consecutive pixels and writes their 192 floats as three wave-contiguous dword stores (through a
+// wave-private LDS transpose) instead of three stores at a 12-byte stride.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gradients_kernel(const float* __restrict__ lvl, float* __restrict__ dI,
+                                                        float* __restrict__ abs2, int w, int h, long long nframes) {
+  __shared__ float s_t[4][192];
+  const long long npx = (long long)w * h;
+  const long long base = (long long)blockIdx.x * 256;  // first pixel (over all frames) of this workgroup
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long i = base + threadIdx.x;
+  float I = 0.f, dx = 0.f, dy = 0.f;
+  const bool in = i < npx * nframes;
+  if (in) {
+    const long long f = i / npx;
+    const int idx = (int)(i - f * npx);
+    const float* p = lvl + f * npx;
+    I = p[idx];
+    if (idx >= w && idx < w * (h - 1)) {
+      dx = 0.5f * (p[idx + 1] - p[idx - 1]);
+      dy = 0.5f * (p[idx + w] - p[idx - w]);
+      if (!isfinite(dx)) dx = 0.f;
+      if (!isfinite(dy)) dy = 0.f;
+    }
+    abs2[i] = dx * dx + dy * dy;
+  }
+  s_t[wave][3 * lane + 0] = I;
+  s_t[wave][3 * lane + 1] = dx;
+  s_t[wave][3 * lane + 2] = dy;
+  // wave-private: no workgroup barrier needed, only the LDS writes of this wave have to land
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  const long long out0 = (base + wave * 64) * 3;
+  const long long total = npx * nframes * 3;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const long long o = out0 + k * 64 + lane;
+    if (o < total) __builtin_nontemporal_store(s_t[wave][k * 64 + lane], dI + o);
+  }
+}
+
 inline int blocks(long long n) { return (int)((n + 255) / 256); }
 
 }  // namespace
@@ -187,6 +232,13 @@ hipError_t launch_vcal_vignette_step(const float* d_images, const float* d_p2x, 
                                                                         (double)oth2, d_tt, d_ct, d_er);
   vcal_vignette_update_kernel<<<blocks((long long)wI * hI), 256, 0, s>>>(d_tt, d_ct, d_vig, wI * hI, d_max_bits);
   vcal_vignette_normalise_kernel<<<blocks((long long)wI * hI), 256, 0, s>>>(d_vig, wI * hI, d_max_bits);
+  return hipGetLastError();
+}
+
+hipError_t launch_gradients(const float* d_level, float* d_dI, float* d_abs2, int w, int h, int64_t nframes, hipStream_t s) {
+  const long long n = (long long)w * h * nframes;
+  if (n <= 0) return hipSuccess;
+  gradients_kernel<<<blocks(n), 256, 0, s>>>(d_level, d_dI, d_abs2, w, h, nframes);
   return hipGetLastError();
 }
 

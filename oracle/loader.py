@@ -64,6 +64,8 @@ class Oracle:
         L.orc_undistort_u8.argtypes = [_vp, _vp, _vp, _vp, _i, _i]
         L.orc_get_image.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i]
         L.orc_pyramid_level.argtypes = [_vp, _i, _i, _vp]
+        L.orc_gradients.argtypes = [_vp, _i, _i, _vp, _vp]
+        L.orc_gradients.restype = None
         L.orc_vcal_plane_step.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]
         L.orc_vcal_plane_step.restype = None
         L.orc_vcal_vignette_step.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]
@@ -150,6 +152,13 @@ class Oracle:
         out = np.zeros((n, npix), np.uint8)
         self.L.orc_synth_frames(_p(out), first, n, npix, seed)
         return out
+
+    def gradients(self, level, w, h):
+        """DSO-style (I, dx, dy) + absSquaredGrad of one level (own definition, parity unpinned)."""
+        lv = np.ascontiguousarray(level, np.float32)
+        dI, a = np.zeros(3 * w * h, np.float32), np.zeros(w * h, np.float32)
+        self.L.orc_gradients(_p(lv), w, h, _p(dI), _p(a))
+        return dI.reshape(h * w, 3), a
 
     def vcal_plane_step(self, images, p2x, p2y, plane_color, vig, oth2):
         """src/main_vignetteCalib.cpp:400-448 -> (new planeColor, FF, FC, E, R); images (n, hI, wI), p2x/p2y (n, np)."""

@@ -545,3 +545,23 @@ void orc_vcal_vignette_step(const float* images, const float* p2x, const float* 
   *E_out = E;
   *R_out = R;
 }
+
+/* DSO hand-off (NOT in the reference; own definition after DSO's FrameHessian::makeImages):
+ * (I, dx, dy) triples and absSquaredGrad of one w x h level.  parity unpinned. */
+void orc_gradients(const float* lvl, int w, int h, float* dI, float* abs2) {
+  for (int i = 0; i < w * h; i++) {
+    dI[3 * i + 0] = lvl[i];
+    dI[3 * i + 1] = 0.f;
+    dI[3 * i + 2] = 0.f;
+    abs2[i] = 0.f;
+  }
+  for (int idx = w; idx < w * (h - 1); idx++) {
+    float dx = 0.5f * (lvl[idx + 1] - lvl[idx - 1]);
+    float dy = 0.5f * (lvl[idx + w] - lvl[idx - w]);
+    if (!isfinite(dx)) dx = 0;
+    if (!isfinite(dy)) dy = 0;
+    dI[3 * idx + 1] = dx;
+    dI[3 * idx + 2] = dy;
+    abs2[idx] = dx * dx + dy * dy;
+  }
+}

@@ -478,6 +478,35 @@ def test_pyramid_config5_full_size(setups, oracle, torch_cuda):
         assert bits_equal(a.cpu().numpy(), b.cpu().numpy())
 
 
+def test_dso_gradients_of_pyramid_levels(setups, oracle, torch_cuda):
+    """DSO hand-off (row f4; not in the reference, own definition, parity unpinned): (I, dx, dy) + absSquaredGrad of
+    every level of the fused pyramid == the oracle's restatement, bit for bit, incl. NaN regions (non-finite
+    differences -> 0) and odd sizes."""
+    from mono_dataset_code_amd import capi
+
+    torch = torch_cuda
+    for name in ("pyr_whole_black", "ragged"):
+        s = setups(name)
+        frames = np.stack(make_frames(s.W, s.H, n_noise=2))
+        n, levels = len(frames), 4
+        d_in = torch.from_numpy(frames).cuda()
+        st = torch.cuda.current_stream().cuda_stream
+        d_base = torch.empty((n, s.w * s.h), dtype=torch.float32, device="cuda")
+        lv = [torch.empty(n * (s.w >> l) * (s.h >> l), dtype=torch.float32, device="cuda") for l in range(1, levels)]
+        s.ctx.process_pyramid_batch(d_in.data_ptr(), d_base.data_ptr(), levels, [t.data_ptr() for t in lv], n, 15, st)
+        for l, t in enumerate([d_base.view(-1)] + lv):
+            w, h = s.w >> l, s.h >> l
+            d_dI = torch.full((n * w * h * 3,), -7.0, dtype=torch.float32, device="cuda")
+            d_abs = torch.full((n * w * h,), -7.0, dtype=torch.float32, device="cuda")
+            s.ctx.gradients_batch(t.data_ptr(), w, h, d_dI.data_ptr(), d_abs.data_ptr(), n, st)
+            torch.cuda.synchronize()
+            src = t.cpu().numpy().reshape(n, w * h)
+            for f in range(n):
+                dI, a = oracle.gradients(src[f], w, h)
+                assert bits_equal(d_dI.view(n, -1)[f].cpu().numpy(), dI), (name, l, f)
+                assert bits_equal(d_abs.view(n, -1)[f].cpu().numpy(), a), (name, l, f)
+
+
 @pytest.mark.parametrize("name", ["small_crop", "ragged"])
 def test_process_frames_host_pipeline(name, setups, oracle):
     """Many host frames in one call (chunks on two streams): equal to the oracle frame by frame, with
