@@ -66,7 +66,6 @@ enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2 /* frames a workgroup lo
        MDC_OPT_WINDOW_BUFFERS = 7 /* tuning: LDS window buffers per workgroup, 2..4 (frames staged ahead + 1); 0 = automatic */,
        MDC_OPT_FRAME_INTERLEAVE = 8 /* tuning: a workgroup takes every G-th frame (1) or a run of consecutive frames (0) */,
        MDC_OPT_TILE_COLS = 9 /* tuning: output tile {64, 128} x rows (128 x {16, 32}: 512 / 1024 threads); 0 = automatic */,
-       MDC_OPT_LDS_ROW_PAD = 11 /* tuning: pad every source row of a window to a 128-byte pitch in LDS (masked filler chunks) */,
        MDC_OPT_PIN_CALLER_BUFFERS = 10 /* 1: page-lock, in place, the W*H float buffer a caller passes repeatedly as
           image_out of mdc_unmap_host / input of mdc_undistort_host_f32 (hipHostRegister on the second consecutive
           sighting of the same pointer + size; released by mdc_destroy or when the option is cleared), so that the

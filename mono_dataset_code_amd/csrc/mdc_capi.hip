@@ -66,7 +66,6 @@ struct mdc_ctx {
   int opt_nbuf = 0;  // 0 = automatic
   int opt_interleave = 0;
   int opt_pin_caller = 0;  // MDC_OPT_PIN_CALLER_BUFFERS
-  int opt_row_pad = 0;     // MDC_OPT_LDS_ROW_PAD
 
   // Caller buffers page-locked in place (opt-in): the W*H float image that the reference's two-call composition
   // moves host -> device -> host -> device (DatasetReader::internalTempBuffer, src/BenchmarkDatasetReader.h:145,222).
@@ -312,11 +311,6 @@ int plan_source(mdc_ctx* c, int es, int kTileW, int kTileH, mdc_ctx::SrcPlan& pl
       const int n = (r.hi - r.x0) / ppc + 1;
       if (r.x0 + n * ppc > iw) ok = false;
       for (int j = 0; j < n; j++) chunks[t].push_back((uint32_t)(((y_lo + (int)k) * iw + r.x0 + j * ppc) * es));
-      // Row pitch in LDS = a multiple of 128 bytes: the lanes of one tap instruction read from at most two adjacent
-      // source rows; with a pitch of 32 banks two different rows can only collide on a bank at equal column, which the
-      // two lane groups never share.  The filler entries are kOutside: masked lanes, they fetch and write nothing.
-      if (c->opt_row_pad)
-        while (chunks[t].size() % 8) chunks[t].push_back(kOutside);
     }
     nch[t] = (int)chunks[t].size();
     if (nch[t] > (lut ? kTileMaxChunks : kTileMaxChunksF32) * kTileThreads || nch[t] * 16 > 65535) ok = false;
@@ -649,14 +643,6 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
     case MDC_OPT_FRAME_INTERLEAVE:
       c->opt_interleave = value != 0;
       return MDC_OK;
-    case MDC_OPT_LDS_ROW_PAD: {
-      if ((value != 0) == (c->opt_row_pad != 0)) return MDC_OK;
-      c->opt_row_pad = value != 0;
-      if (!c->valid_remap) return MDC_OK;
-      DeviceGuard dg(c->device);
-      MDC_HIP(c, hipDeviceSynchronize());
-      return plan_tiles(c);
-    }
     case MDC_OPT_PIN_CALLER_BUFFERS: {
       c->opt_pin_caller = value != 0;
       if (!c->opt_pin_caller) {

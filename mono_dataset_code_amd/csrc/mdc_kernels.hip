@@ -520,15 +520,20 @@ __device__ __forceinline__ void wait_vm_barrier() {
   static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
-// A = allowance of the per-frame wait for a wave that issues `rw` DMA instructions per frame with
-// D frames staged ahead: everything issued after the DMA of frame f+1 may stay in flight, which is
-// at least (D-1) later DMA groups and the 4 stores of frame f  ->  (D-1)*rw + 4.
+// A = allowance of the per-frame wait for a wave that issues `rw` DMA instructions per frame with D frames staged
+// ahead.  Iteration i issues DMA(i+D), then the 4 stores of frame i (the fused pyramid: more).  At the end of iteration
+// f the wave needs DMA(f+1), issued in iteration f+1-D; everything issued after it may stay in flight:
+// the stores of that iteration (4) and the D-1 later iterations' DMA groups and stores  ->  (D-1)*(rw+4) + 4.
+// (Round 1 allowed only (D-1)*rw + 4: with D >= 2 every frame then also waited for the ACKNOWLEDGEMENT of the
+// previous frame's stores, which is what deeper staging is meant to avoid.)  More stores than 4 per frame (pyramid)
+// only make the wait more conservative.  The count relies on the chunk list being dense: a wave's round k has a
+// chunk for its first lane iff wave*64 + k*NT < nch.
 template <int D, int R>
 __device__ __forceinline__ void frame_barrier(int rw) {
-  if (R >= 4 && rw >= 4) wait_vm_barrier<(D - 1) * 4 + 4>();
-  else if (R >= 3 && rw == 3) wait_vm_barrier<(D - 1) * 3 + 4>();
-  else if (R >= 2 && rw == 2) wait_vm_barrier<(D - 1) * 2 + 4>();
-  else if (rw == 1) wait_vm_barrier<(D - 1) * 1 + 4>();
+  if (R >= 4 && rw >= 4) wait_vm_barrier<(D - 1) * (4 + 4) + 4>();
+  else if (R >= 3 && rw == 3) wait_vm_barrier<(D - 1) * (3 + 4) + 4>();
+  else if (R >= 2 && rw == 2) wait_vm_barrier<(D - 1) * (2 + 4) + 4>();
+  else if (rw == 1) wait_vm_barrier<(D - 1) * (1 + 4) + 4>();
   else wait_vm_barrier<4>();
 }
 
@@ -720,7 +725,7 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
     return;
   }
   const int rounds = (nch + NT - 1) / NT;  // workgroup-uniform
-  MDC_CHECK(nch * 16 <= p.win_bytes && rounds <= RMAX && (tid < nch || goff[0] == kOutside));
+  MDC_CHECK(nch * 16 <= p.win_bytes && rounds <= RMAX && (goff[0] == kOutside) == (tid >= nch));  // dense chunk list: the vmcnt allowances count on it
 #define MDC_TILE_RUN(R_)                                                                                              \
   tile_frames<VIG, BLACK, PYR, F32, R_, TW, NT, NBUF>(t, src, dst, in_bytes, out_bytes, nf, nch, goff, s_win, p.win_bytes, \
                                              my_lut, tid, py, (long long)f0, fstep, p3byte, (uint32_t)a.out_w * 4u)

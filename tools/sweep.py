@@ -117,7 +117,6 @@ def main():
             m, ctx = ctxs[v[0]]
             ctx.set_option(m.OPT_KERNEL, kmap[v[1]])
             ctx.set_option(m.OPT_FRAMES_PER_BLOCK, v[2])
-            try_set(m, ctx, "OPT_LDS_ROW_PAD", v[8])
             try_set(m, ctx, "OPT_TILE_COLS", v[7])
             try_set(m, ctx, "OPT_TILE_ROWS", v[3])
             try_set(m, ctx, "OPT_TILE_ORDER", v[4])
