@@ -61,12 +61,30 @@ def need(binary):
         pytest.skip("%s not built (needs /root/reference at build time)" % binary)
 
 
-def test_reference_reader_cpu_path_matches_oracle(sequence, oracle, tmp_path):
-    need(REF_BIN)
+@pytest.fixture(scope="module")
+def zipped_sequence(sequence, tmp_path_factory):
+    """The same sequence with its frames in images.zip (deflated, archive order reversed) instead of images/."""
+    import shutil
+    import zipfile
+
     d, frames = sequence
+    z = str(tmp_path_factory.mktemp("sequence_zipped"))
+    for f in ("camera.txt", "pcalib.txt", "vignette.png", "times.txt"):
+        shutil.copy(os.path.join(d, f), z)
+    with zipfile.ZipFile(os.path.join(z, "images.zip"), "w", zipfile.ZIP_DEFLATED) as a:
+        for n in sorted(os.listdir(os.path.join(d, "images")), reverse=True):
+            a.write(os.path.join(d, "images", n), n)
+    return z, frames
+
+
+@pytest.mark.parametrize("zipped", [False, True])
+def test_reference_reader_cpu_path_matches_oracle(sequence, zipped_sequence, oracle, tmp_path, zipped):
+    need(REF_BIN)
+    d, frames = zipped_sequence if zipped else sequence
     out = str(tmp_path / "ref.bin")
     log = run_playback(REF_BIN, d, out)
     assert "PLAYBACK 3 images, 320x256 -> 192x144" in log
+    assert ("got 3 entries and 3 files from zipfile!" in log) == zipped
     recs = parse(out)
     assert len(recs) == len(FLAGS) * N_FRAMES
     cam = oracle.parse_camera(os.path.join(d, "camera.txt"))

@@ -105,11 +105,12 @@ def parse(path):
     return recs
 
 
+@pytest.mark.parametrize("zipped", [False, True])
 @pytest.mark.parametrize("which", ["playback_fast", "playback_batch"])
-def test_playdataset_driver_on_our_reader_equals_the_reference_reader(tmp_path, which):
+def test_playdataset_driver_on_our_reader_equals_the_reference_reader(tmp_path, which, zipped):
     """tests/dropin/playback_headless.cpp is ONE source file: compiled against the reference's BenchmarkDatasetReader.h +
     classes (playback_ref, CPU) and against this repo's reader header (playback_fast, GPU); playback_batch drives
-    getImages().  Same bytes out."""
+    getImages().  Same bytes out, from an images/ folder and from images.zip."""
     for b in ("playback_ref", which):
         if not os.path.exists(BIN[b]):
             pytest.skip("%s not built" % b)
@@ -117,7 +118,9 @@ def test_playdataset_driver_on_our_reader_equals_the_reference_reader(tmp_path, 
     frames = frames_for(5, h, w)
     d = str(tmp_path / "seq")
     os.makedirs(d)
-    make_sequence(d, frames, False, "png")
+    # zipped: the reference's unmodified reader goes through its zip_fopen / zip_fread / cv::imdecode path
+    # (src/BenchmarkDatasetReader.h:256-274; oracle/shim_zip.cpp + libpng, independent of the product's zip reader and decoders)
+    make_sequence(d, frames, zipped, "png")
     outs = {}
     for b in ("playback_ref", which):
         out = str(tmp_path / (b + ".bin"))

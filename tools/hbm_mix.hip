@@ -251,6 +251,52 @@ __global__ __launch_bounds__(TW* TH / 4) void tile_rw_chunked(const uint8_t* __r
   }
 }
 
+// tile skeleton with explicit frame strides (bytes in, floats out): do the power-of-two-ish frame sizes
+// (1280*1024 B, 640*480*4 B) alias the frames of one tile onto the same channels / banks?
+template <int TW, int TH, int SMODE>
+__global__ __launch_bounds__(TW* TH / 4) void tile_rw_strided(const uint8_t* __restrict__ in, float* __restrict__ out, int nframes,
+                                                               int fpb, int winw, int winh, long long sin, long long sout) {
+  constexpr int NT = TW * TH / 4;
+  constexpr int TX = OW / TW, TY = OH / TH, NTILES = TX * TY;
+  __shared__ u32x4 sink[NT];
+  const int ntp = gridDim.x;
+  int tile = (blockIdx.x & 7) * (ntp >> 3) + (blockIdx.x >> 3);
+  if (tile >= NTILES) return;
+  const int tx = tile % TX, ty = tile / TX;
+  const int f0 = blockIdx.y * fpb, f1 = min(nframes, f0 + fpb);
+  const int tid = threadIdx.x;
+  const int cx = (int)(640.f + (tx * TW + TW / 2 - 320) * 1.345f), cy = (int)(512.f + (ty * TH + TH / 2 - 240) * 1.52f);
+  const int x0 = max(0, (cx - winw / 2)) & ~15, y0 = max(0, cy - winh / 2);
+  const int cpr = winw / 16, nch = cpr * winh;
+  const int lane_x = tid % TW, row0 = (tid / TW) * 4;
+  const long long obase = (long long)(ty * TH + row0) * OW + tx * TW + lane_x;
+  long long so[2];
+  bool has[2];
+  for (int k = 0; k < 2; k++) {
+    const int c = tid + k * NT;
+    has[k] = c < nch;
+    const int r = has[k] ? c / cpr : 0;
+    so[k] = (long long)(y0 + r) * IW + x0 + (c - r * cpr) * 16;
+  }
+  u32x4 cur[2] = {}, nxt[2] = {};
+  for (int k = 0; k < 2; k++)
+    if (has[k]) cur[k] = *reinterpret_cast<const u32x4*>(in + (long long)f0 * sin + so[k]);
+  for (int f = f0; f < f1; f++) {
+    if (f + 1 < f1)
+      for (int k = 0; k < 2; k++)
+        if (has[k]) nxt[k] = *reinterpret_cast<const u32x4*>(in + (long long)(f + 1) * sin + so[k]);
+    uint32_t acc = 0;
+    for (int k = 0; k < 2; k++) acc ^= cur[k].x ^ cur[k].y ^ cur[k].z ^ cur[k].w;
+    sink[tid] = cur[0];
+    __syncthreads();
+    float* dst = out + (long long)f * sout + obase;
+    const float x = __uint_as_float(acc & 0x3fffffffu);
+#pragma unroll
+    for (int j = 0; j < 4; j++) st<SMODE>(x, dst + j * OW);
+    for (int k = 0; k < 2; k++) cur[k] = nxt[k];
+  }
+}
+
 // read-only "pieces": a workgroup reads 7168 bytes of each of its frames as rows of L contiguous bytes
 // (stride = one image row); the 104 workgroups of a frame group tile a 1024 x 728 byte region without
 // overlap.  Same bytes for every L -- isolates how the piece length affects the achieved read rate.
@@ -376,6 +422,17 @@ int main() {
     report("strips 64x4 per wave, no prefetch, no barrier", rbs + wb, time_ms([&] { strip_rw<0, false, ST_NT><<<g64, 512>>>(d_in, d_out, F, fpb, 1); }));
     report("strips 64x4 per wave, prefetch, no barrier", rbs + wb, time_ms([&] { strip_rw<1, false, ST_NT><<<g64, 512>>>(d_in, d_out, F, fpb, 1); }));
     report("strips 64x4 per wave, prefetch, barrier", rbs + wb, time_ms([&] { strip_rw<1, true, ST_NT><<<g64, 512>>>(d_in, d_out, F, fpb, 1); }));
+    // frame strides: dense (as the API has them) vs padded by odd multiples of 128 B / a few KB
+    {
+      const int Fs = 960;  // fewer frames so that padded strides still fit the buffers
+      for (long long pin : {0LL, 128LL, 1152LL, 4096LL + 128, 65536LL + 128})
+        for (long long pout : {0LL, 32LL, 288LL, 1024LL + 32}) {
+          if ((pin == 0) != (pout == 0) && !(pin == 0 || pout == 0)) continue;
+          char nm[96];
+          snprintf(nm, sizeof nm, "tile64x32 pf strided: in +%lld B, out +%lld floats", pin, pout);
+          report(nm, (rb + wb) * Fs / F, time_ms([&] { tile_rw_strided<64, 32, ST_NT><<<dim3(152, Fs / 32), 512>>>(d_in, d_out, Fs, 32, 128, 56, NIN + pin, NOUT + pout); }));
+        }
+    }
     // compact in-flight frame set without a short workgroup life: chunks of c frames, groups interleaved
     for (int lds : {0, 52 * 1024})
       for (int fp : {32, 64, 128})
