@@ -84,6 +84,8 @@ def parse():
     p.add_argument("--tile-rows", type=int, default=0, help="output tile rows of the tiled kernel (0 = library default)")
     p.add_argument("--tile-cols", type=int, default=0, help="output tile columns of the tiled kernel (0 = library default)")
     p.add_argument("--nbuf", type=int, default=0, help="LDS window buffers (0 = automatic)")
+    p.add_argument("--no-tune", action="store_true", help="keep the library's built-in tile shape / frames per workgroup instead "
+                                                          "of mdc_tune_device's measured choice (untimed, before the warm-up)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ceiling", action="store_true", help="skip the same-box linear-mix ceiling")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of the all-core baseline sample")
@@ -303,6 +305,13 @@ def main():
     if wl == "pyramid":
         d_levels = [torch.empty(B * (out_w >> l) * (out_h >> l), dtype=torch.float32, device=dev) for l in range(1, levels)]
     flags = capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED | (capi.RECTIFY if rect else 0)
+    tuned = None
+    if wl in ("fused", "seq50k") and args.kernel == "auto" and not (args.no_tune or args.fpb or args.tile_rows or args.tile_cols or args.nbuf):
+        # plan selection by measurement, on (a part of) this rank's own batch; untimed set-up like the table build
+        t = ctx.tune(d_in.data_ptr(), d_out.data_ptr(), min(B, 4096), flags, stream)
+        tuned = {"tile": [t.tile_w, t.tile_h], "frames_per_workgroup": t.frames_per_block, "candidates": t.candidates,
+                 "ms_on_%d_frames" % min(B, 4096): round(t.ms, 4)}
+        info = ctx.info()
     kernel_name = ctx.describe_launch(flags, levels if wl == "pyramid" else 0)
 
     def step():
@@ -450,6 +459,7 @@ def main():
                        "preroll_s": args.preroll_s, "sharding": "round-robin frame f -> rank f %% %d" % world,
                        "tables": ("rank-0 build + one %s broadcast" % ("RCCL" if backend == "nccl" else backend)) if use_dist else "local build",
                        "collective_backend": backend if use_dist else None,
+                       "plan": tuned if tuned is not None else "built-in",
                        "frames_per_s": round(frames_total / elapsed, 1),
                        "out_mpix_per_s": round(frames_total * npix_out / 1e6 / elapsed, 1)},
             "roofline": roof,

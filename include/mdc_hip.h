@@ -237,6 +237,20 @@ int mdc_vcal_vignette_step_device(mdc_ctx* ctx, const float* d_images, const flo
 int mdc_synth_frames_device(mdc_ctx* ctx, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix,
                             uint32_t seed, void* stream);
 
+/* Plan selection by measurement.  Which tile shape and workgroup length is fastest depends on the remap (window sizes)
+ * and, by a few per cent, on the individual GPU (profiles/r02_experiments/04_*, 13_*).  mdc_tune_device runs the fused
+ * pass (flags must contain MDC_RECTIFY) over the caller's device batch with each candidate -- tile 128x16 / 64x32 /
+ * 128x32 x 32 / 64 frames per workgroup, 7 launches each, results in d_out are valid ones -- and keeps the fastest as
+ * the context's plan for all later calls (it sets MDC_OPT_TILE_COLS / _ROWS / _FRAMES_PER_BLOCK; setting those to 0
+ * returns to the built-in choice).  Synchronises `stream`. */
+typedef struct mdc_tune_result {
+  int tile_w, tile_h, frames_per_block;
+  float ms;        /* median launch time of the winner over the given batch */
+  int candidates;  /* configurations that could be planned and timed */
+} mdc_tune_result;
+int mdc_tune_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, void* stream,
+                    mdc_tune_result* result);
+
 /* Measurement utilities (bench.py; nothing of the reference corresponds to them).
  * mdc_describe_launch: the kernel instantiation mdc_process_batch_device (pyramid_levels <= 1) or
  * mdc_process_pyramid_batch_device (pyramid_levels = its `levels`) launches for `flags` with the current tables

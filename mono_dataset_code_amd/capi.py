@@ -30,7 +30,7 @@ HIP_SYMBOLS = [
     "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device", "mdc_synth_frames_device",
     "mdc_distort_points_device", "mdc_distort_points_host", "mdc_export_tables", "mdc_import_tables",
     "mdc_synchronize", "mdc_describe_launch", "mdc_ceiling_mix_device", "mdc_vcal_plane_step_device",
-    "mdc_vcal_vignette_step_device", "mdc_gradients_batch_device",
+    "mdc_vcal_vignette_step_device", "mdc_gradients_batch_device", "mdc_tune_device",
 ]
 HOST_SYMBOLS = [
     "mdch_fov_create", "mdch_fov_destroy", "mdch_fov_valid", "mdch_fov_has_gpu", "mdch_fov_dims",
@@ -56,6 +56,10 @@ class MdcInfo(C.Structure):
                 ("window_buffers", C.c_int), ("f32_tiled", C.c_int), ("f32_tile_w", C.c_int), ("f32_tile_h", C.c_int),
                 ("src_bbox", C.c_int * 4), ("src_bbox_bytes", C.c_int64), ("src_staged_bytes", C.c_int64),
                 ("n_black", C.c_int64)]
+
+
+class TuneResult(C.Structure):
+    _fields_ = [("tile_w", C.c_int), ("tile_h", C.c_int), ("frames_per_block", C.c_int), ("ms", C.c_float), ("candidates", C.c_int)]
 
 
 class MdcError(RuntimeError):
@@ -122,6 +126,7 @@ def hip_lib():
             L.mdc_describe_launch.argtypes = [_vp, C.c_uint, _i, C.c_char_p, _sz]
             L.mdc_ceiling_mix_device.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int64, _i, _i, _vp]
             L.mdc_vcal_plane_step_device.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]
+            L.mdc_tune_device.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_uint, _vp, C.POINTER(TuneResult)]
             L.mdc_gradients_batch_device.argtypes = [_vp, _vp, _i, _i, _vp, _vp, C.c_int64, _vp]
             L.mdc_vcal_vignette_step_device.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]
         for n in HIP_SYMBOLS:
@@ -373,6 +378,11 @@ class Context:
 
     def ceiling_mix(self, d_read, read_bytes, d_write, write_bytes, blocks=16384, span=0, stream=0):
         self._chk(self._L.mdc_ceiling_mix_device(self._h, d_read, read_bytes, d_write, write_bytes, blocks, span, stream if stream else None))
+
+    def tune(self, d_in, d_out, nframes, flags, stream=0):
+        r = TuneResult()
+        self._chk(self._L.mdc_tune_device(self._h, d_in, d_out, nframes, flags, stream if stream else None, C.byref(r)))
+        return r
 
     def gradients_batch(self, d_level, w, h, d_dI, d_abs, nframes, stream=0):
         self._chk(self._L.mdc_gradients_batch_device(self._h, d_level, w, h, d_dI, d_abs, nframes, stream if stream else None))

@@ -948,6 +948,71 @@ int mdc_synth_frames_device(mdc_ctx* c, uint8_t* d_out, int64_t first_frame, int
   return MDC_OK;
 }
 
+// Plan selection by measurement (as FFT / BLAS libraries do): which tile shape and workgroup length is fastest depends on
+// the remap (window sizes) and, by a few per cent, on the individual GPU.  Runs the fused pass over the caller's
+// batch with every candidate, keeps the fastest as the context's plan.
+int mdc_tune_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, void* stream,
+                    mdc_tune_result* result) {
+  if (!c) return MDC_ERR_ARG;
+  if (!d_in || !d_out || nframes <= 0) return fail(c, MDC_ERR_ARG, "mdc_tune_device: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  if (!(flags & MDC_RECTIFY) || !c->valid_remap) return fail(c, MDC_ERR_STATE, "mdc_tune_device: needs a remap and MDC_RECTIFY");
+  hipStream_t s = (hipStream_t)stream;
+  static const TileShape shapes[] = {{128, 16}, {64, 32}, {128, 32}};
+  static const int fpbs[] = {32, 64};
+  hipEvent_t e0, e1;
+  MDC_HIP(c, hipEventCreate(&e0));
+  MDC_HIP(c, hipEventCreate(&e1));
+  float best = 1e30f;
+  int bw = 0, bh = 0, bf = 0, tried = 0;
+  int rc = MDC_OK;
+  for (const TileShape& sh : shapes) {
+    c->opt_tile_w = sh.w;
+    c->opt_tile_h = sh.h;
+    (void)hipStreamSynchronize(s);
+    if ((rc = plan_tiles(c)) != MDC_OK) break;
+    if (!c->plan[0].tiled) continue;
+    for (int fpb : fpbs) {
+      c->opt_fpb = fpb;
+      float ms[5];
+      bool ok = true;
+      for (int k = 0; k < 7 && ok; k++) {  // 2 warm-up launches, 5 timed
+        if (k >= 2) ok = hipEventRecord(e0, s) == hipSuccess;
+        ok = ok && enqueue_process(c, d_in, d_out, nframes, flags, s) == MDC_OK;
+        if (k >= 2) ok = ok && hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+                         hipEventElapsedTime(&ms[k - 2], e0, e1) == hipSuccess;
+      }
+      if (!ok) continue;
+      std::sort(ms, ms + 5);
+      tried++;
+      if (ms[2] < best) {
+        best = ms[2];
+        bw = sh.w;
+        bh = sh.h;
+        bf = fpb;
+      }
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipStreamSynchronize(s);
+  // the winner (or, if nothing could be timed, the automatic choice) becomes the plan
+  c->opt_tile_w = bw;
+  c->opt_tile_h = bh;
+  c->opt_fpb = bf;
+  const int rc2 = plan_tiles(c);
+  if (rc == MDC_OK) rc = rc2;
+  if (result) {
+    result->tile_w = bw;
+    result->tile_h = bh;
+    result->frames_per_block = bf;
+    result->ms = tried ? best : 0.f;
+    result->candidates = tried;
+  }
+  return rc;
+}
+
 int mdc_describe_launch(mdc_ctx* c, unsigned flags, int pyramid_levels, char* buf, size_t cap) {
   if (!c || !buf || cap == 0) return MDC_ERR_ARG;
   std::lock_guard<std::mutex> lk(c->mu);

@@ -282,6 +282,36 @@ def test_automatic_tile_shape_keeps_strong_distortion_on_the_tiled_kernel(setups
     assert i.f32_tiled and (i.f32_tile_w, i.f32_tile_h) == (128, 16)
 
 
+def test_tune_keeps_results_and_picks_a_plan(setups, oracle, torch_cuda):
+    """mdc_tune_device: whatever plan wins, the outputs it leaves and all later launches are the oracle's bits."""
+    from mono_dataset_code_amd import capi, synth
+
+    torch = torch_cuda
+    s = setups("full_1280_to_640")
+    n, npix, nout = 96, s.W * s.H, s.w * s.h
+    st = torch.cuda.current_stream().cuda_stream
+    d_in = torch.empty(n * npix, dtype=torch.uint8, device="cuda")
+    s.ctx.synth_frames(d_in.data_ptr(), 500, n, npix, synth.SEED, st)
+    d_out = torch.full((n, nout), -7.0, dtype=torch.float32, device="cuda")
+    r = s.ctx.tune(d_in.data_ptr(), d_out.data_ptr(), n, 15, st)
+    assert r.candidates == 6 and (r.tile_w, r.tile_h) in ((128, 16), (64, 32), (128, 32)) and r.frames_per_block in (32, 64) and r.ms > 0
+    info = s.ctx.info()
+    assert info.tiled and (info.tile_w, info.tile_h) == (r.tile_w, r.tile_h)
+    frames = d_in.view(n, npix).cpu().numpy()
+    want = {f: s.want(oracle, frames[f], 1, 1, 1, 1) for f in (0, 57, n - 1)}
+    for f, w in want.items():
+        assert bits_equal(d_out[f].cpu().numpy(), w), ("left by the tuner", f)
+    d_out.fill_(-7.0)
+    s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, 15, st)
+    torch.cuda.synchronize()
+    for f, w in want.items():
+        assert bits_equal(d_out[f].cpu().numpy(), w), ("after tuning", f)
+    with pytest.raises(capi.MdcError):
+        s.ctx.tune(d_in.data_ptr(), d_out.data_ptr(), n, 7, st)  # no MDC_RECTIFY
+    for opt in (capi.OPT_TILE_COLS, capi.OPT_TILE_ROWS, capi.OPT_FRAMES_PER_BLOCK):
+        s.ctx.set_option(opt, 0)
+
+
 def test_batch_beyond_4gib(setups, oracle, torch_cuda):
     """A batch whose frames lie beyond 4 GiB from the base pointers (3400 frames: 4.46 GB in, 4.18 GB out):
     the per-frame buffer descriptors take a 48-bit base, lane offsets stay 32-bit.  Checked against the
