@@ -232,6 +232,24 @@ int mdc_vcal_vignette_step_device(mdc_ctx* ctx, const float* d_images, const flo
                                   int h, int n_plane, const float* d_plane_color, float* d_vignette_factor, int oth2, float* d_tt,
                                   float* d_ct, double* d_er, void* stream);
 
+/* The same half-iteration WITHOUT atomics and bit-identical to the reference.  plane2img coordinates and image colours
+ * are fixed over the solver's iterations, so the scatter :489-503 is inverted once: mdc_vcal_index_create lists, for
+ * every image pixel, the (image, plane point, corner) contributions it receives in the order of the reference's
+ * sequential loop (image-major, plane point ascending).  mdc_vcal_vignette_step_indexed_device then lets one lane walk
+ * one pixel's list front to back: same terms, same f32 expressions, same order -> d_tt, d_ct and d_vignette_factor
+ * equal the reference bit for bit.  The index holds 4 x 16 bytes per valid sample (12.8 GB for 200 images x 10^6
+ * plane points -- sized for HBM) and belongs to the (d_images, d_p2x, d_p2y) it was built from; building it
+ * synchronises `stream`.  Samples whose 2x2 footprint leaves the image (the reference's caller excludes them, :283-300)
+ * are dropped instead of written out of bounds.  d_er = {E, R} as above (E in tree order). */
+typedef struct mdc_vcal_index mdc_vcal_index;
+int mdc_vcal_index_create(mdc_ctx* ctx, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
+                          int n_plane, void* stream, mdc_vcal_index** out);
+void mdc_vcal_index_destroy(mdc_vcal_index* index);
+int64_t mdc_vcal_index_bytes(const mdc_vcal_index* index);   /* device bytes of the contribution lists */
+int64_t mdc_vcal_index_entries(const mdc_vcal_index* index); /* list entries = 4 x valid samples */
+int mdc_vcal_vignette_step_indexed_device(mdc_ctx* ctx, const mdc_vcal_index* index, const float* d_plane_color,
+                                          float* d_vignette_factor, int oth2, float* d_tt, float* d_ct, double* d_er, void* stream);
+
 /* Synthetic sequence generator (bench/test utility):
  * byte i of frame f = fmix32(seed + (first_frame+f)*npix + i) >> 24. */
 int mdc_synth_frames_device(mdc_ctx* ctx, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix,

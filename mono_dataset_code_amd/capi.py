@@ -31,6 +31,8 @@ HIP_SYMBOLS = [
     "mdc_distort_points_device", "mdc_distort_points_host", "mdc_export_tables", "mdc_import_tables",
     "mdc_synchronize", "mdc_describe_launch", "mdc_ceiling_mix_device", "mdc_vcal_plane_step_device",
     "mdc_vcal_vignette_step_device", "mdc_gradients_batch_device", "mdc_tune_device",
+    "mdc_vcal_index_create", "mdc_vcal_index_destroy", "mdc_vcal_index_bytes", "mdc_vcal_index_entries",
+    "mdc_vcal_vignette_step_indexed_device",
 ]
 HOST_SYMBOLS = [
     "mdch_fov_create", "mdch_fov_destroy", "mdch_fov_valid", "mdch_fov_has_gpu", "mdch_fov_dims",
@@ -129,10 +131,20 @@ def hip_lib():
             L.mdc_tune_device.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_uint, _vp, C.POINTER(TuneResult)]
             L.mdc_gradients_batch_device.argtypes = [_vp, _vp, _i, _i, _vp, _vp, C.c_int64, _vp]
             L.mdc_vcal_vignette_step_device.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]
+        if not old_build or hasattr(L, "mdc_vcal_index_create"):
+            L.mdc_vcal_index_create.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(_vp)]
+            L.mdc_vcal_index_destroy.argtypes = [_vp]
+            L.mdc_vcal_index_destroy.restype = None
+            L.mdc_vcal_index_bytes.argtypes = [_vp]
+            L.mdc_vcal_index_bytes.restype = C.c_int64
+            L.mdc_vcal_index_entries.argtypes = [_vp]
+            L.mdc_vcal_index_entries.restype = C.c_int64
+            L.mdc_vcal_vignette_step_indexed_device.argtypes = [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]
         for n in HIP_SYMBOLS:
             if old_build and not hasattr(L, n):
                 continue
-            if n not in ("mdc_destroy", "mdc_last_error", "mdc_host_alloc", "mdc_host_free"):
+            if n not in ("mdc_destroy", "mdc_last_error", "mdc_host_alloc", "mdc_host_free", "mdc_vcal_index_destroy",
+                         "mdc_vcal_index_bytes", "mdc_vcal_index_entries"):
                 getattr(L, n).restype = _i
         _hip = L
     return _hip
@@ -417,9 +429,50 @@ class Context:
         e, r = er.cpu().tolist()
         return tt, ct, e, r
 
+    def vcal_index(self, d_images, d_p2x, d_p2y, stream=0):
+        """Contribution index of the vignette half-iteration for these images / coordinates (mdc_vcal_index_create)."""
+        return VcalIndex(self, d_images, d_p2x, d_p2y, stream)
+
+    def vcal_vignette_step_indexed(self, index, d_plane_color, d_vig, oth2, stream=0):
+        """The vignette half-iteration as an ordered gather (bit-identical to the reference); d_vig is updated in place
+        -> (TT, CT, E, R)."""
+        import torch
+
+        tt = torch.empty(index.h * index.w, dtype=torch.float32, device=d_vig.device)
+        ct = torch.empty_like(tt)
+        er = torch.zeros(2, dtype=torch.float64, device=d_vig.device)
+        self._chk(self._L.mdc_vcal_vignette_step_indexed_device(self._h, index._h, d_plane_color.data_ptr(), d_vig.data_ptr(), int(oth2),
+                                                                tt.data_ptr(), ct.data_ptr(), er.data_ptr(), stream if stream else None))
+        e, r = er.cpu().tolist()
+        return tt, ct, e, r
+
     def bind(self, fov=None, photo=None):
         rc = host_lib().mdch_bind(self._h, fov._h if fov is not None else None, photo._h if photo is not None else None)
         self._chk(rc)
+
+
+class VcalIndex:
+    """mdc_vcal_index: per image pixel, the (image, plane point, corner) contributions in the reference's order."""
+
+    def __init__(self, ctx, d_images, d_p2x, d_p2y, stream=0):
+        self._L = ctx._L
+        self._h = _vp()
+        n, self.h, self.w = d_images.shape
+        ctx._chk(self._L.mdc_vcal_index_create(ctx._h, d_images.data_ptr(), d_p2x.data_ptr(), d_p2y.data_ptr(), n, self.w, self.h,
+                                               d_p2x.shape[1], stream if stream else None, C.byref(self._h)))
+        self.bytes = self._L.mdc_vcal_index_bytes(self._h)
+        self.entries = self._L.mdc_vcal_index_entries(self._h)
+
+    def close(self):
+        if self._h:
+            self._L.mdc_vcal_index_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def pack_tables(fov=None, photo=None):

@@ -938,6 +938,51 @@ int mdc_vcal_vignette_step_device(mdc_ctx* c, const float* d_images, const float
   return MDC_OK;
 }
 
+struct mdc_vcal_index {
+  mdc::VcalIndex* ix;
+  int device;
+};
+
+int mdc_vcal_index_create(mdc_ctx* c, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
+                          int n_plane, void* stream, mdc_vcal_index** out) {
+  if (!c) return MDC_ERR_ARG;
+  if (!out) return fail(c, MDC_ERR_ARG, "mdc_vcal_index_create: out is NULL");
+  *out = nullptr;
+  if (!d_images || !d_p2x || !d_p2y || n_images < 0 || n_images > 65535 || w < 2 || h < 2 || n_plane < 0 || n_plane >= (1 << 30) ||
+      (long long)w * h >= (1ll << 31))
+    return fail(c, MDC_ERR_ARG, "mdc_vcal_index_create: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  mdc::VcalIndex* ix = nullptr;
+  MDC_HIP(c, mdc::vcal_index_build(d_images, d_p2x, d_p2y, n_images, w, h, n_plane, (hipStream_t)stream, &ix));
+  *out = new mdc_vcal_index{ix, c->device};
+  return MDC_OK;
+}
+
+void mdc_vcal_index_destroy(mdc_vcal_index* index) {
+  if (!index) return;
+  DeviceGuard dg(index->device);
+  mdc::vcal_index_free(index->ix);
+  delete index;
+}
+
+int64_t mdc_vcal_index_bytes(const mdc_vcal_index* index) { return index ? mdc::vcal_index_bytes(index->ix) : 0; }
+int64_t mdc_vcal_index_entries(const mdc_vcal_index* index) { return index ? mdc::vcal_index_entries(index->ix) : 0; }
+
+int mdc_vcal_vignette_step_indexed_device(mdc_ctx* c, const mdc_vcal_index* index, const float* d_plane_color,
+                                          float* d_vignette_factor, int oth2, float* d_tt, float* d_ct, double* d_er, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (!index || !d_plane_color || !d_vignette_factor || !d_tt || !d_ct || !d_er)
+    return fail(c, MDC_ERR_ARG, "mdc_vcal_vignette_step_indexed_device: bad argument");
+  if (index->device != c->device) return fail(c, MDC_ERR_ARG, "mdc_vcal_vignette_step_indexed_device: index built on another device");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  if (!c->d_vcal_max) MDC_HIP(c, hipMalloc(&c->d_vcal_max, sizeof(unsigned)));
+  MDC_HIP(c, mdc::launch_vcal_vignette_step_indexed(index->ix, d_plane_color, d_vignette_factor, oth2, d_tt, d_ct, d_er,
+                                                    c->d_vcal_max, (hipStream_t)stream));
+  return MDC_OK;
+}
+
 int mdc_synth_frames_device(mdc_ctx* c, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix, uint32_t seed,
                             void* stream) {
   if (!c) return MDC_ERR_ARG;

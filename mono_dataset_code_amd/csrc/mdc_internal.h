@@ -101,6 +101,17 @@ hipError_t launch_vcal_vignette_step(const float* d_images, const float* d_p2x, 
                                      const float* d_plane_color, float* d_vig, int oth2, float* d_tt, float* d_ct, double* d_er,
                                      unsigned* d_max_bits, hipStream_t s);
 
+// The vignette half-iteration as an ordered gather over a prebuilt per-pixel contribution index (mdc_vcal.hip):
+// bit-identical to the reference's sequential scatter, no atomics.
+struct VcalIndex;
+hipError_t vcal_index_build(const float* d_images, const float* d_p2x, const float* d_p2y, int n, int wI, int hI, int np,
+                            hipStream_t s, VcalIndex** out);
+void vcal_index_free(VcalIndex* ix);
+long long vcal_index_bytes(const VcalIndex* ix);
+long long vcal_index_entries(const VcalIndex* ix);
+hipError_t launch_vcal_vignette_step_indexed(const VcalIndex* ix, const float* d_plane_color, float* d_vig, int oth2, float* d_tt,
+                                             float* d_ct, double* d_er, unsigned* d_max_bits, hipStream_t s);
+
 // DSO hand-off of one pyramid level: (I, dx, dy) triples + absSquaredGrad (see mdc_vcal.hip)
 hipError_t launch_gradients(const float* d_level, float* d_dI, float* d_abs2, int w, int h, int64_t nframes, hipStream_t s);
 

@@ -8,10 +8,13 @@
 // Numerics (this file is built with -ffp-contract=off, division correctly rounded):
 //   plane step    : every plane point sums over the images in the reference's order -> FF, FC and the new
 //                   planeColor are BIT-IDENTICAL to the reference;
-//   vignette step : a scatter-add into the image grid.  The reference's sequential order cannot be kept by
-//                   concurrent float atomics, so TT / CT / vignetteFactor agree to ~1e-6 relative, not bitwise
-//                   (tests/test_vcal.py: 1e-5);
+//   vignette step : a scatter-add into the image grid.  As written (vcal_vignette_accumulate_kernel, concurrent float
+//                   atomics) the reference's sequential order cannot be kept: TT / CT / vignetteFactor agree to ~1e-6
+//                   relative (tests/test_vcal.py: 1e-5).  Inverted into an ordered gather over a prebuilt index
+//                   (VcalIndex, vcal_vignette_gather_kernel) it is BIT-IDENTICAL and has no atomics on the data path;
 //   E (printed only, :449,:523): double sums in tree order instead of sequential order; R is an exact count.
+#include <vector>
+
 #include "mdc_internal.h"
 
 namespace mdc {
@@ -129,6 +132,212 @@ __global__ __launch_bounds__(256) void vcal_vignette_accumulate_kernel(const flo
   block_add_er(E, R, er);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// "optimize vignette" WITHOUT atomics, bit-identical to the reference: the scatter turned into a gather.
+// plane2img coordinates and image colours do not change between iterations (:395 ff. only updates planeColor and
+// vignetteFactor), so which (image, plane point, corner) lands in which image pixel is fixed.  Built once
+// (VcalIndex, below): for every image pixel ("bin") the list of its contributions in the REFERENCE'S ORDER
+// (image-major, plane point ascending = the order of the sequential loop :461-509).  Per iteration one lane walks
+// one bin's list front to back and adds exactly the terms the reference adds, in the same order, with the same f32
+// expressions -> TT, CT and the new vignetteFactor equal the reference's bit for bit, and nothing is atomic.
+// Memory layout sized for HBM, not for a cache: 4 entries of 16 bytes per valid (image, point) sample (200 images x
+// 10^6 points -> 12.8 GB), ELL-packed per group of 64 consecutive bins (entry k of the 64 bins is one 1-KB line
+// group, so a wave's k-th load is one coalesced dwordx4 per lane); a group is as long as its longest bin.
+// ---------------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) VcalEntry {
+  float x, y;     // plane2img coordinates of the sample
+  float color;    // interpolated image colour (:473), constant over the iterations
+  unsigned pc;    // plane point | corner << 30 (corner 0..3 = +0, +1, +w, +1+w of :495-503)
+};
+constexpr unsigned kCornerShift = 30;
+constexpr int kVcalSlackRows = 8;  // rows a walking wave may read past a group's last row (= its loads in flight)
+
+// validity that does not depend on the iteration: coordinate present (:468), taps inside the image (the reference
+// relies on its caller for that, :283-300 -- a sample whose 2x2 footprint leaves the image is dropped here instead
+// of writing out of bounds), colour not NaN (:478)
+__device__ __forceinline__ bool vcal_sample(const float* __restrict__ images, const float* __restrict__ p2x,
+                                            const float* __restrict__ p2y, int img, int pi, int wI, int hI, int np, float* x,
+                                            float* y, float* color) {
+  *x = p2x[(size_t)img * np + pi];
+  if (isnan(*x)) return false;
+  *y = p2y[(size_t)img * np + pi];
+  if (!(*x >= 0.f && *y >= 0.f && *x < (float)(wI - 1) && *y < (float)(hI - 1))) return false;
+  *color = interp(images + (size_t)img * wI * hI, *x, *y, wI);
+  return !isnan(*color);
+}
+
+__global__ __launch_bounds__(256) void vcal_index_count_kernel(const float* __restrict__ images, const float* __restrict__ p2x,
+                                                               const float* __restrict__ p2y, int wI, int hI, int np,
+                                                               unsigned* __restrict__ counts) {
+  const int pi = blockIdx.x * 256 + threadIdx.x;
+  if (pi >= np) return;
+  float x, y, c;
+  if (!vcal_sample(images, p2x, p2y, blockIdx.y, pi, wI, hI, np, &x, &y, &c)) return;
+  unsigned* b = counts + (int)x + (int)y * wI;
+  atomicAdd(b, 1u);  // integer counts: the result does not depend on the order
+  atomicAdd(b + 1, 1u);
+  atomicAdd(b + wI, 1u);
+  atomicAdd(b + 1 + wI, 1u);
+}
+
+// group g = bins 64g .. 64g+63: length = longest list; exclusive scan of the lengths by one workgroup
+__global__ __launch_bounds__(1024) void vcal_index_scan_kernel(const unsigned* __restrict__ counts, int nbins, int ngroups,
+                                                               unsigned* __restrict__ glen, unsigned long long* __restrict__ gbase) {
+  __shared__ unsigned long long s_sum[1024];
+  __shared__ unsigned long long s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int g0 = 0; g0 < ngroups; g0 += 1024) {
+    const int g = g0 + threadIdx.x;
+    unsigned m = 0;
+    if (g < ngroups)
+      for (int k = 0; k < 64; k++) {
+        const int b = g * 64 + k;
+        if (b < nbins) m = max(m, counts[b]);
+      }
+    if (g < ngroups) glen[g] = m;
+    s_sum[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+      const unsigned long long v = (int)threadIdx.x >= d ? s_sum[threadIdx.x - d] : 0;
+      __syncthreads();
+      s_sum[threadIdx.x] += v;
+      __syncthreads();
+    }
+    if (g < ngroups) gbase[g] = s_carry + s_sum[threadIdx.x] - m;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry += s_sum[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gbase[ngroups] = s_carry;  // total number of 64-entry rows
+}
+
+__device__ __forceinline__ size_t vcal_slot(const unsigned long long* __restrict__ gbase, int bin, unsigned k) {
+  return ((size_t)gbase[bin >> 6] + k) * 64 + (bin & 63);
+}
+
+// entries of ONE image appended to the lists (launched image by image, so lists stay image-major); within the
+// image's segment the order is whatever the slot atomics gave -- vcal_index_sort_kernel puts it right
+__global__ __launch_bounds__(256) void vcal_index_fill_kernel(const float* __restrict__ images, const float* __restrict__ p2x,
+                                                              const float* __restrict__ p2y, int img, int wI, int hI, int np,
+                                                              const unsigned long long* __restrict__ gbase,
+                                                              unsigned* __restrict__ cursor, VcalEntry* __restrict__ entries) {
+  const int pi = blockIdx.x * 256 + threadIdx.x;
+  if (pi >= np) return;
+  VcalEntry e;
+  if (!vcal_sample(images, p2x, p2y, img, pi, wI, hI, np, &e.x, &e.y, &e.color)) return;
+  const int bin0 = (int)e.x + (int)e.y * wI;
+#pragma unroll
+  for (unsigned c = 0; c < 4; c++) {
+    const int bin = bin0 + (c & 1) + (c >> 1) * wI;
+    e.pc = (unsigned)pi | c << kCornerShift;
+    entries[vcal_slot(gbase, bin, atomicAdd(cursor + bin, 1u))] = e;
+  }
+}
+
+// one lane per bin: the segment [seg_begin, cursor) this image appended, ordered by plane point (insertion sort;
+// a pixel receives a handful of samples per image)
+__global__ __launch_bounds__(256) void vcal_index_sort_kernel(const unsigned long long* __restrict__ gbase,
+                                                              const unsigned* __restrict__ seg_begin,
+                                                              const unsigned* __restrict__ cursor, int nbins,
+                                                              VcalEntry* __restrict__ entries) {
+  const int bin = blockIdx.x * 256 + threadIdx.x;
+  if (bin >= nbins) return;
+  const unsigned a = seg_begin[bin], b = cursor[bin];
+  for (unsigned i = a + 1; i < b; i++) {
+    const VcalEntry e = entries[vcal_slot(gbase, bin, i)];
+    const unsigned key = e.pc & ((1u << kCornerShift) - 1);
+    unsigned j = i;
+    while (j > a) {
+      const VcalEntry p = entries[vcal_slot(gbase, bin, j - 1)];
+      if ((p.pc & ((1u << kCornerShift) - 1)) <= key) break;
+      entries[vcal_slot(gbase, bin, j)] = p;
+      j--;
+    }
+    if (j != i) entries[vcal_slot(gbase, bin, j)] = e;
+  }
+}
+
+// the accumulation (:461-509) as a gather: a wave owns a group of 64 bins, lane = bin, lists walked front to back
+__global__ __launch_bounds__(256) void vcal_vignette_gather_kernel(const VcalEntry* __restrict__ entries,
+                                                                   const unsigned long long* __restrict__ gbase,
+                                                                   const unsigned* __restrict__ glen,
+                                                                   const unsigned* __restrict__ counts, int nbins, int wI,
+                                                                   const float* __restrict__ plane_color,
+                                                                   const float* __restrict__ vig, double oth2,
+                                                                   float* __restrict__ TT, float* __restrict__ CT,
+                                                                   double* __restrict__ er) {
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int bin = g * 64 + lane;
+  double E = 0, R = 0;
+  if (g * 64 < nbins) {  // wave-uniform
+    const unsigned len = bin < nbins ? counts[bin] : 0;
+    const unsigned rows = __builtin_amdgcn_readfirstlane(glen[g]);  // wave-uniform trip count
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u* row = reinterpret_cast<const v4u*>(entries) + (size_t)gbase[g] * 64 + lane;
+    float tt = 0.f, ct = 0.f;  // :457-458
+    // Every sample in this bin's list has its 2x2 footprint (:52-70) inside the 3x3 pixels around the bin: the
+    // current factors of that neighbourhood live in registers, the taps of interp(vignetteFactor, x, y) are picked
+    // from them by the entry's corner.  (Neighbours outside the image are never picked: clamped addresses.)
+    float V[3][3];
+    {
+      const int bx = bin % wI, by = bin / wI, hI = nbins / wI;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const int yy = min(max(by + r - 1, 0), hI - 1), xx = min(max(bx + q - 1, 0), wI - 1);
+          V[r][q] = vig[bin < nbins ? yy * wI + xx : 0];
+        }
+    }
+    // Branch-free body: an entry that the reference skips adds +0.0f, which leaves a sum that started at +0 unchanged
+    // bit for bit (x + 0 == x for every x but -0, and a sum that starts at +0 never becomes -0).  Loads are
+    // unconditional too: the lists are allocated with kVcalSlackRows rows of slack, rows beyond a bin's own length hold
+    // padding that `live` masks.
+    unsigned Rn = 0;
+    for (unsigned k0 = 0; k0 < rows; k0 += kVcalSlackRows) {
+      v4u raw[kVcalSlackRows];
+#pragma unroll
+      for (int u = 0; u < kVcalSlackRows; u++) raw[u] = __builtin_nontemporal_load(row + (size_t)(k0 + u) * 64);
+#pragma unroll
+      for (int u = 0; u < kVcalSlackRows; u++) {
+        const bool live = k0 + u < len;
+        const float x = __uint_as_float(raw[u].x), y = __uint_as_float(raw[u].y), colorImage = __uint_as_float(raw[u].z);
+        const unsigned corner = raw[u].w >> kCornerShift;
+        const float colorPlane = plane_color[live ? raw[u].w & ((1u << kCornerShift) - 1) : 0u];
+        const int ix = (int)x, iy = (int)y;
+        const float dx = x - ix, dy = y - iy, dxdy = dx * dy;
+        // the sample's pixel (ix, iy) is the bin minus the corner offset: rows (1 - cy, 2 - cy), columns (1 - cx, 2 - cx)
+        const bool cx = corner & 1, cy = corner >> 1;
+        const float a0 = cy ? V[0][0] : V[1][0], a1 = cy ? V[0][1] : V[1][1], a2 = cy ? V[0][2] : V[1][2];
+        const float b0 = cy ? V[1][0] : V[2][0], b1 = cy ? V[1][1] : V[2][1], b2 = cy ? V[1][2] : V[2][2];
+        const float t00 = cx ? a0 : a1, t01 = cx ? a1 : a2, t10 = cx ? b0 : b1, t11 = cx ? b1 : b2;
+        const float w0 = 1 - dx - dy + dxdy, w1 = dx - dxdy, w2 = dy - dxdy;
+        const float fac = dxdy * t11 + w2 * t10 + w1 * t01 + w0 * t00;  // getInterpolatedElement, :52-70
+        const float diff = colorImage - colorPlane * fac;
+        const double residual = (double)(diff * diff);  // :480
+        const bool seen = live && !isnan(colorPlane);   // :468 and :478 were settled when the index was built, :477 here
+        const bool outlier = fabs(residual) > oth2;     // :481-486 (false for a NaN residual, as in the reference)
+        const bool adds = seen && !outlier;
+        const float w = cy ? (cx ? dxdy : w2) : (cx ? w1 : w0);
+        tt += adds ? w * colorPlane * colorPlane : 0.f;  // :495-498
+        ct += adds ? w * colorImage * colorPlane : 0.f;  // :500-503
+        // E and R once per sample (its corner-0 entry): oth2 for an outlier, else the residual unless fac is NaN (:505-507)
+        const bool counted = seen && corner == 0 && (outlier || !isnan(fac));
+        E += counted ? (outlier ? oth2 : residual) : 0.0;
+        Rn += counted;
+      }
+    }
+    R = (double)Rn;
+    if (bin < nbins) {
+      TT[bin] = tt;
+      CT[bin] = ct;
+    }
+  }
+  block_add_er(E, R, er);
+}
+
 // :511-521: the new factor and its maximum (NaN where fewer than 1 unit of weight arrived)
 __global__ __launch_bounds__(256) void vcal_vignette_update_kernel(const float* __restrict__ TT, const float* __restrict__ CT,
                                                                    float* __restrict__ vig, int npix, unsigned* max_bits) {
@@ -232,6 +441,96 @@ hipError_t launch_vcal_vignette_step(const float* d_images, const float* d_p2x, 
                                                                         (double)oth2, d_tt, d_ct, d_er);
   vcal_vignette_update_kernel<<<blocks((long long)wI * hI), 256, 0, s>>>(d_tt, d_ct, d_vig, wI * hI, d_max_bits);
   vcal_vignette_normalise_kernel<<<blocks((long long)wI * hI), 256, 0, s>>>(d_vig, wI * hI, d_max_bits);
+  return hipGetLastError();
+}
+
+struct VcalIndex {
+  int n = 0, wI = 0, hI = 0, np = 0, nbins = 0, ngroups = 0;
+  unsigned* d_counts = nullptr;           // entries per bin
+  unsigned* d_glen = nullptr;             // rows (of 64 entries) per group of 64 bins
+  unsigned long long* d_gbase = nullptr;  // first row of each group; [ngroups] = total rows
+  VcalEntry* d_entries = nullptr;
+  unsigned long long rows = 0, samples4 = 0;
+};
+
+void vcal_index_free(VcalIndex* ix) {
+  if (!ix) return;
+  (void)hipFree(ix->d_counts);
+  (void)hipFree(ix->d_glen);
+  (void)hipFree(ix->d_gbase);
+  (void)hipFree(ix->d_entries);
+  delete ix;
+}
+
+long long vcal_index_bytes(const VcalIndex* ix) { return ix ? (long long)((ix->rows + kVcalSlackRows) * 64 * sizeof(VcalEntry)) : 0; }
+long long vcal_index_entries(const VcalIndex* ix) { return ix ? (long long)ix->samples4 : 0; }
+
+// Synchronises the stream twice (list sizes come back to the host before the entries can be allocated): set-up work,
+// once per calibration run.
+hipError_t vcal_index_build(const float* d_images, const float* d_p2x, const float* d_p2y, int n, int wI, int hI, int np,
+                            hipStream_t s, VcalIndex** out) {
+  *out = nullptr;
+  VcalIndex* ix = new VcalIndex;
+  ix->n = n;
+  ix->wI = wI;
+  ix->hI = hI;
+  ix->np = np;
+  ix->nbins = wI * hI;
+  ix->ngroups = (ix->nbins + 63) / 64;
+  unsigned *d_cursor = nullptr, *d_seg = nullptr;
+  const size_t bin_bytes = (size_t)ix->nbins * sizeof(unsigned);
+  hipError_t e;
+  auto bail = [&](hipError_t err) {
+    (void)hipFree(d_cursor);
+    (void)hipFree(d_seg);
+    vcal_index_free(ix);
+    return err;
+  };
+  if ((e = hipMalloc(&ix->d_counts, bin_bytes)) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ix->d_glen, (size_t)ix->ngroups * sizeof(unsigned))) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ix->d_gbase, ((size_t)ix->ngroups + 1) * sizeof(unsigned long long))) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&d_cursor, bin_bytes)) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&d_seg, bin_bytes)) != hipSuccess) return bail(e);
+  if ((e = hipMemsetAsync(ix->d_counts, 0, bin_bytes, s)) != hipSuccess) return bail(e);
+  if ((e = hipMemsetAsync(d_cursor, 0, bin_bytes, s)) != hipSuccess) return bail(e);
+  vcal_index_count_kernel<<<dim3(blocks(np), n), 256, 0, s>>>(d_images, d_p2x, d_p2y, wI, hI, np, ix->d_counts);
+  vcal_index_scan_kernel<<<1, 1024, 0, s>>>(ix->d_counts, ix->nbins, ix->ngroups, ix->d_glen, ix->d_gbase);
+  if ((e = hipGetLastError()) != hipSuccess) return bail(e);
+  if ((e = hipMemcpyAsync(&ix->rows, ix->d_gbase + ix->ngroups, sizeof(unsigned long long), hipMemcpyDeviceToHost, s)) != hipSuccess)
+    return bail(e);
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail(e);
+  if (ix->rows) {
+    if ((e = hipMalloc(&ix->d_entries, ((size_t)ix->rows + kVcalSlackRows) * 64 * sizeof(VcalEntry))) != hipSuccess) return bail(e);
+    for (int img = 0; img < n; img++) {
+      if ((e = hipMemcpyAsync(d_seg, d_cursor, bin_bytes, hipMemcpyDeviceToDevice, s)) != hipSuccess) return bail(e);
+      vcal_index_fill_kernel<<<blocks(np), 256, 0, s>>>(d_images, d_p2x, d_p2y, img, wI, hI, np, ix->d_gbase, d_cursor, ix->d_entries);
+      vcal_index_sort_kernel<<<blocks(ix->nbins), 256, 0, s>>>(ix->d_gbase, d_seg, d_cursor, ix->nbins, ix->d_entries);
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return bail(e);
+  }
+  // number of list entries (4 per valid sample): sum of the counts, on the host (set-up)
+  {
+    std::vector<unsigned> h((size_t)ix->nbins);
+    if ((e = hipMemcpyAsync(h.data(), ix->d_counts, bin_bytes, hipMemcpyDeviceToHost, s)) != hipSuccess) return bail(e);
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail(e);
+    for (unsigned v : h) ix->samples4 += v;
+  }
+  (void)hipFree(d_cursor);
+  (void)hipFree(d_seg);
+  *out = ix;
+  return hipSuccess;
+}
+
+hipError_t launch_vcal_vignette_step_indexed(const VcalIndex* ix, const float* d_plane_color, float* d_vig, int oth2, float* d_tt,
+                                             float* d_ct, double* d_er, unsigned* d_max_bits, hipStream_t s) {
+  hipError_t e;
+  if ((e = hipMemsetAsync(d_er, 0, 2 * sizeof(double), s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(d_max_bits, 0, sizeof(unsigned), s)) != hipSuccess) return e;
+  // every bin is written by its lane (empty lists write the reference's memset value 0)
+  vcal_vignette_gather_kernel<<<(ix->ngroups + 3) / 4, 256, 0, s>>>(ix->d_entries, ix->d_gbase, ix->d_glen, ix->d_counts, ix->nbins,
+                                                                    ix->wI, d_plane_color, d_vig, (double)oth2, d_tt, d_ct, d_er);
+  vcal_vignette_update_kernel<<<blocks(ix->nbins), 256, 0, s>>>(d_tt, d_ct, d_vig, ix->nbins, d_max_bits);
+  vcal_vignette_normalise_kernel<<<blocks(ix->nbins), 256, 0, s>>>(d_vig, ix->nbins, d_max_bits);
   return hipGetLastError();
 }
 

@@ -4,7 +4,9 @@ CPU : oracle/mdc_oracle.c's restatement == the reference's own loop text (cut ou
       oracle/vcal_extract.py -> oracle/_ref/libvcal_ref.so), bit for bit, over several alternating iterations.
 GPU : mdc_vcal_plane_step == oracle bit for bit (each plane point sums over the images in the reference's order);
       mdc_vcal_vignette_step within 1e-5 relative (a scatter-add: the summation ORDER of the reference's sequential
-      loop cannot be kept by concurrent atomics; float sums of positive terms differ in the last bits only)."""
+      loop cannot be kept by concurrent atomics; float sums of positive terms differ in the last bits only);
+      mdc_vcal_vignette_step_indexed (the scatter inverted into an ordered gather over mdc_vcal_index) == oracle bit
+      for bit, so the whole alternating iteration on the GPU equals the reference's."""
 import numpy as np
 import pytest
 
@@ -100,3 +102,51 @@ def test_gpu_steps_against_oracle(oracle):
             assert r == r_o and abs(e - e_o) <= 1e-6 * abs(e_o) + 1e-6
             # the next iteration continues from the GPU's own (tolerance-equal) factors on both sides
             vf = d_vf.cpu().numpy().copy()
+
+
+@pytest.mark.gpu
+def test_gpu_indexed_vignette_step_is_bit_identical(oracle):
+    """The vignette half-iteration as an ordered gather over mdc_vcal_index: the whole alternating iteration run on
+    the GPU (plane step, indexed vignette step) stays bit-identical to the oracle (== the reference's loops, test
+    above) over 6 iterations WITHOUT ever re-synchronising the two sides; the atomic variant needs a tolerance."""
+    import torch
+
+    from mono_dataset_code_amd import capi
+
+    ctx = capi.Context(0)
+    st = torch.cuda.current_stream().cuda_stream
+    for seed, shape in ((0, {}), (1, dict(n=9, wI=160, hI=120, gw=140, gh=110)), (2, dict(n=40, wI=97, hI=61, gw=150, gh=95))):
+        images, p2x, p2y, gw, gh = problem(seed, **shape)
+        if seed == 2:  # coordinates the reference's caller would have masked (:283-300): dropped, not written out of bounds
+            p2x[3, 17], p2y[3, 17] = np.float32(images.shape[2] - 0.5), np.float32(5.0)
+            p2x[4, 18], p2y[4, 18] = np.float32(5.0), np.float32(np.nan)
+        n, hI, wI = images.shape
+        d_img, d_x, d_y = (torch.from_numpy(a).cuda() for a in (images, p2x, p2y))
+        index = ctx.vcal_index(d_img, d_x, d_y, st)
+        valid = ~np.isnan(p2x) & ~np.isnan(p2y) & (p2x < wI - 1) & (p2y < hI - 1)
+        assert 0 < index.entries <= 4 * int(valid.sum()) and index.bytes >= 16 * index.entries
+        if seed == 2:
+            p2x[3, 17] = p2x[4, 18] = np.nan  # what the oracle sees: the same samples masked by the caller
+        pc = np.zeros(gw * gh, np.float32)
+        vf = np.ones(hI * wI, np.float32)
+        d_pc, d_vf = torch.from_numpy(pc).cuda(), torch.from_numpy(vf).cuda()
+        for it in range(6):
+            oth2 = 10000 * 10000 if it < 3 else 15 * 15
+            pc, ff_o, fc_o, e_o, r_o = oracle.vcal_plane_step(images, p2x, p2y, pc, vf, oth2)
+            if seed == 2:
+                d_x2, d_y2 = torch.from_numpy(p2x).cuda(), torch.from_numpy(p2y).cuda()
+                ctx.vcal_plane_step(d_img, d_x2, d_y2, d_pc, d_vf, oth2, st)
+            else:
+                ctx.vcal_plane_step(d_img, d_x, d_y, d_pc, d_vf, oth2, st)
+            assert bits_equal(d_pc.cpu().numpy(), pc), (seed, it)
+            vf, tt_o, ct_o, e_o, r_o = oracle.vcal_vignette_step(images, p2x, p2y, pc, vf, oth2)
+            for rep in range(2):  # repeatable: no atomics on the data path
+                d_vf_in = d_vf.clone()
+                tt, ct, e, r = ctx.vcal_vignette_step_indexed(index, d_pc, d_vf_in, oth2, st)
+                torch.cuda.synchronize()
+                assert bits_equal(tt.cpu().numpy(), tt_o), (seed, it, rep)
+                assert bits_equal(ct.cpu().numpy(), ct_o), (seed, it, rep)
+                assert bits_equal(d_vf_in.cpu().numpy(), vf), (seed, it, rep)
+                assert r == r_o and abs(e - e_o) <= 1e-9 * abs(e_o) + 1e-9
+            d_vf = d_vf_in
+        index.close()

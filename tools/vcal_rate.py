@@ -36,8 +36,16 @@ ctx = capi.Context(0)
 st = torch.cuda.current_stream().cuda_stream
 pc = torch.zeros(gw * gh, dtype=torch.float32, device=dev)
 vf = torch.ones(hI * wI, dtype=torch.float32, device=dev)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+index = ctx.vcal_index(images, p2x, p2y, st)
+torch.cuda.synchronize()
+print("GPU contribution index: built in %.1f ms, %.2f GB for %.1f M list entries (%.1f %% padding)"
+      % ((time.perf_counter() - t0) * 1e3, index.bytes / 1e9, index.entries / 1e6, 100.0 * (index.bytes / 16.0 / max(index.entries, 1) - 1)),
+      flush=True)
 for name, fn in (("plane step", lambda: ctx.vcal_plane_step(images, p2x, p2y, pc, vf, 10 ** 8, st)),
-                 ("vignette step", lambda: ctx.vcal_vignette_step(images, p2x, p2y, pc, vf, 10 ** 8, st))):
+                 ("vignette step, atomics", lambda: ctx.vcal_vignette_step(images, p2x, p2y, pc, vf, 10 ** 8, st)),
+                 ("vignette step, indexed", lambda: ctx.vcal_vignette_step_indexed(index, pc, vf, 10 ** 8, st))):
     fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -46,11 +54,13 @@ for name, fn in (("plane step", lambda: ctx.vcal_plane_step(images, p2x, p2y, pc
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
     samples = N * gw * gh
-    print("GPU %-14s: %d images, %.1f ms per half-iteration = %.2f G samples/s" % (name, N, dt * 1e3, samples / dt / 1e9), flush=True)
+    print("GPU %-22s: %d images, %.1f ms per half-iteration = %.2f G samples/s" % (name, N, dt * 1e3, samples / dt / 1e9), flush=True)
 
 try:
     from oracle import loader
 
+    if NC <= 0:
+        raise OSError("skipped (0 images asked for)")
     ref = loader.VcalRef()
     im = images[:NC].cpu().numpy()
     x, y = p2x[:NC].cpu().numpy(), p2y[:NC].cpu().numpy()
