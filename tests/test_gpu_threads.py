@@ -1,0 +1,82 @@
+"""Threading contract of the boundary ("Threading"): the reference's unMapImage and undistort are
+re-entrant on a shared object (read-only tables, caller-owned buffers; undistort is const), and 8 threads sharing one
+pair of objects is how a multi-threaded caller would drive them.  Here: 8 host threads share ONE PhotometricUndistorter,
+ONE UndistorterFOV and ONE mdc_ctx and call the class methods and the C-ABI host / device entry points concurrently
+(ctypes releases the GIL for the duration of a call), every thread on its own frames; every result must be the
+oracle's, bit for bit."""
+import itertools
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+from test_gpu_parity import Setup
+
+pytestmark = pytest.mark.gpu
+
+NTHREADS, ROUNDS = 8, 12
+
+
+def test_shared_objects_from_many_threads(calib_dirs, oracle):
+    import torch
+
+    from mono_dataset_code_amd import capi, synth
+
+    s = Setup("small_explicit", calib_dirs, oracle)
+    npi, npo = s.W * s.H, s.w * s.h
+    all_flags = [(capi.RECTIFY * r) | (capi.GAMMA * g) | (capi.VIGNETTE * v) | (capi.KILL_OVEREXPOSED * o)
+                 for r, g, v, o in itertools.product((0, 1), repeat=4)]
+    rng = np.random.default_rng(5)
+    frames = [rng.integers(0, 256, npi, dtype=np.uint8) for _ in range(NTHREADS)]
+    for f in frames:
+        f[rng.integers(0, npi, 50)] = 255
+    # expected results, computed up front on one thread
+    want_proc = [{fl: s.want(oracle, f, bool(fl & capi.RECTIFY), bool(fl & capi.GAMMA), bool(fl & capi.VIGNETTE),
+                             bool(fl & capi.KILL_OVEREXPOSED)) for fl in all_flags} for f in frames]
+    want_unmap = [oracle.unmap(f, s.ginv, s.vinv, True, True, 1, 1, 1) for f in frames]
+    want_und = [oracle.undistort(u, s.rx, s.ry, s.W) for u in want_unmap]
+    want_und8 = [oracle.undistort(f, s.rx, s.ry, s.W) for f in frames]
+    errors = []
+    start = threading.Barrier(NTHREADS)
+
+    def worker(k):
+        try:
+            raw = frames[k]
+            stream = torch.cuda.Stream()
+            d_in = torch.from_numpy(np.stack([raw] * 3)).cuda()
+            d_out = torch.empty((3, npo), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            start.wait()
+            for it in range(ROUNDS):
+                # the two class methods, as DatasetReader::getImage chains them (reference src/BenchmarkDatasetReader.h:222-223)
+                tmp = np.full(npi, -7.0, np.float32)
+                s.photo.unmap(raw, tmp, 1, 1, 1)
+                assert bits_equal(tmp, want_unmap[k]), ("unMapImage", k, it)
+                out = np.full(npo, -7.0, np.float32)
+                s.fov.undistort(tmp, out)
+                assert bits_equal(out, want_und[k]), ("undistort<float>", k, it)
+                out8 = np.full(npo, -7.0, np.float32)
+                s.fov.undistort(raw, out8)
+                assert bits_equal(out8, want_und8[k]), ("undistort<uchar>", k, it)
+                # the fused host call with a flag combination that differs per thread and iteration
+                fl = all_flags[(k * 5 + it) % 16]
+                o2 = np.full(npo if fl & capi.RECTIFY else npi, -7.0, np.float32)
+                s.ctx.process_host(raw, o2, fl)
+                assert bits_equal(o2, want_proc[k][fl]), ("process_host", k, it, fl)
+                # a device batch on the thread's own stream
+                d_out.fill_(-7.0)
+                s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), 3, 15, stream.cuda_stream)
+                stream.synchronize()
+                got = d_out.cpu().numpy()
+                for j in range(3):
+                    assert bits_equal(got[j], want_proc[k][15]), ("process_batch", k, it, j)
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(NTHREADS)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
