@@ -76,7 +76,7 @@ def parse():
                    help="untimed clock ramp before the warmup steps: the first ~30 ms after an idle period run ~15 %% "
                         "slow (DVFS, profiles/r01_dvfs_warmup_curve.txt)")
     p.add_argument("--frames", type=int, default=0,
-                   help="frames per GPU per step = batch of one launch (0 = 4096 for fused/unmap, 256 for pyramid; "
+                   help="frames per GPU per step = batch of one launch (0 = 4096 for fused/unmap, 1024 for pyramid; "
                         "seq50k: the rank's shard)")
     p.add_argument("--workload", default="fused", choices=["fused", "unmap", "pyramid", "seq50k"])
     p.add_argument("--kernel", default="auto", choices=["auto", "gather", "tiled"])
@@ -286,7 +286,10 @@ def main():
         total = args.frames * world if args.frames else SEQ50K  # --frames shrinks the sequence for tests
         mine = shard.frames_of_rank(total, rank, world)
     else:
-        per = args.frames or (256 if wl == "pyramid" else 4096)
+        # pyramid: 1024 frames = 1.3 GB in + 7.1 GB out.  Not fewer: below ~384 frames the raw batch (1.3 MB a frame) partly
+        # survives in the 256-MiB Infinity Cache from one step to the next and the rate comes out up to 40 % too high
+        # (tools/footprint_curve.py, profiles/r02c_footprint_curve.txt)
+        per = args.frames or (1024 if wl == "pyramid" else 4096)
         total = per * world
         mine = shard.frames_of_rank(total, rank, world)
     B = len(mine)

@@ -528,13 +528,17 @@ __device__ __forceinline__ void wait_vm_barrier() {
 // previous frame's stores, which is what deeper staging is meant to avoid.)  More stores than 4 per frame (pyramid)
 // only make the wait more conservative.  The count relies on the chunk list being dense: a wave's round k has a
 // chunk for its first lane iff wave*64 + k*NT < nch.
-template <int D, int R>
+// S = stores a wave issues per frame after its DMA group: 4 (the outputs), or 7 in the fused pyramid when levels 1 and 2
+// are both written (2 + 1 more; level 3's single store -- issued by a few threads at the top of the NEXT iteration, before
+// that iteration's DMA group -- is left out of the count, which keeps the allowance on the safe side).  Counting the
+// pyramid's stores as 4 made every frame wait for the acknowledgement of half of the previous frame's stores.
+template <int D, int R, int S = 4>
 __device__ __forceinline__ void frame_barrier(int rw) {
-  if (R >= 4 && rw >= 4) wait_vm_barrier<(D - 1) * (4 + 4) + 4>();
-  else if (R >= 3 && rw == 3) wait_vm_barrier<(D - 1) * (3 + 4) + 4>();
-  else if (R >= 2 && rw == 2) wait_vm_barrier<(D - 1) * (2 + 4) + 4>();
-  else if (rw == 1) wait_vm_barrier<(D - 1) * (1 + 4) + 4>();
-  else wait_vm_barrier<4>();
+  if (R >= 4 && rw >= 4) wait_vm_barrier<(D - 1) * (4 + S) + S>();
+  else if (R >= 3 && rw == 3) wait_vm_barrier<(D - 1) * (3 + S) + S>();
+  else if (R >= 2 && rw == 2) wait_vm_barrier<(D - 1) * (2 + S) + S>();
+  else if (rw == 1) wait_vm_barrier<(D - 1) * (1 + S) + S>();
+  else wait_vm_barrier<S>();
 }
 
 // Frames [0, nframes) of one tile.  NBUF window buffers, D = NBUF-1 frames staged ahead: the DMA
@@ -580,6 +584,7 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
   float* s_pyr = (float*)(s_win + NBUF * win_bytes);  // [2][G][L2W] level-2 rows (PYR only)
   const int pyr_slot = (wave / (TW / 64)) * L2W + (wave % (TW / 64)) * 16;  // this wave's 16 floats inside one [G][L2W] set
   const uint32_t l1_bytes = out_bytes / 4, l2_bytes = out_bytes / 16, l3_bytes = out_bytes / 64;
+  const bool pyr_all_levels = PYR && py.l1 && py.l2;  // workgroup-uniform: 7 stores per wave and frame
   for (int f = 0; f <= last; f++) {
     if (PYR && f > 0)
       pyramid_level3<G, TW>(py, f_first + (long long)(f - 1) * fstep, l3_bytes, s_pyr + ((f - 1) & 1) * G * L2W, p3byte, tid);
@@ -594,7 +599,9 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
       pyramid_levels12(t, res, py, f_first + (long long)f * fstep, l1_bytes, l2_bytes, s_pyr + (f & 1) * G * L2W + pyr_slot,
                        tid & 63);
     dst += out_step;
-    frame_barrier<D, R>(rw);  // frame f+1 landed in every wave's part of w[1]; everyone is done reading w[0]
+    // frame f+1 landed in every wave's part of w[1]; everyone is done reading w[0]
+    if (PYR && pyr_all_levels) frame_barrier<D, R, 7>(rw);
+    else frame_barrier<D, R>(rw);
     lds_u8_ptr x = w[0];
 #pragma unroll
     for (int i = 0; i < D; i++) w[i] = w[i + 1];
