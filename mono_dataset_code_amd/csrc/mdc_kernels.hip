@@ -41,6 +41,9 @@ constexpr int kLutBytes = 256 * kLutRep * 4;
 #ifndef MDC_EXP_FAKE_COMPUTE
 #define MDC_EXP_FAKE_COMPUTE 0  // diagnosis (wrong results): 1 = one tap + one LUT read per output instead of 4 + 4, 2 = no LDS reads
 #endif
+#ifndef MDC_EXP_TIMING
+#define MDC_EXP_TIMING 0      // diagnosis: wave 0 / 5 of some workgroups print the cycles their frame loop spent per phase (tools/phase_timing.sh)
+#endif
 #ifndef MDC_EXP_SKIP_LOAD
 #define MDC_EXP_SKIP_LOAD 0   // diagnosis: every frame re-stages frame 0 (L2 hits) -> write side alone
 #endif
@@ -528,10 +531,31 @@ __device__ __forceinline__ void wait_vm_barrier() {
 // previous frame's stores, which is what deeper staging is meant to avoid.)  More stores than 4 per frame (pyramid)
 // only make the wait more conservative.  The count relies on the chunk list being dense: a wave's round k has a
 // chunk for its first lane iff wave*64 + k*NT < nch.
+#if MDC_EXP_TIMING
+__device__ __forceinline__ unsigned long long exp_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#endif
 // S = stores a wave issues per frame after its DMA group: 4 (the outputs), or 7 in the fused pyramid when levels 1 and 2
 // are both written (2 + 1 more; level 3's single store -- issued by a few threads at the top of the NEXT iteration, before
 // that iteration's DMA group -- is left out of the count, which keeps the allowance on the safe side).  Counting the
 // pyramid's stores as 4 made every frame wait for the acknowledgement of half of the previous frame's stores.
+#if MDC_EXP_TIMING
+template <int N>
+__device__ __forceinline__ void wait_vm_only() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+template <int D, int R, int S = 4>
+__device__ __forceinline__ void frame_wait_only(int rw) {
+  if (R >= 4 && rw >= 4) wait_vm_only<(D - 1) * (4 + S) + S>();
+  else if (R >= 3 && rw == 3) wait_vm_only<(D - 1) * (3 + S) + S>();
+  else if (R >= 2 && rw == 2) wait_vm_only<(D - 1) * (2 + S) + S>();
+  else if (rw == 1) wait_vm_only<(D - 1) * (1 + S) + S>();
+  else wait_vm_only<S>();
+}
+#endif
 template <int D, int R, int S = 4>
 __device__ __forceinline__ void frame_barrier(int rw) {
   if (R >= 4 && rw >= 4) wait_vm_barrier<(D - 1) * (4 + S) + S>();
@@ -585,13 +609,23 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
   const int pyr_slot = (wave / (TW / 64)) * L2W + (wave % (TW / 64)) * 16;  // this wave's 16 floats inside one [G][L2W] set
   const uint32_t l1_bytes = out_bytes / 4, l2_bytes = out_bytes / 16, l3_bytes = out_bytes / 64;
   const bool pyr_all_levels = PYR && py.l1 && py.l2;  // workgroup-uniform: 7 stores per wave and frame
+#if MDC_EXP_TIMING
+  unsigned long long tp[4] = {0, 0, 0, 0};
+  const unsigned long long t_begin = exp_now();
+#endif
   for (int f = 0; f <= last; f++) {
+#if MDC_EXP_TIMING
+    const unsigned long long t0 = exp_now();
+#endif
     if (PYR && f > 0)
       pyramid_level3<G, TW>(py, f_first + (long long)(f - 1) * fstep, l3_bytes, s_pyr + ((f - 1) & 1) * G * L2W, p3byte, tid);
 #if MDC_EXP_SKIP_LOAD
     stage_window<R, NT>(src, in_bytes, w[D], goff, wave);
 #else
     stage_window<R, NT>(src + min(f + D, last) * in_step, in_bytes, w[D], goff, wave);
+#endif
+#if MDC_EXP_TIMING
+    const unsigned long long t1 = exp_now();
 #endif
     float res[4];
     tile_compute<VIG, BLACK, F32, (NT >= 960), ((NT >= 960 || PYR) ? 2 : 4)>(t, w[0], my_lut, dst, out_bytes, row_bytes, res, win_bytes);
@@ -600,14 +634,33 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
                        tid & 63);
     dst += out_step;
     // frame f+1 landed in every wave's part of w[1]; everyone is done reading w[0]
+#if MDC_EXP_TIMING
+    const unsigned long long t2 = exp_now();
+    if (PYR && pyr_all_levels) frame_wait_only<D, R, 7>(rw);
+    else frame_wait_only<D, R>(rw);
+    const unsigned long long t3 = exp_now();
+    asm volatile("s_barrier" ::: "memory");
+    const unsigned long long t4 = exp_now();
+    tp[0] += t1 - t0;  // level 3 of the previous frame + DMA issue
+    tp[1] += t2 - t1;  // tap reads, LUT reads, arithmetic, store issue (+ levels 1, 2)
+    tp[2] += t3 - t2;  // s_waitcnt vmcnt: the wave's DMA of the next frame landed, older stores retired
+    tp[3] += t4 - t3;  // s_barrier: the other waves
+#else
     if (PYR && pyr_all_levels) frame_barrier<D, R, 7>(rw);
     else frame_barrier<D, R>(rw);
+#endif
     lds_u8_ptr x = w[0];
 #pragma unroll
     for (int i = 0; i < D; i++) w[i] = w[i + 1];
     w[D] = x;
   }
   if (PYR) pyramid_level3<G, TW>(py, f_first + (long long)last * fstep, l3_bytes, s_pyr + (last & 1) * G * L2W, p3byte, tid);
+#if MDC_EXP_TIMING
+  if ((tid & 63) == 0 && (wave == 0 || wave == 5) && blockIdx.x % 41 == 3 && blockIdx.y % 7 == 2)
+    printf("TIMING block %d,%d wave %d frames %d cycles/frame: issue %.0f compute+stores %.0f vmwait %.0f barrier %.0f total %.0f\n",
+           (int)blockIdx.x, (int)blockIdx.y, wave, nframes, (double)tp[0] / nframes, (double)tp[1] / nframes, (double)tp[2] / nframes,
+           (double)tp[3] / nframes, (double)(exp_now() - t_begin) / nframes);
+#endif
 }
 
 // Occupancy is set by LDS (LUT replicas + two window buffers): 3 workgroups of 512 threads or 2 of

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Target for PC sampling: N launches of the fused kernel (or the pyramid one) on 1024 frames.
-usage: python tools/pc_sample_target.py [fused|pyramid] [launches]"""
+"""N launches of the fused kernel (or the fused-pyramid one) on 1024 frames: the process diagnosis builds and profilers are
+pointed at (tools/phase_timing.sh; PC sampling and thread trace are not available on the pool's boxes: rocprofv3 reports no
+agent that supports PC sampling, and the ATT decoder library is not installed).
+usage: python tools/launch_target.py [fused|pyramid] [launches]"""
 import os
 import sys
 import tempfile
