@@ -334,7 +334,8 @@ struct TileThread {
   uint32_t obyte[4];     // byte offset of the output inside a frame, kOutside if not in the image (LEAN: [0] only)
   bool black[4];
   float v00[4], v10[4], v01[4], v11[4];
-  uint32_t p1byte[2], p2byte;  // fused pyramid: byte offsets of this lane's level-1 / level-2 outputs (kOutside if none)
+  uint32_t p1byte, p2byte;  // fused pyramid: byte offsets of this lane's level-1 / level-2 outputs (p2byte: kOutside if none).
+                            // Level 1: even lanes store the box of rows 0-1, odd lanes the box of rows 2-3 of their LEFT neighbour's column pair -- one full store
 };
 
 template <bool VIG, bool BLACK, bool F32, bool LEAN, int B>
@@ -457,8 +458,11 @@ __device__ __forceinline__ void pyramid_levels12(const TileThread& t, const floa
   }
   if (py.l1) {
     const auto r1 = MDC_FRAME_RSRC(py.l1 + f * (l1_bytes / 4), l1_bytes);
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1[0]), r1, t.p1byte[0], 0, kStoreAux);
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1[1]), r1, t.p1byte[1], 0, kStoreAux);
+    // both level-1 rows of the wave in ONE 64-lane store (quad_perm [0,0,2,2]: odd lanes take their left neighbour's
+    // second box): a vector-memory instruction less per frame than two half-empty stores
+    const float left2 = dpp_quad<0xA0>(v1[1]);  // executed by ALL lanes: a DPP read of a lane that is masked off returns nothing useful
+    const float m = (lane & 1) ? left2 : v1[0];
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), r1, t.p1byte, 0, kStoreAux);
   }
   const float b2 = dpp_quad<0xAA>(v1[0]);  // quad_perm [2,2,2,2]: lane 4k reads lane 4k+2
   const float d2 = dpp_quad<0xAA>(v1[1]);
@@ -475,11 +479,11 @@ __device__ __forceinline__ void pyramid_levels12(const TileThread& t, const floa
 // (RG = row groups of 4 output rows, each leaving one level-2 row of TW/4 floats)
 template <int RG, int TW>
 __device__ __forceinline__ void pyramid_level3(const PyramidOut& py, long long f, uint32_t l3_bytes, const float* s_rows,
-                                               uint32_t p3byte, int tid) {
+                                               uint32_t p3byte, int u3) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int L2W = TW / 4, L3W = TW / 8;
-  if (py.l3 && tid < L3W * (RG / 2)) {
-    const int m = tid / L3W, k = tid % L3W;
+  if (py.l3 && u3 >= 0 && u3 < L3W * (RG / 2)) {  // u3 = lane of the last wave (negative in the other waves)
+    const int m = u3 / L3W, k = u3 % L3W;
     const float* top = s_rows + (2 * m) * L2W + 2 * k;
     const float* bot = s_rows + (2 * m + 1) * L2W + 2 * k;
     const float v3 = box4(top[0], top[1], bot[0], bot[1]);
@@ -538,8 +542,8 @@ __device__ __forceinline__ unsigned long long exp_now() {
   return t;
 }
 #endif
-// S = stores a wave issues per frame after its DMA group: 4 (the outputs), or 7 in the fused pyramid when levels 1 and 2
-// are both written (2 + 1 more; level 3's single store -- issued by a few threads at the top of the NEXT iteration, before
+// S = stores a wave issues per frame after its DMA group: 4 (the outputs), or 6 in the fused pyramid when levels 1 and 2
+// are both written (1 + 1 more; level 3's single store -- issued by a few threads at the top of the NEXT iteration, before
 // that iteration's DMA group -- is left out of the count, which keeps the allowance on the safe side).  Counting the
 // pyramid's stores as 4 made every frame wait for the acknowledgement of half of the previous frame's stores.
 #if MDC_EXP_TIMING
@@ -608,7 +612,7 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
   float* s_pyr = (float*)(s_win + NBUF * win_bytes);  // [2][G][L2W] level-2 rows (PYR only)
   const int pyr_slot = (wave / (TW / 64)) * L2W + (wave % (TW / 64)) * 16;  // this wave's 16 floats inside one [G][L2W] set
   const uint32_t l1_bytes = out_bytes / 4, l2_bytes = out_bytes / 16, l3_bytes = out_bytes / 64;
-  const bool pyr_all_levels = PYR && py.l1 && py.l2;  // workgroup-uniform: 7 stores per wave and frame
+  const bool pyr_all_levels = PYR && py.l1 && py.l2;  // workgroup-uniform: 6 stores per wave and frame
 #if MDC_EXP_TIMING
   unsigned long long tp[4] = {0, 0, 0, 0};
   const unsigned long long t_begin = exp_now();
@@ -618,7 +622,7 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
     const unsigned long long t0 = exp_now();
 #endif
     if (PYR && f > 0)
-      pyramid_level3<G, TW>(py, f_first + (long long)(f - 1) * fstep, l3_bytes, s_pyr + ((f - 1) & 1) * G * L2W, p3byte, tid);
+      pyramid_level3<G, TW>(py, f_first + (long long)(f - 1) * fstep, l3_bytes, s_pyr + ((f - 1) & 1) * G * L2W, p3byte, tid - (NT - 64));
 #if MDC_EXP_SKIP_LOAD
     stage_window<R, NT>(src, in_bytes, w[D], goff, wave);
 #else
@@ -636,7 +640,7 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
     // frame f+1 landed in every wave's part of w[1]; everyone is done reading w[0]
 #if MDC_EXP_TIMING
     const unsigned long long t2 = exp_now();
-    if (PYR && pyr_all_levels) frame_wait_only<D, R, 7>(rw);
+    if (PYR && pyr_all_levels) frame_wait_only<D, R, 6>(rw);
     else frame_wait_only<D, R>(rw);
     const unsigned long long t3 = exp_now();
     asm volatile("s_barrier" ::: "memory");
@@ -646,7 +650,7 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
     tp[2] += t3 - t2;  // s_waitcnt vmcnt: the wave's DMA of the next frame landed, older stores retired
     tp[3] += t4 - t3;  // s_barrier: the other waves
 #else
-    if (PYR && pyr_all_levels) frame_barrier<D, R, 7>(rw);
+    if (PYR && pyr_all_levels) frame_barrier<D, R, 6>(rw);
     else frame_barrier<D, R>(rw);
 #endif
     lds_u8_ptr x = w[0];
@@ -654,7 +658,7 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
     for (int i = 0; i < D; i++) w[i] = w[i + 1];
     w[D] = x;
   }
-  if (PYR) pyramid_level3<G, TW>(py, f_first + (long long)last * fstep, l3_bytes, s_pyr + (last & 1) * G * L2W, p3byte, tid);
+  if (PYR) pyramid_level3<G, TW>(py, f_first + (long long)last * fstep, l3_bytes, s_pyr + (last & 1) * G * L2W, p3byte, tid - (NT - 64));
 #if MDC_EXP_TIMING
   if ((tid & 63) == 0 && (wave == 0 || wave == 5) && blockIdx.x % 41 == 3 && blockIdx.y % 7 == 2)
     printf("TIMING block %d,%d wave %d frames %d cycles/frame: issue %.0f compute+stores %.0f vmwait %.0f barrier %.0f total %.0f\n",
@@ -732,8 +736,8 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
       xx[j] = yy[j] = -1.f;
       tp[j] = 0;
     }
-    if (PYR && (j & 1) == 0)  // level 1: even lanes, rows oy/2; (whole tiles only, so `inside` holds)
-      t.p1byte[j >> 1] = (lane_x & 1) ? kOutside : (uint32_t)((oy >> 1) * (a.out_w >> 1) + (ox >> 1)) * 4u;
+    if (PYR && j == 0)  // level 1: even lanes row oy/2, odd lanes row oy/2 + 1, column ox/2 (whole tiles only, so `inside` holds)
+      t.p1byte = (uint32_t)(((oy >> 1) + (lane_x & 1)) * (a.out_w >> 1) + (ox >> 1)) * 4u;
     if (PYR && j == 0) t.p2byte = (lane_x & 3) ? kOutside : (uint32_t)((oy >> 2) * (a.out_w >> 2) + (ox >> 2)) * 4u;
     t.black[j] = xx[j] < 0;  // outputs outside the image count as black: their taps read window byte 0, their store is dropped
     t.bl[j] = bilin_of(t.black[j] ? 0.f : xx[j], t.black[j] ? 0.f : yy[j]);
@@ -759,10 +763,16 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
   const uint32_t out_bytes = (uint32_t)a.out_w * (uint32_t)a.out_h * 4u;
   const uint8_t* src = in + (long long)f0 * in_bytes;
   float* dst = out + (long long)f0 * (out_bytes / 4);
-  uint32_t p3byte = kOutside;  // level 3: thread u < (TW/8)*(rows/8) owns pixel (u % (TW/8), u / (TW/8)) of the tile's level-3 block
-  if (PYR && tid < (TW / 8) * (kTileRows / 8))
-    p3byte = (uint32_t)(((tile / p.tiles_x) * (kTileRows / 8) + tid / (TW / 8)) * (a.out_w >> 3) + (tile % p.tiles_x) * (TW / 8) +
-                        tid % (TW / 8)) * 4u;
+  // level 3: lane u < (TW/8)*(rows/8) (<= 64 for every tile shape) of the LAST wave owns pixel (u % (TW/8), u / (TW/8)) of the
+  // tile's level-3 block.  The last wave, not the first: with small windows (a scale-1 remap stages ~160 chunks) only the
+  // first waves have LDS-DMA to issue at the top of a frame, and whoever does level 3 there is the wave everybody else
+  // waits for at the frame's barrier (tools/phase_timing.sh: 2600 cycles against 170).
+  static_assert((TW / 8) * (kTileRows / 8) <= 64, "level 3 of a tile is one wave's work");
+  const int u3 = tid - (NT - 64);
+  uint32_t p3byte = kOutside;
+  if (PYR && u3 >= 0 && u3 < (TW / 8) * (kTileRows / 8))
+    p3byte = (uint32_t)(((tile / p.tiles_x) * (kTileRows / 8) + u3 / (TW / 8)) * (a.out_w >> 3) + (tile % p.tiles_x) * (TW / 8) +
+                        u3 % (TW / 8)) * 4u;
   if (nch == 0) {  // every output of the tile is black (or outside): zeros (on every level), no staging
 #if __HIP_DEVICE_COMPILE__
     for (int f = 0; f < nf; f++, dst += (long long)fstep * (out_bytes / 4)) {
@@ -774,8 +784,7 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
         const long long fa = (long long)f0 + (long long)f * fstep;
         if (py.l1) {
           const auto r1 = MDC_FRAME_RSRC(py.l1 + fa * (out_bytes / 16), out_bytes / 4);
-          __builtin_amdgcn_raw_buffer_store_b32(0u, r1, t.p1byte[0], 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(0u, r1, t.p1byte[1], 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(0u, r1, t.p1byte, 0, 0);
         }
         if (py.l2) __builtin_amdgcn_raw_buffer_store_b32(0u, MDC_FRAME_RSRC(py.l2 + fa * (out_bytes / 64), out_bytes / 16), t.p2byte, 0, 0);
         if (py.l3) __builtin_amdgcn_raw_buffer_store_b32(0u, MDC_FRAME_RSRC(py.l3 + fa * (out_bytes / 256), out_bytes / 64), p3byte, 0, 0);
