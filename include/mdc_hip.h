@@ -250,6 +250,18 @@ int64_t mdc_vcal_index_entries(const mdc_vcal_index* index); /* list entries = 4
 int mdc_vcal_vignette_step_indexed_device(mdc_ctx* ctx, const mdc_vcal_index* index, const float* d_plane_color,
                                           float* d_vignette_factor, int oth2, float* d_tt, float* d_ct, double* d_er, void* stream);
 
+/* The whole iteration loop :395-527 in one call: builds the contribution index, then max_iterations times the plane step
+ * and the indexed vignette step with the reference's outlier schedule (oth2 = 10000^2 in the first half of the iterations,
+ * outlier_th^2 after, :397-398; the reference's defaults are 20 iterations, outlierTh 15), everything on `stream`,
+ * one synchronisation at the end.  d_plane_color (n_plane floats; the reference starts from an uninitialised array --
+ * pass what you want it to start from, e.g. zeros) and d_vignette_factor (w*h floats; the reference starts from 1,
+ * :391) are updated in place and end up bit-identical to the reference's arrays after the same iterations from the
+ * same start.  er_out (host, may be NULL): max_iterations x {E, R of the plane step, E, R of the vignette step} -- what
+ * the reference prints as "R residual terms => sqrtf(E/R)" (:449, :523). */
+int mdc_vcal_solve_device(mdc_ctx* ctx, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
+                          int n_plane, float* d_plane_color, float* d_vignette_factor, int max_iterations, int outlier_th,
+                          double* er_out, void* stream);
+
 /* Synthetic sequence generator (bench/test utility):
  * byte i of frame f = fmix32(seed + (first_frame+f)*npix + i) >> 24. */
 int mdc_synth_frames_device(mdc_ctx* ctx, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix,

@@ -32,7 +32,7 @@ HIP_SYMBOLS = [
     "mdc_synchronize", "mdc_describe_launch", "mdc_ceiling_mix_device", "mdc_vcal_plane_step_device",
     "mdc_vcal_vignette_step_device", "mdc_gradients_batch_device", "mdc_tune_device",
     "mdc_vcal_index_create", "mdc_vcal_index_destroy", "mdc_vcal_index_bytes", "mdc_vcal_index_entries",
-    "mdc_vcal_vignette_step_indexed_device",
+    "mdc_vcal_vignette_step_indexed_device", "mdc_vcal_solve_device",
 ]
 HOST_SYMBOLS = [
     "mdch_fov_create", "mdch_fov_destroy", "mdch_fov_valid", "mdch_fov_has_gpu", "mdch_fov_dims",
@@ -140,6 +140,8 @@ def hip_lib():
             L.mdc_vcal_index_entries.argtypes = [_vp]
             L.mdc_vcal_index_entries.restype = C.c_int64
             L.mdc_vcal_vignette_step_indexed_device.argtypes = [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]
+        if not old_build or hasattr(L, "mdc_vcal_solve_device"):
+            L.mdc_vcal_solve_device.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]
         for n in HIP_SYMBOLS:
             if old_build and not hasattr(L, n):
                 continue
@@ -428,6 +430,16 @@ class Context:
                                                         er.data_ptr(), stream if stream else None))
         e, r = er.cpu().tolist()
         return tt, ct, e, r
+
+    def vcal_solve(self, d_images, d_p2x, d_p2y, d_plane_color, d_vig, max_iterations=20, outlier_th=15, stream=0):
+        """The reference's whole iteration loop (src/main_vignetteCalib.cpp:395-527); d_plane_color and d_vig are updated
+        in place -> array [max_iterations][4] = E, R of the plane step, E, R of the vignette step."""
+        n, h, w = d_images.shape
+        er = np.zeros((max(max_iterations, 0), 4), np.float64)
+        self._chk(self._L.mdc_vcal_solve_device(self._h, d_images.data_ptr(), d_p2x.data_ptr(), d_p2y.data_ptr(), n, w, h, d_p2x.shape[1],
+                                                d_plane_color.data_ptr(), d_vig.data_ptr(), int(max_iterations), int(outlier_th),
+                                                _np_ptr(er), stream if stream else None))
+        return er
 
     def vcal_index(self, d_images, d_p2x, d_p2y, stream=0):
         """Contribution index of the vignette half-iteration for these images / coordinates (mdc_vcal_index_create)."""

@@ -983,6 +983,52 @@ int mdc_vcal_vignette_step_indexed_device(mdc_ctx* c, const mdc_vcal_index* inde
   return MDC_OK;
 }
 
+int mdc_vcal_solve_device(mdc_ctx* c, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
+                          int n_plane, float* d_plane_color, float* d_vignette_factor, int max_iterations, int outlier_th,
+                          double* er_out, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (!d_plane_color || !d_vignette_factor || max_iterations < 0 || outlier_th < 0 || outlier_th > 46340)
+    return fail(c, MDC_ERR_ARG, "mdc_vcal_solve_device: bad argument");
+  if (max_iterations == 0) return MDC_OK;
+  mdc_vcal_index* index = nullptr;
+  int rc = mdc_vcal_index_create(c, d_images, d_p2x, d_p2y, n_images, w, h, n_plane, stream, &index);
+  if (rc != MDC_OK) return rc;
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  hipStream_t s = (hipStream_t)stream;
+  float *d_ff = nullptr, *d_fc = nullptr, *d_tt = nullptr, *d_ct = nullptr;
+  double* d_er = nullptr;
+  const size_t plane_bytes = (size_t)std::max(n_plane, 1) * sizeof(float), img_bytes = (size_t)w * h * sizeof(float);
+  const size_t er_bytes = (size_t)max_iterations * 4 * sizeof(double);
+  auto done = [&](int code) {
+    (void)hipStreamSynchronize(s);
+    for (void* p : {(void*)d_ff, (void*)d_fc, (void*)d_tt, (void*)d_ct, (void*)d_er}) (void)hipFree(p);
+    mdc_vcal_index_destroy(index);
+    return code;
+  };
+#define MDC_SOLVE(call_)                                                  \
+  do {                                                                    \
+    hipError_t e_ = (call_);                                              \
+    if (e_ != hipSuccess) return done(fail(c, MDC_ERR_HIP, "%s: %s", #call_, hipGetErrorString(e_))); \
+  } while (0)
+  MDC_SOLVE(hipMalloc(&d_ff, plane_bytes));
+  MDC_SOLVE(hipMalloc(&d_fc, plane_bytes));
+  MDC_SOLVE(hipMalloc(&d_tt, img_bytes));
+  MDC_SOLVE(hipMalloc(&d_ct, img_bytes));
+  MDC_SOLVE(hipMalloc(&d_er, er_bytes));
+  if (!c->d_vcal_max) MDC_SOLVE(hipMalloc(&c->d_vcal_max, sizeof(unsigned)));
+  for (int it = 0; it < max_iterations; it++) {
+    const int oth2 = it < max_iterations / 2 ? 10000 * 10000 : outlier_th * outlier_th;  // :397-398
+    MDC_SOLVE(launch_vcal_plane_step(d_images, d_p2x, d_p2y, n_images, w, h, n_plane, d_plane_color, d_vignette_factor, oth2, d_ff,
+                                     d_fc, d_er + 4 * it, s));
+    MDC_SOLVE(mdc::launch_vcal_vignette_step_indexed(index->ix, d_plane_color, d_vignette_factor, oth2, d_tt, d_ct, d_er + 4 * it + 2,
+                                                     c->d_vcal_max, s));
+  }
+  if (er_out) MDC_SOLVE(hipMemcpyAsync(er_out, d_er, er_bytes, hipMemcpyDeviceToHost, s));
+#undef MDC_SOLVE
+  return done(MDC_OK);
+}
+
 int mdc_synth_frames_device(mdc_ctx* c, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix, uint32_t seed,
                             void* stream) {
   if (!c) return MDC_ERR_ARG;

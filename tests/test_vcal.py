@@ -150,3 +150,35 @@ def test_gpu_indexed_vignette_step_is_bit_identical(oracle):
                 assert r == r_o and abs(e - e_o) <= 1e-9 * abs(e_o) + 1e-9
             d_vf = d_vf_in
         index.close()
+
+
+@pytest.mark.gpu
+def test_gpu_solver_loop_in_one_call(oracle):
+    """mdc_vcal_solve_device = the reference's whole loop :395-527 (index, 2 x max_iterations half-iterations, outlier
+    schedule) in one call: plane colours and vignette factors after 10 iterations are the oracle's, bit for bit; the
+    printed statistics agree (R exactly, E to 1e-9)."""
+    import torch
+
+    from mono_dataset_code_amd import capi
+
+    ctx = capi.Context(0)
+    st = torch.cuda.current_stream().cuda_stream
+    for seed, shape, iters, th in ((0, {}, 10, 15), (3, dict(n=12, wI=128, hI=96, gw=120, gh=90), 7, 4)):
+        images, p2x, p2y, gw, gh = problem(seed, **shape)
+        n, hI, wI = images.shape
+        pc = np.zeros(gw * gh, np.float32)
+        vf = np.ones(hI * wI, np.float32)
+        want_er = []
+        for it in range(iters):
+            oth2 = 10000 * 10000 if it < iters // 2 else th * th
+            pc, _, _, e1, r1 = oracle.vcal_plane_step(images, p2x, p2y, pc, vf, oth2)
+            vf, _, _, e2, r2 = oracle.vcal_vignette_step(images, p2x, p2y, pc, vf, oth2)
+            want_er.append((e1, r1, e2, r2))
+        d_img, d_x, d_y = (torch.from_numpy(a).cuda() for a in (images, p2x, p2y))
+        d_pc = torch.zeros(gw * gh, dtype=torch.float32, device="cuda")
+        d_vf = torch.ones(hI * wI, dtype=torch.float32, device="cuda")
+        er = ctx.vcal_solve(d_img, d_x, d_y, d_pc, d_vf, iters, th, st)
+        assert bits_equal(d_pc.cpu().numpy(), pc) and bits_equal(d_vf.cpu().numpy(), vf), seed
+        for it, (e1, r1, e2, r2) in enumerate(want_er):
+            assert er[it, 1] == r1 and er[it, 3] == r2, (seed, it)
+            assert abs(er[it, 0] - e1) <= 1e-9 * abs(e1) + 1e-9 and abs(er[it, 2] - e2) <= 1e-9 * abs(e2) + 1e-9, (seed, it)
