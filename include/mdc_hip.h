@@ -262,6 +262,13 @@ int mdc_vcal_solve_device(mdc_ctx* ctx, const float* d_images, const float* d_p2
                           int n_plane, float* d_plane_color, float* d_vignette_factor, int max_iterations, int outlier_th,
                           double* er_out, void* stream);
 
+/* "dilate & smoothe vignette by 4 pixel for output" (:541-566): four passes of a NaN-aware 3 x 3 mean over the w x h
+ * factor map (what the reference writes as vignetteSmoothed.png, i.e. the vignette image PhotometricUndistorter reads).
+ * d_smoothed (result) and d_scratch are w*h floats each, distinct from each other; d_vignette_factor is not modified and
+ * must not be d_scratch.  Bit-identical to the reference. */
+int mdc_vcal_smooth_device(mdc_ctx* ctx, const float* d_vignette_factor, int w, int h, float* d_smoothed, float* d_scratch,
+                           void* stream);
+
 /* Synthetic sequence generator (bench/test utility):
  * byte i of frame f = fmix32(seed + (first_frame+f)*npix + i) >> 24. */
 int mdc_synth_frames_device(mdc_ctx* ctx, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix,

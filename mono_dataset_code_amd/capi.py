@@ -32,7 +32,7 @@ HIP_SYMBOLS = [
     "mdc_synchronize", "mdc_describe_launch", "mdc_ceiling_mix_device", "mdc_vcal_plane_step_device",
     "mdc_vcal_vignette_step_device", "mdc_gradients_batch_device", "mdc_tune_device",
     "mdc_vcal_index_create", "mdc_vcal_index_destroy", "mdc_vcal_index_bytes", "mdc_vcal_index_entries",
-    "mdc_vcal_vignette_step_indexed_device", "mdc_vcal_solve_device",
+    "mdc_vcal_vignette_step_indexed_device", "mdc_vcal_solve_device", "mdc_vcal_smooth_device",
 ]
 HOST_SYMBOLS = [
     "mdch_fov_create", "mdch_fov_destroy", "mdch_fov_valid", "mdch_fov_has_gpu", "mdch_fov_dims",
@@ -142,6 +142,7 @@ def hip_lib():
             L.mdc_vcal_vignette_step_indexed_device.argtypes = [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]
         if not old_build or hasattr(L, "mdc_vcal_solve_device"):
             L.mdc_vcal_solve_device.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]
+            L.mdc_vcal_smooth_device.argtypes = [_vp, _vp, _i, _i, _vp, _vp, _vp]
         for n in HIP_SYMBOLS:
             if old_build and not hasattr(L, n):
                 continue
@@ -440,6 +441,14 @@ class Context:
                                                 d_plane_color.data_ptr(), d_vig.data_ptr(), int(max_iterations), int(outlier_th),
                                                 _np_ptr(er), stream if stream else None))
         return er
+
+    def vcal_smooth(self, d_vig, w, h, stream=0):
+        """vignetteCalib's output smoothing (src/main_vignetteCalib.cpp:541-566) -> (smoothed, scratch) device tensors."""
+        import torch
+
+        tt, ct = torch.empty_like(d_vig), torch.empty_like(d_vig)
+        self._chk(self._L.mdc_vcal_smooth_device(self._h, d_vig.data_ptr(), w, h, tt.data_ptr(), ct.data_ptr(), stream if stream else None))
+        return tt, ct
 
     def vcal_index(self, d_images, d_p2x, d_p2y, stream=0):
         """Contribution index of the vignette half-iteration for these images / coordinates (mdc_vcal_index_create)."""

@@ -983,6 +983,18 @@ int mdc_vcal_vignette_step_indexed_device(mdc_ctx* c, const mdc_vcal_index* inde
   return MDC_OK;
 }
 
+int mdc_vcal_smooth_device(mdc_ctx* c, const float* d_vignette_factor, int w, int h, float* d_smoothed, float* d_scratch,
+                           void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (!d_vignette_factor || !d_smoothed || !d_scratch || w < 1 || h < 1 || (long long)w * h >= (1ll << 31) ||
+      d_smoothed == d_scratch || d_vignette_factor == d_scratch)
+    return fail(c, MDC_ERR_ARG, "mdc_vcal_smooth_device: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  MDC_HIP(c, launch_vcal_smooth(d_vignette_factor, w, h, d_smoothed, d_scratch, (hipStream_t)stream));
+  return MDC_OK;
+}
+
 int mdc_vcal_solve_device(mdc_ctx* c, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
                           int n_plane, float* d_plane_color, float* d_vignette_factor, int max_iterations, int outlier_th,
                           double* er_out, void* stream) {

@@ -112,6 +112,9 @@ long long vcal_index_entries(const VcalIndex* ix);
 hipError_t launch_vcal_vignette_step_indexed(const VcalIndex* ix, const float* d_plane_color, float* d_vig, int oth2, float* d_tt,
                                              float* d_ct, double* d_er, unsigned* d_max_bits, hipStream_t s);
 
+// vignetteCalib's output smoothing (:541-566): four NaN-aware 3 x 3 mean passes; d_tt = result, d_ct = scratch
+hipError_t launch_vcal_smooth(const float* d_vig, int wI, int hI, float* d_tt, float* d_ct, hipStream_t s);
+
 // DSO hand-off of one pyramid level: (I, dx, dy) triples + absSquaredGrad (see mdc_vcal.hip)
 hipError_t launch_gradients(const float* d_level, float* d_dI, float* d_abs2, int w, int h, int64_t nframes, hipStream_t s);
 

@@ -367,6 +367,28 @@ __global__ __launch_bounds__(256) void vcal_vignette_normalise_kernel(float* __r
   if (i < npix) vig[i] = vig[i] / __uint_as_float(*max_bits);
 }
 
+// "dilate & smoothe vignette by 4 pixel for output" (:541-566): one pass of the NaN-aware 3 x 3 mean, src -> dst; the nine
+// conditional adds in the reference's order, float sum / float count; a pixel without a finite neighbour keeps its value
+__global__ __launch_bounds__(256) void vcal_smooth_pass_kernel(const float* __restrict__ src, float* __restrict__ dst, int wI, int hI) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= wI * hI) return;
+  const int y = idx / wI, x = idx - y * wI;
+  float sum = 0, num = 0;
+  const bool xr = x < wI - 1, xl = x > 0, yd = y < hI - 1, yu = y > 0;
+  float v;
+  if (xr && yd && !isnan(v = src[idx + 1 + wI])) { sum += v; num++; }  // :551-562
+  if (xr && !isnan(v = src[idx + 1])) { sum += v; num++; }
+  if (xr && yu && !isnan(v = src[idx + 1 - wI])) { sum += v; num++; }
+  if (yd && !isnan(v = src[idx + wI])) { sum += v; num++; }
+  const float own = src[idx];
+  if (!isnan(own)) { sum += own; num++; }
+  if (yu && !isnan(v = src[idx - wI])) { sum += v; num++; }
+  if (yd && xl && !isnan(v = src[idx - 1 + wI])) { sum += v; num++; }
+  if (xl && !isnan(v = src[idx - 1])) { sum += v; num++; }
+  if (yu && xl && !isnan(v = src[idx - 1 - wI])) { sum += v; num++; }
+  dst[idx] = num > 0 ? sum / num : own;  // :563
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // DSO hand-off (NOT in the reference -- DSO's FrameHessian::makeImages, definition in
 // DESIGN.md section 5.5): for one pyramid level, per pixel the triple (I, dx, dy) with central differences
@@ -531,6 +553,17 @@ hipError_t launch_vcal_vignette_step_indexed(const VcalIndex* ix, const float* d
                                                                     ix->wI, d_plane_color, d_vig, (double)oth2, d_tt, d_ct, d_er);
   vcal_vignette_update_kernel<<<blocks(ix->nbins), 256, 0, s>>>(d_tt, d_ct, d_vig, ix->nbins, d_max_bits);
   vcal_vignette_normalise_kernel<<<blocks(ix->nbins), 256, 0, s>>>(d_vig, ix->nbins, d_max_bits);
+  return hipGetLastError();
+}
+
+// four passes, d_vig -> d_ct -> d_tt -> d_ct -> d_tt: d_tt ends as the smoothed map, d_ct as the input of the last pass
+// (the reference's TT and CT after :541-566)
+hipError_t launch_vcal_smooth(const float* d_vig, int wI, int hI, float* d_tt, float* d_ct, hipStream_t s) {
+  const int n = wI * hI;
+  vcal_smooth_pass_kernel<<<blocks(n), 256, 0, s>>>(d_vig, d_ct, wI, hI);
+  vcal_smooth_pass_kernel<<<blocks(n), 256, 0, s>>>(d_ct, d_tt, wI, hI);
+  vcal_smooth_pass_kernel<<<blocks(n), 256, 0, s>>>(d_tt, d_ct, wI, hI);
+  vcal_smooth_pass_kernel<<<blocks(n), 256, 0, s>>>(d_ct, d_tt, wI, hI);
   return hipGetLastError();
 }
 

@@ -70,6 +70,8 @@ class Oracle:
         L.orc_vcal_plane_step.restype = None
         L.orc_vcal_vignette_step.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]
         L.orc_vcal_vignette_step.restype = None
+        L.orc_vcal_smooth.argtypes = [_vp, _i, _i, _vp, _vp]
+        L.orc_vcal_smooth.restype = None
         L.orc_synth_frames.argtypes = [_vp, C.c_longlong, C.c_longlong, _i, C.c_uint]
         L.orc_time_path.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(C.c_double)]
         L.orc_time_path.restype = C.c_double
@@ -181,6 +183,13 @@ class Oracle:
         self.L.orc_vcal_vignette_step(_p(images), _p(p2x), _p(p2y), n, wI, hI, npnt, _p(plane_color), _p(vf), _p(tt), _p(ct), int(oth2),
                                       er.ctypes.data, er.ctypes.data + 8)
         return vf, tt, ct, float(er[0]), float(er[1])
+
+    def vcal_smooth(self, vig, wI, hI):
+        """src/main_vignetteCalib.cpp:541-566 -> (smoothed factors, scratch)."""
+        v = np.ascontiguousarray(vig, np.float32)
+        tt, ct = np.zeros(hI * wI, np.float32), np.zeros(hI * wI, np.float32)
+        self.L.orc_vcal_smooth(_p(v), wI, hI, _p(tt), _p(ct))
+        return tt, ct
 
     def time_path(self, frames, passes, in_w, in_h, out_w, out_h, ginv, vinv, rx, ry, rectify, g, v, o):
         cs = C.c_double(0)
@@ -333,6 +342,12 @@ class VcalRef:
         self.L.ref_vcal_plane_step(n, self._rows(p2x), self._rows(p2y), self._rows(images.reshape(n, -1)), gw, gh, wI, hI, _p(pc), _p(ff),
                                    _p(fc), _p(vf), int(oth2), C.byref(e), C.byref(r))
         return pc, ff, fc, e.value, r.value
+
+    def smooth(self, vig, wI, hI):
+        v = np.array(vig, np.float32, copy=True)
+        tt, ct = np.zeros(hI * wI, np.float32), np.zeros(hI * wI, np.float32)
+        self.L.ref_vcal_smooth(wI, hI, _p(v), _p(tt), _p(ct))
+        return tt, ct
 
     def vignette_step(self, images, p2x, p2y, gw, gh, plane_color, vig, oth2):
         n, hI, wI = images.shape

@@ -546,6 +546,31 @@ void orc_vcal_vignette_step(const float* images, const float* p2x, const float* 
   *R_out = R;
 }
 
+/* "dilate & smoothe vignette by 4 pixel for output", src/main_vignetteCalib.cpp:541-566: four passes of a NaN-aware
+ * 3 x 3 mean (a pixel with no finite neighbour keeps its value); the nine conditional adds in the reference's order.
+ * tt = result, ct = scratch (ends up holding the input of the last pass, as in the reference). */
+void orc_vcal_smooth(const float* vignetteFactor, int wI, int hI, float* tt, float* ct) {
+  memcpy(tt, vignetteFactor, sizeof(float) * hI * wI); /* :541 */
+  for (int dilit = 0; dilit < 4; dilit++) {            /* :542 */
+    memcpy(ct, tt, sizeof(float) * hI * wI);
+    for (int y = 0; y < hI; y++)
+      for (int x = 0; x < wI; x++) {
+        int idx = x + y * wI;
+        float sum = 0, num = 0;
+        if (x < wI - 1 && y < hI - 1 && !isnan(ct[idx + 1 + wI])) { sum += ct[idx + 1 + wI]; num++; } /* :551-562 */
+        if (x < wI - 1 && !isnan(ct[idx + 1])) { sum += ct[idx + 1]; num++; }
+        if (x < wI - 1 && y > 0 && !isnan(ct[idx + 1 - wI])) { sum += ct[idx + 1 - wI]; num++; }
+        if (y < hI - 1 && !isnan(ct[idx + wI])) { sum += ct[idx + wI]; num++; }
+        if (!isnan(ct[idx])) { sum += ct[idx]; num++; }
+        if (y > 0 && !isnan(ct[idx - wI])) { sum += ct[idx - wI]; num++; }
+        if (y < hI - 1 && x > 0 && !isnan(ct[idx - 1 + wI])) { sum += ct[idx - 1 + wI]; num++; }
+        if (x > 0 && !isnan(ct[idx - 1])) { sum += ct[idx - 1]; num++; }
+        if (y > 0 && x > 0 && !isnan(ct[idx - 1 - wI])) { sum += ct[idx - 1 - wI]; num++; }
+        if (num > 0) tt[idx] = sum / num; /* :563 */
+      }
+  }
+}
+
 /* DSO hand-off (NOT in the reference; own definition after DSO's FrameHessian::makeImages):
  * (I, dx, dy) triples and absSquaredGrad of one w x h level.  parity unpinned. */
 void orc_gradients(const float* lvl, int w, int h, float* dI, float* abs2) {

@@ -2,8 +2,8 @@
 """TEST INFRASTRUCTURE.  The vignetteCalib solver's accumulate loops live inside main() of the reference's
 src/main_vignetteCalib.cpp (:395-527) -- they cannot be linked, and the file as a whole needs aruco + OpenCV.
 This script cuts the loop bodies (and getInterpolatedElement, :52-70) out of the reference file WHERE IT LIES,
-by their comment anchors, into oracle/_ref/*.inc (git-ignored, never committed); oracle/vcal_ref_wrapper.cpp wraps
-them into two functions and oracle/Makefile compiles that into oracle/_ref/libvcal_ref.so -- the pin for
+by their comment anchors (the output smoothing :541-566 by its first and last statement), into oracle/_ref/*.inc
+(git-ignored, never committed); oracle/vcal_ref_wrapper.cpp wraps them into three functions and oracle/Makefile compiles that into oracle/_ref/libvcal_ref.so -- the pin for
 oracle/mdc_oracle.c's restatement (tests/test_vcal.py).  usage: vcal_extract.py <reference src dir> <out dir>"""
 import os
 import sys
@@ -24,8 +24,14 @@ i1 = next(i for i in range(i0, len(lines)) if lines[i].rstrip() == "}")
 a0 = find("optimize planeColor")
 b0 = find("optimize vignette", a0)
 b1 = find("vignetteFactor[pi] /= maxFac;", b0)
+# "dilate & smoothe vignette by 4 pixel for output" (:541-566): from the memcpy into TT to the end of the dilit loop
+c0 = find("memcpy(vignetteFactorTT, vignetteFactor", b1)
+c1 = find('displayImageV(vignetteFactorTT', c0)  # its own block opens on the line before
+while lines[c1 - 1].strip() in ("{", ""):
+    c1 -= 1
 os.makedirs(out, exist_ok=True)
 open(os.path.join(out, "vcal_interp.inc"), "w").write("\n".join(lines[i0:i1 + 1]) + "\n")
 open(os.path.join(out, "vcal_body_plane.inc"), "w").write("\n".join(lines[a0 + 1:b0]) + "\n")
 open(os.path.join(out, "vcal_body_vignette.inc"), "w").write("\n".join(lines[b0 + 1:b1 + 1]) + "\n")
-print("vcal: interp %d-%d, plane step %d-%d, vignette step %d-%d" % (i0 + 1, i1 + 1, a0 + 2, b0, b0 + 2, b1 + 1))
+open(os.path.join(out, "vcal_body_smooth.inc"), "w").write("\n".join(lines[c0:c1]) + "\n")
+print("vcal: interp %d-%d, plane step %d-%d, vignette step %d-%d, smoothing %d-%d" % (i0 + 1, i1 + 1, a0 + 2, b0, b0 + 2, b1 + 1, c0 + 1, c1))

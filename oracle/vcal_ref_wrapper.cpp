@@ -43,4 +43,9 @@ void ref_vcal_vignette_step(int n, float** p2x, float** p2y, float** imgs, int g
   *R_out = R;
 }
 
+// "dilate & smoothe vignette by 4 pixel for output" (:541-566): TT = the smoothed factors, CT = its scratch copy
+void ref_vcal_smooth(int wI, int hI, float* vignetteFactor, float* vignetteFactorTT, float* vignetteFactorCT) {
+#include "vcal_body_smooth.inc"
+}
+
 }  // extern "C"

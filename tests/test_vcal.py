@@ -182,3 +182,44 @@ def test_gpu_solver_loop_in_one_call(oracle):
         for it, (e1, r1, e2, r2) in enumerate(want_er):
             assert er[it, 1] == r1 and er[it, 3] == r2, (seed, it)
             assert abs(er[it, 0] - e1) <= 1e-9 * abs(e1) + 1e-9 and abs(er[it, 2] - e2) <= 1e-9 * abs(e2) + 1e-9, (seed, it)
+
+
+def _smooth_cases():
+    rng = np.random.default_rng(11)
+    for w, h in ((48, 40), (7, 5), (1, 1), (2, 9), (257, 131)):
+        v = rng.random(w * h).astype(np.float32)
+        v[rng.random(w * h) < 0.3] = np.nan
+        if w * h > 1000:  # a hole wider than the four passes can close, and an empty border band
+            v[: w * 3] = np.nan
+            v.reshape(h, w)[10:30, 5:25] = np.nan
+        yield w, h, v
+
+
+def test_oracle_smoothing_equals_reference_text(oracle):
+    """The output smoothing :541-566 (four NaN-aware 3 x 3 mean passes): oracle == the reference's own lines."""
+    from oracle import loader
+
+    try:
+        ref = loader.VcalRef()
+    except OSError as e:
+        pytest.skip(str(e))
+    for w, h, v in _smooth_cases():
+        for got, want in zip(oracle.vcal_smooth(v, w, h), ref.smooth(v, w, h)):
+            assert bits_equal(got, want), (w, h)
+
+
+@pytest.mark.gpu
+def test_gpu_smoothing_is_bit_identical(oracle):
+    import torch
+
+    from mono_dataset_code_amd import capi
+
+    ctx = capi.Context(0)
+    st = torch.cuda.current_stream().cuda_stream
+    for w, h, v in _smooth_cases():
+        d_v = torch.from_numpy(v).cuda()
+        tt, ct = ctx.vcal_smooth(d_v, w, h, st)
+        torch.cuda.synchronize()
+        want_tt, want_ct = oracle.vcal_smooth(v, w, h)
+        assert bits_equal(tt.cpu().numpy(), want_tt) and bits_equal(ct.cpu().numpy(), want_ct), (w, h)
+        assert bits_equal(d_v.cpu().numpy(), v)
