@@ -262,6 +262,13 @@ int mdc_vcal_solve_device(mdc_ctx* ctx, const float* d_images, const float* d_p2
                           int n_plane, float* d_plane_color, float* d_vignette_factor, int max_iterations, int outlier_th,
                           double* er_out, void* stream);
 
+/* The step between distortCoordinates and the solver (:345-357): plane points whose image position, rounded as
+ * (int)(v + 0.5), is not strictly inside (1, w-2) x (1, h-2) get NaN coordinates -- the "outside this image" marker the
+ * two half-iterations test for (:409, :468).  In place on n coordinate pairs (n_images x n_plane in one call is fine: the
+ * rule does not depend on the image).  With mdc_distort_points_device before it, the plane -> image coordinates never
+ * leave the device. */
+int mdc_vcal_mask_coords_device(mdc_ctx* ctx, float* d_x, float* d_y, int64_t n, int w, int h, void* stream);
+
 /* "dilate & smoothe vignette by 4 pixel for output" (:541-566): four passes of a NaN-aware 3 x 3 mean over the w x h
  * factor map (what the reference writes as vignetteSmoothed.png, i.e. the vignette image PhotometricUndistorter reads).
  * d_smoothed (result) and d_scratch are w*h floats each, distinct from each other; d_vignette_factor is not modified and

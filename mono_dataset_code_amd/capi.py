@@ -32,7 +32,7 @@ HIP_SYMBOLS = [
     "mdc_synchronize", "mdc_describe_launch", "mdc_ceiling_mix_device", "mdc_vcal_plane_step_device",
     "mdc_vcal_vignette_step_device", "mdc_gradients_batch_device", "mdc_tune_device",
     "mdc_vcal_index_create", "mdc_vcal_index_destroy", "mdc_vcal_index_bytes", "mdc_vcal_index_entries",
-    "mdc_vcal_vignette_step_indexed_device", "mdc_vcal_solve_device", "mdc_vcal_smooth_device",
+    "mdc_vcal_vignette_step_indexed_device", "mdc_vcal_solve_device", "mdc_vcal_smooth_device", "mdc_vcal_mask_coords_device",
 ]
 HOST_SYMBOLS = [
     "mdch_fov_create", "mdch_fov_destroy", "mdch_fov_valid", "mdch_fov_has_gpu", "mdch_fov_dims",
@@ -143,6 +143,7 @@ def hip_lib():
         if not old_build or hasattr(L, "mdc_vcal_solve_device"):
             L.mdc_vcal_solve_device.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]
             L.mdc_vcal_smooth_device.argtypes = [_vp, _vp, _i, _i, _vp, _vp, _vp]
+            L.mdc_vcal_mask_coords_device.argtypes = [_vp, _vp, _vp, C.c_int64, _i, _i, _vp]
         for n in HIP_SYMBOLS:
             if old_build and not hasattr(L, n):
                 continue
@@ -441,6 +442,10 @@ class Context:
                                                 d_plane_color.data_ptr(), d_vig.data_ptr(), int(max_iterations), int(outlier_th),
                                                 _np_ptr(er), stream if stream else None))
         return er
+
+    def vcal_mask_coords(self, d_x, d_y, w, h, stream=0):
+        """NaN coordinates for plane points outside the w x h image (src/main_vignetteCalib.cpp:345-357), in place."""
+        self._chk(self._L.mdc_vcal_mask_coords_device(self._h, d_x.data_ptr(), d_y.data_ptr(), d_x.numel(), w, h, stream if stream else None))
 
     def vcal_smooth(self, d_vig, w, h, stream=0):
         """vignetteCalib's output smoothing (src/main_vignetteCalib.cpp:541-566) -> (smoothed, scratch) device tensors."""

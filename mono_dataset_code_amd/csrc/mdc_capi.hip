@@ -983,6 +983,15 @@ int mdc_vcal_vignette_step_indexed_device(mdc_ctx* c, const mdc_vcal_index* inde
   return MDC_OK;
 }
 
+int mdc_vcal_mask_coords_device(mdc_ctx* c, float* d_x, float* d_y, int64_t n, int w, int h, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (n < 0 || (n > 0 && (!d_x || !d_y)) || w < 1 || h < 1) return fail(c, MDC_ERR_ARG, "mdc_vcal_mask_coords_device: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  MDC_HIP(c, launch_vcal_mask_coords(d_x, d_y, n, w, h, (hipStream_t)stream));
+  return MDC_OK;
+}
+
 int mdc_vcal_smooth_device(mdc_ctx* c, const float* d_vignette_factor, int w, int h, float* d_smoothed, float* d_scratch,
                            void* stream) {
   if (!c) return MDC_ERR_ARG;

@@ -367,6 +367,20 @@ __global__ __launch_bounds__(256) void vcal_vignette_normalise_kernel(float* __r
   if (i < npix) vig[i] = vig[i] / __uint_as_float(*max_bits);
 }
 
+// :345-357: plane points whose image position, rounded as (int)(v + 0.5) (float + double), is not strictly inside
+// (1, w-2) x (1, h-2) lose both coordinates.  (NaN / out-of-range conversions saturate here and give INT_MIN on the
+// reference's x86 -- either way the test fails and the point is masked.)
+__global__ __launch_bounds__(256) void vcal_mask_coords_kernel(float* __restrict__ x, float* __restrict__ y, long long n, int wI, int hI) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int u_d = (int)(x[i] + 0.5);
+  const int v_d = (int)(y[i] + 0.5);
+  if (!(u_d > 1 && v_d > 1 && u_d < wI - 2 && v_d < hI - 2)) {
+    x[i] = __builtin_nanf("");
+    y[i] = __builtin_nanf("");
+  }
+}
+
 // "dilate & smoothe vignette by 4 pixel for output" (:541-566): one pass of the NaN-aware 3 x 3 mean, src -> dst; the nine
 // conditional adds in the reference's order, float sum / float count; a pixel without a finite neighbour keeps its value
 __global__ __launch_bounds__(256) void vcal_smooth_pass_kernel(const float* __restrict__ src, float* __restrict__ dst, int wI, int hI) {
@@ -553,6 +567,12 @@ hipError_t launch_vcal_vignette_step_indexed(const VcalIndex* ix, const float* d
                                                                     ix->wI, d_plane_color, d_vig, (double)oth2, d_tt, d_ct, d_er);
   vcal_vignette_update_kernel<<<blocks(ix->nbins), 256, 0, s>>>(d_tt, d_ct, d_vig, ix->nbins, d_max_bits);
   vcal_vignette_normalise_kernel<<<blocks(ix->nbins), 256, 0, s>>>(d_vig, ix->nbins, d_max_bits);
+  return hipGetLastError();
+}
+
+hipError_t launch_vcal_mask_coords(float* d_x, float* d_y, int64_t n, int wI, int hI, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  vcal_mask_coords_kernel<<<blocks(n), 256, 0, s>>>(d_x, d_y, n, wI, hI);
   return hipGetLastError();
 }
 

@@ -71,6 +71,8 @@ class Oracle:
         L.orc_vcal_vignette_step.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]
         L.orc_vcal_vignette_step.restype = None
         L.orc_vcal_smooth.argtypes = [_vp, _i, _i, _vp, _vp]
+        L.orc_vcal_mask_coords.argtypes = [_vp, _vp, _i, _i, _i]
+        L.orc_vcal_mask_coords.restype = None
         L.orc_vcal_smooth.restype = None
         L.orc_synth_frames.argtypes = [_vp, C.c_longlong, C.c_longlong, _i, C.c_uint]
         L.orc_time_path.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(C.c_double)]
@@ -183,6 +185,12 @@ class Oracle:
         self.L.orc_vcal_vignette_step(_p(images), _p(p2x), _p(p2y), n, wI, hI, npnt, _p(plane_color), _p(vf), _p(tt), _p(ct), int(oth2),
                                       er.ctypes.data, er.ctypes.data + 8)
         return vf, tt, ct, float(er[0]), float(er[1])
+
+    def vcal_mask_coords(self, x, y, wI, hI):
+        """src/main_vignetteCalib.cpp:345-357 -> (x, y) with NaN where the plane point falls outside the image."""
+        a, b = np.array(x, np.float32, copy=True), np.array(y, np.float32, copy=True)
+        self.L.orc_vcal_mask_coords(_p(a), _p(b), a.size, wI, hI)
+        return a, b
 
     def vcal_smooth(self, vig, wI, hI):
         """src/main_vignetteCalib.cpp:541-566 -> (smoothed factors, scratch)."""
@@ -342,6 +350,11 @@ class VcalRef:
         self.L.ref_vcal_plane_step(n, self._rows(p2x), self._rows(p2y), self._rows(images.reshape(n, -1)), gw, gh, wI, hI, _p(pc), _p(ff),
                                    _p(fc), _p(vf), int(oth2), C.byref(e), C.byref(r))
         return pc, ff, fc, e.value, r.value
+
+    def mask_coords(self, x, y, gw, gh, wI, hI):
+        a, b = np.array(x, np.float32, copy=True), np.array(y, np.float32, copy=True)
+        self.L.ref_vcal_mask_coords(_p(a), _p(b), gw, gh, wI, hI)
+        return a, b
 
     def smooth(self, vig, wI, hI):
         v = np.array(vig, np.float32, copy=True)

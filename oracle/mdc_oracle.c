@@ -546,6 +546,20 @@ void orc_vcal_vignette_step(const float* images, const float* p2x, const float* 
   *R_out = R;
 }
 
+/* src/main_vignetteCalib.cpp:345-357: a plane point whose image position, rounded by (int)(v + 0.5) (float + double 0.5,
+ * truncated), is not strictly inside (1, w-2) x (1, h-2) loses both coordinates (NaN included: the conversion of NaN is
+ * whatever cvttsd2si gives, INT_MIN, which fails the test). */
+void orc_vcal_mask_coords(float* x, float* y, int n, int wI, int hI) {
+  for (int i = 0; i < n; i++) {
+    int u_d = (int)(x[i] + 0.5);
+    int v_d = (int)(y[i] + 0.5);
+    if (!(u_d > 1 && v_d > 1 && u_d < wI - 2 && v_d < hI - 2)) {
+      x[i] = NAN;
+      y[i] = NAN;
+    }
+  }
+}
+
 /* "dilate & smoothe vignette by 4 pixel for output", src/main_vignetteCalib.cpp:541-566: four passes of a NaN-aware
  * 3 x 3 mean (a pixel with no finite neighbour keeps its value); the nine conditional adds in the reference's order.
  * tt = result, ct = scratch (ends up holding the input of the last pass, as in the reference). */

@@ -29,9 +29,14 @@ c0 = find("memcpy(vignetteFactorTT, vignetteFactor", b1)
 c1 = find('displayImageV(vignetteFactorTT', c0)  # its own block opens on the line before
 while lines[c1 - 1].strip() in ("{", ""):
     c1 -= 1
+# plane points that fall outside the image -> NaN coordinates (:345-357)
+d0 = find("int u_d = plane2imgX[x+y*gw]+0.5;") - 3
+assert lines[d0].strip().startswith("for(int x=0; x<gw;x++)"), lines[d0]
+d1 = find("cv::imshow(\"inRaw\",dbgImg);", d0)
 os.makedirs(out, exist_ok=True)
 open(os.path.join(out, "vcal_interp.inc"), "w").write("\n".join(lines[i0:i1 + 1]) + "\n")
 open(os.path.join(out, "vcal_body_plane.inc"), "w").write("\n".join(lines[a0 + 1:b0]) + "\n")
 open(os.path.join(out, "vcal_body_vignette.inc"), "w").write("\n".join(lines[b0 + 1:b1 + 1]) + "\n")
 open(os.path.join(out, "vcal_body_smooth.inc"), "w").write("\n".join(lines[c0:c1]) + "\n")
+open(os.path.join(out, "vcal_body_mask.inc"), "w").write("\n".join(lines[d0:d1]) + "\n")
 print("vcal: interp %d-%d, plane step %d-%d, vignette step %d-%d, smoothing %d-%d" % (i0 + 1, i1 + 1, a0 + 2, b0, b0 + 2, b1 + 1, c0 + 1, c1))

@@ -48,4 +48,9 @@ void ref_vcal_smooth(int wI, int hI, float* vignetteFactor, float* vignetteFacto
 #include "vcal_body_smooth.inc"
 }
 
+// plane points whose rounded image position is not strictly inside [2, w-3] x [2, h-3] get NaN coordinates (:345-357)
+void ref_vcal_mask_coords(float* plane2imgX, float* plane2imgY, int gw, int gh, int wI, int hI) {
+#include "vcal_body_mask.inc"
+}
+
 }  // extern "C"

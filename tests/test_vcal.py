@@ -223,3 +223,42 @@ def test_gpu_smoothing_is_bit_identical(oracle):
         want_tt, want_ct = oracle.vcal_smooth(v, w, h)
         assert bits_equal(tt.cpu().numpy(), want_tt) and bits_equal(ct.cpu().numpy(), want_ct), (w, h)
         assert bits_equal(d_v.cpu().numpy(), v)
+
+
+def _coord_cases():
+    rng = np.random.default_rng(1)
+    gw, gh, wI, hI = 50, 40, 64, 48
+    x = (rng.random(gw * gh) * 80 - 8).astype(np.float32)
+    y = (rng.random(gw * gh) * 60 - 6).astype(np.float32)
+    x[::17] = np.nan
+    y[5::31] = np.inf
+    x[3], y[3], x[4], x[7], x[8], x[9], y[10] = 1.5, 1.5, 1.4999, wI - 2.5, wI - 2.51, 3e9, -3e9
+    return gw, gh, wI, hI, x, y
+
+
+def test_oracle_coordinate_mask_equals_reference_text(oracle):
+    """:345-357 (NaN coordinates for plane points outside the image), NaN / inf / out-of-int-range inputs included."""
+    from oracle import loader
+
+    try:
+        ref = loader.VcalRef()
+    except OSError as e:
+        pytest.skip(str(e))
+    gw, gh, wI, hI, x, y = _coord_cases()
+    for got, want in zip(oracle.vcal_mask_coords(x, y, wI, hI), ref.mask_coords(x, y, gw, gh, wI, hI)):
+        assert bits_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_gpu_coordinate_mask_is_bit_identical(oracle):
+    import torch
+
+    from mono_dataset_code_amd import capi
+
+    ctx = capi.Context(0)
+    gw, gh, wI, hI, x, y = _coord_cases()
+    d_x, d_y = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    ctx.vcal_mask_coords(d_x, d_y, wI, hI, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want_x, want_y = oracle.vcal_mask_coords(x, y, wI, hI)
+    assert bits_equal(d_x.cpu().numpy(), want_x) and bits_equal(d_y.cpu().numpy(), want_y)
