@@ -40,6 +40,12 @@ __global__ __launch_bounds__(256) void w_lin16(f32x4* __restrict__ p, size_t n) 
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, s = (size_t)gridDim.x * 256;
   for (; i < n; i += s) { f32x4 v = {(float)i, 1.f, 2.f, 3.f}; st<MODE>(v, p + i); }
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int MODE>
+__global__ __launch_bounds__(256) void w_lin8(f32x2* __restrict__ p, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, s = (size_t)gridDim.x * 256;
+  for (; i < n; i += s) { f32x2 v = {(float)i, 1.f}; st<MODE>(v, p + i); }
+}
 // block-contiguous: each workgroup owns a contiguous span (no grid stride) and walks it
 template <int MODE>
 __global__ __launch_bounds__(256) void w_span4(float* __restrict__ p, size_t n, size_t span) {
@@ -377,6 +383,10 @@ int main() {
     report(nm, out_bytes, time_ms([&] { w_lin4<ST_NT><<<G, 256>>>(d_out, n4); }));
     snprintf(nm, sizeof nm, "write lin 4B plain   grid %d", G);
     report(nm, out_bytes, time_ms([&] { w_lin4<ST_PLAIN><<<G, 256>>>(d_out, n4); }));
+    snprintf(nm, sizeof nm, "write lin 8B nt      grid %d", G);
+    report(nm, out_bytes, time_ms([&] { w_lin8<ST_NT><<<G, 256>>>((f32x2*)d_out, out_bytes / 8); }));
+    snprintf(nm, sizeof nm, "write lin 8B plain   grid %d", G);
+    report(nm, out_bytes, time_ms([&] { w_lin8<ST_PLAIN><<<G, 256>>>((f32x2*)d_out, out_bytes / 8); }));
     snprintf(nm, sizeof nm, "write lin 16B nt     grid %d", G);
     report(nm, out_bytes, time_ms([&] { w_lin16<ST_NT><<<G, 256>>>((f32x4*)d_out, n16); }));
     snprintf(nm, sizeof nm, "write lin 16B plain  grid %d", G);
