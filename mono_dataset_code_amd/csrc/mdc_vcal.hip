@@ -529,7 +529,8 @@ hipError_t vcal_index_build(const float* d_images, const float* d_p2x, const flo
   if ((e = hipMalloc(&d_seg, bin_bytes)) != hipSuccess) return bail(e);
   if ((e = hipMemsetAsync(ix->d_counts, 0, bin_bytes, s)) != hipSuccess) return bail(e);
   if ((e = hipMemsetAsync(d_cursor, 0, bin_bytes, s)) != hipSuccess) return bail(e);
-  vcal_index_count_kernel<<<dim3(blocks(np), n), 256, 0, s>>>(d_images, d_p2x, d_p2y, wI, hI, np, ix->d_counts);
+  if (np > 0 && n > 0)  // an empty problem has empty lists: every bin keeps the reference's memset value
+    vcal_index_count_kernel<<<dim3(blocks(np), n), 256, 0, s>>>(d_images, d_p2x, d_p2y, wI, hI, np, ix->d_counts);
   vcal_index_scan_kernel<<<1, 1024, 0, s>>>(ix->d_counts, ix->nbins, ix->ngroups, ix->d_glen, ix->d_gbase);
   if ((e = hipGetLastError()) != hipSuccess) return bail(e);
   if ((e = hipMemcpyAsync(&ix->rows, ix->d_gbase + ix->ngroups, sizeof(unsigned long long), hipMemcpyDeviceToHost, s)) != hipSuccess)

@@ -150,6 +150,18 @@ def test_gpu_indexed_vignette_step_is_bit_identical(oracle):
                 assert r == r_o and abs(e - e_o) <= 1e-9 * abs(e_o) + 1e-9
             d_vf = d_vf_in
         index.close()
+    # no valid sample at all: empty lists, every factor NaN -- as the oracle says
+    images, p2x, p2y, gw, gh = problem(5)
+    p2x[:], p2y[:] = np.nan, np.nan
+    n, hI, wI = images.shape
+    d_img, d_x, d_y = (torch.from_numpy(a).cuda() for a in (images, p2x, p2y))
+    index = ctx.vcal_index(d_img, d_x, d_y, st)
+    assert index.entries == 0
+    pc = np.full(gw * gh, 50.0, np.float32)
+    vf_o, tt_o, ct_o, e_o, r_o = oracle.vcal_vignette_step(images, p2x, p2y, pc, np.ones(hI * wI, np.float32), 225)
+    d_vf = torch.ones(hI * wI, dtype=torch.float32, device="cuda")
+    tt, ct, e, r = ctx.vcal_vignette_step_indexed(index, torch.from_numpy(pc).cuda(), d_vf, 225, st)
+    assert bits_equal(tt.cpu().numpy(), tt_o) and bits_equal(ct.cpu().numpy(), ct_o) and bits_equal(d_vf.cpu().numpy(), vf_o) and r == r_o == 0
 
 
 @pytest.mark.gpu
