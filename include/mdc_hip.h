@@ -262,6 +262,12 @@ int mdc_vcal_solve_device(mdc_ctx* ctx, const float* d_images, const float* d_p2
                           int n_plane, float* d_plane_color, float* d_vignette_factor, int max_iterations, int outlier_th,
                           double* er_out, void* stream);
 
+/* The gradient mask of the calibration images (:293-301; max_abs_grad = the reference's int maxAbsGrad, :130, default
+ * 255): a pixel and a 5 x 5 neighbour that differ by more than max_abs_grad both become NaN, in place, with the
+ * reference's raster-order semantics (a masked pixel no longer takes part) -- replayed exactly as a skewed wavefront,
+ * one workgroup per image, n_images stacked w x h float images side by side.  Bit-identical to the reference. */
+int mdc_vcal_gradient_mask_device(mdc_ctx* ctx, float* d_images, int n_images, int w, int h, int max_abs_grad, void* stream);
+
 /* The step between distortCoordinates and the solver (:345-357): plane points whose image position, rounded as
  * (int)(v + 0.5), is not strictly inside (1, w-2) x (1, h-2) get NaN coordinates -- the "outside this image" marker the
  * two half-iterations test for (:409, :468).  In place on n coordinate pairs (n_images x n_plane in one call is fine: the

@@ -32,7 +32,7 @@ HIP_SYMBOLS = [
     "mdc_synchronize", "mdc_describe_launch", "mdc_ceiling_mix_device", "mdc_vcal_plane_step_device",
     "mdc_vcal_vignette_step_device", "mdc_gradients_batch_device", "mdc_tune_device",
     "mdc_vcal_index_create", "mdc_vcal_index_destroy", "mdc_vcal_index_bytes", "mdc_vcal_index_entries",
-    "mdc_vcal_vignette_step_indexed_device", "mdc_vcal_solve_device", "mdc_vcal_smooth_device", "mdc_vcal_mask_coords_device",
+    "mdc_vcal_vignette_step_indexed_device", "mdc_vcal_solve_device", "mdc_vcal_smooth_device", "mdc_vcal_mask_coords_device", "mdc_vcal_gradient_mask_device",
 ]
 HOST_SYMBOLS = [
     "mdch_fov_create", "mdch_fov_destroy", "mdch_fov_valid", "mdch_fov_has_gpu", "mdch_fov_dims",
@@ -144,6 +144,7 @@ def hip_lib():
             L.mdc_vcal_solve_device.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]
             L.mdc_vcal_smooth_device.argtypes = [_vp, _vp, _i, _i, _vp, _vp, _vp]
             L.mdc_vcal_mask_coords_device.argtypes = [_vp, _vp, _vp, C.c_int64, _i, _i, _vp]
+            L.mdc_vcal_gradient_mask_device.argtypes = [_vp, _vp, _i, _i, _i, _i, _vp]
         for n in HIP_SYMBOLS:
             if old_build and not hasattr(L, n):
                 continue
@@ -442,6 +443,11 @@ class Context:
                                                 d_plane_color.data_ptr(), d_vig.data_ptr(), int(max_iterations), int(outlier_th),
                                                 _np_ptr(er), stream if stream else None))
         return er
+
+    def vcal_gradient_mask(self, d_images, max_abs_grad=255, stream=0):
+        """Gradient mask of a stack of calibration images (n, h, w), in place (src/main_vignetteCalib.cpp:293-301)."""
+        n, h, w = d_images.shape
+        self._chk(self._L.mdc_vcal_gradient_mask_device(self._h, d_images.data_ptr(), n, w, h, int(max_abs_grad), stream if stream else None))
 
     def vcal_mask_coords(self, d_x, d_y, w, h, stream=0):
         """NaN coordinates for plane points outside the w x h image (src/main_vignetteCalib.cpp:345-357), in place."""

@@ -983,6 +983,16 @@ int mdc_vcal_vignette_step_indexed_device(mdc_ctx* c, const mdc_vcal_index* inde
   return MDC_OK;
 }
 
+int mdc_vcal_gradient_mask_device(mdc_ctx* c, float* d_images, int n_images, int w, int h, int max_abs_grad, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (n_images < 0 || (n_images > 0 && !d_images) || w < 1 || h < 1 || (long long)w * h >= (1ll << 31) || max_abs_grad < 0)
+    return fail(c, MDC_ERR_ARG, "mdc_vcal_gradient_mask_device: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  MDC_HIP(c, launch_vcal_gradient_mask(d_images, n_images, w, h, max_abs_grad, (hipStream_t)stream));
+  return MDC_OK;
+}
+
 int mdc_vcal_mask_coords_device(mdc_ctx* c, float* d_x, float* d_y, int64_t n, int w, int h, void* stream) {
   if (!c) return MDC_ERR_ARG;
   if (n < 0 || (n > 0 && (!d_x || !d_y)) || w < 1 || h < 1) return fail(c, MDC_ERR_ARG, "mdc_vcal_mask_coords_device: bad argument");

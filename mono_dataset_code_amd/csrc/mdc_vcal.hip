@@ -367,6 +367,39 @@ __global__ __launch_bounds__(256) void vcal_vignette_normalise_kernel(float* __r
   if (i < npix) vig[i] = vig[i] / __uint_as_float(*max_bits);
 }
 
+// :293-301, the gradient mask of a calibration image: a pixel and a 5 x 5 neighbour that differ by more than maxAbsGrad
+// both become NaN -- IN PLACE and in raster order, so a pixel an earlier one masked no longer takes part.  The result
+// depends on that order, but only between pixels whose 5 x 5 neighbourhoods intersect (|dx| <= 4, |dy| <= 4), and for
+// every such pair the later one in raster order also has the larger t = x + 5*y.  Pixels of equal t are 5 columns apart
+// per row -- their neighbourhoods are disjoint -- so sweeping t upwards with all pixels of one t in parallel replays the
+// sequential loop exactly.  One workgroup per image (the images of a stack run side by side), a barrier per step.
+__global__ __launch_bounds__(256) void vcal_gradient_mask_kernel(float* __restrict__ images, int wI, int hI, float max_abs_grad) {
+  volatile float* img = images + (size_t)blockIdx.x * wI * hI;  // volatile: every step sees the NaNs of the steps before
+  const int t_last = (wI - 3) + 5 * (hI - 3);
+  for (int t = 2 + 5 * 2; t <= t_last; t++) {
+    // rows with a pixel on this front: 2 <= x = t - 5y <= wI-3
+    const int y_lo = max(2, (t - (wI - 3) + 4) / 5), y_hi = min(hI - 3, (t - 2) / 5);
+    for (int y = y_lo + (int)threadIdx.x; y <= y_hi; y += 256) {
+      const int x = t - 5 * y;
+      const int p = x + y * wI;
+      float vp = img[p];
+      if (!isnan(vp)) {
+        for (int deltax = -2; deltax < 3 && !isnan(vp); deltax++)
+          for (int deltay = -2; deltay < 3; deltay++) {
+            const int q = p + deltax + deltay * wI;
+            if (fabsf(vp - img[q]) > max_abs_grad) {  // false for a NaN neighbour
+              vp = __builtin_nanf("");
+              img[p] = vp;
+              img[q] = vp;
+              break;  // image[x+y*wI] is NaN from here on: no later comparison of this pixel can be true
+            }
+          }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // :345-357: plane points whose image position, rounded as (int)(v + 0.5) (float + double), is not strictly inside
 // (1, w-2) x (1, h-2) lose both coordinates.  (NaN / out-of-range conversions saturate here and give INT_MIN on the
 // reference's x86 -- either way the test fails and the point is masked.)
@@ -568,6 +601,12 @@ hipError_t launch_vcal_vignette_step_indexed(const VcalIndex* ix, const float* d
                                                                     ix->wI, d_plane_color, d_vig, (double)oth2, d_tt, d_ct, d_er);
   vcal_vignette_update_kernel<<<blocks(ix->nbins), 256, 0, s>>>(d_tt, d_ct, d_vig, ix->nbins, d_max_bits);
   vcal_vignette_normalise_kernel<<<blocks(ix->nbins), 256, 0, s>>>(d_vig, ix->nbins, d_max_bits);
+  return hipGetLastError();
+}
+
+hipError_t launch_vcal_gradient_mask(float* d_images, int n, int wI, int hI, int max_abs_grad, hipStream_t s) {
+  if (n <= 0 || wI < 5 || hI < 5) return hipSuccess;  // the loops :293-294 are empty
+  vcal_gradient_mask_kernel<<<n, 256, 0, s>>>(d_images, wI, hI, (float)max_abs_grad);
   return hipGetLastError();
 }
 

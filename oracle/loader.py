@@ -72,6 +72,8 @@ class Oracle:
         L.orc_vcal_vignette_step.restype = None
         L.orc_vcal_smooth.argtypes = [_vp, _i, _i, _vp, _vp]
         L.orc_vcal_mask_coords.argtypes = [_vp, _vp, _i, _i, _i]
+        L.orc_vcal_gradient_mask.argtypes = [_vp, _i, _i, _i]
+        L.orc_vcal_gradient_mask.restype = None
         L.orc_vcal_mask_coords.restype = None
         L.orc_vcal_smooth.restype = None
         L.orc_synth_frames.argtypes = [_vp, C.c_longlong, C.c_longlong, _i, C.c_uint]
@@ -185,6 +187,12 @@ class Oracle:
         self.L.orc_vcal_vignette_step(_p(images), _p(p2x), _p(p2y), n, wI, hI, npnt, _p(plane_color), _p(vf), _p(tt), _p(ct), int(oth2),
                                       er.ctypes.data, er.ctypes.data + 8)
         return vf, tt, ct, float(er[0]), float(er[1])
+
+    def vcal_gradient_mask(self, image, max_abs_grad):
+        """src/main_vignetteCalib.cpp:293-301 -> the image (h x w) with the masked pixels NaN."""
+        a = np.array(image, np.float32, copy=True)
+        self.L.orc_vcal_gradient_mask(_p(a), a.shape[1], a.shape[0], int(max_abs_grad))
+        return a
 
     def vcal_mask_coords(self, x, y, wI, hI):
         """src/main_vignetteCalib.cpp:345-357 -> (x, y) with NaN where the plane point falls outside the image."""
@@ -350,6 +358,11 @@ class VcalRef:
         self.L.ref_vcal_plane_step(n, self._rows(p2x), self._rows(p2y), self._rows(images.reshape(n, -1)), gw, gh, wI, hI, _p(pc), _p(ff),
                                    _p(fc), _p(vf), int(oth2), C.byref(e), C.byref(r))
         return pc, ff, fc, e.value, r.value
+
+    def gradient_mask(self, image, max_abs_grad):
+        a = np.array(image, np.float32, copy=True)
+        self.L.ref_vcal_gradient_mask(_p(a), a.shape[1], a.shape[0], int(max_abs_grad))
+        return a
 
     def mask_coords(self, x, y, gw, gh, wI, hI):
         a, b = np.array(x, np.float32, copy=True), np.array(y, np.float32, copy=True)

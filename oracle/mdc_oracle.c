@@ -546,6 +546,20 @@ void orc_vcal_vignette_step(const float* images, const float* p2x, const float* 
   *R_out = R;
 }
 
+/* src/main_vignetteCalib.cpp:293-301: a pixel and a 5 x 5 neighbour that differ by more than maxAbsGrad (the reference's
+ * int, :130) both become NaN -- in place and in raster order, so what an earlier pixel masked no longer takes part
+ * (fabsf of a NaN difference is never > anything). */
+void orc_vcal_gradient_mask(float* image, int wI, int hI, int maxAbsGrad) {
+  for (int y = 2; y < hI - 2; y++)
+    for (int x = 2; x < wI - 2; x++)
+      for (int deltax = -2; deltax < 3; deltax++)
+        for (int deltay = -2; deltay < 3; deltay++)
+          if (fabsf(image[x + y * wI] - image[x + deltax + (y + deltay) * wI]) > maxAbsGrad) {
+            image[x + y * wI] = NAN;
+            image[x + deltax + (y + deltay) * wI] = NAN;
+          }
+}
+
 /* src/main_vignetteCalib.cpp:345-357: a plane point whose image position, rounded by (int)(v + 0.5) (float + double 0.5,
  * truncated), is not strictly inside (1, w-2) x (1, h-2) loses both coordinates (NaN included: the conversion of NaN is
  * whatever cvttsd2si gives, INT_MIN, which fails the test). */

@@ -33,10 +33,14 @@ while lines[c1 - 1].strip() in ("{", ""):
 d0 = find("int u_d = plane2imgX[x+y*gw]+0.5;") - 3
 assert lines[d0].strip().startswith("for(int x=0; x<gw;x++)"), lines[d0]
 d1 = find("cv::imshow(\"inRaw\",dbgImg);", d0)
+# gradient mask of a calibration image (:293-301): the double loop up to images.push_back
+e0 = find("for(int y=2; y<hI-2;y++)")
+e1 = find("images.push_back(image);", e0)
 os.makedirs(out, exist_ok=True)
 open(os.path.join(out, "vcal_interp.inc"), "w").write("\n".join(lines[i0:i1 + 1]) + "\n")
 open(os.path.join(out, "vcal_body_plane.inc"), "w").write("\n".join(lines[a0 + 1:b0]) + "\n")
 open(os.path.join(out, "vcal_body_vignette.inc"), "w").write("\n".join(lines[b0 + 1:b1 + 1]) + "\n")
 open(os.path.join(out, "vcal_body_smooth.inc"), "w").write("\n".join(lines[c0:c1]) + "\n")
 open(os.path.join(out, "vcal_body_mask.inc"), "w").write("\n".join(lines[d0:d1]) + "\n")
+open(os.path.join(out, "vcal_body_gradmask.inc"), "w").write("\n".join(lines[e0:e1]) + "\n")
 print("vcal: interp %d-%d, plane step %d-%d, vignette step %d-%d, smoothing %d-%d" % (i0 + 1, i1 + 1, a0 + 2, b0, b0 + 2, b1 + 1, c0 + 1, c1))

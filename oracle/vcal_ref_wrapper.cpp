@@ -53,4 +53,10 @@ void ref_vcal_mask_coords(float* plane2imgX, float* plane2imgY, int gw, int gh, 
 #include "vcal_body_mask.inc"
 }
 
+// pixels of a calibration image that differ from a 5 x 5 neighbour by more than maxAbsGrad -> NaN, both of them, in place
+// and in raster order (:293-301; maxAbsGrad is the reference's int, :130)
+void ref_vcal_gradient_mask(float* image, int wI, int hI, int maxAbsGrad) {
+#include "vcal_body_gradmask.inc"
+}
+
 }  // extern "C"

@@ -274,3 +274,45 @@ def test_gpu_coordinate_mask_is_bit_identical(oracle):
     torch.cuda.synchronize()
     want_x, want_y = oracle.vcal_mask_coords(x, y, wI, hI)
     assert bits_equal(d_x.cpu().numpy(), want_x) and bits_equal(d_y.cpu().numpy(), want_y)
+
+
+def _gradient_cases():
+    rng = np.random.default_rng(3)
+    for w, h, th in ((64, 48, 30), (9, 7, 10), (5, 5, 1), (4, 4, 1), (200, 90, 60), (333, 257, 25)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = (100 + 30 * np.sin(0.2 * xx) * np.cos(0.15 * yy) + rng.normal(0, 8, (h, w))).astype(np.float32)
+        img[rng.random((h, w)) < 0.02] += 200
+        img[rng.random((h, w)) < 0.01] = np.nan
+        yield w, h, th, img
+
+
+def test_oracle_gradient_mask_equals_reference_text(oracle):
+    """:293-301, the in-place, order-dependent gradient mask of a calibration image: oracle == the reference's own lines."""
+    from oracle import loader
+
+    try:
+        ref = loader.VcalRef()
+    except OSError as e:
+        pytest.skip(str(e))
+    for w, h, th, img in _gradient_cases():
+        assert bits_equal(oracle.vcal_gradient_mask(img, th), ref.gradient_mask(img, th)), (w, h)
+
+
+@pytest.mark.gpu
+def test_gpu_gradient_mask_replays_the_sequential_loop(oracle):
+    """The wavefront kernel (t = x + 5y) gives exactly the mask of the sequential raster-order loop, several images of a
+    stack at once."""
+    import torch
+
+    from mono_dataset_code_amd import capi
+
+    ctx = capi.Context(0)
+    st = torch.cuda.current_stream().cuda_stream
+    for w, h, th, img in _gradient_cases():
+        stack = np.stack([img, img[::-1].copy(), np.roll(img, 3, axis=1)])
+        d = torch.from_numpy(stack).cuda()
+        ctx.vcal_gradient_mask(d, th, st)
+        torch.cuda.synchronize()
+        got = d.cpu().numpy()
+        for k in range(3):
+            assert bits_equal(got[k], oracle.vcal_gradient_mask(stack[k], th)), (w, h, k)

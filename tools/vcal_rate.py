@@ -56,6 +56,27 @@ for name, fn in (("plane step", lambda: ctx.vcal_plane_step(images, p2x, p2y, pc
     samples = N * gw * gh
     print("GPU %-22s: %d images, %.1f ms per half-iteration = %.2f G samples/s" % (name, N, dt * 1e3, samples / dt / 1e9), flush=True)
 
+# the per-image preparation that has a device form: gradient mask (:293-301, wavefront replay of the sequential loop),
+# coordinate mask (:345-357), output smoothing (:541-566)
+work = images.clone()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+ctx.vcal_gradient_mask(work, 255, st)
+torch.cuda.synchronize()
+print("GPU gradient mask         : %d images %dx%d in %.1f ms (one workgroup per image, %d barrier steps)"
+      % (N, wI, hI, (time.perf_counter() - t0) * 1e3, (wI - 3) + 5 * (hI - 3) - 11), flush=True)
+cx, cy = p2x.clone(), p2y.clone()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+ctx.vcal_mask_coords(cx, cy, wI, hI, st)
+torch.cuda.synchronize()
+print("GPU coordinate mask       : %d x %d points in %.2f ms" % (N, gw * gh, (time.perf_counter() - t0) * 1e3), flush=True)
+t0 = time.perf_counter()
+ctx.vcal_smooth(vf, wI, hI, st)
+torch.cuda.synchronize()
+print("GPU output smoothing      : %dx%d in %.2f ms" % (wI, hI, (time.perf_counter() - t0) * 1e3), flush=True)
+del work, cx, cy
+
 try:
     from oracle import loader
 
