@@ -262,6 +262,13 @@ int mdc_vcal_solve_device(mdc_ctx* ctx, const float* d_images, const float* d_p2
                           int n_plane, float* d_plane_color, float* d_vignette_factor, int max_iterations, int outlier_th,
                           double* er_out, void* stream);
 
+/* The calibration images as the solver wants them (:286-291): image k = mean_exposure * image k / exposure_time k
+ * (an exposure of 0 counts as 1), in place on n_images stacked images of npix floats -- e.g. the output of
+ * mdc_unmap_batch_device with MDC_GAMMA only, which is getImage(i, false, true, false, false) of :265.
+ * d_exposure_times: n_images floats on the device. */
+int mdc_vcal_scale_images_device(mdc_ctx* ctx, float* d_images, int n_images, int64_t npix, float mean_exposure,
+                                 const float* d_exposure_times, void* stream);
+
 /* The gradient mask of the calibration images (:293-301; max_abs_grad = the reference's int maxAbsGrad, :130, default
  * 255): a pixel and a 5 x 5 neighbour that differ by more than max_abs_grad both become NaN, in place, with the
  * reference's raster-order semantics (a masked pixel no longer takes part) -- replayed exactly as a skewed wavefront,

@@ -32,7 +32,7 @@ HIP_SYMBOLS = [
     "mdc_synchronize", "mdc_describe_launch", "mdc_ceiling_mix_device", "mdc_vcal_plane_step_device",
     "mdc_vcal_vignette_step_device", "mdc_gradients_batch_device", "mdc_tune_device",
     "mdc_vcal_index_create", "mdc_vcal_index_destroy", "mdc_vcal_index_bytes", "mdc_vcal_index_entries",
-    "mdc_vcal_vignette_step_indexed_device", "mdc_vcal_solve_device", "mdc_vcal_smooth_device", "mdc_vcal_mask_coords_device", "mdc_vcal_gradient_mask_device",
+    "mdc_vcal_vignette_step_indexed_device", "mdc_vcal_solve_device", "mdc_vcal_smooth_device", "mdc_vcal_mask_coords_device", "mdc_vcal_gradient_mask_device", "mdc_vcal_scale_images_device",
 ]
 HOST_SYMBOLS = [
     "mdch_fov_create", "mdch_fov_destroy", "mdch_fov_valid", "mdch_fov_has_gpu", "mdch_fov_dims",
@@ -145,6 +145,7 @@ def hip_lib():
             L.mdc_vcal_smooth_device.argtypes = [_vp, _vp, _i, _i, _vp, _vp, _vp]
             L.mdc_vcal_mask_coords_device.argtypes = [_vp, _vp, _vp, C.c_int64, _i, _i, _vp]
             L.mdc_vcal_gradient_mask_device.argtypes = [_vp, _vp, _i, _i, _i, _i, _vp]
+            L.mdc_vcal_scale_images_device.argtypes = [_vp, _vp, _i, C.c_int64, C.c_float, _vp, _vp]
         for n in HIP_SYMBOLS:
             if old_build and not hasattr(L, n):
                 continue
@@ -443,6 +444,12 @@ class Context:
                                                 d_plane_color.data_ptr(), d_vig.data_ptr(), int(max_iterations), int(outlier_th),
                                                 _np_ptr(er), stream if stream else None))
         return er
+
+    def vcal_scale_images(self, d_images, mean_exposure, d_exposure_times, stream=0):
+        """image k = mean_exposure * image k / exposure_time k, in place (src/main_vignetteCalib.cpp:286-291)."""
+        n = d_images.shape[0]
+        self._chk(self._L.mdc_vcal_scale_images_device(self._h, d_images.data_ptr(), n, d_images[0].numel(), float(mean_exposure),
+                                                       d_exposure_times.data_ptr(), stream if stream else None))
 
     def vcal_gradient_mask(self, d_images, max_abs_grad=255, stream=0):
         """Gradient mask of a stack of calibration images (n, h, w), in place (src/main_vignetteCalib.cpp:293-301)."""

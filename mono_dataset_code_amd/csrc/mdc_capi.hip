@@ -983,6 +983,17 @@ int mdc_vcal_vignette_step_indexed_device(mdc_ctx* c, const mdc_vcal_index* inde
   return MDC_OK;
 }
 
+int mdc_vcal_scale_images_device(mdc_ctx* c, float* d_images, int n_images, int64_t npix, float mean_exposure,
+                                 const float* d_exposure_times, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (n_images < 0 || n_images > 65535 || npix < 0 || (n_images > 0 && npix > 0 && (!d_images || !d_exposure_times)))
+    return fail(c, MDC_ERR_ARG, "mdc_vcal_scale_images_device: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  DeviceGuard dg(c->device);
+  MDC_HIP(c, launch_vcal_scale_images(d_images, n_images, npix, mean_exposure, d_exposure_times, (hipStream_t)stream));
+  return MDC_OK;
+}
+
 int mdc_vcal_gradient_mask_device(mdc_ctx* c, float* d_images, int n_images, int w, int h, int max_abs_grad, void* stream) {
   if (!c) return MDC_ERR_ARG;
   if (n_images < 0 || (n_images > 0 && !d_images) || w < 1 || h < 1 || (long long)w * h >= (1ll << 31) || max_abs_grad < 0)

@@ -112,6 +112,8 @@ long long vcal_index_entries(const VcalIndex* ix);
 hipError_t launch_vcal_vignette_step_indexed(const VcalIndex* ix, const float* d_plane_color, float* d_vig, int oth2, float* d_tt,
                                              float* d_ct, double* d_er, unsigned* d_max_bits, hipStream_t s);
 
+// vignetteCalib: image = meanExposure * image / exposure_time[image] (:286-291), in place
+hipError_t launch_vcal_scale_images(float* d_images, int n, int64_t npix, float mean_exposure, const float* d_exposure, hipStream_t s);
 // vignetteCalib: gradient mask of n stacked w x h images, in place (:293-301)
 hipError_t launch_vcal_gradient_mask(float* d_images, int n, int wI, int hI, int max_abs_grad, hipStream_t s);
 // vignetteCalib: NaN coordinates for plane points outside the image (:345-357)

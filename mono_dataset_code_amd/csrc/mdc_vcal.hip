@@ -367,6 +367,17 @@ __global__ __launch_bounds__(256) void vcal_vignette_normalise_kernel(float* __r
   if (i < npix) vig[i] = vig[i] / __uint_as_float(*max_bits);
 }
 
+// :286-291: image = meanExposure * getImage(i, false, true, false, false) / exposure_time (0 counts as 1), float
+__global__ __launch_bounds__(256) void vcal_scale_images_kernel(float* __restrict__ images, long long npix, float mean_exposure,
+                                                                const float* __restrict__ exposure) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix) return;
+  float e = exposure[blockIdx.y];
+  if (e == 0) e = 1;
+  float* p = images + (size_t)blockIdx.y * npix + i;
+  *p = mean_exposure * *p / e;
+}
+
 // :293-301, the gradient mask of a calibration image: a pixel and a 5 x 5 neighbour that differ by more than maxAbsGrad
 // both become NaN -- IN PLACE and in raster order, so a pixel an earlier one masked no longer takes part.  The result
 // depends on that order, but only between pixels whose 5 x 5 neighbourhoods intersect (|dx| <= 4, |dy| <= 4), and for
@@ -601,6 +612,13 @@ hipError_t launch_vcal_vignette_step_indexed(const VcalIndex* ix, const float* d
                                                                     ix->wI, d_plane_color, d_vig, (double)oth2, d_tt, d_ct, d_er);
   vcal_vignette_update_kernel<<<blocks(ix->nbins), 256, 0, s>>>(d_tt, d_ct, d_vig, ix->nbins, d_max_bits);
   vcal_vignette_normalise_kernel<<<blocks(ix->nbins), 256, 0, s>>>(d_vig, ix->nbins, d_max_bits);
+  return hipGetLastError();
+}
+
+hipError_t launch_vcal_scale_images(float* d_images, int n, int64_t npix, float mean_exposure, const float* d_exposure,
+                                    hipStream_t s) {
+  if (n <= 0 || npix <= 0) return hipSuccess;
+  vcal_scale_images_kernel<<<dim3(blocks(npix), n), 256, 0, s>>>(d_images, npix, mean_exposure, d_exposure);
   return hipGetLastError();
 }
 

@@ -316,3 +316,24 @@ def test_gpu_gradient_mask_replays_the_sequential_loop(oracle):
         got = d.cpu().numpy()
         for k in range(3):
             assert bits_equal(got[k], oracle.vcal_gradient_mask(stack[k], th)), (w, h, k)
+
+
+@pytest.mark.gpu
+def test_gpu_image_scaling():
+    """:286-291, image = meanExposure * image / exposure_time in float (0 counts as 1): the same two float operations as
+    numpy's float32 arithmetic."""
+    import torch
+
+    from mono_dataset_code_amd import capi
+
+    ctx = capi.Context(0)
+    rng = np.random.default_rng(9)
+    imgs = (rng.random((5, 37, 53)) * 255).astype(np.float32)
+    imgs[1, 3, 4] = np.nan
+    expo = np.array([0.0, 0.5, 13.25, 1e-3, 7.0], np.float32)
+    mean = np.float32(3.7)
+    want = np.stack([(mean * imgs[k]) / (np.float32(1) if expo[k] == 0 else expo[k]) for k in range(5)])
+    d = torch.from_numpy(imgs).cuda()
+    ctx.vcal_scale_images(d, mean, torch.from_numpy(expo).cuda(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert bits_equal(d.cpu().numpy(), want)
