@@ -298,8 +298,11 @@ int mdc_synth_frames_device(mdc_ctx* ctx, uint8_t* d_out, int64_t first_frame, i
  * and, by a few per cent, on the individual GPU (profiles/r02_experiments/04_*, 13_*).  mdc_tune_device runs the fused
  * pass (flags must contain MDC_RECTIFY) over the caller's device batch with each candidate -- tile 128x16 / 64x32 /
  * 128x32 x 32 / 64 frames per workgroup, 7 launches each, results in d_out are valid ones -- and keeps the fastest as
- * the context's plan for all later calls (it sets MDC_OPT_TILE_COLS / _ROWS / _FRAMES_PER_BLOCK; setting those to 0
- * returns to the built-in choice).  Synchronises `stream`. */
+ * the context's plan for all later calls: it sets MDC_OPT_TILE_COLS / _ROWS (setting those to 0 returns to the built-in
+ * choice) and remembers the winning frames-per-workgroup for fused launches of a comparable size (>= nframes / 4); small
+ * launches, unMapImage and a caller's own MDC_OPT_FRAMES_PER_BLOCK are not affected.  Re-planning replaces device
+ * tables, so the call waits for the WHOLE device first (like mdc_set_remap): do not call it while other streams of this
+ * process have work in flight that must not be delayed. */
 typedef struct mdc_tune_result {
   int tile_w, tile_h, frames_per_block;
   float ms;        /* median launch time of the winner over the given batch */

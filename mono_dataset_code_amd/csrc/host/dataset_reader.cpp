@@ -9,6 +9,7 @@
 //                                     the pool decodes the next chunks while chunk k is on the GPU
 #include "BenchmarkDatasetReader.h"
 
+#include <exception>
 #include <dirent.h>
 #include <algorithm>
 #include <chrono>
@@ -106,7 +107,20 @@ struct DatasetReader::State {
   size_t frame_bytes() const { return (size_t)W * H; }
 
   // ---- decoding (any thread) ------------------------------------------------------------------
+  // Never throws: it runs in the decode pool's threads, where an escaping exception (bad_alloc on a corrupt size field,
+  // ...) would terminate the process instead of reporting one bad frame.
   void decode_now(Decode& d) const {
+    try {
+      decode_unguarded(d);
+    } catch (const std::exception& e) {
+      d.ok = false;
+      d.err = std::string("decode failed: ") + e.what();
+    } catch (...) {
+      d.ok = false;
+      d.err = "decode failed";
+    }
+  }
+  void decode_unguarded(Decode& d) const {
     static thread_local std::vector<unsigned char> bytes;  // per-thread scratch, keeps its capacity between frames
     d.ok = false;
     d.w = d.h = 0;

@@ -44,33 +44,37 @@ bool ZipArchive::open(const std::string& path, std::string* err) {
   uint64_t n = le16(map_ + eocd + 10), cd_size = le32(map_ + eocd + 12), cd_off = le32(map_ + eocd + 16);
   if (eocd >= 20 && le32(map_ + eocd - 20) == 0x07064b50u) {  // ZIP64 locator -> ZIP64 EOCD
     const uint64_t z = le64(map_ + eocd - 20 + 8);
-    if (z + 56 <= size_ && le32(map_ + z) == 0x06064b50u) {
+    if (size_ >= 56 && z <= size_ - 56 && le32(map_ + z) == 0x06064b50u) {
       n = le64(map_ + z + 32);
       cd_size = le64(map_ + z + 40);
       cd_off = le64(map_ + z + 48);
     }
   }
-  if (cd_off + cd_size > size_) return fail(err, path + ": central directory out of range");
+  // untrusted 64-bit fields: every range check is written without an addition that could wrap
+  if (cd_off > size_ || cd_size > size_ - cd_off) return fail(err, path + ": central directory out of range");
   size_t p = (size_t)cd_off;
   dir_.clear();
   for (uint64_t i = 0; i < n; i++) {
-    if (p + 46 > size_ || le32(map_ + p) != 0x02014b50u) return fail(err, path + ": bad central directory entry");
+    if (size_ < 46 || p > size_ - 46 || le32(map_ + p) != 0x02014b50u) return fail(err, path + ": bad central directory entry");
     Entry e;
     e.method = (int)le16(map_ + p + 10);
     e.csize = le32(map_ + p + 20);
     e.usize = le32(map_ + p + 24);
     const size_t nl = le16(map_ + p + 28), xl = le16(map_ + p + 30), cl = le16(map_ + p + 32);
     e.local_off = le32(map_ + p + 42);
-    if (p + 46 + nl + xl + cl > size_) return fail(err, path + ": truncated central directory");
+    if (nl + xl + cl > size_ - 46 - p) return fail(err, path + ": truncated central directory");  // p + 46 <= size_ holds
     e.name.assign((const char*)map_ + p + 46, nl);
     // ZIP64 extended information: the fields that read 0xffffffff, in this order
-    for (size_t x = p + 46 + nl; x + 4 <= p + 46 + nl + xl;) {
+    const size_t xend = p + 46 + nl + xl;  // <= size_ (checked above)
+    for (size_t x = p + 46 + nl; x + 4 <= xend;) {
       const uint32_t id = le16(map_ + x), sz = le16(map_ + x + 2);
+      if (sz > xend - (x + 4)) break;  // a field that claims to run past the extra area: ignore the rest
       if (id == 1) {
         size_t q = x + 4;
-        if (e.usize == 0xffffffffu && q + 8 <= x + 4 + sz) { e.usize = le64(map_ + q); q += 8; }
-        if (e.csize == 0xffffffffu && q + 8 <= x + 4 + sz) { e.csize = le64(map_ + q); q += 8; }
-        if (e.local_off == 0xffffffffu && q + 8 <= x + 4 + sz) { e.local_off = le64(map_ + q); q += 8; }
+        const size_t fend = x + 4 + sz;
+        if (e.usize == 0xffffffffu && q + 8 <= fend) { e.usize = le64(map_ + q); q += 8; }
+        if (e.csize == 0xffffffffu && q + 8 <= fend) { e.csize = le64(map_ + q); q += 8; }
+        if (e.local_off == 0xffffffffu && q + 8 <= fend) { e.local_off = le64(map_ + q); q += 8; }
       }
       x += 4 + sz;
     }
@@ -89,9 +93,13 @@ int ZipArchive::find(const std::string& name) const {
 bool ZipArchive::read(int i, std::vector<unsigned char>& out, std::string* err) const {
   if (i < 0 || i >= (int)dir_.size()) return fail(err, "zip: no such entry");
   const Entry& e = dir_[(size_t)i];
-  if (e.local_off + 30 > size_ || le32(map_ + e.local_off) != 0x04034b50u) return fail(err, "zip: bad local header of " + e.name);
+  if (size_ < 30 || e.local_off > size_ - 30 || le32(map_ + e.local_off) != 0x04034b50u) return fail(err, "zip: bad local header of " + e.name);
   const size_t data = (size_t)e.local_off + 30 + le16(map_ + e.local_off + 26) + le16(map_ + e.local_off + 28);
-  if (data + e.csize > size_) return fail(err, "zip: entry " + e.name + " runs past the end of the archive");
+  if (data > size_ || e.csize > size_ - data) return fail(err, "zip: entry " + e.name + " runs past the end of the archive");
+  // a corrupted size field must not turn into a giant allocation: deflate expands at most 1032 : 1, stored entries 1 : 1,
+  // and both zlib counters are 32-bit
+  if (e.usize > (uint64_t)e.csize * 1032u + 64u || e.usize > 0xffffffffull || e.csize > 0xffffffffull)
+    return fail(err, "zip: entry " + e.name + " declares an implausible size");
   out.resize((size_t)e.usize);
   if (e.method == 0) {
     if (e.csize != e.usize) return fail(err, "zip: stored entry with differing sizes");

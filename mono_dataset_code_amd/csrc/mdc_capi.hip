@@ -60,6 +60,8 @@ struct mdc_ctx {
   // options
   int opt_kernel = MDC_KERNEL_AUTO;
   int opt_fpb = 0;
+  int tuned_fpb = 0;        // mdc_tune_device's pick for the u8 tiled plan; applies to launches of >= tuned_min_frames only
+  int64_t tuned_min_frames = 0;
   int opt_tile_h = 0;  // 0 = automatic: the first shape of the candidate list whose windows fit
   int opt_tile_w = 0;  // 0 = automatic
   int opt_order = MDC_ORDER_BANDS;
@@ -526,7 +528,10 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
     return fail(c, MDC_ERR_STATE, "tiled kernel requested but not plannable for this remap / alignment");
   if (use_tiled) {
     const TilePlan p = tile_plan(c, 0);
-    const int fpb = frames_per_block(c, nframes, p.n_blocks);
+    int fpb = frames_per_block(c, nframes, p.n_blocks);
+    // a measured pick (mdc_tune_device) belongs to this plan and to batches of the size it was measured on: small
+    // launches (undistort<uchar>, the 16-frame chunks of mdc_process_frames_host) and the unmap path keep their own rule
+    if (!c->opt_fpb && c->tuned_fpb > 0 && nframes >= c->tuned_min_frames) fpb = (int)std::min<int64_t>(c->tuned_fpb, nframes);
     // the fused pyramid adds level-2 hand-over rows to the workgroup's LDS: without room for them the
     // per-level passes run instead
     const bool fuse_pyr = pyr && p.tile_h % 8 == 0 && c->out_w % p.tile_w == 0 && c->out_h % p.tile_h == 0 &&
@@ -626,6 +631,7 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
         return fail(c, MDC_ERR_ARG, "tile rows must be 0 (automatic), 16, 32, 60 or 64");
       if (value == c->opt_tile_h) return MDC_OK;
       c->opt_tile_h = value;
+      c->tuned_fpb = 0;  // a measured frames-per-workgroup belongs to the plan it was measured on
       if (!c->valid_remap) return MDC_OK;
       DeviceGuard dg(c->device);
       MDC_HIP(c, hipDeviceSynchronize());
@@ -635,6 +641,7 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
       if (value != 0 && value != 64 && value != 128) return fail(c, MDC_ERR_ARG, "tile columns must be 0 (automatic), 64 or 128");
       if (value == c->opt_tile_w) return MDC_OK;
       c->opt_tile_w = value;
+      c->tuned_fpb = 0;
       if (!c->valid_remap) return MDC_OK;
       DeviceGuard dg(c->device);
       MDC_HIP(c, hipDeviceSynchronize());
@@ -746,6 +753,7 @@ static int set_remap_locked(mdc_ctx* c, const float* rx, const float* ry, int in
   DeviceGuard dg(c->device);
   MDC_HIP(c, hipDeviceSynchronize());
   c->valid_remap = false;
+  c->tuned_fpb = 0;
   free_plan(c);
   for (float** p : {&c->d_rx, &c->d_ry})
     if (*p) {
@@ -1100,10 +1108,16 @@ int mdc_tune_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
   float best = 1e30f;
   int bw = 0, bh = 0, bf = 0, tried = 0;
   int rc = MDC_OK;
+  const int caller_fpb = c->opt_fpb;  // the caller's own override is restored afterwards: the pick goes into tuned_fpb
   for (const TileShape& sh : shapes) {
     c->opt_tile_w = sh.w;
     c->opt_tile_h = sh.h;
-    (void)hipStreamSynchronize(s);
+    // re-planning frees the plan tables: like every setter that re-plans, wait for the WHOLE device -- kernels that
+    // other threads put on other streams through the *_device entry points may still be reading them
+    if (hipDeviceSynchronize() != hipSuccess) {
+      rc = fail(c, MDC_ERR_HIP, "mdc_tune_device: hipDeviceSynchronize failed");
+      break;
+    }
     if ((rc = plan_tiles(c)) != MDC_OK) break;
     if (!c->plan[0].tiled) continue;
     for (int fpb : fpbs) {
@@ -1129,11 +1143,13 @@ int mdc_tune_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  (void)hipStreamSynchronize(s);
+  (void)hipDeviceSynchronize();
   // the winner (or, if nothing could be timed, the automatic choice) becomes the plan
   c->opt_tile_w = bw;
   c->opt_tile_h = bh;
-  c->opt_fpb = bf;
+  c->opt_fpb = caller_fpb;
+  c->tuned_fpb = bf;
+  c->tuned_min_frames = bf ? std::max<int64_t>(nframes / 4, (int64_t)bf * 8) : 0;
   const int rc2 = plan_tiles(c);
   if (rc == MDC_OK) rc = rc2;
   if (result) {

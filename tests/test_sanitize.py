@@ -66,12 +66,46 @@ def test_host_layer_under_asan_ubsan(tmp_path):
     flipped[len(whole) // 3] ^= 0xFF
     open(root / "zips" / "flipped.zip", "wb").write(bytes(flipped))
     open(root / "zips" / "garbage.zip", "wb").write(os.urandom(500))
+    # hostile 64-bit / size fields: range checks must not wrap, sizes must not become allocations
+    import struct
+    stored = open(root / "zips" / "stored.zip", "rb").read()
+    eocd = stored.rfind(b"PK\x05\x06")
+    cd_off = struct.unpack_from("<I", stored, eocd + 16)[0]
+    # (1) ZIP64 EOCD whose cd_off + cd_size wraps around 2^64
+    z64 = struct.pack("<IQHHIIQQQQ", 0x06064B50, 44, 45, 45, 0, 0, 2, 2, 20, 2**64 - 10)
+    loc = struct.pack("<IIQI", 0x07064B50, 0, eocd, 1)
+    open(root / "zips" / "zip64_wrap.zip", "wb").write(stored[:eocd] + z64 + loc + stored[eocd:])
+    # (2) a central-directory entry that declares 0xfffffff0 uncompressed bytes
+    big = bytearray(stored)
+    struct.pack_into("<I", big, cd_off + 24, 0xFFFFFFF0)
+    open(root / "zips" / "huge_usize.zip", "wb").write(bytes(big))
+    # (3) a ZIP64 extra field in the LAST entry whose length runs past the extra area (and the file)
+    ent = bytearray(stored[cd_off:eocd])
+    last = ent.rfind(b"PK\x01\x02")
+    nl = struct.unpack_from("<H", ent, last + 28)[0]
+    struct.pack_into("<III", ent, last + 20, 0xFFFFFFFF, 0xFFFFFFFF, 0)  # csize, usize = "see ZIP64 extra"
+    struct.pack_into("<I", ent, last + 42, 0xFFFFFFFF)
+    struct.pack_into("<H", ent, last + 30, 4)  # extra length: just the 4-byte field header
+    extra = struct.pack("<HH", 1, 0xFFFF)
+    ent = ent[: last + 46 + nl] + extra
+    tail = bytearray(stored[eocd:])
+    struct.pack_into("<I", tail, 12, len(ent))
+    open(root / "zips" / "zip64_extra_overrun.zip", "wb").write(stored[:cd_off] + bytes(ent) + bytes(tail))
     # sequences (folder + zip), one with a corrupt frame
     frames = [textured(32, 48, s) for s in range(6)]
     for name, zipped, fmt in (("seq_png", False, "png"), ("seq_zip_jpg", True, "jpg")):
         (root / "sequences" / name).mkdir()
         make_sequence(str(root / "sequences" / name), frames, zipped, fmt)
     open(root / "sequences" / "seq_png" / "images" / "00003.png", "wb").write(b"\x89PNG\r\n\x1a\n" + os.urandom(64))
+    # a sequence archive with one implausible size field: the decode POOL's threads meet it (must report a bad frame, not terminate)
+    (root / "sequences" / "seq_zip_badsize").mkdir()
+    make_sequence(str(root / "sequences" / "seq_zip_badsize"), frames, True, "png")
+    zp = root / "sequences" / "seq_zip_badsize" / "images.zip"
+    zb = bytearray(open(zp, "rb").read())
+    e0 = zb.rfind(b"PK\x05\x06")
+    c0 = struct.unpack_from("<I", zb, e0 + 16)[0]
+    struct.pack_into("<I", zb, c0 + 24, 0xFFFFFFF0)
+    open(zp, "wb").write(bytes(zb))
 
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe, str(root)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)

@@ -3,8 +3,19 @@ re-entrant on a shared object (read-only tables, caller-owned buffers; undistort
 pair of objects is how a multi-threaded caller would drive them.  Here: 8 host threads share ONE PhotometricUndistorter,
 ONE UndistorterFOV and ONE mdc_ctx and call the class methods and the C-ABI host / device entry points concurrently
 (ctypes releases the GIL for the duration of a call), every thread on its own frames; every result must be the
-oracle's, bit for bit."""
+oracle's, bit for bit.
+
+The file is named test_zz_* on purpose: the driver runs `pytest -x`, and stress / concurrency tests go LAST in collection
+order so that a flake here can never keep the parity tests from running.
+
+Stream discipline (round-2 post-mortem): every torch operation that touches a buffer a kernel on `stream` also touches
+runs under `with torch.cuda.stream(stream)` -- torch.cuda.Stream() is a hipStreamNonBlocking stream, so work enqueued on
+torch's default (null) stream is NOT ordered with it; round 2's version poisoned d_out with fill_ on the null stream
+and the fill could land after the kernel had written its results.  tests/native/thread_soak.cpp is the same contract
+without torch (hipMemsetAsync / launch / hipMemcpyAsync all on the thread's own stream)."""
 import itertools
+import os
+import subprocess
 import threading
 
 import numpy as np
@@ -44,9 +55,10 @@ def test_shared_objects_from_many_threads(calib_dirs, oracle):
         try:
             raw = frames[k]
             stream = torch.cuda.Stream()
-            d_in = torch.from_numpy(np.stack([raw] * 3)).cuda()
-            d_out = torch.empty((3, npo), dtype=torch.float32, device="cuda")
-            torch.cuda.synchronize()
+            with torch.cuda.stream(stream):
+                d_in = torch.from_numpy(np.stack([raw] * 3)).cuda()
+                d_out = torch.empty((3, npo), dtype=torch.float32, device="cuda")
+            stream.synchronize()
             start.wait()
             for it in range(ROUNDS):
                 # the two class methods, as DatasetReader::getImage chains them (reference src/BenchmarkDatasetReader.h:222-223)
@@ -65,10 +77,10 @@ def test_shared_objects_from_many_threads(calib_dirs, oracle):
                 s.ctx.process_host(raw, o2, fl)
                 assert bits_equal(o2, want_proc[k][fl]), ("process_host", k, it, fl)
                 # a device batch on the thread's own stream
-                d_out.fill_(-7.0)
-                s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), 3, 15, stream.cuda_stream)
-                stream.synchronize()
-                got = d_out.cpu().numpy()
+                with torch.cuda.stream(stream):  # poison, launch and read-back are all ordered on `stream`
+                    d_out.fill_(-7.0)
+                    s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), 3, 15, stream.cuda_stream)
+                    got = d_out.cpu().numpy()
                 for j in range(3):
                     assert bits_equal(got[j], want_proc[k][15]), ("process_batch", k, it, j)
         except Exception as e:  # noqa: BLE001 -- reported by the main thread
@@ -80,3 +92,22 @@ def test_shared_objects_from_many_threads(calib_dirs, oracle):
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+SOAK = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "thread_soak")
+
+
+@pytest.mark.parametrize("name,threads,iters", [("small_explicit", 8, 400), ("full_1280_to_640", 8, 24)])
+def test_native_threads_one_context_own_streams(name, threads, iters, calib_dirs):
+    """The same contract without torch (tests/native/thread_soak.cpp): T std::threads, ONE mdc_ctx, every thread its own
+    hipStreamNonBlocking stream with hipMemsetAsync poison -> mdc_process_batch_device -> hipMemcpyAsync on THAT stream,
+    flags rotating, plus the blocking host entry points, all against the C oracle.  (tools/soak_threads.sh runs it for
+    2000+ iterations per thread; this is the short version.)"""
+    if not os.path.exists(SOAK):
+        pytest.skip("thread_soak not built")
+    r = subprocess.run([SOAK, calib_dirs[name], str(threads), str(iters)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("THREAD_SOAK")]
+    assert r.returncode == 0 and line, r.stdout[-3000:]
+    kv = dict(zip(line[-1].split()[1::2], line[-1].split()[2::2]))
+    assert int(kv["mismatches"]) == 0 and int(kv["call_failures"]) == 0 and int(kv["device_launches"]) == threads * iters, line[-1]
