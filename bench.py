@@ -84,6 +84,7 @@ def parse():
     p.add_argument("--tile-rows", type=int, default=0, help="output tile rows of the tiled kernel (0 = library default)")
     p.add_argument("--tile-cols", type=int, default=0, help="output tile columns of the tiled kernel (0 = library default)")
     p.add_argument("--nbuf", type=int, default=0, help="LDS window buffers (0 = automatic)")
+    p.add_argument("--two-stage", type=int, default=0, choices=[0, 1, 2], help="wave-private strip kernel: 0 = library's choice, 1 = wherever plannable, 2 = off")
     p.add_argument("--no-tune", action="store_true", help="keep the library's built-in tile shape / frames per workgroup instead "
                                                           "of mdc_tune_device's measured choice (untimed, before the warm-up)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -278,6 +279,8 @@ def main():
         ctx.set_option(capi.OPT_TILE_ROWS, args.tile_rows)
     if args.nbuf:
         ctx.set_option(capi.OPT_WINDOW_BUFFERS, args.nbuf)
+    if args.two_stage:
+        ctx.set_option(capi.OPT_TWO_STAGE, args.two_stage)
     info = ctx.info()
     out_w, out_h = (info.out_w, info.out_h) if rect else (IN_W, IN_H)
 

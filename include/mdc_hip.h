@@ -72,7 +72,12 @@ enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2 /* frames a workgroup lo
           reference's two-call composition (unMapImage -> internalTempBuffer -> undistort<float>,
           src/BenchmarkDatasetReader.h:222-223) copies at PCIe rate.  OFF by default -- the caller promises that such a
           buffer stays allocated for as long as the context lives.  Also switched on by the environment variable
-          MDC_PIN_CALLER_BUFFERS=1, for callers that cannot be recompiled. */ };
+          MDC_PIN_CALLER_BUFFERS=1, for callers that cannot be recompiled. */,
+       MDC_OPT_TWO_STAGE = 11 /* tuning: the wave-private strip kernel -- a wave owns a 128 x 8 output tile, stages its own source
+          window, converts every staged source pixel to lut * vignette ONCE and samples floats, 16 outputs per lane, pyramid
+          levels out of registers -- for remaps with about one output or more per source pixel (the scale-1 rectification of
+          BASELINE.json configs[4], magnifying remaps): 0 = automatic (when fewer source pixels are staged than there are
+          outputs), 1 = whenever it can be planned, 2 = never */ };
 enum { MDC_ORDER_BANDS = 0 /* row-major runs of tiles per XCD */, MDC_ORDER_ROWS = 1 /* whole tile rows per XCD */,
        MDC_ORDER_IDENTITY = 2 /* block b = tile b (diagnosis) */,
        MDC_ORDER_BLOCKS2D = 3 /* the tile grid cut into 8 rectangles, one per XCD */ };
@@ -95,6 +100,7 @@ typedef struct mdc_info {
   int64_t src_bbox_bytes;    /* bbox area in bytes (u8 source)                      */
   int64_t src_staged_bytes;  /* bytes the tiled kernel stages per frame (sum of the exact per-row windows) */
   int64_t n_black;           /* outputs whose remap is the (-1,-1) sentinel         */
+  int two_stage;             /* 1 if the fused pass runs on the wave-private strip kernel (MDC_OPT_TWO_STAGE) */
 } mdc_info;
 
 /* ---- lifetime -------------------------------------------------------------- */

@@ -54,6 +54,16 @@ struct mdc_ctx {
     bool tiled = false;
     int64_t staged_bytes = 0;
   } plan[2];
+  // wave-private strip kernel (StripPlan, mdc_internal.h): u8 frames, remaps with about one output or more per source pixel
+  struct Strip {
+    uint32_t* d_chunks = nullptr;
+    int* d_nch = nullptr;
+    uint32_t* d_taps = nullptr;
+    int* d_order = nullptr;
+    int n_blocks = 0, n_tiles = 0, tiles_x = 0, win_bytes = 0, passes = 0, nbuf = 2;
+    bool planned = false;
+    int64_t staged_bytes = 0;
+  } strip;
   int bbox[4] = {0, 0, -1, -1};
   int64_t n_black = 0;
 
@@ -68,6 +78,8 @@ struct mdc_ctx {
   int opt_nbuf = 0;  // 0 = automatic
   int opt_interleave = 0;
   int opt_pin_caller = 0;  // MDC_OPT_PIN_CALLER_BUFFERS
+  int opt_two_stage = 0;   // MDC_OPT_TWO_STAGE: 0 = automatic (strip kernel by source pixels per output), 1 = strip kernel whenever
+                           // plannable, 2 = never
 
   // Caller buffers page-locked in place (opt-in): the W*H float image that the reference's two-call composition
   // moves host -> device -> host -> device (DatasetReader::internalTempBuffer, src/BenchmarkDatasetReader.h:145,222).
@@ -247,10 +259,21 @@ void free_src_plan(mdc_ctx::SrcPlan& pl) {
   pl.staged_bytes = 0;
   pl.n_tiles = pl.tiles_x = pl.n_blocks = 0;
 }
+void free_strip_plan(mdc_ctx::Strip& st) {
+  for (void** p : {(void**)&st.d_chunks, (void**)&st.d_nch, (void**)&st.d_taps, (void**)&st.d_order})
+    if (*p) {
+      (void)hipFree(*p);
+      *p = nullptr;
+    }
+  st.planned = false;
+  st.staged_bytes = 0;
+  st.n_blocks = st.n_tiles = st.tiles_x = 0;
+}
 void free_plan(mdc_ctx* c) {
   for (auto& pl : c->plan) {
     free_src_plan(pl);
   }
+  free_strip_plan(c->strip);
 }
 
 template <typename T>
@@ -272,15 +295,13 @@ int plan_source(mdc_ctx* c, int es, int kTileW, int kTileH, mdc_ctx::SrcPlan& pl
   const int ppc = 16 / es;  // pixels per chunk
   const bool lut = es == 1;
   // whole 16-byte chunks per frame row; one frame within the 32-bit lane offsets of the buffer descriptors
+  const char* why = "frame rows are not whole chunks / frame too large";
   bool ok = (iw % ppc == 0) && (int64_t)iw * c->rm_in_h * es < (int64_t)kOutside && (int64_t)ow * oh * 4 < (int64_t)kOutside;
   // the 960-/1024-thread tiles derive the output offsets of rows 1..3 from row 0 (kOutsideLean, mdc_kernels.hip)
   if (kTileThreads >= 960 && (int64_t)ow * (oh + kTileH) * 4 >= 0xc0000000ll) ok = false;
   std::vector<std::vector<uint32_t>> chunks(n_tiles);
   std::vector<int> nch(n_tiles, 0);
   std::vector<uint32_t> taps((size_t)ow * oh, 0u);
-  struct Row {
-    int lo = std::numeric_limits<int>::max(), hi = -1, x0 = 0, lds = 0;
-  };
   for (int t = 0; t < n_tiles && ok; t++) {
     const int bx = (t % tx) * kTileW, by = (t / tx) * kTileH;
     const int x1 = std::min(bx + kTileW, ow), y1 = std::min(by + kTileH, oh);
@@ -293,37 +314,44 @@ int plan_source(mdc_ctx* c, int es, int kTileW, int kTileH, mdc_ctx::SrcPlan& pl
         y_hi = std::max(y_hi, (int)yy + 1);
       }
     if (y_hi < 0) continue;  // every output black: no window
-    std::vector<Row> rows(y_hi - y_lo + 1);
+    // Exact chunk SET per source row (not one run from the leftmost to the rightmost tap: the source footprint of a wide,
+    // flat tile is a bowed band that touches a row in two separate places).  pos[row][chunk] = index of the chunk in the
+    // tile's list, -1 = not staged.  A tap pair (xi, xi+1) marks both bytes' chunks, so chunks that are neighbours in a
+    // frame row and both used are neighbours in the list too: the pair stays contiguous in LDS.
+    const int cpr = iw / ppc;  // chunks per frame row
+    const int nrows = y_hi - y_lo + 1;
+    std::vector<int> pos((size_t)nrows * cpr, -1);
     for (int y = by; y < y1; y++)
       for (int x = bx; x < x1; x++) {
         const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
         if (xx < 0) continue;
         const int xi = (int)xx, yi = (int)yy;
         for (int dy = 0; dy < 2; dy++) {
-          Row& r = rows[yi + dy - y_lo];
-          r.lo = std::min(r.lo, xi);
-          r.hi = std::max(r.hi, xi + 1);
+          int* pr = &pos[(size_t)(yi + dy - y_lo) * cpr];
+          pr[xi / ppc] = 0;
+          pr[(xi + 1) / ppc] = 0;
         }
       }
-    for (size_t k = 0; k < rows.size(); k++) {
-      Row& r = rows[k];
-      if (r.hi < 0) continue;  // no tap in this row (cannot happen between two used rows, harmless if it does)
-      r.x0 = r.lo - r.lo % ppc;
-      r.lds = (int)chunks[t].size() * 16;
-      const int n = (r.hi - r.x0) / ppc + 1;
-      if (r.x0 + n * ppc > iw) ok = false;
-      for (int j = 0; j < n; j++) chunks[t].push_back((uint32_t)(((y_lo + (int)k) * iw + r.x0 + j * ppc) * es));
-    }
+    for (int k = 0; k < nrows; k++)
+      for (int ch = 0; ch < cpr; ch++) {
+        int& q = pos[(size_t)k * cpr + ch];
+        if (q < 0) continue;
+        q = (int)chunks[t].size();
+        chunks[t].push_back((uint32_t)(((y_lo + k) * iw + ch * ppc) * es));
+      }
     nch[t] = (int)chunks[t].size();
-    if (nch[t] > (lut ? kTileMaxChunks : kTileMaxChunksF32) * kTileThreads || nch[t] * 16 > 65535) ok = false;
+    if (nch[t] > (lut ? kTileMaxChunks : kTileMaxChunksF32) * kTileThreads || nch[t] * 16 > 65535) {
+      ok = false;
+      why = "a window has too many chunks";
+    }
     pl.staged_bytes += (int64_t)nch[t] * 16;
     for (int y = by; y < y1 && ok; y++)
       for (int x = bx; x < x1; x++) {
         const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
         if (xx < 0) continue;
         const int xi = (int)xx, yi = (int)yy;
-        const Row &r0 = rows[yi - y_lo], &r1 = rows[yi + 1 - y_lo];
-        taps[(size_t)y * ow + x] = (uint32_t)(r0.lds + (xi - r0.x0) * es) | ((uint32_t)(r1.lds + (xi - r1.x0) * es) << 16);
+        const int p0 = pos[(size_t)(yi - y_lo) * cpr + xi / ppc], p1 = pos[(size_t)(yi + 1 - y_lo) * cpr + xi / ppc];
+        taps[(size_t)y * ow + x] = (uint32_t)(p0 * 16 + (xi % ppc) * es) | ((uint32_t)(p1 * 16 + (xi % ppc) * es) << 16);
       }
   }
   // every tile's chunk list is padded (kOutside) to the kernel's maximum of staging rounds: the kernel loads
@@ -339,9 +367,15 @@ int plan_source(mdc_ctx* c, int es, int kTileW, int kTileH, mdc_ctx::SrcPlan& pl
   const int nbuf_max = kTileThreads > 512 ? 3 : 4;
   int nbuf = 2;
   while (nbuf < nbuf_max && tiled_lds_bytes(win_bytes, nbuf + 1, lut) * wg_per_cu <= kLdsPerCU) nbuf++;
-  if (c->opt_nbuf) nbuf = std::min(c->opt_nbuf, nbuf_max);
-  if (tiled_lds_bytes(win_bytes, nbuf, lut) > kLdsPerCU) ok = false;
-  if (!ok) return MDC_OK;
+  if (c->opt_nbuf >= 2) nbuf = std::min(c->opt_nbuf, nbuf_max);
+  if (tiled_lds_bytes(win_bytes, nbuf, lut) > kLdsPerCU) {
+    ok = false;
+    why = "windows do not fit LDS";
+  }
+  if (!ok) {
+    if (getenv("MDC_DEBUG_PLAN")) fprintf(stderr, "mdc plan %dx%d (element size %d): not plannable: %s\n", kTileW, kTileH, es, why);
+    return MDC_OK;
+  }
   std::vector<uint32_t> flat((size_t)n_tiles * cap, kOutside);
   for (int t = 0; t < n_tiles; t++) std::copy(chunks[t].begin(), chunks[t].end(), flat.begin() + (size_t)t * cap);
   int rc;
@@ -359,6 +393,101 @@ int plan_source(mdc_ctx* c, int es, int kTileW, int kTileH, mdc_ctx::SrcPlan& pl
   pl.win_bytes = win_bytes;
   pl.nbuf = nbuf;
   pl.tiled = true;
+  return MDC_OK;
+}
+
+// Plan of the wave-private strip kernel (StripPlan): per 128 x 8 output tile the exact source window as a dense list of
+// 16-byte chunks (<= kStripChunkCap), per output the byte offsets of its two tap rows inside the wave's FLOAT window.
+// Planned when the remap stages fewer source pixels than it has outputs (config 5's scale-1 rectification, magnifying
+// remaps) or on request (MDC_OPT_TWO_STAGE = 1); leaves st.planned = false when a window is too large, frame rows are not
+// whole chunks, or the output height is not a multiple of 8 (rows are addressed through the store's scalar offset,
+// which the hardware's range check does not cover).
+int plan_strip(mdc_ctx* c) {
+  mdc_ctx::Strip& st = c->strip;
+  free_strip_plan(st);
+  if (c->opt_two_stage == 2) return MDC_OK;
+  const int ow = c->out_w, oh = c->out_h, iw = c->rm_in_w;
+  constexpr int TW = kStripTileW, TH = kStripTileH;
+  if (iw % 16 != 0 || oh % TH != 0 || (int64_t)iw * c->rm_in_h >= (int64_t)kOutside || (int64_t)ow * (oh + TH) * 4 >= 0xc0000000ll) return MDC_OK;
+  const int tx = (ow + TW - 1) / TW, ty = oh / TH, n_tiles = tx * ty;
+  std::vector<uint32_t> flat((size_t)n_tiles * kStripChunkCap, kOutside);
+  std::vector<int> nch(n_tiles, 0);
+  std::vector<uint32_t> taps((size_t)ow * oh, 0u);
+  struct Row {
+    int lo = std::numeric_limits<int>::max(), hi = -1, x0 = 0, lds = 0;
+  };
+  int nch_max = 1;
+  int64_t staged = 0;
+  for (int t = 0; t < n_tiles; t++) {
+    const int bx = (t % tx) * TW, by = (t / tx) * TH;
+    const int x1 = std::min(bx + TW, ow), y1 = by + TH;
+    int y_lo = std::numeric_limits<int>::max(), y_hi = -1;
+    for (int y = by; y < y1; y++)
+      for (int x = bx; x < x1; x++) {
+        const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
+        if (xx < 0) continue;
+        y_lo = std::min(y_lo, (int)yy);
+        y_hi = std::max(y_hi, (int)yy + 1);
+      }
+    if (y_hi < 0) continue;  // every output black
+    std::vector<Row> rows(y_hi - y_lo + 1);
+    for (int y = by; y < y1; y++)
+      for (int x = bx; x < x1; x++) {
+        const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
+        if (xx < 0) continue;
+        const int xi = (int)xx, yi = (int)yy;
+        for (int dy = 0; dy < 2; dy++) {
+          Row& r = rows[yi + dy - y_lo];
+          r.lo = std::min(r.lo, xi);
+          r.hi = std::max(r.hi, xi + 1);
+        }
+      }
+    int n = 0;
+    for (size_t k = 0; k < rows.size(); k++) {
+      Row& r = rows[k];
+      if (r.hi < 0) continue;
+      r.x0 = r.lo - r.lo % 16;
+      r.lds = n * 16;
+      const int cnt = (r.hi - r.x0) / 16 + 1;
+      if (r.x0 + cnt * 16 > iw || n + cnt > kStripChunkCap) return MDC_OK;  // not plannable: the workgroup kernels keep the job
+      for (int j = 0; j < cnt; j++) flat[(size_t)t * kStripChunkCap + n + j] = (uint32_t)((y_lo + (int)k) * iw + r.x0 + j * 16);
+      n += cnt;
+    }
+    nch[t] = n;
+    nch_max = std::max(nch_max, n);
+    staged += (int64_t)n * 16;
+    for (int y = by; y < y1; y++)
+      for (int x = bx; x < x1; x++) {
+        const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
+        if (xx < 0) continue;
+        const int xi = (int)xx, yi = (int)yy;
+        const Row &r0 = rows[yi - y_lo], &r1 = rows[yi + 1 - y_lo];
+        taps[(size_t)y * ow + x] = (uint32_t)(4 * (r0.lds + xi - r0.x0)) | ((uint32_t)(4 * (r1.lds + xi - r1.x0)) << 16);
+      }
+  }
+  const double src_per_out = (double)staged / std::max<double>(1.0, (double)ow * oh);
+  if (c->opt_two_stage != 1 && src_per_out >= 1.0) return MDC_OK;
+  const int win = (nch_max * 16 + 63) & ~63;
+  const int need = (4 * nch_max + 63) / 64;  // convert passes
+  const int passes = need <= 2 ? 2 : need <= 3 ? 3 : need <= 4 ? 4 : need <= 5 ? 5 : 8;
+  const int nbuf = c->opt_nbuf >= 1 && c->opt_nbuf <= 4 ? c->opt_nbuf : 2;
+  if (strip_lds_bytes(win, nbuf, kStripWaves) > kLdsPerCU) return MDC_OK;
+  int rc;
+  if ((rc = upload(c, &st.d_chunks, flat)) != MDC_OK || (rc = upload(c, &st.d_nch, nch)) != MDC_OK || (rc = upload(c, &st.d_taps, taps)) != MDC_OK)
+    return rc;
+  // groups of kStripWaves consecutive tiles (row-major: neighbours along a tile row); XCD placement as for the workgroup tiles
+  const int n_groups = (n_tiles + kStripWaves - 1) / kStripWaves;
+  const int gx = std::max(1, tx / kStripWaves);
+  const std::vector<int> order = (tx % kStripWaves == 0) ? tile_order(gx, n_groups / gx, c->opt_order) : tile_order(n_groups, 1, MDC_ORDER_BANDS);
+  if ((rc = upload(c, &st.d_order, order)) != MDC_OK) return rc;
+  st.n_blocks = (int)order.size();
+  st.n_tiles = n_tiles;
+  st.tiles_x = tx;
+  st.win_bytes = win;
+  st.passes = passes;
+  st.nbuf = nbuf;
+  st.staged_bytes = staged;
+  st.planned = true;
   return MDC_OK;
 }
 
@@ -403,7 +532,7 @@ int plan_tiles(mdc_ctx* c) {
       if (c->plan[which].tiled) break;
     }
   }
-  return MDC_OK;
+  return plan_strip(c);
 }
 
 // role 0: image_out of unMapImage, role 1: input of undistort<float>
@@ -522,6 +651,17 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
                 c->rm_in_h);
   RemapArgs a = remap_args(c, lut, vinv);
   const bool aligned = (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
+  if (c->strip.planned && aligned && c->opt_kernel != MDC_KERNEL_GATHER) {  // wave-private strips (scale >= ~1 remaps)
+    const mdc_ctx::Strip& st = c->strip;
+    const StripPlan sp{st.d_chunks, st.d_nch, st.d_taps, st.d_order, st.n_blocks, st.n_tiles, st.tiles_x, st.win_bytes, st.passes, st.nbuf,
+                       c->opt_interleave != 0};
+    int fpb = frames_per_block(c, nframes, st.n_blocks);
+    const bool fuse_pyr = pyr && c->out_w % kStripTileW == 0;
+    MDC_HIP(c, launch_remap_strip_u8(d_in, d_out, a, sp, nframes, fpb, s, fuse_pyr ? pyr[0] : nullptr, fuse_pyr ? pyr[1] : nullptr,
+                                     fuse_pyr ? pyr[2] : nullptr));
+    if (pyr_done) *pyr_done = fuse_pyr;
+    return MDC_OK;
+  }
   bool use_tiled = c->plan[0].tiled && aligned;
   if (c->opt_kernel == MDC_KERNEL_GATHER) use_tiled = false;
   if (c->opt_kernel == MDC_KERNEL_TILED && !use_tiled)
@@ -660,9 +800,19 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
       return MDC_OK;
     }
     case MDC_OPT_WINDOW_BUFFERS: {
-      if (value != 0 && (value < 2 || value > 4)) return fail(c, MDC_ERR_ARG, "window buffers must be 0 (auto) or 2..4");
+      if (value < 0 || value > 4) return fail(c, MDC_ERR_ARG, "window buffers must be 0 (auto) or 1..4 (1: strip kernel only)");
       if (value == c->opt_nbuf) return MDC_OK;
       c->opt_nbuf = value;
+      if (!c->valid_remap) return MDC_OK;
+      DeviceGuard dg(c->device);
+      MDC_HIP(c, hipDeviceSynchronize());
+      return plan_tiles(c);
+    }
+    case MDC_OPT_TWO_STAGE: {
+      if (value < 0 || value > 2) return fail(c, MDC_ERR_ARG, "two-stage selector must be 0 (automatic), 1 (on) or 2 (off)");
+      if (value == c->opt_two_stage) return MDC_OK;
+      c->opt_two_stage = value;
+      c->tuned_fpb = 0;
       if (!c->valid_remap) return MDC_OK;
       DeviceGuard dg(c->device);
       MDC_HIP(c, hipDeviceSynchronize());
@@ -699,13 +849,22 @@ int mdc_get_info(mdc_ctx* c, mdc_info* i) {
   i->tile_h = p0.tiled ? p0.tile_h : c->opt_tile_h;
   i->n_tiles = p0.n_tiles;
   i->lds_bytes = p0.tiled ? (int)tiled_lds_bytes(p0.win_bytes, p0.nbuf, true) : 0;
+  i->two_stage = c->strip.planned ? 1 : 0;
+  if (c->strip.planned) {
+    i->tiled = c->valid_remap;
+    i->tile_w = kStripTileW;
+    i->tile_h = kStripTileH;
+    i->n_tiles = c->strip.n_tiles;
+    i->lds_bytes = (int)strip_lds_bytes(c->strip.win_bytes, c->strip.nbuf, kStripWaves);
+    i->window_buffers = c->strip.nbuf;
+  }
   i->window_buffers = p0.tiled ? p0.nbuf : 0;
   i->f32_tiled = c->valid_remap && c->plan[1].tiled;
   i->f32_tile_w = c->plan[1].tiled ? c->plan[1].tile_w : 0;
   i->f32_tile_h = c->plan[1].tiled ? c->plan[1].tile_h : 0;
   for (int k = 0; k < 4; k++) i->src_bbox[k] = c->bbox[k];
   i->src_bbox_bytes = c->bbox[2] >= 0 ? (int64_t)(c->bbox[2] - c->bbox[0] + 1) * (c->bbox[3] - c->bbox[1] + 1) : 0;
-  i->src_staged_bytes = p0.staged_bytes;
+  i->src_staged_bytes = c->strip.planned ? c->strip.staged_bytes : p0.staged_bytes;
   i->n_black = c->n_black;
   return MDC_OK;
 }
@@ -1173,6 +1332,10 @@ int mdc_describe_launch(mdc_ctx* c, unsigned flags, int pyramid_levels, char* bu
     snprintf(tmp, sizeof tmp, "%s<%s>", ((int64_t)fw * fh) % 4 == 0 ? "unmap_xpose_kernel" : "unmap_scalar_kernel", v ? "true" : "false");
   } else if (!c->valid_remap) {
     return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
+  } else if (c->strip.planned && c->opt_kernel != MDC_KERNEL_GATHER) {
+    const bool pyr = pyramid_levels > 1 && c->out_w % kStripTileW == 0;
+    snprintf(tmp, sizeof tmp, "remap_strip_kernel<%s, %s, %d, %d, %d>", v ? "true" : "false", pyr ? "true" : "false", c->strip.nbuf,
+             c->strip.passes, kStripWaves);
   } else if (c->plan[0].tiled && c->opt_kernel != MDC_KERNEL_GATHER) {
     const mdc_ctx::SrcPlan& p = c->plan[0];
     const bool pyr = pyramid_levels > 1 && p.tile_h % 8 == 0 && c->out_w % p.tile_w == 0 && c->out_h % p.tile_h == 0 &&

@@ -55,6 +55,30 @@ struct TilePlan {
   bool interleave; // frame groups take every G-th frame instead of fpb consecutive ones
 };
 
+// Plan of the wave-private strip kernel (remap_strip_kernel): a WAVE owns a 128 x 8 output tile (lane l: columns l and
+// l + 64, 8 rows), stages its own source window (<= kStripChunkCap chunks, dense list, kOutside-padded), converts it to
+// lut * vignette floats and samples those.  Offsets in d_taps are bytes inside the wave's FLOAT window (4 x the u8 offset).
+constexpr int kStripTileW = 128, kStripTileH = 8;
+constexpr int kStripChunkCap = 128;  // two LDS-DMA instructions per wave and frame at most
+#ifndef MDC_EXP_STRIP_WAVES
+#define MDC_EXP_STRIP_WAVES 4
+#endif
+constexpr int kStripWaves = MDC_EXP_STRIP_WAVES;  // waves (tiles) per workgroup: they share the LUT replicas
+struct StripPlan {
+  const uint32_t* d_chunks;  // [n_tiles][kStripChunkCap]
+  const int* d_nch;          // [n_tiles]
+  const uint32_t* d_taps;    // [out_w*out_h] float-window byte offset of tap (xi,yi) | of tap (xi,yi+1) << 16
+  const int* d_order;        // block -> group of kStripWaves consecutive tiles (or -1); block b runs on XCD b % 8
+  int n_blocks, n_tiles, tiles_x;
+  int win_bytes;             // u8 window bytes of a wave: 16 * max nch, rounded up to 64
+  int passes;                // convert passes per frame (64 dwords each): 2, 3, 4, 5 or 8
+  int nbuf;                  // u8 windows per wave: 1 or 2
+  bool interleave;
+};
+hipError_t launch_remap_strip_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const StripPlan& p, int64_t nframes, int fpb,
+                                 hipStream_t s, float* d_l1 = nullptr, float* d_l2 = nullptr, float* d_l3 = nullptr);
+size_t strip_lds_bytes(int win_bytes, int nbuf, int waves);
+
 // out[f][i] = lut[in[f][i]] (* vinv[i]) over nframes frames of npix pixels.
 hipError_t launch_unmap(const uint8_t* d_in, float* d_out, const float* d_lut, const float* d_vinv, int64_t npix,
                         int64_t nframes, int fpb, hipStream_t s);

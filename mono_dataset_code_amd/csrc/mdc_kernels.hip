@@ -44,6 +44,18 @@ constexpr int kLutBytes = 256 * kLutRep * 4;
 #ifndef MDC_EXP_TIMING
 #define MDC_EXP_TIMING 0      // diagnosis: wave 0 / 5 of some workgroups print the cycles their frame loop spent per phase (tools/phase_timing.sh)
 #endif
+#ifndef MDC_EXP_STRIP_LUT_REP
+#define MDC_EXP_STRIP_LUT_REP 8  // LUT replicas of the strip kernel (8 KiB): its LUT reads are per SOURCE pixel, a few bank conflicts cost little
+#endif
+#ifndef MDC_EXP_STRIP_NOCONVERT
+#define MDC_EXP_STRIP_NOCONVERT 0  // diagnosis (wrong results): the strip kernel skips its convert phase
+#endif
+#ifndef MDC_EXP_STRIP_NOSAMPLE
+#define MDC_EXP_STRIP_NOSAMPLE 0   // diagnosis (wrong results): the strip kernel stores a register instead of sampling
+#endif
+#ifndef MDC_EXP_STRIP_WAVES_PER_EU
+#define MDC_EXP_STRIP_WAVES_PER_EU 5  // register budget of the strip kernel: 512 / 5 -> 100 VGPRs
+#endif
 #ifndef MDC_EXP_SKIP_LOAD
 #define MDC_EXP_SKIP_LOAD 0   // diagnosis: every frame re-stages frame 0 (L2 hits) -> write side alone
 #endif
@@ -650,7 +662,13 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
     tp[2] += t3 - t2;  // s_waitcnt vmcnt: the wave's DMA of the next frame landed, older stores retired
     tp[3] += t4 - t3;  // s_barrier: the other waves
 #else
-    if (PYR && pyr_all_levels) frame_barrier<D, R, 6>(rw);
+    // The allowance below counts what iteration f+1-D issued AFTER its DMA group -- but for f < D-1 the DMA of frame f+1
+    // was issued by the PROLOGUE, back to back with the other prologue groups and with no stores behind it, so fewer
+    // operations follow it than the formula assumes (D = 2, f = 0: rw + S follow, the formula allows rw + 2 S: the wait
+    // could pass with DMA(1) still in flight -- never observed, frame 1 has a whole frame's time to land, but not
+    // guaranteed).  Those first D-1 iterations wait for everything but the frame's own 4 stores.
+    if (D > 1 && f < D - 1) wait_vm_barrier<4>();
+    else if (PYR && pyr_all_levels) frame_barrier<D, R, 6>(rw);
     else frame_barrier<D, R>(rw);
 #endif
     lds_u8_ptr x = w[0];
@@ -803,6 +821,368 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
   else if (rounds == 3 || !F32) MDC_TILE_RUN(3);
   else if constexpr (F32) MDC_TILE_RUN(4);  // float windows are 4x the bytes: up to kTileMaxChunksF32 rounds
 #undef MDC_TILE_RUN
+}
+
+// s_waitcnt vmcnt(N) without a barrier (wave-private windows), and a pointer the compiler cannot prove wave-uniform
+// (it is: derived from block indices and loop counters) moved into SGPRs, so that a buffer descriptor built from it needs
+// no waterfall loop.
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
+// ----------------------------------------------------------------------------
+// Wave-private strips: the two-stage idea without any workgroup barrier, 16 outputs per lane.
+//
+// What round 3's phase timing showed for the scale-1 rectification of config 5 (1280x1024 -> 1280x1024): with the stores
+// compiled out both workgroup-tiled kernels still need ~2500 cycles per frame and workgroup for ~140 instructions per
+// wave -- a serial chain "DMA landed -> barrier -> LDS round trips -> arithmetic" per FOUR outputs of a thread, with
+// three workgroups per CU to hide it.  unMapImage, which runs at the memory system's ceiling, has no barrier and 16
+// outputs per thread.  This kernel gives the remap the same shape:
+//   * a WAVE owns a 128 x 8 output tile: lane l has columns l and l+64, 8 rows each -> 16 outputs per lane and frame;
+//   * its source window (<= 128 chunks, host plan) is staged by the wave itself (LDS-DMA), converted by the wave itself
+//     (byte -> lut * vignette, once per source pixel) into its own float window and sampled by the wave itself:
+//     no other wave ever touches it -> no s_barrier in the frame loop, only s_waitcnt;
+//   * levels 1..3 of the box pyramid come out of the wave's registers: rows are in-lane (8 of them), columns are
+//     neighbouring lanes (DPP quad permutes for levels 1 and 2, row_shl:4 for level 3) -- no LDS hand-over;
+//   * a workgroup is just W such waves sharing the LUT replicas (W consecutive tiles of a tile row: their windows share
+//     128-byte lines, which then meet in the CU's vector L1).
+// Same products, same sum order as the direct kernel -> bit-identical (black outputs sample a zero pair with weights
+// (0, 0, 0, 1): +0.0f exactly, as the reference's `output = 0`).
+// ----------------------------------------------------------------------------
+constexpr int kStripLutRep = MDC_EXP_STRIP_LUT_REP;  // LUT replicas of the strip kernel (convert reads only: 0.65 per output)
+constexpr int kStripLutBytes = 256 * kStripLutRep * 4;
+constexpr int kStripCap = kStripChunkCap;
+constexpr int kStripPad = 64;   // bytes behind a float window: the zero pair black outputs sample
+
+template <int NT, int REP>
+__device__ __forceinline__ void fill_lut_rep(float* s_lut, const float* __restrict__ lut, int tid) {
+  constexpr int N = 256 * (REP / 4);  // 16-byte stores in total; entry e occupies words [REP e, REP e + REP)
+  constexpr int IT = (N + NT - 1) / NT;
+  float v[IT];
+#pragma unroll
+  for (int k = 0; k < IT; k++) v[k] = lut[min(tid + k * NT, N - 1) / (REP / 4)];
+#pragma unroll
+  for (int k = 0; k < IT; k++)
+    if (IT * NT == N || tid + k * NT < N) reinterpret_cast<f32x4*>(s_lut)[tid + k * NT] = f32x4{v[k], v[k], v[k], v[k]};
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {  // row_shl:n = 0x100 + n, row_shr:n = 0x110 + n (within rows of 16 lanes)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// P = convert passes (64 dwords = 256 source pixels each), NBUF = u8 windows (1: the next frame's DMA is issued right
+// after the convert, into the window just consumed; 2: one frame ahead), W = waves (tiles) per workgroup
+template <bool VIG, bool PYR, int NBUF, int P, int W>
+__global__ __launch_bounds__(64 * W, (PYR ? MDC_EXP_STRIP_WAVES_PER_EU - 1 : MDC_EXP_STRIP_WAVES_PER_EU)) void remap_strip_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, RemapArgs a,
+                                                            StripPlan p, PyramidOut py, int nframes, int fpb, int interleave) {
+#if __HIP_DEVICE_COMPILE__
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int win = p.win_bytes;                       // u8 window bytes (multiple of 64)
+  const int per_wave = (4 + NBUF) * win + kStripPad;  // [float window 4 win][zero pad][NBUF u8 windows]
+  float* s_lut = reinterpret_cast<float*>(smem + W * per_wave);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int group = p.d_order[blockIdx.x];
+  // the LUT is filled by the whole workgroup before anybody leaves
+  fill_lut_rep<64 * W, kStripLutRep>(s_lut, a.lut, tid);
+  __syncthreads();
+  if (group < 0) return;
+  const int tile = group * W + wave;
+  if (tile >= p.n_tiles) return;
+  const int fstep = interleave ? (int)gridDim.y : 1;
+  const int f0 = interleave ? (int)blockIdx.y : (int)blockIdx.y * fpb;
+  const int nf = interleave ? (nframes - f0 + fstep - 1) / fstep : min(nframes, f0 + fpb) - f0;
+  if (nf <= 0) return;
+
+  lds_u8_ptr s_f32 = (lds_u8_ptr)smem + wave * per_wave;
+  lds_u8_ptr s_u8 = s_f32 + 4 * win + kStripPad;
+  lds_f32_ptr my_lut = (lds_f32_ptr)s_lut + (lane & (kStripLutRep - 1));
+  if (lane < kStripPad / 4) reinterpret_cast<__attribute__((address_space(3))) float*>(s_f32 + 4 * win)[lane] = 0.f;
+
+  const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+  const int nch = p.d_nch[tile];
+  const uint32_t* chunks = p.d_chunks + (size_t)tile * kStripCap;
+  uint32_t goff[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) goff[k] = chunks[lane + 64 * k];  // kOutside past the window (host padding)
+  uint32_t cgoff[P];
+  bool cvalid[P];
+#pragma unroll
+  for (int j = 0; j < P; j++) {
+    const int d = j * 64 + lane;
+    cvalid[j] = (d >> 2) < nch;
+    cgoff[j] = chunks[min(d >> 2, kStripCap - 1)] + (uint32_t)(d & 3) * 4u;
+  }
+  // 16 outputs: o = 8 h + r, column tx*128 + lane + 64 h, row ty*8 + r
+  float fx[16], fy[16];
+  uint32_t tap[16];
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int ox = tx * 128 + lane + 64 * h, oy = ty * 8 + r;
+      const bool inside = ox < a.out_w && oy < a.out_h;
+      const int oidx = inside ? oy * a.out_w + ox : 0;
+      float xx = a.rx[oidx], yy = a.ry[oidx];
+      uint32_t tp = p.d_taps[oidx];
+      const bool black = !inside || xx < 0;  // black (and outside) outputs sample the zero pair with weights (0, 0, 0, 1)
+      if (black) {
+        xx = yy = 0.f;
+        tp = (uint32_t)(4 * win) * 0x00010001u;
+      }
+      fx[8 * h + r] = xx - (float)(int)xx;  // src/FOVUndistorter.cpp:352-355
+      fy[8 * h + r] = yy - (float)(int)yy;
+      tap[8 * h + r] = tp;
+    }
+  f32x4 vin[P];
+#pragma unroll
+  for (int j = 0; j < P; j++) {
+    vin[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (VIG && cvalid[j]) vin[j] = *reinterpret_cast<const f32x4*>(a.vinv + cgoff[j]);
+  }
+  const uint32_t in_bytes = (uint32_t)a.in_w * (uint32_t)a.in_h;
+  const uint32_t out_bytes = (uint32_t)a.out_w * (uint32_t)a.out_h * 4u;
+  const uint32_t row_bytes = (uint32_t)a.out_w * 4u;
+  // store offsets: lane part in a VGPR (kOutsideLean-style sentinel for columns outside the image: still beyond the
+  // frame after adding any row's offset), row part as the instruction's scalar offset; rows below the image fall
+  // outside the frame's descriptor and are dropped
+  uint32_t vo[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int ox = tx * 128 + lane + 64 * h;
+    vo[h] = ox < a.out_w ? (uint32_t)((ty * 8) * a.out_w + ox) * 4u : kOutsideLean;
+  }
+  // pyramid offsets (whole tiles only, so everything is inside)
+  uint32_t p1o[2] = {0, 0}, p2o = kOutside, p3o = kOutside;
+  if (PYR) {
+#pragma unroll
+    for (int h = 0; h < 2; h++)  // level 1: even lanes row 2q (+0), odd lanes row 2q + 1, column (ox >> 1); q adds 2 rows (scalar)
+      p1o[h] = (uint32_t)((ty * 4 + (lane & 1)) * (a.out_w >> 1) + ((tx * 128 + lane + 64 * h) >> 1)) * 4u;
+    {  // level 2: lane 4k + j stores the value of (h, q) = (j >> 1, j & 1): row ty*2 + q, column tx*32 + 16 h + k
+      const int j = lane & 3, k = lane >> 2;
+      p2o = (uint32_t)((ty * 2 + (j & 1)) * (a.out_w >> 2) + tx * 32 + 16 * (j >> 1) + k) * 4u;
+    }
+    if ((lane & 3) == 0) {  // level 3: lane 8 i stores h = 0, lane 8 i + 4 stores h = 1: row ty, column tx*16 + 8 h + i
+      const int h = (lane >> 2) & 1, i = lane >> 3;
+      p3o = (uint32_t)(ty * (a.out_w >> 3) + tx * 16 + 8 * h + i) * 4u;
+    }
+  }
+  const long long in_step = (long long)fstep * in_bytes;
+  const long long out_step = (long long)fstep * (out_bytes / 4);
+  const uint8_t* src = in + (long long)f0 * in_bytes;
+  float* dst = out + (long long)f0 * (out_bytes / 4);
+  const int last = nf - 1;
+  const int rw = nch > 64 ? 2 : 1;  // DMA instructions per frame (wave-uniform)
+  const uint32_t l1_bytes = out_bytes / 4, l2_bytes = out_bytes / 16, l3_bytes = out_bytes / 64;
+
+  if (nch == 0) {  // every output of the tile is black: zeros on every level, no staging
+    for (int f = 0; f < nf; f++, dst += out_step) {
+      const auto ro = MDC_FRAME_RSRC(uniform_ptr(dst), out_bytes);
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) __builtin_amdgcn_raw_buffer_store_b32(0u, ro, vo[h], r * row_bytes, 0);
+      if (PYR) {
+        const long long fa = (long long)f0 + (long long)f * fstep;
+        if (py.l1) {
+          const auto r1 = MDC_FRAME_RSRC(uniform_ptr(py.l1 + fa * (l1_bytes / 4)), l1_bytes);
+#pragma unroll
+          for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) __builtin_amdgcn_raw_buffer_store_b32(0u, r1, p1o[h], q * row_bytes, 0);
+        }
+        if (py.l2) __builtin_amdgcn_raw_buffer_store_b32(0u, MDC_FRAME_RSRC(uniform_ptr(py.l2 + fa * (l2_bytes / 4)), l2_bytes), p2o, 0, 0);
+        if (py.l3) __builtin_amdgcn_raw_buffer_store_b32(0u, MDC_FRAME_RSRC(uniform_ptr(py.l3 + fa * (l3_bytes / 4)), l3_bytes), p3o, 0, 0);
+      }
+    }
+    return;
+  }
+  MDC_CHECK(nch <= kStripCap && nch * 16 <= win && 4 * nch <= 64 * P);
+
+  auto stage = [&](int fr, int buf) {
+#if MDC_EXP_SKIP_LOAD
+    const auto ri = MDC_FRAME_RSRC(uniform_ptr(src + 0 * (long long)min(fr, last) * in_step), in_bytes);
+#else
+    const auto ri = MDC_FRAME_RSRC(uniform_ptr(src + (long long)min(fr, last) * in_step), in_bytes);
+#endif
+    lds_u8_ptr u = s_u8 + buf * win;
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      if (k < rw && goff[k] != kOutside) {
+        MDC_CHECK(goff[k] + 16u <= in_bytes && (goff[k] & 15u) == 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (lds_void_ptr)(u + k * 1024), 16, goff[k], 0, 0, kLoadAux);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // S = stores per frame issued after the frame's DMA: 16 (+ 4 + 1 + 1 with all pyramid levels)
+  const bool pyr_all = PYR && py.l1 && py.l2 && py.l3;
+  // NBUF >= 2: D = NBUF - 1 frames are staged ahead (the u8 windows are small: depth is cheap, and what the read side of
+  // this kernel needs is bytes in flight -- its DMA latency is ~2.5 us).  NBUF == 1: the next frame's DMA is issued right
+  // after the convert, into the window just consumed.
+  constexpr int D = NBUF >= 2 ? NBUF - 1 : 1;
+  if (NBUF >= 2) {
+#pragma unroll
+    for (int d = 0; d < D; d++) stage(d, d);
+  } else {
+    stage(0, 0);
+  }
+  int ub = 0;
+  for (int f = 0; f <= last; f++) {
+    if (NBUF >= 2) {
+      int nb = ub + D;
+      if (nb >= NBUF) nb -= NBUF;
+      stage(f + D, nb);
+      // DMA(f) landed.  Issued after it: f >= D: the stores of iteration f-D, then (rw + S) per iteration f-D+1 .. f-1, then
+      // this iteration's DMA = D (rw + S); f < D (prologue): at least the D DMA groups.  A count beyond the counter's 63
+      // cannot be waited for -- and need not: with 64 younger operations issued the older one has retired (in order).
+      constexpr int Sn = 16, Sp = 22;
+      if (f < D) {
+        if (rw == 2) wait_vm<(2 * D < 63 ? 2 * D : 63)>();
+        else wait_vm<D>();
+      } else if (pyr_all) {
+        if (rw == 2) wait_vm<(D * (2 + Sp) < 63 ? D * (2 + Sp) : 63)>();
+        else wait_vm<(D * (1 + Sp) < 63 ? D * (1 + Sp) : 63)>();
+      } else {
+        if (rw == 2) wait_vm<(D * (2 + Sn) < 63 ? D * (2 + Sn) : 63)>();
+        else wait_vm<(D * (1 + Sn) < 63 ? D * (1 + Sn) : 63)>();
+      }
+    } else {  // single window: DMA(f) was issued after the previous frame's convert, followed by that frame's stores only
+      if (f == 0) wait_vm<0>();
+      else if (pyr_all) wait_vm<22>();
+      else wait_vm<16>();
+    }
+    // ---- convert: u8 window -> lut (* vignette) -> float window
+    lds_u8_ptr ubuf = s_u8 + (NBUF >= 2 ? ub : 0) * win;
+#if !MDC_EXP_STRIP_NOCONVERT
+    {
+      uint32_t word[P];
+#pragma unroll
+      for (int j = 0; j < P; j++) word[j] = *reinterpret_cast<const volatile __attribute__((address_space(3))) uint32_t*>(ubuf + (j * 64 + lane) * 4);
+#pragma unroll
+      for (int j = 0; j < P; j++) {
+        f32x4 r;
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = my_lut[(int)((word[j] >> (8 * k)) & 0xffu) * kStripLutRep];
+        if (VIG) r = r * vin[j];
+        if (cvalid[j]) *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(s_f32 + (j * 64 + lane) * 16) = r;
+      }
+    }
+#endif
+    // LDS operations of one wave execute in order: the sample phase's reads see the convert's writes.  (The compiler
+    // keeps the order too: same address space, may alias.)
+    if (NBUF == 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the u8 reads above have returned: the window may be overwritten
+      stage(f + 1, 0);
+    }
+    const auto ro = MDC_FRAME_RSRC(uniform_ptr(dst), out_bytes);
+    const long long fa = (long long)f0 + (long long)f * fstep;
+    const uint32_t f_base = (uint32_t)(uintptr_t)s_f32;  // LDS byte address of the wave's float window
+    float v2[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        float res[4];
+        // Two outputs at a time.  Their addresses and weights are REDONE every frame from the packed per-output constants
+        // (tap offsets 16 | 16 bits, fx, fy: 48 registers for 16 outputs) -- hoisted out of the frame loop they would be
+        // 32 addresses + 64 weights and the kernel would run at 3 waves per SIMD.  volatile asm is what keeps the
+        // optimiser from hoisting: v_add_u32_sdwa adds one 16-bit half of the packed offsets to the window base in ONE
+        // instruction (no unpack), v_mul / v_sub seed the weight expressions (IEEE single operations, the same the compiler
+        // would emit: same bits).
+#pragma unroll
+        for (int u0 = 0; u0 < 4; u0 += 2) {
+          float tv[2][4];
+          uint32_t a0[2], a1[2];
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            const int o = 8 * h + 4 * q + u0 + u;
+            asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a0[u]) : "v"(f_base), "v"(tap[o]));
+            asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a1[u]) : "v"(f_base), "v"(tap[o]));
+            MDC_CHECK(a0[u] - f_base + 8 <= (uint32_t)(4 * win + kStripPad) && a1[u] - f_base + 8 <= (uint32_t)(4 * win + kStripPad));
+          }
+#if MDC_EXP_STRIP_NOSAMPLE
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            res[u0 + u] = __uint_as_float(a0[u] ^ a1[u]);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[u0 + u]), ro, vo[h], (uint32_t)(4 * q + u0 + u) * row_bytes, kStoreAux);
+          }
+          continue;
+#endif
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            lds_f32_ptr t0 = reinterpret_cast<lds_f32_ptr>((lds_u8_ptr)0 + a0[u]);
+            lds_f32_ptr t1 = reinterpret_cast<lds_f32_ptr>((lds_u8_ptr)0 + a1[u]);
+            tv[u][0] = t0[0];
+            tv[u][1] = t0[1];
+            tv[u][2] = t1[0];
+            tv[u][3] = t1[1];
+          }
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            const int o = 8 * h + 4 * q + u0 + u;
+            Bilin bw;
+            float xxyy, omx;
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(xxyy) : "v"(fx[o]), "v"(fy[o]));  // xx*yy        src/FOVUndistorter.cpp:356
+            asm volatile("v_sub_f32 %0, 1.0, %1" : "=v"(omx) : "v"(fx[o]));              // 1 - xx        :365
+            bw.w11 = xxyy;
+            bw.w01 = fy[o] - xxyy;
+            bw.w10 = fx[o] - xxyy;
+            bw.w00 = (omx - fy[o]) + xxyy;
+            res[u0 + u] = bilin_sum(bw, tv[u][0], tv[u][1], tv[u][2], tv[u][3]);
+#if MDC_EXP_SKIP_STORE
+            if (res[u0 + u] != -1.2345e30f) continue;
+#endif
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[u0 + u]), ro, vo[h], (uint32_t)(4 * q + u0 + u) * row_bytes, kStoreAux);
+          }
+        }
+        if (PYR) {  // levels 1 and 2 of this column half / row quad, as pyramid_levels12
+          float v1[2];
+#pragma unroll
+          for (int pp = 0; pp < 2; pp++) {
+            const float b = dpp_quad<0xF5>(res[2 * pp]);
+            const float d = dpp_quad<0xF5>(res[2 * pp + 1]);
+            v1[pp] = box4(res[2 * pp], b, res[2 * pp + 1], d);
+          }
+          if (py.l1) {
+            const auto r1 = MDC_FRAME_RSRC(uniform_ptr(py.l1 + fa * (l1_bytes / 4)), l1_bytes);
+            const float left2 = dpp_quad<0xA0>(v1[1]);
+            const float mm = (lane & 1) ? left2 : v1[0];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mm), r1, p1o[h], (uint32_t)q * row_bytes, kStoreAux);  // 2 level-1 rows = row_bytes
+          }
+          const float b2 = dpp_quad<0xAA>(v1[0]);
+          const float d2 = dpp_quad<0xAA>(v1[1]);
+          v2[h][q] = box4(v1[0], b2, v1[1], d2);  // valid in lanes 4k
+        }
+      }
+    if (PYR) {
+      if (py.l2) {  // lane 4k + j stores (h, q) = (j >> 1, j & 1): one 64-lane store
+        const float a00 = dpp_quad<0x00>(v2[0][0]), a01 = dpp_quad<0x00>(v2[0][1]), a10 = dpp_quad<0x00>(v2[1][0]), a11 = dpp_quad<0x00>(v2[1][1]);
+        const int j = lane & 3;
+        const float mm = j == 0 ? a00 : j == 1 ? a01 : j == 2 ? a10 : a11;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mm), MDC_FRAME_RSRC(uniform_ptr(py.l2 + fa * (l2_bytes / 4)), l2_bytes), p2o, 0, kStoreAux);
+      }
+      if (py.l3) {  // level 3: lanes 8 i; the right neighbour's level-2 pixel sits 4 lanes up (same row of 16 lanes)
+        float v3[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) v3[h] = box4(v2[h][0], dpp_row<0x104>(v2[h][0]), v2[h][1], dpp_row<0x104>(v2[h][1]));
+        const float up = dpp_row<0x114>(v3[1]);  // lane 8 i + 4 takes h = 1 from lane 8 i
+        const float mm = (lane & 4) ? up : v3[0];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mm), MDC_FRAME_RSRC(uniform_ptr(py.l3 + fa * (l3_bytes / 4)), l3_bytes), p3o, 0, kStoreAux);
+      }
+    }
+    dst += out_step;
+    ub = ub + 1 == NBUF ? 0 : ub + 1;
+  }
+#endif
 }
 
 // ----------------------------------------------------------------------------
@@ -1044,6 +1424,50 @@ template <bool VIG, bool BLACK>
 static hipError_t launch_tiled_nt(const TiledLaunch& l) {
   const bool pyr = l.py.l1 || l.py.l2 || l.py.l3;
   return pyr ? launch_tiled_shape<VIG, BLACK, true, false>(l) : launch_tiled_shape<VIG, BLACK, false, false>(l);
+}
+
+// ---- strip kernel: VIG x PYR x NBUF {1..4} x P {2, 3, 4, 5, 8}
+size_t strip_lds_bytes(int win_bytes, int nbuf, int waves) { return (size_t)waves * ((4 + nbuf) * win_bytes + kStripPad) + kStripLutBytes; }
+template <bool VIG, bool PYR, int NBUF, int P>
+static hipError_t launch_strip_variant(const uint8_t* d_in, float* d_out, const RemapArgs& a, const StripPlan& p, const PyramidOut& py,
+                                       int64_t nframes, int fpb, hipStream_t s) {
+  constexpr int W = kStripWaves;
+  dim3 grid(p.n_blocks, ceil_div(nframes, fpb));
+  const size_t lds = strip_lds_bytes(p.win_bytes, NBUF, W);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&remap_strip_kernel<VIG, PYR, NBUF, P, W>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  remap_strip_kernel<VIG, PYR, NBUF, P, W><<<grid, 64 * W, lds, s>>>(d_in, d_out, a, p, py, (int)nframes, fpb, p.interleave ? 1 : 0);
+  return hipGetLastError();
+}
+template <bool VIG, bool PYR, int NBUF>
+static hipError_t launch_strip_passes(const uint8_t* d_in, float* d_out, const RemapArgs& a, const StripPlan& p, const PyramidOut& py,
+                                      int64_t nframes, int fpb, hipStream_t s) {
+  switch (p.passes) {
+    case 2: return launch_strip_variant<VIG, PYR, NBUF, 2>(d_in, d_out, a, p, py, nframes, fpb, s);
+    case 3: return launch_strip_variant<VIG, PYR, NBUF, 3>(d_in, d_out, a, p, py, nframes, fpb, s);
+    case 4: return launch_strip_variant<VIG, PYR, NBUF, 4>(d_in, d_out, a, p, py, nframes, fpb, s);
+    case 5: return launch_strip_variant<VIG, PYR, NBUF, 5>(d_in, d_out, a, p, py, nframes, fpb, s);
+    case 8: return launch_strip_variant<VIG, PYR, NBUF, 8>(d_in, d_out, a, p, py, nframes, fpb, s);
+  }
+  return hipErrorInvalidValue;
+}
+hipError_t launch_remap_strip_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const StripPlan& p, int64_t nframes, int fpb,
+                                 hipStream_t s, float* d_l1, float* d_l2, float* d_l3) {
+  if (nframes <= 0) return hipSuccess;
+  if ((int64_t)a.in_w * a.in_h >= (int64_t)kOutside || (int64_t)a.out_w * (a.out_h + 8) * 4 >= 0xc0000000ll) return hipErrorInvalidValue;
+  const PyramidOut py{d_l1, d_l2, d_l3};
+  const bool pyr = d_l1 || d_l2 || d_l3;
+#define MDC_STRIP(V_, P_)                                                                                        \
+  (p.nbuf == 1   ? launch_strip_passes<V_, P_, 1>(d_in, d_out, a, p, py, nframes, fpb, s)                          \
+   : p.nbuf == 2 ? launch_strip_passes<V_, P_, 2>(d_in, d_out, a, p, py, nframes, fpb, s)                          \
+   : p.nbuf == 3 ? launch_strip_passes<V_, P_, 3>(d_in, d_out, a, p, py, nframes, fpb, s)                          \
+                 : launch_strip_passes<V_, P_, 4>(d_in, d_out, a, p, py, nframes, fpb, s))
+  if (a.vinv) return pyr ? MDC_STRIP(true, true) : MDC_STRIP(true, false);
+  return pyr ? MDC_STRIP(false, true) : MDC_STRIP(false, false);
+#undef MDC_STRIP
 }
 
 hipError_t launch_remap_tiled_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const TilePlan& p,

@@ -58,6 +58,14 @@ CAMERAS = {
     "full_1280_to_1280": (("0.349153 0.436593 0.493140 0.499021 0.933271", "1280 1024", "0.4 0.53 0.5 0.5 0", "1280 1024"), 16),
     # magnifying remap (output larger than input)
     "upsample": (("0.349153 0.436593 0.493140 0.499021 0.5", "160 128", "crop", "320 256"), 16),
+    # two-stage kernel cases: a magnifying 'full' remap made of whole 128x16 / 64x32 tiles with a wide black border (0.45-0.49
+    # staged source pixels per output: the automatic choice), and a ~1:1 crop whose windows need 4 convert passes per wave
+    "mag_full_black": (("0.349153 0.436593 0.493140 0.499021 0.933271", "320 256", "full", "640 512"), 16),
+    "crop_384": (("0.349153 0.436593 0.493140 0.499021 0.933271", "320 256", "crop", "384 256"), 8),
+    # strip kernel cases (windows of a 128 x 8 output tile <= 128 chunks): 4x magnifying 'full' remaps with a third of
+    # the outputs black, whole 128 x 8 tiles (640 x 512) and a ragged last tile column (520 wide), two DMA rounds (67 / 80 chunks)
+    "mag4_full_black": (("0.349153 0.436593 0.493140 0.499021 0.933271", "160 128", "full", "640 512"), 16),
+    "mag4_ragged": (("0.349153 0.436593 0.493140 0.499021 0.933271", "160 128", "full", "520 384"), 8),
 }
 
 

@@ -2,7 +2,8 @@
 """N launches of the fused kernel (or the fused-pyramid one) on 1024 frames: the process diagnosis builds and profilers are
 pointed at (tools/phase_timing.sh; PC sampling and thread trace are not available on the pool's boxes: rocprofv3 reports no
 agent that supports PC sampling, and the ATT decoder library is not installed).
-usage: python tools/launch_target.py [fused|pyramid] [launches]"""
+usage: python tools/launch_target.py [fused|pyramid|base1280] [launches] [two-stage selector 0/1/2]
+(base1280 = the scale-1 rectification of the pyramid workload without the levels)"""
 import os
 import sys
 import tempfile
@@ -21,6 +22,8 @@ fov = capi.UndistorterFOV(os.path.join(d, "camera.txt"))
 photo = capi.PhotometricUndistorter(os.path.join(d, "pcalib.txt"), os.path.join(d, "vignette.png"), 1280, 1024)
 ctx = capi.Context(0)
 ctx.bind(fov, photo)
+if len(sys.argv) > 3:
+    ctx.set_option(capi.OPT_TWO_STAGE, int(sys.argv[3]))
 n = 1024
 npi = 1280 * 1024
 info = ctx.info()

@@ -43,7 +43,10 @@ p_base = torch.empty(PB * npi, dtype=torch.float32, device="cuda")
 p_lv = [torch.empty(PB * (1280 >> l) * (1024 >> l), dtype=torch.float32, device="cuda") for l in (1, 2, 3)]
 p_ref = [torch.empty_like(t) for t in p_lv]
 configs = [(64, 32, 2), (64, 32, 3), (128, 16, 2), (64, 60, 2), (128, 32, 2), (64, 64, 2), (128, 16, 4), (64, 16, 2), (128, 32, 3), (64, 16, 4)]
-pyr_configs = [(128, 16, 0), (64, 32, 2), (128, 32, 2), (64, 64, 3), (64, 16, 4), (128, 16, 2)]
+# (two-stage selector, tile cols, rows, window buffers): 1 = wave-private strips (the automatic choice for this scale-1 remap),
+# 2 = the direct kernel
+pyr_configs = [(1, 0, 0, 2), (2, 128, 16, 0), (1, 0, 0, 1), (2, 64, 32, 2), (1, 0, 0, 3), (2, 128, 32, 2), (1, 0, 0, 2), (2, 64, 64, 3),
+               (1, 0, 0, 4), (2, 64, 16, 4), (1, 0, 0, 1), (2, 128, 16, 2)]
 
 
 def same(a, b):
@@ -56,12 +59,14 @@ bad = 0
 for it in range(iters):
     ctx.synth_frames(d_in.data_ptr(), it * B, B, npi, synth.SEED + it, s)
     if it % 3 == 2:
-        cols, rows, nbuf = pyr_configs[(it // 3) % len(pyr_configs)]
+        sel, cols, rows, nbuf = pyr_configs[(it // 3) % len(pyr_configs)]
+        pyr.set_option(capi.OPT_TWO_STAGE, sel)
         pyr.set_option(capi.OPT_TILE_COLS, cols)
         pyr.set_option(capi.OPT_TILE_ROWS, rows)
         pyr.set_option(capi.OPT_WINDOW_BUFFERS, nbuf)
         pyr.set_option(capi.OPT_FRAMES_PER_BLOCK, (0, 5, 12)[it % 3])
-        assert ", true, false," in pyr.describe_launch(15, 4), "the fused-pyramid instantiation must be the one that runs"
+        kname = pyr.describe_launch(15, 4)
+        assert kname.startswith({1: "remap_strip_kernel<true, true", 2: "remap_tiled_kernel<true, false, true"}[sel]), kname
         for rep in range(3):
             for t in p_lv:
                 t.fill_(-7.0)
@@ -71,7 +76,7 @@ for it in range(iters):
             for l, (a, b) in enumerate(zip(p_lv, p_ref)):
                 if not same(a, b):
                     bad += 1
-                    print("PYRAMID MISMATCH iteration", it, "tile", cols, rows, "nbuf", nbuf, "level", l + 1, "rep", rep, flush=True)
+                    print("PYRAMID MISMATCH iteration", it, "kernel", kname, "tile", cols, rows, "nbuf", nbuf, "level", l + 1, "rep", rep, flush=True)
         continue
     ctx.set_option(capi.OPT_KERNEL, capi.KERNEL_GATHER)
     ctx.process_batch(d_in.data_ptr(), d_ref.data_ptr(), B, 15, s)
