@@ -268,8 +268,19 @@ def main():
                                                 os.path.join(calib_dir, "vignette.png"), IN_W, IN_H)
         assert fov.is_valid() and photo.valid() == 3
         blob = capi.pack_tables(fov, photo)  # host-side serialisation of GInv, vignetteInv, remapX/Y
+    bcast_ms = None
     if use_dist:
-        blob = shard.broadcast_tables(blob, src=0, device=coll_dev)  # the only collective: once, over RCCL
+        if backend == "nccl":
+            torch.cuda.synchronize()
+        t_b = time.perf_counter()
+        sent = None if blob is None else blob.copy()
+        blob = shard.broadcast_tables(blob, src=0, device=coll_dev, even_alone=True)  # the only collective: once, over RCCL
+        if backend == "nccl":
+            torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t_b) * 1e3
+        assert dist.get_world_size() == world, "process group has %d ranks, WORLD_SIZE says %d" % (dist.get_world_size(), world)
+        if sent is not None:
+            assert np.array_equal(sent, blob), "the broadcast changed the root's own blob"
     ctx.import_tables(blob)  # every rank (rank 0 included) uploads the same bytes
     ctx.set_option(capi.OPT_KERNEL, {"auto": capi.KERNEL_AUTO, "gather": capi.KERNEL_GATHER, "tiled": capi.KERNEL_TILED}[args.kernel])
     ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, args.fpb)
@@ -451,6 +462,7 @@ def main():
             roof["frac_of_same_box_mix_ceiling"] = round(ceiling["ms_median"] / kernel_med, 4)
         if world > 1 or use_dist:
             roof["per_rank_kernel_ms_mean_median_min"] = per_rank_kernel_ms
+            roof["per_rank_frac"] = [round(alg_frame * B / (k[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k in per_rank_kernel_ms]
         out = {
             "metric": "Mpix/s photometric+FOV undistort, 1280x1024 gray",
             "value": round(mpix, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -465,6 +477,8 @@ def main():
                        "preroll_s": args.preroll_s, "sharding": "round-robin frame f -> rank f %% %d" % world,
                        "tables": ("rank-0 build + one %s broadcast" % ("RCCL" if backend == "nccl" else backend)) if use_dist else "local build",
                        "collective_backend": backend if use_dist else None,
+                       "table_broadcast_ms": round(bcast_ms, 3) if bcast_ms is not None else None,
+                       "table_blob_bytes": int(blob.size),
                        "plan": tuned if tuned is not None else "built-in",
                        "frames_per_s": round(frames_total / elapsed, 1),
                        "out_mpix_per_s": round(frames_total * npix_out / 1e6 / elapsed, 1)},

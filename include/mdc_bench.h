@@ -1,0 +1,30 @@
+/*
+ * mdc_bench.h -- C interface of libmdc_bench.so: measurement and test utilities.
+ *
+ * NOT part of the product (nothing of the reference corresponds to these; libmdc_hip.so / libmdc_host.so /
+ * libmdc_multi.so neither link nor load this library).  Used by bench.py, tools/ and tests/ only.
+ * Both functions enqueue on `stream` (hipStream_t as void*, NULL = default stream) of HIP device `device`
+ * (-1 = the calling thread's current device) without synchronising; 0 = ok, negative = error.
+ */
+#ifndef MDC_BENCH_H
+#define MDC_BENCH_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Synthetic sequence generator: byte i of frame f = fmix32(seed + (first_frame+f)*npix + i) >> 24. */
+int mdcb_synth_frames_device(int device, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix, uint32_t seed, void* stream);
+
+/* A linear, arithmetic-free stream reading read_bytes from d_read (16-byte aligned) while writing write_bytes to d_write
+ * with `blocks` workgroups of 256 (span = 0: grid-stride; 1: each workgroup walks its own contiguous span) -- the rate the
+ * memory system of THIS box gives to a kernel's traffic mix, to normalise the kernel's own rate against; bench.py takes
+ * the fastest of several (blocks, span) settings. */
+int mdcb_ceiling_mix_device(int device, const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes, int blocks, int span,
+                            void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDC_BENCH_H */

@@ -17,8 +17,15 @@
  *   - *_device functions take device pointers valid on the context's GPU and
  *     enqueue on `stream` (a hipStream_t passed as void*; NULL = HIP's default
  *     stream, as everywhere in HIP) without synchronising;
- *   - a context is bound to one GPU; calls on one context are serialised by an
- *     internal mutex, different contexts are independent; no global state.
+ *   - a context is bound to one GPU and may be used from several host threads at
+ *     once (the reference's unMapImage / undistort are re-entrant on shared objects,
+ *     src/FOVUndistorter.cpp:322 is const): the per-frame entry points only read the
+ *     context's tables and run concurrently -- every host-pointer call on its own
+ *     internal stream and staging buffers (up to 8 in flight, further callers wait),
+ *     every *_device call on the caller's stream; the setters (tables, options,
+ *     mdc_tune_device) are exclusive and wait for the device.  mdc_last_error(ctx)
+ *     returns the calling thread's own last failure on that context.  Different
+ *     contexts are independent; no global state.
  */
 #ifndef MDC_HIP_H
 #define MDC_HIP_H
@@ -226,7 +233,10 @@ int mdc_distort_points_host(mdc_ctx* ctx, const mdc_fov_model* model, float* x, 
  * plane point outside that image, after distortCoordinates, :284): for every plane point the sums FF, FC over the
  * images (d_ff, d_fc: n_plane floats, overwritten) and the new colour FC / FF (NaN where FF < 1) in d_plane_color,
  * which is read first for the residual test against oth2 (the reference's int, :397-398).  d_er receives
- * {E, R} of the reference's printf (:449).  FF, FC and the colours are bit-identical to the reference. */
+ * {E, R} of the reference's printf (:449).  FF, FC and the colours are bit-identical to the reference.
+ * Samples whose 2x2 footprint would leave the image -- the reference relies on its caller's mask (:345-357,
+ * mdc_vcal_mask_coords_device) and would read out of bounds -- are skipped, in this step, in the atomic vignette step
+ * and in the contribution index alike: all three always see the same sample set. */
 int mdc_vcal_plane_step_device(mdc_ctx* ctx, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
                                int n_plane, float* d_plane_color, const float* d_vignette_factor, int oth2, float* d_ff,
                                float* d_fc, double* d_er, void* stream);
@@ -295,11 +305,6 @@ int mdc_vcal_mask_coords_device(mdc_ctx* ctx, float* d_x, float* d_y, int64_t n,
 int mdc_vcal_smooth_device(mdc_ctx* ctx, const float* d_vignette_factor, int w, int h, float* d_smoothed, float* d_scratch,
                            void* stream);
 
-/* Synthetic sequence generator (bench/test utility):
- * byte i of frame f = fmix32(seed + (first_frame+f)*npix + i) >> 24. */
-int mdc_synth_frames_device(mdc_ctx* ctx, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix,
-                            uint32_t seed, void* stream);
-
 /* Plan selection by measurement.  Which tile shape and workgroup length is fastest depends on the remap (window sizes)
  * and, by a few per cent, on the individual GPU (profiles/r02_experiments/04_*, 13_*).  mdc_tune_device runs the fused
  * pass (flags must contain MDC_RECTIFY) over the caller's device batch with each candidate -- tile 128x16 / 64x32 /
@@ -317,18 +322,12 @@ typedef struct mdc_tune_result {
 int mdc_tune_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, void* stream,
                     mdc_tune_result* result);
 
-/* Measurement utilities (bench.py; nothing of the reference corresponds to them).
- * mdc_describe_launch: the kernel instantiation mdc_process_batch_device (pyramid_levels <= 1) or
- * mdc_process_pyramid_batch_device (pyramid_levels = its `levels`) launches for `flags` with the current tables
- * and options, spelt as rocprofv3 prints it without namespaces -- so a recorded PMC figure can be matched to
- * the kernel that actually ran.
- * mdc_ceiling_mix_device: a linear, arithmetic-free stream reading read_bytes from d_read (16-byte aligned)
- * while writing write_bytes to d_write with `blocks` workgroups of 256 (span = 0: grid-stride; 1: each workgroup
- * walks its own contiguous span) -- the rate the memory system of THIS box gives to a kernel's traffic mix, to
- * normalise the kernel's own rate against; bench.py takes the fastest of several (blocks, span) settings. */
+/* Diagnostics: the kernel instantiation mdc_process_batch_device (pyramid_levels <= 1) or
+ * mdc_process_pyramid_batch_device (pyramid_levels = its `levels`) launches for `flags` with the current tables and
+ * options, spelt as rocprofv3 prints it without namespaces -- so a profile line can be matched to the kernel that ran.
+ * (Measurement utilities -- the synthetic sequence generator, the linear-stream yardstick -- live in libmdc_bench.so,
+ * include/mdc_bench.h: they are not part of this ABI.) */
 int mdc_describe_launch(mdc_ctx* ctx, unsigned flags, int pyramid_levels, char* buf, size_t cap);
-int mdc_ceiling_mix_device(mdc_ctx* ctx, const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes,
-                           int blocks, int span, void* stream);
 
 /* ---- calibration hand-over between ranks (multi-GPU) ------------------------ */
 
@@ -339,7 +338,7 @@ int mdc_ceiling_mix_device(mdc_ctx* ctx, const void* d_read, int64_t read_bytes,
 int mdc_export_tables(mdc_ctx* ctx, void* blob, size_t cap, size_t* size);
 int mdc_import_tables(mdc_ctx* ctx, const void* blob, size_t size);
 
-/* Blocks until the context's own stream (used by the *_host calls) is idle. */
+/* Blocks until the context's own streams (used by the *_host calls) are idle. */
 int mdc_synchronize(mdc_ctx* ctx);
 
 #ifdef __cplusplus

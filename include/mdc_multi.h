@@ -46,9 +46,10 @@ int mdc_multi_process_sequence_device(mdc_multi* m, const uint8_t* const* d_in, 
                                       int64_t nframes_total, unsigned flags);
 int mdc_multi_synchronize(mdc_multi* m);
 
-/* Bench / test utility: the synthetic sequence of SURVEY.md 8(d), sharded -- local frame i of rank r is
- * global frame r + i*N (byte j = fmix32(seed + frame*npix + j) >> 24). */
-int mdc_multi_synth_sequence_device(mdc_multi* m, uint8_t* const* d_in, int64_t nframes_total, int npix, uint32_t seed);
+/* Ranks of rank's RCCL communicator (ncclCommCount): == mdc_multi_size() for a healthy object; -1 on error. */
+int mdc_multi_comm_count(const mdc_multi* m, int rank);
+/* The stream (hipStream_t as void*) rank's launches go on -- for callers that enqueue their own work in order with them. */
+void* mdc_multi_stream(mdc_multi* m, int rank);
 
 #ifdef __cplusplus
 }

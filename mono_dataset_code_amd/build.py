@@ -86,6 +86,17 @@ def build_host(force=False):
     return LIB_HOST
 
 
+LIB_BENCH = os.path.join(PKG, "libmdc_bench.so")
+BENCH_SOURCE = os.path.join(CSRC, "bench", "mdc_bench.hip")
+
+
+def build_bench(force=False):
+    """libmdc_bench.so: measurement / test utilities (include/mdc_bench.h) -- not part of the product, not linked by it."""
+    if force or _stale(LIB_BENCH, [BENCH_SOURCE, os.path.join(INC, "mdc_bench.h")]):
+        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + INC, BENCH_SOURCE, "-o", LIB_BENCH])
+    return LIB_BENCH
+
+
 LIB_MULTI = os.path.join(PKG, "libmdc_multi.so")
 MULTI_SOURCE = os.path.join(CSRC, "mdc_multi.hip")
 
@@ -132,6 +143,7 @@ def build_all(force=False):
     build_hip(force)
     build_host(force)
     build_multi(force)
+    build_bench(force)
     build_debug()
     return LIB_HIP, LIB_HOST, LIB_MULTI
 

@@ -28,9 +28,9 @@ HIP_SYMBOLS = [
     "mdc_set_remap", "mdc_unmap_host", "mdc_undistort_host_f32", "mdc_undistort_host_u8", "mdc_process_host",
     "mdc_host_alloc", "mdc_host_free", "mdc_process_frames_host",
     "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
-    "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device", "mdc_synth_frames_device",
+    "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device",
     "mdc_distort_points_device", "mdc_distort_points_host", "mdc_export_tables", "mdc_import_tables",
-    "mdc_synchronize", "mdc_describe_launch", "mdc_ceiling_mix_device", "mdc_vcal_plane_step_device",
+    "mdc_synchronize", "mdc_describe_launch", "mdc_vcal_plane_step_device",
     "mdc_vcal_vignette_step_device", "mdc_gradients_batch_device", "mdc_tune_device",
     "mdc_vcal_index_create", "mdc_vcal_index_destroy", "mdc_vcal_index_bytes", "mdc_vcal_index_entries",
     "mdc_vcal_vignette_step_indexed_device", "mdc_vcal_solve_device", "mdc_vcal_smooth_device", "mdc_vcal_mask_coords_device", "mdc_vcal_gradient_mask_device", "mdc_vcal_scale_images_device",
@@ -88,6 +88,25 @@ def _share_hip_runtime_with_torch():
         pass
 
 
+LIB_BENCH_PATH = os.path.join(_PKG, "libmdc_bench.so")
+BENCH_SYMBOLS = ["mdcb_synth_frames_device", "mdcb_ceiling_mix_device"]  # include/mdc_bench.h (not the product ABI)
+_bench = None
+
+
+def bench_lib():
+    """libmdc_bench.so: the synthetic sequence generator and the linear-stream yardstick (bench.py, tools/, tests/)."""
+    global _bench
+    if _bench is None:
+        _share_hip_runtime_with_torch()
+        if not os.path.exists(LIB_BENCH_PATH):
+            raise OSError("%s not built: run `python -m mono_dataset_code_amd.build`" % LIB_BENCH_PATH)
+        L = C.CDLL(LIB_BENCH_PATH)
+        L.mdcb_synth_frames_device.argtypes = [_i, _vp, _i64, _i64, _i, _u32, _vp]
+        L.mdcb_ceiling_mix_device.argtypes = [_i, _vp, C.c_int64, _vp, C.c_int64, _i, _i, _vp]
+        _bench = L
+    return _bench
+
+
 def hip_lib():
     global _hip
     if _hip is None:
@@ -118,7 +137,6 @@ def hip_lib():
         L.mdc_undistort_batch_device_f32.argtypes = [_vp, _vp, _vp, _i64, _vp]
         L.mdc_pyramid_batch_device.argtypes = [_vp, _vp, _i, _i, _i, C.POINTER(_vp), _i64, _vp]
         L.mdc_process_pyramid_batch_device.argtypes = [_vp, _vp, _vp, _i, C.POINTER(_vp), _i64, C.c_uint, _vp]
-        L.mdc_synth_frames_device.argtypes = [_vp, _vp, _i64, _i64, _i, _u32, _vp]
         L.mdc_distort_points_device.argtypes = [_vp, C.POINTER(FovModel), _vp, _vp, _i64, _vp]
         L.mdc_distort_points_host.argtypes = [_vp, C.POINTER(FovModel), _vp, _vp, _i64]
         L.mdc_export_tables.argtypes = [_vp, _vp, _sz, C.POINTER(_sz)]
@@ -127,7 +145,6 @@ def hip_lib():
         old_build = LIB_HIP_PATH != os.path.join(_PKG, "libmdc_hip.so")  # tools/sweep.py --libs: A/B against earlier builds
         if not old_build or hasattr(L, "mdc_describe_launch"):
             L.mdc_describe_launch.argtypes = [_vp, C.c_uint, _i, C.c_char_p, _sz]
-            L.mdc_ceiling_mix_device.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int64, _i, _i, _vp]
             L.mdc_vcal_plane_step_device.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]
             L.mdc_tune_device.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_uint, _vp, C.POINTER(TuneResult)]
             L.mdc_gradients_batch_device.argtypes = [_vp, _vp, _i, _i, _vp, _vp, C.c_int64, _vp]
@@ -299,6 +316,9 @@ class Context:
         self._chk(self._L.mdc_get_info(self._h, C.byref(i)))
         return i
 
+    def device(self):
+        return self.info().device
+
     def set_option(self, opt, value):
         self._chk(self._L.mdc_set_option(self._h, opt, value))
 
@@ -374,7 +394,10 @@ class Context:
         self._chk(self._L.mdc_distort_points_device(self._h, C.byref(model), d_x, d_y, n, stream if stream else None))
 
     def synth_frames(self, d_out, first_frame, nframes, npix, seed, stream=0):
-        self._chk(self._L.mdc_synth_frames_device(self._h, d_out, first_frame, nframes, npix, seed, stream if stream else None))
+        """(bench / test utility, libmdc_bench.so -- not part of the product ABI)"""
+        rc = bench_lib().mdcb_synth_frames_device(self.device(), d_out, first_frame, nframes, npix, seed, stream if stream else None)
+        if rc != 0:
+            raise MdcError(rc, "mdcb_synth_frames_device failed")
 
     def export_tables(self):
         n = _sz(0)
@@ -396,7 +419,10 @@ class Context:
         return buf.value.decode()
 
     def ceiling_mix(self, d_read, read_bytes, d_write, write_bytes, blocks=16384, span=0, stream=0):
-        self._chk(self._L.mdc_ceiling_mix_device(self._h, d_read, read_bytes, d_write, write_bytes, blocks, span, stream if stream else None))
+        """(bench utility, libmdc_bench.so -- not part of the product ABI)"""
+        rc = bench_lib().mdcb_ceiling_mix_device(self.device(), d_read, read_bytes, d_write, write_bytes, blocks, span, stream if stream else None)
+        if rc != 0:
+            raise MdcError(rc, "mdcb_ceiling_mix_device failed")
 
     def tune(self, d_in, d_out, nframes, flags, stream=0):
         r = TuneResult()

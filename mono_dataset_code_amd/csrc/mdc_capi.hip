@@ -16,7 +16,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -24,9 +27,31 @@ using namespace mdc;
 
 struct mdc_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
-  std::mutex mu;
+  // Locking.  `mu` guards the calibration tables, the plans and the options: the entry points that only READ them -- every
+  // per-frame call, host- or device-pointer -- take it shared and run concurrently; the setters (tables, options, tuning)
+  // take it exclusively (and then wait for the whole device, kernels on caller streams may still read the tables).
+  // What the readers do mutate has its own small lock: the last-error string, the list of page-locked caller buffers, the
+  // slots of the host-pointer calls, the pipeline of mdc_process_frames_host.
+  std::shared_timed_mutex mu;
+  mutable std::mutex err_mu;
   std::string err;
+  std::mutex pin_mu, pipe_mu;
+
+  // Host-pointer calls (mdc_unmap_host, mdc_undistort_host_*, mdc_process_host, mdc_distort_points_host): each call leases a
+  // slot -- its own stream and staging buffers -- so that calls from several host threads overlap their copies and
+  // kernels instead of queueing on one stream.  Slots are created on demand, at most kMaxSlots; a caller beyond that waits.
+  struct HostSlot {
+    hipStream_t stream = nullptr;
+    void* d_in = nullptr;
+    size_t in_cap = 0;
+    float* d_out = nullptr;
+    size_t out_cap = 0;
+    bool busy = false;
+  };
+  static constexpr int kMaxSlots = 8;
+  std::mutex slot_mu;
+  std::condition_variable slot_cv;
+  std::vector<HostSlot*> slots;
 
   // photometric tables
   int in_w = 0, in_h = 0;
@@ -102,18 +127,23 @@ struct mdc_ctx {
   float* d_pipe_out[2] = {nullptr, nullptr};
   size_t pipe_in_cap = 0, pipe_out_cap = 0;
 
-  unsigned* d_vcal_max = nullptr;  // vignetteCalib: bit pattern of the largest new vignette factor
+  // vignetteCalib: bit pattern of the largest new vignette factor of ONE vignette step.  A ring of words, one per call:
+  // steps that different threads put on different streams of one context never share a word.
+  static constexpr int kVcalMaxWords = 256;
+  unsigned* d_vcal_max = nullptr;
+  std::atomic<unsigned> vcal_max_next{0};
 
-  // staging for the host-pointer calls
-  void* d_stage_in = nullptr;
-  size_t stage_in_cap = 0;
-  float* d_stage_out = nullptr;
-  size_t stage_out_cap = 0;
 };
+using ReadLock = std::shared_lock<std::shared_timed_mutex>;
+using WriteLock = std::unique_lock<std::shared_timed_mutex>;
 
 namespace {
 
 thread_local std::string g_create_err;
+// mdc_last_error(ctx) returns the calling thread's own last failure on that context if it had one (several threads may
+// use one context), else the context's most recent one
+thread_local std::string t_err, t_err_other;
+thread_local const mdc_ctx* t_err_ctx = nullptr;
 
 int fail(mdc_ctx* c, int code, const char* fmt, ...) {
   char buf[512];
@@ -121,8 +151,16 @@ int fail(mdc_ctx* c, int code, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  if (c) c->err = buf;
-  else g_create_err = buf;
+  if (c) {
+    {
+      std::lock_guard<std::mutex> lk(c->err_mu);
+      c->err = buf;
+    }
+    t_err = buf;
+    t_err_ctx = c;
+  } else {
+    g_create_err = buf;
+  }
   return code;
 }
 
@@ -538,6 +576,7 @@ int plan_tiles(mdc_ctx* c) {
 // role 0: image_out of unMapImage, role 1: input of undistort<float>
 void maybe_pin(mdc_ctx* c, int role, const void* p, size_t bytes) {
   if (!c->opt_pin_caller || bytes < (256u << 10)) return;
+  std::lock_guard<std::mutex> plk(c->pin_mu);
   for (auto& e : c->pinned)
     if (e.p == p && e.bytes == bytes) {
       e.used = ++c->pin_clock;
@@ -570,26 +609,68 @@ void maybe_pin(mdc_ctx* c, int role, const void* p, size_t bytes) {
   c->pinned.push_back(e);
 }
 void unpin_all(mdc_ctx* c) {
+  std::lock_guard<std::mutex> plk(c->pin_mu);
   for (auto& e : c->pinned)
     if (e.ok) (void)hipHostUnregister(const_cast<void*>(e.p));
   c->pinned.clear();
   c->pin_candidate[0] = c->pin_candidate[1] = nullptr;
 }
 
-int ensure_stage(mdc_ctx* c, size_t in_bytes, size_t out_bytes) {
-  if (in_bytes > c->stage_in_cap) {
-    if (c->d_stage_in) (void)hipFree(c->d_stage_in);
-    c->d_stage_in = nullptr;
-    c->stage_in_cap = 0;
-    MDC_HIP(c, hipMalloc(&c->d_stage_in, in_bytes));
-    c->stage_in_cap = in_bytes;
+// A slot of the host-pointer calls for the duration of one call (RAII).  s == nullptr: no slot could be made (error set).
+struct SlotLease {
+  mdc_ctx* c;
+  mdc_ctx::HostSlot* s = nullptr;
+  explicit SlotLease(mdc_ctx* ctx) : c(ctx) {
+    std::unique_lock<std::mutex> lk(c->slot_mu);
+    for (;;) {
+      for (mdc_ctx::HostSlot* h : c->slots)
+        if (!h->busy) {
+          h->busy = true;
+          s = h;
+          return;
+        }
+      if ((int)c->slots.size() < mdc_ctx::kMaxSlots) {
+        mdc_ctx::HostSlot* h = new mdc_ctx::HostSlot();
+        const hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+          delete h;
+          fail(c, MDC_ERR_HIP, "hipStreamCreateWithFlags: %s", hipGetErrorString(e));
+          return;
+        }
+        h->busy = true;
+        c->slots.push_back(h);
+        s = h;
+        return;
+      }
+      c->slot_cv.wait(lk);
+    }
   }
-  if (out_bytes > c->stage_out_cap) {
-    if (c->d_stage_out) (void)hipFree(c->d_stage_out);
-    c->d_stage_out = nullptr;
-    c->stage_out_cap = 0;
-    MDC_HIP(c, hipMalloc(&c->d_stage_out, out_bytes));
-    c->stage_out_cap = out_bytes;
+  ~SlotLease() {
+    if (!s) return;
+    {
+      std::lock_guard<std::mutex> lk(c->slot_mu);
+      s->busy = false;
+    }
+    c->slot_cv.notify_one();
+  }
+  SlotLease(const SlotLease&) = delete;
+  SlotLease& operator=(const SlotLease&) = delete;
+};
+
+int ensure_stage(mdc_ctx* c, mdc_ctx::HostSlot* h, size_t in_bytes, size_t out_bytes) {
+  if (in_bytes > h->in_cap) {
+    if (h->d_in) (void)hipFree(h->d_in);
+    h->d_in = nullptr;
+    h->in_cap = 0;
+    MDC_HIP(c, hipMalloc(&h->d_in, in_bytes));
+    h->in_cap = in_bytes;
+  }
+  if (out_bytes > h->out_cap) {
+    if (h->d_out) (void)hipFree(h->d_out);
+    h->d_out = nullptr;
+    h->out_cap = 0;
+    MDC_HIP(c, hipMalloc(&h->d_out, out_bytes));
+    h->out_cap = out_bytes;
   }
   return MDC_OK;
 }
@@ -674,7 +755,7 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
     if (!c->opt_fpb && c->tuned_fpb > 0 && nframes >= c->tuned_min_frames) fpb = (int)std::min<int64_t>(c->tuned_fpb, nframes);
     // the fused pyramid adds level-2 hand-over rows to the workgroup's LDS: without room for them the
     // per-level passes run instead
-    const bool fuse_pyr = pyr && p.tile_h % 8 == 0 && c->out_w % p.tile_w == 0 && c->out_h % p.tile_h == 0 &&
+    const bool fuse_pyr = pyr && p.tile_w * p.tile_h <= 2048 && p.tile_h % 8 == 0 && c->out_w % p.tile_w == 0 && c->out_h % p.tile_h == 0 &&
                           tiled_lds_bytes(p.win_bytes, p.nbuf, true) + tiled_pyramid_lds_bytes(p.tile_w, p.tile_h) <= kLdsPerCU;
     MDC_HIP(c, launch_remap_tiled_u8(d_in, d_out, a, p, nframes, fpb, s, fuse_pyr ? pyr[0] : nullptr,
                                      fuse_pyr ? pyr[1] : nullptr, fuse_pyr ? pyr[2] : nullptr));
@@ -713,18 +794,15 @@ int mdc_create(int device, mdc_ctx** out) {
   mdc_ctx* c = new mdc_ctx();
   c->device = device;
   DeviceGuard dg(device);
-  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) {
-    fail(nullptr, MDC_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
-    delete c;
-    return MDC_ERR_HIP;
-  }
   c->h_ginv.assign(256, 0.f);
   if (const char* e = getenv("MDC_PIN_CALLER_BUFFERS")) c->opt_pin_caller = atoi(e) != 0;
   int rc = upload_luts(c);
+  if (rc == MDC_OK && hipMalloc(&c->d_vcal_max, mdc_ctx::kVcalMaxWords * sizeof(unsigned)) != hipSuccess)
+    rc = fail(c, MDC_ERR_HIP, "hipMalloc of the context's scratch words failed");
   if (rc != MDC_OK) {
-    g_create_err = c->err;
-    (void)hipStreamDestroy(c->stream);
+    g_create_err = t_err;
+    if (c->d_luts) (void)hipFree(c->d_luts);
+    t_err_ctx = nullptr;
     delete c;
     return rc;
   }
@@ -736,27 +814,41 @@ void mdc_destroy(mdc_ctx* c) {
   if (!c) return;
   {
     DeviceGuard dg(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (mdc_ctx::HostSlot* h : c->slots) {
+      if (h->stream) (void)hipStreamSynchronize(h->stream);
+      if (h->d_in) (void)hipFree(h->d_in);
+      if (h->d_out) (void)hipFree(h->d_out);
+      if (h->stream) (void)hipStreamDestroy(h->stream);
+      delete h;
+    }
+    c->slots.clear();
+    for (int k = 0; k < 2; k++)
+      if (c->pipe_stream[k]) (void)hipStreamSynchronize(c->pipe_stream[k]);
     unpin_all(c);
     free_plan(c);
-    void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_stage_in, c->d_stage_out, c->d_vcal_max,
-                    c->d_pipe_in[0], c->d_pipe_in[1], c->d_pipe_out[0], c->d_pipe_out[1]};
+    void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_vcal_max, c->d_pipe_in[0], c->d_pipe_in[1], c->d_pipe_out[0], c->d_pipe_out[1]};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     for (int k = 0; k < 2; k++) {
       if (c->pipe_done[k]) (void)hipEventDestroy(c->pipe_done[k]);
       if (c->pipe_stream[k]) (void)hipStreamDestroy(c->pipe_stream[k]);
     }
-    if (c->stream) (void)hipStreamDestroy(c->stream);
   }
+  if (t_err_ctx == c) t_err_ctx = nullptr;
   delete c;
 }
 
-const char* mdc_last_error(const mdc_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+const char* mdc_last_error(const mdc_ctx* c) {
+  if (!c) return g_create_err.c_str();
+  if (t_err_ctx == c) return t_err.c_str();
+  std::lock_guard<std::mutex> lk(c->err_mu);
+  t_err_other = c->err;
+  return t_err_other.c_str();
+}
 
 int mdc_set_option(mdc_ctx* c, int option, int value) {
   if (!c) return MDC_ERR_ARG;
-  std::lock_guard<std::mutex> lk(c->mu);
+  WriteLock lk(c->mu);
   switch (option) {
     case MDC_OPT_KERNEL:
       if (value < MDC_KERNEL_AUTO || value > MDC_KERNEL_TILED) return fail(c, MDC_ERR_ARG, "bad kernel selector %d", value);
@@ -833,7 +925,7 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
 
 int mdc_get_info(mdc_ctx* c, mdc_info* i) {
   if (!c || !i) return MDC_ERR_ARG;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   memset(i, 0, sizeof *i);
   i->device = c->device;
   i->in_w = c->in_w ? c->in_w : c->rm_in_w;
@@ -872,7 +964,7 @@ int mdc_get_info(mdc_ctx* c, mdc_info* i) {
 int mdc_set_photometric(mdc_ctx* c, const float* ginv, const float* vignette_inv, int w, int h) {
   if (!c) return MDC_ERR_ARG;
   if (w <= 0 || h <= 0) return fail(c, MDC_ERR_ARG, "bad frame size %dx%d", w, h);
-  std::lock_guard<std::mutex> lk(c->mu);
+  WriteLock lk(c->mu);
   return set_photometric_locked(c, ginv, vignette_inv, w, h);
 }
 
@@ -904,7 +996,7 @@ static int set_photometric_locked(mdc_ctx* c, const float* ginv, const float* vi
 
 int mdc_set_remap(mdc_ctx* c, const float* rx, const float* ry, int in_w, int in_h, int out_w, int out_h) {
   if (!c) return MDC_ERR_ARG;
-  std::lock_guard<std::mutex> lk(c->mu);
+  WriteLock lk(c->mu);
   return set_remap_locked(c, rx, ry, in_w, in_h, out_w, out_h);
 }
 
@@ -952,7 +1044,7 @@ static int set_remap_locked(mdc_ctx* c, const float* rx, const float* ry, int in
 int mdc_unmap_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, void* stream) {
   if (!c) return MDC_ERR_ARG;
   if (!d_in || !d_out || nframes < 0) return fail(c, MDC_ERR_ARG, "mdc_unmap_batch_device: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   return enqueue_process(c, d_in, d_out, nframes, flags & ~MDC_RECTIFY, (hipStream_t)stream);
 }
@@ -960,7 +1052,7 @@ int mdc_unmap_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_
 int mdc_process_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, void* stream) {
   if (!c) return MDC_ERR_ARG;
   if (!d_in || !d_out || nframes < 0) return fail(c, MDC_ERR_ARG, "mdc_process_batch_device: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   return enqueue_process(c, d_in, d_out, nframes, flags, (hipStream_t)stream);
 }
@@ -968,7 +1060,7 @@ int mdc_process_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int6
 int mdc_undistort_batch_device_f32(mdc_ctx* c, const float* d_in, float* d_out, int64_t nframes, void* stream) {
   if (!c) return MDC_ERR_ARG;
   if (!d_in || !d_out || nframes < 0) return fail(c, MDC_ERR_ARG, "mdc_undistort_batch_device_f32: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   if (!c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
   return enqueue_undistort_f32(c, d_in, d_out, nframes, (hipStream_t)stream);
@@ -979,7 +1071,7 @@ int mdc_pyramid_batch_device(mdc_ctx* c, const float* d_base, int w, int h, int 
   if (!c) return MDC_ERR_ARG;
   if (!d_base || w <= 0 || h <= 0 || levels < 1 || nframes < 0 || (levels > 1 && !d_levels))
     return fail(c, MDC_ERR_ARG, "mdc_pyramid_batch_device: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   hipStream_t s = (hipStream_t)stream;
   const float* src = d_base;
@@ -998,7 +1090,7 @@ int mdc_process_pyramid_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_b
     return fail(c, MDC_ERR_ARG, "mdc_process_pyramid_batch_device: bad argument");
   for (int l = 1; l < levels; l++)
     if (!d_levels[l - 1]) return fail(c, MDC_ERR_ARG, "level %d buffer is NULL", l);
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   hipStream_t s = (hipStream_t)stream;
   const bool rect = (flags & MDC_RECTIFY) != 0;
@@ -1039,7 +1131,7 @@ static DistortModel distort_model(const mdc_fov_model* f) {
 int mdc_distort_points_device(mdc_ctx* c, const mdc_fov_model* model, float* d_x, float* d_y, int64_t n, void* stream) {
   if (!c) return MDC_ERR_ARG;
   if (!model || n < 0 || (n > 0 && (!d_x || !d_y))) return fail(c, MDC_ERR_ARG, "mdc_distort_points_device: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   MDC_HIP(c, launch_distort_points(d_x, d_y, n, distort_model(model), (hipStream_t)stream));
   return MDC_OK;
@@ -1049,19 +1141,22 @@ int mdc_distort_points_host(mdc_ctx* c, const mdc_fov_model* model, float* x, fl
   if (!c) return MDC_ERR_ARG;
   if (!model || n < 0 || (n > 0 && (!x || !y))) return fail(c, MDC_ERR_ARG, "mdc_distort_points_host: bad argument");
   if (n == 0) return MDC_OK;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   const size_t bytes = (size_t)n * sizeof(float);
-  int rc = ensure_stage(c, bytes, bytes);
+  SlotLease slot(c);
+  if (!slot.s) return MDC_ERR_HIP;
+  int rc = ensure_stage(c, slot.s, bytes, bytes);
   if (rc != MDC_OK) return rc;
-  float* dx = (float*)c->d_stage_in;
-  float* dy = c->d_stage_out;
-  MDC_HIP(c, hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, c->stream));
-  MDC_HIP(c, hipMemcpyAsync(dy, y, bytes, hipMemcpyHostToDevice, c->stream));
-  MDC_HIP(c, launch_distort_points(dx, dy, n, distort_model(model), c->stream));
-  MDC_HIP(c, hipMemcpyAsync(x, dx, bytes, hipMemcpyDeviceToHost, c->stream));
-  MDC_HIP(c, hipMemcpyAsync(y, dy, bytes, hipMemcpyDeviceToHost, c->stream));
-  MDC_HIP(c, hipStreamSynchronize(c->stream));
+  hipStream_t st = slot.s->stream;
+  float* dx = (float*)slot.s->d_in;
+  float* dy = slot.s->d_out;
+  MDC_HIP(c, hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, st));
+  MDC_HIP(c, hipMemcpyAsync(dy, y, bytes, hipMemcpyHostToDevice, st));
+  MDC_HIP(c, launch_distort_points(dx, dy, n, distort_model(model), st));
+  MDC_HIP(c, hipMemcpyAsync(x, dx, bytes, hipMemcpyDeviceToHost, st));
+  MDC_HIP(c, hipMemcpyAsync(y, dy, bytes, hipMemcpyDeviceToHost, st));
+  MDC_HIP(c, hipStreamSynchronize(st));
   return MDC_OK;
 }
 
@@ -1070,7 +1165,7 @@ int mdc_gradients_batch_device(mdc_ctx* c, const float* d_level, int w, int h, f
   if (!c) return MDC_ERR_ARG;
   if (!d_level || !d_dI || !d_abs_squared_grad || w < 1 || h < 1 || nframes < 0 || (int64_t)w * h >= (1ll << 31))
     return fail(c, MDC_ERR_ARG, "mdc_gradients_batch_device: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   MDC_HIP(c, launch_gradients(d_level, d_dI, d_abs_squared_grad, w, h, nframes, (hipStream_t)stream));
   return MDC_OK;
@@ -1083,7 +1178,7 @@ int mdc_vcal_plane_step_device(mdc_ctx* c, const float* d_images, const float* d
   if (!d_images || !d_p2x || !d_p2y || !d_plane_color || !d_vignette_factor || !d_ff || !d_fc || !d_er || n_images < 0 || w < 2 ||
       h < 2 || n_plane < 0)
     return fail(c, MDC_ERR_ARG, "mdc_vcal_plane_step_device: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   MDC_HIP(c, launch_vcal_plane_step(d_images, d_p2x, d_p2y, n_images, w, h, n_plane, d_plane_color, d_vignette_factor, oth2, d_ff,
                                     d_fc, d_er, (hipStream_t)stream));
@@ -1097,11 +1192,10 @@ int mdc_vcal_vignette_step_device(mdc_ctx* c, const float* d_images, const float
   if (!d_images || !d_p2x || !d_p2y || !d_plane_color || !d_vignette_factor || !d_tt || !d_ct || !d_er || n_images < 0 || w < 2 ||
       h < 2 || n_plane < 0)
     return fail(c, MDC_ERR_ARG, "mdc_vcal_vignette_step_device: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
-  if (!c->d_vcal_max) MDC_HIP(c, hipMalloc(&c->d_vcal_max, sizeof(unsigned)));
   MDC_HIP(c, launch_vcal_vignette_step(d_images, d_p2x, d_p2y, n_images, w, h, n_plane, d_plane_color, d_vignette_factor, oth2,
-                                       d_tt, d_ct, d_er, c->d_vcal_max, (hipStream_t)stream));
+                                       d_tt, d_ct, d_er, c->d_vcal_max + (c->vcal_max_next++ % mdc_ctx::kVcalMaxWords), (hipStream_t)stream));
   return MDC_OK;
 }
 
@@ -1118,7 +1212,7 @@ int mdc_vcal_index_create(mdc_ctx* c, const float* d_images, const float* d_p2x,
   if (!d_images || !d_p2x || !d_p2y || n_images < 0 || n_images > 65535 || w < 2 || h < 2 || n_plane < 0 || n_plane >= (1 << 30) ||
       (long long)w * h >= (1ll << 31))
     return fail(c, MDC_ERR_ARG, "mdc_vcal_index_create: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   mdc::VcalIndex* ix = nullptr;
   MDC_HIP(c, mdc::vcal_index_build(d_images, d_p2x, d_p2y, n_images, w, h, n_plane, (hipStream_t)stream, &ix));
@@ -1142,11 +1236,10 @@ int mdc_vcal_vignette_step_indexed_device(mdc_ctx* c, const mdc_vcal_index* inde
   if (!index || !d_plane_color || !d_vignette_factor || !d_tt || !d_ct || !d_er)
     return fail(c, MDC_ERR_ARG, "mdc_vcal_vignette_step_indexed_device: bad argument");
   if (index->device != c->device) return fail(c, MDC_ERR_ARG, "mdc_vcal_vignette_step_indexed_device: index built on another device");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
-  if (!c->d_vcal_max) MDC_HIP(c, hipMalloc(&c->d_vcal_max, sizeof(unsigned)));
   MDC_HIP(c, mdc::launch_vcal_vignette_step_indexed(index->ix, d_plane_color, d_vignette_factor, oth2, d_tt, d_ct, d_er,
-                                                    c->d_vcal_max, (hipStream_t)stream));
+                                                    c->d_vcal_max + (c->vcal_max_next++ % mdc_ctx::kVcalMaxWords), (hipStream_t)stream));
   return MDC_OK;
 }
 
@@ -1155,7 +1248,7 @@ int mdc_vcal_scale_images_device(mdc_ctx* c, float* d_images, int n_images, int6
   if (!c) return MDC_ERR_ARG;
   if (n_images < 0 || n_images > 65535 || npix < 0 || (n_images > 0 && npix > 0 && (!d_images || !d_exposure_times)))
     return fail(c, MDC_ERR_ARG, "mdc_vcal_scale_images_device: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   MDC_HIP(c, launch_vcal_scale_images(d_images, n_images, npix, mean_exposure, d_exposure_times, (hipStream_t)stream));
   return MDC_OK;
@@ -1165,7 +1258,7 @@ int mdc_vcal_gradient_mask_device(mdc_ctx* c, float* d_images, int n_images, int
   if (!c) return MDC_ERR_ARG;
   if (n_images < 0 || (n_images > 0 && !d_images) || w < 1 || h < 1 || (long long)w * h >= (1ll << 31) || max_abs_grad < 0)
     return fail(c, MDC_ERR_ARG, "mdc_vcal_gradient_mask_device: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   MDC_HIP(c, launch_vcal_gradient_mask(d_images, n_images, w, h, max_abs_grad, (hipStream_t)stream));
   return MDC_OK;
@@ -1174,7 +1267,7 @@ int mdc_vcal_gradient_mask_device(mdc_ctx* c, float* d_images, int n_images, int
 int mdc_vcal_mask_coords_device(mdc_ctx* c, float* d_x, float* d_y, int64_t n, int w, int h, void* stream) {
   if (!c) return MDC_ERR_ARG;
   if (n < 0 || (n > 0 && (!d_x || !d_y)) || w < 1 || h < 1) return fail(c, MDC_ERR_ARG, "mdc_vcal_mask_coords_device: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   MDC_HIP(c, launch_vcal_mask_coords(d_x, d_y, n, w, h, (hipStream_t)stream));
   return MDC_OK;
@@ -1186,7 +1279,7 @@ int mdc_vcal_smooth_device(mdc_ctx* c, const float* d_vignette_factor, int w, in
   if (!d_vignette_factor || !d_smoothed || !d_scratch || w < 1 || h < 1 || (long long)w * h >= (1ll << 31) ||
       d_smoothed == d_scratch || d_vignette_factor == d_scratch)
     return fail(c, MDC_ERR_ARG, "mdc_vcal_smooth_device: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   MDC_HIP(c, launch_vcal_smooth(d_vignette_factor, w, h, d_smoothed, d_scratch, (hipStream_t)stream));
   return MDC_OK;
@@ -1202,7 +1295,7 @@ int mdc_vcal_solve_device(mdc_ctx* c, const float* d_images, const float* d_p2x,
   mdc_vcal_index* index = nullptr;
   int rc = mdc_vcal_index_create(c, d_images, d_p2x, d_p2y, n_images, w, h, n_plane, stream, &index);
   if (rc != MDC_OK) return rc;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   hipStream_t s = (hipStream_t)stream;
   float *d_ff = nullptr, *d_fc = nullptr, *d_tt = nullptr, *d_ct = nullptr;
@@ -1225,27 +1318,16 @@ int mdc_vcal_solve_device(mdc_ctx* c, const float* d_images, const float* d_p2x,
   MDC_SOLVE(hipMalloc(&d_tt, img_bytes));
   MDC_SOLVE(hipMalloc(&d_ct, img_bytes));
   MDC_SOLVE(hipMalloc(&d_er, er_bytes));
-  if (!c->d_vcal_max) MDC_SOLVE(hipMalloc(&c->d_vcal_max, sizeof(unsigned)));
   for (int it = 0; it < max_iterations; it++) {
     const int oth2 = it < max_iterations / 2 ? 10000 * 10000 : outlier_th * outlier_th;  // :397-398
     MDC_SOLVE(launch_vcal_plane_step(d_images, d_p2x, d_p2y, n_images, w, h, n_plane, d_plane_color, d_vignette_factor, oth2, d_ff,
                                      d_fc, d_er + 4 * it, s));
     MDC_SOLVE(mdc::launch_vcal_vignette_step_indexed(index->ix, d_plane_color, d_vignette_factor, oth2, d_tt, d_ct, d_er + 4 * it + 2,
-                                                     c->d_vcal_max, s));
+                                                     c->d_vcal_max + (c->vcal_max_next++ % mdc_ctx::kVcalMaxWords), s));
   }
   if (er_out) MDC_SOLVE(hipMemcpyAsync(er_out, d_er, er_bytes, hipMemcpyDeviceToHost, s));
 #undef MDC_SOLVE
   return done(MDC_OK);
-}
-
-int mdc_synth_frames_device(mdc_ctx* c, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix, uint32_t seed,
-                            void* stream) {
-  if (!c) return MDC_ERR_ARG;
-  if (!d_out || nframes < 0 || npix <= 0) return fail(c, MDC_ERR_ARG, "mdc_synth_frames_device: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
-  DeviceGuard dg(c->device);
-  MDC_HIP(c, launch_synth(d_out, first_frame, nframes, npix, seed, (hipStream_t)stream));
-  return MDC_OK;
 }
 
 // Plan selection by measurement (as FFT / BLAS libraries do): which tile shape and workgroup length is fastest depends on
@@ -1255,7 +1337,7 @@ int mdc_tune_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
                     mdc_tune_result* result) {
   if (!c) return MDC_ERR_ARG;
   if (!d_in || !d_out || nframes <= 0) return fail(c, MDC_ERR_ARG, "mdc_tune_device: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  WriteLock lk(c->mu);
   DeviceGuard dg(c->device);
   if (!(flags & MDC_RECTIFY) || !c->valid_remap) return fail(c, MDC_ERR_STATE, "mdc_tune_device: needs a remap and MDC_RECTIFY");
   hipStream_t s = (hipStream_t)stream;
@@ -1323,7 +1405,7 @@ int mdc_tune_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
 
 int mdc_describe_launch(mdc_ctx* c, unsigned flags, int pyramid_levels, char* buf, size_t cap) {
   if (!c || !buf || cap == 0) return MDC_ERR_ARG;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   bool g, v, o;
   normalise(c, flags, g, v, o);
   char tmp[160];
@@ -1338,7 +1420,7 @@ int mdc_describe_launch(mdc_ctx* c, unsigned flags, int pyramid_levels, char* bu
              c->strip.passes, kStripWaves);
   } else if (c->plan[0].tiled && c->opt_kernel != MDC_KERNEL_GATHER) {
     const mdc_ctx::SrcPlan& p = c->plan[0];
-    const bool pyr = pyramid_levels > 1 && p.tile_h % 8 == 0 && c->out_w % p.tile_w == 0 && c->out_h % p.tile_h == 0 &&
+    const bool pyr = pyramid_levels > 1 && p.tile_w * p.tile_h <= 2048 && p.tile_h % 8 == 0 && c->out_w % p.tile_w == 0 && c->out_h % p.tile_h == 0 &&
                      tiled_lds_bytes(p.win_bytes, p.nbuf, true) + tiled_pyramid_lds_bytes(p.tile_w, p.tile_h) <= kLdsPerCU;
     snprintf(tmp, sizeof tmp, "remap_tiled_kernel<%s, %s, %s, false, %d, %d, %d>", v ? "true" : "false",
              c->n_black > 0 ? "true" : "false", pyr ? "true" : "false", p.tile_w, p.tile_w * p.tile_h / 4, p.nbuf);
@@ -1350,23 +1432,18 @@ int mdc_describe_launch(mdc_ctx* c, unsigned flags, int pyramid_levels, char* bu
   return MDC_OK;
 }
 
-int mdc_ceiling_mix_device(mdc_ctx* c, const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes,
-                           int blocks, int span, void* stream) {
-  if (!c) return MDC_ERR_ARG;
-  if (read_bytes < 0 || write_bytes < 0 || (read_bytes > 0 && !d_read) || (write_bytes > 0 && !d_write) || blocks <= 0 ||
-      (reinterpret_cast<uintptr_t>(d_read) & 15) != 0)
-    return fail(c, MDC_ERR_ARG, "mdc_ceiling_mix_device: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
-  DeviceGuard dg(c->device);
-  MDC_HIP(c, launch_mix_ceiling(d_read, read_bytes, d_write, write_bytes, blocks, span, (hipStream_t)stream));
-  return MDC_OK;
-}
-
 int mdc_synchronize(mdc_ctx* c) {
   if (!c) return MDC_ERR_ARG;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
-  MDC_HIP(c, hipStreamSynchronize(c->stream));
+  std::vector<hipStream_t> streams;
+  {
+    std::lock_guard<std::mutex> sl(c->slot_mu);
+    for (mdc_ctx::HostSlot* h : c->slots) streams.push_back(h->stream);
+  }
+  for (int k = 0; k < 2; k++)
+    if (c->pipe_stream[k]) streams.push_back(c->pipe_stream[k]);
+  for (hipStream_t st : streams) MDC_HIP(c, hipStreamSynchronize(st));
   return MDC_OK;
 }
 
@@ -1375,7 +1452,7 @@ int mdc_synchronize(mdc_ctx* c) {
 int mdc_unmap_host(mdc_ctx* c, const uint8_t* in, float* out, int n, unsigned flags) {
   if (!c) return MDC_ERR_ARG;
   if (!in || !out || n < 0) return fail(c, MDC_ERR_ARG, "mdc_unmap_host: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   if (n == 0) return MDC_OK;
   bool g, v, o;
@@ -1384,21 +1461,23 @@ int mdc_unmap_host(mdc_ctx* c, const uint8_t* in, float* out, int n, unsigned fl
   // vignetteMapInv[i] for i < n; with the vignette on we refuse a mismatching n.
   if (v && (int64_t)n != (int64_t)c->in_w * c->in_h)
     return fail(c, MDC_ERR_SIZE, "unMapImage: n = %d but the vignette holds %d pixels", n, c->in_w * c->in_h);
-  int rc = ensure_stage(c, (size_t)n, (size_t)n * sizeof(float));
+  SlotLease slot(c);
+  if (!slot.s) return MDC_ERR_HIP;
+  int rc = ensure_stage(c, slot.s, (size_t)n, (size_t)n * sizeof(float));
   if (rc != MDC_OK) return rc;
+  hipStream_t st = slot.s->stream;
   maybe_pin(c, 0, out, (size_t)n * sizeof(float));
-  MDC_HIP(c, hipMemcpyAsync(c->d_stage_in, in, (size_t)n, hipMemcpyHostToDevice, c->stream));
-  MDC_HIP(c, launch_unmap((const uint8_t*)c->d_stage_in, c->d_stage_out, lut_for(c, g, o), v ? c->d_vinv : nullptr, n, 1,
-                          1, c->stream));
-  MDC_HIP(c, hipMemcpyAsync(out, c->d_stage_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  MDC_HIP(c, hipStreamSynchronize(c->stream));
+  MDC_HIP(c, hipMemcpyAsync(slot.s->d_in, in, (size_t)n, hipMemcpyHostToDevice, st));
+  MDC_HIP(c, launch_unmap((const uint8_t*)slot.s->d_in, slot.s->d_out, lut_for(c, g, o), v ? c->d_vinv : nullptr, n, 1, 1, st));
+  MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+  MDC_HIP(c, hipStreamSynchronize(st));
   return MDC_OK;
 }
 
 static int undistort_host(mdc_ctx* c, const void* in, bool is_f32, float* out, int n_in, int n_out) {
   if (!c) return MDC_ERR_ARG;
   if (!in || !out) return fail(c, MDC_ERR_ARG, "undistort: NULL buffer");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   if (!c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
   if (n_in != c->rm_in_w * c->rm_in_h)
@@ -1408,19 +1487,21 @@ static int undistort_host(mdc_ctx* c, const void* in, bool is_f32, float* out, i
     return fail(c, MDC_ERR_SIZE, "undistort called with wrong output image dimensions (expected %d pixel, got %d pixel)",
                 c->out_w * c->out_h, n_out);
   const size_t in_bytes = (size_t)n_in * (is_f32 ? 4 : 1);
-  int rc = ensure_stage(c, in_bytes, (size_t)n_out * sizeof(float));
+  SlotLease slot(c);
+  if (!slot.s) return MDC_ERR_HIP;
+  int rc = ensure_stage(c, slot.s, in_bytes, (size_t)n_out * sizeof(float));
   if (rc != MDC_OK) return rc;
+  hipStream_t st = slot.s->stream;
   if (is_f32) maybe_pin(c, 1, in, in_bytes);
-  MDC_HIP(c, hipMemcpyAsync(c->d_stage_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
-  if (is_f32) {
-    rc = enqueue_undistort_f32(c, (const float*)c->d_stage_in, c->d_stage_out, 1, c->stream);
-    if (rc != MDC_OK) return rc;
-  } else {
-    rc = enqueue_process(c, (const uint8_t*)c->d_stage_in, c->d_stage_out, 1, MDC_RECTIFY, c->stream);
-    if (rc != MDC_OK) return rc;
+  MDC_HIP(c, hipMemcpyAsync(slot.s->d_in, in, in_bytes, hipMemcpyHostToDevice, st));
+  if (is_f32) rc = enqueue_undistort_f32(c, (const float*)slot.s->d_in, slot.s->d_out, 1, st);
+  else rc = enqueue_process(c, (const uint8_t*)slot.s->d_in, slot.s->d_out, 1, MDC_RECTIFY, st);
+  if (rc != MDC_OK) {
+    (void)hipStreamSynchronize(st);  // the upload borrows the caller's buffer: not in flight after the call
+    return rc;
   }
-  MDC_HIP(c, hipMemcpyAsync(out, c->d_stage_out, (size_t)n_out * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  MDC_HIP(c, hipStreamSynchronize(c->stream));
+  MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, (size_t)n_out * sizeof(float), hipMemcpyDeviceToHost, st));
+  MDC_HIP(c, hipStreamSynchronize(st));
   return MDC_OK;
 }
 
@@ -1434,7 +1515,7 @@ int mdc_undistort_host_u8(mdc_ctx* c, const uint8_t* in, float* out, int n_in, i
 int mdc_process_host(mdc_ctx* c, const uint8_t* raw, float* out, unsigned flags) {
   if (!c) return MDC_ERR_ARG;
   if (!raw || !out) return fail(c, MDC_ERR_ARG, "mdc_process_host: NULL buffer");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   const bool rect = (flags & MDC_RECTIFY) != 0;
   if (rect && !c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
@@ -1442,13 +1523,19 @@ int mdc_process_host(mdc_ctx* c, const uint8_t* raw, float* out, unsigned flags)
   if (iw <= 0 || ih <= 0) return fail(c, MDC_ERR_STATE, "frame size unknown");
   const size_t n_in = (size_t)iw * ih;
   const size_t n_out = rect ? (size_t)c->out_w * c->out_h : n_in;
-  int rc = ensure_stage(c, n_in, n_out * sizeof(float));
+  SlotLease slot(c);
+  if (!slot.s) return MDC_ERR_HIP;
+  int rc = ensure_stage(c, slot.s, n_in, n_out * sizeof(float));
   if (rc != MDC_OK) return rc;
-  MDC_HIP(c, hipMemcpyAsync(c->d_stage_in, raw, n_in, hipMemcpyHostToDevice, c->stream));
-  rc = enqueue_process(c, (const uint8_t*)c->d_stage_in, c->d_stage_out, 1, flags, c->stream);
-  if (rc != MDC_OK) return rc;
-  MDC_HIP(c, hipMemcpyAsync(out, c->d_stage_out, n_out * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  MDC_HIP(c, hipStreamSynchronize(c->stream));
+  hipStream_t st = slot.s->stream;
+  MDC_HIP(c, hipMemcpyAsync(slot.s->d_in, raw, n_in, hipMemcpyHostToDevice, st));
+  rc = enqueue_process(c, (const uint8_t*)slot.s->d_in, slot.s->d_out, 1, flags, st);
+  if (rc != MDC_OK) {
+    (void)hipStreamSynchronize(st);
+    return rc;
+  }
+  MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, st));
+  MDC_HIP(c, hipStreamSynchronize(st));
   return MDC_OK;
 }
 
@@ -1466,7 +1553,8 @@ void mdc_host_free(void* p) {
 int mdc_process_frames_host(mdc_ctx* c, const uint8_t* const* raw, float* const* out, int64_t nframes, unsigned flags) {
   if (!c) return MDC_ERR_ARG;
   if (nframes < 0 || (nframes > 0 && (!raw || !out))) return fail(c, MDC_ERR_ARG, "mdc_process_frames_host: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
+  std::lock_guard<std::mutex> pipe_lk(c->pipe_mu);  // one pipelined call at a time per context (it overlaps internally)
   DeviceGuard dg(c->device);
   const bool rect = (flags & MDC_RECTIFY) != 0;
   if (rect && !c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
@@ -1538,7 +1626,7 @@ int mdc_process_frames_host(mdc_ctx* c, const uint8_t* const* raw, float* const*
 
 int mdc_export_tables(mdc_ctx* c, void* blob, size_t cap, size_t* size) {
   if (!c || !size) return MDC_ERR_ARG;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ReadLock lk(c->mu);
   const size_t nv = c->valid_vignette ? c->h_vinv.size() : 0;
   const size_t nr = c->valid_remap ? c->h_rx.size() : 0;
   const size_t need = sizeof(BlobHeader) + 256 * 4 + nv * 4 + 2 * nr * 4;
@@ -1580,7 +1668,7 @@ int mdc_import_tables(mdc_ctx* c, const void* blob, size_t size) {
   const float* rx = (const float*)p;
   const float* ry = rx + nr;
   // one critical section: no other thread may see the new photometric tables next to the old remap
-  std::lock_guard<std::mutex> lk(c->mu);
+  WriteLock lk(c->mu);
   int rc = MDC_OK;
   if (h.in_w > 0 && h.in_h > 0) {
     rc = set_photometric_locked(c, h.valid_gamma ? ginv : nullptr, h.valid_vignette ? vinv : nullptr, h.in_w, h.in_h);

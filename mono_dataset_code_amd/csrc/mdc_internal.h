@@ -113,10 +113,6 @@ struct DistortModel {
 // (x, y) rectified pixel -> raw pixel, in place (UndistorterFOV::distortCoordinates).
 hipError_t launch_distort_points(float* d_x, float* d_y, int64_t n, const DistortModel& m, hipStream_t s);
 
-// Bench utility: linear read of read_bytes interleaved with a linear write of write_bytes (no arithmetic).
-hipError_t launch_mix_ceiling(const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes, int blocks,
-                              int span, hipStream_t s);
-
 // vignetteCalib solver half-iterations (src/main_vignetteCalib.cpp:400-448, :455-527); d_er = {E, R}
 hipError_t launch_vcal_plane_step(const float* d_images, const float* d_p2x, const float* d_p2y, int n, int wI, int hI, int np,
                                   float* d_plane_color, const float* d_vig, int oth2, float* d_ff, float* d_fc, double* d_er,
@@ -147,7 +143,5 @@ hipError_t launch_vcal_smooth(const float* d_vig, int wI, int hI, float* d_tt, f
 
 // DSO hand-off of one pyramid level: (I, dx, dy) triples + absSquaredGrad (see mdc_vcal.hip)
 hipError_t launch_gradients(const float* d_level, float* d_dI, float* d_abs2, int w, int h, int64_t nframes, hipStream_t s);
-
-hipError_t launch_synth(uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix, uint32_t seed, hipStream_t s);
 
 }  // namespace mdc

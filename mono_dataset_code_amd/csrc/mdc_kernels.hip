@@ -882,7 +882,7 @@ __device__ __forceinline__ float dpp_row(float v) {  // row_shl:n = 0x100 + n, r
 // P = convert passes (64 dwords = 256 source pixels each), NBUF = u8 windows (1: the next frame's DMA is issued right
 // after the convert, into the window just consumed; 2: one frame ahead), W = waves (tiles) per workgroup
 template <bool VIG, bool PYR, int NBUF, int P, int W>
-__global__ __launch_bounds__(64 * W, (PYR ? MDC_EXP_STRIP_WAVES_PER_EU - 1 : MDC_EXP_STRIP_WAVES_PER_EU)) void remap_strip_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, RemapArgs a,
+__global__ __launch_bounds__(64 * W, ((PYR || P > 5 || NBUF > 2) ? MDC_EXP_STRIP_WAVES_PER_EU - 1 : MDC_EXP_STRIP_WAVES_PER_EU)) void remap_strip_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, RemapArgs a,
                                                             StripPlan p, PyramidOut py, int nframes, int fpb, int interleave) {
 #if __HIP_DEVICE_COMPILE__
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -1266,66 +1266,6 @@ __global__ __launch_bounds__(256) void distort_points_kernel(float* __restrict__
   ys[i] = iy;
 }
 
-__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
-  h ^= h >> 16;
-  h *= 0x85ebca6bu;
-  h ^= h >> 13;
-  h *= 0xc2b2ae35u;
-  h ^= h >> 16;
-  return h;
-}
-__global__ __launch_bounds__(256) void synth_kernel(uint8_t* __restrict__ out, long long first_pix, long long n,
-                                                    uint32_t seed) {
-  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= n) return;
-  uint32_t word = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const uint32_t b = fmix32(seed + (uint32_t)(first_pix + i + k)) >> 24;
-    word |= b << (8 * k);
-  }
-  if (i + 3 < n && ((reinterpret_cast<uintptr_t>(out + i) & 3) == 0)) *reinterpret_cast<uint32_t*>(out + i) = word;
-  else
-    for (int k = 0; k < 4 && i + k < n; k++) out[i + k] = (uint8_t)(word >> (8 * k));
-}
-
-// Bench utility (no arithmetic of the path): a LINEAR stream that reads n_r 16-byte chunks and writes n_w
-// dwords, interleaved at that ratio -- the memory system's rate for the traffic MIX of a kernel without
-// its access pattern.  bench.py runs it with the algorithmic byte counts of the benchmarked launch, in
-// the same process on the same box, and reports the kernel's rate as a fraction of it.
-// Stores are wave-contiguous dwords with the nontemporal hint (the fastest store form measured on this
-// memory system, tools/hbm_mix.hip), loads wave-contiguous 16-byte.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// SPAN = false: grid-stride (thread t touches element t, t+T, ...); SPAN = true: every workgroup walks its own
-// contiguous span of the write range (and of the read range), as a tiled kernel's workgroups do.
-template <bool SPAN>
-__global__ __launch_bounds__(256) void mix_ceiling_kernel(const u32x4* __restrict__ a, float* __restrict__ b,
-                                                          unsigned long long n_r, unsigned long long n_w) {
-  const unsigned long long G = gridDim.x, T = G * 256;
-  const unsigned long long iters = SPAN ? (n_w + T - 1) / T : (n_w + T - 1) / T;
-  // SPAN: block g owns writes [g*iters*256, (g+1)*iters*256) and reads [g*riters*256, ...)
-  const unsigned long long riters = (n_r + T - 1) / T;
-  const unsigned long long w0 = SPAN ? (unsigned long long)blockIdx.x * iters * 256 + threadIdx.x : (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-  const unsigned long long r0 = SPAN ? (unsigned long long)blockIdx.x * riters * 256 + threadIdx.x : (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-  const unsigned long long step = SPAN ? 256 : T;
-  unsigned long long racc = 0, rk = r0, rdone = 0;
-  uint32_t x = 0;
-  for (unsigned long long it = 0; it < iters; it++) {
-    racc += n_r;  // one chunk is read every n_w / n_r stores, the same iteration for every thread
-    if (racc >= n_w) {
-      racc -= n_w;
-      if (rk < n_r && rdone < riters) {
-        const u32x4 v = __builtin_nontemporal_load(a + rk);  // streamed once: the faster load form (tools/hbm_mix.hip)
-        x ^= v.x ^ v.y ^ v.z ^ v.w;
-      }
-      rk += step;
-      rdone++;
-    }
-    const unsigned long long i = w0 + it * step;
-    if (i < n_w) __builtin_nontemporal_store(__uint_as_float(x & 0x3fffffffu), b + i);
-  }
-}
-
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace
@@ -1413,9 +1353,15 @@ static hipError_t launch_tiled_shape(const TiledLaunch& l) {
     case 64060:  // 15 row groups: no level-3 pairs
       if constexpr (!PYR) return launch_tiled_buf<VIG, BLACK, false, F32, 64, 960>(l);
       break;
-    case 64064: return launch_tiled_buf<VIG, BLACK, PYR, F32, 64, 1024>(l);
+    // (the 1024-thread tiles have no fused-pyramid instantiation: at their 64-VGPR budget it spilled 12 bytes; the host
+    // runs the per-level passes for them)
+    case 64064:
+      if constexpr (!PYR) return launch_tiled_buf<VIG, BLACK, false, F32, 64, 1024>(l);
+      break;
     case 128016: return launch_tiled_buf<VIG, BLACK, PYR, F32, 128, 512>(l);
-    case 128032: return launch_tiled_buf<VIG, BLACK, PYR, F32, 128, 1024>(l);
+    case 128032:
+      if constexpr (!PYR) return launch_tiled_buf<VIG, BLACK, false, F32, 128, 1024>(l);
+      break;
   }
   return hipErrorInvalidValue;
 }
@@ -1500,23 +1446,6 @@ hipError_t launch_pyramid_level(const float* d_src, float* d_dst, int w, int h, 
 hipError_t launch_distort_points(float* d_x, float* d_y, int64_t n, const DistortModel& m, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   distort_points_kernel<<<ceil_div(n, 256), 256, 0, s>>>(d_x, d_y, n, m);
-  return hipGetLastError();
-}
-
-hipError_t launch_mix_ceiling(const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes, int blocks,
-                              int span, hipStream_t s) {
-  if (write_bytes <= 0) return hipSuccess;
-  const unsigned long long n_r = (unsigned long long)(read_bytes / 16), n_w = (unsigned long long)(write_bytes / 4);
-  if (span) mix_ceiling_kernel<true><<<blocks, 256, 0, s>>>(reinterpret_cast<const u32x4*>(d_read), d_write, n_r, n_w);
-  else mix_ceiling_kernel<false><<<blocks, 256, 0, s>>>(reinterpret_cast<const u32x4*>(d_read), d_write, n_r, n_w);
-  return hipGetLastError();
-}
-
-hipError_t launch_synth(uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix, uint32_t seed,
-                        hipStream_t s) {
-  const long long n = (long long)nframes * npix;
-  if (n <= 0) return hipSuccess;
-  synth_kernel<<<ceil_div(n, 1024), 256, 0, s>>>(d_out, first_frame * (long long)npix, n, seed);
   return hipGetLastError();
 }
 

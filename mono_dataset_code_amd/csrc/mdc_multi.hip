@@ -6,18 +6,34 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
+
+// One PERSISTENT host thread per device (created with the object, parked on a condition variable between calls): it has
+// the device current once and for all and launches that device's work, so a call costs a wake-up, not a thread spawn.
+struct Worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<int()> job;  // set = work pending
+  bool has_job = false, done = false, stop = false;
+  int rc = 0;
+};
 
 struct mdc_multi {
   std::vector<int> dev;
   std::vector<mdc_ctx*> ctx;
   std::vector<ncclComm_t> comm;
   std::vector<hipStream_t> stream;
+  std::vector<Worker*> worker;
+  std::mutex call_mu;  // one multi-device call at a time
   std::string err;
 };
 
@@ -36,21 +52,43 @@ int fail(mdc_multi* m, int code, const char* fmt, ...) {
   return code;
 }
 
-// runs fn(rank) on one host thread per device; the first non-zero status wins
+void worker_main(Worker* w, int device) {
+  (void)hipSetDevice(device);
+  std::unique_lock<std::mutex> lk(w->mu);
+  for (;;) {
+    w->cv.wait(lk, [&] { return w->stop || w->has_job; });
+    if (w->stop) return;
+    std::function<int()> job = std::move(w->job);
+    lk.unlock();
+    const int rc = job();
+    lk.lock();
+    w->rc = rc;
+    w->has_job = false;
+    w->done = true;
+    w->cv.notify_all();
+  }
+}
+
+// runs fn(rank) on every device's worker thread, concurrently; the first non-zero status wins
 template <typename F>
 int per_device(mdc_multi* m, F fn) {
   const int n = (int)m->dev.size();
-  std::vector<int> rc((size_t)n, MDC_OK);
-  if (n == 1) {
-    rc[0] = fn(0);
-  } else {
-    std::vector<std::thread> th;
-    for (int r = 0; r < n; r++) th.emplace_back([&, r] { rc[(size_t)r] = fn(r); });
-    for (auto& t : th) t.join();
+  for (int r = 0; r < n; r++) {
+    Worker* w = m->worker[(size_t)r];
+    std::lock_guard<std::mutex> lk(w->mu);
+    w->job = [fn, r]() { return fn(r); };
+    w->has_job = true;
+    w->done = false;
+    w->cv.notify_all();
   }
-  for (int r = 0; r < n; r++)
-    if (rc[(size_t)r] != MDC_OK) return rc[(size_t)r];
-  return MDC_OK;
+  int rc = MDC_OK;
+  for (int r = 0; r < n; r++) {
+    Worker* w = m->worker[(size_t)r];
+    std::unique_lock<std::mutex> lk(w->mu);
+    w->cv.wait(lk, [&] { return w->done; });
+    if (rc == MDC_OK && w->rc != MDC_OK) rc = w->rc;
+  }
+  return rc;
 }
 
 }  // namespace
@@ -91,6 +129,9 @@ int mdc_multi_create(const int* devices, int ndev, mdc_multi** out) {
       return MDC_ERR_HIP;
     }
     m->stream.push_back(s);
+    Worker* w = new Worker();
+    w->th = std::thread(worker_main, w, m->dev[(size_t)r]);
+    m->worker.push_back(w);
   }
   // one communicator per device, all in this process (xGMI between the devices of a node)
   m->comm.assign((size_t)ndev, nullptr);
@@ -107,6 +148,15 @@ int mdc_multi_create(const int* devices, int ndev, mdc_multi** out) {
 
 void mdc_multi_destroy(mdc_multi* m) {
   if (!m) return;
+  for (Worker* w : m->worker) {
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->stop = true;
+      w->cv.notify_all();
+    }
+    w->th.join();
+    delete w;
+  }
   for (size_t r = 0; r < m->comm.size(); r++)
     if (m->comm[r]) (void)ncclCommDestroy(m->comm[r]);
   for (size_t r = 0; r < m->stream.size(); r++) {
@@ -119,12 +169,19 @@ void mdc_multi_destroy(mdc_multi* m) {
 }
 
 int mdc_multi_size(const mdc_multi* m) { return m ? (int)m->dev.size() : 0; }
+int mdc_multi_comm_count(const mdc_multi* m, int rank) {
+  if (!m || rank < 0 || rank >= (int)m->comm.size()) return -1;
+  int n = -1;
+  return ncclCommCount(m->comm[(size_t)rank], &n) == ncclSuccess ? n : -1;
+}
+void* mdc_multi_stream(mdc_multi* m, int rank) { return (m && rank >= 0 && rank < (int)m->stream.size()) ? (void*)m->stream[(size_t)rank] : nullptr; }
 mdc_ctx* mdc_multi_ctx(mdc_multi* m, int rank) { return (m && rank >= 0 && rank < (int)m->ctx.size()) ? m->ctx[(size_t)rank] : nullptr; }
 int mdc_multi_device(const mdc_multi* m, int rank) { return (m && rank >= 0 && rank < (int)m->dev.size()) ? m->dev[(size_t)rank] : -1; }
 const char* mdc_multi_last_error(const mdc_multi* m) { return m ? m->err.c_str() : g_err.c_str(); }
 
 int mdc_multi_bcast_tables(mdc_multi* m, int root) {
   if (!m) return MDC_ERR_ARG;
+  std::lock_guard<std::mutex> call(m->call_mu);
   const int n = (int)m->dev.size();
   if (root < 0 || root >= n) return fail(m, MDC_ERR_ARG, "root %d out of range [0,%d)", root, n);
   size_t bytes = 0;
@@ -187,6 +244,7 @@ int64_t mdc_multi_frames_of_rank(const mdc_multi* m, int64_t total, int rank) {
 int mdc_multi_process_sequence_device(mdc_multi* m, const uint8_t* const* d_in, float* const* d_out, int64_t total,
                                       unsigned flags) {
   if (!m || !d_in || !d_out || total < 0) return fail(m, MDC_ERR_ARG, "mdc_multi_process_sequence_device: bad argument");
+  std::lock_guard<std::mutex> call(m->call_mu);
   const int rc = per_device(m, [&](int r) {
     const int64_t mine = mdc_multi_frames_of_rank(m, total, r);
     if (mine == 0) return (int)MDC_OK;
@@ -204,23 +262,6 @@ int mdc_multi_synchronize(mdc_multi* m) {
     (void)hipSetDevice(m->dev[r]);
     if (hipStreamSynchronize(m->stream[r]) != hipSuccess) return fail(m, MDC_ERR_HIP, "stream of rank %zu failed", r);
   }
-  return MDC_OK;
-}
-
-int mdc_multi_synth_sequence_device(mdc_multi* m, uint8_t* const* d_in, int64_t total, int npix, uint32_t seed) {
-  if (!m || !d_in || total < 0 || npix <= 0) return fail(m, MDC_ERR_ARG, "mdc_multi_synth_sequence_device: bad argument");
-  const int64_t n = (int64_t)m->dev.size();
-  const int rc = per_device(m, [&](int r) {
-    (void)hipSetDevice(m->dev[(size_t)r]);
-    const int64_t mine = mdc_multi_frames_of_rank(m, total, r);
-    for (int64_t i = 0; i < mine; i++) {
-      const int s = mdc_synth_frames_device(m->ctx[(size_t)r], d_in[r] + (size_t)i * (size_t)npix, r + i * n, 1, npix, seed,
-                                            m->stream[(size_t)r]);
-      if (s != MDC_OK) return s;
-    }
-    return (int)MDC_OK;
-  });
-  if (rc != MDC_OK) return fail(m, rc, "frame synthesis failed on a rank");
   return MDC_OK;
 }
 

@@ -46,6 +46,11 @@ __device__ __forceinline__ void block_add_er(double e, double r, double* er) {
   }
 }
 
+// the 2x2 footprint of a sample lies inside the image (also false for NaN coordinates)
+__device__ __forceinline__ bool vcal_inside(float x, float y, int wI, int hI) {
+  return x >= 0.f && y >= 0.f && x < (float)(wI - 1) && y < (float)(hI - 1);
+}
+
 // "optimize planeColor" (:400-448): one thread per plane point, images in order
 __global__ __launch_bounds__(256) void vcal_plane_kernel(const float* __restrict__ images, const float* __restrict__ p2x,
                                                          const float* __restrict__ p2y, int n, int wI, int hI, int np,
@@ -62,6 +67,10 @@ __global__ __launch_bounds__(256) void vcal_plane_kernel(const float* __restrict
       const float x = p2x[(size_t)img * np + pi];
       if (isnan(x)) continue;
       const float y = p2y[(size_t)img * np + pi];
+      // a sample whose 2x2 footprint leaves the image: the reference relies on its caller's mask (:345-357) and would read
+      // out of bounds; dropped here, exactly as the contribution index drops it (vcal_sample), so both half-iterations
+      // always see the same sample set
+      if (!vcal_inside(x, y, wI, hI)) continue;
       const float color = interp(images + img * img_px, x, y, wI);
       const float fac = interp(vig, x, y, wI);
       if (isnan(fac)) continue;
@@ -99,8 +108,8 @@ __global__ __launch_bounds__(256) void vcal_vignette_accumulate_kernel(const flo
   if (pi < np) {
     const float x = p2x[(size_t)img * np + pi];
     const float colorPlane = plane_color[pi];
-    if (!isnan(x) && !isnan(colorPlane)) {
-      const float y = p2y[(size_t)img * np + pi];
+    const float y = isnan(x) ? 0.f : p2y[(size_t)img * np + pi];
+    if (!isnan(x) && !isnan(colorPlane) && vcal_inside(x, y, wI, hI)) {  // (footprint outside the image: dropped, see vcal_plane_kernel)
       const float colorImage = interp(images + (size_t)img * wI * hI, x, y, wI);
       if (!isnan(colorImage)) {
         const float fac = interp(vig, x, y, wI);
@@ -161,7 +170,7 @@ __device__ __forceinline__ bool vcal_sample(const float* __restrict__ images, co
   *x = p2x[(size_t)img * np + pi];
   if (isnan(*x)) return false;
   *y = p2y[(size_t)img * np + pi];
-  if (!(*x >= 0.f && *y >= 0.f && *x < (float)(wI - 1) && *y < (float)(hI - 1))) return false;
+  if (!vcal_inside(*x, *y, wI, hI)) return false;
   *color = interp(images + (size_t)img * wI * hI, *x, *y, wI);
   return !isnan(*color);
 }

@@ -27,14 +27,17 @@ def local_index(frame, world):
     return frame // world
 
 
-def broadcast_tables(blob, src=0, device=None):
+def broadcast_tables(blob, src=0, device=None, even_alone=False):
     """Broadcast the table blob (numpy uint8, as mdc_export_tables wrote it) from
     rank `src` to every rank; returns the blob each rank should import.  Ranks
-    other than src may pass None."""
+    other than src may pass None.  A world of one returns the blob untouched
+    unless `even_alone` (bench.py under MDC_BENCH_FORCE_DIST=1: the collective then
+    really runs -- size word, payload, device round trip -- so that every line of the
+    multi-GPU path executes on a one-GPU box)."""
     import torch
     import torch.distributed as dist
 
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not even_alone):
         return blob
     dev = device if device is not None else "cpu"
     size = torch.zeros(1, dtype=torch.int64, device=dev)

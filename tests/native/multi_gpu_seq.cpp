@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "MdcBind.h"
+#include "mdc_bench.h"
 #include "mdc_multi.h"
 
 #define CHECK(x)                                                                      \
@@ -83,8 +84,22 @@ int main(int argc, char** argv) {
       return 8;
     }
   }
-  CHECK(mdc_multi_synth_sequence_device(m, d_in.data(), total, (int)npi, 12345u));
+  // the synthetic sequence of SURVEY.md 8(d), sharded: local frame i of rank r is global frame r + i*N
+  // (libmdc_bench.so, a test utility: the product libraries do not generate frames)
+  for (int r = 0; r < n; r++) {
+    const long long mine = mdc_multi_frames_of_rank(m, total, r);
+    for (long long i = 0; i < mine; i++)
+      if (mdcb_synth_frames_device(mdc_multi_device(m, r), d_in[(size_t)r] + (size_t)i * npi, r + i * n, 1, (int)npi, 12345u, mdc_multi_stream(m, r)) != 0) {
+        std::fprintf(stderr, "frame synthesis failed on rank %d\n", r);
+        return 8;
+      }
+  }
   CHECK(mdc_multi_synchronize(m));
+  for (int r = 0; r < n; r++)
+    if (mdc_multi_comm_count(m, r) != n) {
+      std::fprintf(stderr, "rank %d: ncclCommCount = %d, expected %d\n", r, mdc_multi_comm_count(m, r), n);
+      return 11;
+    }
   const unsigned flags = MDC_GAMMA | MDC_VIGNETTE | MDC_KILL_OVEREXPOSED | MDC_RECTIFY;
   for (int k = 0; k < 3; k++) CHECK(mdc_multi_process_sequence_device(m, d_in.data(), d_out.data(), total, flags));
   CHECK(mdc_multi_synchronize(m));

@@ -27,6 +27,25 @@ def test_libmdc_hip_exports_header():
         assert hasattr(lib, n), n
 
 
+def test_bench_utilities_are_not_in_the_product_abi():
+    """The synthetic frame generator and the linear-stream yardstick live in libmdc_bench.so (include/mdc_bench.h); the
+    product libraries neither export nor import them."""
+    import subprocess
+
+    from mono_dataset_code_amd import build, capi
+
+    names = declared("mdc_bench.h", "mdcb_")
+    assert sorted(capi.BENCH_SYMBOLS) == names
+    out = subprocess.run(["nm", "-D", build.LIB_BENCH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    for n in names:
+        assert (" T " + n) in out, n
+    for lib in (build.LIB_HIP, build.LIB_HOST, build.LIB_MULTI):
+        sym = subprocess.run(["nm", "-D", lib], stdout=subprocess.PIPE, text=True, check=True).stdout
+        assert "mdcb_" not in sym and "synth_frames" not in sym and "ceiling_mix" not in sym, lib
+        needed = subprocess.run(["readelf", "-d", lib], stdout=subprocess.PIPE, text=True, check=True).stdout
+        assert "libmdc_bench" not in needed, lib
+
+
 def test_libmdc_host_exports_header():
     from mono_dataset_code_amd import capi
 

@@ -172,6 +172,9 @@ def test_bench_rccl_branch_executes_with_a_world_of_one(tmp_path):
     assert out["config"]["tables"] == "rank-0 build + one RCCL broadcast"
     assert out["parity"]["mismatching_pixels"] == 0
     assert out["roofline"]["frac_of_same_box_mix_ceiling"] > 0.3 and out["roofline"]["kernel"].startswith("remap_tiled_kernel<")
+    # the table broadcast itself ran through RCCL (a world of one does not skip it under MDC_BENCH_FORCE_DIST): 7.7 MB, timed
+    assert out["config"]["table_blob_bytes"] > 7_000_000 and out["config"]["table_broadcast_ms"] > 0
+    assert len(out["roofline"]["per_rank_frac"]) == 1 and out["roofline"]["per_rank_frac"][0] > 0.1
 
 
 @pytest.mark.gpu

@@ -53,10 +53,17 @@ def test_sequence_over_all_devices_equals_oracle(tmp_path, oracle):
     line = [l for l in r.stdout.splitlines() if l.startswith("MULTI_GPU_SEQ")][-1].split()
     kv = dict(zip(line[1::2], line[2::2]))
     assert int(kv["devices"]) == ndev and int(kv["frames"]) == total and kv["tables_bit_equal"] == "1"
-    fov = capi.UndistorterFOV(os.path.join(d, "camera.txt"))
-    photo = capi.PhotometricUndistorter(os.path.join(d, "pcalib.txt"), os.path.join(d, "vignette.png"), 1280, 1024)
-    rx, ry = fov.remap()
-    ginv, vinv = photo.ginv(), photo.vignette()[1]
+    # expected tables from the ORACLE's own table builders (oracle/mdc_oracle.c, pinned to the reference build), not from
+    # the product's classes: the comparison below is then product (classes + RCCL broadcast + kernels) vs oracle end to end
+    cam = oracle.parse_camera(os.path.join(d, "camera.txt"))
+    tab = oracle.fov_setup(cam)
+    rx, ry = tab["remap_x"], tab["remap_y"]
+    ginv = oracle.photo_gamma(oracle.parse_pcalib(os.path.join(d, "pcalib.txt")))[0]
+    from PIL import Image  # an independent PNG decoder for the vignette file
+
+    vpx = np.asarray(Image.open(os.path.join(d, "vignette.png")))
+    assert vpx.dtype == np.uint16 and vpx.shape == (1024, 1280)
+    vinv = oracle.photo_vignette(vpx.reshape(-1))[1]
     for rank in range(ndev):
         out = np.fromfile(str(dump / ("rank%d_out.bin" % rank)), np.float32).reshape(-1, 640 * 480)
         assert out.shape[0] == 2

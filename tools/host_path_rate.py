@@ -91,3 +91,33 @@ for name, (raws, outs) in (("mdc_process_frames_host, %d frames per call, pageab
                             ([pin_in.array[i] for i in range(M)], [pin_out.array[i] for i in range(M)]))):
     fps, mpix = many(raws, outs)
     print("%-90s %8.1f frames/s  %9.1f Mpix/s" % (name, fps, mpix), file=sys.stderr)
+
+
+# ---- several host threads on ONE context (SURVEY.md 8b "Threading"): every call leases its own stream + staging slot, so the
+# uploads, kernels and downloads of different threads overlap (round 2 held one mutex across the whole call: no scaling)
+import threading  # noqa: E402
+
+for T in (1, 2, 4, 8, 12):
+    ins = [capi.PinnedArray((W * H,), np.uint8) for _ in range(T)]
+    outs = [capi.PinnedArray((w * h,), np.float32) for _ in range(T)]
+    for k in range(T):
+        ins[k].array[:] = frames[k % 8]
+    per = 400
+    go = threading.Barrier(T + 1)
+
+    def work(k):
+        ctx.process_host(ins[k].array, outs[k].array, 15)
+        go.wait()
+        for _ in range(per):
+            ctx.process_host(ins[k].array, outs[k].array, 15)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(T)]
+    for t in th:
+        t.start()
+    go.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    print("%-90s %8.1f frames/s  %9.1f Mpix/s" % ("mdc_process_host, page-locked buffers, %2d host threads on one context" % T, T * per / dt, T * per * W * H / dt / 1e6),
+          file=sys.stderr)

@@ -55,7 +55,8 @@ def kernels(asm):
 
 
 if __name__ == "__main__":
-    flt = [a for a in sys.argv[1:] if not a.startswith("--")]
+    args = sys.argv[1:]
+    flt = [a for i, a in enumerate(args) if not a.startswith("--") and not (i and args[i - 1] in ("--asm", "--from"))]
     asm = open(sys.argv[sys.argv.index("--from") + 1]).read() if "--from" in sys.argv else device_asm()
     if "--asm" in sys.argv:
         open(sys.argv[sys.argv.index("--asm") + 1], "w").write(asm)
