@@ -19,6 +19,15 @@
 #pragma once
 #include <string>
 
+// The reference's header pulls OpenCV in (src/BenchmarkDatasetReader.h:33-37) and hands out cv::Mat from
+// getImageRaw_internal (:247, used by src/main_responseCalib.cpp:194).  This library itself needs no OpenCV, so the
+// include is taken only where the headers exist; wherever they do, the accessor below is a regular public member.
+#if defined(__has_include)
+#if __has_include(<opencv2/core/core.hpp>)
+#include <opencv2/core/core.hpp>
+#endif
+#endif
+
 #include "ExposureImage.h"
 #include "FOVUndistorter.h"
 #include "PhotometricUndistorter.h"
@@ -51,7 +60,8 @@ class DatasetReader {
   // The decoded 8-bit frame (what cv::imread / cv::imdecode give the reference, :247-276); the
   // pointer stays valid until the next call on this object.  0 on failure.
   const unsigned char* getImageRaw(int id, int* width, int* height);
-#ifdef CV_8U  // a translation unit that has OpenCV (or the test shim) also gets the reference's accessor
+#ifdef CV_8U  // OpenCV (or the test shim) is on the include path: the reference's accessor (:247-276), same signature.
+              // The Mat wraps the reader's own buffer: valid until the next call on this object (clone() to keep it).
   cv::Mat getImageRaw_internal(int id) {
     int w = 0, h = 0;
     const unsigned char* p = getImageRaw(id, &w, &h);

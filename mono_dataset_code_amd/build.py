@@ -25,9 +25,9 @@ HIP_SOURCES = [os.path.join(CSRC, f) for f in ("mdc_kernels.hip", "mdc_vcal.hip"
 HIP_DEPS = HIP_SOURCES + [os.path.join(CSRC, "mdc_internal.h"), os.path.join(INC, "mdc_hip.h")]
 HOST_SOURCES = [os.path.join(HOST, f) for f in (
     "fov_undistorter.cpp", "photometric_undistorter.cpp", "gray_png.cpp", "host_device.cpp", "mdc_host_capi.cpp",
-    "image_codecs.cpp", "zip_reader.cpp", "image_pool.cpp", "dataset_reader.cpp")]
+    "image_codecs.cpp", "image_codecs_ext.cpp", "zip_reader.cpp", "image_pool.cpp", "dataset_reader.cpp")]
 HOST_DEPS = HOST_SOURCES + [os.path.join(HOST, "gray_png.h"), os.path.join(HOST, "host_device.h"),
-                            os.path.join(HOST, "image_codecs.h"), os.path.join(HOST, "zip_reader.h"),
+                            os.path.join(HOST, "image_codecs.h"), os.path.join(HOST, "image_codecs_internal.h"), os.path.join(HOST, "zip_reader.h"),
                             os.path.join(INC, "mono_dataset_code", "BenchmarkDatasetReader.h"),
                             os.path.join(INC, "mdc_hip.h"), os.path.join(INC, "mdc_host.h"),
                             os.path.join(INC, "mono_dataset_code", "FOVUndistorter.h"),

@@ -1,4 +1,5 @@
 #include "gray_png.h"
+#include "image_codecs_internal.h"
 
 #include <zlib.h>
 #include <cstdio>
@@ -7,8 +8,6 @@
 
 namespace mdc_host {
 namespace {
-
-unsigned be32(const unsigned char* p) { return (unsigned)p[0] << 24 | (unsigned)p[1] << 16 | (unsigned)p[2] << 8 | p[3]; }
 
 bool slurp(const std::string& path, std::vector<unsigned char>& buf) {
   FILE* f = fopen(path.c_str(), "rb");
@@ -23,61 +22,18 @@ bool slurp(const std::string& path, std::vector<unsigned char>& buf) {
   return ok;
 }
 
-int paeth(int a, int b, int c) {
-  int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
-  return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-}
-
 GrayImage decode_png(const std::vector<unsigned char>& buf) {
   GrayImage none;
-  size_t pos = 8;
-  unsigned w = 0, h = 0;
-  int depth = 0, ctype = -1, interlace = 0;
-  std::vector<unsigned char> idat;
-  while (pos + 12 <= buf.size()) {
-    unsigned len = be32(&buf[pos]);
-    const unsigned char* tag = &buf[pos + 4];
-    if (pos + 12 + (size_t)len > buf.size()) return none;
-    const unsigned char* body = &buf[pos + 8];
-    if (!memcmp(tag, "IHDR", 4) && len >= 13) {
-      w = be32(body); h = be32(body + 4);
-      depth = body[8]; ctype = body[9]; interlace = body[12];
-    } else if (!memcmp(tag, "IDAT", 4)) {
-      idat.insert(idat.end(), body, body + len);
-    } else if (!memcmp(tag, "IEND", 4)) {
-      break;
-    }
-    pos += 12 + (size_t)len;
-  }
-  if (w == 0 || h == 0 || ctype != 0 || interlace != 0 || (depth != 8 && depth != 16)) return none;
-  const size_t bpp = (size_t)depth / 8, stride = (size_t)w * bpp;
-  std::vector<unsigned char> raw((stride + 1) * h);
-  uLongf got = (uLongf)raw.size();
-  if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw.size()) return none;
-  std::vector<unsigned char> prev(stride, 0), cur(stride);
+  PngAny any;
+  std::string err;
+  if (!png_decode_any(buf.data(), buf.size(), any, &err)) return none;
   GrayImage im;
-  im.width = (int)w; im.height = (int)h; im.bits = depth;
-  im.px.resize((size_t)w * h);
-  for (unsigned y = 0; y < h; y++) {
-    const unsigned char* line = &raw[(stride + 1) * y];
-    const int ft = line[0];
-    for (size_t i = 0; i < stride; i++) {
-      int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0, x = line[1 + i];
-      int v;
-      switch (ft) {
-        case 0: v = x; break;
-        case 1: v = x + a; break;
-        case 2: v = x + b; break;
-        case 3: v = x + ((a + b) >> 1); break;
-        case 4: v = x + paeth(a, b, c); break;
-        default: return none;
-      }
-      cur[i] = (unsigned char)v;
-    }
-    for (unsigned x = 0; x < w; x++)
-      im.px[(size_t)y * w + x] = depth == 8 ? cur[x] : (unsigned short)(cur[2 * x] << 8 | cur[2 * x + 1]);
-    prev.swap(cur);
-  }
+  im.width = any.w;
+  im.height = any.h;
+  im.channels = any.channels;
+  if (any.channels != 1) return im;  // bits stays 0: not a single-channel image
+  im.bits = any.bits;
+  im.px.assign(any.px.begin(), any.px.end());
   return im;
 }
 
@@ -88,7 +44,7 @@ GrayImage decode_pgm(const std::vector<unsigned char>& buf) {
   size_t off = (size_t)used + 1, bps = maxv > 255 ? 2 : 1;
   if (off + (size_t)w * h * bps > buf.size()) return none;
   GrayImage im;
-  im.width = w; im.height = h; im.bits = bps == 2 ? 16 : 8;
+  im.width = w; im.height = h; im.channels = 1; im.bits = bps == 2 ? 16 : 8;
   im.px.resize((size_t)w * h);
   for (size_t i = 0; i < (size_t)w * h; i++)
     im.px[i] = bps == 1 ? buf[off + i] : (unsigned short)(buf[off + 2 * i] << 8 | buf[off + 2 * i + 1]);

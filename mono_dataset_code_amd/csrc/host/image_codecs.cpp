@@ -1,4 +1,5 @@
 #include "image_codecs.h"
+#include "image_codecs_internal.h"
 
 #include <zlib.h>
 #include <algorithm>
@@ -71,8 +72,13 @@ bool png_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap,
   if (W == 0 || H == 0 || W > 65535 || H > 65535) return fail(err, "PNG: no IHDR");
   *w = (int)W;
   *h = (int)H;
-  if (ctype != 0 || depth != 8 || interlace != 0) return fail(err, "PNG: only 8-bit grayscale, non-interlaced frames are supported");
   if ((size_t)W * H > cap) return fail(err, "frame larger than the buffer");
+  if (ctype != 0 || depth != 8 || interlace != 0) {  // any other PNG flavour: general decoder + OpenCV's conversion to 8-bit gray
+    PngAny im;
+    if (!png_decode_any(d, n, im, err)) return false;
+    png_any_to_gray8(im, out);
+    return true;
+  }
   const size_t stride = W;
   raw.resize((stride + 1) * H);
   uLongf got = (uLongf)raw.size();
@@ -125,9 +131,14 @@ bool pgm_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap,
   if (vals[0] <= 0 || vals[1] <= 0) return fail(err, "PGM: bad size");
   *w = vals[0];
   *h = vals[1];
-  if (vals[2] > 255 || vals[2] <= 0) return fail(err, "PGM: only maxval <= 255 is supported");
+  if (vals[2] != 65535 && (vals[2] > 255 || vals[2] <= 0)) return fail(err, "PGM: only maxval <= 255 or 65535 is supported");
   const size_t px = (size_t)vals[0] * vals[1];
   if (px > cap) return fail(err, "frame larger than the buffer");
+  if (vals[2] == 65535) {  // 16-bit samples (big endian): the high byte, as OpenCV's 8-bit read of such a file
+    if (p + 2 * px > n) return fail(err, "PGM: truncated");
+    for (size_t i = 0; i < px; i++) out[i] = d[p + 2 * i];
+    return true;
+  }
   if (p + px > n) return fail(err, "PGM: truncated");
   memcpy(out, d + p, px);
   return true;
@@ -413,8 +424,10 @@ bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap
       have_sof = true;
       *w = W;
       *h = H;
-    } else if (m == 0xc2 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
-      return fail(err, "JPEG: only baseline (sequential Huffman) files are supported");
+    } else if (m == 0xc2) {  // progressive: its own decoder (image_codecs_ext.cpp)
+      return jpeg_progressive_gray8(d, n, out, cap, w, h, err);
+    } else if (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
+      return fail(err, "JPEG: lossless, hierarchical and arithmetic-coded files are not supported");
     } else if (m == 0xdd) {  // DRI
       if (sl >= 2) restart = s[0] << 8 | s[1];
     } else if (m == 0xda) {  // SOS: the one scan of a baseline file
@@ -517,13 +530,15 @@ bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap
 
 }  // namespace
 
+void jpeg_idct_islow(const int* coef, unsigned char* out, size_t stride, bool dc_only) { idct_islow(coef, out, stride, dc_only); }
+
 bool decode_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap, int* w, int* h, std::string* err) {
   *w = *h = 0;
   static const unsigned char png_sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
   if (n >= 16 && !memcmp(d, png_sig, 8)) return png_gray8(d, n, out, cap, w, h, err);
   if (n >= 4 && d[0] == 0xff && d[1] == 0xd8) return jpeg_gray8(d, n, out, cap, w, h, err);
   if (n >= 8 && d[0] == 'P' && d[1] == '5') return pgm_gray8(d, n, out, cap, w, h, err);
-  return fail(err, "unknown image format (PNG, PGM P5 and baseline JPEG are supported)");
+  return fail(err, "unknown image format (PNG, PGM P5 and JPEG are supported)");
 }
 
 }  // namespace mdc_host

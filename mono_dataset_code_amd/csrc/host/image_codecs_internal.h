@@ -1,0 +1,25 @@
+// Shared between image_codecs.cpp (the common formats, decoded in place) and image_codecs_ext.cpp (every other PNG
+// flavour, progressive JPEG) and gray_png.cpp (the vignette image).  Not installed.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mdc_host {
+
+struct PngAny {
+  int w = 0, h = 0;
+  int channels = 0;  // 1 gray, 2 gray + alpha, 3 RGB (also expanded palettes), 4 RGBA
+  int bits = 0;      // 8 (1/2/4-bit gray already scaled to 8) or 16
+  bool palette = false;
+  std::vector<uint16_t> px;  // interleaved samples
+};
+bool png_decode_any(const unsigned char* data, size_t n, PngAny& im, std::string* err);
+void png_any_to_gray8(const PngAny& im, unsigned char* out);  // w*h bytes, OpenCV's grayscale read of that PNG
+
+bool jpeg_progressive_gray8(const unsigned char* data, size_t n, unsigned char* out, size_t cap, int* w, int* h, std::string* err);
+// libjpeg's islow inverse DCT on dequantised coefficients in natural order (image_codecs.cpp)
+void jpeg_idct_islow(const int* coef, unsigned char* out, size_t stride, bool dc_only);
+
+}  // namespace mdc_host

@@ -84,7 +84,9 @@ void PhotometricUndistorter::read_calibration(const std::string& file, const std
   } else if (img.bits != 8 && img.bits != 16) {
     // the reference asserts here (compiled out under NDEBUG) and carries on with
     // uninitialised maps; we refuse the image instead
-    std::printf("PhotometricUndistorter: vignette image is not 8/16-bit grayscale. Set vignette to 1.\n");
+    // (a colour, alpha or palette PNG: OpenCV would hand the reference a multi-channel Mat)
+    std::printf("PhotometricUndistorter: ERROR: vignette image has %d channels, need 8- or 16-bit single-channel grayscale "
+                "(the reference's behaviour for such a file is undefined). Set vignette to 1.\n", img.channels);
   } else {
     float peak = 0;  // (:130-147) same loop for 8- and 16-bit samples
     for (int i = 0; i < n; i++)

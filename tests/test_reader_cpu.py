@@ -58,18 +58,186 @@ def test_png_and_pgm_decoders():
     assert np.array_equal(capi.decode_gray8(b.getvalue()), img)
     pgm = b"P5\n# a comment\n131 77\n255\n" + img.tobytes()
     assert np.array_equal(capi.decode_gray8(pgm), img)
-    for bad, why in ((b"GIF89a" + bytes(40), "unknown image format"), (jpeg_bytes(img, quality=80, progressive=True), "baseline"),
-                     (b"\x89PNG\r\n\x1a\n" + bytes(30), "PNG"), (b"P5\n10 10\n65535\n" + bytes(200), "maxval")):
+    pgm16 = b"P5\n131 77\n65535\n" + (img.astype(">u2") * 257).tobytes()
+    assert np.array_equal(capi.decode_gray8(pgm16), img)  # the high byte
+    for bad, why in ((b"GIF89a" + bytes(40), "unknown image format"), (b"\x89PNG\r\n\x1a\n" + bytes(30), "PNG"),
+                     (b"P5\n10 10\n1000\n" + bytes(200), "maxval")):
         with pytest.raises(ValueError, match=why):
             capi.decode_gray8(bad)
-    b16 = io.BytesIO()
-    Image.fromarray((img.astype(np.uint16) << 8)).save(b16, "PNG")
-    with pytest.raises(ValueError, match="8-bit"):
-        capi.decode_gray8(b16.getvalue())
-    rgb = io.BytesIO()
-    Image.fromarray(np.stack([img] * 3, -1)).save(rgb, "PNG")
-    with pytest.raises(ValueError, match="grayscale"):
-        capi.decode_gray8(rgb.getvalue())
+
+
+def opencv_gray_of_rgb(rgb):
+    """What OpenCV's grayscale read makes of an RGB PNG: libpng's png_set_rgb_to_gray(1, 0.299, 0.587) -- 15-bit fixed
+    point, coefficients truncated to 9797 / 19234 / 3737, no rounding for 8-bit samples, + 16384 for 16-bit ones, equal
+    channels pass through; 16-bit results keep their high byte."""
+    r, g, b = (rgb[..., k].astype(np.uint32) for k in range(3))
+    if rgb.dtype == np.uint8:
+        y = (9797 * r + 19234 * g + 3737 * b) >> 15
+    else:
+        y = (9797 * r + 19234 * g + 3737 * b + 16384) >> 15
+    y = np.where((r == g) & (r == b), r, y)
+    return (y >> 8 if rgb.dtype == np.uint16 else y).astype(np.uint8)
+
+
+def png_bytes(arr_or_image, **kw):
+    b = io.BytesIO()
+    (arr_or_image if isinstance(arr_or_image, Image.Image) else Image.fromarray(arr_or_image)).save(b, "PNG", **kw)
+    return b.getvalue()
+
+
+def test_every_png_flavour_opencv_reads_as_gray():
+    """cv::imread(..., CV_LOAD_IMAGE_GRAYSCALE) (reference src/BenchmarkDatasetReader.h:252,274) takes any PNG: 16-bit,
+    colour, alpha, palette, low bit depths, interlaced.  Gray / alpha / depth cases are compared with PIL's decode of
+    the same file (pure sample selection), colour against the libpng formula OpenCV configures (stated above; PIL's own
+    'L' conversion rounds differently: the two are shown to differ by at most 1)."""
+    from mono_dataset_code_amd import capi
+
+    img = textured(61, 83, 5)
+    rng = np.random.default_rng(2)
+    rgb = np.stack([img, np.roll(img, 5, 1), (255 - img // 2).astype(np.uint8)], -1)
+    rgb[:7] = img[:7, :, None]  # rows with R == G == B
+    # 16-bit gray -> high byte
+    g16 = (img.astype(np.uint16) << 8) | rng.integers(0, 256, img.shape).astype(np.uint16)
+    assert np.array_equal(capi.decode_gray8(png_bytes(g16)), (g16 >> 8).astype(np.uint8))
+    # gray + alpha (8 and 16 bit): alpha dropped
+    la = np.stack([img, rng.integers(0, 256, img.shape).astype(np.uint8)], -1)
+    assert np.array_equal(capi.decode_gray8(png_bytes(Image.fromarray(la, "LA"))), img)
+    # RGB, RGBA
+    want = opencv_gray_of_rgb(rgb)
+    assert np.array_equal(capi.decode_gray8(png_bytes(rgb)), want)
+    rgba = np.concatenate([rgb, rng.integers(0, 256, img.shape + (1,)).astype(np.uint8)], -1)
+    assert np.array_equal(capi.decode_gray8(png_bytes(Image.fromarray(rgba, "RGBA"))), want)
+    pil_l = np.asarray(Image.fromarray(rgb).convert("L")).astype(int)
+    assert np.abs(pil_l - want.astype(int)).max() <= 1  # the documented difference to PIL's rounding
+    # palette (8-bit and 4-bit indices) -> RGB -> gray
+    pal = Image.fromarray(rgb).quantize(colors=200)
+    assert np.array_equal(capi.decode_gray8(png_bytes(pal)), opencv_gray_of_rgb(np.asarray(pal.convert("RGB"))))
+    pal16 = Image.fromarray(rgb).quantize(colors=13)
+    data = png_bytes(pal16, bits=4)
+    assert data[24] == 4 and data[25] == 3  # IHDR: depth 4, colour type 3
+    assert np.array_equal(capi.decode_gray8(data), opencv_gray_of_rgb(np.asarray(pal16.convert("RGB"))))
+    # 1-bit gray -> 0 / 255
+    one = Image.fromarray(((img > 127) * 255).astype(np.uint8)).convert("1")
+    data = png_bytes(one)
+    assert data[24] == 1 and data[25] == 0
+    assert np.array_equal(capi.decode_gray8(data), np.asarray(one).astype(np.uint8) * 255)
+    # Adam7 interlacing: own minimal encoder (PIL cannot write it), every flavour again, odd sizes incl. 1 x 1 and widths < 8
+    for arr in (img, g16, rgb, img[:1, :1], img[:3, :5], rgb[:9, :2], g16[:5, :9]):
+        data = interlaced_png(arr)
+        want_i = arr if arr.dtype == np.uint8 and arr.ndim == 2 else (arr >> 8).astype(np.uint8) if arr.ndim == 2 else opencv_gray_of_rgb(arr)
+        assert np.array_equal(capi.decode_gray8(data), want_i), arr.shape
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(data))).astype(arr.dtype).reshape(arr.shape), arr)  # PIL agrees the file is sound
+    # 16-bit RGB (own encoder: PIL does not write it)
+    rgb16 = (rgb.astype(np.uint16) << 8) | rng.integers(0, 256, rgb.shape).astype(np.uint16)
+    assert np.array_equal(capi.decode_gray8(raw_png(rgb16)), opencv_gray_of_rgb(rgb16))
+
+
+def _png_chunks(w, h, depth, ctype, interlace, raw):
+    import struct
+    import zlib
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace)) + chunk(b"IDAT", zlib.compress(raw, 6)) +
+            chunk(b"IEND", b""))
+
+
+def _png_rows(arr):
+    """(depth, colour type, list of filtered scanlines) of a gray / RGB, 8 / 16-bit array with filter types cycling 0..4."""
+    depth = 16 if arr.dtype == np.uint16 else 8
+    ctype = 0 if arr.ndim == 2 else 2
+    a = arr.reshape(arr.shape[0], -1)
+    body = a.astype(">u2").tobytes() if depth == 16 else a.tobytes()
+    stride = a.shape[1] * depth // 8
+    bpp = max(1, (1 if arr.ndim == 2 else 3) * depth // 8)
+    rows, prev = [], bytes(stride)
+    for y in range(arr.shape[0]):
+        cur = body[y * stride:(y + 1) * stride]
+        ft = y % 5
+        out = bytearray(stride)
+        for i in range(stride):
+            aa = cur[i - bpp] if i >= bpp else 0
+            bb = prev[i]
+            cc = prev[i - bpp] if i >= bpp else 0
+            if ft == 0:
+                pr = 0
+            elif ft == 1:
+                pr = aa
+            elif ft == 2:
+                pr = bb
+            elif ft == 3:
+                pr = (aa + bb) >> 1
+            else:
+                p = aa + bb - cc
+                pa, pb, pc = abs(p - aa), abs(p - bb), abs(p - cc)
+                pr = aa if pa <= pb and pa <= pc else (bb if pb <= pc else cc)
+            out[i] = (cur[i] - pr) & 255
+        rows.append(bytes([ft]) + bytes(out))
+        prev = cur
+    return depth, ctype, rows
+
+
+def raw_png(arr):
+    depth, ctype, rows = _png_rows(arr)
+    return _png_chunks(arr.shape[1], arr.shape[0], depth, ctype, 0, b"".join(rows))
+
+
+def interlaced_png(arr):
+    """Adam7: the seven reduced images, each filtered on its own."""
+    h, w = arr.shape[:2]
+    x0, y0, dx, dy = (0, 4, 0, 2, 0, 1, 0), (0, 0, 4, 0, 2, 0, 1), (8, 8, 4, 4, 2, 2, 1), (8, 8, 8, 4, 4, 2, 2)
+    raw, depth, ctype = b"", None, None
+    for p in range(7):
+        sub = arr[y0[p]::dy[p], x0[p]::dx[p]]
+        d, c, rows = _png_rows(sub) if sub.size else (16 if arr.dtype == np.uint16 else 8, 0 if arr.ndim == 2 else 2, [])
+        depth, ctype = d, c
+        raw += b"".join(rows)
+    return _png_chunks(w, h, depth, ctype, 1, raw)
+
+
+@pytest.mark.parametrize("size", [(64, 64), (100, 130), (17, 23), (8, 8), (250, 322)])
+def test_progressive_jpeg_decoder_equals_libjpeg_bit_for_bit(size):
+    """SOF2 files (spectral selection + successive approximation): gray and YCbCr with every chroma subsampling, with and
+    without restart markers -- the luma plane libjpeg-turbo delivers for JCS_GRAYSCALE, bit for bit."""
+    from mono_dataset_code_amd import capi
+
+    img = textured(*size)
+    for kw in ({"quality": 30}, {"quality": 85}, {"quality": 95, "optimize": True}, {"quality": 100}, {"quality": 75, "restart_marker_blocks": 5},
+               {"quality": 75, "restart_marker_rows": 1}):
+        data = jpeg_bytes(img, progressive=True, **kw)
+        assert b"\xff\xc2" in data
+        assert np.array_equal(capi.decode_gray8(data), np.asarray(Image.open(io.BytesIO(data)))), kw
+    rgb = np.stack([img, np.roll(img, 3, 1), 255 - img], -1)
+    for sub in (0, 1, 2):
+        for extra in ({}, {"restart_marker_blocks": 3}):
+            data = jpeg_bytes(rgb, quality=85, subsampling=sub, progressive=True, **extra)
+            im = Image.open(io.BytesIO(data))
+            im.draft("L", im.size)
+            assert np.array_equal(capi.decode_gray8(data), np.asarray(im)), (sub, extra)
+
+
+def test_vignette_of_any_png_flavour(tmp_path, capfd):
+    """cv::imread(vignette, CV_LOAD_IMAGE_UNCHANGED) (reference src/PhotometricUndistorter.cpp:120): every single-channel
+    PNG works (interlaced, 16-bit, low bit depth), a multi-channel one is refused LOUDLY (the reference's behaviour for it
+    is undefined) instead of silently becoming 1."""
+    from mono_dataset_code_amd import capi, synth
+
+    w, h = 48, 32
+    v16 = np.asarray(synth.vignette_image(w, h, 16)).reshape(h, w).astype(np.uint16)
+    good = " ".join("%.6f" % (255.0 * (i / 255.0) ** 2.2 + 0.01 * i) for i in range(256))
+    open(tmp_path / "pcalib.txt", "w").write(good + "\n")
+    synth.write_png_gray(str(tmp_path / "plain16.png"), v16)
+    open(tmp_path / "interlaced16.png", "wb").write(interlaced_png(v16))
+    ref = capi.PhotometricUndistorter(str(tmp_path / "pcalib.txt"), str(tmp_path / "plain16.png"), w, h)
+    lace = capi.PhotometricUndistorter(str(tmp_path / "pcalib.txt"), str(tmp_path / "interlaced16.png"), w, h)
+    assert ref.valid() == 3 and lace.valid() == 3
+    assert np.array_equal(ref.vignette()[1].view(np.uint32), lace.vignette()[1].view(np.uint32))
+    c_out(capfd)
+    open(tmp_path / "rgb.png", "wb").write(png_bytes(np.stack([(v16 >> 8).astype(np.uint8)] * 3, -1)))
+    col = capi.PhotometricUndistorter(str(tmp_path / "pcalib.txt"), str(tmp_path / "rgb.png"), w, h)
+    log = c_out(capfd)
+    assert col.valid() == 1 and "ERROR: vignette image has 3 channels" in log
 
 
 def make_sequence(d, frames, zipped=False, fmt="png", times=True, stored=False):
@@ -173,3 +341,20 @@ def test_image_pool_recycles_blocks():
     L.mdch_image_free(b)  # a second free of the same block is ignored, not a crash
     L.mdch_image_pool_trim()
     assert L.mdch_image_pool_idle_bytes() == 0
+
+
+def test_get_image_raw_internal_is_there_for_opencv_callers(tmp_path):
+    """responseCalib's use of the reader (reference src/main_responseCalib.cpp:194): getImageRaw_internal(int) -> cv::Mat, from a
+    translation unit that includes only this repo's reader header (tests/dropin/raw_internal.cpp).  No GPU involved."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "raw_internal")
+    if not os.path.exists(exe):
+        pytest.skip("raw_internal not built")
+    frames = [textured(48, 64, s) for s in range(5)]
+    make_sequence(str(tmp_path), frames, zipped=True, fmt="png")
+    out = subprocess.run([exe, str(tmp_path)], stdout=subprocess.PIPE, text=True, timeout=120).stdout
+    rows = [l.split() for l in out.splitlines() if l.startswith("RAW ")]
+    assert len(rows) == 5
+    for i, r in enumerate(rows):
+        assert [int(x) for x in r[1:]] == [i, 48, 64, 0, int(frames[i].astype(np.uint64).sum())]

@@ -3,6 +3,7 @@ the host sources under -fsanitize=address,undefined and run on valid, malformed,
 calibration files, images and zip archives, plus the reader's decode pool.  No GPU involved."""
 import io
 import os
+import sys
 import subprocess
 import zipfile
 
@@ -11,6 +12,9 @@ import pytest
 from PIL import Image
 
 from test_reader_cpu import make_sequence, textured
+
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_host_layer_under_asan_ubsan(tmp_path):
@@ -35,6 +39,25 @@ def test_host_layer_under_asan_ubsan(tmp_path):
     open(root / "images_any" / "h.pgm", "wb").write(b"P5\n# c\n90 70\n255\n" + img.tobytes())
     open(root / "images_any" / "i.pgm", "wb").write(b"P5 99999 99999 255\n" + bytes(100))
     open(root / "images_any" / "j.bin", "wb").write(os.urandom(3000))
+    # the extended decoders (image_codecs_ext.cpp): every PNG flavour, Adam7, progressive JPEG -- sound, truncated and bit-flipped
+    from test_reader_cpu import interlaced_png, png_bytes, raw_png
+
+    rgb = np.stack([img, img[::-1], 255 - img], -1)
+    prog = open(root / "images_any" / "f_prog.jpg", "rb").read()
+    extra = {"k_rgb.png": png_bytes(rgb), "l_pal.png": png_bytes(Image.fromarray(rgb).quantize(colors=13), bits=4),
+             "m_lace.png": interlaced_png(img), "n_lace16rgb.png": interlaced_png((rgb.astype(np.uint16) << 8)),
+             "o_rgb16.png": raw_png(rgb.astype(np.uint16) * 257), "p_prog_color.jpg": None}
+    b = __import__("io").BytesIO()
+    Image.fromarray(rgb).save(b, "JPEG", quality=80, progressive=True, subsampling=2, restart_marker_blocks=4)
+    extra["p_prog_color.jpg"] = b.getvalue()
+    for k, v in extra.items():
+        open(root / "images_any" / k, "wb").write(v)
+        open(root / "images_any" / ("t_" + k), "wb").write(v[: len(v) * 3 // 5])
+        for j, at in enumerate((len(v) // 3, len(v) // 2, len(v) - 40)):
+            f = bytearray(v)
+            f[at] ^= 0x5A
+            open(root / "images_any" / ("f%d_" % j + k), "wb").write(bytes(f))
+    open(root / "images_any" / "t_prog.jpg", "wb").write(prog[: len(prog) // 2])
     # calibration files: valid variants + malformed ones (as tests/test_tables_vs_ref.py uses)
     cams = {"camera_ok.txt": "0.349153 0.436593 0.493140 0.499021 0.933271\n48 32\ncrop\n30 20\n",
             "camera_full.txt": "0.349153 0.436593 0.493140 0.499021 0.933271\n48 32\nfull\n30 20\n",
