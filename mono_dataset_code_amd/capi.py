@@ -31,7 +31,7 @@ HIP_SYMBOLS = [
     "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device",
     "mdc_distort_points_device", "mdc_distort_points_host", "mdc_export_tables", "mdc_import_tables",
     "mdc_synchronize", "mdc_describe_launch", "mdc_vcal_plane_step_device",
-    "mdc_vcal_vignette_step_device", "mdc_gradients_batch_device", "mdc_tune_device",
+    "mdc_vcal_vignette_step_device", "mdc_gradients_batch_device", "mdc_process_pyramid_gradients_batch_device", "mdc_tune_device",
     "mdc_vcal_index_create", "mdc_vcal_index_destroy", "mdc_vcal_index_bytes", "mdc_vcal_index_entries",
     "mdc_vcal_vignette_step_indexed_device", "mdc_vcal_solve_device", "mdc_vcal_smooth_device", "mdc_vcal_mask_coords_device", "mdc_vcal_gradient_mask_device", "mdc_vcal_scale_images_device",
 ]
@@ -148,6 +148,9 @@ def hip_lib():
             L.mdc_vcal_plane_step_device.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]
             L.mdc_tune_device.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_uint, _vp, C.POINTER(TuneResult)]
             L.mdc_gradients_batch_device.argtypes = [_vp, _vp, _i, _i, _vp, _vp, C.c_int64, _vp]
+            if hasattr(L, "mdc_process_pyramid_gradients_batch_device"):
+                L.mdc_process_pyramid_gradients_batch_device.argtypes = [_vp, _vp, _vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i64,
+                                                                         C.c_uint, _i, _vp]
             L.mdc_vcal_vignette_step_device.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]
         if not old_build or hasattr(L, "mdc_vcal_index_create"):
             L.mdc_vcal_index_create.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(_vp)]
@@ -385,6 +388,14 @@ class Context:
         arr = (_vp * max(1, len(d_levels)))(*d_levels)
         self._chk(self._L.mdc_process_pyramid_batch_device(self._h, d_in, d_base, levels, arr, nframes, flags,
                                                            stream if stream else None))
+
+    def process_pyramid_gradients_batch(self, d_in, d_base, levels, d_levels, d_dI, d_abs, nframes, flags, chunk_frames=0, stream=0):
+        """base + levels + (I, dx, dy) / absSquaredGrad of every level in one call; d_dI / d_abs: one address per level (0 = base)."""
+        lv = (_vp * max(1, len(d_levels)))(*d_levels)
+        di = (_vp * levels)(*d_dI)
+        ab = (_vp * levels)(*d_abs)
+        self._chk(self._L.mdc_process_pyramid_gradients_batch_device(self._h, d_in, d_base, levels, lv, di, ab, nframes, flags, chunk_frames,
+                                                                     stream if stream else None))
 
     def distort_points_host(self, model, x, y):
         assert x.dtype == np.float32 and y.dtype == np.float32 and x.size == y.size

@@ -143,5 +143,8 @@ hipError_t launch_vcal_smooth(const float* d_vig, int wI, int hI, float* d_tt, f
 
 // DSO hand-off of one pyramid level: (I, dx, dy) triples + absSquaredGrad (see mdc_vcal.hip)
 hipError_t launch_gradients(const float* d_level, float* d_dI, float* d_abs2, int w, int h, int64_t nframes, hipStream_t s);
+// ... of up to four levels in one launch
+hipError_t launch_gradients_levels(int n_levels, const float* const* d_src, float* const* d_dI, float* const* d_abs2, const int* w,
+                                   const int* h, int64_t nframes, hipStream_t s);
 
 }  // namespace mdc

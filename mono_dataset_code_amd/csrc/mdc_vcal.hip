@@ -501,9 +501,83 @@ __global__ __launch_bounds__(256) void gradients_kernel(const float* __restrict_
   }
 }
 
+// The same for up to four pyramid levels of a chunk of frames in ONE launch (mdc_process_pyramid_gradients_batch_device): a
+// workgroup finds its level from the first-block table; the body is gradients_kernel's.
+struct GradLevels {
+  const float* src[4];
+  float* dI[4];
+  float* abs2[4];
+  int w[4], h[4];
+  unsigned first_block[5];  // blocks [first_block[l], first_block[l+1]) belong to level l
+  int n;
+};
+__global__ __launch_bounds__(256) void gradients_levels_kernel(GradLevels g, long long nframes) {
+  __shared__ float s_t[4][192];
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < 4; k++)
+    if (k < g.n && blockIdx.x >= g.first_block[k]) l = k;
+  const float* lvl = g.src[l];
+  float* dI = g.dI[l];
+  float* abs2 = g.abs2[l];
+  const int w = g.w[l], h = g.h[l];
+  const long long npx = (long long)w * h;
+  const long long base = (long long)(blockIdx.x - g.first_block[l]) * 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long i = base + threadIdx.x;
+  float I = 0.f, dx = 0.f, dy = 0.f;
+  if (i < npx * nframes) {
+    const long long f = i / npx;
+    const int idx = (int)(i - f * npx);
+    const float* p = lvl + f * npx;
+    I = p[idx];
+    if (idx >= w && idx < w * (h - 1)) {
+      dx = 0.5f * (p[idx + 1] - p[idx - 1]);
+      dy = 0.5f * (p[idx + w] - p[idx - w]);
+      if (!isfinite(dx)) dx = 0.f;
+      if (!isfinite(dy)) dy = 0.f;
+    }
+    abs2[i] = dx * dx + dy * dy;
+  }
+  s_t[wave][3 * lane + 0] = I;
+  s_t[wave][3 * lane + 1] = dx;
+  s_t[wave][3 * lane + 2] = dy;
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): wave-private transpose
+  const long long out0 = (base + wave * 64) * 3;
+  const long long total = npx * nframes * 3;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const long long o = out0 + k * 64 + lane;
+    if (o < total) __builtin_nontemporal_store(s_t[wave][k * 64 + lane], dI + o);
+  }
+}
+
 inline int blocks(long long n) { return (int)((n + 255) / 256); }
 
 }  // namespace
+
+hipError_t launch_gradients_levels(int n_levels, const float* const* d_src, float* const* d_dI, float* const* d_abs2, const int* w,
+                                   const int* h, int64_t nframes, hipStream_t s) {
+  if (n_levels <= 0 || nframes <= 0) return hipSuccess;
+  if (n_levels > 4) return hipErrorInvalidValue;
+  GradLevels g;
+  unsigned nb = 0;
+  for (int l = 0; l < 4; l++) {
+    const bool on = l < n_levels;
+    g.src[l] = on ? d_src[l] : nullptr;
+    g.dI[l] = on ? d_dI[l] : nullptr;
+    g.abs2[l] = on ? d_abs2[l] : nullptr;
+    g.w[l] = on ? w[l] : 1;
+    g.h[l] = on ? h[l] : 1;
+    g.first_block[l] = nb;
+    if (on) nb += (unsigned)blocks((long long)w[l] * h[l] * nframes);
+  }
+  g.first_block[4] = nb;
+  g.n = n_levels;
+  if (nb == 0) return hipSuccess;
+  gradients_levels_kernel<<<nb, 256, 0, s>>>(g, nframes);
+  return hipGetLastError();
+}
 
 hipError_t launch_vcal_plane_step(const float* d_images, const float* d_p2x, const float* d_p2y, int n, int wI, int hI, int np,
                                   float* d_plane_color, const float* d_vig, int oth2, float* d_ff, float* d_fc, double* d_er,

@@ -618,6 +618,42 @@ def test_dso_gradients_of_pyramid_levels(setups, oracle, torch_cuda):
                 assert bits_equal(d_abs.view(n, -1)[f].cpu().numpy(), a), (name, l, f)
 
 
+@pytest.mark.parametrize("name", ["pyr_whole_black", "ragged", "upsample", "mag4_full_black"])
+def test_dso_preprocessing_in_one_call(name, setups, oracle, torch_cuda):
+    """mdc_process_pyramid_gradients_batch_device (row f4; parity unpinned: DSO is not in the reference, own definition and oracle):
+    base, levels and the gradient images of every level from one call, walked in chunks (also a chunk size that does not divide
+    the batch) -- every array bit-equal to the oracle's chain remap -> box levels -> orc_gradients."""
+    from mono_dataset_code_amd import capi
+
+    torch = torch_cuda
+    s = setups(name)
+    frames = np.stack(make_frames(s.W, s.H, n_noise=3))
+    n = len(frames)
+    d_in = torch.from_numpy(frames).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    for levels, chunk in ((4, 0), (4, 2), (3, 1), (1, 4), (5, 3)):
+        if (min(s.w, s.h) >> (levels - 1)) < 1:
+            continue
+        dims = [(s.w >> l, s.h >> l) for l in range(levels)]
+        d_base = torch.full((n, s.w * s.h), -7.0, dtype=torch.float32, device="cuda")
+        lv = [torch.full((n, w * h), -7.0, dtype=torch.float32, device="cuda") for w, h in dims[1:]]
+        dI = [torch.full((n, w * h * 3), -7.0, dtype=torch.float32, device="cuda") for w, h in dims]
+        ab = [torch.full((n, w * h), -7.0, dtype=torch.float32, device="cuda") for w, h in dims]
+        s.ctx.process_pyramid_gradients_batch(d_in.data_ptr(), d_base.data_ptr(), levels, [t.data_ptr() for t in lv], [t.data_ptr() for t in dI],
+                                              [t.data_ptr() for t in ab], n, 15, chunk, st)
+        torch.cuda.synchronize()
+        for f in range(n):
+            src = s.want(oracle, frames[f], 1, 1, 1, 1)
+            for l, (w, h) in enumerate(dims):
+                if l:
+                    src = oracle.pyramid_level(src, dims[l - 1][0], dims[l - 1][1])
+                got = (d_base if l == 0 else lv[l - 1])[f].cpu().numpy()
+                assert bits_equal(got, src), (name, levels, chunk, f, l)
+                want_dI, want_abs = oracle.gradients(src, w, h)
+                assert bits_equal(dI[l][f].cpu().numpy(), want_dI), (name, levels, chunk, f, l, "dI")
+                assert bits_equal(ab[l][f].cpu().numpy(), want_abs), (name, levels, chunk, f, l, "abs2")
+
+
 @pytest.mark.parametrize("name", ["small_crop", "ragged"])
 def test_process_frames_host_pipeline(name, setups, oracle):
     """Many host frames in one call (chunks on two streams): equal to the oracle frame by frame, with
