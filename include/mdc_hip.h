@@ -167,6 +167,20 @@ void mdc_host_free(void* p);
 int mdc_process_frames_host(mdc_ctx* ctx, const uint8_t* const* raw, float* const* out, int64_t nframes,
                             unsigned flags);
 
+/* JPEG ingest with the inverse DCT on the GPU.  The host does the serial half of JPEG decoding
+ * -- Huffman decoding, mdch_decode_jpeg_coefs in include/mdc_host.h -- into a coefficient RECORD per frame:
+ *   [64 x uint16 luma quantisation table, natural order][blocks_rows x blocks_w blocks of 64 int16 quantised coefficients,
+ *   natural order]        (block grid padded to whole MCUs; the frame covers the first ceil(h/8) rows, ceil(w/8) blocks a row)
+ * mdc_process_jpeg_frames_host is mdc_process_frames_host with record i in place of raw frame i: records go up over PCIe
+ * (page-locked memory: mdc_host_alloc), the device dequantises + runs libjpeg's islow integer inverse DCT into the frame
+ * buffer the fused kernel reads, results come back as before.  Identical to decoding on the host and calling
+ * mdc_process_frames_host, bit for bit (integer arithmetic).  mdc_jpeg_idct_batch_device is the device stage alone:
+ * nframes records, record_bytes apart (multiple of 16), -> nframes * w * h bytes. */
+int mdc_process_jpeg_frames_host(mdc_ctx* ctx, const void* const* records, int64_t record_bytes, int blocks_w, int blocks_rows,
+                                 float* const* out, int64_t nframes, unsigned flags);
+int mdc_jpeg_idct_batch_device(mdc_ctx* ctx, const void* d_records, int64_t record_bytes, uint8_t* d_frames, int w, int h, int blocks_w,
+                               int blocks_rows, int64_t nframes, void* stream);
+
 /* ---- device-pointer, batched: the throughput path --------------------------- */
 
 /* unMapImage over nframes back-to-back frames (in: nframes*w*h u8; out: same count f32). */

@@ -75,6 +75,7 @@ int mdch_reader_get_images(mdch_reader*, int first, int count, int rectify, int 
 int mdch_reader_get_raw(mdch_reader*, int id, unsigned char* out, long cap, int wh[2]); /* getImageRaw(); 1 / 0 */
 void mdch_reader_set_threads(mdch_reader*, int n);       /* setDecodeThreads() */
 void mdch_reader_set_prefetch(mdch_reader*, int frames); /* setPrefetch() */
+void mdch_reader_set_gpu_jpeg(mdch_reader*, int on);      /* setGpuJpeg() */
 const char* mdch_reader_last_error(mdch_reader*);
 void mdch_reader_prefetch_stats(mdch_reader*, long hits_misses[2]); /* getPrefetchStats() */
 
@@ -82,6 +83,15 @@ void mdch_reader_prefetch_stats(mdch_reader*, long hits_misses[2]); /* getPrefet
  * with the reason in err (errcap bytes).  wh = decoded size (also set when only cap was too small). */
 int mdch_decode_gray8(const unsigned char* data, size_t n, unsigned char* out, size_t cap, int wh[2], char* err,
                       size_t errcap);
+
+/* The host half of JPEG decoding for the GPU stage (mdc_process_jpeg_frames_host / mdc_jpeg_idct_batch_device, include/mdc_hip.h):
+ * Huffman-decodes a baseline or progressive JPEG into a coefficient record -- 64 x uint16 luma quantisation table (natural
+ * order), then rows of `pitch_blocks` blocks of 64 int16 quantised luma coefficients (natural order) -- WITHOUT the inverse
+ * DCT.  dims = {w, h, pitch_blocks, block rows}.  mdch_jpeg_record_bytes(w, h, dims2) gives the record size and the
+ * {pitch, rows} that fit every sampling layout of a w x h file.  1 on success, else 0 with the reason in err. */
+size_t mdch_jpeg_record_bytes(int w, int h, int pitch_rows[2]);
+int mdch_decode_jpeg_record(const unsigned char* data, size_t n, void* record, size_t record_bytes, int pitch_blocks, int dims[4], char* err,
+                            size_t errcap);
 
 /* ExposureImage's pixel pool (include/mono_dataset_code/ExposureImage.h). */
 float* mdch_image_alloc(unsigned long nfloats);

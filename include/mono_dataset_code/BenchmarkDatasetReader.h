@@ -71,6 +71,9 @@ class DatasetReader {
 
   void setDecodeThreads(int n);  // worker threads of the decode pool; 0 = automatic (default)
   void setPrefetch(int frames);  // frames decoded ahead after a getImage (default 16, 0 = off)
+  // getImages on JPEG sequences: the host only Huffman-decodes, the inverse DCT runs on the GPU in front of the fused pass
+  // (same bytes; default on, also MDC_GPU_JPEG=0 in the environment)
+  void setGpuJpeg(bool on);
   const char* lastError() const; // why the last getImage / getImages / getImageRaw returned 0 / fewer images
   void getPrefetchStats(long* hits, long* misses) const;  // frames found decoded ahead / decoded by the calling thread
 

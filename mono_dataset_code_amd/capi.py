@@ -26,7 +26,7 @@ OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 HIP_SYMBOLS = [
     "mdc_create", "mdc_destroy", "mdc_last_error", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
     "mdc_set_remap", "mdc_unmap_host", "mdc_undistort_host_f32", "mdc_undistort_host_u8", "mdc_process_host",
-    "mdc_host_alloc", "mdc_host_free", "mdc_process_frames_host",
+    "mdc_host_alloc", "mdc_host_free", "mdc_process_frames_host", "mdc_process_jpeg_frames_host", "mdc_jpeg_idct_batch_device",
     "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
     "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device",
     "mdc_distort_points_device", "mdc_distort_points_host", "mdc_export_tables", "mdc_import_tables",
@@ -42,7 +42,8 @@ HOST_SYMBOLS = [
     "mdch_photo_g", "mdch_photo_vignette", "mdch_photo_unmap", "mdch_bind", "mdch_pack_tables",
     "mdch_reader_create", "mdch_reader_destroy", "mdch_reader_num_images", "mdch_reader_timestamp", "mdch_reader_exposure",
     "mdch_reader_dims", "mdch_reader_get_image", "mdch_reader_get_images", "mdch_reader_get_raw", "mdch_reader_set_threads",
-    "mdch_reader_set_prefetch", "mdch_reader_last_error", "mdch_reader_prefetch_stats", "mdch_decode_gray8", "mdch_image_alloc", "mdch_image_free",
+    "mdch_reader_set_prefetch", "mdch_reader_set_gpu_jpeg", "mdch_reader_last_error", "mdch_reader_prefetch_stats", "mdch_decode_gray8", "mdch_jpeg_record_bytes",
+    "mdch_decode_jpeg_record", "mdch_image_alloc", "mdch_image_free",
     "mdch_image_pool_trim", "mdch_image_pool_idle_bytes",
 ]
 
@@ -132,6 +133,9 @@ def hip_lib():
         L.mdc_host_free.argtypes = [_vp]
         L.mdc_host_free.restype = None
         L.mdc_process_frames_host.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), _i64, C.c_uint]
+        if hasattr(L, "mdc_process_jpeg_frames_host"):
+            L.mdc_process_jpeg_frames_host.argtypes = [_vp, C.POINTER(_vp), _i64, _i, _i, C.POINTER(_vp), _i64, C.c_uint]
+            L.mdc_jpeg_idct_batch_device.argtypes = [_vp, _vp, _i64, _vp, _i, _i, _i, _i, _i64, _vp]
         L.mdc_unmap_batch_device.argtypes = [_vp, _vp, _vp, _i64, C.c_uint, _vp]
         L.mdc_process_batch_device.argtypes = [_vp, _vp, _vp, _i64, C.c_uint, _vp]
         L.mdc_undistort_batch_device_f32.argtypes = [_vp, _vp, _vp, _i64, _vp]
@@ -241,12 +245,16 @@ def host_lib():
         L.mdch_reader_set_threads.argtypes = [_vp, _i]
         L.mdch_reader_set_threads.restype = None
         L.mdch_reader_set_prefetch.argtypes = [_vp, _i]
+        L.mdch_reader_set_gpu_jpeg.argtypes = [_vp, _i]
         L.mdch_reader_set_prefetch.restype = None
         L.mdch_reader_last_error.argtypes = [_vp]
         L.mdch_reader_last_error.restype = C.c_char_p
         L.mdch_reader_prefetch_stats.argtypes = [_vp, _vp]
         L.mdch_reader_prefetch_stats.restype = None
         L.mdch_decode_gray8.argtypes = [_vp, _sz, _vp, _sz, _vp, C.c_char_p, _sz]
+        L.mdch_jpeg_record_bytes.argtypes = [_i, _i, _vp]
+        L.mdch_jpeg_record_bytes.restype = _sz
+        L.mdch_decode_jpeg_record.argtypes = [_vp, _sz, _vp, _sz, _i, _vp, C.c_char_p, _sz]
         L.mdch_image_alloc.argtypes = [C.c_ulong]
         L.mdch_image_alloc.restype = _vp
         L.mdch_image_free.argtypes = [_vp]
@@ -369,6 +377,18 @@ class Context:
         a = (_vp * max(1, n))(*[_np_ptr(r) for r in raws])
         b = (_vp * max(1, n))(*[_np_ptr(o) for o in outs])
         self._chk(self._L.mdc_process_frames_host(self._h, a, b, n, flags))
+
+    def process_jpeg_frames_host(self, records, record_bytes, blocks_w, blocks_rows, outs, flags):
+        """records: numpy uint8 arrays (one JPEG coefficient record per frame, decode_jpeg_record), outs: f32 result arrays."""
+        n = len(records)
+        assert len(outs) == n
+        a = (_vp * max(1, n))(*[_np_ptr(r) for r in records])
+        b = (_vp * max(1, n))(*[_np_ptr(o) for o in outs])
+        self._chk(self._L.mdc_process_jpeg_frames_host(self._h, a, record_bytes, blocks_w, blocks_rows, b, n, flags))
+
+    def jpeg_idct_batch(self, d_records, record_bytes, d_frames, w, h, blocks_w, blocks_rows, nframes, stream=0):
+        self._chk(self._L.mdc_jpeg_idct_batch_device(self._h, d_records, record_bytes, d_frames, w, h, blocks_w, blocks_rows, nframes,
+                                                     stream if stream else None))
 
     # device-pointer batched calls (addresses as ints)
     def unmap_batch(self, d_in, d_out, nframes, flags, stream=0):
@@ -675,6 +695,25 @@ def decode_gray8(data):
     return out.reshape(int(wh[1]), int(wh[0]))
 
 
+def jpeg_record_bytes(w, h):
+    """-> (record bytes, pitch in blocks, block rows) that fit every sampling layout of a w x h JPEG."""
+    pr = np.zeros(2, np.int32)
+    n = host_lib().mdch_jpeg_record_bytes(w, h, _np_ptr(pr))
+    return int(n), int(pr[0]), int(pr[1])
+
+
+def decode_jpeg_record(data, record, pitch_blocks):
+    """Huffman-decodes a JPEG byte string into `record` (numpy uint8, jpeg_record_bytes long; page-locked for the GPU stage):
+    quantisation table + quantised luma coefficients, no inverse DCT.  -> (w, h, pitch_blocks, block rows); ValueError on failure."""
+    L = host_lib()
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    dims = np.zeros(4, np.int32)
+    err = C.create_string_buffer(256)
+    if not L.mdch_decode_jpeg_record(_np_ptr(buf), buf.size, _np_ptr(record), record.size, pitch_blocks, _np_ptr(dims), err, 256):
+        raise ValueError(err.value.decode())
+    return tuple(int(x) for x in dims)
+
+
 class DatasetReader:
     """class DatasetReader (include/mono_dataset_code/BenchmarkDatasetReader.h) through the C facade."""
 
@@ -716,6 +755,9 @@ class DatasetReader:
 
     def set_prefetch(self, n):
         self._L.mdch_reader_set_prefetch(self._h, n)
+
+    def set_gpu_jpeg(self, on):
+        self._L.mdch_reader_set_gpu_jpeg(self._h, int(bool(on)))
 
     def get_image(self, i, rectify, g, v, o):
         """-> (image (h, w) float32, timestamp, exposure, id) or None (getImage returned 0)."""

@@ -26,6 +26,7 @@
 #include "MdcBind.h"
 #include "host_device.h"
 #include "image_codecs.h"
+#include "image_codecs_internal.h"
 #include "mdc_hip.h"
 #include "zip_reader.h"
 
@@ -40,6 +41,11 @@ struct Decode {
   int w = 0, h = 0;
   bool ok = false, done = true, busy = false;  // busy: queued or being decoded
   bool consumed = true;                        // prefetch cache: already handed to the caller (or never filled)
+  // getImages with the GPU JPEG stage: a JPEG file is only Huffman-decoded, into a coefficient record at dst (pitch in blocks
+  // as asked for); is_record tells what dst holds afterwards (other formats still decode to pixels)
+  int want_record_pitch = 0;
+  bool is_record = false;
+  int rec_rows = 0;
   std::string err;
   unsigned long stamp = 0;  // prefetch cache: age
 };
@@ -105,6 +111,12 @@ struct DatasetReader::State {
   std::vector<HostBuffer> ring;  // kRing * kChunk frames (250 MB at 1280x1024, allocated on the first getImages)
 
   size_t frame_bytes() const { return (size_t)W * H; }
+  // GPU JPEG stage of getImages: JPEG frames travel as coefficient records (2 bytes per pixel + table), the inverse DCT runs on
+  // the device.  Default on; MDC_GPU_JPEG=0 or setGpuJpeg(false) keeps the whole decode on the host.
+  bool gpu_jpeg = true;
+  int rec_pitch = 0, rec_rows = 0;
+  size_t rec_bytes = 0;
+  size_t ring_bytes = 0;  // bytes of one ring buffer (a frame, or a record when the GPU JPEG stage is on)
 
   // ---- decoding (any thread) ------------------------------------------------------------------
   // Never throws: it runs in the decode pool's threads, where an escaping exception (bad_alloc on a corrupt size field,
@@ -134,7 +146,23 @@ struct DatasetReader::State {
       d.err = "cannot read " + files[(size_t)d.id];
       return;
     }
-    d.ok = mdc_host::decode_gray8(bytes.data(), bytes.size(), d.dst, d.cap, &d.w, &d.h, &d.err);
+    d.is_record = false;
+    if (d.want_record_pitch > 0 && bytes.size() > 4 && bytes[0] == 0xff && bytes[1] == 0xd8 && d.cap > 256) {
+      mdc_host::JpegCoefSink sink;
+      sink.coef = reinterpret_cast<int16_t*>(d.dst + 128);
+      sink.cap_blocks = (d.cap - 128) / 128;
+      sink.pitch_blocks = d.want_record_pitch;
+      d.ok = mdc_host::decode_jpeg_coefs(bytes.data(), bytes.size(), &sink, &d.err);
+      if (d.ok) {
+        std::memcpy(d.dst, sink.quant, 128);
+        d.w = sink.w;
+        d.h = sink.h;
+        d.rec_rows = sink.blocks_rows;
+        d.is_record = true;
+      }
+    } else {
+      d.ok = mdc_host::decode_gray8(bytes.data(), bytes.size(), d.dst, d.cap, &d.w, &d.h, &d.err);
+    }
     if (!d.ok) d.err = files[(size_t)d.id] + ": " + d.err;
   }
 
@@ -314,6 +342,7 @@ void list_folder(const std::string& dir, std::vector<std::string>& files) {
 }  // namespace
 
 DatasetReader::DatasetReader(std::string folder) : s_(new State()) {
+  if (const char* e = std::getenv("MDC_GPU_JPEG")) s_->gpu_jpeg = std::atoi(e) != 0;
   State& s = *s_;
   s.path = folder;
   list_folder(s.path + "images/", s.files);
@@ -414,6 +443,8 @@ void DatasetReader::setDecodeThreads(int n) {
   s.want_threads = n;
 }
 
+void DatasetReader::setGpuJpeg(bool on) { s_->gpu_jpeg = on; }
+
 void DatasetReader::setPrefetch(int frames) {
   State& s = *s_;
   s.prefetch = std::max(0, std::min(frames, 64));
@@ -485,9 +516,17 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
     return 0;
   }
   const int C = State::kChunk, RG = State::kRing;
-  if (s.ring.empty()) {
+  // coefficient records (include/mdc_hip.h): MCUs are at most 4 x 4 blocks, so a grid rounded up to multiples of 4 blocks
+  // holds every sampling layout of a W x H file (the same rule as mdch_jpeg_record_bytes)
+  s.rec_pitch = ((s.W + 7) / 8 + 3) & ~3;
+  s.rec_rows = ((s.H + 7) / 8 + 3) & ~3;
+  s.rec_bytes = 128 + (size_t)s.rec_pitch * s.rec_rows * 128;
+  const size_t want_bytes = s.gpu_jpeg ? std::max(s.frame_bytes(), s.rec_bytes) : s.frame_bytes();
+  if (s.ring.empty() || s.ring_bytes < want_bytes) {
+    for (auto& m : s.ring) m.release();
     s.ring.assign((size_t)RG * C, HostBuffer());
-    for (auto& m : s.ring) m.alloc(s.frame_bytes());
+    for (auto& m : s.ring) m.alloc(want_bytes);
+    s.ring_bytes = want_bytes;
   }
   s.start_pool();
   std::vector<Decode> rec((size_t)count);
@@ -498,7 +537,8 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
       Decode& d = rec[(size_t)i];
       d.id = first + i;
       d.dst = s.ring[(size_t)((k % RG) * C + (i - k * C))].p;
-      d.cap = s.frame_bytes();
+      d.cap = s.ring_bytes;
+      d.want_record_pitch = s.gpu_jpeg ? s.rec_pitch : 0;
       s.submit(&d);
     }
     s.cv_job.notify_all();
@@ -511,6 +551,8 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
   int produced = 0;
   std::vector<const uint8_t*> src;
   std::vector<float*> dst;
+  std::vector<const void*> rsrc;  // frames of the chunk that arrived as JPEG coefficient records
+  std::vector<float*> rdst;
   for (int k = 0; k < nchunks; k++) {
     const int i0 = k * C, i1 = std::min(count, (k + 1) * C);
     const double tw = now();
@@ -525,6 +567,8 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
     t_wait += now() - tw;
     src.clear();
     dst.clear();
+    rsrc.clear();
+    rdst.clear();
     for (int i = i0; i < i1; i++) {
       const Decode& d = rec[(size_t)i];
       const int id = first + i;
@@ -536,12 +580,19 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
       }
       out[i] = rectify ? new ExposureImage(s.w, s.h, s.timestamps[(size_t)id], s.exposures[(size_t)id], id)
                        : new ExposureImage(s.W, s.H, s.timestamps[(size_t)id], s.exposures[(size_t)id], id);
-      src.push_back(d.dst);
-      dst.push_back(out[i]->image);
+      if (d.is_record && d.rec_rows <= s.rec_rows) {
+        rsrc.push_back(d.dst);
+        rdst.push_back(out[i]->image);
+      } else {
+        src.push_back(d.dst);
+        dst.push_back(out[i]->image);
+      }
     }
     // chunk k on the GPU (uploads, kernels and downloads pipelined inside the call) while the pool decodes chunk k+1
     const double tg = now();
-    const int grc = src.empty() ? MDC_OK : mdc_process_frames_host(s.gpu, src.data(), dst.data(), (int64_t)src.size(), flags);
+    int grc = src.empty() ? MDC_OK : mdc_process_frames_host(s.gpu, src.data(), dst.data(), (int64_t)src.size(), flags);
+    if (grc == MDC_OK && !rsrc.empty())  // records: Huffman-decoded on the host, inverse DCT on the device
+      grc = mdc_process_jpeg_frames_host(s.gpu, rsrc.data(), (int64_t)s.rec_bytes, s.rec_pitch, s.rec_rows, rdst.data(), (int64_t)rsrc.size(), flags);
     t_gpu += now() - tg;
     if (grc != MDC_OK) {
       s.err = mdc_last_error(s.gpu);
@@ -551,7 +602,7 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
         out[i] = 0;
       }
     } else {
-      produced += (int)src.size();
+      produced += (int)src.size() + (int)rsrc.size();
     }
     if (k + RG < nchunks) submit_chunk(k + RG);  // chunk k's buffers are free again
   }

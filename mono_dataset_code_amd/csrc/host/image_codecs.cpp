@@ -369,7 +369,7 @@ struct Comp {
   int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0;
 };
 
-bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap, int* w, int* h, std::string* err) {
+bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap, int* w, int* h, std::string* err, JpegCoefSink* sink = nullptr) {
   uint16_t qt[4][64];
   bool have_qt[4] = {false, false, false, false};
   Huff dc[4], ac[4];
@@ -425,14 +425,14 @@ bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap
       *w = W;
       *h = H;
     } else if (m == 0xc2) {  // progressive: its own decoder (image_codecs_ext.cpp)
-      return jpeg_progressive_gray8(d, n, out, cap, w, h, err);
+      return jpeg_progressive_gray8(d, n, out, cap, w, h, err, sink);
     } else if (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
       return fail(err, "JPEG: lossless, hierarchical and arithmetic-coded files are not supported");
     } else if (m == 0xdd) {  // DRI
       if (sl >= 2) restart = s[0] << 8 | s[1];
     } else if (m == 0xda) {  // SOS: the one scan of a baseline file
       if (!have_sof) return fail(err, "JPEG: scan before frame header");
-      if ((size_t)W * H > cap) return fail(err, "frame larger than the buffer");
+      if (!sink && (size_t)W * H > cap) return fail(err, "frame larger than the buffer");
       const int ns = s[0];
       if (ns != ncomp || sl < 1 + 2 * (size_t)ns + 3) return fail(err, "JPEG: only single-scan files are supported");
       for (int i = 0; i < ns; i++) {
@@ -455,7 +455,16 @@ bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap
       const int mx = (W + mcu_w - 1) / mcu_w, my = (H + mcu_h - 1) / mcu_h;
       const size_t pw = (size_t)mx * mcu_w;  // padded luma row (luma has the full resolution)
       static thread_local std::vector<unsigned char> rows;
-      rows.resize(pw * mcu_h);
+      if (!sink) rows.resize(pw * mcu_h);
+      if (sink) {  // coefficient output: quantised luma coefficients, natural order, [block row][block][64]; no inverse DCT here
+        sink->w = W;
+        sink->h = H;
+        if (sink->pitch_blocks && sink->pitch_blocks < mx * yh) return fail(err, "coefficient row pitch too small for this file");
+        sink->blocks_w = sink->pitch_blocks ? sink->pitch_blocks : mx * yh;
+        sink->blocks_rows = my * yv;
+        if ((size_t)sink->blocks_w * sink->blocks_rows > sink->cap_blocks) return fail(err, "frame larger than the coefficient buffer");
+        for (int i = 0; i < 64; i++) sink->quant[i] = qt[comp[0].tq][i];
+      }
       Bits b;
       b.p = d + p + len;
       b.end = d + n;
@@ -475,12 +484,20 @@ bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap
             const int nb = ncomp == 1 ? 1 : comp[c].h * comp[c].v;
             for (int k = 0; k < nb; k++) {
               const bool luma = c == 0;
-              if (luma) memset(coef, 0, sizeof coef);
+              int16_t* blk = nullptr;  // (coefficient output) this luma block
+              if (luma && sink) {
+                const int bx = ncomp == 1 ? 0 : k % comp[c].h, by = ncomp == 1 ? 0 : k / comp[c].h;
+                blk = sink->coef + ((size_t)(y * yv + by) * sink->blocks_w + (size_t)x * yh + bx) * 64;
+                memset(blk, 0, 64 * sizeof(int16_t));
+              } else if (luma) {
+                memset(coef, 0, sizeof coef);
+              }
               const uint16_t* q = qt[comp[c].tq];
               int t = decode_sym(b, dc[comp[c].td]);
               if (t < 0 || t > 11) return fail(err, "JPEG: bad DC code");
               comp[c].pred += t ? extend(b.get(t), t) : 0;
-              if (luma) coef[0] = comp[c].pred * q[0];
+              if (blk) blk[0] = (int16_t)comp[c].pred;
+              else if (luma) coef[0] = comp[c].pred * q[0];
               bool dc_only = true;
               const Huff& act = ac[comp[c].ta];
               for (int i = 1; i < 64;) {
@@ -490,7 +507,8 @@ bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap
                   i += (fa >> 4) & 15;
                   if (i > 63) return fail(err, "JPEG: coefficient index out of range");
                   b.skip(fa & 15);
-                  if (luma) coef[kZigzag[i]] = (fa >> 8) * q[kZigzag[i]];
+                  if (blk) blk[kZigzag[i]] = (int16_t)(fa >> 8);
+                  else if (luma) coef[kZigzag[i]] = (fa >> 8) * q[kZigzag[i]];
                   dc_only = false;
                   i++;
                   continue;
@@ -506,11 +524,12 @@ bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap
                 i += r;
                 if (i > 63) return fail(err, "JPEG: coefficient index out of range");
                 const int v = extend(b.get(sz), sz);
-                if (luma) coef[kZigzag[i]] = v * q[kZigzag[i]];
+                if (blk) blk[kZigzag[i]] = (int16_t)v;
+                else if (luma) coef[kZigzag[i]] = v * q[kZigzag[i]];
                 dc_only = false;
                 i++;
               }
-              if (luma) {
+              if (luma && !sink) {
                 const int bx = ncomp == 1 ? 0 : k % comp[c].h, by = ncomp == 1 ? 0 : k / comp[c].h;
                 idct_islow(coef, rows.data() + (size_t)by * 8 * pw + (size_t)x * mcu_w + (size_t)bx * 8, pw, dc_only);
               }
@@ -519,7 +538,8 @@ bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap
           if (restart) to_restart--;
         }
         const int y0 = y * mcu_h, ny = std::min(mcu_h, H - y0);
-        for (int r = 0; r < ny; r++) memcpy(out + (size_t)(y0 + r) * W, rows.data() + (size_t)r * pw, (size_t)W);
+        if (!sink)
+          for (int r = 0; r < ny; r++) memcpy(out + (size_t)(y0 + r) * W, rows.data() + (size_t)r * pw, (size_t)W);
       }
       return true;
     }
@@ -531,6 +551,13 @@ bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap
 }  // namespace
 
 void jpeg_idct_islow(const int* coef, unsigned char* out, size_t stride, bool dc_only) { idct_islow(coef, out, stride, dc_only); }
+
+bool decode_jpeg_coefs(const unsigned char* d, size_t n, JpegCoefSink* sink, std::string* err) {
+  if (!sink || !sink->coef) return fail(err, "no coefficient buffer");
+  if (n < 4 || d[0] != 0xff || d[1] != 0xd8) return fail(err, "not a JPEG file");
+  int w = 0, h = 0;
+  return jpeg_gray8(d, n, nullptr, 0, &w, &h, err, sink);
+}
 
 bool decode_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap, int* w, int* h, std::string* err) {
   *w = *h = 0;

@@ -273,7 +273,7 @@ struct PComp {
 
 }  // namespace
 
-bool jpeg_progressive_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap, int* w, int* h, std::string* err) {
+bool jpeg_progressive_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap, int* w, int* h, std::string* err, JpegCoefSink* sink) {
   uint16_t qt[4][64];
   bool have_qt[4] = {false, false, false, false};
   PHuff dc[4], ac[4];
@@ -335,7 +335,7 @@ bool jpeg_progressive_gray8(const unsigned char* d, size_t n, unsigned char* out
       if (comp[0].h != hmax || comp[0].v != vmax) return fail(err, "JPEG: luma is subsampled; unsupported");
       *w = W;
       *h = H;
-      if ((size_t)W * H > cap) return fail(err, "frame larger than the buffer");
+      if (!sink && (size_t)W * H > cap) return fail(err, "frame larger than the buffer");
       mx = (W + 8 * hmax - 1) / (8 * hmax);
       my = (H + 8 * vmax - 1) / (8 * vmax);
       lbw = mx * hmax;
@@ -491,8 +491,20 @@ bool jpeg_progressive_gray8(const unsigned char* d, size_t n, unsigned char* out
   }
   if (!have_sof || !saw_luma_scan) return fail(err, "JPEG: no scan found");
   if (!have_qt[comp[0].tq]) return fail(err, "JPEG: scan refers to a missing table");
-  // coefficients -> samples: dequantise, islow IDCT, crop
   const uint16_t* q = qt[comp[0].tq];
+  if (sink) {  // coefficient output (see JpegCoefSink): the scans' result as it is
+    sink->w = W;
+    sink->h = H;
+    if (sink->pitch_blocks && sink->pitch_blocks < lbw) return fail(err, "coefficient row pitch too small for this file");
+    sink->blocks_w = sink->pitch_blocks ? sink->pitch_blocks : lbw;
+    sink->blocks_rows = lbh;
+    if ((size_t)sink->blocks_w * lbh > sink->cap_blocks) return fail(err, "frame larger than the coefficient buffer");
+    for (int r = 0; r < lbh; r++)
+      memcpy(sink->coef + (size_t)r * sink->blocks_w * 64, coef.data() + (size_t)r * lbw * 64, (size_t)lbw * 64 * sizeof(int16_t));
+    for (int i = 0; i < 64; i++) sink->quant[i] = q[i];
+    return true;
+  }
+  // coefficients -> samples: dequantise, islow IDCT, crop
   std::vector<unsigned char> rows((size_t)lbw * 8 * 8);
   int cf[64];
   for (int by = 0; by < lch; by++) {

@@ -18,7 +18,21 @@ struct PngAny {
 bool png_decode_any(const unsigned char* data, size_t n, PngAny& im, std::string* err);
 void png_any_to_gray8(const PngAny& im, unsigned char* out);  // w*h bytes, OpenCV's grayscale read of that PNG
 
-bool jpeg_progressive_gray8(const unsigned char* data, size_t n, unsigned char* out, size_t cap, int* w, int* h, std::string* err);
+// JPEG entropy decoding WITHOUT the inverse DCT: the quantised luma coefficients of a file, natural order, 64 int16 per
+// 8x8 block, [blocks_rows][blocks_w][64] (the grid is padded to whole MCUs; the image covers the first ceil(h/8) rows and
+// ceil(w/8) blocks of a row), + the luma quantisation table (natural order).  What the GPU stage of the reader takes
+// (mdc_jpeg_idct_batch_device dequantises, inverts and crops on the device).  `coef` / `cap_blocks` are the caller's.
+struct JpegCoefSink {
+  int16_t* coef = nullptr;
+  size_t cap_blocks = 0;
+  int pitch_blocks = 0;  // in: row pitch in blocks the caller wants (0 = the file's own MCU-padded width)
+  uint16_t quant[64];
+  int w = 0, h = 0, blocks_w = 0, blocks_rows = 0;  // out: blocks_w = the row pitch used
+};
+bool decode_jpeg_coefs(const unsigned char* data, size_t n, JpegCoefSink* sink, std::string* err);
+
+bool jpeg_progressive_gray8(const unsigned char* data, size_t n, unsigned char* out, size_t cap, int* w, int* h, std::string* err,
+                            JpegCoefSink* sink = nullptr);
 // libjpeg's islow inverse DCT on dequantised coefficients in natural order (image_codecs.cpp)
 void jpeg_idct_islow(const int* coef, unsigned char* out, size_t stride, bool dc_only);
 

@@ -7,6 +7,7 @@
 #include "BenchmarkDatasetReader.h"
 #include "FOVUndistorter.h"
 #include "image_codecs.h"
+#include "image_codecs_internal.h"
 #include "MdcBind.h"
 #include "PhotometricUndistorter.h"
 
@@ -267,8 +268,46 @@ int mdch_reader_get_raw(mdch_reader* h, int id, unsigned char* out, long cap, in
 }
 void mdch_reader_set_threads(mdch_reader* h, int n) { h->r->setDecodeThreads(n); }
 void mdch_reader_set_prefetch(mdch_reader* h, int n) { h->r->setPrefetch(n); }
+void mdch_reader_set_gpu_jpeg(mdch_reader* h, int on) { h->r->setGpuJpeg(on != 0); }
 const char* mdch_reader_last_error(mdch_reader* h) { return h->r->lastError(); }
 void mdch_reader_prefetch_stats(mdch_reader* h, long hm[2]) { h->r->getPrefetchStats(&hm[0], &hm[1]); }
+
+size_t mdch_jpeg_record_bytes(int w, int h, int pitch_rows[2]) {
+  // MCUs are at most 4 x 4 blocks: a pitch / row count rounded up to a multiple of 4 blocks holds every sampling layout
+  const int pitch = ((w + 7) / 8 + 3) & ~3, rows = ((h + 7) / 8 + 3) & ~3;
+  if (pitch_rows) {
+    pitch_rows[0] = pitch;
+    pitch_rows[1] = rows;
+  }
+  return 128 + (size_t)pitch * rows * 128;
+}
+
+int mdch_decode_jpeg_record(const unsigned char* data, size_t n, void* record, size_t record_bytes, int pitch_blocks, int dims[4], char* err,
+                            size_t errcap) {
+  std::string e;
+  bool ok = false;
+  if (record && record_bytes >= 128 + 128 && dims) {
+    mdc_host::JpegCoefSink sink;
+    sink.coef = reinterpret_cast<int16_t*>(static_cast<unsigned char*>(record) + 128);
+    sink.cap_blocks = (record_bytes - 128) / 128;
+    sink.pitch_blocks = pitch_blocks;
+    ok = mdc_host::decode_jpeg_coefs(data, n, &sink, &e);
+    if (ok) {
+      memcpy(record, sink.quant, 128);
+      dims[0] = sink.w;
+      dims[1] = sink.h;
+      dims[2] = sink.blocks_w;
+      dims[3] = sink.blocks_rows;
+    }
+  } else {
+    e = "bad record buffer";
+  }
+  if (err && errcap) {
+    strncpy(err, e.c_str(), errcap - 1);
+    err[errcap - 1] = 0;
+  }
+  return ok ? 1 : 0;
+}
 
 int mdch_decode_gray8(const unsigned char* data, size_t n, unsigned char* out, size_t cap, int wh[2], char* err, size_t errcap) {
   std::string e;

@@ -125,7 +125,8 @@ struct mdc_ctx {
   hipEvent_t pipe_done[2] = {nullptr, nullptr};
   uint8_t* d_pipe_in[2] = {nullptr, nullptr};
   float* d_pipe_out[2] = {nullptr, nullptr};
-  size_t pipe_in_cap = 0, pipe_out_cap = 0;
+  void* d_pipe_rec[2] = {nullptr, nullptr};  // JPEG coefficient records of a chunk (mdc_process_jpeg_frames_host)
+  size_t pipe_in_cap = 0, pipe_out_cap = 0, pipe_rec_cap = 0;
 
   // vignetteCalib: bit pattern of the largest new vignette factor of ONE vignette step.  A ring of words, one per call:
   // steps that different threads put on different streams of one context never share a word.
@@ -826,7 +827,8 @@ void mdc_destroy(mdc_ctx* c) {
       if (c->pipe_stream[k]) (void)hipStreamSynchronize(c->pipe_stream[k]);
     unpin_all(c);
     free_plan(c);
-    void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_vcal_max, c->d_pipe_in[0], c->d_pipe_in[1], c->d_pipe_out[0], c->d_pipe_out[1]};
+    void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_vcal_max, c->d_pipe_in[0], c->d_pipe_in[1], c->d_pipe_out[0], c->d_pipe_out[1],
+                    c->d_pipe_rec[0], c->d_pipe_rec[1]};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     for (int k = 0; k < 2; k++) {
@@ -1611,9 +1613,12 @@ void mdc_host_free(void* p) {
   if (p) (void)hipHostFree(p);
 }
 
-int mdc_process_frames_host(mdc_ctx* c, const uint8_t* const* raw, float* const* out, int64_t nframes, unsigned flags) {
+// Common body of the two pipelined host calls: frame i comes from raw[i] (bytes) or, with `rec`, from the JPEG
+// coefficient record rec[i] through the device-side inverse DCT.
+static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const void* const* rec, int64_t record_bytes, int blocks_w,
+                                   int blocks_rows, float* const* out, int64_t nframes, unsigned flags, const char* who) {
   if (!c) return MDC_ERR_ARG;
-  if (nframes < 0 || (nframes > 0 && (!raw || !out))) return fail(c, MDC_ERR_ARG, "mdc_process_frames_host: bad argument");
+  if (nframes < 0 || (nframes > 0 && ((!raw && !rec) || !out))) return fail(c, MDC_ERR_ARG, "%s: bad argument", who);
   ReadLock lk(c->mu);
   std::lock_guard<std::mutex> pipe_lk(c->pipe_mu);  // one pipelined call at a time per context (it overlaps internally)
   DeviceGuard dg(c->device);
@@ -1623,27 +1628,35 @@ int mdc_process_frames_host(mdc_ctx* c, const uint8_t* const* raw, float* const*
   if (iw <= 0 || ih <= 0) return fail(c, MDC_ERR_STATE, "frame size unknown");
   const size_t n_in = (size_t)iw * ih;
   const size_t n_out = rect ? (size_t)c->out_w * c->out_h : n_in;
+  if (rec && (blocks_w < (iw + 7) / 8 || blocks_rows < (ih + 7) / 8 || record_bytes % 16 != 0 ||
+              record_bytes < 128 + (int64_t)blocks_w * blocks_rows * 128))
+    return fail(c, MDC_ERR_ARG, "%s: coefficient records do not describe a %dx%d frame", who, iw, ih);
   for (int64_t i = 0; i < nframes; i++)
-    if (!raw[i] || !out[i]) return fail(c, MDC_ERR_ARG, "mdc_process_frames_host: frame %lld has a NULL buffer", (long long)i);
-  constexpr int kChunk = 16;  // frames per slot: one kernel launch, 2 x 16 async copies
-  if (c->pipe_in_cap < kChunk * n_in || c->pipe_out_cap < kChunk * n_out * sizeof(float) || !c->pipe_stream[0] ||
+    if (!(rec ? rec[i] : (const void*)raw[i]) || !out[i]) return fail(c, MDC_ERR_ARG, "%s: frame %lld has a NULL buffer", who, (long long)i);
+  constexpr int kChunk = 16;  // frames per slot: one kernel launch (two with the inverse DCT), 2 x 16 async copies
+  const size_t rec_need = rec ? (size_t)kChunk * (size_t)record_bytes : 0;
+  if (c->pipe_in_cap < kChunk * n_in || c->pipe_out_cap < kChunk * n_out * sizeof(float) || c->pipe_rec_cap < rec_need || !c->pipe_stream[0] ||
       !c->pipe_stream[1]) {
-    c->pipe_in_cap = c->pipe_out_cap = 0;  // a failure part-way leaves "no slots", not stale capacities
+    const size_t rec_cap = std::max(rec_need, c->pipe_rec_cap);
+    c->pipe_in_cap = c->pipe_out_cap = c->pipe_rec_cap = 0;  // a failure part-way leaves "no slots", not stale capacities
     for (int k = 0; k < 2; k++) {
       if (c->pipe_stream[k]) MDC_HIP(c, hipStreamSynchronize(c->pipe_stream[k]));
       if (!c->pipe_stream[k]) MDC_HIP(c, hipStreamCreateWithFlags(&c->pipe_stream[k], hipStreamNonBlocking));
       if (!c->pipe_done[k]) MDC_HIP(c, hipEventCreateWithFlags(&c->pipe_done[k], hipEventDisableTiming));
-      if (c->d_pipe_in[k]) (void)hipFree(c->d_pipe_in[k]);
-      if (c->d_pipe_out[k]) (void)hipFree(c->d_pipe_out[k]);
-      c->d_pipe_in[k] = nullptr;
-      c->d_pipe_out[k] = nullptr;
+      for (void** p : {(void**)&c->d_pipe_in[k], (void**)&c->d_pipe_out[k], &c->d_pipe_rec[k]})
+        if (*p) {
+          (void)hipFree(*p);
+          *p = nullptr;
+        }
       MDC_HIP(c, hipMalloc(&c->d_pipe_in[k], kChunk * n_in));
       MDC_HIP(c, hipMalloc(&c->d_pipe_out[k], kChunk * n_out * sizeof(float)));
+      if (rec_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_rec[k], rec_cap));
     }
     c->pipe_in_cap = kChunk * n_in;
     c->pipe_out_cap = kChunk * n_out * sizeof(float);
+    c->pipe_rec_cap = rec_cap;
   }
-  // chunk k runs entirely on stream k%2 (H2D, kernel, D2H in order); the two streams overlap one
+  // chunk k runs entirely on stream k%2 (H2D, kernel(s), D2H in order); the two streams overlap one
   // chunk's copies with the other's kernel.  Re-using a slot waits for its previous chunk.
   // On a failure the loop stops, BOTH streams are drained (asynchronous copies into the caller's buffers
   // may still be in flight) and only then the error is returned.
@@ -1660,8 +1673,14 @@ int mdc_process_frames_host(mdc_ctx* c, const uint8_t* const* raw, float* const*
     hipStream_t s = c->pipe_stream[slot];
     const int n = (int)std::min<int64_t>(kChunk, nframes - f0);
     if (k >= 2) MDC_PIPE(hipEventSynchronize(c->pipe_done[slot]));
-    for (int i = 0; i < n; i++)
-      MDC_PIPE(hipMemcpyAsync(c->d_pipe_in[slot] + (size_t)i * n_in, raw[f0 + i], n_in, hipMemcpyHostToDevice, s));
+    if (rec) {
+      for (int i = 0; i < n; i++)
+        MDC_PIPE(hipMemcpyAsync((char*)c->d_pipe_rec[slot] + (size_t)i * record_bytes, rec[f0 + i], (size_t)record_bytes, hipMemcpyHostToDevice, s));
+      MDC_PIPE(launch_jpeg_idct(c->d_pipe_rec[slot], record_bytes, c->d_pipe_in[slot], iw, ih, blocks_w, blocks_rows, n, s));
+    } else {
+      for (int i = 0; i < n; i++)
+        MDC_PIPE(hipMemcpyAsync(c->d_pipe_in[slot] + (size_t)i * n_in, raw[f0 + i], n_in, hipMemcpyHostToDevice, s));
+    }
     if (he != hipSuccess) break;
     rc = enqueue_process(c, c->d_pipe_in[slot], c->d_pipe_out[slot], n, flags, s);
     if (rc != MDC_OK) break;
@@ -1680,6 +1699,25 @@ int mdc_process_frames_host(mdc_ctx* c, const uint8_t* const* raw, float* const*
 #undef MDC_PIPE
   if (rc != MDC_OK) return rc;
   if (he != hipSuccess) return fail(c, MDC_ERR_HIP, "%s: %s", what, hipGetErrorString(he));
+  return MDC_OK;
+}
+
+int mdc_process_frames_host(mdc_ctx* c, const uint8_t* const* raw, float* const* out, int64_t nframes, unsigned flags) {
+  return process_frames_pipeline(c, raw, nullptr, 0, 0, 0, out, nframes, flags, "mdc_process_frames_host");
+}
+
+int mdc_process_jpeg_frames_host(mdc_ctx* c, const void* const* records, int64_t record_bytes, int blocks_w, int blocks_rows,
+                                 float* const* out, int64_t nframes, unsigned flags) {
+  return process_frames_pipeline(c, nullptr, records, record_bytes, blocks_w, blocks_rows, out, nframes, flags, "mdc_process_jpeg_frames_host");
+}
+
+int mdc_jpeg_idct_batch_device(mdc_ctx* c, const void* d_records, int64_t record_bytes, uint8_t* d_frames, int w, int h, int blocks_w,
+                               int blocks_rows, int64_t nframes, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (!d_records || !d_frames || nframes < 0 || w <= 0 || h <= 0) return fail(c, MDC_ERR_ARG, "mdc_jpeg_idct_batch_device: bad argument");
+  ReadLock lk(c->mu);
+  DeviceGuard dg(c->device);
+  MDC_HIP(c, launch_jpeg_idct(d_records, record_bytes, d_frames, w, h, blocks_w, blocks_rows, nframes, (hipStream_t)stream));
   return MDC_OK;
 }
 

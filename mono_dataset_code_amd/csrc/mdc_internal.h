@@ -141,6 +141,12 @@ hipError_t launch_vcal_mask_coords(float* d_x, float* d_y, int64_t n, int wI, in
 // vignetteCalib's output smoothing (:541-566): four NaN-aware 3 x 3 mean passes; d_tt = result, d_ct = scratch
 hipError_t launch_vcal_smooth(const float* d_vig, int wI, int hI, float* d_tt, float* d_ct, hipStream_t s);
 
+// JPEG ingest, device half: coefficient records (per frame: 64 x u16 luma quantisation table, then blocks_rows x blocks_w blocks
+// of 64 quantised int16 coefficients, natural order; record_bytes apart) -> 8-bit frames (nframes * w * h), libjpeg's islow
+// inverse DCT (mdc_jpeg.hip)
+hipError_t launch_jpeg_idct(const void* d_records, int64_t record_bytes, uint8_t* d_frames, int w, int h, int blocks_w, int blocks_rows,
+                            int64_t nframes, hipStream_t s);
+
 // DSO hand-off of one pyramid level: (I, dx, dy) triples + absSquaredGrad (see mdc_vcal.hip)
 hipError_t launch_gradients(const float* d_level, float* d_dI, float* d_abs2, int w, int h, int64_t nframes, hipStream_t s);
 // ... of up to four levels in one launch

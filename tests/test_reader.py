@@ -131,3 +131,57 @@ def test_playdataset_driver_on_our_reader_equals_the_reference_reader(tmp_path, 
     for x, y in zip(outs["playback_ref"], outs[which]):
         assert x[:6] == y[:6]
         assert bits_equal(x[6], y[6]), x[:4]
+
+
+@pytest.mark.parametrize("size", [(64, 64), (100, 130), (17, 23), (250, 322), (256, 320)])
+def test_gpu_jpeg_stage_equals_the_host_decoder(size):
+    """Row f2's GPU JPEG stage: host Huffman decoding into coefficient records (mdch_decode_jpeg_record) + dequantisation and
+    libjpeg's islow inverse DCT on the device (mdc_jpeg_idct_batch_device) == the host decoder (itself pinned to libjpeg-turbo
+    in test_reader_cpu.py), byte for byte: gray and YCbCr with every chroma subsampling, baseline and progressive, restart
+    markers, sizes that are not whole blocks."""
+    import torch
+
+    from mono_dataset_code_amd import capi
+
+    h, w = size
+    img = textured(h, w, 4)
+    rgb = np.stack([img, np.roll(img, 3, 1), 255 - img], -1)
+    files = []
+    for kw in ({"quality": 30}, {"quality": 92}, {"quality": 100}, {"quality": 80, "restart_marker_blocks": 7}, {"quality": 85, "progressive": True}):
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, "JPEG", **kw)
+        files.append(b.getvalue())
+    for sub in (0, 1, 2):
+        for prog in (False, True):
+            b = io.BytesIO()
+            Image.fromarray(rgb).save(b, "JPEG", quality=88, subsampling=sub, progressive=prog)
+            files.append(b.getvalue())
+    rec_bytes, pitch, rows = capi.jpeg_record_bytes(w, h)
+    recs = np.zeros((len(files), rec_bytes), np.uint8)
+    for i, data in enumerate(files):
+        dims = capi.decode_jpeg_record(data, recs[i], pitch)
+        assert dims[:3] == (w, h, pitch) and dims[3] <= rows
+    ctx = capi.Context(0)
+    d_rec = torch.from_numpy(recs).cuda()
+    d_frames = torch.full((len(files), h * w), 77, dtype=torch.uint8, device="cuda")
+    ctx.jpeg_idct_batch(d_rec.data_ptr(), rec_bytes, d_frames.data_ptr(), w, h, pitch, rows, len(files), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_frames.cpu().numpy().reshape(len(files), h, w)
+    for i, data in enumerate(files):
+        assert np.array_equal(got[i], capi.decode_gray8(data)), i
+
+
+def test_reader_gpu_jpeg_on_and_off_give_the_same_images(tmp_path):
+    """getImages over a zipped JPEG sequence with the GPU JPEG stage (default) and without: identical ExposureImages."""
+    from mono_dataset_code_amd import capi
+
+    h, w = 256, 320
+    frames = frames_for(40, h, w)  # longer than one chunk of 32
+    make_sequence(str(tmp_path), frames, True, "jpg")
+    r = capi.DatasetReader(str(tmp_path))
+    on, ok_on, n_on = r.get_images(0, 40, 1, 1, 1, 1)
+    r.set_gpu_jpeg(False)
+    off, ok_off, n_off = r.get_images(0, 40, 1, 1, 1, 1)
+    assert n_on == n_off == 40 and ok_on.all() and ok_off.all()
+    for i in range(40):
+        assert bits_equal(on[i], off[i]), i

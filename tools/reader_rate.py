@@ -50,20 +50,25 @@ def make(kind):
     return d, sum(len(b) for b in blobs) / N
 
 
-def run(binary, folder, passes, *extra):
+def run(binary, folder, passes, *extra, env=None):
     p = os.path.join(BIN, binary)
     if not os.path.exists(p):
         return "%s: not built" % binary
-    r = subprocess.run([p, folder, "1111", str(passes)] + list(extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    r = subprocess.run([p, folder, "1111", str(passes)] + list(extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
+                       env=dict(os.environ, **(env or {})))
     lines = [l for l in r.stdout.splitlines() if l.startswith("READER_RATE")]
     return "\n".join(l.replace(BIN + "/", "") for l in lines) if lines else "%s failed: %s" % (binary, r.stdout[-300:])
 
 
-for kind in ("folder_png", "zip_png", "zip_jpg"):
+for kind in os.environ.get("MDC_RATE_KINDS", "folder_png,zip_png,zip_jpg").split(","):
     d, avg = make(kind)
     print("== %s: %d frames 1280x1024, %.0f KB/frame on disk" % (kind, N, avg / 1e3), flush=True)
     if kind != "zip_jpg":  # the test shim's imread / imdecode stand-ins decode PNG (libpng), not JPEG
         print(run("reader_rate_ref", d, 1), flush=True)
         print(run("reader_rate_mdc", d, 2), flush=True)
     print(run("reader_rate_fast", d, 3), flush=True)
+    if kind == "zip_jpg":  # getImages: whole decode on the host vs Huffman on the host + inverse DCT on the GPU
+        print("-- getImages, JPEG decoded entirely on the host (MDC_GPU_JPEG=0):", flush=True)
+        print(run("reader_rate_fast", d, 3, "batch", env={"MDC_GPU_JPEG": "0"}), flush=True)
+        print("-- getImages, GPU JPEG stage (host: Huffman only; device: dequantisation + inverse DCT):", flush=True)
     print(run("reader_rate_fast", d, 3, "batch"), flush=True)
