@@ -84,7 +84,10 @@ enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2 /* frames a workgroup lo
           window, converts every staged source pixel to lut * vignette ONCE and samples floats, 16 outputs per lane, pyramid
           levels out of registers -- for remaps with about one output or more per source pixel (the scale-1 rectification of
           BASELINE.json configs[4], magnifying remaps): 0 = automatic (when fewer source pixels are staged than there are
-          outputs), 1 = whenever it can be planned, 2 = never */ };
+          outputs), 1 = whenever it can be planned, 2 = never */,
+       MDC_OPT_PREFETCH_CHUNK = 12 /* tuning: the strip path walks large batches in chunks and reads the next chunk's source
+          rows linearly into the Infinity Cache before the launch that samples them: frames per chunk, 0 = automatic
+          (~96 MiB of source rows), -1 = no prefetch (one launch over the whole batch) */ };
 enum { MDC_ORDER_BANDS = 0 /* row-major runs of tiles per XCD */, MDC_ORDER_ROWS = 1 /* whole tile rows per XCD */,
        MDC_ORDER_IDENTITY = 2 /* block b = tile b (diagnosis) */,
        MDC_ORDER_BLOCKS2D = 3 /* the tile grid cut into 8 rectangles, one per XCD */ };

@@ -19,6 +19,7 @@ GAMMA, VIGNETTE, KILL_OVEREXPOSED, RECTIFY = 1, 2, 4, 8
 KERNEL_AUTO, KERNEL_GATHER, KERNEL_TILED = 0, 1, 2
 OPT_KERNEL, OPT_FRAMES_PER_BLOCK, OPT_TILE_ROWS, OPT_TILE_ORDER, OPT_WINDOW_BUFFERS, OPT_FRAME_INTERLEAVE, OPT_TILE_COLS, OPT_PIN_CALLER_BUFFERS = 1, 2, 5, 6, 7, 8, 9, 10
 OPT_TWO_STAGE = 11
+OPT_PREFETCH_CHUNK = 12
 ORDER_BANDS, ORDER_ROWS, ORDER_IDENTITY, ORDER_BLOCKS2D = 0, 1, 2, 3
 OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 

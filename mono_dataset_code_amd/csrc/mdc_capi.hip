@@ -103,6 +103,7 @@ struct mdc_ctx {
   int opt_nbuf = 0;  // 0 = automatic
   int opt_interleave = 0;
   int opt_pin_caller = 0;  // MDC_OPT_PIN_CALLER_BUFFERS
+  int opt_prefetch_chunk = 0;  // MDC_OPT_PREFETCH_CHUNK: frames per prefetched chunk of the strip path; 0 = automatic, -1 = no prefetch
   int opt_two_stage = 0;   // MDC_OPT_TWO_STAGE: 0 = automatic (strip kernel by source pixels per output), 1 = strip kernel whenever
                            // plannable, 2 = never
 
@@ -737,10 +738,37 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
     const mdc_ctx::Strip& st = c->strip;
     const StripPlan sp{st.d_chunks, st.d_nch, st.d_taps, st.d_order, st.n_blocks, st.n_tiles, st.tiles_x, st.win_bytes, st.passes, st.nbuf,
                        c->opt_interleave != 0};
-    int fpb = frames_per_block(c, nframes, st.n_blocks);
     const bool fuse_pyr = pyr && c->out_w % kStripTileW == 0;
-    MDC_HIP(c, launch_remap_strip_u8(d_in, d_out, a, sp, nframes, fpb, s, fuse_pyr ? pyr[0] : nullptr, fuse_pyr ? pyr[1] : nullptr,
-                                     fuse_pyr ? pyr[2] : nullptr));
+    // Large batches go in chunks, each preceded by a linear prefetch of the NEXT chunk's source rows into the Infinity
+    // Cache (launch_prefetch_rows): the strips' small window reads then hit the cache instead of interrupting the output
+    // stream in HBM.  Chunk = as many frames as keep the prefetched rows (bounding box rows x frame width) within ~96 MiB.
+    const int iw = c->rm_in_w;
+    const int x0 = c->bbox[0], x1 = c->bbox[2], y0 = c->bbox[1], y1 = c->bbox[3];
+    const int64_t frame_in = (int64_t)iw * c->rm_in_h;
+    const int64_t box_bytes = y1 >= y0 ? (int64_t)(y1 - y0 + 1) * std::min(iw, ((x1 + 128) & ~127) - (x0 & ~127)) : 0;
+    // 48 frames of the bench camera (0.65 MB of box each): measured best -- beyond ~64 frames the prefetched lines no
+    // longer survive until they are used (the launch's own output passes through the same cache)
+    int64_t chunk = c->opt_prefetch_chunk > 0 ? c->opt_prefetch_chunk : std::max<int64_t>(16, (31ll << 20) / std::max<int64_t>(1, box_bytes));
+    // Measured (profiles/r03_experiments/08_*): with the fused pyramid (6.96 MB written per frame, 4 waves per SIMD) the
+    // prefetch takes 1.86-1.94 ms per 1024 frames down to 1.64-1.70; without the levels it changes nothing (1.54 -> 1.56),
+    // so it is used for the pyramid launches (or on request: a positive MDC_OPT_PREFETCH_CHUNK).
+    const bool prefetch = c->opt_prefetch_chunk >= 0 && (fuse_pyr || c->opt_prefetch_chunk > 0) && box_bytes >= 4096 && nframes >= 2 * chunk;
+    if (!prefetch) chunk = nframes;
+    const size_t no = (size_t)c->out_w * c->out_h;
+    if (prefetch) MDC_HIP(c, launch_prefetch_rows(d_in, frame_in, iw, x0, x1, y0, y1, std::min<int64_t>(chunk, nframes), c->d_vcal_max, s));
+    for (int64_t f0 = 0; f0 < nframes; f0 += chunk) {
+      const int64_t n = std::min<int64_t>(chunk, nframes - f0);
+      if (prefetch && f0 + chunk < nframes)
+        MDC_HIP(c, launch_prefetch_rows(d_in + (size_t)(f0 + chunk) * frame_in, frame_in, iw, x0, x1, y0, y1, std::min<int64_t>(chunk, nframes - f0 - chunk),
+                                        c->d_vcal_max, s));
+      // one round of workgroups per chunk where that is possible: a chunk is a launch of its own, its tail is not hidden
+      int fpb = frames_per_block(c, n, st.n_blocks);
+      const int64_t resident = 256 * (fuse_pyr ? 4 : 5);  // workgroups of kStripWaves waves the chip holds at once
+      if (prefetch && !c->opt_fpb) fpb = (int)std::max<int64_t>(8, (n * st.n_blocks + resident - 1) / resident);
+      MDC_HIP(c, launch_remap_strip_u8(d_in + (size_t)f0 * frame_in, d_out + (size_t)f0 * no, a, sp, n, fpb, s,
+                                       fuse_pyr ? pyr[0] + (size_t)f0 * (no / 4) : nullptr, fuse_pyr ? pyr[1] + (size_t)f0 * (no / 16) : nullptr,
+                                       fuse_pyr ? pyr[2] + (size_t)f0 * (no / 64) : nullptr));
+    }
     if (pyr_done) *pyr_done = fuse_pyr;
     return MDC_OK;
   }
@@ -902,6 +930,10 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
       MDC_HIP(c, hipDeviceSynchronize());
       return plan_tiles(c);
     }
+    case MDC_OPT_PREFETCH_CHUNK:
+      if (value < -1) return fail(c, MDC_ERR_ARG, "prefetch chunk must be -1 (off), 0 (automatic) or a frame count");
+      c->opt_prefetch_chunk = value;
+      return MDC_OK;
     case MDC_OPT_TWO_STAGE: {
       if (value < 0 || value > 2) return fail(c, MDC_ERR_ARG, "two-stage selector must be 0 (automatic), 1 (on) or 2 (off)");
       if (value == c->opt_two_stage) return MDC_OK;

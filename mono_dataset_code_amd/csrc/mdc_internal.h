@@ -102,6 +102,12 @@ size_t tiled_lds_bytes(int win_bytes, int nbuf, bool lut = true);  // (LUT repli
 size_t tiled_pyramid_lds_bytes(int tile_w, int tile_h);  // + level-2 hand-over rows of the fused pyramid
 constexpr size_t kLdsPerCU = 160 * 1024;
 
+// Linear read of rows [y0, y1] x byte columns [x0, x1] (widened to whole 128-byte lines) of each of nframes u8 frames
+// (frame_bytes apart, row_pitch bytes a row): a software prefetch into the Infinity Cache ahead of a remap launch over
+// those frames (d_sink: any device word, never written in practice)
+hipError_t launch_prefetch_rows(const uint8_t* d_frames, int64_t frame_bytes, int row_pitch, int x0, int x1, int y0, int y1, int64_t nframes,
+                                uint32_t* d_sink, hipStream_t s);
+
 // One 2x2 box level: dst (w/2 x h/2) from src (w x h), nframes images each.
 hipError_t launch_pyramid_level(const float* d_src, float* d_dst, int w, int h, int64_t nframes, hipStream_t s);
 

@@ -536,6 +536,42 @@ def test_strip_kernel(name, setups, oracle, torch_cuda):
     assert ran == 4, "the strip kernel should be plannable for %s" % name
 
 
+def test_strip_kernel_in_prefetched_chunks(setups, oracle, torch_cuda):
+    """Large batches on the strip path go in chunks with a linear prefetch of the next chunk's source rows
+    (MDC_OPT_PREFETCH_CHUNK): forced to 2 / 3 / 4 frames per chunk on a 9-frame batch (chunk sizes that do and do not
+    divide it), with and without the fused pyramid -- the same bits as one launch."""
+    from mono_dataset_code_amd import capi
+
+    torch = torch_cuda
+    for name in ("mag4_full_black", "upsample"):
+        s = setups(name)
+        frames = np.stack(make_frames(s.W, s.H, n_noise=6))
+        n = len(frames)
+        d_in = torch.from_numpy(frames).cuda()
+        st = torch.cuda.current_stream().cuda_stream
+        want = [s.want(oracle, f, 1, 1, 1, 1) for f in frames]
+        try:
+            for chunk in (2, 3, 4, -1):
+                s.ctx.set_option(capi.OPT_PREFETCH_CHUNK, chunk)
+                d_out = torch.full((n, s.w * s.h), -7.0, dtype=torch.float32, device="cuda")
+                s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, 15, st)
+                levels = 4
+                d_base = torch.full((n, s.w * s.h), -7.0, dtype=torch.float32, device="cuda")
+                lv = [torch.full((n * (s.w >> l) * (s.h >> l),), -7.0, dtype=torch.float32, device="cuda") for l in range(1, levels)]
+                s.ctx.process_pyramid_batch(d_in.data_ptr(), d_base.data_ptr(), levels, [t.data_ptr() for t in lv], n, 15, st)
+                torch.cuda.synchronize()
+                for f in range(n):
+                    assert bits_equal(d_out[f].cpu().numpy(), want[f]), (name, chunk, f)
+                    src, cw, ch = want[f], s.w, s.h
+                    assert bits_equal(d_base[f].cpu().numpy(), src), (name, chunk, f)
+                    for l in range(levels - 1):
+                        src = oracle.pyramid_level(src, cw, ch)
+                        cw, ch = cw // 2, ch // 2
+                        assert bits_equal(lv[l].view(n, -1)[f].cpu().numpy(), src), (name, chunk, f, l + 1)
+        finally:
+            s.ctx.set_option(capi.OPT_PREFETCH_CHUNK, 0)
+
+
 def test_two_stage_is_chosen_by_source_pixels_per_output(setups):
     """Automatic choice: the scale-1 rectification of config 5 and magnifying remaps run on wave-private strips (fewer
     staged source pixels than outputs), the 1.5x downscale of the headline camera stays on the direct kernel."""
