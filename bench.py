@@ -457,6 +457,12 @@ def main():
                 "algorithmic_bytes_per_frame": alg_frame, "algorithmic_read_bytes_per_frame": alg_read,
                 "frames_per_launch": B, "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
                 "tile": [info.tile_w, info.tile_h] if rect and info.tiled else None, "window_buffers": info.window_buffers if rect else None}
+        if wl == "pyramid" and info.prefetch_chunk and B >= 2 * info.prefetch_chunk:
+            # the strip path walks the batch in chunks: per chunk one linear prefetch of the next chunk's source rows into the
+            # Infinity Cache + one remap launch.  kernel_ms is the time of ALL launches of a step (HIP events around the
+            # call); the prefetch's reads are extra traffic, not algorithmic bytes.
+            nchunk = -(-B // info.prefetch_chunk)
+            roof["launches_per_step"] = {"remap_strip_kernel": nchunk, "prefetch_rows_kernel": nchunk, "frames_per_chunk": info.prefetch_chunk}
         if ceiling is not None:
             roof["same_box_mix_ceiling"] = ceiling
             roof["frac_of_same_box_mix_ceiling"] = round(ceiling["ms_median"] / kernel_med, 4)

@@ -111,6 +111,8 @@ typedef struct mdc_info {
   int64_t src_staged_bytes;  /* bytes the tiled kernel stages per frame (sum of the exact per-row windows) */
   int64_t n_black;           /* outputs whose remap is the (-1,-1) sentinel         */
   int two_stage;             /* 1 if the fused pass runs on the wave-private strip kernel (MDC_OPT_TWO_STAGE) */
+  int prefetch_chunk;        /* strip path: frames per chunk of a fused-pyramid batch of >= 2 chunks (each chunk: one linear
+                                prefetch launch + one remap launch, MDC_OPT_PREFETCH_CHUNK); 0 = batches go in one launch */
 } mdc_info;
 
 /* ---- lifetime -------------------------------------------------------------- */

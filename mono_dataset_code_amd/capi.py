@@ -60,7 +60,7 @@ class MdcInfo(C.Structure):
                 ("tile_w", C.c_int), ("tile_h", C.c_int), ("n_tiles", C.c_int), ("lds_bytes", C.c_int),
                 ("window_buffers", C.c_int), ("f32_tiled", C.c_int), ("f32_tile_w", C.c_int), ("f32_tile_h", C.c_int),
                 ("src_bbox", C.c_int * 4), ("src_bbox_bytes", C.c_int64), ("src_staged_bytes", C.c_int64),
-                ("n_black", C.c_int64), ("two_stage", C.c_int)]
+                ("n_black", C.c_int64), ("two_stage", C.c_int), ("prefetch_chunk", C.c_int)]
 
 
 class TuneResult(C.Structure):

@@ -696,6 +696,17 @@ RemapArgs remap_args(const mdc_ctx* c, const float* lut, const float* vinv) {
   return a;
 }
 
+// Strip path, chunked launches with prefetch (enqueue_process): bytes of the source bounding box widened to whole 128-byte
+// lines, and the frames per chunk.  48 frames of the bench camera (0.65 MB of box each) measured best -- beyond ~64 frames
+// the prefetched lines no longer survive until they are used (the launch's own output passes through the same cache).
+int64_t prefetch_box_bytes(const mdc_ctx* c) {
+  const int x0 = c->bbox[0], x1 = c->bbox[2], y0 = c->bbox[1], y1 = c->bbox[3];
+  return y1 >= y0 ? (int64_t)(y1 - y0 + 1) * std::min(c->rm_in_w, ((x1 + 128) & ~127) - (x0 & ~127)) : 0;
+}
+int64_t prefetch_chunk_frames(const mdc_ctx* c) {
+  return c->opt_prefetch_chunk > 0 ? c->opt_prefetch_chunk : std::max<int64_t>(16, (31ll << 20) / std::max<int64_t>(1, prefetch_box_bytes(c)));
+}
+
 // UndistorterFOV::undistort<float> over float frames: LDS-tiled kernel when planned, else the gather kernel.
 int enqueue_undistort_f32(mdc_ctx* c, const float* d_in, float* d_out, int64_t nframes, hipStream_t s) {
   RemapArgs a = remap_args(c, nullptr, nullptr);
@@ -745,10 +756,8 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
     const int iw = c->rm_in_w;
     const int x0 = c->bbox[0], x1 = c->bbox[2], y0 = c->bbox[1], y1 = c->bbox[3];
     const int64_t frame_in = (int64_t)iw * c->rm_in_h;
-    const int64_t box_bytes = y1 >= y0 ? (int64_t)(y1 - y0 + 1) * std::min(iw, ((x1 + 128) & ~127) - (x0 & ~127)) : 0;
-    // 48 frames of the bench camera (0.65 MB of box each): measured best -- beyond ~64 frames the prefetched lines no
-    // longer survive until they are used (the launch's own output passes through the same cache)
-    int64_t chunk = c->opt_prefetch_chunk > 0 ? c->opt_prefetch_chunk : std::max<int64_t>(16, (31ll << 20) / std::max<int64_t>(1, box_bytes));
+    const int64_t box_bytes = prefetch_box_bytes(c);
+    int64_t chunk = prefetch_chunk_frames(c);
     // Measured (profiles/r03_experiments/08_*): with the fused pyramid (6.96 MB written per frame, 4 waves per SIMD) the
     // prefetch takes 1.86-1.94 ms per 1024 frames down to 1.64-1.70; without the levels it changes nothing (1.54 -> 1.56),
     // so it is used for the pyramid launches (or on request: a positive MDC_OPT_PREFETCH_CHUNK).
@@ -976,6 +985,7 @@ int mdc_get_info(mdc_ctx* c, mdc_info* i) {
   i->n_tiles = p0.n_tiles;
   i->lds_bytes = p0.tiled ? (int)tiled_lds_bytes(p0.win_bytes, p0.nbuf, true) : 0;
   i->two_stage = c->strip.planned ? 1 : 0;
+  i->prefetch_chunk = (c->strip.planned && c->opt_prefetch_chunk >= 0 && prefetch_box_bytes(c) >= 4096) ? (int)prefetch_chunk_frames(c) : 0;
   if (c->strip.planned) {
     i->tiled = c->valid_remap;
     i->tile_w = kStripTileW;

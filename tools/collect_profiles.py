@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-WORKLOADS = {"fused": "remap_tiled_kernel", "unmap": "unmap_xpose_kernel", "pyramid": "remap_tiled_kernel", "seq50k": "remap_tiled_kernel"}
+WORKLOADS = {"fused": "remap_tiled_kernel", "unmap": "unmap_xpose_kernel", "pyramid": "remap_strip_kernel", "seq50k": "remap_tiled_kernel"}
 traffic_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
 for wl, kname in WORKLOADS.items():
@@ -29,6 +29,32 @@ for wl, kname in WORKLOADS.items():
     except (OSError, IndexError, KeyError, ValueError):
         pass
     if not frames:
+        continue
+    # a step made of several launches (the strip path in prefetched chunks): every launch of the step counts, per frame
+    lps = None
+    try:
+        lps = json.loads(line)["roofline"].get("launches_per_step")
+    except (NameError, KeyError, ValueError):
+        pass
+    if lps:
+        main = [k for k in s["kernels"] if k.startswith(kname) and "hbm_bytes_per_launch" in s["kernels"][k]]
+        pre = [k for k in s["kernels"] if k.startswith("prefetch_rows_kernel") and "hbm_bytes_per_launch" in s["kernels"][k]]
+        if main:
+            k = main[0]
+            v = s["kernels"][k]
+            nsteps = v["calls"] / lps[kname]
+            rd = v["hbm_read_bytes_per_launch"] * v["calls"]
+            wr = v["hbm_write_bytes_per_launch"] * v["calls"]
+            pre_rd = sum(s["kernels"][p]["hbm_read_bytes_per_launch"] * s["kernels"][p]["calls"] for p in pre)
+            traffic["%s:%s" % (wl, k)] = {
+                "bytes_per_frame": (rd + wr + pre_rd) / nsteps / frames,
+                "read_bytes_per_frame": (rd + pre_rd) / nsteps / frames, "write_bytes_per_frame": wr / nsteps / frames,
+                "of_which_prefetch_read_bytes_per_frame": pre_rd / nsteps / frames,
+                "kernel": k, "avg_us_under_profiler": v["avg_us"], "frames_per_launch": frames, "launches_per_step": lps,
+                "source": "profiles/%s_%s_summary.json" % (tag, wl),
+                "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 half-count, verified profiles/r01_fetch_calibration.txt) + WRITE_SIZE KiB x1024; all "
+                              "launches of a step (chunked remap + prefetch) summed",
+            }
         continue
     for k, v in s["kernels"].items():
         if k.startswith(kname) and "hbm_bytes_per_launch" in v:
