@@ -462,7 +462,8 @@ def main():
             # Infinity Cache + one remap launch.  kernel_ms is the time of ALL launches of a step (HIP events around the
             # call); the prefetch's reads are extra traffic, not algorithmic bytes.
             nchunk = -(-B // info.prefetch_chunk)
-            roof["launches_per_step"] = {"remap_strip_kernel": nchunk, "prefetch_rows_kernel": nchunk, "frames_per_chunk": info.prefetch_chunk}
+            roof["launches_per_step"] = {"remap_strip_kernel": nchunk, "prefetch_rows_kernel": nchunk, "frames_per_chunk": info.prefetch_chunk,
+                                         "streams": info.prefetch_streams}
         if ceiling is not None:
             roof["same_box_mix_ceiling"] = ceiling
             roof["frac_of_same_box_mix_ceiling"] = round(ceiling["ms_median"] / kernel_med, 4)

@@ -87,7 +87,10 @@ enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2 /* frames a workgroup lo
           outputs), 1 = whenever it can be planned, 2 = never */,
        MDC_OPT_PREFETCH_CHUNK = 12 /* tuning: the strip path walks large batches in chunks and reads the next chunk's source
           rows linearly into the Infinity Cache before the launch that samples them: frames per chunk, 0 = automatic
-          (~96 MiB of source rows), -1 = no prefetch (one launch over the whole batch) */ };
+          (~26 MiB of source rows, in whole frame groups), -1 = no prefetch (one launch over the whole batch) */,
+       MDC_OPT_PREFETCH_STREAMS = 13 /* tuning: those chunks alternate between the caller's stream and a second, internal one
+          (joined back into the caller's stream before the call returns: the caller sees one stream), so that a chunk's tail
+          and the next chunk's prefetch run under the other chunk's launch: 0 = automatic (2), 1, 2 */ };
 enum { MDC_ORDER_BANDS = 0 /* row-major runs of tiles per XCD */, MDC_ORDER_ROWS = 1 /* whole tile rows per XCD */,
        MDC_ORDER_IDENTITY = 2 /* block b = tile b (diagnosis) */,
        MDC_ORDER_BLOCKS2D = 3 /* the tile grid cut into 8 rectangles, one per XCD */ };
@@ -113,6 +116,7 @@ typedef struct mdc_info {
   int two_stage;             /* 1 if the fused pass runs on the wave-private strip kernel (MDC_OPT_TWO_STAGE) */
   int prefetch_chunk;        /* strip path: frames per chunk of a fused-pyramid batch of >= 2 chunks (each chunk: one linear
                                 prefetch launch + one remap launch, MDC_OPT_PREFETCH_CHUNK); 0 = batches go in one launch */
+  int prefetch_streams;      /* streams those chunks alternate over (MDC_OPT_PREFETCH_STREAMS); 0 if prefetch_chunk is 0 */
 } mdc_info;
 
 /* ---- lifetime -------------------------------------------------------------- */

@@ -20,6 +20,7 @@ KERNEL_AUTO, KERNEL_GATHER, KERNEL_TILED = 0, 1, 2
 OPT_KERNEL, OPT_FRAMES_PER_BLOCK, OPT_TILE_ROWS, OPT_TILE_ORDER, OPT_WINDOW_BUFFERS, OPT_FRAME_INTERLEAVE, OPT_TILE_COLS, OPT_PIN_CALLER_BUFFERS = 1, 2, 5, 6, 7, 8, 9, 10
 OPT_TWO_STAGE = 11
 OPT_PREFETCH_CHUNK = 12
+OPT_PREFETCH_STREAMS = 13
 ORDER_BANDS, ORDER_ROWS, ORDER_IDENTITY, ORDER_BLOCKS2D = 0, 1, 2, 3
 OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 
@@ -60,7 +61,7 @@ class MdcInfo(C.Structure):
                 ("tile_w", C.c_int), ("tile_h", C.c_int), ("n_tiles", C.c_int), ("lds_bytes", C.c_int),
                 ("window_buffers", C.c_int), ("f32_tiled", C.c_int), ("f32_tile_w", C.c_int), ("f32_tile_h", C.c_int),
                 ("src_bbox", C.c_int * 4), ("src_bbox_bytes", C.c_int64), ("src_staged_bytes", C.c_int64),
-                ("n_black", C.c_int64), ("two_stage", C.c_int), ("prefetch_chunk", C.c_int)]
+                ("n_black", C.c_int64), ("two_stage", C.c_int), ("prefetch_chunk", C.c_int), ("prefetch_streams", C.c_int)]
 
 
 class TuneResult(C.Structure):

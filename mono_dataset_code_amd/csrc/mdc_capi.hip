@@ -46,6 +46,7 @@ struct mdc_ctx {
     size_t in_cap = 0;
     float* d_out = nullptr;
     size_t out_cap = 0;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // the chunked strip path borrows a slot's stream as its second one
     bool busy = false;
   };
   static constexpr int kMaxSlots = 8;
@@ -103,6 +104,7 @@ struct mdc_ctx {
   int opt_nbuf = 0;  // 0 = automatic
   int opt_interleave = 0;
   int opt_pin_caller = 0;  // MDC_OPT_PIN_CALLER_BUFFERS
+  int opt_prefetch_streams = 0;  // MDC_OPT_PREFETCH_STREAMS: 0 = automatic (2), 1, 2
   int opt_prefetch_chunk = 0;  // MDC_OPT_PREFETCH_CHUNK: frames per prefetched chunk of the strip path; 0 = automatic, -1 = no prefetch
   int opt_two_stage = 0;   // MDC_OPT_TWO_STAGE: 0 = automatic (strip kernel by source pixels per output), 1 = strip kernel whenever
                            // plannable, 2 = never
@@ -622,7 +624,8 @@ void unpin_all(mdc_ctx* c) {
 struct SlotLease {
   mdc_ctx* c;
   mdc_ctx::HostSlot* s = nullptr;
-  explicit SlotLease(mdc_ctx* ctx) : c(ctx) {
+  // wait == false: take a free slot (or make one) or come back empty-handed, without an error
+  explicit SlotLease(mdc_ctx* ctx, bool wait = true) : c(ctx) {
     std::unique_lock<std::mutex> lk(c->slot_mu);
     for (;;) {
       for (mdc_ctx::HostSlot* h : c->slots)
@@ -636,7 +639,7 @@ struct SlotLease {
         const hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
           delete h;
-          fail(c, MDC_ERR_HIP, "hipStreamCreateWithFlags: %s", hipGetErrorString(e));
+          if (wait) fail(c, MDC_ERR_HIP, "hipStreamCreateWithFlags: %s", hipGetErrorString(e));
           return;
         }
         h->busy = true;
@@ -644,6 +647,7 @@ struct SlotLease {
         s = h;
         return;
       }
+      if (!wait) return;
       c->slot_cv.wait(lk);
     }
   }
@@ -703,8 +707,23 @@ int64_t prefetch_box_bytes(const mdc_ctx* c) {
   const int x0 = c->bbox[0], x1 = c->bbox[2], y0 = c->bbox[1], y1 = c->bbox[3];
   return y1 >= y0 ? (int64_t)(y1 - y0 + 1) * std::min(c->rm_in_w, ((x1 + 128) & ~127) - (x0 & ~127)) : 0;
 }
-int64_t prefetch_chunk_frames(const mdc_ctx* c) {
-  return c->opt_prefetch_chunk > 0 ? c->opt_prefetch_chunk : std::max<int64_t>(16, (31ll << 20) / std::max<int64_t>(1, prefetch_box_bytes(c)));
+// Two streams (MDC_OPT_PREFETCH_STREAMS, the default): the chunks alternate between the caller's stream and a second
+// one, so a chunk's tail and the next prefetch run under the other chunk's launch; a launch then holds ~5/8 of the
+// workgroups the chip has room for (two of them overlap, staggered), in whole frame groups.  Measured on config 5
+// (profiles/r03_experiments/10_*): 40 frames per chunk, 2 groups of 20 -- 1.76 -> 1.52 ms per 1024 frames.
+int prefetch_streams(const mdc_ctx* c) { return c->opt_prefetch_streams == 1 ? 1 : 2; }
+int64_t strip_resident(bool pyr) { return 256 * (pyr ? 4 : 5); }  // workgroups of kStripWaves waves the chip holds at once
+int64_t chunk_groups(const mdc_ctx* c, bool pyr) {
+  const int64_t nb = std::max(1, c->strip.n_blocks);
+  return std::max<int64_t>(1, (strip_resident(pyr) * 5 / 8 + nb / 2) / nb);
+}
+int64_t prefetch_chunk_frames(const mdc_ctx* c, bool pyr = true) {
+  if (c->opt_prefetch_chunk > 0) return c->opt_prefetch_chunk;
+  const int64_t box = std::max<int64_t>(1, prefetch_box_bytes(c));
+  if (prefetch_streams(c) == 1) return std::max<int64_t>(16, (31ll << 20) / box);
+  const int64_t g = chunk_groups(c, pyr);
+  const int64_t per_group = std::max<int64_t>(8, ((26ll << 20) / box + g / 2) / g);  // >= 8 frames per workgroup
+  return g * per_group;
 }
 
 // UndistorterFOV::undistort<float> over float frames: LDS-tiled kernel when planned, else the gather kernel.
@@ -757,13 +776,49 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
     const int x0 = c->bbox[0], x1 = c->bbox[2], y0 = c->bbox[1], y1 = c->bbox[3];
     const int64_t frame_in = (int64_t)iw * c->rm_in_h;
     const int64_t box_bytes = prefetch_box_bytes(c);
-    int64_t chunk = prefetch_chunk_frames(c);
+    int64_t chunk = prefetch_chunk_frames(c, fuse_pyr);
     // Measured (profiles/r03_experiments/08_*): with the fused pyramid (6.96 MB written per frame, 4 waves per SIMD) the
     // prefetch takes 1.86-1.94 ms per 1024 frames down to 1.64-1.70; without the levels it changes nothing (1.54 -> 1.56),
     // so it is used for the pyramid launches (or on request: a positive MDC_OPT_PREFETCH_CHUNK).
     const bool prefetch = c->opt_prefetch_chunk >= 0 && (fuse_pyr || c->opt_prefetch_chunk > 0) && box_bytes >= 4096 && nframes >= 2 * chunk;
     if (!prefetch) chunk = nframes;
     const size_t no = (size_t)c->out_w * c->out_h;
+    const int64_t resident = strip_resident(fuse_pyr);
+    auto strip = [&](int64_t f0, int64_t n, int fpb, hipStream_t t) {
+      return launch_remap_strip_u8(d_in + (size_t)f0 * frame_in, d_out + (size_t)f0 * no, a, sp, n, fpb, t,
+                                   fuse_pyr ? pyr[0] + (size_t)f0 * (no / 4) : nullptr, fuse_pyr ? pyr[1] + (size_t)f0 * (no / 16) : nullptr,
+                                   fuse_pyr ? pyr[2] + (size_t)f0 * (no / 64) : nullptr);
+    };
+    if (prefetch && prefetch_streams(c) == 2) {
+      // The second stream is a slot's (with its two events), borrowed while the launches are enqueued: what is queued on it
+      // stays ordered after the lease ends.  No free slot (every one held by a host call): one stream.
+      SlotLease side(c, false);
+      mdc_ctx::HostSlot* h = side.s;
+      if (h && !h->ev_fork) {
+        if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) h->ev_fork = nullptr;
+        if (h->ev_fork && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+          (void)hipEventDestroy(h->ev_fork);
+          h->ev_fork = nullptr;
+        }
+      }
+      if (h && h->ev_fork) {
+        const int64_t groups = chunk_groups(c, fuse_pyr);
+        MDC_HIP(c, hipEventRecord(h->ev_fork, s));
+        MDC_HIP(c, hipStreamWaitEvent(h->stream, h->ev_fork, 0));
+        int k = 0;
+        for (int64_t f0 = 0; f0 < nframes; f0 += chunk, k++) {
+          const int64_t n = std::min<int64_t>(chunk, nframes - f0);
+          hipStream_t t = (k & 1) ? h->stream : s;
+          MDC_HIP(c, launch_prefetch_rows(d_in + (size_t)f0 * frame_in, frame_in, iw, x0, x1, y0, y1, n, c->d_vcal_max, t));
+          const int fpb = c->opt_fpb > 0 ? (int)std::min<int64_t>(c->opt_fpb, n) : (int)((n + groups - 1) / groups);
+          MDC_HIP(c, strip(f0, n, fpb, t));
+        }
+        MDC_HIP(c, hipEventRecord(h->ev_join, h->stream));
+        MDC_HIP(c, hipStreamWaitEvent(s, h->ev_join, 0));
+        if (pyr_done) *pyr_done = fuse_pyr;
+        return MDC_OK;
+      }
+    }
     if (prefetch) MDC_HIP(c, launch_prefetch_rows(d_in, frame_in, iw, x0, x1, y0, y1, std::min<int64_t>(chunk, nframes), c->d_vcal_max, s));
     for (int64_t f0 = 0; f0 < nframes; f0 += chunk) {
       const int64_t n = std::min<int64_t>(chunk, nframes - f0);
@@ -772,11 +827,8 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
                                         c->d_vcal_max, s));
       // one round of workgroups per chunk where that is possible: a chunk is a launch of its own, its tail is not hidden
       int fpb = frames_per_block(c, n, st.n_blocks);
-      const int64_t resident = 256 * (fuse_pyr ? 4 : 5);  // workgroups of kStripWaves waves the chip holds at once
       if (prefetch && !c->opt_fpb) fpb = (int)std::max<int64_t>(8, (n * st.n_blocks + resident - 1) / resident);
-      MDC_HIP(c, launch_remap_strip_u8(d_in + (size_t)f0 * frame_in, d_out + (size_t)f0 * no, a, sp, n, fpb, s,
-                                       fuse_pyr ? pyr[0] + (size_t)f0 * (no / 4) : nullptr, fuse_pyr ? pyr[1] + (size_t)f0 * (no / 16) : nullptr,
-                                       fuse_pyr ? pyr[2] + (size_t)f0 * (no / 64) : nullptr));
+      MDC_HIP(c, strip(f0, n, fpb, s));
     }
     if (pyr_done) *pyr_done = fuse_pyr;
     return MDC_OK;
@@ -856,6 +908,8 @@ void mdc_destroy(mdc_ctx* c) {
       if (h->stream) (void)hipStreamSynchronize(h->stream);
       if (h->d_in) (void)hipFree(h->d_in);
       if (h->d_out) (void)hipFree(h->d_out);
+      if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+      if (h->ev_join) (void)hipEventDestroy(h->ev_join);
       if (h->stream) (void)hipStreamDestroy(h->stream);
       delete h;
     }
@@ -939,6 +993,10 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
       MDC_HIP(c, hipDeviceSynchronize());
       return plan_tiles(c);
     }
+    case MDC_OPT_PREFETCH_STREAMS:
+      if (value < 0 || value > 2) return fail(c, MDC_ERR_ARG, "prefetch streams must be 0 (automatic), 1 or 2");
+      c->opt_prefetch_streams = value;
+      return MDC_OK;
     case MDC_OPT_PREFETCH_CHUNK:
       if (value < -1) return fail(c, MDC_ERR_ARG, "prefetch chunk must be -1 (off), 0 (automatic) or a frame count");
       c->opt_prefetch_chunk = value;
@@ -986,6 +1044,7 @@ int mdc_get_info(mdc_ctx* c, mdc_info* i) {
   i->lds_bytes = p0.tiled ? (int)tiled_lds_bytes(p0.win_bytes, p0.nbuf, true) : 0;
   i->two_stage = c->strip.planned ? 1 : 0;
   i->prefetch_chunk = (c->strip.planned && c->opt_prefetch_chunk >= 0 && prefetch_box_bytes(c) >= 4096) ? (int)prefetch_chunk_frames(c) : 0;
+  i->prefetch_streams = i->prefetch_chunk ? prefetch_streams(c) : 0;
   if (c->strip.planned) {
     i->tiled = c->valid_remap;
     i->tile_w = kStripTileW;

@@ -539,7 +539,9 @@ def test_strip_kernel(name, setups, oracle, torch_cuda):
 def test_strip_kernel_in_prefetched_chunks(setups, oracle, torch_cuda):
     """Large batches on the strip path go in chunks with a linear prefetch of the next chunk's source rows
     (MDC_OPT_PREFETCH_CHUNK): forced to 2 / 3 / 4 frames per chunk on a 9-frame batch (chunk sizes that do and do not
-    divide it), with and without the fused pyramid -- the same bits as one launch."""
+    divide it), the chunks on one stream and alternating over two (MDC_OPT_PREFETCH_STREAMS: the second one is internal
+    and joined back -- the caller's stream order must hold: the results are read right after on the caller's stream),
+    with and without the fused pyramid -- the same bits as one launch."""
     from mono_dataset_code_amd import capi
 
     torch = torch_cuda
@@ -551,8 +553,12 @@ def test_strip_kernel_in_prefetched_chunks(setups, oracle, torch_cuda):
         st = torch.cuda.current_stream().cuda_stream
         want = [s.want(oracle, f, 1, 1, 1, 1) for f in frames]
         try:
-            for chunk in (2, 3, 4, -1):
+            for chunk, streams in ((2, 2), (3, 2), (4, 0), (2, 1), (3, 1), (-1, 0)):
                 s.ctx.set_option(capi.OPT_PREFETCH_CHUNK, chunk)
+                s.ctx.set_option(capi.OPT_PREFETCH_STREAMS, streams)
+                i = s.ctx.info()
+                assert i.prefetch_streams == (0 if i.prefetch_chunk == 0 else 1 if streams == 1 else 2)
+                assert (i.prefetch_chunk == 0) == (chunk < 0), 'the cameras of this test have a source box worth prefetching'
                 d_out = torch.full((n, s.w * s.h), -7.0, dtype=torch.float32, device="cuda")
                 s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, 15, st)
                 levels = 4
@@ -570,6 +576,7 @@ def test_strip_kernel_in_prefetched_chunks(setups, oracle, torch_cuda):
                         assert bits_equal(lv[l].view(n, -1)[f].cpu().numpy(), src), (name, chunk, f, l + 1)
         finally:
             s.ctx.set_option(capi.OPT_PREFETCH_CHUNK, 0)
+            s.ctx.set_option(capi.OPT_PREFETCH_STREAMS, 0)
 
 
 def test_two_stage_is_chosen_by_source_pixels_per_output(setups):
