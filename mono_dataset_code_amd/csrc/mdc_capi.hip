@@ -1298,11 +1298,17 @@ int mdc_process_pyramid_gradients_batch_device(mdc_ctx* c, const uint8_t* d_in, 
     if (lw[l] < 1 || lh[l] < 1) return fail(c, MDC_ERR_ARG, "level %d of a %dx%d image is empty", l, w0, h0);
     level_bytes += (size_t)lw[l] * lh[l] * sizeof(float);
   }
-  // Frames per chunk: the gradient launch of a chunk follows the launch that wrote its levels immediately, so the tail of
-  // what was written is still in the 256-MiB Infinity Cache; measured (tools/dso_rate.py, 1280 x 1024): 8 frames per chunk
-  // 4.35 ms per 384 frames, 24: 3.81, 96: 3.68, separate launches over the whole batch: 3.92 -- the chunk should be a few
-  // times the cache, launches of fewer than ~100 frames lose more to their tails than residency gains.
+  // Frames per chunk.  Measured (tools/dso_rate.py, 1280 x 1024, 512 frames, profiles/r03_dso_rate.txt): 8 frames per chunk
+  // 5.0 ms, 24: 4.2, 96: 3.85-3.89, separate launches over the whole batch: 3.87-3.95 -- the levels are NOT read back from the
+  // Infinity Cache (the remap's stores are nontemporal: plain ones evict its prefetched source rows and measured slower in
+  // total, experiment 11), the whole path runs at what the memory system gives 34.8 MB of writes + 7.6 MB of reads per
+  // frame; chunks exist to bound the launch sizes, and below ~100 frames they lose to their tails.
   int64_t chunk = chunk_frames > 0 ? chunk_frames : std::max<int64_t>(1, (int64_t)((640u << 20) / level_bytes));
+  {  // a gradient launch holds a chunk's workgroups of up to four levels: fewer than 2^31 (128 x 8 pixels each)
+    int64_t wgs = 0;
+    for (int l = 0; l < std::min(levels, 4); l++) wgs += (int64_t)((lw[l] + 127) / 128) * ((lh[l] + 7) / 8);
+    chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, ((1ll << 31) - 1) / std::max<int64_t>(1, wgs)));
+  }
   const size_t npi = (size_t)iw * ih;
   for (int64_t f0 = 0; f0 < nframes; f0 += chunk) {
     const int64_t n = std::min<int64_t>(chunk, nframes - f0);

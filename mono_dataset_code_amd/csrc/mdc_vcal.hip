@@ -462,93 +462,73 @@ __global__ __launch_bounds__(256) void vcal_smooth_pass_kernel(const float* __re
 // dx = 0.5f*(I[idx+1] - I[idx-1]), dy = 0.5f*(I[idx+w] - I[idx-w]) over the LINEAR index range [w, w*(h-1)) -- rows
 // 1 .. h-2, all columns, so the first and last column difference across the row boundary exactly as DSO's loop
 // does --, non-finite differences replaced by 0, and absSquaredGrad = dx*dx + dy*dy.  First and last row: 0.
-// A wave handles 64 consecutive pixels and writes their 192 floats as three wave-contiguous dword stores (through a
-// wave-private LDS transpose) instead of three stores at a 12-byte stride.
+// A wave handles 64 consecutive columns of kGradRows rows: all of its loads (rows y0-1 .. y0+R of the column, the left and
+// right neighbours of the R rows) are issued before the first result is needed -- the first version (one pixel per thread, one
+// 256-pixel workgroup per 4 KB of output) ran at the latency of its five loads, 3.5 TB/s of output; per row the wave's 192
+// floats (I, dx, dy interleaved) leave as three wave-contiguous dword stores through a wave-private LDS transpose instead
+// of three stores at a 12-byte stride.  Up to four pyramid levels of a chunk of frames in ONE launch
+// (mdc_process_pyramid_gradients_batch_device): a workgroup finds its level from the first-block table.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gradients_kernel(const float* __restrict__ lvl, float* __restrict__ dI,
-                                                        float* __restrict__ abs2, int w, int h, long long nframes) {
-  __shared__ float s_t[4][192];
-  const long long npx = (long long)w * h;
-  const long long base = (long long)blockIdx.x * 256;  // first pixel (over all frames) of this workgroup
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long i = base + threadIdx.x;
-  float I = 0.f, dx = 0.f, dy = 0.f;
-  const bool in = i < npx * nframes;
-  if (in) {
-    const long long f = i / npx;
-    const int idx = (int)(i - f * npx);
-    const float* p = lvl + f * npx;
-    I = p[idx];
-    if (idx >= w && idx < w * (h - 1)) {
-      dx = 0.5f * (p[idx + 1] - p[idx - 1]);
-      dy = 0.5f * (p[idx + w] - p[idx - w]);
-      if (!isfinite(dx)) dx = 0.f;
-      if (!isfinite(dy)) dy = 0.f;
-    }
-    abs2[i] = dx * dx + dy * dy;
-  }
-  s_t[wave][3 * lane + 0] = I;
-  s_t[wave][3 * lane + 1] = dx;
-  s_t[wave][3 * lane + 2] = dy;
-  // wave-private: no workgroup barrier needed, only the LDS writes of this wave have to land
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-  const long long out0 = (base + wave * 64) * 3;
-  const long long total = npx * nframes * 3;
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const long long o = out0 + k * 64 + lane;
-    if (o < total) __builtin_nontemporal_store(s_t[wave][k * 64 + lane], dI + o);
-  }
-}
-
-// The same for up to four pyramid levels of a chunk of frames in ONE launch (mdc_process_pyramid_gradients_batch_device): a
-// workgroup finds its level from the first-block table; the body is gradients_kernel's.
+constexpr int kGradRows = 8, kGradThreads = 128;
 struct GradLevels {
   const float* src[4];
   float* dI[4];
   float* abs2[4];
   int w[4], h[4];
-  unsigned first_block[5];  // blocks [first_block[l], first_block[l+1]) belong to level l
+  unsigned bx[4], bands[4];  // workgroups per row band (128 columns each), row bands (kGradRows rows each)
+  unsigned first_block[5];   // blocks [first_block[l], first_block[l+1]) belong to level l
   int n;
 };
-__global__ __launch_bounds__(256) void gradients_levels_kernel(GradLevels g, long long nframes) {
-  __shared__ float s_t[4][192];
+__global__ __launch_bounds__(kGradThreads) void gradients_levels_kernel(GradLevels g) {
+  constexpr int R = kGradRows;
+  __shared__ float s_t[kGradThreads / 64][2][192];
   int l = 0;
 #pragma unroll
   for (int k = 1; k < 4; k++)
     if (k < g.n && blockIdx.x >= g.first_block[k]) l = k;
-  const float* lvl = g.src[l];
-  float* dI = g.dI[l];
-  float* abs2 = g.abs2[l];
   const int w = g.w[l], h = g.h[l];
-  const long long npx = (long long)w * h;
-  const long long base = (long long)(blockIdx.x - g.first_block[l]) * 256;
+  const unsigned b = blockIdx.x - g.first_block[l], per_frame = g.bx[l] * g.bands[l];
+  const unsigned f = b / per_frame, rb = b - f * per_frame, band = rb / g.bx[l], bx = rb - band * g.bx[l];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long i = base + threadIdx.x;
-  float I = 0.f, dx = 0.f, dy = 0.f;
-  if (i < npx * nframes) {
-    const long long f = i / npx;
-    const int idx = (int)(i - f * npx);
-    const float* p = lvl + f * npx;
-    I = p[idx];
-    if (idx >= w && idx < w * (h - 1)) {
-      dx = 0.5f * (p[idx + 1] - p[idx - 1]);
-      dy = 0.5f * (p[idx + w] - p[idx - w]);
+  const int x0 = (int)bx * kGradThreads + wave * 64;  // first column of this wave
+  const int nvalid = min(64, w - x0);                  // wave-uniform
+  if (nvalid <= 0) return;
+  const int x = min(x0 + lane, w - 1);  // lanes past the row end repeat its last column (loads stay in bounds; nothing stored)
+  const int y0 = (int)band * R;
+  const int npx = w * h;
+  const float* p = g.src[l] + (long long)f * npx;
+  float c[R + 2], lf[R], rt[R];
+#pragma unroll
+  for (int r = -1; r <= R; r++) c[r + 1] = p[min(max(y0 + r, 0), h - 1) * w + x];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int idx = min(y0 + r, h - 1) * w + x;
+    lf[r] = p[max(idx - 1, 0)];
+    rt[r] = p[min(idx + 1, npx - 1)];
+  }
+  float* dI = g.dI[l] + ((long long)f * npx + (long long)y0 * w + x0) * 3;
+  float* abs2 = g.abs2[l] + (long long)f * npx + (long long)y0 * w + x0;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int y = y0 + r;
+    if (y >= h) break;  // wave-uniform
+    float dx = 0.f, dy = 0.f;
+    if (y >= 1 && y <= h - 2) {  // the linear index range [w, w*(h-1))
+      dx = 0.5f * (rt[r] - lf[r]);
+      dy = 0.5f * (c[r + 2] - c[r]);
       if (!isfinite(dx)) dx = 0.f;
       if (!isfinite(dy)) dy = 0.f;
     }
-    abs2[i] = dx * dx + dy * dy;
-  }
-  s_t[wave][3 * lane + 0] = I;
-  s_t[wave][3 * lane + 1] = dx;
-  s_t[wave][3 * lane + 2] = dy;
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): wave-private transpose
-  const long long out0 = (base + wave * 64) * 3;
-  const long long total = npx * nframes * 3;
+    if (lane < nvalid) __builtin_nontemporal_store(dx * dx + dy * dy, abs2 + (long long)r * w + lane);
+    float* t = s_t[wave][r & 1];
+    t[3 * lane + 0] = c[r + 1];
+    t[3 * lane + 1] = dx;
+    t[3 * lane + 2] = dy;
+    __builtin_amdgcn_wave_barrier();  // wave-private transpose: a wave's LDS operations execute in order
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const long long o = out0 + k * 64 + lane;
-    if (o < total) __builtin_nontemporal_store(s_t[wave][k * 64 + lane], dI + o);
+    for (int k = 0; k < 3; k++)
+      if (k * 64 + lane < 3 * nvalid) __builtin_nontemporal_store(t[k * 64 + lane], dI + (long long)r * w * 3 + k * 64 + lane);
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -561,21 +541,25 @@ hipError_t launch_gradients_levels(int n_levels, const float* const* d_src, floa
   if (n_levels <= 0 || nframes <= 0) return hipSuccess;
   if (n_levels > 4) return hipErrorInvalidValue;
   GradLevels g;
-  unsigned nb = 0;
+  uint64_t nb = 0;
   for (int l = 0; l < 4; l++) {
-    const bool on = l < n_levels;
+    const bool on = l < n_levels && w[l] > 0 && h[l] > 0;
     g.src[l] = on ? d_src[l] : nullptr;
     g.dI[l] = on ? d_dI[l] : nullptr;
     g.abs2[l] = on ? d_abs2[l] : nullptr;
     g.w[l] = on ? w[l] : 1;
     g.h[l] = on ? h[l] : 1;
-    g.first_block[l] = nb;
-    if (on) nb += (unsigned)blocks((long long)w[l] * h[l] * nframes);
+    g.bx[l] = (unsigned)((g.w[l] + kGradThreads - 1) / kGradThreads);
+    g.bands[l] = (unsigned)((g.h[l] + kGradRows - 1) / kGradRows);
+    g.first_block[l] = (unsigned)nb;
+    if (on) nb += (uint64_t)g.bx[l] * g.bands[l] * (uint64_t)nframes;
+    if ((int64_t)g.w[l] * g.h[l] >= (1ll << 30)) return hipErrorInvalidValue;  // 32-bit pixel indices inside a frame
   }
-  g.first_block[4] = nb;
+  if (nb >= (1ull << 31)) return hipErrorInvalidValue;  // callers split such batches (mdc_capi.hip)
+  g.first_block[4] = (unsigned)nb;
   g.n = n_levels;
   if (nb == 0) return hipSuccess;
-  gradients_levels_kernel<<<nb, 256, 0, s>>>(g, nframes);
+  gradients_levels_kernel<<<(unsigned)nb, kGradThreads, 0, s>>>(g);
   return hipGetLastError();
 }
 
@@ -729,10 +713,19 @@ hipError_t launch_vcal_smooth(const float* d_vig, int wI, int hI, float* d_tt, f
 }
 
 hipError_t launch_gradients(const float* d_level, float* d_dI, float* d_abs2, int w, int h, int64_t nframes, hipStream_t s) {
-  const long long n = (long long)w * h * nframes;
-  if (n <= 0) return hipSuccess;
-  gradients_kernel<<<blocks(n), 256, 0, s>>>(d_level, d_dI, d_abs2, w, h, nframes);
-  return hipGetLastError();
+  if (w <= 0 || h <= 0) return hipSuccess;
+  // launches of at most 2^30 workgroups
+  const int64_t per_frame = (int64_t)((w + kGradThreads - 1) / kGradThreads) * ((h + kGradRows - 1) / kGradRows);
+  const int64_t step = std::max<int64_t>(1, (1ll << 30) / per_frame);
+  const int64_t npx = (int64_t)w * h;
+  for (int64_t f0 = 0; f0 < nframes; f0 += step) {
+    const float* src = d_level + f0 * npx;
+    float* dI = d_dI + f0 * npx * 3;
+    float* a2 = d_abs2 + f0 * npx;
+    hipError_t e = launch_gradients_levels(1, &src, &dI, &a2, &w, &h, std::min(step, nframes - f0), s);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 }  // namespace mdc
