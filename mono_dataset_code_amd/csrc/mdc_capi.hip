@@ -805,16 +805,20 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
         const int64_t groups = chunk_groups(c, fuse_pyr);
         MDC_HIP(c, hipEventRecord(h->ev_fork, s));
         MDC_HIP(c, hipStreamWaitEvent(h->stream, h->ev_fork, 0));
+        // whatever happens below, the caller's stream waits for what reached the second one
+        hipError_t e = hipSuccess;
         int k = 0;
-        for (int64_t f0 = 0; f0 < nframes; f0 += chunk, k++) {
+        for (int64_t f0 = 0; f0 < nframes && e == hipSuccess; f0 += chunk, k++) {
           const int64_t n = std::min<int64_t>(chunk, nframes - f0);
           hipStream_t t = (k & 1) ? h->stream : s;
-          MDC_HIP(c, launch_prefetch_rows(d_in + (size_t)f0 * frame_in, frame_in, iw, x0, x1, y0, y1, n, c->d_vcal_max, t));
+          e = launch_prefetch_rows(d_in + (size_t)f0 * frame_in, frame_in, iw, x0, x1, y0, y1, n, c->d_vcal_max, t);
           const int fpb = c->opt_fpb > 0 ? (int)std::min<int64_t>(c->opt_fpb, n) : (int)((n + groups - 1) / groups);
-          MDC_HIP(c, strip(f0, n, fpb, t));
+          if (e == hipSuccess) e = strip(f0, n, fpb, t);
         }
-        MDC_HIP(c, hipEventRecord(h->ev_join, h->stream));
-        MDC_HIP(c, hipStreamWaitEvent(s, h->ev_join, 0));
+        const hipError_t ej = hipEventRecord(h->ev_join, h->stream);
+        const hipError_t ew = ej == hipSuccess ? hipStreamWaitEvent(s, h->ev_join, 0) : ej;
+        MDC_HIP(c, e);
+        MDC_HIP(c, ew);
         if (pyr_done) *pyr_done = fuse_pyr;
         return MDC_OK;
       }

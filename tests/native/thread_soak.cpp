@@ -1,7 +1,11 @@
 // Threading contract of the C ABI (SURVEY.md section 8b "Threading"; the reference's unMapImage / undistort are
 // re-entrant on shared objects, reference src/FOVUndistorter.cpp:322-368 is const) proved WITHOUT torch:
 //
-//   thread_soak <calibration folder> <threads> <iterations per thread> [<frames per batch>]
+//   thread_soak <calibration folder> <threads> <iterations per thread> [<frames per batch> [<prefetch chunk>]]
+//
+// <prefetch chunk> > 0 (a calibration the strip kernel takes, batches of >= 2 chunks): every rectifying launch walks its
+// batch in prefetched chunks alternating between the caller's stream and a stream borrowed from the context's slot pool
+// (MDC_OPT_PREFETCH_CHUNK / MDC_OPT_PREFETCH_STREAMS) -- from T threads at once, next to host calls that lease slots too.
 //
 // T host threads share ONE mdc_ctx.  Every thread owns a hipStreamNonBlocking stream, its own frames and its own
 // device buffers and loops: hipMemsetAsync poison on ITS stream -> mdc_process_batch_device on that stream (flag
@@ -48,12 +52,13 @@ static bool same_bits(const float* a, const float* b, size_t n) {
 
 int main(int argc, char** argv) {
   if (argc < 4) {
-    std::fprintf(stderr, "usage: %s <calibration folder> <threads> <iterations> [<frames per batch>]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <calibration folder> <threads> <iterations> [<frames per batch> [<prefetch chunk>]]\n", argv[0]);
     return 2;
   }
   std::string folder = argv[1];
   if (folder[folder.size() - 1] != '/') folder += "/";
   const int T = std::atoi(argv[2]), iters = std::atoi(argv[3]), B = argc > 4 ? std::atoi(argv[4]) : 3;
+  const int prefetch_chunk = argc > 5 ? std::atoi(argv[5]) : 0;
 
   mdch_fov* fov = mdch_fov_create((folder + "camera.txt").c_str());
   int d4[4];
@@ -78,6 +83,14 @@ int main(int argc, char** argv) {
   if (mdch_bind(ctx, fov, photo) != MDC_OK) {
     std::fprintf(stderr, "bind: %s\n", mdc_last_error(ctx));
     return 5;
+  }
+  if (prefetch_chunk > 0) {
+    mdc_info info;
+    if (mdc_set_option(ctx, MDC_OPT_PREFETCH_CHUNK, prefetch_chunk) != MDC_OK || mdc_get_info(ctx, &info) != MDC_OK || !info.two_stage ||
+        info.prefetch_streams != 2) {
+      std::fprintf(stderr, "prefetch chunk %d: not on the strip path with two streams (%s)\n", prefetch_chunk, mdc_last_error(ctx));
+      return 6;
+    }
   }
 
   // frames and expected results, up front on one thread: thread k owns frames k*B .. k*B+B-1 of the counter-hash sequence;
@@ -163,9 +176,9 @@ int main(int argc, char** argv) {
   for (auto& t : th) t.join();
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (failed) std::fprintf(stderr, "a HIP / mdc call failed: %s\n", mdc_last_error(ctx));
-  std::printf("THREAD_SOAK threads %d iterations %d frames_per_batch %d size %dx%d->%dx%d device_launches %lld host_calls %lld seconds %.2f "
+  std::printf("THREAD_SOAK threads %d iterations %d frames_per_batch %d prefetch_chunk %d size %dx%d->%dx%d device_launches %lld host_calls %lld seconds %.2f "
               "call_failures %d mismatches %lld\n",
-              T, iters, B, W, H, w, h, (long long)launches, (long long)host_calls, sec, (int)failed, (long long)mismatches);
+              T, iters, B, prefetch_chunk, W, H, w, h, (long long)launches, (long long)host_calls, sec, (int)failed, (long long)mismatches);
   mdc_destroy(ctx);
   mdch_photo_destroy(photo);
   mdch_fov_destroy(fov);

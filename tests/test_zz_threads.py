@@ -111,3 +111,19 @@ def test_native_threads_one_context_own_streams(name, threads, iters, calib_dirs
     assert r.returncode == 0 and line, r.stdout[-3000:]
     kv = dict(zip(line[-1].split()[1::2], line[-1].split()[2::2]))
     assert int(kv["mismatches"]) == 0 and int(kv["call_failures"]) == 0 and int(kv["device_launches"]) == threads * iters, line[-1]
+
+
+@pytest.mark.parametrize("name,threads,iters,batch,chunk", [("mag4_full_black", 8, 150, 5, 1), ("upsample", 12, 60, 7, 2)])
+def test_native_threads_share_the_second_stream_pool(name, threads, iters, batch, chunk, calib_dirs):
+    """The chunked strip path borrows its second stream from the context's slot pool (at most 8 slots, shared with the host
+    entry points): 8 / 12 threads launching batches that go in 1- / 2-frame chunks over two streams, on ONE context, next to
+    blocking host calls -- every result against the C oracle; a thread that finds no free slot runs its chunks on one stream."""
+    if not os.path.exists(SOAK):
+        pytest.skip("thread_soak not built")
+    r = subprocess.run([SOAK, calib_dirs[name], str(threads), str(iters), str(batch), str(chunk)], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("THREAD_SOAK")]
+    assert r.returncode == 0 and line, r.stdout[-3000:]
+    kv = dict(zip(line[-1].split()[1::2], line[-1].split()[2::2]))
+    assert int(kv["mismatches"]) == 0 and int(kv["call_failures"]) == 0 and int(kv["device_launches"]) == threads * iters, line[-1]
+    assert int(kv["prefetch_chunk"]) == chunk

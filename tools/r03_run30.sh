@@ -1,0 +1,5 @@
+#!/bin/bash
+# round 3, run 30: whole GPU suite with the two-stream strip path + gradient v2; thread soak on the shared slot pool
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r3_30; mkdir -p $O
+( time timeout 2400 python -m pytest tests -x -q -m gpu ) > $O/pytest.txt 2>&1; grep -E "passed|failed" $O/pytest.txt | tail -1; grep -E "^E " $O/pytest.txt | head -8
