@@ -777,10 +777,10 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
     const int64_t frame_in = (int64_t)iw * c->rm_in_h;
     const int64_t box_bytes = prefetch_box_bytes(c);
     int64_t chunk = prefetch_chunk_frames(c, fuse_pyr);
-    // Measured (profiles/r03_experiments/08_*): with the fused pyramid (6.96 MB written per frame, 4 waves per SIMD) the
-    // prefetch takes 1.86-1.94 ms per 1024 frames down to 1.64-1.70; without the levels it changes nothing (1.54 -> 1.56),
-    // so it is used for the pyramid launches (or on request: a positive MDC_OPT_PREFETCH_CHUNK).
-    const bool prefetch = c->opt_prefetch_chunk >= 0 && (fuse_pyr || c->opt_prefetch_chunk > 0) && box_bytes >= 4096 && nframes >= 2 * chunk;
+    // Measured (profiles/r03_experiments/08_*, 10_*), ms per 1024 frames of config 5: with the fused pyramid one launch 1.86-1.94,
+    // chunks on one stream 1.64-1.70, over two streams 1.47-1.52; without the levels 1.62 / 1.55-1.65 / 1.29.
+    const bool prefetch = c->opt_prefetch_chunk >= 0 && (fuse_pyr || c->opt_prefetch_chunk > 0 || prefetch_streams(c) == 2) && box_bytes >= 4096 &&
+                          nframes >= 2 * chunk;
     if (!prefetch) chunk = nframes;
     const size_t no = (size_t)c->out_w * c->out_h;
     const int64_t resident = strip_resident(fuse_pyr);
