@@ -90,7 +90,13 @@ enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2 /* frames a workgroup lo
           (~26 MiB of source rows, in whole frame groups), -1 = no prefetch (one launch over the whole batch) */,
        MDC_OPT_PREFETCH_STREAMS = 13 /* tuning: those chunks alternate between the caller's stream and a second, internal one
           (joined back into the caller's stream before the call returns: the caller sees one stream), so that a chunk's tail
-          and the next chunk's prefetch run under the other chunk's launch: 0 = automatic (2), 1, 2 */ };
+          and the next chunk's prefetch run under the other chunk's launch: 0 = automatic (2), 1, 2 */,
+       MDC_OPT_ZERO_COPY = 14 /* the host-pointer calls (mdc_process_host, mdc_unmap_host, mdc_undistort_host_*,
+          mdc_process_frames_host, mdc_process_jpeg_frames_host) hand a caller's buffer to the kernels AS IT IS when it lies in
+          page-locked memory mapped into the device's address space (mdc_host_alloc, hipHostMalloc, hipHostRegister; asked
+          of the runtime per call): the kernel reads the frame / writes the result over PCIe itself, both directions at once,
+          instead of copy in -> kernel -> copy out.  Pageable buffers go through the staging copies as before.
+          0 = automatic (on), 1 = on, 2 = off */ };
 enum { MDC_ORDER_BANDS = 0 /* row-major runs of tiles per XCD */, MDC_ORDER_ROWS = 1 /* whole tile rows per XCD */,
        MDC_ORDER_IDENTITY = 2 /* block b = tile b (diagnosis) */,
        MDC_ORDER_BLOCKS2D = 3 /* the tile grid cut into 8 rectangles, one per XCD */ };

@@ -104,6 +104,7 @@ struct mdc_ctx {
   int opt_nbuf = 0;  // 0 = automatic
   int opt_interleave = 0;
   int opt_pin_caller = 0;  // MDC_OPT_PIN_CALLER_BUFFERS
+  int opt_zero_copy = 0;         // MDC_OPT_ZERO_COPY: 0 = automatic (on), 1 = on, 2 = off
   int opt_prefetch_streams = 0;  // MDC_OPT_PREFETCH_STREAMS: 0 = automatic (2), 1, 2
   int opt_prefetch_chunk = 0;  // MDC_OPT_PREFETCH_CHUNK: frames per prefetched chunk of the strip path; 0 = automatic, -1 = no prefetch
   int opt_two_stage = 0;   // MDC_OPT_TWO_STAGE: 0 = automatic (strip kernel by source pixels per output), 1 = strip kernel whenever
@@ -620,6 +621,31 @@ void unpin_all(mdc_ctx* c) {
   c->pin_candidate[0] = c->pin_candidate[1] = nullptr;
 }
 
+// Zero copy (MDC_OPT_ZERO_COPY): a host buffer that is page-locked and mapped into the device's address space (hipHostMalloc
+// -- mdc_host_alloc, the reader's rings and image pool --, hipHostRegister) is handed to the kernels as it is: they read the
+// frame / write the result over PCIe themselves, both directions at once, instead of copy in -> kernel -> copy out.  Returns
+// the device's view of [p, p + bytes) or nullptr (pageable memory, a range that leaves its allocation, zero copy off).
+// Asked of the runtime on every call -- nothing is remembered about a caller's memory.
+template <class T>
+T* device_view(const mdc_ctx* c, T* p, size_t bytes) {
+  if (c->opt_zero_copy == 2 || !p || bytes == 0) return nullptr;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, (const void*)p) != hipSuccess) {
+    (void)hipGetLastError();  // pageable memory: not an error of ours
+    return nullptr;
+  }
+  if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)a.devicePointer) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  const uintptr_t lo = (uintptr_t)a.devicePointer, b0 = (uintptr_t)base;
+  if (lo < b0 || lo + bytes > b0 + size) return nullptr;
+  return (T*)a.devicePointer;
+}
+
 // A slot of the host-pointer calls for the duration of one call (RAII).  s == nullptr: no slot could be made (error set).
 struct SlotLease {
   mdc_ctx* c;
@@ -997,6 +1023,10 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
       MDC_HIP(c, hipDeviceSynchronize());
       return plan_tiles(c);
     }
+    case MDC_OPT_ZERO_COPY:
+      if (value < 0 || value > 2) return fail(c, MDC_ERR_ARG, "zero-copy selector must be 0 (automatic), 1 (on) or 2 (off)");
+      c->opt_zero_copy = value;
+      return MDC_OK;
     case MDC_OPT_PREFETCH_STREAMS:
       if (value < 0 || value > 2) return fail(c, MDC_ERR_ARG, "prefetch streams must be 0 (automatic), 1 or 2");
       c->opt_prefetch_streams = value;
@@ -1637,13 +1667,16 @@ int mdc_unmap_host(mdc_ctx* c, const uint8_t* in, float* out, int n, unsigned fl
     return fail(c, MDC_ERR_SIZE, "unMapImage: n = %d but the vignette holds %d pixels", n, c->in_w * c->in_h);
   SlotLease slot(c);
   if (!slot.s) return MDC_ERR_HIP;
-  int rc = ensure_stage(c, slot.s, (size_t)n, (size_t)n * sizeof(float));
+  maybe_pin(c, 0, out, (size_t)n * sizeof(float));
+  const uint8_t* z_in = device_view(c, in, (size_t)n);
+  float* z_out = device_view(c, out, (size_t)n * sizeof(float));
+  int rc = ensure_stage(c, slot.s, z_in ? 0 : (size_t)n, z_out ? 0 : (size_t)n * sizeof(float));
   if (rc != MDC_OK) return rc;
   hipStream_t st = slot.s->stream;
-  maybe_pin(c, 0, out, (size_t)n * sizeof(float));
-  MDC_HIP(c, hipMemcpyAsync(slot.s->d_in, in, (size_t)n, hipMemcpyHostToDevice, st));
-  MDC_HIP(c, launch_unmap((const uint8_t*)slot.s->d_in, slot.s->d_out, lut_for(c, g, o), v ? c->d_vinv : nullptr, n, 1, 1, st));
-  MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (!z_in) MDC_HIP(c, hipMemcpyAsync(slot.s->d_in, in, (size_t)n, hipMemcpyHostToDevice, st));
+  MDC_HIP(c, launch_unmap(z_in ? z_in : (const uint8_t*)slot.s->d_in, z_out ? z_out : slot.s->d_out, lut_for(c, g, o), v ? c->d_vinv : nullptr, n,
+                          1, 1, st));
+  if (!z_out) MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
   MDC_HIP(c, hipStreamSynchronize(st));
   return MDC_OK;
 }
@@ -1663,18 +1696,22 @@ static int undistort_host(mdc_ctx* c, const void* in, bool is_f32, float* out, i
   const size_t in_bytes = (size_t)n_in * (is_f32 ? 4 : 1);
   SlotLease slot(c);
   if (!slot.s) return MDC_ERR_HIP;
-  int rc = ensure_stage(c, slot.s, in_bytes, (size_t)n_out * sizeof(float));
+  if (is_f32) maybe_pin(c, 1, in, in_bytes);
+  const void* z_in = device_view(c, in, in_bytes);
+  float* z_out = device_view(c, out, (size_t)n_out * sizeof(float));
+  int rc = ensure_stage(c, slot.s, z_in ? 0 : in_bytes, z_out ? 0 : (size_t)n_out * sizeof(float));
   if (rc != MDC_OK) return rc;
   hipStream_t st = slot.s->stream;
-  if (is_f32) maybe_pin(c, 1, in, in_bytes);
-  MDC_HIP(c, hipMemcpyAsync(slot.s->d_in, in, in_bytes, hipMemcpyHostToDevice, st));
-  if (is_f32) rc = enqueue_undistort_f32(c, (const float*)slot.s->d_in, slot.s->d_out, 1, st);
-  else rc = enqueue_process(c, (const uint8_t*)slot.s->d_in, slot.s->d_out, 1, MDC_RECTIFY, st);
+  if (!z_in) MDC_HIP(c, hipMemcpyAsync(slot.s->d_in, in, in_bytes, hipMemcpyHostToDevice, st));
+  const void* src = z_in ? z_in : slot.s->d_in;
+  float* dst = z_out ? z_out : slot.s->d_out;
+  if (is_f32) rc = enqueue_undistort_f32(c, (const float*)src, dst, 1, st);
+  else rc = enqueue_process(c, (const uint8_t*)src, dst, 1, MDC_RECTIFY, st);
   if (rc != MDC_OK) {
     (void)hipStreamSynchronize(st);  // the upload borrows the caller's buffer: not in flight after the call
     return rc;
   }
-  MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, (size_t)n_out * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (!z_out) MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, (size_t)n_out * sizeof(float), hipMemcpyDeviceToHost, st));
   MDC_HIP(c, hipStreamSynchronize(st));
   return MDC_OK;
 }
@@ -1699,16 +1736,18 @@ int mdc_process_host(mdc_ctx* c, const uint8_t* raw, float* out, unsigned flags)
   const size_t n_out = rect ? (size_t)c->out_w * c->out_h : n_in;
   SlotLease slot(c);
   if (!slot.s) return MDC_ERR_HIP;
-  int rc = ensure_stage(c, slot.s, n_in, n_out * sizeof(float));
+  const uint8_t* z_in = device_view(c, raw, n_in);
+  float* z_out = device_view(c, out, n_out * sizeof(float));
+  int rc = ensure_stage(c, slot.s, z_in ? 0 : n_in, z_out ? 0 : n_out * sizeof(float));
   if (rc != MDC_OK) return rc;
   hipStream_t st = slot.s->stream;
-  MDC_HIP(c, hipMemcpyAsync(slot.s->d_in, raw, n_in, hipMemcpyHostToDevice, st));
-  rc = enqueue_process(c, (const uint8_t*)slot.s->d_in, slot.s->d_out, 1, flags, st);
+  if (!z_in) MDC_HIP(c, hipMemcpyAsync(slot.s->d_in, raw, n_in, hipMemcpyHostToDevice, st));
+  rc = enqueue_process(c, z_in ? z_in : (const uint8_t*)slot.s->d_in, z_out ? z_out : slot.s->d_out, 1, flags, st);
   if (rc != MDC_OK) {
     (void)hipStreamSynchronize(st);
     return rc;
   }
-  MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (!z_out) MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, st));
   MDC_HIP(c, hipStreamSynchronize(st));
   return MDC_OK;
 }
@@ -1745,10 +1784,19 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
   for (int64_t i = 0; i < nframes; i++)
     if (!(rec ? rec[i] : (const void*)raw[i]) || !out[i]) return fail(c, MDC_ERR_ARG, "%s: frame %lld has a NULL buffer", who, (long long)i);
   constexpr int kChunk = 16;  // frames per slot: one kernel launch (two with the inverse DCT), 2 x 16 async copies
+  // Zero copy (device_view): results go straight into the caller's images when every one of them is mapped page-locked
+  // memory, frames are read straight from the caller's buffers when every one of them is (coefficient records are always
+  // copied: the inverse DCT reads a record 16 bytes at a time per thread, uncached that would cross PCIe several times).
+  std::vector<float*> z_out((size_t)nframes);
+  std::vector<const uint8_t*> z_in(rec ? 0 : (size_t)nframes);
+  bool zc_out = nframes > 0, zc_in = !rec && nframes > 0;
+  for (int64_t i = 0; i < nframes && zc_out; i++) zc_out = (z_out[(size_t)i] = device_view(c, out[i], n_out * sizeof(float))) != nullptr;
+  for (int64_t i = 0; i < nframes && zc_in; i++) zc_in = (z_in[(size_t)i] = device_view(c, raw[i], n_in)) != nullptr;
+  if (!zc_out) zc_in = false;  // frames alone: the copy pipeline (one launch per chunk) stays
+  const size_t in_need = zc_in ? 0 : kChunk * n_in, out_need = zc_out ? 0 : kChunk * n_out * sizeof(float);
   const size_t rec_need = rec ? (size_t)kChunk * (size_t)record_bytes : 0;
-  if (c->pipe_in_cap < kChunk * n_in || c->pipe_out_cap < kChunk * n_out * sizeof(float) || c->pipe_rec_cap < rec_need || !c->pipe_stream[0] ||
-      !c->pipe_stream[1]) {
-    const size_t rec_cap = std::max(rec_need, c->pipe_rec_cap);
+  if (c->pipe_in_cap < in_need || c->pipe_out_cap < out_need || c->pipe_rec_cap < rec_need || !c->pipe_stream[0] || !c->pipe_stream[1]) {
+    const size_t in_cap = std::max(in_need, c->pipe_in_cap), out_cap = std::max(out_need, c->pipe_out_cap), rec_cap = std::max(rec_need, c->pipe_rec_cap);
     c->pipe_in_cap = c->pipe_out_cap = c->pipe_rec_cap = 0;  // a failure part-way leaves "no slots", not stale capacities
     for (int k = 0; k < 2; k++) {
       if (c->pipe_stream[k]) MDC_HIP(c, hipStreamSynchronize(c->pipe_stream[k]));
@@ -1759,12 +1807,12 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
           (void)hipFree(*p);
           *p = nullptr;
         }
-      MDC_HIP(c, hipMalloc(&c->d_pipe_in[k], kChunk * n_in));
-      MDC_HIP(c, hipMalloc(&c->d_pipe_out[k], kChunk * n_out * sizeof(float)));
+      if (in_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_in[k], in_cap));
+      if (out_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_out[k], out_cap));
       if (rec_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_rec[k], rec_cap));
     }
-    c->pipe_in_cap = kChunk * n_in;
-    c->pipe_out_cap = kChunk * n_out * sizeof(float);
+    c->pipe_in_cap = in_cap;
+    c->pipe_out_cap = out_cap;
     c->pipe_rec_cap = rec_cap;
   }
   // chunk k runs entirely on stream k%2 (H2D, kernel(s), D2H in order); the two streams overlap one
@@ -1779,25 +1827,40 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
     he = (call);                    \
     if (he != hipSuccess) what = #call; \
   }
-  for (int64_t f0 = 0, k = 0; f0 < nframes && rc == MDC_OK && he == hipSuccess; f0 += kChunk, k++) {
+  const int chunk = (zc_in && zc_out) ? 64 : kChunk;  // nothing staged: the chunk only alternates the streams
+  for (int64_t f0 = 0, k = 0; f0 < nframes && rc == MDC_OK && he == hipSuccess; f0 += chunk, k++) {
     const int slot = (int)(k & 1);
     hipStream_t s = c->pipe_stream[slot];
-    const int n = (int)std::min<int64_t>(kChunk, nframes - f0);
-    if (k >= 2) MDC_PIPE(hipEventSynchronize(c->pipe_done[slot]));
+    const int n = (int)std::min<int64_t>(chunk, nframes - f0);
+    if (k >= 2 && !(zc_in && zc_out)) MDC_PIPE(hipEventSynchronize(c->pipe_done[slot]));  // the slot's staging is free again
     if (rec) {
       for (int i = 0; i < n; i++)
         MDC_PIPE(hipMemcpyAsync((char*)c->d_pipe_rec[slot] + (size_t)i * record_bytes, rec[f0 + i], (size_t)record_bytes, hipMemcpyHostToDevice, s));
       MDC_PIPE(launch_jpeg_idct(c->d_pipe_rec[slot], record_bytes, c->d_pipe_in[slot], iw, ih, blocks_w, blocks_rows, n, s));
-    } else {
+    } else if (!zc_in) {
       for (int i = 0; i < n; i++)
         MDC_PIPE(hipMemcpyAsync(c->d_pipe_in[slot] + (size_t)i * n_in, raw[f0 + i], n_in, hipMemcpyHostToDevice, s));
     }
     if (he != hipSuccess) break;
-    rc = enqueue_process(c, c->d_pipe_in[slot], c->d_pipe_out[slot], n, flags, s);
-    if (rc != MDC_OK) break;
-    for (int i = 0; i < n; i++)
-      MDC_PIPE(hipMemcpyAsync(out[f0 + i], c->d_pipe_out[slot] + (size_t)i * n_out, n_out * sizeof(float),
-                              hipMemcpyDeviceToHost, s));
+    if (zc_out) {  // one launch per run of frames that lie back to back on both sides
+      for (int i = 0; i < n && rc == MDC_OK;) {
+        const uint8_t* src = zc_in ? z_in[(size_t)(f0 + i)] : c->d_pipe_in[slot] + (size_t)i * n_in;
+        float* dst = z_out[(size_t)(f0 + i)];
+        int run = 1;
+        while (i + run < n && z_out[(size_t)(f0 + i + run)] == dst + (size_t)run * n_out &&
+               (!zc_in || z_in[(size_t)(f0 + i + run)] == src + (size_t)run * n_in))
+          run++;
+        rc = enqueue_process(c, src, dst, run, flags, s);
+        i += run;
+      }
+      if (rc != MDC_OK) break;
+    } else {
+      rc = enqueue_process(c, c->d_pipe_in[slot], c->d_pipe_out[slot], n, flags, s);
+      if (rc != MDC_OK) break;
+      for (int i = 0; i < n; i++)
+        MDC_PIPE(hipMemcpyAsync(out[f0 + i], c->d_pipe_out[slot] + (size_t)i * n_out, n_out * sizeof(float),
+                                hipMemcpyDeviceToHost, s));
+    }
     MDC_PIPE(hipEventRecord(c->pipe_done[slot], s));
   }
   for (int k = 0; k < 2; k++) {

@@ -728,6 +728,68 @@ def test_process_frames_host_pipeline(name, setups, oracle):
         assert bits_equal(pin_out.array[i], want[i % len(base)]), (name, "pinned", i)
 
 
+@pytest.mark.parametrize("name", ["small_crop", "ragged", "mag4_full_black"])
+def test_zero_copy_host_calls(name, setups, oracle):
+    """MDC_OPT_ZERO_COPY: buffers in mapped page-locked memory are read / written by the kernels directly -- every host entry
+    point, every mix of page-locked and pageable sides, buffers that start inside an allocation, frames scattered over the
+    block (runs of 1, 2, 3 back-to-back frames, a step backwards), against the oracle, with zero copy on and switched off."""
+    from mono_dataset_code_amd import capi
+
+    s = setups(name)
+    base = make_frames(s.W, s.H, n_noise=5)
+    npi, npo = s.W * s.H, s.w * s.h
+    n = 9
+    pin_in = capi.PinnedArray((n + 1, npi), np.uint8)
+    pin_out = capi.PinnedArray((n + 1, npo), np.float32)
+    pin_unm = capi.PinnedArray((4, npi), np.float32)
+    for i in range(n + 1):
+        pin_in.array[i] = base[i % len(base)]
+    want = [s.want(oracle, f, 1, 1, 1, 1) for f in base]
+    want_unmap = [oracle.unmap(f, s.ginv, s.vinv, True, True, 1, 1, 1) for f in base]
+    want_und8 = [oracle.undistort(f, s.rx, s.ry, s.W) for f in base]
+    try:
+        for zc in (0, 2, 1):
+            s.ctx.set_option(capi.OPT_ZERO_COPY, zc)
+            # single-frame calls: pinned -> pinned, pageable -> pinned, pinned -> pageable
+            for src_pinned, dst_pinned in ((1, 1), (0, 1), (1, 0)):
+                for i in (0, 3):
+                    raw = pin_in.array[i] if src_pinned else base[i % len(base)].copy()
+                    out = pin_out.array[i] if dst_pinned else np.empty(npo, np.float32)
+                    out[:] = -7.0
+                    s.ctx.process_host(raw, out, 15)
+                    assert bits_equal(out, want[i % len(base)]), (name, zc, "process_host", src_pinned, dst_pinned, i)
+                    out_u = pin_unm.array[i] if dst_pinned else np.empty(npi, np.float32)
+                    out_u[:] = -7.0
+                    s.ctx.unmap_host(raw, out_u, 7)
+                    assert bits_equal(out_u, want_unmap[i % len(base)]), (name, zc, "unmap_host", src_pinned, dst_pinned, i)
+                    out[:] = -7.0
+                    s.ctx.undistort_host(raw, out)
+                    assert bits_equal(out, want_und8[i % len(base)]), (name, zc, "undistort_u8", src_pinned, dst_pinned, i)
+                    if src_pinned and dst_pinned:  # undistort<float> from a page-locked float frame into a pageable result
+                        res = np.full(npo, -7.0, np.float32)
+                        s.ctx.undistort_host(out_u, res)
+                        assert bits_equal(res, oracle.undistort(want_unmap[i % len(base)], s.rx, s.ry, s.W)), (name, zc, "undistort_f32", i)
+            # many frames: rows of the page-locked blocks in an order with runs of 1, 2 and 3 neighbours and a step backwards
+            order = [0, 1, 2, 4, 6, 7, 5, 3, 8]
+            ins = [pin_in.array[i] for i in order]
+            outs = [pin_out.array[i] for i in order]
+            pin_out.array[:] = -7.0
+            s.ctx.process_frames_host(ins, outs, 15)
+            for k, i in enumerate(order):
+                assert bits_equal(outs[k], want[i % len(base)]), (name, zc, "frames_host", k, i)
+            # results into page-locked rows, frames from pageable memory; and the other way round
+            pin_out.array[:] = -7.0
+            s.ctx.process_frames_host([base[i % len(base)].copy() for i in order], outs, 15)
+            for k, i in enumerate(order):
+                assert bits_equal(outs[k], want[i % len(base)]), (name, zc, "frames_host pageable in", k, i)
+            loose = [np.full(npo, -7.0, np.float32) for _ in order]
+            s.ctx.process_frames_host(ins, loose, 15)
+            for k, i in enumerate(order):
+                assert bits_equal(loose[k], want[i % len(base)]), (name, zc, "frames_host pageable out", k, i)
+    finally:
+        s.ctx.set_option(capi.OPT_ZERO_COPY, 0)
+
+
 def test_table_blob_roundtrip(setups, oracle, torch_cuda):
     """export -> import into a second context (what the RCCL broadcast carries)."""
     from mono_dataset_code_amd import capi
