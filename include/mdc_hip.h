@@ -196,6 +196,38 @@ int mdc_process_jpeg_frames_host(mdc_ctx* ctx, const void* const* records, int64
 int mdc_jpeg_idct_batch_device(mdc_ctx* ctx, const void* d_records, int64_t record_bytes, uint8_t* d_frames, int w, int h, int blocks_w,
                                int blocks_rows, int64_t nframes, void* stream);
 
+/* JPEG ingest with the Huffman decoding on the GPU too.  The host only parses the file's markers, builds the two decode
+ * tables of the scan and copies the entropy-coded segment with its FF00 byte stuffing removed (mdch_jpeg_stream in
+ * include/mdc_host.h: ~0.1 ms per 1280 x 1024 frame against ~2.5 ms for the Huffman decoding) into a STREAM per frame:
+ *   mdc_jpeg_stream_header, then ecs_bytes entropy-coded bytes, then at least 16 zero bytes.
+ * Single-component (grayscale) baseline / extended-sequential Huffman files without restart markers -- what the TUM mono
+ * dataset ships; for anything else mdch_jpeg_stream says no and the caller takes the record path above.
+ * mdc_process_jpeg_streams_host: stream i in place of raw frame i.  The device decodes every stream with 1024 threads
+ * (subsequences of the bit stream whose entry states are relaxed until they are the sequential decoder's, csrc/mdc_jpeg.hip),
+ * then runs the inverse DCT and the fused kernel as for records: the results equal the host decoder's path bit for bit.
+ * status[i] (optional): 0 = done, 1 = the stream holds a code no table knows or too few blocks, 2 = header does not describe
+ * a frame of this context -- out[i] is then not a result and the caller decodes that file on the host.
+ * mdc_jpeg_huffman_batch_device is the device stage alone: nframes streams, stream_stride bytes apart (multiple of 16) ->
+ * nframes records (layout above), d_status[i] as status[i]. */
+#define MDC_JPEG_STREAM_MAGIC 0x31534a4du /* "MJS1" */
+typedef struct mdc_jpeg_huff {
+  uint16_t look[512];  /* codes of <= 9 bits, indexed by the next 9 bits: length << 8 | symbol; 0 = longer code */
+  int16_t fast[512];   /* AC table: a 9-bit window holding code + magnitude bits: value << 8 | run << 4 | bits used; 0 = no */
+  int32_t maxcode[18]; /* [l], l = 1..16: largest code of length l or -1; [17] = INT_MAX */
+  int32_t valoff[18];  /* [l]: index into vals of the first code of length l, minus that code */
+  uint8_t vals[256];
+} mdc_jpeg_huff;
+typedef struct mdc_jpeg_stream_header {
+  uint32_t magic, w, h, ecs_bytes;
+  uint32_t reserved[4];
+  uint16_t quant[64]; /* natural order */
+  mdc_jpeg_huff dc, ac;
+} mdc_jpeg_stream_header; /* 5056 bytes */
+int mdc_process_jpeg_streams_host(mdc_ctx* ctx, const void* const* streams, const int64_t* stream_bytes, float* const* out, int64_t nframes,
+                                  unsigned flags, int* status);
+int mdc_jpeg_huffman_batch_device(mdc_ctx* ctx, const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w,
+                                  int h, int blocks_w, int blocks_rows, int64_t nframes, int* d_status, void* stream);
+
 /* ---- device-pointer, batched: the throughput path --------------------------- */
 
 /* unMapImage over nframes back-to-back frames (in: nframes*w*h u8; out: same count f32). */

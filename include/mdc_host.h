@@ -75,7 +75,7 @@ int mdch_reader_get_images(mdch_reader*, int first, int count, int rectify, int 
 int mdch_reader_get_raw(mdch_reader*, int id, unsigned char* out, long cap, int wh[2]); /* getImageRaw(); 1 / 0 */
 void mdch_reader_set_threads(mdch_reader*, int n);       /* setDecodeThreads() */
 void mdch_reader_set_prefetch(mdch_reader*, int frames); /* setPrefetch() */
-void mdch_reader_set_gpu_jpeg(mdch_reader*, int on);      /* setGpuJpeg() */
+void mdch_reader_set_gpu_jpeg(mdch_reader*, int stage);   /* setGpuJpegStage(): 0 host, 1 device inverse DCT, 2 (or any other) device Huffman too */
 const char* mdch_reader_last_error(mdch_reader*);
 void mdch_reader_prefetch_stats(mdch_reader*, long hits_misses[2]); /* getPrefetchStats() */
 
@@ -92,6 +92,13 @@ int mdch_decode_gray8(const unsigned char* data, size_t n, unsigned char* out, s
 size_t mdch_jpeg_record_bytes(int w, int h, int pitch_rows[2]);
 int mdch_decode_jpeg_record(const unsigned char* data, size_t n, void* record, size_t record_bytes, int pitch_blocks, int dims[4], char* err,
                             size_t errcap);
+
+/* The host part of JPEG decoding when the GPU does the Huffman decoding as well (mdc_process_jpeg_streams_host, include/mdc_hip.h):
+ * parses the markers, builds the scan's two decode tables and copies the entropy-coded segment without its byte stuffing into
+ * `stream` (4-byte aligned, cap bytes; page-locked memory for the upload): mdc_jpeg_stream_header + bytes + 16 zero bytes.
+ * Returns the bytes written, 0 (reason in err) for what the device decoder does not take -- more than one component,
+ * progressive files, restart markers, a stream that does not fit: decode those with mdch_decode_jpeg_record / _gray8. */
+long long mdch_jpeg_stream(const unsigned char* data, size_t n, void* stream, size_t cap, int wh[2], char* err, size_t errcap);
 
 /* ExposureImage's pixel pool (include/mono_dataset_code/ExposureImage.h). */
 float* mdch_image_alloc(unsigned long nfloats);

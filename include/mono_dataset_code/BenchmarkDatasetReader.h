@@ -71,9 +71,12 @@ class DatasetReader {
 
   void setDecodeThreads(int n);  // worker threads of the decode pool; 0 = automatic (default)
   void setPrefetch(int frames);  // frames decoded ahead after a getImage (default 16, 0 = off)
-  // getImages on JPEG sequences: the host only Huffman-decodes, the inverse DCT runs on the GPU in front of the fused pass
-  // (same bytes; default on, also MDC_GPU_JPEG=0 in the environment)
+  // getImages on JPEG sequences: stage 2 (default): the decode threads only parse the file's markers and strip the byte
+  // stuffing, Huffman decoding, inverse DCT and the fused pass run on the GPU (grayscale baseline files without restart
+  // markers; others take stage 1); stage 1: the host Huffman-decodes, the inverse DCT runs on the GPU; stage 0: JPEG is decoded
+  // on the host.  Same bytes in every stage.  setGpuJpeg(on) = stage 2 / 0; MDC_GPU_JPEG=0|1|2 in the environment.
   void setGpuJpeg(bool on);
+  void setGpuJpegStage(int stage);
   const char* lastError() const; // why the last getImage / getImages / getImageRaw returned 0 / fewer images
   void getPrefetchStats(long* hits, long* misses) const;  // frames found decoded ahead / decoded by the calling thread
 

@@ -29,7 +29,7 @@ OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 HIP_SYMBOLS = [
     "mdc_create", "mdc_destroy", "mdc_last_error", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
     "mdc_set_remap", "mdc_unmap_host", "mdc_undistort_host_f32", "mdc_undistort_host_u8", "mdc_process_host",
-    "mdc_host_alloc", "mdc_host_free", "mdc_process_frames_host", "mdc_process_jpeg_frames_host", "mdc_jpeg_idct_batch_device",
+    "mdc_host_alloc", "mdc_host_free", "mdc_process_frames_host", "mdc_process_jpeg_frames_host", "mdc_jpeg_idct_batch_device", "mdc_process_jpeg_streams_host", "mdc_jpeg_huffman_batch_device",
     "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
     "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device",
     "mdc_distort_points_device", "mdc_distort_points_host", "mdc_export_tables", "mdc_import_tables",
@@ -46,7 +46,7 @@ HOST_SYMBOLS = [
     "mdch_reader_create", "mdch_reader_destroy", "mdch_reader_num_images", "mdch_reader_timestamp", "mdch_reader_exposure",
     "mdch_reader_dims", "mdch_reader_get_image", "mdch_reader_get_images", "mdch_reader_get_raw", "mdch_reader_set_threads",
     "mdch_reader_set_prefetch", "mdch_reader_set_gpu_jpeg", "mdch_reader_last_error", "mdch_reader_prefetch_stats", "mdch_decode_gray8", "mdch_jpeg_record_bytes",
-    "mdch_decode_jpeg_record", "mdch_image_alloc", "mdch_image_free",
+    "mdch_decode_jpeg_record", "mdch_jpeg_stream", "mdch_image_alloc", "mdch_image_free",
     "mdch_image_pool_trim", "mdch_image_pool_idle_bytes",
 ]
 
@@ -139,6 +139,8 @@ def hip_lib():
         if hasattr(L, "mdc_process_jpeg_frames_host"):
             L.mdc_process_jpeg_frames_host.argtypes = [_vp, C.POINTER(_vp), _i64, _i, _i, C.POINTER(_vp), _i64, C.c_uint]
             L.mdc_jpeg_idct_batch_device.argtypes = [_vp, _vp, _i64, _vp, _i, _i, _i, _i, _i64, _vp]
+            L.mdc_process_jpeg_streams_host.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_int64), C.POINTER(_vp), _i64, C.c_uint, C.POINTER(C.c_int)]
+            L.mdc_jpeg_huffman_batch_device.argtypes = [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i64, _vp, _vp]
         L.mdc_unmap_batch_device.argtypes = [_vp, _vp, _vp, _i64, C.c_uint, _vp]
         L.mdc_process_batch_device.argtypes = [_vp, _vp, _vp, _i64, C.c_uint, _vp]
         L.mdc_undistort_batch_device_f32.argtypes = [_vp, _vp, _vp, _i64, _vp]
@@ -258,6 +260,8 @@ def host_lib():
         L.mdch_jpeg_record_bytes.argtypes = [_i, _i, _vp]
         L.mdch_jpeg_record_bytes.restype = _sz
         L.mdch_decode_jpeg_record.argtypes = [_vp, _sz, _vp, _sz, _i, _vp, C.c_char_p, _sz]
+        L.mdch_jpeg_stream.argtypes = [_vp, _sz, _vp, _sz, _vp, C.c_char_p, _sz]
+        L.mdch_jpeg_stream.restype = C.c_longlong
         L.mdch_image_alloc.argtypes = [C.c_ulong]
         L.mdch_image_alloc.restype = _vp
         L.mdch_image_free.argtypes = [_vp]
@@ -388,6 +392,21 @@ class Context:
         a = (_vp * max(1, n))(*[_np_ptr(r) for r in records])
         b = (_vp * max(1, n))(*[_np_ptr(o) for o in outs])
         self._chk(self._L.mdc_process_jpeg_frames_host(self._h, a, record_bytes, blocks_w, blocks_rows, b, n, flags))
+
+    def process_jpeg_streams_host(self, streams, sizes, outs, flags):
+        """streams: numpy uint8 arrays (jpeg_stream), sizes: bytes used of each, outs: f32 result arrays -> per-frame status list."""
+        n = len(streams)
+        assert len(outs) == n and len(sizes) == n
+        a = (_vp * max(1, n))(*[_np_ptr(r) for r in streams])
+        b = (_vp * max(1, n))(*[_np_ptr(o) for o in outs])
+        sz = (C.c_int64 * max(1, n))(*[int(x) for x in sizes])
+        st = (C.c_int * max(1, n))()
+        self._chk(self._L.mdc_process_jpeg_streams_host(self._h, a, sz, b, n, flags, st))
+        return [int(st[i]) for i in range(n)]
+
+    def jpeg_huffman_batch(self, d_streams, stream_stride, d_records, record_bytes, w, h, blocks_w, blocks_rows, nframes, d_status, stream=0):
+        self._chk(self._L.mdc_jpeg_huffman_batch_device(self._h, d_streams, stream_stride, d_records, record_bytes, w, h, blocks_w, blocks_rows,
+                                                        nframes, d_status, stream if stream else None))
 
     def jpeg_idct_batch(self, d_records, record_bytes, d_frames, w, h, blocks_w, blocks_rows, nframes, stream=0):
         self._chk(self._L.mdc_jpeg_idct_batch_device(self._h, d_records, record_bytes, d_frames, w, h, blocks_w, blocks_rows, nframes,
@@ -717,6 +736,22 @@ def decode_jpeg_record(data, record, pitch_blocks):
     return tuple(int(x) for x in dims)
 
 
+JPEG_STREAM_HEADER_BYTES = 5056
+
+
+def jpeg_stream(data, stream):
+    """Markers parsed, decode tables built, entropy-coded segment unstuffed into `stream` (numpy uint8; page-locked for the GPU
+    stage) -> (bytes used, w, h); ValueError for files the device Huffman decoder does not take."""
+    L = host_lib()
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    wh = np.zeros(2, np.int32)
+    err = C.create_string_buffer(256)
+    used = L.mdch_jpeg_stream(_np_ptr(buf), buf.size, _np_ptr(stream), stream.size, _np_ptr(wh), err, 256)
+    if not used:
+        raise ValueError(err.value.decode())
+    return int(used), int(wh[0]), int(wh[1])
+
+
 class DatasetReader:
     """class DatasetReader (include/mono_dataset_code/BenchmarkDatasetReader.h) through the C facade."""
 
@@ -759,8 +794,9 @@ class DatasetReader:
     def set_prefetch(self, n):
         self._L.mdch_reader_set_prefetch(self._h, n)
 
-    def set_gpu_jpeg(self, on):
-        self._L.mdch_reader_set_gpu_jpeg(self._h, int(bool(on)))
+    def set_gpu_jpeg(self, stage):
+        """True / 2: Huffman decoding + inverse DCT on the GPU; 1: inverse DCT only; False / 0: JPEG decoded on the host."""
+        self._L.mdch_reader_set_gpu_jpeg(self._h, (2 if stage else 0) if isinstance(stage, bool) else int(stage))
 
     def get_image(self, i, rectify, g, v, o):
         """-> (image (h, w) float32, timestamp, exposure, id) or None (getImage returned 0)."""

@@ -46,6 +46,9 @@ struct Decode {
   int want_record_pitch = 0;
   bool is_record = false;
   int rec_rows = 0;
+  // ... or, with the Huffman decoding on the GPU as well, only unstuffed into a stream (mdc_jpeg_stream_header + bytes) at dst
+  bool want_stream = false, is_stream = false;
+  size_t stream_bytes = 0;
   std::string err;
   unsigned long stamp = 0;  // prefetch cache: age
 };
@@ -103,17 +106,16 @@ struct DatasetReader::State {
   unsigned long clock = 0;
   long cache_hits = 0, cache_misses = 0;  // frames found decoded (or being decoded) ahead / decoded by the caller itself
 
-  // ring of getImages
-  // ring of getImages: kRing chunks of kChunk page-locked frame buffers.  Chunk k is on the GPU while the pool decodes
-  // chunks k+1 .. k+kRing-1 (up to 160 frames in flight): a decode thread that is slow on one frame delays only the
+  // ring of getImages: chunks of 32 (64 in JPEG stage 2) page-locked frame buffers, 256 in all.  Chunk k is on the GPU while
+  // the pool decodes chunks k+1 .. (up to 192 frames in flight): a decode thread that is slow on one frame delays only the
   // chunk that frame is in, not the pipeline (two half-rings of 64 stalled on every straggler: 2.5-2.9 k frames/s)
-  static const int kChunk = 32, kRing = 6;
-  std::vector<HostBuffer> ring;  // kRing * kChunk frames (250 MB at 1280x1024, allocated on the first getImages)
+  static const int kRingFrames = 256;  // page-locked decode buffers of getImages (335 MB at 1280x1024, 670 MB in stage 1; first getImages)
+  std::vector<HostBuffer> ring;
 
   size_t frame_bytes() const { return (size_t)W * H; }
   // GPU JPEG stage of getImages: JPEG frames travel as coefficient records (2 bytes per pixel + table), the inverse DCT runs on
   // the device.  Default on; MDC_GPU_JPEG=0 or setGpuJpeg(false) keeps the whole decode on the host.
-  bool gpu_jpeg = true;
+  int gpu_jpeg = 2;  // 0: JPEG decoded on the host; 1: host Huffman + device inverse DCT; 2: device Huffman + inverse DCT
   int rec_pitch = 0, rec_rows = 0;
   size_t rec_bytes = 0;
   size_t ring_bytes = 0;  // bytes of one ring buffer (a frame, or a record when the GPU JPEG stage is on)
@@ -146,8 +148,18 @@ struct DatasetReader::State {
       d.err = "cannot read " + files[(size_t)d.id];
       return;
     }
-    d.is_record = false;
-    if (d.want_record_pitch > 0 && bytes.size() > 4 && bytes[0] == 0xff && bytes[1] == 0xd8 && d.cap > 256) {
+    d.is_record = d.is_stream = false;
+    const bool is_jpeg = bytes.size() > 4 && bytes[0] == 0xff && bytes[1] == 0xd8;
+    if (d.want_stream && is_jpeg) {  // what the device decoder takes (grayscale baseline, no restart markers); else the record path
+      std::string why;
+      size_t used = 0;
+      if (mdc_host::jpeg_stream(bytes.data(), bytes.size(), d.dst, d.cap, &used, &d.w, &d.h, &why)) {
+        d.ok = d.is_stream = true;
+        d.stream_bytes = used;
+        return;
+      }
+    }
+    if (d.want_record_pitch > 0 && is_jpeg && d.cap > 256) {
       mdc_host::JpegCoefSink sink;
       sink.coef = reinterpret_cast<int16_t*>(d.dst + 128);
       sink.cap_blocks = (d.cap - 128) / 128;
@@ -342,7 +354,7 @@ void list_folder(const std::string& dir, std::vector<std::string>& files) {
 }  // namespace
 
 DatasetReader::DatasetReader(std::string folder) : s_(new State()) {
-  if (const char* e = std::getenv("MDC_GPU_JPEG")) s_->gpu_jpeg = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MDC_GPU_JPEG")) s_->gpu_jpeg = std::max(0, std::min(2, std::atoi(e)));
   State& s = *s_;
   s.path = folder;
   list_folder(s.path + "images/", s.files);
@@ -443,7 +455,8 @@ void DatasetReader::setDecodeThreads(int n) {
   s.want_threads = n;
 }
 
-void DatasetReader::setGpuJpeg(bool on) { s_->gpu_jpeg = on; }
+void DatasetReader::setGpuJpeg(bool on) { s_->gpu_jpeg = on ? 2 : 0; }
+void DatasetReader::setGpuJpegStage(int stage) { s_->gpu_jpeg = std::max(0, std::min(2, stage)); }
 
 void DatasetReader::setPrefetch(int frames) {
   State& s = *s_;
@@ -515,13 +528,17 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
     std::fprintf(stderr, "DatasetReader::getImages: %s\n", s.err.c_str());
     return 0;
   }
-  const int C = State::kChunk, RG = State::kRing;
+  // frames per GPU call / calls in the ring: stage 2 hands over 64 at a time (the device Huffman decoder's launch time does
+  // not depend on the frame count up to ~64)
+  const int C = s.gpu_jpeg >= 2 ? 64 : 32, RG = State::kRingFrames / C;
   // coefficient records (include/mdc_hip.h): MCUs are at most 4 x 4 blocks, so a grid rounded up to multiples of 4 blocks
   // holds every sampling layout of a W x H file (the same rule as mdch_jpeg_record_bytes)
   s.rec_pitch = ((s.W + 7) / 8 + 3) & ~3;
   s.rec_rows = ((s.H + 7) / 8 + 3) & ~3;
   s.rec_bytes = 128 + (size_t)s.rec_pitch * s.rec_rows * 128;
-  const size_t want_bytes = s.gpu_jpeg ? std::max(s.frame_bytes(), s.rec_bytes) : s.frame_bytes();
+  // a ring buffer holds a decoded frame, or (stage 1) a coefficient record -- 2 bytes per pixel --, or (stage 2) a stream: the
+  // compressed bytes + 5 KB; a file stage 2 does not take, or whose stream does not fit, is decoded to pixels on the host
+  const size_t want_bytes = s.gpu_jpeg == 1 ? std::max(s.frame_bytes(), s.rec_bytes) : s.frame_bytes();
   if (s.ring.empty() || s.ring_bytes < want_bytes) {
     for (auto& m : s.ring) m.release();
     s.ring.assign((size_t)RG * C, HostBuffer());
@@ -538,7 +555,8 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
       d.id = first + i;
       d.dst = s.ring[(size_t)((k % RG) * C + (i - k * C))].p;
       d.cap = s.ring_bytes;
-      d.want_record_pitch = s.gpu_jpeg ? s.rec_pitch : 0;
+      d.want_record_pitch = (s.gpu_jpeg && s.ring_bytes >= s.rec_bytes) ? s.rec_pitch : 0;
+      d.want_stream = s.gpu_jpeg >= 2;
       s.submit(&d);
     }
     s.cv_job.notify_all();
@@ -553,6 +571,10 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
   std::vector<float*> dst;
   std::vector<const void*> rsrc;  // frames of the chunk that arrived as JPEG coefficient records
   std::vector<float*> rdst;
+  std::vector<const void*> ssrc;  // ... as JPEG streams (Huffman decoding on the device)
+  std::vector<float*> sdst;
+  std::vector<int64_t> ssize;
+  std::vector<int> sstatus, sidx;
   for (int k = 0; k < nchunks; k++) {
     const int i0 = k * C, i1 = std::min(count, (k + 1) * C);
     const double tw = now();
@@ -569,6 +591,10 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
     dst.clear();
     rsrc.clear();
     rdst.clear();
+    ssrc.clear();
+    sdst.clear();
+    ssize.clear();
+    sidx.clear();
     for (int i = i0; i < i1; i++) {
       const Decode& d = rec[(size_t)i];
       const int id = first + i;
@@ -580,7 +606,12 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
       }
       out[i] = rectify ? new ExposureImage(s.w, s.h, s.timestamps[(size_t)id], s.exposures[(size_t)id], id)
                        : new ExposureImage(s.W, s.H, s.timestamps[(size_t)id], s.exposures[(size_t)id], id);
-      if (d.is_record && d.rec_rows <= s.rec_rows) {
+      if (d.is_stream) {
+        ssrc.push_back(d.dst);
+        sdst.push_back(out[i]->image);
+        ssize.push_back((int64_t)d.stream_bytes);
+        sidx.push_back(i);
+      } else if (d.is_record && d.rec_rows <= s.rec_rows) {
         rsrc.push_back(d.dst);
         rdst.push_back(out[i]->image);
       } else {
@@ -593,6 +624,29 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
     int grc = src.empty() ? MDC_OK : mdc_process_frames_host(s.gpu, src.data(), dst.data(), (int64_t)src.size(), flags);
     if (grc == MDC_OK && !rsrc.empty())  // records: Huffman-decoded on the host, inverse DCT on the device
       grc = mdc_process_jpeg_frames_host(s.gpu, rsrc.data(), (int64_t)s.rec_bytes, s.rec_pitch, s.rec_rows, rdst.data(), (int64_t)rsrc.size(), flags);
+    if (grc == MDC_OK && !ssrc.empty()) {  // streams: Huffman decoding, inverse DCT and the fused pass on the device
+      sstatus.assign(ssrc.size(), 0);
+      grc = mdc_process_jpeg_streams_host(s.gpu, ssrc.data(), ssize.data(), sdst.data(), (int64_t)ssrc.size(), flags, sstatus.data());
+      for (size_t j = 0; j < ssrc.size() && grc == MDC_OK; j++)
+        if (sstatus[j] != 0) {  // a stream the device could not decode (damaged file): the host decoder has the last word
+          const int i = sidx[j];
+          Decode one;
+          one.id = first + i;
+          one.dst = const_cast<unsigned char*>(static_cast<const unsigned char*>(ssrc[j]));  // the ring buffer of this frame
+          one.cap = s.ring_bytes;
+          s.decode_now(one);
+          if (one.ok && one.w == s.W && one.h == s.H) {
+            grc = mdc_process_host(s.gpu, one.dst, out[i]->image, flags);
+          } else {
+            std::printf("ERROR: expected cv-mat to have dimensions %d x %d; found %d x %d (image %s)!\n", s.W, s.H, one.w, one.h,
+                        s.files[(size_t)(first + i)].c_str());
+            if (!one.ok) s.err = one.err;
+            delete out[i];
+            out[i] = 0;
+            produced--;
+          }
+        }
+    }
     t_gpu += now() - tg;
     if (grc != MDC_OK) {
       s.err = mdc_last_error(s.gpu);
@@ -602,7 +656,7 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
         out[i] = 0;
       }
     } else {
-      produced += (int)src.size() + (int)rsrc.size();
+      produced += (int)src.size() + (int)rsrc.size() + (int)ssrc.size();
     }
     if (k + RG < nchunks) submit_chunk(k + RG);  // chunk k's buffers are free again
   }

@@ -1,5 +1,6 @@
 #include "image_codecs.h"
 #include "image_codecs_internal.h"
+#include "mdc_hip.h"
 
 #include <zlib.h>
 #include <algorithm>
@@ -557,6 +558,117 @@ bool decode_jpeg_coefs(const unsigned char* d, size_t n, JpegCoefSink* sink, std
   if (n < 4 || d[0] != 0xff || d[1] != 0xd8) return fail(err, "not a JPEG file");
   int w = 0, h = 0;
   return jpeg_gray8(d, n, nullptr, 0, &w, &h, err, sink);
+}
+
+bool jpeg_stream(const unsigned char* d, size_t n, unsigned char* stream, size_t cap, size_t* used, int* w, int* h, std::string* err) {
+  if (n < 4 || d[0] != 0xff || d[1] != 0xd8) return fail(err, "not a JPEG file");
+  if (!stream || cap < sizeof(mdc_jpeg_stream_header) + 32 || (reinterpret_cast<uintptr_t>(stream) & 3) != 0) return fail(err, "stream buffer too small");
+  uint16_t qt[4][64];
+  bool have_qt[4] = {false, false, false, false};
+  Huff dc[4], ac[4];
+  int W = 0, H = 0, tq = 0;
+  bool have_sof = false;
+  size_t p = 2;
+  while (p + 4 <= n) {
+    if (d[p] != 0xff) return fail(err, "JPEG: marker expected");
+    while (p < n && d[p] == 0xff) p++;
+    if (p >= n) break;
+    const int m = d[p++];
+    if (m == 0xd8 || m == 0x01) continue;
+    if (m >= 0xd0 && m <= 0xd7) return fail(err, "JPEG stream: restart markers");
+    if (m == 0xd9) break;
+    if (p + 2 > n) return fail(err, "JPEG: truncated");
+    const size_t len = (size_t)d[p] << 8 | d[p + 1];
+    if (len < 2 || p + len > n) return fail(err, "JPEG: bad segment length");
+    const unsigned char* s = d + p + 2;
+    const size_t sl = len - 2;
+    if (m == 0xdb) {
+      size_t q = 0;
+      while (q < sl) {
+        const int pq = s[q] >> 4, t = s[q] & 15;
+        q++;
+        if (t > 3 || q + (pq ? 128 : 64) > sl) return fail(err, "JPEG: bad DQT");
+        for (int i = 0; i < 64; i++, q += pq ? 2 : 1) qt[t][kZigzag[i]] = pq ? (uint16_t)(s[q] << 8 | s[q + 1]) : s[q];
+        have_qt[t] = true;
+      }
+    } else if (m == 0xc4) {
+      size_t q = 0;
+      while (q + 17 <= sl) {
+        const int tc = s[q] >> 4, th = s[q] & 15;
+        int cnt = 0;
+        for (int i = 0; i < 16; i++) cnt += s[q + 1 + i];
+        if (th > 3 || tc > 1 || cnt > 256 || q + 17 + (size_t)cnt > sl) return fail(err, "JPEG: bad DHT");
+        if (!build_huff(tc ? ac[th] : dc[th], s + q + 1, s + q + 17, cnt)) return fail(err, "JPEG: bad Huffman table");
+        q += 17 + (size_t)cnt;
+      }
+    } else if (m == 0xc0 || m == 0xc1) {
+      if (sl < 9 || s[0] != 8) return fail(err, "JPEG: only 8-bit samples are supported");
+      H = s[1] << 8 | s[2];
+      W = s[3] << 8 | s[4];
+      if (s[5] != 1) return fail(err, "JPEG stream: more than one component");
+      tq = s[8] & 3;
+      if (W <= 0 || H <= 0) return fail(err, "JPEG: unsupported frame header");
+      have_sof = true;
+    } else if (m >= 0xc2 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
+      return fail(err, "JPEG stream: not a sequential Huffman file");
+    } else if (m == 0xdd) {
+      if (sl >= 2 && (s[0] << 8 | s[1]) != 0) return fail(err, "JPEG stream: restart interval");
+    } else if (m == 0xda) {
+      if (!have_sof) return fail(err, "JPEG: scan before frame header");
+      if (sl < 6 || s[0] != 1) return fail(err, "JPEG: only single-scan files are supported");
+      const int td = s[2] >> 4, ta = s[2] & 15;
+      if (td > 3 || ta > 3 || !dc[td].present || !ac[ta].present || !have_qt[tq]) return fail(err, "JPEG: scan refers to a missing table");
+      mdc_jpeg_stream_header* hd = reinterpret_cast<mdc_jpeg_stream_header*>(stream);
+      memset(hd, 0, sizeof *hd);
+      hd->magic = MDC_JPEG_STREAM_MAGIC;
+      hd->w = (uint32_t)W;
+      hd->h = (uint32_t)H;
+      for (int i = 0; i < 64; i++) hd->quant[i] = qt[tq][i];
+      const Huff* src[2] = {&dc[td], &ac[ta]};
+      mdc_jpeg_huff* dst[2] = {&hd->dc, &hd->ac};
+      for (int k = 0; k < 2; k++) {
+        memcpy(dst[k]->look, src[k]->look, sizeof dst[k]->look);
+        if (k) memcpy(dst[k]->fast, src[k]->fast_ac, sizeof dst[k]->fast);
+        for (int l = 0; l < 18; l++) dst[k]->maxcode[l] = l >= 1 ? src[k]->maxcode[l] : -1;
+        for (int l = 0; l < 18; l++) dst[k]->valoff[l] = (l >= 1 && l <= 16) ? src[k]->valoff[l] : 0;
+        memcpy(dst[k]->vals, src[k]->vals, 256);
+      }
+      // entropy-coded segment without its byte stuffing; ends at the first marker (EOI)
+      const unsigned char* q = d + p + len;
+      const unsigned char* end = d + n;
+      unsigned char* o = stream + sizeof *hd;
+      unsigned char* const o_end = stream + cap - 16;
+      while (q < end) {
+        const unsigned char* ff = static_cast<const unsigned char*>(memchr(q, 0xff, (size_t)(end - q)));
+        const size_t run = ff ? (size_t)(ff - q) : (size_t)(end - q);
+        if (o + run + 1 > o_end) return fail(err, "JPEG stream: does not fit the buffer");
+        memcpy(o, q, run);
+        o += run;
+        q += run;
+        if (!ff) break;
+        if (q + 1 < end && q[1] == 0x00) {  // stuffed zero: a data byte FF
+          *o++ = 0xff;
+          q += 2;
+        } else if (q + 1 < end && q[1] == 0xff) {  // fill byte
+          q++;
+        } else if (q + 1 < end && q[1] >= 0xd0 && q[1] <= 0xd7) {
+          return fail(err, "JPEG stream: restart markers");
+        } else {
+          break;  // EOI (or any other marker): end of the scan
+        }
+      }
+      const size_t ecs = (size_t)(o - (stream + sizeof *hd));
+      if (ecs == 0 || ecs >= (1u << 28)) return fail(err, "JPEG stream: empty scan");
+      memset(o, 0, 16);
+      hd->ecs_bytes = (uint32_t)ecs;
+      *used = sizeof *hd + ecs + 16;
+      *w = W;
+      *h = H;
+      return true;
+    }
+    p += len;
+  }
+  return fail(err, "JPEG: no scan found");
 }
 
 bool decode_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap, int* w, int* h, std::string* err) {

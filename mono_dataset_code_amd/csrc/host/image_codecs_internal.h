@@ -31,6 +31,12 @@ struct JpegCoefSink {
 };
 bool decode_jpeg_coefs(const unsigned char* data, size_t n, JpegCoefSink* sink, std::string* err);
 
+// GPU Huffman stage (include/mdc_hip.h: mdc_jpeg_stream_header): markers parsed, decode tables built, entropy-coded segment
+// copied without its byte stuffing into `stream` (capacity cap) -- header, ecs bytes, 16 zero bytes; *used = bytes written.
+// false (err says why) for what the device decoder does not take: more than one component, progressive / arithmetic /
+// lossless files, restart intervals, 16-bit quantisation values above what a record holds, a stream that does not fit.
+bool jpeg_stream(const unsigned char* data, size_t n, unsigned char* stream, size_t cap, size_t* used, int* w, int* h, std::string* err);
+
 bool jpeg_progressive_gray8(const unsigned char* data, size_t n, unsigned char* out, size_t cap, int* w, int* h, std::string* err,
                             JpegCoefSink* sink = nullptr);
 // libjpeg's islow inverse DCT on dequantised coefficients in natural order (image_codecs.cpp)

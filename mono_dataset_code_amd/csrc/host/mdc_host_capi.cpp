@@ -268,7 +268,7 @@ int mdch_reader_get_raw(mdch_reader* h, int id, unsigned char* out, long cap, in
 }
 void mdch_reader_set_threads(mdch_reader* h, int n) { h->r->setDecodeThreads(n); }
 void mdch_reader_set_prefetch(mdch_reader* h, int n) { h->r->setPrefetch(n); }
-void mdch_reader_set_gpu_jpeg(mdch_reader* h, int on) { h->r->setGpuJpeg(on != 0); }
+void mdch_reader_set_gpu_jpeg(mdch_reader* h, int stage) { h->r->setGpuJpegStage(stage == 1 ? 1 : (stage ? 2 : 0)); }
 const char* mdch_reader_last_error(mdch_reader* h) { return h->r->lastError(); }
 void mdch_reader_prefetch_stats(mdch_reader* h, long hm[2]) { h->r->getPrefetchStats(&hm[0], &hm[1]); }
 
@@ -307,6 +307,24 @@ int mdch_decode_jpeg_record(const unsigned char* data, size_t n, void* record, s
     err[errcap - 1] = 0;
   }
   return ok ? 1 : 0;
+}
+
+long long mdch_jpeg_stream(const unsigned char* data, size_t n, void* stream, size_t cap, int wh[2], char* err, size_t errcap) {
+  std::string e;
+  size_t used = 0;
+  int w = 0, h = 0;
+  const bool ok = data && stream && wh && mdc_host::jpeg_stream(data, n, static_cast<unsigned char*>(stream), cap, &used, &w, &h, &e);
+  if (ok) {
+    wh[0] = w;
+    wh[1] = h;
+  } else if (e.empty()) {
+    e = "bad argument";
+  }
+  if (err && errcap) {
+    strncpy(err, e.c_str(), errcap - 1);
+    err[errcap - 1] = 0;
+  }
+  return ok ? (long long)used : 0;
 }
 
 int mdch_decode_gray8(const unsigned char* data, size_t n, unsigned char* out, size_t cap, int wh[2], char* err, size_t errcap) {

@@ -130,7 +130,11 @@ struct mdc_ctx {
   uint8_t* d_pipe_in[2] = {nullptr, nullptr};
   float* d_pipe_out[2] = {nullptr, nullptr};
   void* d_pipe_rec[2] = {nullptr, nullptr};  // JPEG coefficient records of a chunk (mdc_process_jpeg_frames_host)
-  size_t pipe_in_cap = 0, pipe_out_cap = 0, pipe_rec_cap = 0;
+  void* d_pipe_strm[2] = {nullptr, nullptr};  // JPEG streams of a chunk (mdc_process_jpeg_streams_host)
+  int* d_pipe_status[2] = {nullptr, nullptr}; // their decode status words (one chunk each)
+  int* h_pipe_status = nullptr;               // page-locked landing buffer for them (a whole call)
+  size_t pipe_status_cap = 0;
+  size_t pipe_in_cap = 0, pipe_out_cap = 0, pipe_rec_cap = 0, pipe_strm_cap = 0;
 
   // vignetteCalib: bit pattern of the largest new vignette factor of ONE vignette step.  A ring of words, one per call:
   // steps that different threads put on different streams of one context never share a word.
@@ -949,9 +953,10 @@ void mdc_destroy(mdc_ctx* c) {
     unpin_all(c);
     free_plan(c);
     void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_vcal_max, c->d_pipe_in[0], c->d_pipe_in[1], c->d_pipe_out[0], c->d_pipe_out[1],
-                    c->d_pipe_rec[0], c->d_pipe_rec[1]};
+                    c->d_pipe_rec[0], c->d_pipe_rec[1], c->d_pipe_strm[0], c->d_pipe_strm[1], c->d_pipe_status[0], c->d_pipe_status[1]};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
+    if (c->h_pipe_status) (void)hipHostFree(c->h_pipe_status);
     for (int k = 0; k < 2; k++) {
       if (c->pipe_done[k]) (void)hipEventDestroy(c->pipe_done[k]);
       if (c->pipe_stream[k]) (void)hipStreamDestroy(c->pipe_stream[k]);
@@ -1763,12 +1768,14 @@ void mdc_host_free(void* p) {
   if (p) (void)hipHostFree(p);
 }
 
-// Common body of the two pipelined host calls: frame i comes from raw[i] (bytes) or, with `rec`, from the JPEG
-// coefficient record rec[i] through the device-side inverse DCT.
+// Common body of the pipelined host calls: frame i comes from raw[i] (bytes), or, with `rec`, from the JPEG coefficient
+// record rec[i] through the device-side inverse DCT, or, with `strm`, from the JPEG stream strm[i] (strm_bytes[i] bytes)
+// through the device-side Huffman decoder and the inverse DCT (status: per-frame decode status, may be NULL).
 static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const void* const* rec, int64_t record_bytes, int blocks_w,
-                                   int blocks_rows, float* const* out, int64_t nframes, unsigned flags, const char* who) {
+                                   int blocks_rows, float* const* out, int64_t nframes, unsigned flags, const char* who,
+                                   const void* const* strm = nullptr, const int64_t* strm_bytes = nullptr, int* status = nullptr) {
   if (!c) return MDC_ERR_ARG;
-  if (nframes < 0 || (nframes > 0 && ((!raw && !rec) || !out))) return fail(c, MDC_ERR_ARG, "%s: bad argument", who);
+  if (nframes < 0 || (nframes > 0 && ((!raw && !rec && !strm) || !out || (strm && !strm_bytes)))) return fail(c, MDC_ERR_ARG, "%s: bad argument", who);
   ReadLock lk(c->mu);
   std::lock_guard<std::mutex> pipe_lk(c->pipe_mu);  // one pipelined call at a time per context (it overlaps internally)
   DeviceGuard dg(c->device);
@@ -1778,31 +1785,60 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
   if (iw <= 0 || ih <= 0) return fail(c, MDC_ERR_STATE, "frame size unknown");
   const size_t n_in = (size_t)iw * ih;
   const size_t n_out = rect ? (size_t)c->out_w * c->out_h : n_in;
-  if (rec && (blocks_w < (iw + 7) / 8 || blocks_rows < (ih + 7) / 8 || record_bytes % 16 != 0 ||
-              record_bytes < 128 + (int64_t)blocks_w * blocks_rows * 128))
+  size_t strm_stride = 0;
+  if (strm) {  // streams are decoded into records of the reader's geometry (block grid rounded up to multiples of 4)
+    blocks_w = ((iw + 7) / 8 + 3) & ~3;
+    blocks_rows = ((ih + 7) / 8 + 3) & ~3;
+    record_bytes = 128 + (int64_t)blocks_w * blocks_rows * 128;
+    for (int64_t i = 0; i < nframes; i++) {
+      if (strm_bytes[i] < (int64_t)sizeof(mdc_jpeg_stream_header) + 17 || strm_bytes[i] > (1ll << 28))
+        return fail(c, MDC_ERR_ARG, "%s: stream %lld has an impossible size", who, (long long)i);
+      strm_stride = std::max(strm_stride, (size_t)strm_bytes[i]);
+    }
+    strm_stride = (strm_stride + 15) & ~(size_t)15;
+  }
+  if ((rec || strm) && (blocks_w < (iw + 7) / 8 || blocks_rows < (ih + 7) / 8 || record_bytes % 16 != 0 ||
+                        record_bytes < 128 + (int64_t)blocks_w * blocks_rows * 128))
     return fail(c, MDC_ERR_ARG, "%s: coefficient records do not describe a %dx%d frame", who, iw, ih);
   for (int64_t i = 0; i < nframes; i++)
-    if (!(rec ? rec[i] : (const void*)raw[i]) || !out[i]) return fail(c, MDC_ERR_ARG, "%s: frame %lld has a NULL buffer", who, (long long)i);
+    if (!(strm ? strm[i] : rec ? rec[i] : (const void*)raw[i]) || !out[i])
+      return fail(c, MDC_ERR_ARG, "%s: frame %lld has a NULL buffer", who, (long long)i);
+  if (status)
+    for (int64_t i = 0; i < nframes; i++) status[i] = 0;
+  if (strm && status && c->pipe_status_cap < (size_t)nframes) {  // status words come back asynchronously: page-locked landing buffer
+    if (c->h_pipe_status) (void)hipHostFree(c->h_pipe_status);
+    c->h_pipe_status = nullptr;
+    c->pipe_status_cap = 0;
+    const size_t cap = std::max<size_t>(256, (size_t)nframes * 2);
+    MDC_HIP(c, hipHostMalloc((void**)&c->h_pipe_status, cap * sizeof(int), hipHostMallocDefault));
+    c->pipe_status_cap = cap;
+  }
   constexpr int kChunk = 16;  // frames per slot: one kernel launch (two with the inverse DCT), 2 x 16 async copies
   // Zero copy (device_view): results go straight into the caller's images when every one of them is mapped page-locked
   // memory, frames are read straight from the caller's buffers when every one of them is (coefficient records are always
   // copied: the inverse DCT reads a record 16 bytes at a time per thread, uncached that would cross PCIe several times).
   std::vector<float*> z_out((size_t)nframes);
-  std::vector<const uint8_t*> z_in(rec ? 0 : (size_t)nframes);
-  bool zc_out = nframes > 0, zc_in = !rec && nframes > 0;
+  std::vector<const uint8_t*> z_in((rec || strm) ? 0 : (size_t)nframes);
+  bool zc_out = nframes > 0, zc_in = !rec && !strm && nframes > 0;
   for (int64_t i = 0; i < nframes && zc_out; i++) zc_out = (z_out[(size_t)i] = device_view(c, out[i], n_out * sizeof(float))) != nullptr;
   for (int64_t i = 0; i < nframes && zc_in; i++) zc_in = (z_in[(size_t)i] = device_view(c, raw[i], n_in)) != nullptr;
   if (!zc_out) zc_in = false;  // frames alone: the copy pipeline (one launch per chunk) stays
-  const size_t in_need = zc_in ? 0 : kChunk * n_in, out_need = zc_out ? 0 : kChunk * n_out * sizeof(float);
-  const size_t rec_need = rec ? (size_t)kChunk * (size_t)record_bytes : 0;
-  if (c->pipe_in_cap < in_need || c->pipe_out_cap < out_need || c->pipe_rec_cap < rec_need || !c->pipe_stream[0] || !c->pipe_stream[1]) {
+  // frames per slot.  Streams: 32 -- the Huffman kernel's time does not depend on the frame count up to ~64 (one workgroup per
+  // frame, 1.3 ms), so small chunks would only repeat that latency; nothing staged: the chunk only alternates the streams
+  const int chunk = (zc_in && zc_out) ? 64 : (strm ? 32 : kChunk);
+  const size_t in_need = zc_in ? 0 : chunk * n_in, out_need = zc_out ? 0 : chunk * n_out * sizeof(float);
+  const size_t rec_need = (rec || strm) ? (size_t)chunk * (size_t)record_bytes : 0;
+  const size_t strm_need = strm ? (size_t)chunk * strm_stride : 0;
+  if (c->pipe_in_cap < in_need || c->pipe_out_cap < out_need || c->pipe_rec_cap < rec_need || c->pipe_strm_cap < strm_need || !c->pipe_stream[0] ||
+      !c->pipe_stream[1]) {
     const size_t in_cap = std::max(in_need, c->pipe_in_cap), out_cap = std::max(out_need, c->pipe_out_cap), rec_cap = std::max(rec_need, c->pipe_rec_cap);
-    c->pipe_in_cap = c->pipe_out_cap = c->pipe_rec_cap = 0;  // a failure part-way leaves "no slots", not stale capacities
+    const size_t strm_cap = std::max(strm_need + strm_need / 4, c->pipe_strm_cap);  // (stream sizes vary from call to call: some headroom)
+    c->pipe_in_cap = c->pipe_out_cap = c->pipe_rec_cap = c->pipe_strm_cap = 0;  // a failure part-way leaves "no slots", not stale capacities
     for (int k = 0; k < 2; k++) {
       if (c->pipe_stream[k]) MDC_HIP(c, hipStreamSynchronize(c->pipe_stream[k]));
       if (!c->pipe_stream[k]) MDC_HIP(c, hipStreamCreateWithFlags(&c->pipe_stream[k], hipStreamNonBlocking));
       if (!c->pipe_done[k]) MDC_HIP(c, hipEventCreateWithFlags(&c->pipe_done[k], hipEventDisableTiming));
-      for (void** p : {(void**)&c->d_pipe_in[k], (void**)&c->d_pipe_out[k], &c->d_pipe_rec[k]})
+      for (void** p : {(void**)&c->d_pipe_in[k], (void**)&c->d_pipe_out[k], &c->d_pipe_rec[k], &c->d_pipe_strm[k], (void**)&c->d_pipe_status[k]})
         if (*p) {
           (void)hipFree(*p);
           *p = nullptr;
@@ -1810,10 +1846,13 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
       if (in_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_in[k], in_cap));
       if (out_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_out[k], out_cap));
       if (rec_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_rec[k], rec_cap));
+      if (strm_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_strm[k], strm_cap));
+      if (strm_cap) MDC_HIP(c, hipMalloc((void**)&c->d_pipe_status[k], 64 * sizeof(int)));
     }
     c->pipe_in_cap = in_cap;
     c->pipe_out_cap = out_cap;
     c->pipe_rec_cap = rec_cap;
+    c->pipe_strm_cap = strm_cap;
   }
   // chunk k runs entirely on stream k%2 (H2D, kernel(s), D2H in order); the two streams overlap one
   // chunk's copies with the other's kernel.  Re-using a slot waits for its previous chunk.
@@ -1827,13 +1866,19 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
     he = (call);                    \
     if (he != hipSuccess) what = #call; \
   }
-  const int chunk = (zc_in && zc_out) ? 64 : kChunk;  // nothing staged: the chunk only alternates the streams
   for (int64_t f0 = 0, k = 0; f0 < nframes && rc == MDC_OK && he == hipSuccess; f0 += chunk, k++) {
     const int slot = (int)(k & 1);
     hipStream_t s = c->pipe_stream[slot];
     const int n = (int)std::min<int64_t>(chunk, nframes - f0);
     if (k >= 2 && !(zc_in && zc_out)) MDC_PIPE(hipEventSynchronize(c->pipe_done[slot]));  // the slot's staging is free again
-    if (rec) {
+    if (strm) {
+      for (int i = 0; i < n; i++)
+        MDC_PIPE(hipMemcpyAsync((char*)c->d_pipe_strm[slot] + (size_t)i * strm_stride, strm[f0 + i], (size_t)strm_bytes[f0 + i], hipMemcpyHostToDevice, s));
+      MDC_PIPE(launch_jpeg_huffman(c->d_pipe_strm[slot], (int64_t)strm_stride, c->d_pipe_rec[slot], record_bytes, iw, ih, blocks_w, blocks_rows, n,
+                                   c->d_pipe_status[slot], s));
+      if (status) MDC_PIPE(hipMemcpyAsync(c->h_pipe_status + f0, c->d_pipe_status[slot], (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+      MDC_PIPE(launch_jpeg_idct(c->d_pipe_rec[slot], record_bytes, c->d_pipe_in[slot], iw, ih, blocks_w, blocks_rows, n, s));
+    } else if (rec) {
       for (int i = 0; i < n; i++)
         MDC_PIPE(hipMemcpyAsync((char*)c->d_pipe_rec[slot] + (size_t)i * record_bytes, rec[f0 + i], (size_t)record_bytes, hipMemcpyHostToDevice, s));
       MDC_PIPE(launch_jpeg_idct(c->d_pipe_rec[slot], record_bytes, c->d_pipe_in[slot], iw, ih, blocks_w, blocks_rows, n, s));
@@ -1873,6 +1918,7 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
 #undef MDC_PIPE
   if (rc != MDC_OK) return rc;
   if (he != hipSuccess) return fail(c, MDC_ERR_HIP, "%s: %s", what, hipGetErrorString(he));
+  if (strm && status) memcpy(status, c->h_pipe_status, (size_t)nframes * sizeof(int));
   return MDC_OK;
 }
 
@@ -1883,6 +1929,21 @@ int mdc_process_frames_host(mdc_ctx* c, const uint8_t* const* raw, float* const*
 int mdc_process_jpeg_frames_host(mdc_ctx* c, const void* const* records, int64_t record_bytes, int blocks_w, int blocks_rows,
                                  float* const* out, int64_t nframes, unsigned flags) {
   return process_frames_pipeline(c, nullptr, records, record_bytes, blocks_w, blocks_rows, out, nframes, flags, "mdc_process_jpeg_frames_host");
+}
+
+int mdc_process_jpeg_streams_host(mdc_ctx* c, const void* const* streams, const int64_t* stream_bytes, float* const* out, int64_t nframes,
+                                  unsigned flags, int* status) {
+  return process_frames_pipeline(c, nullptr, nullptr, 0, 0, 0, out, nframes, flags, "mdc_process_jpeg_streams_host", streams, stream_bytes, status);
+}
+
+int mdc_jpeg_huffman_batch_device(mdc_ctx* c, const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w, int h,
+                                  int blocks_w, int blocks_rows, int64_t nframes, int* d_status, void* stream) {
+  if (!c) return MDC_ERR_ARG;
+  if (!d_streams || !d_records || !d_status || nframes < 0 || w <= 0 || h <= 0) return fail(c, MDC_ERR_ARG, "mdc_jpeg_huffman_batch_device: bad argument");
+  ReadLock lk(c->mu);
+  DeviceGuard dg(c->device);
+  MDC_HIP(c, launch_jpeg_huffman(d_streams, stream_stride, d_records, record_bytes, w, h, blocks_w, blocks_rows, nframes, d_status, (hipStream_t)stream));
+  return MDC_OK;
 }
 
 int mdc_jpeg_idct_batch_device(mdc_ctx* c, const void* d_records, int64_t record_bytes, uint8_t* d_frames, int w, int h, int blocks_w,

@@ -9,6 +9,7 @@
 // writes eight 8-byte row pieces; neighbouring lanes own neighbouring blocks of a block row, so a wave's stores of one
 // row are 512 contiguous bytes.  The arithmetic is a few microseconds per frame on the whole chip -- the stage is bound
 // by the PCIe transfer of the coefficients (2 bytes per pixel), which is what it trades for the host's IDCT time.
+#include "../../include/mdc_hip.h"
 #include "mdc_internal.h"
 
 namespace mdc {
@@ -128,7 +129,314 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const int16_t* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Huffman decoding on the device (the serial half of JPEG decoding, made parallel).  Input: a STREAM per frame
+// (mdc_jpeg_stream_header, include/mdc_hip.h): the host has parsed the file's markers, built the two decode tables of a
+// single-component baseline scan and copied the entropy-coded segment with its FF00 byte stuffing removed -- 0.1 ms per frame,
+// against 2.5 ms for the Huffman decoding itself.  Output: the coefficient record the inverse-DCT kernel above reads.
+//
+// One workgroup of 1024 threads per frame.  The bit stream is cut into 1024 subsequences of S bits; thread i decodes
+// [i S, (i+1) S) from an entry state (bit position of a symbol boundary, coefficient index z inside the current block;
+// z == 0: a DC symbol comes next).  The true entry state of subsequence i is the exit state of subsequence i-1 -- unknown at
+// first, so every thread starts from the guess (i S, 0), and the states are RELAXED: decode, hand the exit state to the right
+// neighbour, decode again where the entry state changed, until nothing changes.  Subsequence 0's entry state (0, 0) is exact,
+// so after k rounds the first k are exact: the fixed point is the sequential decoder's state sequence; and because Huffman
+// streams resynchronise after a few symbols (bit position) and every end-of-block resets z, wrong guesses heal inside one
+// subsequence: 2-3 rounds in practice (the bound, 1024, only costs time).  Then a prefix sum over the blocks each
+// subsequence completed gives every thread its first block, a last pass decodes once more and WRITES the coefficients
+// (the record is zero-filled first; DC differences are written and turned into DC values by a prefix sum over the frame's
+// blocks, as the predictor of a non-interleaved scan runs over all of them).  Integer logic only: the record equals the host
+// decoder's bit for bit; a code no table holds sets the frame's status (the caller falls back to the host decoder).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __constant__ unsigned char c_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                                      41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                                      30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct HuffLds {  // a table as the kernel uses it (copied from mdc_jpeg_huff)
+  uint16_t look[512];
+  int16_t fast[512];
+  int maxcode[18];
+  int valoff[18];
+  unsigned char vals[256];
+};
+
+struct BitReader {
+  const uint32_t* base;  // entropy-coded bytes, 4-byte aligned, zero-padded past the end
+  uint64_t acc;          // next bits, MSB first
+  int cnt;               // valid bits in acc
+  uint32_t widx;         // next word to fetch
+  uint32_t next;         // that word, already loaded (one refill ahead: the load's latency hides behind ~5 symbols)
+  uint32_t last;         // index of the last word that may be read
+  __device__ __forceinline__ uint32_t word(uint32_t i) const { return __builtin_bswap32(base[min(i, last)]); }
+  __device__ __forceinline__ void start(uint32_t bit) {
+    widx = bit >> 5;
+    const uint64_t w0 = word(widx), w1 = word(widx + 1);
+    const int sh = (int)(bit & 31);
+    acc = (w0 << 32 | w1) << sh;
+    cnt = 64 - sh;
+    widx += 2;
+    next = word(widx);
+  }
+  __device__ __forceinline__ void refill() {  // afterwards cnt > 32
+    if (cnt <= 32) {
+      acc |= (uint64_t)next << (32 - cnt);
+      cnt += 32;
+      widx++;
+      next = word(widx);
+    }
+  }
+  __device__ __forceinline__ uint32_t pos() const { return widx * 32u - (uint32_t)cnt; }
+  __device__ __forceinline__ int peek(int n) const { return (int)(acc >> (64 - n)); }
+  __device__ __forceinline__ void skip(int n) {
+    acc <<= n;
+    cnt -= n;
+  }
+  __device__ __forceinline__ int get(int n) {  // n in 1..16
+    const int v = peek(n);
+    skip(n);
+    return v;
+  }
+};
+
+__device__ __forceinline__ int huff_extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
+
+// one symbol with the slow path; -1: no such code
+__device__ __forceinline__ int huff_symbol(BitReader& b, const HuffLds& t) {
+  const int e = t.look[b.peek(9)];
+  if (e) {
+    b.skip(e >> 8);
+    return e & 255;
+  }
+  int l = 10, code = b.peek(10);
+  while (l <= 16 && code > t.maxcode[l]) {
+    l++;
+    if (l <= 16) code = b.peek(l);
+  }
+  if (l > 16) return -1;
+  b.skip(l);
+  const int idx = code + t.valoff[l];
+  return (idx >= 0 && idx < 256) ? t.vals[idx] : -1;
+}
+
+// Decodes from (bit, z) until a symbol boundary at or past `end`.  WRITE: coefficients of blocks [blk, nblocks) go to the
+// record.  Returns the exit state; *nblk += blocks completed; *bad set when a code is in no table.
+template <bool WRITE>
+__device__ __forceinline__ void huff_run(BitReader& b, const HuffLds& dc, const HuffLds& ac, uint32_t bit, int z, uint32_t end, uint32_t* out_bit,
+                                         int* out_z, int* nblk, int* bad, int16_t* coef, int blk, int nblocks, int bw_used, int pitch) {
+  b.start(bit);
+  int done = 0;
+  uint32_t p = bit;
+  int16_t* cur = nullptr;
+  if (WRITE && blk < nblocks) cur = coef + ((long long)(blk / bw_used) * pitch + blk % bw_used) * 64;
+  while (p < end) {
+    b.refill();
+    if (z == 0) {
+      int t = huff_symbol(b, dc);
+      if (t < 0 || t > 11) {  // (the host decoder refuses DC categories above 11 too)
+        if (!WRITE || cur) *bad = 1;  // (past the last block: the padding bits, not an error)
+        t = 0;
+        b.skip(1);  // (speculative rounds run through garbage: keep moving)
+      }
+      const int diff = t ? huff_extend(b.get(t), t) : 0;
+      if (WRITE && cur) cur[0] = (int16_t)diff;
+      z = 1;
+    } else {
+      const int fa = ac.fast[b.peek(9)];
+      if (fa) {  // code + magnitude bits in one lookup
+        z += (fa >> 4) & 15;
+        b.skip(fa & 15);
+        if (z <= 63) {
+          if (WRITE && cur) cur[c_zigzag[z]] = (int16_t)(fa >> 8);
+        } else {
+          if (!WRITE || cur) *bad = 1;  // (past the last block: the padding bits, not an error)
+        }
+        z++;
+      } else {
+        const int rs = huff_symbol(b, ac);
+        if (rs < 0) {
+          if (!WRITE || cur) *bad = 1;  // (past the last block: the padding bits, not an error)
+          b.skip(1);
+        } else {
+          const int r = rs >> 4, sz = rs & 15;
+          if (sz == 0) {
+            z = r == 15 ? z + 16 : 64;  // ZRL / EOB
+          } else {
+            z += r;
+            const int v = huff_extend(b.get(sz), sz);
+            if (z <= 63) {
+              if (WRITE && cur) cur[c_zigzag[z]] = (int16_t)v;
+            } else {
+              if (!WRITE || cur) *bad = 1;  // (past the last block: the padding bits, not an error)
+            }
+            z++;
+          }
+        }
+      }
+      if (z >= 64) {
+        z = 0;
+        done++;
+        if (WRITE) {
+          blk++;
+          cur = blk < nblocks ? coef + ((long long)(blk / bw_used) * pitch + blk % bw_used) * 64 : nullptr;
+        }
+      }
+    }
+    p = b.pos();
+  }
+  *out_bit = p;
+  *out_z = z;
+  *nblk += done;
+}
+
+constexpr int kHuffThreads = 1024;
+
+__global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
+                                                                    int16_t* __restrict__ records, long long rec_i16, int W, int H, int pitch,
+                                                                    int rows, int* __restrict__ status) {
+  __shared__ HuffLds s_dc, s_ac;
+  __shared__ uint32_t s_bit[kHuffThreads];
+  __shared__ int s_z[kHuffThreads];
+  __shared__ int s_scan[kHuffThreads / 64 + 1];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long f = blockIdx.x;
+  const unsigned char* st = streams + f * stream_stride;
+  const mdc_jpeg_stream_header* hd = reinterpret_cast<const mdc_jpeg_stream_header*>(st);
+  int16_t* rec = records + f * rec_i16;
+  const int bw_used = (W + 7) / 8, bh_used = (H + 7) / 8, nblocks = bw_used * bh_used;
+  // header checks (uniform): anything off -> status 2, record untouched
+  const uint32_t ecs_bytes = hd->ecs_bytes;
+  const bool ok_hdr = hd->magic == MDC_JPEG_STREAM_MAGIC && (int)hd->w == W && (int)hd->h == H && ecs_bytes > 0 &&
+                      (long long)sizeof(mdc_jpeg_stream_header) + ecs_bytes + 16 <= stream_stride && ecs_bytes < (1u << 28);
+  if (!ok_hdr) {
+    if (tid == 0) status[f] = 2;
+    return;
+  }
+  // tables -> LDS; quantisation table -> record; record body zero-filled
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&hd->dc);
+    uint32_t* d0 = reinterpret_cast<uint32_t*>(&s_dc);
+    for (int i = tid; i < (int)(sizeof(HuffLds) / 4); i += kHuffThreads) d0[i] = src[i];
+    src = reinterpret_cast<const uint32_t*>(&hd->ac);
+    d0 = reinterpret_cast<uint32_t*>(&s_ac);
+    for (int i = tid; i < (int)(sizeof(HuffLds) / 4); i += kHuffThreads) d0[i] = src[i];
+    if (tid < 64) reinterpret_cast<uint16_t*>(rec)[tid] = hd->quant[tid];
+    i32x4* body = reinterpret_cast<i32x4*>(rec + 64);
+    const long long n16 = (long long)pitch * rows * 8;  // 16-byte pieces
+    for (long long i = tid; i < n16; i += kHuffThreads) body[i] = i32x4{0, 0, 0, 0};
+    if (tid == 0) s_flag = 0;
+  }
+  __syncthreads();
+  const uint32_t nbits = ecs_bytes * 8u;
+  uint32_t S = (nbits + kHuffThreads - 1) / kHuffThreads;
+  S = max(256u, (S + 31u) & ~31u);
+  const uint32_t my0 = min(nbits, (uint32_t)tid * S), my1 = min(nbits, my0 + S);
+  BitReader b;
+  b.base = reinterpret_cast<const uint32_t*>(st + sizeof(mdc_jpeg_stream_header));
+  b.last = (ecs_bytes + 3) / 4 + 2;  // the host pads 16 zero bytes
+  int16_t* coef = rec + 64;
+  // ---- relaxation
+  uint32_t in_bit = my0, out_bit = my0;
+  int in_z = 0, out_z = 0, nblk = 0, bad = 0;
+  bool dirty = true;
+  for (int round = 0; round <= kHuffThreads; round++) {
+    if (dirty) {
+      nblk = 0;
+      bad = 0;
+      out_bit = in_bit;
+      out_z = in_z;
+      if (in_bit < my1) huff_run<false>(b, s_dc, s_ac, in_bit, in_z, my1, &out_bit, &out_z, &nblk, &bad, nullptr, 0, 0, 1, 1);
+    }
+    s_bit[tid] = out_bit;
+    s_z[tid] = out_z;
+    __syncthreads();
+    const uint32_t nb = tid ? s_bit[tid - 1] : 0u;
+    const int nz = tid ? s_z[tid - 1] : 0;
+    dirty = nb != in_bit || nz != in_z;
+    in_bit = nb;
+    in_z = nz;
+    if (!__syncthreads_or(dirty ? 1 : 0)) break;
+  }
+  // ---- first block of every subsequence: exclusive prefix sum of nblk
+  int incl = nblk;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) s_scan[wave] = incl;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int w = 0; w < kHuffThreads / 64; w++) {
+      const int v = s_scan[w];
+      s_scan[w] = acc;
+      acc += v;
+    }
+    s_scan[kHuffThreads / 64] = acc;
+  }
+  __syncthreads();
+  const int first = s_scan[wave] + incl - nblk;
+  const int total = s_scan[kHuffThreads / 64];
+  // ---- write pass (the true states)
+  int bad_w = 0;
+  if (in_bit < my1) {
+    int dummy = 0;
+    uint32_t ob;
+    int oz;
+    huff_run<true>(b, s_dc, s_ac, in_bit, in_z, my1, &ob, &oz, &dummy, &bad_w, coef, first, nblocks, bw_used, pitch);
+  }
+  // fewer blocks than the frame has: truncated or damaged.  More: the 1..7 padding bits after the last block can parse as
+  // another (short-coded) block; those are never written.
+  if (bad_w || (tid == 0 && total < nblocks)) s_flag = 1;  // (benign race: every writer writes 1)
+  __syncthreads();
+  // ---- DC differences -> DC values: prefix sum over the frame's blocks in scan order
+  const int per = (nblocks + kHuffThreads - 1) / kHuffThreads;
+  const int b0 = min(nblocks, tid * per), b1 = min(nblocks, b0 + per);
+  int sum = 0;
+  for (int k = b0; k < b1; k++) sum += coef[((long long)(k / bw_used) * pitch + k % bw_used) * 64];
+  int inc2 = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(inc2, d, 64);
+    if (lane >= d) inc2 += up;
+  }
+  __syncthreads();  // s_scan is reused
+  if (lane == 63) s_scan[wave] = inc2;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int w = 0; w < kHuffThreads / 64; w++) {
+      const int v = s_scan[w];
+      s_scan[w] = acc;
+      acc += v;
+    }
+  }
+  __syncthreads();
+  int pred = s_scan[wave] + inc2 - sum;
+  for (int k = b0; k < b1; k++) {
+    int16_t* c0 = coef + ((long long)(k / bw_used) * pitch + k % bw_used) * 64;
+    pred += c0[0];
+    c0[0] = (int16_t)pred;
+  }
+  if (tid == 0) status[f] = s_flag ? 1 : 0;
+}
+
 }  // namespace
+
+hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w, int h, int blocks_w,
+                               int blocks_rows, int64_t nframes, int* d_status, hipStream_t s) {
+  if (nframes <= 0) return hipSuccess;
+  const int bw_used = (w + 7) / 8, bh_used = (h + 7) / 8;
+  if (w <= 0 || h <= 0 || blocks_w < bw_used || blocks_rows < bh_used || record_bytes % 16 != 0 || stream_stride % 16 != 0 ||
+      stream_stride < (int64_t)sizeof(mdc_jpeg_stream_header) + 32 || record_bytes < 128 + (int64_t)blocks_w * blocks_rows * 128 ||
+      ((reinterpret_cast<uintptr_t>(d_records) | reinterpret_cast<uintptr_t>(d_streams)) & 15) != 0 || nframes > (1ll << 30))
+    return hipErrorInvalidValue;
+  jpeg_huffman_kernel<<<(unsigned)nframes, kHuffThreads, 0, s>>>(static_cast<const unsigned char*>(d_streams), stream_stride,
+                                                                 static_cast<int16_t*>(d_records), record_bytes / 2, w, h, blocks_w, blocks_rows,
+                                                                 d_status);
+  return hipGetLastError();
+}
 
 hipError_t launch_jpeg_idct(const void* d_records, int64_t record_bytes, uint8_t* d_frames, int w, int h, int blocks_w, int blocks_rows,
                             int64_t nframes, hipStream_t s) {

@@ -171,6 +171,76 @@ def test_gpu_jpeg_stage_equals_the_host_decoder(size):
         assert np.array_equal(got[i], capi.decode_gray8(data)), i
 
 
+@pytest.mark.parametrize("size", [(64, 64), (100, 130), (17, 23), (250, 322), (256, 320), (1024, 1280)])
+def test_gpu_huffman_stage_equals_the_host_decoder(size):
+    """The Huffman decoding itself on the device (mdch_jpeg_stream: markers parsed, tables built, byte stuffing removed on the
+    host; mdc_jpeg_huffman_batch_device: 1024 threads per stream, subsequence states relaxed to the sequential decoder's):
+    the coefficient RECORD equals the host decoder's record byte for byte -- quantisation table, every coefficient of every
+    block, DC prediction -- for textures, noise (long codes, few zero runs), flat images (blocks of one EOB), qualities 5..100,
+    optimised Huffman tables, sizes that are not whole blocks; then the device inverse DCT gives the host decoder's pixels.
+    Files the device does not take (colour, progressive, restart markers) are refused by mdch_jpeg_stream."""
+    import torch
+
+    from mono_dataset_code_amd import capi
+
+    h, w = size
+    rng = np.random.default_rng(h * 7 + w)
+    imgs = [textured(h, w, 4), rng.integers(0, 256, (h, w), dtype=np.uint8), np.full((h, w), 131, np.uint8),
+            (np.add.outer(np.arange(h), np.arange(w)) % 256).astype(np.uint8)]
+    files = []
+    for k, img in enumerate(imgs):
+        for kw in ({"quality": 5}, {"quality": 50}, {"quality": 92}, {"quality": 100}, {"quality": 75, "optimize": True}):
+            if h * w > 500000 and kw["quality"] not in (92, 100):
+                continue
+            b = io.BytesIO()
+            Image.fromarray(img).save(b, "JPEG", **kw)
+            files.append(b.getvalue())
+    rec_bytes, pitch, rows = capi.jpeg_record_bytes(w, h)
+    n = len(files)
+    want = np.zeros((n, rec_bytes), np.uint8)
+    cap = (capi.JPEG_STREAM_HEADER_BYTES + max(len(f) for f in files) + 64 + 15) & ~15
+    streams = np.zeros((n, cap), np.uint8)
+    for i, data in enumerate(files):
+        dims = capi.decode_jpeg_record(data, want[i], pitch)
+        assert dims[:3] == (w, h, pitch)
+        used, sw, sh = capi.jpeg_stream(data, streams[i])
+        assert (sw, sh) == (w, h) and capi.JPEG_STREAM_HEADER_BYTES + 17 <= used <= cap
+    ctx = capi.Context(0)
+    st = torch.cuda.current_stream().cuda_stream
+    d_streams = torch.from_numpy(streams).cuda()
+    d_rec = torch.full((n, rec_bytes), 0x5A, dtype=torch.uint8, device="cuda")
+    d_status = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    ctx.jpeg_huffman_batch(d_streams.data_ptr(), cap, d_rec.data_ptr(), rec_bytes, w, h, pitch, rows, n, d_status.data_ptr(), st)
+    d_frames = torch.full((n, h * w), 77, dtype=torch.uint8, device="cuda")
+    ctx.jpeg_idct_batch(d_rec.data_ptr(), rec_bytes, d_frames.data_ptr(), w, h, pitch, rows, n, st)
+    torch.cuda.synchronize()
+    assert d_status.cpu().numpy().tolist() == [0] * n
+    got = d_rec.cpu().numpy()
+    bw, bh = (w + 7) // 8, (h + 7) // 8
+    for i in range(n):
+        assert np.array_equal(got[i, :128], want[i, :128]), (i, "quantisation table")
+        g = got[i, 128:].view(np.int16).reshape(rows, pitch, 64)[:bh, :bw]
+        e = want[i, 128:].view(np.int16).reshape(rows, pitch, 64)[:bh, :bw]
+        assert np.array_equal(g, e), (i, int((g != e).any(-1).sum()), "blocks differ", np.argwhere((g != e).any(-1))[:4].tolist())
+        assert np.array_equal(d_frames[i].cpu().numpy().reshape(h, w), capi.decode_gray8(files[i])), i
+    # what the device decoder does not take is refused on the host
+    rgb = np.stack([imgs[0], np.roll(imgs[0], 3, 1), 255 - imgs[0]], -1)
+    for img, kw in ((rgb, {"quality": 88}), (imgs[0], {"quality": 85, "progressive": True}), (imgs[0], {"quality": 80, "restart_marker_blocks": 7})):
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, "JPEG", **kw)
+        with pytest.raises(ValueError):
+            capi.jpeg_stream(b.getvalue(), streams[0])
+    # a stream whose bits were damaged is reported, not decoded into something
+    bad = streams[:2].copy()
+    bad[0, capi.JPEG_STREAM_HEADER_BYTES + 40: capi.JPEG_STREAM_HEADER_BYTES + 60] ^= 0xFF
+    bad[1, 4] ^= 1  # header: another width
+    d_bad = torch.from_numpy(bad).cuda()
+    ctx.jpeg_huffman_batch(d_bad.data_ptr(), cap, d_rec.data_ptr(), rec_bytes, w, h, pitch, rows, 2, d_status.data_ptr(), st)
+    torch.cuda.synchronize()
+    s2 = d_status.cpu().numpy()[:2].tolist()
+    assert s2[1] == 2 and s2[0] in (0, 1)  # (flipped bits may still parse as SOME valid stream of the right length: then 0)
+
+
 def test_reader_gpu_jpeg_on_and_off_give_the_same_images(tmp_path):
     """getImages over a zipped JPEG sequence with the GPU JPEG stage (default) and without: identical ExposureImages."""
     from mono_dataset_code_amd import capi
@@ -179,9 +249,12 @@ def test_reader_gpu_jpeg_on_and_off_give_the_same_images(tmp_path):
     frames = frames_for(40, h, w)  # longer than one chunk of 32
     make_sequence(str(tmp_path), frames, True, "jpg")
     r = capi.DatasetReader(str(tmp_path))
-    on, ok_on, n_on = r.get_images(0, 40, 1, 1, 1, 1)
+    on, ok_on, n_on = r.get_images(0, 40, 1, 1, 1, 1)  # default: Huffman decoding on the device too
+    r.set_gpu_jpeg(1)
+    mid, ok_mid, n_mid = r.get_images(0, 40, 1, 1, 1, 1)  # host Huffman, device inverse DCT
     r.set_gpu_jpeg(False)
     off, ok_off, n_off = r.get_images(0, 40, 1, 1, 1, 1)
-    assert n_on == n_off == 40 and ok_on.all() and ok_off.all()
+    assert n_on == n_mid == n_off == 40 and ok_on.all() and ok_mid.all() and ok_off.all()
     for i in range(40):
         assert bits_equal(on[i], off[i]), i
+        assert bits_equal(mid[i], off[i]), i

@@ -70,5 +70,7 @@ for kind in os.environ.get("MDC_RATE_KINDS", "folder_png,zip_png,zip_jpg").split
     if kind == "zip_jpg":  # getImages: whole decode on the host vs Huffman on the host + inverse DCT on the GPU
         print("-- getImages, JPEG decoded entirely on the host (MDC_GPU_JPEG=0):", flush=True)
         print(run("reader_rate_fast", d, 3, "batch", env={"MDC_GPU_JPEG": "0"}), flush=True)
-        print("-- getImages, GPU JPEG stage (host: Huffman only; device: dequantisation + inverse DCT):", flush=True)
+        print("-- getImages, GPU JPEG stage 1 (host: Huffman decoding; device: dequantisation + inverse DCT; MDC_GPU_JPEG=1):", flush=True)
+        print(run("reader_rate_fast", d, 3, "batch", env={"MDC_GPU_JPEG": "1"}), flush=True)
+        print("-- getImages, GPU JPEG stage 2 (host: markers + byte stuffing only; device: Huffman decoding + inverse DCT; the default):", flush=True)
     print(run("reader_rate_fast", d, 3, "batch"), flush=True)
