@@ -127,6 +127,7 @@ struct mdc_ctx {
   // pipelined host-frame path (mdc_process_frames_host): two chunk slots, each with its own stream
   hipStream_t pipe_stream[2] = {nullptr, nullptr};
   hipEvent_t pipe_done[2] = {nullptr, nullptr};
+  hipEvent_t pipe_dec[2] = {nullptr, nullptr};  // streams: "chunk decoded" (decode stream -> output stream)
   uint8_t* d_pipe_in[2] = {nullptr, nullptr};
   float* d_pipe_out[2] = {nullptr, nullptr};
   void* d_pipe_rec[2] = {nullptr, nullptr};  // JPEG coefficient records of a chunk (mdc_process_jpeg_frames_host)
@@ -959,6 +960,7 @@ void mdc_destroy(mdc_ctx* c) {
     if (c->h_pipe_status) (void)hipHostFree(c->h_pipe_status);
     for (int k = 0; k < 2; k++) {
       if (c->pipe_done[k]) (void)hipEventDestroy(c->pipe_done[k]);
+      if (c->pipe_dec[k]) (void)hipEventDestroy(c->pipe_dec[k]);
       if (c->pipe_stream[k]) (void)hipStreamDestroy(c->pipe_stream[k]);
     }
   }
@@ -1823,9 +1825,9 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
   for (int64_t i = 0; i < nframes && zc_out; i++) zc_out = (z_out[(size_t)i] = device_view(c, out[i], n_out * sizeof(float))) != nullptr;
   for (int64_t i = 0; i < nframes && zc_in; i++) zc_in = (z_in[(size_t)i] = device_view(c, raw[i], n_in)) != nullptr;
   if (!zc_out) zc_in = false;  // frames alone: the copy pipeline (one launch per chunk) stays
-  // frames per slot.  Streams: 32 -- the Huffman kernel's time does not depend on the frame count up to ~64 (one workgroup per
+  // frames per slot.  Streams: 64 -- the Huffman kernel's time does not depend on the frame count up to ~64 (one workgroup per
   // frame, 1.3 ms), so small chunks would only repeat that latency; nothing staged: the chunk only alternates the streams
-  const int chunk = (zc_in && zc_out) ? 64 : (strm ? 32 : kChunk);
+  const int chunk = (zc_in && zc_out) ? 64 : (strm ? 64 : kChunk);
   const size_t in_need = zc_in ? 0 : chunk * n_in, out_need = zc_out ? 0 : chunk * n_out * sizeof(float);
   const size_t rec_need = (rec || strm) ? (size_t)chunk * (size_t)record_bytes : 0;
   const size_t strm_need = strm ? (size_t)chunk * strm_stride : 0;
@@ -1838,6 +1840,7 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
       if (c->pipe_stream[k]) MDC_HIP(c, hipStreamSynchronize(c->pipe_stream[k]));
       if (!c->pipe_stream[k]) MDC_HIP(c, hipStreamCreateWithFlags(&c->pipe_stream[k], hipStreamNonBlocking));
       if (!c->pipe_done[k]) MDC_HIP(c, hipEventCreateWithFlags(&c->pipe_done[k], hipEventDisableTiming));
+      if (!c->pipe_dec[k]) MDC_HIP(c, hipEventCreateWithFlags(&c->pipe_dec[k], hipEventDisableTiming));
       for (void** p : {(void**)&c->d_pipe_in[k], (void**)&c->d_pipe_out[k], &c->d_pipe_rec[k], &c->d_pipe_strm[k], (void**)&c->d_pipe_status[k]})
         if (*p) {
           (void)hipFree(*p);
@@ -1868,9 +1871,17 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
   }
   for (int64_t f0 = 0, k = 0; f0 < nframes && rc == MDC_OK && he == hipSuccess; f0 += chunk, k++) {
     const int slot = (int)(k & 1);
-    hipStream_t s = c->pipe_stream[slot];
+    // Streams: ALL chunks decode on stream 0 (upload, Huffman kernel, inverse DCT) and go out on stream 1 (fused pass into the
+    // caller's images), tied by events -- the Huffman kernel takes ~1.3 ms whatever the frame count (one workgroup per frame)
+    // and the output is PCIe-bound, so chunk k+1 decodes while chunk k goes out.  Otherwise chunk k runs on stream k % 2.
+    hipStream_t s = strm ? c->pipe_stream[0] : c->pipe_stream[slot];
+    hipStream_t s_out = strm ? c->pipe_stream[1] : s;
     const int n = (int)std::min<int64_t>(chunk, nframes - f0);
-    if (k >= 2 && !(zc_in && zc_out)) MDC_PIPE(hipEventSynchronize(c->pipe_done[slot]));  // the slot's staging is free again
+    if (k >= 2 && strm) {  // the slot's staging is free again: in stream order ...
+      MDC_PIPE(hipStreamWaitEvent(s, c->pipe_done[slot], 0));
+    } else if (k >= 2 && !(zc_in && zc_out)) {  // ... or on the host
+      MDC_PIPE(hipEventSynchronize(c->pipe_done[slot]));
+    }
     if (strm) {
       for (int i = 0; i < n; i++)
         MDC_PIPE(hipMemcpyAsync((char*)c->d_pipe_strm[slot] + (size_t)i * strm_stride, strm[f0 + i], (size_t)strm_bytes[f0 + i], hipMemcpyHostToDevice, s));
@@ -1887,6 +1898,11 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
         MDC_PIPE(hipMemcpyAsync(c->d_pipe_in[slot] + (size_t)i * n_in, raw[f0 + i], n_in, hipMemcpyHostToDevice, s));
     }
     if (he != hipSuccess) break;
+    if (strm) {
+      MDC_PIPE(hipEventRecord(c->pipe_dec[slot], s));
+      MDC_PIPE(hipStreamWaitEvent(s_out, c->pipe_dec[slot], 0));
+      if (he != hipSuccess) break;
+    }
     if (zc_out) {  // one launch per run of frames that lie back to back on both sides
       for (int i = 0; i < n && rc == MDC_OK;) {
         const uint8_t* src = zc_in ? z_in[(size_t)(f0 + i)] : c->d_pipe_in[slot] + (size_t)i * n_in;
@@ -1895,18 +1911,18 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
         while (i + run < n && z_out[(size_t)(f0 + i + run)] == dst + (size_t)run * n_out &&
                (!zc_in || z_in[(size_t)(f0 + i + run)] == src + (size_t)run * n_in))
           run++;
-        rc = enqueue_process(c, src, dst, run, flags, s);
+        rc = enqueue_process(c, src, dst, run, flags, s_out);
         i += run;
       }
       if (rc != MDC_OK) break;
     } else {
-      rc = enqueue_process(c, c->d_pipe_in[slot], c->d_pipe_out[slot], n, flags, s);
+      rc = enqueue_process(c, c->d_pipe_in[slot], c->d_pipe_out[slot], n, flags, s_out);
       if (rc != MDC_OK) break;
       for (int i = 0; i < n; i++)
         MDC_PIPE(hipMemcpyAsync(out[f0 + i], c->d_pipe_out[slot] + (size_t)i * n_out, n_out * sizeof(float),
-                                hipMemcpyDeviceToHost, s));
+                                hipMemcpyDeviceToHost, s_out));
     }
-    MDC_PIPE(hipEventRecord(c->pipe_done[slot], s));
+    MDC_PIPE(hipEventRecord(c->pipe_done[slot], s_out));
   }
   for (int k = 0; k < 2; k++) {
     const hipError_t e = hipStreamSynchronize(c->pipe_stream[k]);

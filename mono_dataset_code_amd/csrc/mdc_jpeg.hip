@@ -339,7 +339,9 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
   uint32_t in_bit = my0, out_bit = my0;
   int in_z = 0, out_z = 0, nblk = 0, bad = 0;
   bool dirty = true;
+  int rounds = 0;
   for (int round = 0; round <= kHuffThreads; round++) {
+    rounds++;
     if (dirty) {
       nblk = 0;
       bad = 0;
@@ -419,7 +421,12 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
     pred += c0[0];
     c0[0] = (int16_t)pred;
   }
+#ifdef MDC_EXP_HUFF_ROUNDS  // experiment build: relaxation rounds in the status word's upper bits
+  if (tid == 0) status[f] = (s_flag ? 1 : 0) | rounds << 8;
+#else
+  (void)rounds;
   if (tid == 0) status[f] = s_flag ? 1 : 0;
+#endif
 }
 
 }  // namespace

@@ -241,6 +241,50 @@ def test_gpu_huffman_stage_equals_the_host_decoder(size):
     assert s2[1] == 2 and s2[0] in (0, 1)  # (flipped bits may still parse as SOME valid stream of the right length: then 0)
 
 
+def test_reader_gpu_jpeg_stages_agree_on_damaged_and_mixed_files(tmp_path):
+    """A folder whose JPEGs are not all what the device Huffman decoder takes or can decode: gray baseline files, a colour file,
+    a progressive one, one with restart markers (stage 2 refuses them on the host: they take the record path), a file whose
+    entropy-coded bytes were damaged and a truncated one (the device reports them or decodes the same symbols as the host).
+    getImages must give the same images -- and the same failures -- in stage 2, stage 1 and on the host."""
+    from mono_dataset_code_amd import capi, synth
+
+    h, w = 96, 160
+    base = [textured(h, w, s) for s in range(9)]
+    d = str(tmp_path)
+    cam = ("0.349153 0.436593 0.493140 0.499021 0.933271", "%d %d" % (w, h), "crop", "%d %d" % (w * 3 // 5, h * 9 // 16))
+    synth.write_sequence_calibration(d, cam, vignette_bits=16, n_times=len(base))
+    os.makedirs(os.path.join(d, "images"))
+
+    def jpeg(img, **kw):
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, "JPEG", **kw)
+        return bytearray(b.getvalue())
+
+    blobs = [jpeg(base[0], quality=90), jpeg(np.stack([base[1], base[1] // 2, 255 - base[1]], -1), quality=90),
+             jpeg(base[2], quality=85, progressive=True), jpeg(base[3], quality=80, restart_marker_blocks=5), jpeg(base[4], quality=95),
+             jpeg(base[5], quality=90), jpeg(base[6], quality=90), jpeg(base[7], quality=30, optimize=True), jpeg(base[8], quality=100)]
+    sos = bytes(blobs[5]).index(b"\xff\xda")
+    for k in range(sos + 400, sos + 420):  # damaged scan data (no FF bytes introduced: still one scan)
+        blobs[5][k] = (blobs[5][k] ^ 0x55) if (blobs[5][k] ^ 0x55) != 0xff else 0x54
+    blobs[6] = blobs[6][: sos + (len(blobs[6]) - sos) // 2] + b"\xff\xd9"  # truncated scan
+    for i, b in enumerate(blobs):
+        open(os.path.join(d, "images", "%05d.jpg" % i), "wb").write(bytes(b))
+    results = {}
+    for stage in (2, 1, 0):
+        r = capi.DatasetReader(d)
+        r.set_gpu_jpeg(stage)
+        imgs, ok, n = r.get_images(0, len(blobs), 1, 1, 1, 1)
+        results[stage] = (imgs, ok.copy(), n)
+        r.close()
+    ok0 = results[0][1]
+    assert ok0[[0, 1, 2, 3, 4, 7, 8]].all()
+    for stage in (2, 1):
+        assert results[stage][2] == results[0][2] and (results[stage][1] == ok0).all(), (stage, results[stage][1], ok0)
+        for i in range(len(blobs)):
+            if ok0[i]:
+                assert bits_equal(results[stage][0][i], results[0][0][i]), (stage, i)
+
+
 def test_reader_gpu_jpeg_on_and_off_give_the_same_images(tmp_path):
     """getImages over a zipped JPEG sequence with the GPU JPEG stage (default) and without: identical ExposureImages."""
     from mono_dataset_code_amd import capi
