@@ -528,9 +528,10 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
     std::fprintf(stderr, "DatasetReader::getImages: %s\n", s.err.c_str());
     return 0;
   }
-  // frames per GPU call / calls in the ring: stage 2 hands over 128 at a time (the device Huffman decoder's launch time does
-  // not depend on the frame count up to ~64; inside the call a 64-frame chunk decodes while the one before it goes out)
-  const int C = s.gpu_jpeg >= 2 ? 128 : 32, RG = State::kRingFrames / C;
+  // frames per GPU call / calls in the ring: stage 2 hands over the whole ring at a time -- its host work is ~0.1 ms per
+  // frame and thread, and inside the GPU call a 64-frame chunk decodes while the one before it goes out: the longer the call,
+  // the less its first decode and last output weigh (128 per call: 16.5 k frames/s, 256: 20+ k)
+  const int C = s.gpu_jpeg >= 2 ? State::kRingFrames : 32, RG = State::kRingFrames / C;
   // coefficient records (include/mdc_hip.h): MCUs are at most 4 x 4 blocks, so a grid rounded up to multiples of 4 blocks
   // holds every sampling layout of a W x H file (the same rule as mdch_jpeg_record_bytes)
   s.rec_pitch = ((s.W + 7) / 8 + 3) & ~3;

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
     __syncthreads();
     const uint32_t nb = tid ? s_bit[tid - 1] : 0u;
     const int nz = tid ? s_z[tid - 1] : 0;
-    dirty = nb != in_bit || nz != in_z;
+    dirty = (nb != in_bit || nz != in_z) && my0 < nbits;  // (threads past the end of the stream decode nothing: they just follow)
     in_bit = nb;
     in_z = nz;
     if (!__syncthreads_or(dirty ? 1 : 0)) break;
