@@ -16,6 +16,7 @@
 #include "FOVUndistorter.h"
 #include "PhotometricUndistorter.h"
 #include "image_codecs.h"
+#include "image_codecs_internal.h"
 #include "mdc_host.h"
 #include "zip_reader.h"
 
@@ -32,7 +33,7 @@ static std::vector<std::string> list(const std::string& dir) {
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   const std::string root = argv[1];
-  long decoded = 0, refused = 0;
+  long decoded = 0, refused = 0, streams_built = 0;
 
   // 1. every file under images_any/ through the decoders, whole and truncated at many lengths
   for (const std::string& f : list(root + "/images_any")) {
@@ -49,6 +50,16 @@ int main(int argc, char** argv) {
       // a buffer that is too small must be refused, not overrun
       std::vector<unsigned char> tiny(16);
       mdc_host::decode_gray8(part.data(), part.size(), tiny.data(), tiny.size(), &w, &h, &err);
+      // the stream builder of the device Huffman stage: exact-size stream buffers of several capacities (the copy of the
+      // entropy-coded bytes must stop at the capacity), and the coefficient-record decoder
+      for (size_t cap : {part.size() + 5056 + 64, (size_t)5056 + 40, (size_t)5056 + 16, (size_t)5000, (size_t)64}) {
+        std::vector<uint32_t> stream((cap + 3) / 4);
+        size_t used = 0;
+        if (mdc_host::jpeg_stream(part.data(), part.size(), reinterpret_cast<unsigned char*>(stream.data()), cap, &used, &w, &h, &err)) {
+          if (used > cap || used < 5056 + 17) return 9;
+          streams_built++;
+        }
+      }
     }
     // single corrupted bytes inside the entropy-coded / compressed data
     for (size_t pos = bytes.size() / 2; pos < bytes.size() && pos < bytes.size() / 2 + 40; pos += 3) {
@@ -57,8 +68,12 @@ int main(int argc, char** argv) {
       int w = 0, h = 0;
       std::string err;
       mdc_host::decode_gray8(bad.data(), bad.size(), out.data(), out.size(), &w, &h, &err);
+      std::vector<uint32_t> stream((bad.size() + 5056 + 64) / 4);
+      size_t used = 0;
+      mdc_host::jpeg_stream(bad.data(), bad.size(), reinterpret_cast<unsigned char*>(stream.data()), stream.size() * 4, &used, &w, &h, &err);
     }
   }
+  if (streams_built == 0) return 10;  // (the fixtures hold gray baseline JPEGs: some streams must come out)
 
   // 2. calibration parsers: every camera*.txt / pcalib*.txt under calib/ (valid, malformed, empty, truncated)
   for (const std::string& f : list(root + "/calib")) {
