@@ -241,6 +241,65 @@ def test_gpu_huffman_stage_equals_the_host_decoder(size):
     assert s2[1] == 2 and s2[0] in (0, 1)  # (flipped bits may still parse as SOME valid stream of the right length: then 0)
 
 
+def test_gpu_huffman_stage_random_files():
+    """300 random files -- sizes 1x1 .. 97x131, qualities 1..100, optimised tables or the standard ones, content from flat
+    through gradients and sparse dots to noise (the long codes, ZRL runs, 63-coefficient blocks and one-symbol blocks the
+    tables can produce; streams with many FF bytes to unstuff) -- each through the device Huffman decoder and the host
+    decoder: identical records, file by file (streams padded to one stride, one launch per size)."""
+    import torch
+
+    from mono_dataset_code_amd import capi
+
+    rng = np.random.default_rng(20260926)
+    ctx = capi.Context(0)
+    st = torch.cuda.current_stream().cuda_stream
+    checked = 0
+    for trial in range(30):
+        h, w = int(rng.integers(1, 98)), int(rng.integers(1, 132))
+        files = []
+        for k in range(10):
+            kind = int(rng.integers(0, 6))
+            if kind == 0:
+                img = np.full((h, w), int(rng.integers(0, 256)), np.uint8)
+            elif kind == 1:
+                img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            elif kind == 2:
+                img = ((np.add.outer(np.arange(h) * int(rng.integers(1, 9)), np.arange(w) * int(rng.integers(1, 9)))) % 256).astype(np.uint8)
+            elif kind == 3:
+                img = np.zeros((h, w), np.uint8)
+                img[rng.integers(0, h, 5), rng.integers(0, w, 5)] = 255
+            elif kind == 4:
+                img = (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)
+            else:
+                img = np.clip(rng.normal(128, float(rng.integers(1, 90)), (h, w)), 0, 255).astype(np.uint8)
+            b = io.BytesIO()
+            Image.fromarray(img).save(b, "JPEG", quality=int(rng.integers(1, 101)), optimize=bool(rng.integers(0, 2)))
+            files.append(b.getvalue())
+        n = len(files)
+        rec_bytes, pitch, rows = capi.jpeg_record_bytes(w, h)
+        want = np.zeros((n, rec_bytes), np.uint8)
+        cap = (capi.JPEG_STREAM_HEADER_BYTES + max(len(f) for f in files) + 64 + 15) & ~15
+        streams = np.zeros((n, cap), np.uint8)
+        for i, data in enumerate(files):
+            capi.decode_jpeg_record(data, want[i], pitch)
+            capi.jpeg_stream(data, streams[i])
+        d_streams = torch.from_numpy(streams).cuda()
+        d_rec = torch.full((n, rec_bytes), 0x5A, dtype=torch.uint8, device="cuda")
+        d_status = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        ctx.jpeg_huffman_batch(d_streams.data_ptr(), cap, d_rec.data_ptr(), rec_bytes, w, h, pitch, rows, n, d_status.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert d_status.cpu().numpy().tolist() == [0] * n, (trial, h, w)
+        got = d_rec.cpu().numpy()
+        bw, bh = (w + 7) // 8, (h + 7) // 8
+        for i in range(n):
+            assert np.array_equal(got[i, :128], want[i, :128]), (trial, i, h, w, "quantisation table")
+            g = got[i, 128:].view(np.int16).reshape(rows, pitch, 64)[:bh, :bw]
+            e = want[i, 128:].view(np.int16).reshape(rows, pitch, 64)[:bh, :bw]
+            assert np.array_equal(g, e), (trial, i, h, w, len(files[i]))
+            checked += 1
+    assert checked == 300
+
+
 def test_reader_gpu_jpeg_stages_agree_on_damaged_and_mixed_files(tmp_path):
     """A folder whose JPEGs are not all what the device Huffman decoder takes or can decode: gray baseline files, a colour file,
     a progressive one, one with restart markers (stage 2 refuses them on the host: they take the record path), a file whose
