@@ -110,7 +110,9 @@ struct DatasetReader::State {
   // the pool decodes chunks k+1 .. (up to 192 frames in flight): a decode thread that is slow on one frame delays only the
   // chunk that frame is in, not the pipeline (two half-rings of 64 stalled on every straggler: 2.5-2.9 k frames/s)
   static const int kRingFrames = 256;  // page-locked decode buffers of getImages (335 MB at 1280x1024, 670 MB in stage 1; first getImages)
-  std::vector<HostBuffer> ring;
+  HostBuffer ring_block;               // ONE page-locked block: slot i at ring_block.p + i * ring_stride (a chunk's uploads are
+  size_t ring_stride = 0;              // then one strided copy instead of one copy per frame)
+  int ring_slots = 0;
 
   size_t frame_bytes() const { return (size_t)W * H; }
   // GPU JPEG stage of getImages: JPEG frames travel as coefficient records (2 bytes per pixel + table), the inverse DCT runs on
@@ -428,7 +430,7 @@ DatasetReader::~DatasetReader() {
   State& s = *s_;
   s.stop_pool();
   for (auto& m : s.slot_mem) m.release();
-  for (auto& m : s.ring) m.release();
+  s.ring_block.release();
   if (s.gpu) mdc_destroy(s.gpu);
   delete s.fov;
   delete s.photo;
@@ -540,10 +542,11 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
   // a ring buffer holds a decoded frame, or (stage 1) a coefficient record -- 2 bytes per pixel --, or (stage 2) a stream: the
   // compressed bytes + 5 KB; a file stage 2 does not take, or whose stream does not fit, is decoded to pixels on the host
   const size_t want_bytes = s.gpu_jpeg == 1 ? std::max(s.frame_bytes(), s.rec_bytes) : s.frame_bytes();
-  if (s.ring.empty() || s.ring_bytes < want_bytes) {
-    for (auto& m : s.ring) m.release();
-    s.ring.assign((size_t)RG * C, HostBuffer());
-    for (auto& m : s.ring) m.alloc(want_bytes);
+  if (!s.ring_block.p || s.ring_bytes < want_bytes) {
+    s.ring_block.release();
+    s.ring_stride = (want_bytes + 4095) & ~(size_t)4095;
+    s.ring_slots = State::kRingFrames;
+    s.ring_block.alloc(s.ring_stride * (size_t)s.ring_slots);
     s.ring_bytes = want_bytes;
   }
   s.start_pool();
@@ -554,7 +557,7 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
     for (int i = k * C; i < std::min(count, (k + 1) * C); i++) {
       Decode& d = rec[(size_t)i];
       d.id = first + i;
-      d.dst = s.ring[(size_t)((k % RG) * C + (i - k * C))].p;
+      d.dst = s.ring_block.p + (size_t)((k % RG) * C + (i - k * C)) * s.ring_stride;
       d.cap = s.ring_bytes;
       d.want_record_pitch = (s.gpu_jpeg && s.ring_bytes >= s.rec_bytes) ? s.rec_pitch : 0;
       d.want_stream = s.gpu_jpeg >= 2;
