@@ -820,9 +820,15 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
                                    fuse_pyr ? pyr[0] + (size_t)f0 * (no / 4) : nullptr, fuse_pyr ? pyr[1] + (size_t)f0 * (no / 16) : nullptr,
                                    fuse_pyr ? pyr[2] + (size_t)f0 * (no / 64) : nullptr);
     };
-    if (prefetch && prefetch_streams(c) == 2) {
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &capturing) != hipSuccess) {
+      (void)hipGetLastError();
+      capturing = hipStreamCaptureStatusNone;
+    }
+    if (prefetch && prefetch_streams(c) == 2 && capturing == hipStreamCaptureStatusNone) {
       // The second stream is a slot's (with its two events), borrowed while the launches are enqueued: what is queued on it
-      // stays ordered after the lease ends.  No free slot (every one held by a host call): one stream.
+      // stays ordered after the lease ends.  No free slot (every one held by a host call): one stream.  A caller's stream
+      // that is being captured into a graph keeps everything on itself (a shared stream must not be drawn into a capture).
       SlotLease side(c, false);
       mdc_ctx::HostSlot* h = side.s;
       if (h && !h->ev_fork) {

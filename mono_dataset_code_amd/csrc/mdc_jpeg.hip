@@ -281,7 +281,14 @@ __device__ __forceinline__ void huff_run(BitReader& b, const HuffLds& dc, const 
         }
       }
     }
-    p = b.pos();
+    const uint32_t np = b.pos();
+    if (np <= p) {  // a table entry of length 0 (never built by the host, but a stream may come from anywhere): keep moving
+      if (!WRITE || cur) *bad = 1;
+      b.skip(1);
+      p = p + 1;
+    } else {
+      p = np;
+    }
   }
   *out_bit = p;
   *out_z = z;
