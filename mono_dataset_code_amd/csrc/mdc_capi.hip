@@ -10,6 +10,7 @@
 #include "mdc_internal.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1825,12 +1826,16 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
   // Zero copy (device_view): results go straight into the caller's images when every one of them is mapped page-locked
   // memory, frames are read straight from the caller's buffers when every one of them is (coefficient records are always
   // copied: the inverse DCT reads a record 16 bytes at a time per thread, uncached that would cross PCIe several times).
+  static const bool trace = getenv("MDC_PIPE_TRACE") != nullptr;  // where a pipelined call spends its host time (stderr)
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
   std::vector<float*> z_out((size_t)nframes);
   std::vector<const uint8_t*> z_in((rec || strm) ? 0 : (size_t)nframes);
   bool zc_out = nframes > 0, zc_in = !rec && !strm && nframes > 0;
   for (int64_t i = 0; i < nframes && zc_out; i++) zc_out = (z_out[(size_t)i] = device_view(c, out[i], n_out * sizeof(float))) != nullptr;
   for (int64_t i = 0; i < nframes && zc_in; i++) zc_in = (z_in[(size_t)i] = device_view(c, raw[i], n_in)) != nullptr;
   if (!zc_out) zc_in = false;  // frames alone: the copy pipeline (one launch per chunk) stays
+  const double t_views = since();
   // frames per slot.  Streams: 64 -- the Huffman kernel's time does not depend on the frame count up to ~64 (one workgroup per
   // frame, 1.3 ms), so small chunks would only repeat that latency; nothing staged: the chunk only alternates the streams
   const int chunk = (zc_in && zc_out) ? 64 : (strm ? 64 : kChunk);
@@ -1942,6 +1947,7 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
     }
     MDC_PIPE(hipEventRecord(c->pipe_done[slot], s_out));
   }
+  const double t_enqueued = since();
   for (int k = 0; k < 2; k++) {
     const hipError_t e = hipStreamSynchronize(c->pipe_stream[k]);
     if (he == hipSuccess && e != hipSuccess) {
@@ -1950,6 +1956,9 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
     }
   }
 #undef MDC_PIPE
+  if (trace)
+    std::fprintf(stderr, "%s: %lld frames: buffer queries %.2f ms, everything enqueued at %.2f ms, streams drained at %.2f ms\n", who, (long long)nframes,
+                 t_views, t_enqueued, since());
   if (rc != MDC_OK) return rc;
   if (he != hipSuccess) return fail(c, MDC_ERR_HIP, "%s: %s", what, hipGetErrorString(he));
   if (strm && status) memcpy(status, c->h_pipe_status, (size_t)nframes * sizeof(int));
