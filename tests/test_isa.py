@@ -15,7 +15,7 @@ def kernels():
     import isa_stats
 
     ks = []
-    for src in ("mdc_kernels.hip", "mdc_vcal.hip"):
+    for src in ("mdc_kernels.hip", "mdc_vcal.hip", "mdc_jpeg.hip"):
         ks += isa_stats.kernels(isa_stats.device_asm(src))
     assert len(ks) > 100
     return ks
@@ -34,6 +34,8 @@ def test_register_budgets(kernels):
     # strip kernel: 5 waves per SIMD without the pyramid (<= 102), 4 with it (<= 128)
     assert by["remap_strip_kernel<true, false, 2, 5, 4>"]["vgpr"] <= 102
     assert by["remap_strip_kernel<true, true, 2, 5, 4>"]["vgpr"] <= 128
+    # the device Huffman decoder: a 1024-thread workgroup per frame, two of them per CU (<= 64 VGPRs)
+    assert by["jpeg_huffman_kernel"]["vgpr"] <= 64
     # the hot kernels use the LDS-DMA path and contain no MFMA (no contraction on this path)
     fused = by["remap_tiled_kernel<true, false, false, false, 128, 512, 2>"]["counts"]
     assert sum(v for n, v in fused.items() if n.startswith("buffer_load_dwordx4")) >= 1
