@@ -131,6 +131,15 @@ int main(int argc, char** argv) {
         return;
       }
       std::vector<float> ho(npi > npo ? npi : npo), ht(npi);
+      // page-locked twins of the host buffers: every other host leg goes through the zero-copy path (the kernels read the frame
+      // and write the result over PCIe themselves, from this thread's leased stream, next to the other threads' launches)
+      unsigned char* pin_raw = 0;
+      float* pin_out = 0;
+      if (hipHostMalloc((void**)&pin_raw, npi, 0) != hipSuccess || hipHostMalloc((void**)&pin_out, (npi > npo ? npi : npo) * 4, 0) != hipSuccess) {
+        failed = 1;
+        return;
+      }
+      std::memcpy(pin_raw, raw[(size_t)k].data(), npi);
       for (int it = 0; it < iters; it++) {
         const unsigned fl = (unsigned)((k * 5 + it) % 16);
         const size_t no = (fl & MDC_RECTIFY) ? npo : npi;
@@ -146,6 +155,15 @@ int main(int argc, char** argv) {
         }
         if (it % 16 == 0) {  // the blocking host entry points on the shared context
           const unsigned char* r0 = raw[(size_t)k].data();
+          if (it % 32 == 0) {  // zero copy: page-locked frame -> page-locked result
+            for (size_t q = 0; q < no; q++) pin_out[q] = -7.f;
+            if (mdc_process_host(ctx, pin_raw, pin_out, fl) != MDC_OK) failed = 1;
+            if (!same_bits(pin_out, want[(size_t)k][fl].data(), no)) {
+              mismatches++;
+              std::fprintf(stderr, "MISMATCH process_host (zero copy) thread %d iteration %d flags %u\n", k, it, fl);
+            }
+            host_calls++;
+          }
           std::fill(ho.begin(), ho.end(), -7.f);
           if (mdc_process_host(ctx, r0, ho.data(), fl) != MDC_OK) failed = 1;
           if (!same_bits(ho.data(), want[(size_t)k][fl].data(), no)) {
@@ -171,6 +189,8 @@ int main(int argc, char** argv) {
       hipFree(d_in);
       hipFree(d_out);
       hipHostFree(h_out);
+      hipHostFree(pin_raw);
+      hipHostFree(pin_out);
       hipStreamDestroy(s);
     });
   for (auto& t : th) t.join();
