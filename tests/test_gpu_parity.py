@@ -790,6 +790,55 @@ def test_zero_copy_host_calls(name, setups, oracle):
         s.ctx.set_option(capi.OPT_ZERO_COPY, 0)
 
 
+@pytest.mark.parametrize("name", ["small_crop", "upsample"])
+def test_device_batch_calls_inside_a_hip_graph(name, setups, oracle, torch_cuda):
+    """The device-batch entry points only enqueue on the caller's stream: captured into a HIP graph (torch.cuda.CUDAGraph) and
+    replayed on fresh input they give the oracle's results -- the fused pass, the pyramid (on the strip path the chunks stay on
+    the capturing stream: a shared second stream must not be drawn into a capture) and the gradients."""
+    from mono_dataset_code_amd import capi
+
+    torch = torch_cuda
+    s = setups(name)
+    frames = np.stack(make_frames(s.W, s.H, n_noise=7))
+    n = len(frames)
+    levels = 3
+    d_in = torch.zeros((n, s.W * s.H), dtype=torch.uint8, device="cuda")
+    d_out = torch.full((n, s.w * s.h), -7.0, dtype=torch.float32, device="cuda")
+    d_base = torch.full((n, s.w * s.h), -7.0, dtype=torch.float32, device="cuda")
+    lv = [torch.full((n * (s.w >> l) * (s.h >> l),), -7.0, dtype=torch.float32, device="cuda") for l in range(1, levels)]
+    try:
+        s.ctx.set_option(capi.OPT_PREFETCH_CHUNK, 2)  # (strip cameras: chunks + prefetch launches inside the capture too)
+        # first call outside any capture: lazy attribute settings and plan uploads are not stream operations
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, 15, st.cuda_stream)
+            s.ctx.process_pyramid_batch(d_in.data_ptr(), d_base.data_ptr(), levels, [t.data_ptr() for t in lv], n, 15, st.cuda_stream)
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, 15, st.cuda_stream)
+            s.ctx.process_pyramid_batch(d_in.data_ptr(), d_base.data_ptr(), levels, [t.data_ptr() for t in lv], n, 15, st.cuda_stream)
+        for rep in range(2):
+            batch = np.roll(frames, rep + 1, axis=0)
+            d_in.copy_(torch.from_numpy(batch).cuda())
+            d_out.fill_(-7.0)
+            d_base.fill_(-7.0)
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            for f in range(n):
+                want = s.want(oracle, batch[f], 1, 1, 1, 1)
+                assert bits_equal(d_out[f].cpu().numpy(), want), (name, rep, f)
+                assert bits_equal(d_base[f].cpu().numpy(), want), (name, rep, f, "base")
+                src, cw, ch = want, s.w, s.h
+                for l in range(levels - 1):
+                    src = oracle.pyramid_level(src, cw, ch)
+                    cw, ch = cw // 2, ch // 2
+                    assert bits_equal(lv[l].view(n, -1)[f].cpu().numpy(), src), (name, rep, f, l + 1)
+    finally:
+        s.ctx.set_option(capi.OPT_PREFETCH_CHUNK, 0)
+
+
 def test_table_blob_roundtrip(setups, oracle, torch_cuda):
     """export -> import into a second context (what the RCCL broadcast carries)."""
     from mono_dataset_code_amd import capi
