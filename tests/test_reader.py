@@ -359,7 +359,7 @@ def test_reader_gpu_jpeg_on_and_off_give_the_same_images(tmp_path):
 
     h, w = 256, 320
     frames = frames_for(40, h, w)  # longer than one chunk of 32
-    make_sequence(str(tmp_path), frames, True, "jpg")
+    names, blobs = make_sequence(str(tmp_path), frames, True, "jpg")
     r = capi.DatasetReader(str(tmp_path))
     on, ok_on, n_on = r.get_images(0, 40, 1, 1, 1, 1)  # default: Huffman decoding on the device too
     r.set_gpu_jpeg(1)
@@ -370,3 +370,28 @@ def test_reader_gpu_jpeg_on_and_off_give_the_same_images(tmp_path):
     for i in range(40):
         assert bits_equal(on[i], off[i]), i
         assert bits_equal(mid[i], off[i]), i
+    # the C entry point itself, results into ordinary (pageable) arrays -- the staged way out -- and into page-locked ones, for
+    # the photometric-only flags too; 70 streams = more than one 64-frame chunk: decode and output streams hand over
+    d = str(tmp_path)
+    fov = capi.UndistorterFOV(os.path.join(d, "camera.txt"))
+    photo = capi.PhotometricUndistorter(os.path.join(d, "pcalib.txt"), os.path.join(d, "vignette.png"), w, h)
+    ctx = capi.Context(0)
+    ctx.bind(fov, photo)
+    cap = (capi.JPEG_STREAM_HEADER_BYTES + max(len(b) for b in blobs) + 64 + 15) & ~15
+    idx = [i % 40 for i in range(70)]
+    pin = capi.PinnedArray((70, cap), np.uint8)
+    sizes = [capi.jpeg_stream(blobs[i], pin.array[k])[0] for k, i in enumerate(idx)]
+    streams = [pin.array[k] for k in range(70)]
+    loose = [np.full(on.shape[1], -7.0, np.float32) for _ in idx]
+    assert ctx.process_jpeg_streams_host(streams, sizes, loose, 15) == [0] * 70
+    pout = capi.PinnedArray((70, on.shape[1]), np.float32)
+    assert ctx.process_jpeg_streams_host(streams, sizes, [pout.array[k] for k in range(70)], 15) == [0] * 70
+    for k, i in enumerate(idx):
+        assert bits_equal(loose[k], off[i]), (k, "pageable")
+        assert bits_equal(pout.array[k], off[i]), (k, "page-locked")
+    raw_out = [np.full(w * h, -7.0, np.float32) for _ in range(3)]
+    assert ctx.process_jpeg_streams_host(streams[:3], sizes[:3], raw_out, 7) == [0, 0, 0]  # no rectification: W x H results
+    for k in range(3):
+        want = np.zeros(w * h, np.float32)
+        ctx.process_host(np.ascontiguousarray(capi.decode_gray8(blobs[idx[k]]).reshape(-1)), want, 7)
+        assert bits_equal(raw_out[k], want), k
