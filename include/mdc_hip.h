@@ -96,7 +96,10 @@ enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2 /* frames a workgroup lo
           page-locked memory mapped into the device's address space (mdc_host_alloc, hipHostMalloc, hipHostRegister; asked
           of the runtime per call): the kernel reads the frame / writes the result over PCIe itself, both directions at once,
           instead of copy in -> kernel -> copy out.  Pageable buffers go through the staging copies as before.
-          0 = automatic (on), 1 = on, 2 = off */ };
+          0 = automatic (on), 1 = on, 2 = off */,
+       MDC_OPT_TAIL_TAPER = 15 /* tuning: a large launch of the tiled kernel ends on frame groups of 1/2, 1/4 and 1/8 of the
+          frames per workgroup, so the slots that free up when its last long workgroups finish do not idle for a long
+          workgroup's time: 0 = automatic (on), 1 = on, 2 = off */ };
 enum { MDC_ORDER_BANDS = 0 /* row-major runs of tiles per XCD */, MDC_ORDER_ROWS = 1 /* whole tile rows per XCD */,
        MDC_ORDER_IDENTITY = 2 /* block b = tile b (diagnosis) */,
        MDC_ORDER_BLOCKS2D = 3 /* the tile grid cut into 8 rectangles, one per XCD */ };

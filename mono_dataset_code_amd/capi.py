@@ -22,6 +22,7 @@ OPT_TWO_STAGE = 11
 OPT_PREFETCH_CHUNK = 12
 OPT_PREFETCH_STREAMS = 13
 OPT_ZERO_COPY = 14
+OPT_TAIL_TAPER = 15
 ORDER_BANDS, ORDER_ROWS, ORDER_IDENTITY, ORDER_BLOCKS2D = 0, 1, 2, 3
 OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 

@@ -105,6 +105,7 @@ struct mdc_ctx {
   int opt_nbuf = 0;  // 0 = automatic
   int opt_interleave = 0;
   int opt_pin_caller = 0;  // MDC_OPT_PIN_CALLER_BUFFERS
+  int opt_taper = 0;             // MDC_OPT_TAIL_TAPER: 0 = automatic (on), 1 = on, 2 = off
   int opt_zero_copy = 0;         // MDC_OPT_ZERO_COPY: 0 = automatic (on), 1 = on, 2 = off
   int opt_prefetch_streams = 0;  // MDC_OPT_PREFETCH_STREAMS: 0 = automatic (2), 1, 2
   int opt_prefetch_chunk = 0;  // MDC_OPT_PREFETCH_CHUNK: frames per prefetched chunk of the strip path; 0 = automatic, -1 = no prefetch
@@ -716,7 +717,7 @@ int ensure_stage(mdc_ctx* c, mdc_ctx::HostSlot* h, size_t in_bytes, size_t out_b
 TilePlan tile_plan(const mdc_ctx* c, int which) {
   const mdc_ctx::SrcPlan& pl = c->plan[which];
   return TilePlan{pl.d_chunks, pl.d_nch, pl.d_taps, pl.d_order, pl.n_blocks, pl.n_tiles, pl.tiles_x, pl.tile_w, pl.tile_h,
-                  pl.chunk_cap, pl.win_bytes, pl.nbuf, c->n_black > 0, c->opt_interleave != 0};
+                  pl.chunk_cap, pl.win_bytes, pl.nbuf, c->n_black > 0, c->opt_interleave != 0, c->opt_taper != 2};
 }
 
 RemapArgs remap_args(const mdc_ctx* c, const float* lut, const float* vinv) {
@@ -1037,6 +1038,10 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
       MDC_HIP(c, hipDeviceSynchronize());
       return plan_tiles(c);
     }
+    case MDC_OPT_TAIL_TAPER:
+      if (value < 0 || value > 2) return fail(c, MDC_ERR_ARG, "tail taper selector must be 0 (automatic), 1 (on) or 2 (off)");
+      c->opt_taper = value;
+      return MDC_OK;
     case MDC_OPT_ZERO_COPY:
       if (value < 0 || value > 2) return fail(c, MDC_ERR_ARG, "zero-copy selector must be 0 (automatic), 1 (on) or 2 (off)");
       c->opt_zero_copy = value;

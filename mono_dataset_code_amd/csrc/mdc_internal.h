@@ -53,6 +53,7 @@ struct TilePlan {
   int nbuf;        // window buffers per workgroup (2..4): nbuf-1 frames are staged ahead
   bool has_black;  // some output carries the (-1,-1) sentinel
   bool interleave; // frame groups take every G-th frame instead of fpb consecutive ones
+  bool taper = true;  // large launches end on frame groups of fpb/2, fpb/4, fpb/8 (MDC_OPT_TAIL_TAPER)
 };
 
 // Plan of the wave-private strip kernel (remap_strip_kernel): a WAVE owns a 128 x 8 output tile (lane l: columns l and

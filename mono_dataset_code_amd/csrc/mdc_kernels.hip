@@ -691,7 +691,7 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
 template <bool VIG, bool BLACK, bool PYR, bool F32, int TW, int NT, int NBUF>
 __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 : 6) : 4)) void remap_tiled_kernel(
     const uint8_t* __restrict__ in, float* __restrict__ out, RemapArgs a, TilePlan p, PyramidOut py, int nframes, int fpb,
-    int interleave) {
+    int interleave, int taper_full, int taper_r) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   float* s_lut = reinterpret_cast<float*>(smem);
   lds_u8_ptr s_win = (lds_u8_ptr)smem + (F32 ? 0 : kLutBytes);
@@ -702,9 +702,20 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
   // frames g, g+G, g+2G, ...  Interleaved, the groups resident at one time (dispatched in order)
   // walk through ADJACENT frames side by side, so the chip's aggregate traffic sweeps the batch
   // linearly instead of touching a few frames each fpb frames apart.
+  // Tapered tail (taper_r > 0): groups 0 .. taper_full-1 hold fpb frames, then taper_r groups of fpb/2, taper_r of fpb/4 and
+  // groups of fpb/8 for the rest (taper_range(), host side, is the same arithmetic).  Groups are dispatched in order, so the
+  // launch ends on short workgroups: the slots that free up when the last long ones finish do not idle for a long
+  // workgroup's time (a 4096-frame launch ran 3 % behind a 50,000-frame one per frame).
   const int fstep = interleave ? (int)gridDim.y : 1;
-  const int f0 = interleave ? (int)blockIdx.y : (int)blockIdx.y * fpb;
-  const int nf = interleave ? (nframes - f0 + fstep - 1) / fstep : min(nframes, f0 + fpb) - f0;
+  int f0 = interleave ? (int)blockIdx.y : (int)blockIdx.y * fpb;
+  int nf = interleave ? (nframes - f0 + fstep - 1) / fstep : min(nframes, f0 + fpb) - f0;
+  if (!interleave && taper_r > 0 && (int)blockIdx.y >= taper_full) {
+    const int k = (int)blockIdx.y - taper_full;
+    const int lvl = min(k / taper_r, 2);
+    const int size = fpb >> (lvl + 1);
+    f0 = taper_full * fpb + taper_r * (fpb - (fpb >> lvl)) + (k - lvl * taper_r) * size;
+    nf = min(nframes, f0 + size) - f0;
+  }
   if (nf <= 0) return;
 
   const int tid = threadIdx.x;
@@ -1318,17 +1329,33 @@ struct TiledLaunch {
   hipStream_t s;
 };
 
+// Frame groups of a launch with a tapered tail: see remap_tiled_kernel.  -> number of groups; *full = groups of fpb frames
+// (taper_r = 0: no taper, ceil(nframes / fpb) groups).
+static int taper_groups(int64_t nframes, int fpb, int taper_r, int* full) {
+  *full = 0;
+  if (taper_r <= 0) return (int)ceil_div(nframes, fpb);
+  const int64_t tail = (int64_t)taper_r * (fpb / 2 + fpb / 4);  // frames of the fpb/2 and fpb/4 groups
+  *full = (int)((nframes - tail) / fpb);
+  const int64_t rest = nframes - (int64_t)*full * fpb - tail;   // in [0, fpb): groups of fpb/8
+  return *full + 2 * taper_r + (int)ceil_div(rest, fpb / 8);
+}
+
 template <bool VIG, bool BLACK, bool PYR, bool F32, int TW, int NT, int NBUF>
 static hipError_t launch_tiled_variant(const TiledLaunch& l) {
-  dim3 grid(l.p.n_blocks, ceil_div(l.nframes, l.fpb));
   const size_t lds = tiled_lds_bytes(l.p.win_bytes, NBUF, !F32) + (PYR ? tiled_pyramid_lds_bytes(l.p.tile_w, l.p.tile_h) : 0);
+  // taper: about one resident round of workgroups per level; only launches of many rounds, frames per workgroup a multiple of 8
+  const int resident = 256 * (int)std::max<size_t>(1, std::min<size_t>(2048 / NT, kLdsPerCU / std::max<size_t>(lds, 1)));
+  int taper_r = std::max(2, (resident + l.p.n_blocks / 2) / std::max(1, l.p.n_blocks));
+  if (!l.p.taper || l.p.interleave || l.fpb % 8 != 0 || l.fpb < 16 || l.nframes < (int64_t)l.fpb * (4 * taper_r)) taper_r = 0;
+  int taper_full = 0;
+  dim3 grid(l.p.n_blocks, taper_groups(l.nframes, l.fpb, taper_r, &taper_full));
   if (lds > 64 * 1024) {  // more than 64 KiB of dynamic LDS needs the opt-in
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&remap_tiled_kernel<VIG, BLACK, PYR, F32, TW, NT, NBUF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  remap_tiled_kernel<VIG, BLACK, PYR, F32, TW, NT, NBUF><<<grid, NT, lds, l.s>>>(l.d_in, l.d_out, l.a, l.p, l.py,
-                                                                                 (int)l.nframes, l.fpb, l.p.interleave ? 1 : 0);
+  remap_tiled_kernel<VIG, BLACK, PYR, F32, TW, NT, NBUF><<<grid, NT, lds, l.s>>>(l.d_in, l.d_out, l.a, l.p, l.py, (int)l.nframes, l.fpb,
+                                                                                 l.p.interleave ? 1 : 0, taper_full, taper_r);
   return hipGetLastError();
 }
 

@@ -33,6 +33,7 @@ ap.add_argument("--order", default="0")
 ap.add_argument("--sched", default="0")
 ap.add_argument("--prefetch", default="0", help="strip path: frames per prefetched chunk (0 auto, -1 off)")
 ap.add_argument("--pfdist", default="-1", help="(experiment 09 builds only) strip kernel's own prefetch: frames ahead (0 auto, -1 off)")
+ap.add_argument("--taper", default="0", help="tapered tail of large tiled launches (0 auto = on, 1 on, 2 off)")
 ap.add_argument("--streams", default="0", help="streams the prefetched chunks alternate over (0 auto, 1, 2)")
 ap.add_argument("--pyramid", default="0", help="0 = base only (mdc_process_batch_device), 1 = base + levels 1..3")
 ap.add_argument("--flags", type=int, default=15)
@@ -63,7 +64,7 @@ d_out = torch.empty(B * npo, dtype=torch.float32, device="cuda")
 lv = [torch.empty(B * (ow >> l) * (oh >> l), dtype=torch.float32, device="cuda") for l in (1, 2, 3)]
 ctxs[libs[0]][1].synth_frames(d_in.data_ptr(), 0, B, npi, synth.SEED, s)
 ints = lambda x: [int(v) for v in x.split(",")]  # noqa: E731
-variants = list(itertools.product(libs, ints(a.two_stage), ints(a.cols), ints(a.rows), ints(a.nbuf), ints(a.fpb), ints(a.order), ints(a.sched), ints(a.pyramid), ints(a.prefetch), ints(a.pfdist), ints(a.streams)))
+variants = list(itertools.product(libs, ints(a.two_stage), ints(a.cols), ints(a.rows), ints(a.nbuf), ints(a.fpb), ints(a.order), ints(a.sched), ints(a.pyramid), ints(a.prefetch), ints(a.pfdist), ints(a.streams), ints(a.taper)))
 times = {v: [] for v in variants}
 names = {}
 ref_out, same = {}, {}
@@ -93,6 +94,7 @@ for r in range(a.rounds + 1):
         try_set(m, ctx, "OPT_PREFETCH_CHUNK", v[9])
         try_set(m, ctx, "OPT_PREFETCH_DIST", v[10])
         try_set(m, ctx, "OPT_PREFETCH_STREAMS", v[11])
+        try_set(m, ctx, "OPT_TAIL_TAPER", v[12])
         try:
             names[v] = ctx.describe_launch(a.flags, 4 if v[8] else 0)
         except Exception:  # noqa: BLE001
@@ -116,7 +118,7 @@ for r in range(a.rounds + 1):
         if r:
             times[v].append(e0.elapsed_time(e1) / a.iters)
 print("out %dx%d frames %d" % (ow, oh, B))
-print("%-26s %2s %4s %4s %3s %3s %3s %3s %3s %4s %4s %3s %9s %9s %4s  %s" % ("lib", "2s", "cols", "rows", "buf", "fpb", "ord", "sch", "pyr", "pref", "pfd", "str", "median_ms", "min_ms", "same", "kernel"))
+print("%-26s %2s %4s %4s %3s %3s %3s %3s %3s %4s %4s %3s %3s %9s %9s %4s  %s" % ("lib", "2s", "cols", "rows", "buf", "fpb", "ord", "sch", "pyr", "pref", "pfd", "str", "tap", "median_ms", "min_ms", "same", "kernel"))
 for v in variants:
-    print("%-26s %2d %4d %4d %3d %3d %3d %3d %3d %4d %4d %3d %9.4f %9.4f %4s  %s" % (os.path.basename(v[0])[-26:], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11],
+    print("%-26s %2d %4d %4d %3d %3d %3d %3d %3d %4d %4d %3d %3d %9.4f %9.4f %4s  %s" % (os.path.basename(v[0])[-26:], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12],
                                                                       float(np.median(times[v])), float(np.min(times[v])), "yes" if same.get(v) else "NO", names[v]), flush=True)
