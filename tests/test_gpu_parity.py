@@ -314,6 +314,40 @@ def test_tune_keeps_results_and_picks_a_plan(setups, oracle, torch_cuda):
         s.ctx.set_option(opt, 0)
 
 
+def test_tapered_tail_of_large_launches(setups, oracle, torch_cuda):
+    """MDC_OPT_TAIL_TAPER: a launch of many rounds of workgroups ends on frame groups of 1/2, 1/4 and 1/8 of the frames per
+    workgroup.  Frame counts that leave 0, 1 and fpb/8 + 3 frames for the last level, with 16 and 24 frames per workgroup: every
+    frame of the batch equals the launch without the taper bit for bit (no frame skipped, none written twice with another
+    group's data), and sampled frames equal the oracle."""
+    from mono_dataset_code_amd import capi, synth
+
+    torch = torch_cuda
+    s = setups("full_1280_to_640")
+    npix, nout = s.W * s.H, s.w * s.h
+    st = torch.cuda.current_stream().cuda_stream
+    nmax = 700
+    d_in = torch.empty(nmax * npix, dtype=torch.uint8, device="cuda")
+    s.ctx.synth_frames(d_in.data_ptr(), 7, nmax, npix, synth.SEED, st)
+    d_a = torch.empty(nmax * nout, dtype=torch.float32, device="cuda")
+    d_b = torch.empty(nmax * nout, dtype=torch.float32, device="cuda")
+    try:
+        for fpb, n in ((16, 512), (16, 513), (16, 517), (24, 700), (16, 300)):
+            s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, fpb)
+            for taper, dst in ((2, d_a), (1, d_b)):
+                s.ctx.set_option(capi.OPT_TAIL_TAPER, taper)
+                dst.fill_(-7.0)
+                s.ctx.process_batch(d_in.data_ptr(), dst.data_ptr(), n, 15, st)
+            torch.cuda.synchronize()
+            assert torch.equal(d_a[: n * nout].view(torch.int32), d_b[: n * nout].view(torch.int32)), (fpb, n)
+            assert bool((d_b[n * nout:] == -7.0).all()), (fpb, n, "wrote past the batch")
+            frames = d_in.view(nmax, npix)
+            for f in (0, n // 2, n - 9, n - 2, n - 1):
+                assert bits_equal(d_b.view(nmax, nout)[f].cpu().numpy(), s.want(oracle, frames[f].cpu().numpy(), 1, 1, 1, 1)), (fpb, n, f)
+    finally:
+        s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, 0)
+        s.ctx.set_option(capi.OPT_TAIL_TAPER, 0)
+
+
 def test_batch_beyond_4gib(setups, oracle, torch_cuda):
     """A batch whose frames lie beyond 4 GiB from the base pointers (3400 frames: 4.46 GB in, 4.18 GB out):
     the per-frame buffer descriptors take a 48-bit base, lane offsets stay 32-bit.  Checked against the
