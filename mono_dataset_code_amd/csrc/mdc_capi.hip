@@ -929,6 +929,7 @@ int mdc_create(int device, mdc_ctx** out) {
   DeviceGuard dg(device);
   c->h_ginv.assign(256, 0.f);
   if (const char* e = getenv("MDC_PIN_CALLER_BUFFERS")) c->opt_pin_caller = atoi(e) != 0;
+  if (const char* e = getenv("MDC_ZERO_COPY")) c->opt_zero_copy = std::max(0, std::min(2, atoi(e)));  // as MDC_OPT_ZERO_COPY, for callers that cannot be recompiled
   int rc = upload_luts(c);
   if (rc == MDC_OK && hipMalloc(&c->d_vcal_max, mdc_ctx::kVcalMaxWords * sizeof(unsigned)) != hipSuccess)
     rc = fail(c, MDC_ERR_HIP, "hipMalloc of the context's scratch words failed");
@@ -1840,6 +1841,15 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
   for (int64_t i = 0; i < nframes && zc_out; i++) zc_out = (z_out[(size_t)i] = device_view(c, out[i], n_out * sizeof(float))) != nullptr;
   for (int64_t i = 0; i < nframes && zc_in; i++) zc_in = (z_in[(size_t)i] = device_view(c, raw[i], n_in)) != nullptr;
   if (!zc_out) zc_in = false;  // frames alone: the copy pipeline (one launch per chunk) stays
+  if (zc_out) {
+    // Zero copy pays here when frames lie back to back (rows of one block: one launch per chunk reads / writes them in place).
+    // Scattered images -- the reader's pool -- would mean one single-frame launch each: measured next to the decode stream
+    // those run at 47 us per frame where one batched launch + the DMA engines' copies out take 25 (experiment 14).
+    int64_t runs = 1;
+    for (int64_t i = 1; i < nframes; i++)
+      if (z_out[(size_t)i] != z_out[(size_t)i - 1] + n_out || (zc_in && z_in[(size_t)i] != z_in[(size_t)i - 1] + n_in)) runs++;
+    if (runs * 8 > nframes && nframes >= 8) zc_out = zc_in = false;
+  }
   const double t_views = since();
   // frames per slot.  Streams: 64 -- the Huffman kernel's time does not depend on the frame count up to ~64 (one workgroup per
   // frame, 1.3 ms), so small chunks would only repeat that latency; nothing staged: the chunk only alternates the streams
