@@ -138,8 +138,9 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const int16_t* __restric
 // One workgroup of 1024 threads per frame.  The bit stream is cut into 1024 subsequences of S bits; thread i decodes
 // [i S, (i+1) S) from an entry state (bit position of a symbol boundary, coefficient index z inside the current block;
 // z == 0: a DC symbol comes next).  The true entry state of subsequence i is the exit state of subsequence i-1 -- unknown at
-// first, so every thread starts from the guess (i S, 0), and the states are RELAXED: decode, hand the exit state to the right
-// neighbour, decode again where the entry state changed, until nothing changes.  Subsequence 0's entry state (0, 0) is exact,
+// first, so every thread starts from a guess (its left neighbour decodes the last 512 bits of its own subsequence from an
+// arbitrary state), and the states are RELAXED: decode, hand the exit state to the right neighbour, decode again where the
+// entry state changed, until nothing changes.  Subsequence 0's entry state (0, 0) is exact,
 // so after k rounds the first k are exact: the fixed point is the sequential decoder's state sequence; and because Huffman
 // streams resynchronise after a few symbols (bit position) and every end-of-block resets z, wrong guesses heal inside one
 // subsequence: 2-3 rounds in practice (the bound, 1024, only costs time).  Then a prefix sum over the blocks each
@@ -342,9 +343,26 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
   b.base = reinterpret_cast<const uint32_t*>(st + sizeof(mdc_jpeg_stream_header));
   b.last = (ecs_bytes + 3) / 4 + 2;  // the host pads 16 zero bytes
   int16_t* coef = rec + 64;
-  // ---- relaxation
+  // ---- first guesses: only the exit state of a subsequence matters to its right neighbour, and a decoder started anywhere
+  // is on the true path after a few hundred bits -- so the guess comes from the LAST quarter (at least 512 bits) of the subsequence alone
+  // (a quarter of a full pass; where it is wrong, the relaxation below finds out)
+#ifndef MDC_EXP_GUESS_DIV
+#define MDC_EXP_GUESS_DIV 4
+#endif
+  const uint32_t guess_bits = max(512u, S / MDC_EXP_GUESS_DIV);  // (high qualities: ~250 bits per block, 512 bits are two blocks)
   uint32_t in_bit = my0, out_bit = my0;
   int in_z = 0, out_z = 0, nblk = 0, bad = 0;
+  if (my0 < my1) {
+    const uint32_t from = my1 - my0 > guess_bits ? my1 - guess_bits : my0;
+    huff_run<false>(b, s_dc, s_ac, from, 0, my1, &out_bit, &out_z, &nblk, &bad, nullptr, 0, 0, 1, 1);
+  }
+  s_bit[tid] = out_bit;
+  s_z[tid] = out_z;
+  __syncthreads();
+  in_bit = tid ? s_bit[tid - 1] : 0u;
+  in_z = tid ? s_z[tid - 1] : 0;
+  __syncthreads();
+  // ---- relaxation
   bool dirty = true;
   int rounds = 0;
   for (int round = 0; round <= kHuffThreads; round++) {
