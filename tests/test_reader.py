@@ -75,7 +75,7 @@ def test_get_image_and_get_images_equal_the_oracle(tmp_path, oracle, zipped, fmt
 
 
 def test_get_images_longer_than_the_ring(tmp_path, oracle):
-    """More frames than the page-locked ring holds (6 chunks of 32): chunk k+6 re-uses chunk k's buffers while the pool decodes."""
+    """More frames than the page-locked ring holds (256 buffers, chunks of 32): chunk k+8 re-uses chunk k's buffers while the pool decodes."""
     from mono_dataset_code_amd import capi
 
     h, w = 64, 80
