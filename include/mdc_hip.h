@@ -45,7 +45,8 @@ typedef enum mdc_status {
   MDC_ERR_STATE = -2,     /* a table the call needs was never set (cf. the reference's valid/validGamma/validVignette) */
   MDC_ERR_SIZE = -3,      /* pixel count does not match the tables (cf. FOVUndistorter.cpp:327-338) */
   MDC_ERR_HIP = -4,       /* a HIP runtime call failed */
-  MDC_ERR_NO_DEVICE = -5  /* no gfx950 device visible: there is NO CPU fallback */
+  MDC_ERR_NO_DEVICE = -5, /* no gfx950 device visible: there is NO CPU fallback */
+  MDC_ERR_NOMEM = -6      /* a host-side allocation failed (no exception crosses this interface) */
 } mdc_status;
 
 /* Flag word of the per-frame calls: the four bools of

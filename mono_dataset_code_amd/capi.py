@@ -24,7 +24,7 @@ OPT_PREFETCH_STREAMS = 13
 OPT_ZERO_COPY = 14
 OPT_TAIL_TAPER = 15
 ORDER_BANDS, ORDER_ROWS, ORDER_IDENTITY, ORDER_BLOCKS2D = 0, 1, 2, 3
-OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
+OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/mdc_hip.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = [

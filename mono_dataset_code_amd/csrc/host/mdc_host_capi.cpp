@@ -64,27 +64,27 @@ void mdc_fov_model_of(const UndistorterFOV& u, mdc_fov_model* m) {
 
 extern "C" {
 
-void mdch_fov_model(const mdch_fov* h, mdc_fov_model* m) { mdc_fov_model_of(*h->u, m); }
+void mdch_fov_model(const mdch_fov* h, mdc_fov_model* m) try { mdc_fov_model_of(*h->u, m); } catch (...) {}
 
-mdch_fov* mdch_fov_create(const char* camera_txt) {
+mdch_fov* mdch_fov_create(const char* camera_txt) try {
   mdch_fov* h = new mdch_fov;
   h->u = new UndistorterFOV(camera_txt);
   return h;
-}
-void mdch_fov_destroy(mdch_fov* h) {
+} catch (...) { return {}; }  // no exception leaves the C facade
+void mdch_fov_destroy(mdch_fov* h) try {
   if (!h) return;
   delete h->u;
   delete h;
-}
-int mdch_fov_valid(const mdch_fov* h) { return h->u->isValid() ? 1 : 0; }
-int mdch_fov_has_gpu(const mdch_fov* h) { return MdcHostAccess::has_gpu(*h->u) ? 1 : 0; }
-void mdch_fov_dims(const mdch_fov* h, int d[4]) {
+} catch (...) {}
+int mdch_fov_valid(const mdch_fov* h) try { return h->u->isValid() ? 1 : 0; } catch (...) { return {}; }
+int mdch_fov_has_gpu(const mdch_fov* h) try { return MdcHostAccess::has_gpu(*h->u) ? 1 : 0; } catch (...) { return {}; }
+void mdch_fov_dims(const mdch_fov* h, int d[4]) try {
   d[0] = h->u->getInputDims()[0];
   d[1] = h->u->getInputDims()[1];
   d[2] = h->u->getOutputDims()[0];
   d[3] = h->u->getOutputDims()[1];
-}
-void mdch_fov_intrinsics(const mdch_fov* h, float* o) {
+} catch (...) {}
+void mdch_fov_intrinsics(const mdch_fov* h, float* o) try {
   const Eigen::Matrix3f a = h->u->getK_rect(), b = h->u->getK_org();
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 3; c++) {
@@ -95,62 +95,62 @@ void mdch_fov_intrinsics(const mdch_fov* h, float* o) {
   for (int i = 0; i < 5; i++) o[18 + i] = v[i];
   o[23] = h->u->getOmega();
   for (int i = 0; i < 5; i++) o[24 + i] = MdcHostAccess::calib_out(*h->u)[i];
-}
-int mdch_fov_remap(const mdch_fov* h, float* rx, float* ry) {
+} catch (...) {}
+int mdch_fov_remap(const mdch_fov* h, float* rx, float* ry) try {
   if (!h->u->isValid() || !MdcHostAccess::rx(*h->u)) return 0;
   const size_t n = (size_t)h->u->getOutputDims()[0] * h->u->getOutputDims()[1];
   memcpy(rx, MdcHostAccess::rx(*h->u), n * sizeof(float));
   memcpy(ry, MdcHostAccess::ry(*h->u), n * sizeof(float));
   return 1;
-}
-void mdch_fov_distort(mdch_fov* h, float* x, float* y, int n) { h->u->distortCoordinates(x, y, n); }
-void mdch_fov_undistort_f32(const mdch_fov* h, const float* in, float* out, int n_in, int n_out) {
+} catch (...) { return {}; }  // no exception leaves the C facade
+void mdch_fov_distort(mdch_fov* h, float* x, float* y, int n) try { h->u->distortCoordinates(x, y, n); } catch (...) {}
+void mdch_fov_undistort_f32(const mdch_fov* h, const float* in, float* out, int n_in, int n_out) try {
   h->u->undistort<float>(in, out, n_in, n_out);
-}
-void mdch_fov_undistort_u8(const mdch_fov* h, const unsigned char* in, float* out, int n_in, int n_out) {
+} catch (...) {}
+void mdch_fov_undistort_u8(const mdch_fov* h, const unsigned char* in, float* out, int n_in, int n_out) try {
   h->u->undistort<unsigned char>(in, out, n_in, n_out);
-}
+} catch (...) {}
 
-mdch_photo* mdch_photo_create(const char* pcalib, const char* vignette, int w, int h) {
+mdch_photo* mdch_photo_create(const char* pcalib, const char* vignette, int w, int h) try {
   mdch_photo* p = new mdch_photo;
   p->p = new PhotometricUndistorter(pcalib, vignette, w, h);
   return p;
-}
-void mdch_photo_destroy(mdch_photo* p) {
+} catch (...) { return {}; }  // no exception leaves the C facade
+void mdch_photo_destroy(mdch_photo* p) try {
   if (!p) return;
   delete p->p;
   delete p;
-}
-int mdch_photo_valid(const mdch_photo* p) {
+} catch (...) {}
+int mdch_photo_valid(const mdch_photo* p) try {
   return (MdcHostAccess::valid_gamma(*p->p) ? 1 : 0) | (MdcHostAccess::valid_vignette(*p->p) ? 2 : 0);
-}
-int mdch_photo_has_gpu(const mdch_photo* p) { return MdcHostAccess::has_gpu(*p->p) ? 1 : 0; }
-int mdch_photo_ginv(mdch_photo* p, float* o) {
+} catch (...) { return {}; }  // no exception leaves the C facade
+int mdch_photo_has_gpu(const mdch_photo* p) try { return MdcHostAccess::has_gpu(*p->p) ? 1 : 0; } catch (...) { return {}; }
+int mdch_photo_ginv(mdch_photo* p, float* o) try {
   const float* g = p->p->getGInv();
   if (!g) return 0;
   memcpy(o, g, 256 * sizeof(float));
   return 1;
-}
-int mdch_photo_g(mdch_photo* p, float* o) {
+} catch (...) { return {}; }  // no exception leaves the C facade
+int mdch_photo_g(mdch_photo* p, float* o) try {
   const float* g = p->p->getG();
   if (!g) return 0;
   memcpy(o, g, 256 * sizeof(float));
   return 1;
-}
-int mdch_photo_vignette(const mdch_photo* p, float* map, float* inv) {
+} catch (...) { return {}; }  // no exception leaves the C facade
+int mdch_photo_vignette(const mdch_photo* p, float* map, float* inv) try {
   if (!MdcHostAccess::valid_vignette(*p->p)) return 0;
   const size_t n = (size_t)MdcHostAccess::w(*p->p) * MdcHostAccess::h(*p->p);
   if (map) memcpy(map, MdcHostAccess::vmap(*p->p), n * sizeof(float));
   if (inv) memcpy(inv, MdcHostAccess::vinv(*p->p), n * sizeof(float));
   return 1;
-}
-void mdch_photo_unmap(mdch_photo* p, unsigned char* in, float* out, int n, int g, int v, int o) {
+} catch (...) { return {}; }  // no exception leaves the C facade
+void mdch_photo_unmap(mdch_photo* p, unsigned char* in, float* out, int n, int g, int v, int o) try {
   p->p->unMapImage(in, out, n, g != 0, v != 0, o != 0);
-}
+} catch (...) {}
 
-int mdch_bind(mdc_ctx* ctx, const mdch_fov* fov, const mdch_photo* photo) {
+int mdch_bind(mdc_ctx* ctx, const mdch_fov* fov, const mdch_photo* photo) try {
   return mdc_bind_objects(ctx, fov ? fov->u : 0, photo ? photo->p : 0);
-}
+} catch (...) { return {}; }  // no exception leaves the C facade
 
 // Must stay in step with BlobHeader in csrc/mdc_capi.hip (checked by tests/test_multi_gpu.py
 // on the GPU: pack == export after bind).
@@ -162,7 +162,7 @@ struct PackedHeader {
 };
 }  // namespace
 
-int mdch_pack_tables(const mdch_fov* fov, const mdch_photo* photo, void* blob, size_t cap, size_t* size) {
+int mdch_pack_tables(const mdch_fov* fov, const mdch_photo* photo, void* blob, size_t cap, size_t* size) try {
   if (!size) return MDC_ERR_ARG;
   PackedHeader h;
   memset(&h, 0, sizeof h);
@@ -203,33 +203,33 @@ int mdch_pack_tables(const mdch_fov* fov, const mdch_photo* photo, void* blob, s
     memcpy(q + nr * 4, MdcHostAccess::ry(*u), nr * 4);
   }
   return MDC_OK;
-}
+} catch (...) { return {}; }  // no exception leaves the C facade
 
 
 // ---- DatasetReader ---------------------------------------------------------------------------------
 struct mdch_reader { DatasetReader* r; };
 
-mdch_reader* mdch_reader_create(const char* folder) {
+mdch_reader* mdch_reader_create(const char* folder) try {
   mdch_reader* h = new mdch_reader;
   h->r = new DatasetReader(folder);
   return h;
-}
-void mdch_reader_destroy(mdch_reader* h) {
+} catch (...) { return {}; }  // no exception leaves the C facade
+void mdch_reader_destroy(mdch_reader* h) try {
   if (!h) return;
   delete h->r;
   delete h;
-}
-int mdch_reader_num_images(mdch_reader* h) { return h->r->getNumImages(); }
-double mdch_reader_timestamp(mdch_reader* h, int id) { return h->r->getTimestamp(id); }
-float mdch_reader_exposure(mdch_reader* h, int id) { return h->r->getExposure(id); }
-void mdch_reader_dims(mdch_reader* h, int d[4]) {
+} catch (...) {}
+int mdch_reader_num_images(mdch_reader* h) try { return h->r->getNumImages(); } catch (...) { return {}; }
+double mdch_reader_timestamp(mdch_reader* h, int id) try { return h->r->getTimestamp(id); } catch (...) { return {}; }
+float mdch_reader_exposure(mdch_reader* h, int id) try { return h->r->getExposure(id); } catch (...) { return {}; }
+void mdch_reader_dims(mdch_reader* h, int d[4]) try {
   d[0] = h->r->getUndistorter()->getInputDims()[0];
   d[1] = h->r->getUndistorter()->getInputDims()[1];
   d[2] = h->r->getUndistorter()->getOutputDims()[0];
   d[3] = h->r->getUndistorter()->getOutputDims()[1];
-}
+} catch (...) {}
 int mdch_reader_get_image(mdch_reader* h, int id, int rectify, int g, int v, int o, float* out, long cap, int meta[3],
-                          double* stamp, float* exposure) {
+                          double* stamp, float* exposure) try {
   ExposureImage* img = h->r->getImage(id, rectify != 0, g != 0, v != 0, o != 0);
   if (!img) return 0;
   const long n = (long)img->w * img->h;
@@ -242,9 +242,9 @@ int mdch_reader_get_image(mdch_reader* h, int id, int rectify, int g, int v, int
   *exposure = img->exposure_time;
   delete img;  // caller owns the ExposureImage (main_playbackDataset.cpp:82,116)
   return ok;
-}
+} catch (...) { return {}; }  // no exception leaves the C facade
 int mdch_reader_get_images(mdch_reader* h, int first, int count, int rectify, int g, int v, int o, float* out,
-                           long frame_floats, unsigned char* ok) {
+                           long frame_floats, unsigned char* ok) try {
   if (count <= 0) return 0;
   ExposureImage** imgs = new ExposureImage*[count];
   const int n = h->r->getImages(first, count, rectify != 0, g != 0, v != 0, o != 0, imgs);
@@ -259,20 +259,20 @@ int mdch_reader_get_images(mdch_reader* h, int first, int count, int rectify, in
   }
   delete[] imgs;
   return n;
-}
-int mdch_reader_get_raw(mdch_reader* h, int id, unsigned char* out, long cap, int wh[2]) {
+} catch (...) { return {}; }  // no exception leaves the C facade
+int mdch_reader_get_raw(mdch_reader* h, int id, unsigned char* out, long cap, int wh[2]) try {
   const unsigned char* p = h->r->getImageRaw(id, &wh[0], &wh[1]);
   if (!p || (long)wh[0] * wh[1] > cap) return 0;
   memcpy(out, p, (size_t)wh[0] * wh[1]);
   return 1;
-}
-void mdch_reader_set_threads(mdch_reader* h, int n) { h->r->setDecodeThreads(n); }
-void mdch_reader_set_prefetch(mdch_reader* h, int n) { h->r->setPrefetch(n); }
-void mdch_reader_set_gpu_jpeg(mdch_reader* h, int stage) { h->r->setGpuJpegStage(stage == 1 ? 1 : (stage ? 2 : 0)); }
-const char* mdch_reader_last_error(mdch_reader* h) { return h->r->lastError(); }
-void mdch_reader_prefetch_stats(mdch_reader* h, long hm[2]) { h->r->getPrefetchStats(&hm[0], &hm[1]); }
+} catch (...) { return {}; }  // no exception leaves the C facade
+void mdch_reader_set_threads(mdch_reader* h, int n) try { h->r->setDecodeThreads(n); } catch (...) {}
+void mdch_reader_set_prefetch(mdch_reader* h, int n) try { h->r->setPrefetch(n); } catch (...) {}
+void mdch_reader_set_gpu_jpeg(mdch_reader* h, int stage) try { h->r->setGpuJpegStage(stage == 1 ? 1 : (stage ? 2 : 0)); } catch (...) {}
+const char* mdch_reader_last_error(mdch_reader* h) try { return h->r->lastError(); } catch (...) { return {}; }
+void mdch_reader_prefetch_stats(mdch_reader* h, long hm[2]) try { h->r->getPrefetchStats(&hm[0], &hm[1]); } catch (...) {}
 
-size_t mdch_jpeg_record_bytes(int w, int h, int pitch_rows[2]) {
+size_t mdch_jpeg_record_bytes(int w, int h, int pitch_rows[2]) try {
   // MCUs are at most 4 x 4 blocks: a pitch / row count rounded up to a multiple of 4 blocks holds every sampling layout
   const int pitch = ((w + 7) / 8 + 3) & ~3, rows = ((h + 7) / 8 + 3) & ~3;
   if (pitch_rows) {
@@ -280,10 +280,10 @@ size_t mdch_jpeg_record_bytes(int w, int h, int pitch_rows[2]) {
     pitch_rows[1] = rows;
   }
   return 128 + (size_t)pitch * rows * 128;
-}
+} catch (...) { return {}; }  // no exception leaves the C facade
 
 int mdch_decode_jpeg_record(const unsigned char* data, size_t n, void* record, size_t record_bytes, int pitch_blocks, int dims[4], char* err,
-                            size_t errcap) {
+                            size_t errcap) try {
   std::string e;
   bool ok = false;
   if (record && record_bytes >= 128 + 128 && dims) {
@@ -307,9 +307,9 @@ int mdch_decode_jpeg_record(const unsigned char* data, size_t n, void* record, s
     err[errcap - 1] = 0;
   }
   return ok ? 1 : 0;
-}
+} catch (...) { return {}; }  // no exception leaves the C facade
 
-long long mdch_jpeg_stream(const unsigned char* data, size_t n, void* stream, size_t cap, int wh[2], char* err, size_t errcap) {
+long long mdch_jpeg_stream(const unsigned char* data, size_t n, void* stream, size_t cap, int wh[2], char* err, size_t errcap) try {
   std::string e;
   size_t used = 0;
   int w = 0, h = 0;
@@ -325,9 +325,9 @@ long long mdch_jpeg_stream(const unsigned char* data, size_t n, void* stream, si
     err[errcap - 1] = 0;
   }
   return ok ? (long long)used : 0;
-}
+} catch (...) { return {}; }  // no exception leaves the C facade
 
-int mdch_decode_gray8(const unsigned char* data, size_t n, unsigned char* out, size_t cap, int wh[2], char* err, size_t errcap) {
+int mdch_decode_gray8(const unsigned char* data, size_t n, unsigned char* out, size_t cap, int wh[2], char* err, size_t errcap) try {
   std::string e;
   const bool ok = mdc_host::decode_gray8(data, n, out, cap, &wh[0], &wh[1], &e);
   if (err && errcap) {
@@ -335,6 +335,6 @@ int mdch_decode_gray8(const unsigned char* data, size_t n, unsigned char* out, s
     err[errcap - 1] = 0;
   }
   return ok ? 1 : 0;
-}
+} catch (...) { return {}; }  // no exception leaves the C facade
 
 }  // extern "C"

@@ -912,9 +912,22 @@ constexpr uint32_t kMagic = 0x4d444331u;  // "MDC1"
 static int set_photometric_locked(mdc_ctx* c, const float* ginv, const float* vignette_inv, int w, int h);
 static int set_remap_locked(mdc_ctx* c, const float* rx, const float* ry, int in_w, int in_h, int out_w, int out_h);
 
+// No exception leaves the C ABI: allocation failures of the host-side containers (tables, plans, pointer lists) and anything
+// else unexpected become a status + message.
+#define MDC_CATCH(c_)                                                                    \
+  catch (const std::bad_alloc&) {                                                        \
+    return fail((c_), MDC_ERR_NOMEM, "out of host memory");                              \
+  }                                                                                      \
+  catch (const std::exception& e_) {                                                     \
+    return fail((c_), MDC_ERR_HIP, "unexpected exception: %s", e_.what());               \
+  }                                                                                      \
+  catch (...) {                                                                          \
+    return fail((c_), MDC_ERR_HIP, "unexpected exception");                              \
+  }
+
 extern "C" {
 
-int mdc_create(int device, mdc_ctx** out) {
+int mdc_create(int device, mdc_ctx** out) try {
   if (!out) return fail(nullptr, MDC_ERR_ARG, "mdc_create: out is NULL");
   *out = nullptr;
   int n = 0;
@@ -942,7 +955,7 @@ int mdc_create(int device, mdc_ctx** out) {
   }
   *out = c;
   return MDC_OK;
-}
+} MDC_CATCH(nullptr)
 
 void mdc_destroy(mdc_ctx* c) {
   if (!c) return;
@@ -985,7 +998,7 @@ const char* mdc_last_error(const mdc_ctx* c) {
   return t_err_other.c_str();
 }
 
-int mdc_set_option(mdc_ctx* c, int option, int value) {
+int mdc_set_option(mdc_ctx* c, int option, int value) try {
   if (!c) return MDC_ERR_ARG;
   WriteLock lk(c->mu);
   switch (option) {
@@ -1076,9 +1089,9 @@ int mdc_set_option(mdc_ctx* c, int option, int value) {
     }
   }
   return fail(c, MDC_ERR_ARG, "unknown option %d", option);
-}
+} MDC_CATCH(c)
 
-int mdc_get_info(mdc_ctx* c, mdc_info* i) {
+int mdc_get_info(mdc_ctx* c, mdc_info* i) try {
   if (!c || !i) return MDC_ERR_ARG;
   ReadLock lk(c->mu);
   memset(i, 0, sizeof *i);
@@ -1116,14 +1129,14 @@ int mdc_get_info(mdc_ctx* c, mdc_info* i) {
   i->src_staged_bytes = c->strip.planned ? c->strip.staged_bytes : p0.staged_bytes;
   i->n_black = c->n_black;
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
-int mdc_set_photometric(mdc_ctx* c, const float* ginv, const float* vignette_inv, int w, int h) {
+int mdc_set_photometric(mdc_ctx* c, const float* ginv, const float* vignette_inv, int w, int h) try {
   if (!c) return MDC_ERR_ARG;
   if (w <= 0 || h <= 0) return fail(c, MDC_ERR_ARG, "bad frame size %dx%d", w, h);
   WriteLock lk(c->mu);
   return set_photometric_locked(c, ginv, vignette_inv, w, h);
-}
+} MDC_CATCH(c)
 
 // (lock held) The tables are replaced in place: every kernel that may still read them -- also those the
 // *_device entry points put on caller streams -- has to be done first, hence the device-wide wait.
@@ -1151,11 +1164,11 @@ static int set_photometric_locked(mdc_ctx* c, const float* ginv, const float* vi
   return MDC_OK;
 }
 
-int mdc_set_remap(mdc_ctx* c, const float* rx, const float* ry, int in_w, int in_h, int out_w, int out_h) {
+int mdc_set_remap(mdc_ctx* c, const float* rx, const float* ry, int in_w, int in_h, int out_w, int out_h) try {
   if (!c) return MDC_ERR_ARG;
   WriteLock lk(c->mu);
   return set_remap_locked(c, rx, ry, in_w, in_h, out_w, out_h);
-}
+} MDC_CATCH(c)
 
 static int set_remap_locked(mdc_ctx* c, const float* rx, const float* ry, int in_w, int in_h, int out_w, int out_h) {
   DeviceGuard dg(c->device);
@@ -1198,33 +1211,33 @@ static int set_remap_locked(mdc_ctx* c, const float* rx, const float* ry, int in
   return MDC_OK;
 }
 
-int mdc_unmap_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, void* stream) {
+int mdc_unmap_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (!d_in || !d_out || nframes < 0) return fail(c, MDC_ERR_ARG, "mdc_unmap_batch_device: bad argument");
   ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   return enqueue_process(c, d_in, d_out, nframes, flags & ~MDC_RECTIFY, (hipStream_t)stream);
-}
+} MDC_CATCH(c)
 
-int mdc_process_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, void* stream) {
+int mdc_process_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (!d_in || !d_out || nframes < 0) return fail(c, MDC_ERR_ARG, "mdc_process_batch_device: bad argument");
   ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   return enqueue_process(c, d_in, d_out, nframes, flags, (hipStream_t)stream);
-}
+} MDC_CATCH(c)
 
-int mdc_undistort_batch_device_f32(mdc_ctx* c, const float* d_in, float* d_out, int64_t nframes, void* stream) {
+int mdc_undistort_batch_device_f32(mdc_ctx* c, const float* d_in, float* d_out, int64_t nframes, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (!d_in || !d_out || nframes < 0) return fail(c, MDC_ERR_ARG, "mdc_undistort_batch_device_f32: bad argument");
   ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   if (!c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
   return enqueue_undistort_f32(c, d_in, d_out, nframes, (hipStream_t)stream);
-}
+} MDC_CATCH(c)
 
 int mdc_pyramid_batch_device(mdc_ctx* c, const float* d_base, int w, int h, int levels, float* const* d_levels,
-                             int64_t nframes, void* stream) {
+                             int64_t nframes, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (!d_base || w <= 0 || h <= 0 || levels < 1 || nframes < 0 || (levels > 1 && !d_levels))
     return fail(c, MDC_ERR_ARG, "mdc_pyramid_batch_device: bad argument");
@@ -1238,10 +1251,10 @@ int mdc_pyramid_batch_device(mdc_ctx* c, const float* d_base, int w, int h, int 
     src = d_levels[l - 1];
   }
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
 int mdc_process_pyramid_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_base, int levels, float* const* d_levels,
-                                     int64_t nframes, unsigned flags, void* stream) {
+                                     int64_t nframes, unsigned flags, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (!d_in || !d_base || nframes < 0 || levels < 1 || (levels > 1 && !d_levels))
     return fail(c, MDC_ERR_ARG, "mdc_process_pyramid_batch_device: bad argument");
@@ -1264,7 +1277,7 @@ int mdc_process_pyramid_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_b
     src = d_levels[l - 1];
   }
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
 // mdc_fov_model -> pixel-unit lens model, operation for operation as src/FOVUndistorter.cpp:289-301
 // (float products, `- 0.5` in double for the input camera, `- 0.5f`-equivalent narrowing for the output one,
@@ -1285,16 +1298,16 @@ static DistortModel distort_model(const mdc_fov_model* f) {
   return m;
 }
 
-int mdc_distort_points_device(mdc_ctx* c, const mdc_fov_model* model, float* d_x, float* d_y, int64_t n, void* stream) {
+int mdc_distort_points_device(mdc_ctx* c, const mdc_fov_model* model, float* d_x, float* d_y, int64_t n, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (!model || n < 0 || (n > 0 && (!d_x || !d_y))) return fail(c, MDC_ERR_ARG, "mdc_distort_points_device: bad argument");
   ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   MDC_HIP(c, launch_distort_points(d_x, d_y, n, distort_model(model), (hipStream_t)stream));
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
-int mdc_distort_points_host(mdc_ctx* c, const mdc_fov_model* model, float* x, float* y, int64_t n) {
+int mdc_distort_points_host(mdc_ctx* c, const mdc_fov_model* model, float* x, float* y, int64_t n) try {
   if (!c) return MDC_ERR_ARG;
   if (!model || n < 0 || (n > 0 && (!x || !y))) return fail(c, MDC_ERR_ARG, "mdc_distort_points_host: bad argument");
   if (n == 0) return MDC_OK;
@@ -1315,10 +1328,10 @@ int mdc_distort_points_host(mdc_ctx* c, const mdc_fov_model* model, float* x, fl
   MDC_HIP(c, hipMemcpyAsync(y, dy, bytes, hipMemcpyDeviceToHost, st));
   MDC_HIP(c, hipStreamSynchronize(st));
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
 int mdc_gradients_batch_device(mdc_ctx* c, const float* d_level, int w, int h, float* d_dI, float* d_abs_squared_grad,
-                               int64_t nframes, void* stream) {
+                               int64_t nframes, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (!d_level || !d_dI || !d_abs_squared_grad || w < 1 || h < 1 || nframes < 0 || (int64_t)w * h >= (1ll << 31))
     return fail(c, MDC_ERR_ARG, "mdc_gradients_batch_device: bad argument");
@@ -1326,11 +1339,11 @@ int mdc_gradients_batch_device(mdc_ctx* c, const float* d_level, int w, int h, f
   DeviceGuard dg(c->device);
   MDC_HIP(c, launch_gradients(d_level, d_dI, d_abs_squared_grad, w, h, nframes, (hipStream_t)stream));
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
 int mdc_process_pyramid_gradients_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_base, int levels, float* const* d_levels,
                                                float* const* d_dI, float* const* d_abs_squared_grad, int64_t nframes, unsigned flags,
-                                               int chunk_frames, void* stream) {
+                                               int chunk_frames, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (!d_in || !d_base || nframes < 0 || levels < 1 || levels > 8 || (levels > 1 && !d_levels) || !d_dI || !d_abs_squared_grad || chunk_frames < 0)
     return fail(c, MDC_ERR_ARG, "mdc_process_pyramid_gradients_batch_device: bad argument");
@@ -1393,11 +1406,11 @@ int mdc_process_pyramid_gradients_batch_device(mdc_ctx* c, const uint8_t* d_in, 
     }
   }
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
 int mdc_vcal_plane_step_device(mdc_ctx* c, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
                                int n_plane, float* d_plane_color, const float* d_vignette_factor, int oth2, float* d_ff,
-                               float* d_fc, double* d_er, void* stream) {
+                               float* d_fc, double* d_er, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (!d_images || !d_p2x || !d_p2y || !d_plane_color || !d_vignette_factor || !d_ff || !d_fc || !d_er || n_images < 0 || w < 2 ||
       h < 2 || n_plane < 0)
@@ -1407,11 +1420,11 @@ int mdc_vcal_plane_step_device(mdc_ctx* c, const float* d_images, const float* d
   MDC_HIP(c, launch_vcal_plane_step(d_images, d_p2x, d_p2y, n_images, w, h, n_plane, d_plane_color, d_vignette_factor, oth2, d_ff,
                                     d_fc, d_er, (hipStream_t)stream));
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
 int mdc_vcal_vignette_step_device(mdc_ctx* c, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w,
                                   int h, int n_plane, const float* d_plane_color, float* d_vignette_factor, int oth2, float* d_tt,
-                                  float* d_ct, double* d_er, void* stream) {
+                                  float* d_ct, double* d_er, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (!d_images || !d_p2x || !d_p2y || !d_plane_color || !d_vignette_factor || !d_tt || !d_ct || !d_er || n_images < 0 || w < 2 ||
       h < 2 || n_plane < 0)
@@ -1421,7 +1434,7 @@ int mdc_vcal_vignette_step_device(mdc_ctx* c, const float* d_images, const float
   MDC_HIP(c, launch_vcal_vignette_step(d_images, d_p2x, d_p2y, n_images, w, h, n_plane, d_plane_color, d_vignette_factor, oth2,
                                        d_tt, d_ct, d_er, c->d_vcal_max + (c->vcal_max_next++ % mdc_ctx::kVcalMaxWords), (hipStream_t)stream));
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
 struct mdc_vcal_index {
   mdc::VcalIndex* ix;
@@ -1429,7 +1442,7 @@ struct mdc_vcal_index {
 };
 
 int mdc_vcal_index_create(mdc_ctx* c, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
-                          int n_plane, void* stream, mdc_vcal_index** out) {
+                          int n_plane, void* stream, mdc_vcal_index** out) try {
   if (!c) return MDC_ERR_ARG;
   if (!out) return fail(c, MDC_ERR_ARG, "mdc_vcal_index_create: out is NULL");
   *out = nullptr;
@@ -1442,7 +1455,7 @@ int mdc_vcal_index_create(mdc_ctx* c, const float* d_images, const float* d_p2x,
   MDC_HIP(c, mdc::vcal_index_build(d_images, d_p2x, d_p2y, n_images, w, h, n_plane, (hipStream_t)stream, &ix));
   *out = new mdc_vcal_index{ix, c->device};
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
 void mdc_vcal_index_destroy(mdc_vcal_index* index) {
   if (!index) return;
@@ -1455,7 +1468,7 @@ int64_t mdc_vcal_index_bytes(const mdc_vcal_index* index) { return index ? mdc::
 int64_t mdc_vcal_index_entries(const mdc_vcal_index* index) { return index ? mdc::vcal_index_entries(index->ix) : 0; }
 
 int mdc_vcal_vignette_step_indexed_device(mdc_ctx* c, const mdc_vcal_index* index, const float* d_plane_color,
-                                          float* d_vignette_factor, int oth2, float* d_tt, float* d_ct, double* d_er, void* stream) {
+                                          float* d_vignette_factor, int oth2, float* d_tt, float* d_ct, double* d_er, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (!index || !d_plane_color || !d_vignette_factor || !d_tt || !d_ct || !d_er)
     return fail(c, MDC_ERR_ARG, "mdc_vcal_vignette_step_indexed_device: bad argument");
@@ -1465,10 +1478,10 @@ int mdc_vcal_vignette_step_indexed_device(mdc_ctx* c, const mdc_vcal_index* inde
   MDC_HIP(c, mdc::launch_vcal_vignette_step_indexed(index->ix, d_plane_color, d_vignette_factor, oth2, d_tt, d_ct, d_er,
                                                     c->d_vcal_max + (c->vcal_max_next++ % mdc_ctx::kVcalMaxWords), (hipStream_t)stream));
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
 int mdc_vcal_scale_images_device(mdc_ctx* c, float* d_images, int n_images, int64_t npix, float mean_exposure,
-                                 const float* d_exposure_times, void* stream) {
+                                 const float* d_exposure_times, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (n_images < 0 || n_images > 65535 || npix < 0 || (n_images > 0 && npix > 0 && (!d_images || !d_exposure_times)))
     return fail(c, MDC_ERR_ARG, "mdc_vcal_scale_images_device: bad argument");
@@ -1476,9 +1489,9 @@ int mdc_vcal_scale_images_device(mdc_ctx* c, float* d_images, int n_images, int6
   DeviceGuard dg(c->device);
   MDC_HIP(c, launch_vcal_scale_images(d_images, n_images, npix, mean_exposure, d_exposure_times, (hipStream_t)stream));
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
-int mdc_vcal_gradient_mask_device(mdc_ctx* c, float* d_images, int n_images, int w, int h, int max_abs_grad, void* stream) {
+int mdc_vcal_gradient_mask_device(mdc_ctx* c, float* d_images, int n_images, int w, int h, int max_abs_grad, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (n_images < 0 || (n_images > 0 && !d_images) || w < 1 || h < 1 || (long long)w * h >= (1ll << 31) || max_abs_grad < 0)
     return fail(c, MDC_ERR_ARG, "mdc_vcal_gradient_mask_device: bad argument");
@@ -1486,19 +1499,19 @@ int mdc_vcal_gradient_mask_device(mdc_ctx* c, float* d_images, int n_images, int
   DeviceGuard dg(c->device);
   MDC_HIP(c, launch_vcal_gradient_mask(d_images, n_images, w, h, max_abs_grad, (hipStream_t)stream));
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
-int mdc_vcal_mask_coords_device(mdc_ctx* c, float* d_x, float* d_y, int64_t n, int w, int h, void* stream) {
+int mdc_vcal_mask_coords_device(mdc_ctx* c, float* d_x, float* d_y, int64_t n, int w, int h, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (n < 0 || (n > 0 && (!d_x || !d_y)) || w < 1 || h < 1) return fail(c, MDC_ERR_ARG, "mdc_vcal_mask_coords_device: bad argument");
   ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   MDC_HIP(c, launch_vcal_mask_coords(d_x, d_y, n, w, h, (hipStream_t)stream));
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
 int mdc_vcal_smooth_device(mdc_ctx* c, const float* d_vignette_factor, int w, int h, float* d_smoothed, float* d_scratch,
-                           void* stream) {
+                           void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (!d_vignette_factor || !d_smoothed || !d_scratch || w < 1 || h < 1 || (long long)w * h >= (1ll << 31) ||
       d_smoothed == d_scratch || d_vignette_factor == d_scratch)
@@ -1507,11 +1520,11 @@ int mdc_vcal_smooth_device(mdc_ctx* c, const float* d_vignette_factor, int w, in
   DeviceGuard dg(c->device);
   MDC_HIP(c, launch_vcal_smooth(d_vignette_factor, w, h, d_smoothed, d_scratch, (hipStream_t)stream));
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
 int mdc_vcal_solve_device(mdc_ctx* c, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
                           int n_plane, float* d_plane_color, float* d_vignette_factor, int max_iterations, int outlier_th,
-                          double* er_out, void* stream) {
+                          double* er_out, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (!d_plane_color || !d_vignette_factor || max_iterations < 0 || outlier_th < 0 || outlier_th > 46340)
     return fail(c, MDC_ERR_ARG, "mdc_vcal_solve_device: bad argument");
@@ -1552,13 +1565,13 @@ int mdc_vcal_solve_device(mdc_ctx* c, const float* d_images, const float* d_p2x,
   if (er_out) MDC_SOLVE(hipMemcpyAsync(er_out, d_er, er_bytes, hipMemcpyDeviceToHost, s));
 #undef MDC_SOLVE
   return done(MDC_OK);
-}
+} MDC_CATCH(c)
 
 // Plan selection by measurement (as FFT / BLAS libraries do): which tile shape and workgroup length is fastest depends on
 // the remap (window sizes) and, by a few per cent, on the individual GPU.  Runs the fused pass over the caller's
 // batch with every candidate, keeps the fastest as the context's plan.
 int mdc_tune_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, void* stream,
-                    mdc_tune_result* result) {
+                    mdc_tune_result* result) try {
   if (!c) return MDC_ERR_ARG;
   if (!d_in || !d_out || nframes <= 0) return fail(c, MDC_ERR_ARG, "mdc_tune_device: bad argument");
   WriteLock lk(c->mu);
@@ -1625,9 +1638,9 @@ int mdc_tune_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
     result->candidates = tried;
   }
   return rc;
-}
+} MDC_CATCH(c)
 
-int mdc_describe_launch(mdc_ctx* c, unsigned flags, int pyramid_levels, char* buf, size_t cap) {
+int mdc_describe_launch(mdc_ctx* c, unsigned flags, int pyramid_levels, char* buf, size_t cap) try {
   if (!c || !buf || cap == 0) return MDC_ERR_ARG;
   ReadLock lk(c->mu);
   bool g, v, o;
@@ -1654,9 +1667,9 @@ int mdc_describe_launch(mdc_ctx* c, unsigned flags, int pyramid_levels, char* bu
   if (strlen(tmp) + 1 > cap) return fail(c, MDC_ERR_ARG, "mdc_describe_launch: buffer too small");
   memcpy(buf, tmp, strlen(tmp) + 1);
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
-int mdc_synchronize(mdc_ctx* c) {
+int mdc_synchronize(mdc_ctx* c) try {
   if (!c) return MDC_ERR_ARG;
   ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
@@ -1669,11 +1682,11 @@ int mdc_synchronize(mdc_ctx* c) {
     if (c->pipe_stream[k]) streams.push_back(c->pipe_stream[k]);
   for (hipStream_t st : streams) MDC_HIP(c, hipStreamSynchronize(st));
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
 // ---- host-pointer single-frame calls ---------------------------------------------
 
-int mdc_unmap_host(mdc_ctx* c, const uint8_t* in, float* out, int n, unsigned flags) {
+int mdc_unmap_host(mdc_ctx* c, const uint8_t* in, float* out, int n, unsigned flags) try {
   if (!c) return MDC_ERR_ARG;
   if (!in || !out || n < 0) return fail(c, MDC_ERR_ARG, "mdc_unmap_host: bad argument");
   ReadLock lk(c->mu);
@@ -1699,7 +1712,7 @@ int mdc_unmap_host(mdc_ctx* c, const uint8_t* in, float* out, int n, unsigned fl
   if (!z_out) MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
   MDC_HIP(c, hipStreamSynchronize(st));
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
 static int undistort_host(mdc_ctx* c, const void* in, bool is_f32, float* out, int n_in, int n_out) {
   if (!c) return MDC_ERR_ARG;
@@ -1736,14 +1749,14 @@ static int undistort_host(mdc_ctx* c, const void* in, bool is_f32, float* out, i
   return MDC_OK;
 }
 
-int mdc_undistort_host_f32(mdc_ctx* c, const float* in, float* out, int n_in, int n_out) {
+int mdc_undistort_host_f32(mdc_ctx* c, const float* in, float* out, int n_in, int n_out) try {
   return undistort_host(c, in, true, out, n_in, n_out);
-}
-int mdc_undistort_host_u8(mdc_ctx* c, const uint8_t* in, float* out, int n_in, int n_out) {
+} MDC_CATCH(c)
+int mdc_undistort_host_u8(mdc_ctx* c, const uint8_t* in, float* out, int n_in, int n_out) try {
   return undistort_host(c, in, false, out, n_in, n_out);
-}
+} MDC_CATCH(c)
 
-int mdc_process_host(mdc_ctx* c, const uint8_t* raw, float* out, unsigned flags) {
+int mdc_process_host(mdc_ctx* c, const uint8_t* raw, float* out, unsigned flags) try {
   if (!c) return MDC_ERR_ARG;
   if (!raw || !out) return fail(c, MDC_ERR_ARG, "mdc_process_host: NULL buffer");
   ReadLock lk(c->mu);
@@ -1770,7 +1783,7 @@ int mdc_process_host(mdc_ctx* c, const uint8_t* raw, float* out, unsigned flags)
   if (!z_out) MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, st));
   MDC_HIP(c, hipStreamSynchronize(st));
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
 // ---- host-pointer, many frames: copies and kernels overlapped ------------------------------
 
@@ -1980,43 +1993,43 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
   return MDC_OK;
 }
 
-int mdc_process_frames_host(mdc_ctx* c, const uint8_t* const* raw, float* const* out, int64_t nframes, unsigned flags) {
+int mdc_process_frames_host(mdc_ctx* c, const uint8_t* const* raw, float* const* out, int64_t nframes, unsigned flags) try {
   return process_frames_pipeline(c, raw, nullptr, 0, 0, 0, out, nframes, flags, "mdc_process_frames_host");
-}
+} MDC_CATCH(c)
 
 int mdc_process_jpeg_frames_host(mdc_ctx* c, const void* const* records, int64_t record_bytes, int blocks_w, int blocks_rows,
-                                 float* const* out, int64_t nframes, unsigned flags) {
+                                 float* const* out, int64_t nframes, unsigned flags) try {
   return process_frames_pipeline(c, nullptr, records, record_bytes, blocks_w, blocks_rows, out, nframes, flags, "mdc_process_jpeg_frames_host");
-}
+} MDC_CATCH(c)
 
 int mdc_process_jpeg_streams_host(mdc_ctx* c, const void* const* streams, const int64_t* stream_bytes, float* const* out, int64_t nframes,
-                                  unsigned flags, int* status) {
+                                  unsigned flags, int* status) try {
   return process_frames_pipeline(c, nullptr, nullptr, 0, 0, 0, out, nframes, flags, "mdc_process_jpeg_streams_host", streams, stream_bytes, status);
-}
+} MDC_CATCH(c)
 
 int mdc_jpeg_huffman_batch_device(mdc_ctx* c, const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w, int h,
-                                  int blocks_w, int blocks_rows, int64_t nframes, int* d_status, void* stream) {
+                                  int blocks_w, int blocks_rows, int64_t nframes, int* d_status, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (!d_streams || !d_records || !d_status || nframes < 0 || w <= 0 || h <= 0) return fail(c, MDC_ERR_ARG, "mdc_jpeg_huffman_batch_device: bad argument");
   ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   MDC_HIP(c, launch_jpeg_huffman(d_streams, stream_stride, d_records, record_bytes, w, h, blocks_w, blocks_rows, nframes, d_status, (hipStream_t)stream));
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
 int mdc_jpeg_idct_batch_device(mdc_ctx* c, const void* d_records, int64_t record_bytes, uint8_t* d_frames, int w, int h, int blocks_w,
-                               int blocks_rows, int64_t nframes, void* stream) {
+                               int blocks_rows, int64_t nframes, void* stream) try {
   if (!c) return MDC_ERR_ARG;
   if (!d_records || !d_frames || nframes < 0 || w <= 0 || h <= 0) return fail(c, MDC_ERR_ARG, "mdc_jpeg_idct_batch_device: bad argument");
   ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   MDC_HIP(c, launch_jpeg_idct(d_records, record_bytes, d_frames, w, h, blocks_w, blocks_rows, nframes, (hipStream_t)stream));
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
 // ---- table hand-over ------------------------------------------------------------------
 
-int mdc_export_tables(mdc_ctx* c, void* blob, size_t cap, size_t* size) {
+int mdc_export_tables(mdc_ctx* c, void* blob, size_t cap, size_t* size) try {
   if (!c || !size) return MDC_ERR_ARG;
   ReadLock lk(c->mu);
   const size_t nv = c->valid_vignette ? c->h_vinv.size() : 0;
@@ -2041,9 +2054,9 @@ int mdc_export_tables(mdc_ctx* c, void* blob, size_t cap, size_t* size) {
     memcpy(p, c->h_ry.data(), nr * 4);
   }
   return MDC_OK;
-}
+} MDC_CATCH(c)
 
-int mdc_import_tables(mdc_ctx* c, const void* blob, size_t size) {
+int mdc_import_tables(mdc_ctx* c, const void* blob, size_t size) try {
   if (!c || !blob) return MDC_ERR_ARG;
   BlobHeader h;
   if (size < sizeof h) return fail(c, MDC_ERR_ARG, "table blob truncated");
@@ -2080,6 +2093,6 @@ int mdc_import_tables(mdc_ctx* c, const void* blob, size_t size) {
   if (h.valid_remap) rc = set_remap_locked(c, rx, ry, h.rm_in_w, h.rm_in_h, h.out_w, h.out_h);
   else rc = set_remap_locked(c, nullptr, nullptr, 0, 0, 0, 0);
   return rc;
-}
+} MDC_CATCH(c)
 
 }  // extern "C"
