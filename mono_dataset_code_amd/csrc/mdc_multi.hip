@@ -95,7 +95,7 @@ int per_device(mdc_multi* m, F fn) {
 
 extern "C" {
 
-int mdc_multi_create(const int* devices, int ndev, mdc_multi** out) {
+int mdc_multi_create(const int* devices, int ndev, mdc_multi** out) try {
   if (!out) return fail(nullptr, MDC_ERR_ARG, "mdc_multi_create: out is NULL");
   *out = nullptr;
   int visible = 0;
@@ -144,6 +144,10 @@ int mdc_multi_create(const int* devices, int ndev, mdc_multi** out) {
   }
   *out = m;
   return MDC_OK;
+} catch (const std::exception& e_) {
+  return fail(nullptr, MDC_ERR_NOMEM, "mdc_multi_create: %s", e_.what());
+} catch (...) {
+  return fail(nullptr, MDC_ERR_HIP, "mdc_multi_create: unexpected exception");
 }
 
 void mdc_multi_destroy(mdc_multi* m) {
@@ -169,17 +173,21 @@ void mdc_multi_destroy(mdc_multi* m) {
 }
 
 int mdc_multi_size(const mdc_multi* m) { return m ? (int)m->dev.size() : 0; }
-int mdc_multi_comm_count(const mdc_multi* m, int rank) {
+int mdc_multi_comm_count(const mdc_multi* m, int rank) try {
   if (!m || rank < 0 || rank >= (int)m->comm.size()) return -1;
   int n = -1;
   return ncclCommCount(m->comm[(size_t)rank], &n) == ncclSuccess ? n : -1;
+} catch (const std::exception& e_) {
+  return fail(nullptr, MDC_ERR_NOMEM, "mdc_multi_comm_count: %s", e_.what());
+} catch (...) {
+  return fail(nullptr, MDC_ERR_HIP, "mdc_multi_comm_count: unexpected exception");
 }
 void* mdc_multi_stream(mdc_multi* m, int rank) { return (m && rank >= 0 && rank < (int)m->stream.size()) ? (void*)m->stream[(size_t)rank] : nullptr; }
 mdc_ctx* mdc_multi_ctx(mdc_multi* m, int rank) { return (m && rank >= 0 && rank < (int)m->ctx.size()) ? m->ctx[(size_t)rank] : nullptr; }
 int mdc_multi_device(const mdc_multi* m, int rank) { return (m && rank >= 0 && rank < (int)m->dev.size()) ? m->dev[(size_t)rank] : -1; }
 const char* mdc_multi_last_error(const mdc_multi* m) { return m ? m->err.c_str() : g_err.c_str(); }
 
-int mdc_multi_bcast_tables(mdc_multi* m, int root) {
+int mdc_multi_bcast_tables(mdc_multi* m, int root) try {
   if (!m) return MDC_ERR_ARG;
   std::lock_guard<std::mutex> call(m->call_mu);
   const int n = (int)m->dev.size();
@@ -233,6 +241,10 @@ int mdc_multi_bcast_tables(mdc_multi* m, int root) {
   cleanup();
   if (rc != MDC_OK) return fail(m, rc, "import of the broadcast tables failed on a rank");
   return MDC_OK;
+} catch (const std::exception& e_) {
+  return fail(m, MDC_ERR_NOMEM, "mdc_multi_bcast_tables: %s", e_.what());
+} catch (...) {
+  return fail(m, MDC_ERR_HIP, "mdc_multi_bcast_tables: unexpected exception");
 }
 
 int64_t mdc_multi_frames_of_rank(const mdc_multi* m, int64_t total, int rank) {
@@ -242,7 +254,7 @@ int64_t mdc_multi_frames_of_rank(const mdc_multi* m, int64_t total, int rank) {
 }
 
 int mdc_multi_process_sequence_device(mdc_multi* m, const uint8_t* const* d_in, float* const* d_out, int64_t total,
-                                      unsigned flags) {
+                                      unsigned flags) try {
   if (!m || !d_in || !d_out || total < 0) return fail(m, MDC_ERR_ARG, "mdc_multi_process_sequence_device: bad argument");
   std::lock_guard<std::mutex> call(m->call_mu);
   const int rc = per_device(m, [&](int r) {
@@ -254,15 +266,23 @@ int mdc_multi_process_sequence_device(mdc_multi* m, const uint8_t* const* d_in, 
   });
   if (rc != MDC_OK) return fail(m, rc, "a rank failed to launch its shard");
   return MDC_OK;
+} catch (const std::exception& e_) {
+  return fail(m, MDC_ERR_NOMEM, "mdc_multi_process_sequence_device: %s", e_.what());
+} catch (...) {
+  return fail(m, MDC_ERR_HIP, "mdc_multi_process_sequence_device: unexpected exception");
 }
 
-int mdc_multi_synchronize(mdc_multi* m) {
+int mdc_multi_synchronize(mdc_multi* m) try {
   if (!m) return MDC_ERR_ARG;
   for (size_t r = 0; r < m->dev.size(); r++) {
     (void)hipSetDevice(m->dev[r]);
     if (hipStreamSynchronize(m->stream[r]) != hipSuccess) return fail(m, MDC_ERR_HIP, "stream of rank %zu failed", r);
   }
   return MDC_OK;
+} catch (const std::exception& e_) {
+  return fail(m, MDC_ERR_NOMEM, "mdc_multi_synchronize: %s", e_.what());
+} catch (...) {
+  return fail(m, MDC_ERR_HIP, "mdc_multi_synchronize: unexpected exception");
 }
 
 }  // extern "C"
