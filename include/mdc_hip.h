@@ -216,7 +216,7 @@ int mdc_jpeg_idct_batch_device(mdc_ctx* ctx, const void* d_records, int64_t reco
 #define MDC_JPEG_STREAM_MAGIC 0x31534a4du /* "MJS1" */
 typedef struct mdc_jpeg_huff {
   uint16_t look[512];  /* codes of <= 9 bits, indexed by the next 9 bits: length << 8 | symbol; 0 = longer code */
-  int16_t fast[512];   /* AC table: a 9-bit window holding code + magnitude bits: value << 8 | run << 4 | bits used; 0 = no */
+  int16_t fast[2048];  /* AC table: an 11-bit window holding code + magnitude bits: value << 8 | run << 4 | bits used; 0 = no */
   int32_t maxcode[18]; /* [l], l = 1..16: largest code of length l or -1; [17] = INT_MAX */
   int32_t valoff[18];  /* [l]: index into vals of the first code of length l, minus that code */
   uint8_t vals[256];
@@ -226,7 +226,7 @@ typedef struct mdc_jpeg_stream_header {
   uint32_t reserved[4];
   uint16_t quant[64]; /* natural order */
   mdc_jpeg_huff dc, ac;
-} mdc_jpeg_stream_header; /* 5056 bytes */
+} mdc_jpeg_stream_header; /* 11200 bytes */
 int mdc_process_jpeg_streams_host(mdc_ctx* ctx, const void* const* streams, const int64_t* stream_bytes, float* const* out, int64_t nframes,
                                   unsigned flags, int* status);
 int mdc_jpeg_huffman_batch_device(mdc_ctx* ctx, const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w,

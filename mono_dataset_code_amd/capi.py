@@ -737,7 +737,7 @@ def decode_jpeg_record(data, record, pitch_blocks):
     return tuple(int(x) for x in dims)
 
 
-JPEG_STREAM_HEADER_BYTES = 5056
+JPEG_STREAM_HEADER_BYTES = 11200
 
 
 def jpeg_stream(data, stream):

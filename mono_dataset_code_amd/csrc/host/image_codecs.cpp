@@ -628,7 +628,34 @@ bool jpeg_stream(const unsigned char* d, size_t n, unsigned char* stream, size_t
       mdc_jpeg_huff* dst[2] = {&hd->dc, &hd->ac};
       for (int k = 0; k < 2; k++) {
         memcpy(dst[k]->look, src[k]->look, sizeof dst[k]->look);
-        if (k) memcpy(dst[k]->fast, src[k]->fast_ac, sizeof dst[k]->fast);
+        if (k) {  // AC: code + magnitude bits in one lookup of the next 11 bits (values that fit 8 bits)
+          for (int wnd = 0; wnd < 2048; wnd++) {
+            int len = 0, sym = -1;
+            const int e = src[k]->look[wnd >> 2];
+            if (e) {
+              len = e >> 8;
+              sym = e & 255;
+            } else {
+              for (int l = 10; l <= 11 && sym < 0; l++) {
+                const int code = wnd >> (11 - l);
+                if (code <= src[k]->maxcode[l]) {
+                  const int idx = code + src[k]->valoff[l];
+                  if (idx >= 0 && idx < 256) {
+                    len = l;
+                    sym = src[k]->vals[idx];
+                  }
+                }
+              }
+            }
+            dst[k]->fast[wnd] = 0;
+            if (sym < 0) continue;
+            const int run = sym >> 4, sz = sym & 15;
+            if (sz == 0 || len + sz > 11) continue;
+            int v = (wnd >> (11 - len - sz)) & ((1 << sz) - 1);
+            if (v < (1 << (sz - 1))) v += (int)((~0u) << sz) + 1;  // EXTEND
+            if (v >= -128 && v <= 127) dst[k]->fast[wnd] = (int16_t)(v * 256 + run * 16 + (len + sz));
+          }
+        }
         for (int l = 0; l < 18; l++) dst[k]->maxcode[l] = l >= 1 ? src[k]->maxcode[l] : -1;
         for (int l = 0; l < 18; l++) dst[k]->valoff[l] = (l >= 1 && l <= 16) ? src[k]->valoff[l] : 0;
         memcpy(dst[k]->vals, src[k]->vals, 256);

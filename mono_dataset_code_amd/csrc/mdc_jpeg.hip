@@ -155,7 +155,7 @@ __device__ __constant__ unsigned char c_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,
 
 struct HuffLds {  // a table as the kernel uses it (copied from mdc_jpeg_huff)
   uint16_t look[512];
-  int16_t fast[512];
+  int16_t fast[2048];
   int maxcode[18];
   int valoff[18];
   unsigned char vals[256];
@@ -242,7 +242,7 @@ __device__ __forceinline__ void huff_run(BitReader& b, const HuffLds& dc, const 
       if (WRITE && cur) cur[0] = (int16_t)diff;
       z = 1;
     } else {
-      const int fa = ac.fast[b.peek(9)];
+      const int fa = ac.fast[b.peek(11)];
       if (fa) {  // code + magnitude bits in one lookup
         z += (fa >> 4) & 15;
         b.skip(fa & 15);

@@ -17,6 +17,7 @@
 #include "PhotometricUndistorter.h"
 #include "image_codecs.h"
 #include "image_codecs_internal.h"
+#include "mdc_hip.h"
 #include "mdc_host.h"
 #include "zip_reader.h"
 
@@ -34,6 +35,7 @@ int main(int argc, char** argv) {
   if (argc < 2) return 2;
   const std::string root = argv[1];
   long decoded = 0, refused = 0, streams_built = 0;
+  const size_t kHdr = sizeof(mdc_jpeg_stream_header);
 
   // 1. every file under images_any/ through the decoders, whole and truncated at many lengths
   for (const std::string& f : list(root + "/images_any")) {
@@ -52,11 +54,11 @@ int main(int argc, char** argv) {
       mdc_host::decode_gray8(part.data(), part.size(), tiny.data(), tiny.size(), &w, &h, &err);
       // the stream builder of the device Huffman stage: exact-size stream buffers of several capacities (the copy of the
       // entropy-coded bytes must stop at the capacity), and the coefficient-record decoder
-      for (size_t cap : {part.size() + 5056 + 64, (size_t)5056 + 40, (size_t)5056 + 16, (size_t)5000, (size_t)64}) {
+      for (size_t cap : {part.size() + kHdr + 64, kHdr + 40, kHdr + 16, kHdr - 56, (size_t)64}) {
         std::vector<uint32_t> stream((cap + 3) / 4);
         size_t used = 0;
         if (mdc_host::jpeg_stream(part.data(), part.size(), reinterpret_cast<unsigned char*>(stream.data()), cap, &used, &w, &h, &err)) {
-          if (used > cap || used < 5056 + 17) return 9;
+          if (used > cap || used < kHdr + 17) return 9;
           streams_built++;
         }
       }
@@ -68,7 +70,7 @@ int main(int argc, char** argv) {
       int w = 0, h = 0;
       std::string err;
       mdc_host::decode_gray8(bad.data(), bad.size(), out.data(), out.size(), &w, &h, &err);
-      std::vector<uint32_t> stream((bad.size() + 5056 + 64) / 4);
+      std::vector<uint32_t> stream((bad.size() + kHdr + 64) / 4);
       size_t used = 0;
       mdc_host::jpeg_stream(bad.data(), bad.size(), reinterpret_cast<unsigned char*>(stream.data()), stream.size() * 4, &used, &w, &h, &err);
     }

@@ -241,9 +241,11 @@ def test_gpu_huffman_stage_equals_the_host_decoder(size):
     assert s2[1] == 2 and s2[0] in (0, 1)  # (flipped bits may still parse as SOME valid stream of the right length: then 0)
     # tables no JPEG file produces -- every entry a code of length 0 -- must end in a status, not in an endless loop
     hostile = streams[:1].copy()
-    hostile[0, 160:160 + 1024].view(np.uint16)[:] = 0x0005      # dc.look: length 0, symbol 5
-    hostile[0, 2608:2608 + 1024].view(np.uint16)[:] = 0x0011    # ac.look: length 0, run 1 size 1
-    hostile[0, 3632:3632 + 1024].view(np.int16)[:] = 0x0110     # ac.fast: value 1, run 1, 0 bits
+    huff = 1024 + 4096 + 72 + 72 + 256  # sizeof(mdc_jpeg_huff): look, fast, maxcode, valoff, vals
+    assert capi.JPEG_STREAM_HEADER_BYTES == 160 + 2 * huff
+    hostile[0, 160:160 + 1024].view(np.uint16)[:] = 0x0005                        # dc.look: length 0, symbol 5
+    hostile[0, 160 + huff:160 + huff + 1024].view(np.uint16)[:] = 0x0011          # ac.look: length 0, run 1 size 1
+    hostile[0, 160 + huff + 1024:160 + huff + 1024 + 4096].view(np.int16)[:] = 0x0110  # ac.fast: value 1, run 1, 0 bits
     d_h = torch.from_numpy(hostile).cuda()
     ctx.jpeg_huffman_batch(d_h.data_ptr(), cap, d_rec.data_ptr(), rec_bytes, w, h, pitch, rows, 1, d_status.data_ptr(), st)
     torch.cuda.synchronize()
