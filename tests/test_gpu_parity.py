@@ -296,7 +296,7 @@ def test_tune_keeps_results_and_picks_a_plan(setups, oracle, torch_cuda):
     s.ctx.synth_frames(d_in.data_ptr(), 500, n, npix, synth.SEED, st)
     d_out = torch.full((n, nout), -7.0, dtype=torch.float32, device="cuda")
     r = s.ctx.tune(d_in.data_ptr(), d_out.data_ptr(), n, 15, st)
-    assert r.candidates == 6 and (r.tile_w, r.tile_h) in ((128, 16), (64, 32), (128, 32)) and r.frames_per_block in (32, 64) and r.ms > 0
+    assert r.candidates == 12 and (r.tile_w, r.tile_h) in ((128, 16), (64, 32), (128, 32)) and r.frames_per_block in (32, 64, 96, 128) and r.ms > 0
     info = s.ctx.info()
     assert info.tiled and (info.tile_w, info.tile_h) == (r.tile_w, r.tile_h)
     frames = d_in.view(n, npix).cpu().numpy()
