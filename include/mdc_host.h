@@ -75,6 +75,7 @@ int mdch_reader_get_images(mdch_reader*, int first, int count, int rectify, int 
 int mdch_reader_get_raw(mdch_reader*, int id, unsigned char* out, long cap, int wh[2]); /* getImageRaw(); 1 / 0 */
 void mdch_reader_set_threads(mdch_reader*, int n);       /* setDecodeThreads() */
 void mdch_reader_set_prefetch(mdch_reader*, int frames); /* setPrefetch() */
+void mdch_reader_set_lookahead(mdch_reader*, int frames); /* setResultLookahead(): getImage results made ahead on JPEG sequences read in order */
 void mdch_reader_set_gpu_jpeg(mdch_reader*, int stage);   /* setGpuJpegStage(): 0 host, 1 device inverse DCT, 2 (or any other) device Huffman too */
 const char* mdch_reader_last_error(mdch_reader*);
 void mdch_reader_prefetch_stats(mdch_reader*, long hits_misses[2]); /* getPrefetchStats() */

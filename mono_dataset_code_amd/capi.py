@@ -46,7 +46,7 @@ HOST_SYMBOLS = [
     "mdch_photo_g", "mdch_photo_vignette", "mdch_photo_unmap", "mdch_bind", "mdch_pack_tables",
     "mdch_reader_create", "mdch_reader_destroy", "mdch_reader_num_images", "mdch_reader_timestamp", "mdch_reader_exposure",
     "mdch_reader_dims", "mdch_reader_get_image", "mdch_reader_get_images", "mdch_reader_get_raw", "mdch_reader_set_threads",
-    "mdch_reader_set_prefetch", "mdch_reader_set_gpu_jpeg", "mdch_reader_last_error", "mdch_reader_prefetch_stats", "mdch_decode_gray8", "mdch_jpeg_record_bytes",
+    "mdch_reader_set_prefetch", "mdch_reader_set_gpu_jpeg", "mdch_reader_set_lookahead", "mdch_reader_last_error", "mdch_reader_prefetch_stats", "mdch_decode_gray8", "mdch_jpeg_record_bytes",
     "mdch_decode_jpeg_record", "mdch_jpeg_stream", "mdch_image_alloc", "mdch_image_free",
     "mdch_image_pool_trim", "mdch_image_pool_idle_bytes",
 ]
@@ -252,6 +252,7 @@ def host_lib():
         L.mdch_reader_set_threads.restype = None
         L.mdch_reader_set_prefetch.argtypes = [_vp, _i]
         L.mdch_reader_set_gpu_jpeg.argtypes = [_vp, _i]
+        L.mdch_reader_set_lookahead.argtypes = [_vp, _i]
         L.mdch_reader_set_prefetch.restype = None
         L.mdch_reader_last_error.argtypes = [_vp]
         L.mdch_reader_last_error.restype = C.c_char_p
@@ -794,6 +795,9 @@ class DatasetReader:
 
     def set_prefetch(self, n):
         self._L.mdch_reader_set_prefetch(self._h, n)
+
+    def set_lookahead(self, frames):
+        self._L.mdch_reader_set_lookahead(self._h, int(frames))
 
     def set_gpu_jpeg(self, stage):
         """True / 2: Huffman decoding + inverse DCT on the GPU; 1: inverse DCT only; False / 0: JPEG decoded on the host."""

@@ -12,6 +12,7 @@
 #include <exception>
 #include <dirent.h>
 #include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -109,7 +110,7 @@ struct DatasetReader::State {
   // ring of getImages: chunks of 32 (64 in JPEG stage 2) page-locked frame buffers, 256 in all.  Chunk k is on the GPU while
   // the pool decodes chunks k+1 .. (up to 192 frames in flight): a decode thread that is slow on one frame delays only the
   // chunk that frame is in, not the pipeline (two half-rings of 64 stalled on every straggler: 2.5-2.9 k frames/s)
-  static const int kRingFrames = 256;  // page-locked decode buffers of getImages (335 MB at 1280x1024, 670 MB in stage 1; first getImages)
+  enum { kRingFrames = 256 };  // page-locked decode buffers of getImages (335 MB at 1280x1024, 670 MB in stage 1; first getImages)
   HostBuffer ring_block;               // ONE page-locked block: slot i at ring_block.p + i * ring_stride (a chunk's uploads are
   size_t ring_stride = 0;              // then one strided copy instead of one copy per frame)
   int ring_slots = 0;
@@ -118,6 +119,26 @@ struct DatasetReader::State {
   // GPU JPEG stage of getImages: JPEG frames travel as coefficient records (2 bytes per pixel + table), the inverse DCT runs on
   // the device.  Default on; MDC_GPU_JPEG=0 or setGpuJpeg(false) keeps the whole decode on the host.
   int gpu_jpeg = 2;  // 0: JPEG decoded on the host; 1: host Huffman + device inverse DCT; 2: device Huffman + inverse DCT
+  // getImage on a JPEG sequence read in order: after two consecutive ids the next `lookahead` frames go through the getImages
+  // pipeline (Huffman decoding on the device) with the caller's switches, and the following calls hand those results out
+  int lookahead = 64;
+  std::vector<ExposureImage*> ahead;
+  int ahead_first = -1;
+  unsigned ahead_flags = 0;
+  int seq_last = -2, seq_run = 0;
+  void drop_ahead() {
+    for (ExposureImage* e : ahead) delete e;
+    ahead.clear();
+    ahead_first = -1;
+  }
+  bool is_jpeg_name(size_t id) const {
+    const std::string& f = files[id];
+    const size_t dot = f.rfind('.');
+    if (dot == std::string::npos) return false;
+    std::string ext = f.substr(dot + 1);
+    for (char& ch : ext) ch = (char)std::tolower((unsigned char)ch);
+    return ext == "jpg" || ext == "jpeg";
+  }
   int rec_pitch = 0, rec_rows = 0;
   size_t rec_bytes = 0;
   size_t ring_bytes = 0;  // bytes of one ring buffer (a frame, or a record when the GPU JPEG stage is on)
@@ -357,6 +378,7 @@ void list_folder(const std::string& dir, std::vector<std::string>& files) {
 
 DatasetReader::DatasetReader(std::string folder) : s_(new State()) {
   if (const char* e = std::getenv("MDC_GPU_JPEG")) s_->gpu_jpeg = std::max(0, std::min(2, std::atoi(e)));
+  if (const char* e = std::getenv("MDC_READER_LOOKAHEAD")) s_->lookahead = std::max(0, std::min((int)State::kRingFrames, std::atoi(e)));
   State& s = *s_;
   s.path = folder;
   list_folder(s.path + "images/", s.files);
@@ -430,6 +452,7 @@ DatasetReader::~DatasetReader() {
   State& s = *s_;
   s.stop_pool();
   for (auto& m : s.slot_mem) m.release();
+  s.drop_ahead();
   s.ring_block.release();
   if (s.gpu) mdc_destroy(s.gpu);
   delete s.fov;
@@ -457,6 +480,10 @@ void DatasetReader::setDecodeThreads(int n) {
   s.want_threads = n;
 }
 
+void DatasetReader::setResultLookahead(int frames) {
+  s_->lookahead = std::max(0, std::min(frames, (int)State::kRingFrames));
+  if (!s_->lookahead) s_->drop_ahead();
+}
 void DatasetReader::setGpuJpeg(bool on) { s_->gpu_jpeg = on ? 2 : 0; }
 void DatasetReader::setGpuJpegStage(int stage) { s_->gpu_jpeg = std::max(0, std::min(2, stage)); }
 
@@ -484,6 +511,37 @@ const unsigned char* DatasetReader::getImageRaw(int id, int* width, int* height)
 
 ExposureImage* DatasetReader::getImage(int id, bool rectify, bool removeGamma, bool removeVignette, bool nanOverexposed) {
   State& s = *s_;
+  if (id >= 0 && id < (int)s.files.size() && s.gpu && s.lookahead > 0 && s.gpu_jpeg >= 2) {
+    const unsigned flags = flag_word(rectify, removeGamma, removeVignette, nanOverexposed);
+    if (!s.ahead.empty()) {  // results made ahead: hand this one out, or drop them when the caller went elsewhere
+      const int k = id - s.ahead_first;
+      if (flags == s.ahead_flags && k >= 0 && k < (int)s.ahead.size() && s.ahead[(size_t)k]) {
+        ExposureImage* ret = s.ahead[(size_t)k];
+        s.ahead[(size_t)k] = 0;
+        if (k + 1 == (int)s.ahead.size()) s.drop_ahead();
+        s.seq_run = id == s.seq_last + 1 ? s.seq_run + 1 : 0;
+        s.seq_last = id;
+        return ret;
+      }
+      if (flags != s.ahead_flags || k < 0 || k >= (int)s.ahead.size()) s.drop_ahead();
+    }
+    s.seq_run = id == s.seq_last + 1 ? s.seq_run + 1 : 0;
+    s.seq_last = id;
+    if (s.ahead.empty() && s.seq_run >= 2 && s.is_jpeg_name((size_t)id)) {
+      const int n = std::min(s.lookahead, (int)s.files.size() - id);
+      s.ahead.assign((size_t)n, (ExposureImage*)0);
+      getImages(id, n, rectify, removeGamma, removeVignette, nanOverexposed, s.ahead.data());
+      s.ahead_first = id;
+      s.ahead_flags = flags;
+      if (s.ahead[0]) {
+        ExposureImage* ret = s.ahead[0];
+        s.ahead[0] = 0;
+        if (n == 1) s.drop_ahead();
+        return ret;
+      }
+      // (this frame failed in the batch: the single-frame path below says why, as the reference would)
+    }
+  }
   int fw = 0, fh = 0;
   const unsigned char* raw = getImageRaw(id, &fw, &fh);
   if (id < 0 || id >= (int)s.files.size()) return 0;

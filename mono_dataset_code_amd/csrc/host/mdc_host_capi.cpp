@@ -268,6 +268,7 @@ int mdch_reader_get_raw(mdch_reader* h, int id, unsigned char* out, long cap, in
 } catch (...) { return {}; }  // no exception leaves the C facade
 void mdch_reader_set_threads(mdch_reader* h, int n) try { h->r->setDecodeThreads(n); } catch (...) {}
 void mdch_reader_set_prefetch(mdch_reader* h, int n) try { h->r->setPrefetch(n); } catch (...) {}
+void mdch_reader_set_lookahead(mdch_reader* h, int frames) try { h->r->setResultLookahead(frames); } catch (...) {}
 void mdch_reader_set_gpu_jpeg(mdch_reader* h, int stage) try { h->r->setGpuJpegStage(stage == 1 ? 1 : (stage ? 2 : 0)); } catch (...) {}
 const char* mdch_reader_last_error(mdch_reader* h) try { return h->r->lastError(); } catch (...) { return {}; }
 void mdch_reader_prefetch_stats(mdch_reader* h, long hm[2]) try { h->r->getPrefetchStats(&hm[0], &hm[1]); } catch (...) {}

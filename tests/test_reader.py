@@ -311,6 +311,32 @@ def test_gpu_huffman_stage_random_files():
     assert checked == 300
 
 
+def test_get_image_results_made_ahead_on_jpeg_sequences(tmp_path):
+    """getImage on a JPEG sequence read in order: from the third consecutive id on the next frames come out of one pass of the
+    getImages pipeline (setResultLookahead).  Every image -- made ahead or not, across batch borders, after a change of the
+    switches, after a jump backwards, at the end of the sequence -- equals the one the reader gives with the lookahead off,
+    metadata included."""
+    from mono_dataset_code_amd import capi
+
+    h, w = 96, 160
+    frames = frames_for(23, h, w)
+    make_sequence(str(tmp_path), frames, True, "jpg")
+    ref = capi.DatasetReader(str(tmp_path))
+    ref.set_lookahead(0)
+    r = capi.DatasetReader(str(tmp_path))
+    r.set_lookahead(5)
+    walk = [(i, (1, 1, 1, 1)) for i in range(0, 14)] + [(i, (1, 1, 0, 1)) for i in range(14, 19)] + [(3, (1, 1, 0, 1)), (4, (1, 1, 0, 1))] + \
+           [(i, (0, 1, 1, 0)) for i in range(5, 23)] + [(22, (0, 1, 1, 0)), (0, (1, 1, 1, 1))]
+    for i, fl in walk:
+        a = r.get_image(i, *fl)
+        b = ref.get_image(i, *fl)
+        assert a is not None and b is not None, (i, fl)
+        assert a[1:] == b[1:] and a[0].shape == b[0].shape, (i, fl)
+        assert bits_equal(a[0], b[0]), (i, fl)
+    r.close()
+    ref.close()
+
+
 def test_reader_gpu_jpeg_stages_agree_on_damaged_and_mixed_files(tmp_path):
     """A folder whose JPEGs are not all what the device Huffman decoder takes or can decode: gray baseline files, a colour file,
     a progressive one, one with restart markers (stage 2 refuses them on the host: they take the record path), a file whose
