@@ -213,20 +213,22 @@ int mdc_jpeg_idct_batch_device(mdc_ctx* ctx, const void* d_records, int64_t reco
  * a frame of this context -- out[i] is then not a result and the caller decodes that file on the host.
  * mdc_jpeg_huffman_batch_device is the device stage alone: nframes streams, stream_stride bytes apart (multiple of 16) ->
  * nframes records (layout above), d_status[i] as status[i]. */
-#define MDC_JPEG_STREAM_MAGIC 0x31534a4du /* "MJS1" */
+#define MDC_JPEG_STREAM_MAGIC 0x32534a4du /* "MJS2" */
+#define MDC_JPEG_HUFF_SUBTABLES 32
 typedef struct mdc_jpeg_huff {
-  uint16_t look[512];  /* codes of <= 9 bits, indexed by the next 9 bits: length << 8 | symbol; 0 = longer code */
-  int16_t fast[2048];  /* AC table: an 11-bit window holding code + magnitude bits: value << 8 | run << 4 | bits used; 0 = no */
-  int32_t maxcode[18]; /* [l], l = 1..16: largest code of length l or -1; [17] = INT_MAX */
-  int32_t valoff[18];  /* [l]: index into vals of the first code of length l, minus that code */
-  uint8_t vals[256];
-} mdc_jpeg_huff;
+  /* t1, indexed by the next 11 bits (MSB first): bits 0-4 code length L (1..16; 0 = no such code; 31 = longer than 11 bits:
+   * bits 16-31 then hold the index of a subtable), bits 5-8 run, bits 9-12 size (DC table: run 0, size = category), bit 13: the
+   * size magnitude bits lie inside the window too and bits 16-31 hold the (sign-extended) coefficient value.
+   * t2[sub][next 5 bits]: the codes of 12..16 bits below that 11-bit prefix, same entry format. */
+  uint32_t t1[2048];
+  uint32_t t2[MDC_JPEG_HUFF_SUBTABLES][32];
+} mdc_jpeg_huff; /* 12288 bytes */
 typedef struct mdc_jpeg_stream_header {
   uint32_t magic, w, h, ecs_bytes;
   uint32_t reserved[4];
   uint16_t quant[64]; /* natural order */
   mdc_jpeg_huff dc, ac;
-} mdc_jpeg_stream_header; /* 11200 bytes */
+} mdc_jpeg_stream_header; /* 24736 bytes */
 int mdc_process_jpeg_streams_host(mdc_ctx* ctx, const void* const* streams, const int64_t* stream_bytes, float* const* out, int64_t nframes,
                                   unsigned flags, int* status);
 int mdc_jpeg_huffman_batch_device(mdc_ctx* ctx, const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w,

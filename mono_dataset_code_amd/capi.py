@@ -738,7 +738,7 @@ def decode_jpeg_record(data, record, pitch_blocks):
     return tuple(int(x) for x in dims)
 
 
-JPEG_STREAM_HEADER_BYTES = 11200
+JPEG_STREAM_HEADER_BYTES = 24736
 
 
 def jpeg_stream(data, stream):

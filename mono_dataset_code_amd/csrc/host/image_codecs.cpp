@@ -624,41 +624,73 @@ bool jpeg_stream(const unsigned char* d, size_t n, unsigned char* stream, size_t
       hd->w = (uint32_t)W;
       hd->h = (uint32_t)H;
       for (int i = 0; i < 64; i++) hd->quant[i] = qt[tq][i];
+      // the device's tables (mdc_jpeg_huff): one lookup of the next 11 bits gives code length, run and size -- and the value
+      // itself where the magnitude bits lie inside the window; codes of 12..16 bits go through a 32-entry subtable per prefix
       const Huff* src[2] = {&dc[td], &ac[ta]};
       mdc_jpeg_huff* dst[2] = {&hd->dc, &hd->ac};
       for (int k = 0; k < 2; k++) {
-        memcpy(dst[k]->look, src[k]->look, sizeof dst[k]->look);
-        if (k) {  // AC: code + magnitude bits in one lookup of the next 11 bits (values that fit 8 bits)
-          for (int wnd = 0; wnd < 2048; wnd++) {
-            int len = 0, sym = -1;
-            const int e = src[k]->look[wnd >> 2];
-            if (e) {
-              len = e >> 8;
-              sym = e & 255;
-            } else {
-              for (int l = 10; l <= 11 && sym < 0; l++) {
-                const int code = wnd >> (11 - l);
-                if (code <= src[k]->maxcode[l]) {
-                  const int idx = code + src[k]->valoff[l];
-                  if (idx >= 0 && idx < 256) {
-                    len = l;
-                    sym = src[k]->vals[idx];
-                  }
-                }
+        const Huff& t = *src[k];
+        // symbol and length of the code the 16-bit window `w16` starts with (0 = none)
+        auto code_of = [&](int w16, int* sym) {
+          const int e = t.look[w16 >> 7];
+          if (e) {
+            *sym = e & 255;
+            return e >> 8;
+          }
+          for (int l = 10; l <= 16; l++) {
+            const int code = w16 >> (16 - l);
+            if (code <= t.maxcode[l]) {
+              const int idx = code + t.valoff[l];
+              if (idx < 0 || idx > 255) return 0;
+              *sym = t.vals[idx];
+              return l;
+            }
+          }
+          return 0;
+        };
+        int nsub = 0;
+        for (int w11 = 0; w11 < 2048; w11++) {
+          int sym = 0;
+          const int l0 = code_of(w11 << 5, &sym);  // (with the 5 bits below the window zero: right for every code of <= 11 bits)
+          uint32_t e = 0;
+          bool is_short = l0 >= 1 && l0 <= 11;
+          if (is_short) {  // confirm: the code must not depend on the bits below the window
+            int sym1 = 0;
+            is_short = code_of(w11 << 5 | 31, &sym1) == l0 && sym1 == sym;
+          }
+          if (is_short) {
+            const int run = k ? sym >> 4 : 0, sz = k ? sym & 15 : sym;
+            if (!k && sym > 15) {
+              dst[k]->t1[w11] = 0;
+              continue;
+            }
+            e = (uint32_t)l0 | (uint32_t)run << 5 | (uint32_t)sz << 9;
+            if (sz && l0 + sz <= 11) {
+              int v = (w11 >> (11 - l0 - sz)) & ((1 << sz) - 1);
+              if (v < (1 << (sz - 1))) v += (int)((~0u) << sz) + 1;  // EXTEND
+              e |= 1u << 13 | (uint32_t)(uint16_t)(int16_t)v << 16;
+            }
+          } else {  // longer codes below this prefix?
+            uint32_t sub[32];
+            bool any = false;
+            for (int sfx = 0; sfx < 32; sfx++) {
+              int s2 = 0;
+              const int l = code_of(w11 << 5 | sfx, &s2);
+              sub[sfx] = 0;
+              if (l >= 12 && l <= 16 && (k || s2 <= 15)) {
+                sub[sfx] = (uint32_t)l | (uint32_t)(k ? s2 >> 4 : 0) << 5 | (uint32_t)(k ? s2 & 15 : s2) << 9;
+                any = true;
               }
             }
-            dst[k]->fast[wnd] = 0;
-            if (sym < 0) continue;
-            const int run = sym >> 4, sz = sym & 15;
-            if (sz == 0 || len + sz > 11) continue;
-            int v = (wnd >> (11 - len - sz)) & ((1 << sz) - 1);
-            if (v < (1 << (sz - 1))) v += (int)((~0u) << sz) + 1;  // EXTEND
-            if (v >= -128 && v <= 127) dst[k]->fast[wnd] = (int16_t)(v * 256 + run * 16 + (len + sz));
+            if (any) {
+              if (nsub >= MDC_JPEG_HUFF_SUBTABLES) return fail(err, "JPEG stream: too many long Huffman codes for the device tables");
+              memcpy(dst[k]->t2[nsub], sub, sizeof sub);
+              e = 31u | (uint32_t)nsub << 16;
+              nsub++;
+            }
           }
+          dst[k]->t1[w11] = e;
         }
-        for (int l = 0; l < 18; l++) dst[k]->maxcode[l] = l >= 1 ? src[k]->maxcode[l] : -1;
-        for (int l = 0; l < 18; l++) dst[k]->valoff[l] = (l >= 1 && l <= 16) ? src[k]->valoff[l] : 0;
-        memcpy(dst[k]->vals, src[k]->vals, 256);
       }
       // entropy-coded segment without its byte stuffing; ends at the first marker (EOI)
       const unsigned char* q = d + p + len;

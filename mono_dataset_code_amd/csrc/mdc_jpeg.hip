@@ -153,12 +153,9 @@ __device__ __constant__ unsigned char c_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,
                                                       41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                                       30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-struct HuffLds {  // a table as the kernel uses it (copied from mdc_jpeg_huff)
-  uint16_t look[512];
-  int16_t fast[2048];
-  int maxcode[18];
-  int valoff[18];
-  unsigned char vals[256];
+struct HuffLds {  // both tables as the kernel uses them (copied from the stream header): [0] DC, [1] AC
+  uint32_t t1[2][2048];
+  uint32_t t2[2][MDC_JPEG_HUFF_SUBTABLES][32];
 };
 
 struct BitReader {
@@ -201,29 +198,14 @@ struct BitReader {
 
 __device__ __forceinline__ int huff_extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
 
-// one symbol with the slow path; -1: no such code
-__device__ __forceinline__ int huff_symbol(BitReader& b, const HuffLds& t) {
-  const int e = t.look[b.peek(9)];
-  if (e) {
-    b.skip(e >> 8);
-    return e & 255;
-  }
-  int l = 10, code = b.peek(10);
-  while (l <= 16 && code > t.maxcode[l]) {
-    l++;
-    if (l <= 16) code = b.peek(l);
-  }
-  if (l > 16) return -1;
-  b.skip(l);
-  const int idx = code + t.valoff[l];
-  return (idx >= 0 && idx < 256) ? t.vals[idx] : -1;
-}
-
 // Decodes from (bit, z) until a symbol boundary at or past `end`.  WRITE: coefficients of blocks [blk, nblocks) go to the
 // record.  Returns the exit state; *nblk += blocks completed; *bad set when a code is in no table.
+// One code path for every symbol: the table (DC when z == 0, else AC) is picked by address, one lookup of the next 11 bits
+// gives length, run, size and -- mostly -- the value; lanes of a wave are at different symbols anyway, so every branch that
+// some lane takes costs all of them.
 template <bool WRITE>
-__device__ __forceinline__ void huff_run(BitReader& b, const HuffLds& dc, const HuffLds& ac, uint32_t bit, int z, uint32_t end, uint32_t* out_bit,
-                                         int* out_z, int* nblk, int* bad, int16_t* coef, int blk, int nblocks, int bw_used, int pitch) {
+__device__ __forceinline__ void huff_run(BitReader& b, const HuffLds& T, uint32_t bit, int z, uint32_t end, uint32_t* out_bit, int* out_z, int* nblk,
+                                         int* bad, int16_t* coef, int blk, int nblocks, int bw_used, int pitch) {
   b.start(bit);
   int done = 0;
   uint32_t p = bit;
@@ -231,55 +213,47 @@ __device__ __forceinline__ void huff_run(BitReader& b, const HuffLds& dc, const 
   if (WRITE && blk < nblocks) cur = coef + ((long long)(blk / bw_used) * pitch + blk % bw_used) * 64;
   while (p < end) {
     b.refill();
-    if (z == 0) {
-      int t = huff_symbol(b, dc);
-      if (t < 0 || t > 11) {  // (the host decoder refuses DC categories above 11 too)
-        if (!WRITE || cur) *bad = 1;  // (past the last block: the padding bits, not an error)
-        t = 0;
-        b.skip(1);  // (speculative rounds run through garbage: keep moving)
-      }
-      const int diff = t ? huff_extend(b.get(t), t) : 0;
-      if (WRITE && cur) cur[0] = (int16_t)diff;
-      z = 1;
+    const int ac = z != 0;
+    uint32_t e = T.t1[ac][b.peek(11)];
+    if ((e & 31u) == 31u) e = T.t2[ac][(e >> 16) & (MDC_JPEG_HUFF_SUBTABLES - 1)][(uint32_t)(b.acc >> 48) & 31u];  // bits 11..15 of the window
+    const int len = (int)(e & 31u), run = (int)((e >> 5) & 15u), size = (int)((e >> 9) & 15u);
+    bool wrong = len == 0 || len > 16 || (!ac && size > 11);  // (the host decoder refuses DC categories above 11 too)
+    int v = 0;
+    if (wrong) {
+      b.skip(1);  // (speculative rounds run through garbage: keep moving)
+    } else if (e & (1u << 13)) {
+      b.skip(len + size);
+      v = (int)(int16_t)(e >> 16);
     } else {
-      const int fa = ac.fast[b.peek(11)];
-      if (fa) {  // code + magnitude bits in one lookup
-        z += (fa >> 4) & 15;
-        b.skip(fa & 15);
-        if (z <= 63) {
-          if (WRITE && cur) cur[c_zigzag[z]] = (int16_t)(fa >> 8);
-        } else {
-          if (!WRITE || cur) *bad = 1;  // (past the last block: the padding bits, not an error)
-        }
-        z++;
-      } else {
-        const int rs = huff_symbol(b, ac);
-        if (rs < 0) {
-          if (!WRITE || cur) *bad = 1;  // (past the last block: the padding bits, not an error)
-          b.skip(1);
-        } else {
-          const int r = rs >> 4, sz = rs & 15;
-          if (sz == 0) {
-            z = r == 15 ? z + 16 : 64;  // ZRL / EOB
-          } else {
-            z += r;
-            const int v = huff_extend(b.get(sz), sz);
-            if (z <= 63) {
-              if (WRITE && cur) cur[c_zigzag[z]] = (int16_t)v;
-            } else {
-              if (!WRITE || cur) *bad = 1;  // (past the last block: the padding bits, not an error)
-            }
-            z++;
-          }
-        }
+      b.skip(len);
+      if (size) v = huff_extend(b.get(size), size);
+    }
+    int at = 0;  // coefficient index this symbol writes (0: the DC difference), -1: none
+    if (!ac) {
+      z = 1;
+      if (wrong) v = 0;
+    } else if (wrong) {
+      at = -1;
+    } else if (size == 0) {
+      z = run == 15 ? z + 16 : 64;  // ZRL / EOB
+      at = -1;
+    } else {
+      z += run;
+      at = z;
+      if (z > 63) {
+        wrong = true;
+        at = -1;
       }
-      if (z >= 64) {
-        z = 0;
-        done++;
-        if (WRITE) {
-          blk++;
-          cur = blk < nblocks ? coef + ((long long)(blk / bw_used) * pitch + blk % bw_used) * 64 : nullptr;
-        }
+      z++;
+    }
+    if (wrong && (!WRITE || cur)) *bad = 1;  // (past the last block: the padding bits, not an error)
+    if (WRITE && cur && at >= 0) cur[c_zigzag[at]] = (int16_t)v;
+    if (z >= 64) {
+      z = 0;
+      done++;
+      if (WRITE) {
+        blk++;
+        cur = blk < nblocks ? coef + ((long long)(blk / bw_used) * pitch + blk % bw_used) * 64 : nullptr;
       }
     }
     const uint32_t np = b.pos();
@@ -301,7 +275,7 @@ constexpr int kHuffThreads = 1024;
 __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
                                                                     int16_t* __restrict__ records, long long rec_i16, int W, int H, int pitch,
                                                                     int rows, int* __restrict__ status) {
-  __shared__ HuffLds s_dc, s_ac;
+  __shared__ HuffLds s_t;
   __shared__ uint32_t s_bit[kHuffThreads];
   __shared__ int s_z[kHuffThreads];
   __shared__ int s_scan[kHuffThreads / 64 + 1];
@@ -322,12 +296,11 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
   }
   // tables -> LDS; quantisation table -> record; record body zero-filled
   {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(&hd->dc);
-    uint32_t* d0 = reinterpret_cast<uint32_t*>(&s_dc);
-    for (int i = tid; i < (int)(sizeof(HuffLds) / 4); i += kHuffThreads) d0[i] = src[i];
-    src = reinterpret_cast<const uint32_t*>(&hd->ac);
-    d0 = reinterpret_cast<uint32_t*>(&s_ac);
-    for (int i = tid; i < (int)(sizeof(HuffLds) / 4); i += kHuffThreads) d0[i] = src[i];
+    for (int k = 0; k < 2; k++) {
+      const mdc_jpeg_huff* h = k ? &hd->ac : &hd->dc;
+      for (int i = tid; i < 2048; i += kHuffThreads) s_t.t1[k][i] = h->t1[i];
+      for (int i = tid; i < MDC_JPEG_HUFF_SUBTABLES * 32; i += kHuffThreads) (&s_t.t2[k][0][0])[i] = (&h->t2[0][0])[i];
+    }
     if (tid < 64) reinterpret_cast<uint16_t*>(rec)[tid] = hd->quant[tid];
     i32x4* body = reinterpret_cast<i32x4*>(rec + 64);
     const long long n16 = (long long)pitch * rows * 8;  // 16-byte pieces
@@ -354,7 +327,7 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
   int in_z = 0, out_z = 0, nblk = 0, bad = 0;
   if (my0 < my1) {
     const uint32_t from = my1 - my0 > guess_bits ? my1 - guess_bits : my0;
-    huff_run<false>(b, s_dc, s_ac, from, 0, my1, &out_bit, &out_z, &nblk, &bad, nullptr, 0, 0, 1, 1);
+    huff_run<false>(b, s_t, from, 0, my1, &out_bit, &out_z, &nblk, &bad, nullptr, 0, 0, 1, 1);
   }
   s_bit[tid] = out_bit;
   s_z[tid] = out_z;
@@ -372,7 +345,7 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
       bad = 0;
       out_bit = in_bit;
       out_z = in_z;
-      if (in_bit < my1) huff_run<false>(b, s_dc, s_ac, in_bit, in_z, my1, &out_bit, &out_z, &nblk, &bad, nullptr, 0, 0, 1, 1);
+      if (in_bit < my1) huff_run<false>(b, s_t, in_bit, in_z, my1, &out_bit, &out_z, &nblk, &bad, nullptr, 0, 0, 1, 1);
     }
     s_bit[tid] = out_bit;
     s_z[tid] = out_z;
@@ -411,7 +384,7 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
     int dummy = 0;
     uint32_t ob;
     int oz;
-    huff_run<true>(b, s_dc, s_ac, in_bit, in_z, my1, &ob, &oz, &dummy, &bad_w, coef, first, nblocks, bw_used, pitch);
+    huff_run<true>(b, s_t, in_bit, in_z, my1, &ob, &oz, &dummy, &bad_w, coef, first, nblocks, bw_used, pitch);
   }
   // fewer blocks than the frame has: truncated or damaged.  More: the 1..7 padding bits after the last block can parse as
   // another (short-coded) block; those are never written.

@@ -241,11 +241,11 @@ def test_gpu_huffman_stage_equals_the_host_decoder(size):
     assert s2[1] == 2 and s2[0] in (0, 1)  # (flipped bits may still parse as SOME valid stream of the right length: then 0)
     # tables no JPEG file produces -- every entry a code of length 0 -- must end in a status, not in an endless loop
     hostile = streams[:1].copy()
-    huff = 1024 + 4096 + 72 + 72 + 256  # sizeof(mdc_jpeg_huff): look, fast, maxcode, valoff, vals
+    huff = 2048 * 4 + 32 * 32 * 4  # sizeof(mdc_jpeg_huff): t1, t2
     assert capi.JPEG_STREAM_HEADER_BYTES == 160 + 2 * huff
-    hostile[0, 160:160 + 1024].view(np.uint16)[:] = 0x0005                        # dc.look: length 0, symbol 5
-    hostile[0, 160 + huff:160 + huff + 1024].view(np.uint16)[:] = 0x0011          # ac.look: length 0, run 1 size 1
-    hostile[0, 160 + huff + 1024:160 + huff + 1024 + 4096].view(np.int16)[:] = 0x0110  # ac.fast: value 1, run 1, 0 bits
+    hostile[0, 160:160 + 8192].view(np.uint32)[:] = 31 | 5 << 16           # dc.t1: every window -> subtable 5 ...
+    hostile[0, 160 + 8192:160 + huff].view(np.uint32)[:] = 0               # ... which holds no code
+    hostile[0, 160 + huff:160 + huff + 8192].view(np.uint32)[:] = 17 | 3 << 5  # ac.t1: codes of "length 17"
     d_h = torch.from_numpy(hostile).cuda()
     ctx.jpeg_huffman_batch(d_h.data_ptr(), cap, d_rec.data_ptr(), rec_bytes, w, h, pitch, rows, 1, d_status.data_ptr(), st)
     torch.cuda.synchronize()
