@@ -126,6 +126,7 @@ struct DatasetReader::State {
   int ahead_first = -1;
   unsigned ahead_flags = 0;
   int seq_last = -2, seq_run = 0;
+  bool quiet_batch = false;  // the batch behind getImage's lookahead: a frame that fails is reported when the caller asks for it
   void drop_ahead() {
     for (ExposureImage* e : ahead) delete e;
     ahead.clear();
@@ -530,7 +531,9 @@ ExposureImage* DatasetReader::getImage(int id, bool rectify, bool removeGamma, b
     if (s.ahead.empty() && s.seq_run >= 2 && s.is_jpeg_name((size_t)id)) {
       const int n = std::min(s.lookahead, (int)s.files.size() - id);
       s.ahead.assign((size_t)n, (ExposureImage*)0);
+      s.quiet_batch = true;
       getImages(id, n, rectify, removeGamma, removeVignette, nanOverexposed, s.ahead.data());
+      s.quiet_batch = false;
       s.ahead_first = id;
       s.ahead_flags = flags;
       if (s.ahead[0]) {
@@ -661,8 +664,9 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
       const Decode& d = rec[(size_t)i];
       const int id = first + i;
       if (!d.ok || d.w != s.W || d.h != s.H) {
-        std::printf("ERROR: expected cv-mat to have dimensions %d x %d; found %d x %d (image %s)!\n", s.W, s.H, d.w, d.h,
-                    s.files[(size_t)id].c_str());
+        if (!s.quiet_batch)
+          std::printf("ERROR: expected cv-mat to have dimensions %d x %d; found %d x %d (image %s)!\n", s.W, s.H, d.w, d.h,
+                      s.files[(size_t)id].c_str());
         if (!d.ok) s.err = d.err;
         continue;
       }
@@ -683,6 +687,7 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
     }
     // chunk k on the GPU (uploads, kernels and downloads pipelined inside the call) while the pool decodes chunk k+1
     const double tg = now();
+    int refused = 0;  // streams neither the device nor the host decoder could read
     int grc = src.empty() ? MDC_OK : mdc_process_frames_host(s.gpu, src.data(), dst.data(), (int64_t)src.size(), flags);
     if (grc == MDC_OK && !rsrc.empty())  // records: Huffman-decoded on the host, inverse DCT on the device
       grc = mdc_process_jpeg_frames_host(s.gpu, rsrc.data(), (int64_t)s.rec_bytes, s.rec_pitch, s.rec_rows, rdst.data(), (int64_t)rsrc.size(), flags);
@@ -700,12 +705,13 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
           if (one.ok && one.w == s.W && one.h == s.H) {
             grc = mdc_process_host(s.gpu, one.dst, out[i]->image, flags);
           } else {
-            std::printf("ERROR: expected cv-mat to have dimensions %d x %d; found %d x %d (image %s)!\n", s.W, s.H, one.w, one.h,
-                        s.files[(size_t)(first + i)].c_str());
+            if (!s.quiet_batch)
+              std::printf("ERROR: expected cv-mat to have dimensions %d x %d; found %d x %d (image %s)!\n", s.W, s.H, one.w, one.h,
+                          s.files[(size_t)(first + i)].c_str());
             if (!one.ok) s.err = one.err;
             delete out[i];
             out[i] = 0;
-            produced--;
+            refused++;
           }
         }
     }
@@ -718,7 +724,7 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
         out[i] = 0;
       }
     } else {
-      produced += (int)src.size() + (int)rsrc.size() + (int)ssrc.size();
+      produced += (int)src.size() + (int)rsrc.size() + (int)ssrc.size() - refused;
     }
     if (k + RG < nchunks) submit_chunk(k + RG);  // chunk k's buffers are free again
   }

@@ -1930,7 +1930,12 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
       for (int i = 2; i < n && pitch > 0; i++)
         if ((const char*)src[f0 + i] - (const char*)src[f0 + i - 1] != pitch) pitch = 0;
       if (n > 1 && pitch >= (ptrdiff_t)width && width <= d_stride) {
-        MDC_PIPE(hipMemcpy2DAsync(d_dst, d_stride, src[f0], (size_t)pitch, width, (size_t)n, hipMemcpyHostToDevice, s));
+        // rows of `width` bytes: a shorter source is followed by the next one within the pitch, except the LAST -- it goes up
+        // with its own size (nothing is read beyond the end of the caller's last buffer)
+        const size_t last = bytes ? (size_t)bytes[f0 + n - 1] : fixed_bytes;
+        const int rows2d = last == width ? n : n - 1;
+        MDC_PIPE(hipMemcpy2DAsync(d_dst, d_stride, src[f0], (size_t)pitch, width, (size_t)rows2d, hipMemcpyHostToDevice, s));
+        if (rows2d < n) MDC_PIPE(hipMemcpyAsync((char*)d_dst + (size_t)(n - 1) * d_stride, src[f0 + n - 1], last, hipMemcpyHostToDevice, s));
       } else {
         for (int i = 0; i < n; i++)
           MDC_PIPE(hipMemcpyAsync((char*)d_dst + (size_t)i * d_stride, src[f0 + i], bytes ? (size_t)bytes[f0 + i] : fixed_bytes, hipMemcpyHostToDevice, s));

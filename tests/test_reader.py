@@ -7,6 +7,7 @@ interface with the fused pass behind it.
     reader) == the reference's own reader + classes end to end (playback_ref), byte for byte;
   * JPEG frames: identical to the oracle on the libjpeg-decoded bytes.
 """
+import ctypes
 import io
 import itertools
 import os
@@ -337,7 +338,7 @@ def test_get_image_results_made_ahead_on_jpeg_sequences(tmp_path):
     ref.close()
 
 
-def test_reader_gpu_jpeg_stages_agree_on_damaged_and_mixed_files(tmp_path):
+def test_reader_gpu_jpeg_stages_agree_on_damaged_and_mixed_files(tmp_path, capfd):
     """A folder whose JPEGs are not all what the device Huffman decoder takes or can decode: gray baseline files, a colour file,
     a progressive one, one with restart markers (stage 2 refuses them on the host: they take the record path), a file whose
     entropy-coded bytes were damaged and a truncated one (the device reports them or decodes the same symbols as the host).
@@ -374,6 +375,23 @@ def test_reader_gpu_jpeg_stages_agree_on_damaged_and_mixed_files(tmp_path):
         r.close()
     ok0 = results[0][1]
     assert ok0[[0, 1, 2, 3, 4, 7, 8]].all()
+    # getImage in order over the same folder: results made ahead (stage 2, lookahead) or not, the caller sees the same images, the
+    # same failures and the same ERROR lines -- a frame that failed in the batch made ahead is reported when it is asked for, once
+    logs = {}
+    for look in (4, 0):
+        r = capi.DatasetReader(d)
+        r.set_lookahead(look)
+        ctypes.CDLL(None).fflush(None)  # (libc's buffer: the C++ side printf's)
+        capfd.readouterr()
+        got = [r.get_image(i, 1, 1, 1, 1) for i in range(len(blobs))]
+        r.close()
+        ctypes.CDLL(None).fflush(None)
+        logs[look] = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("ERROR")]
+        for i in range(len(blobs)):
+            assert (got[i] is not None) == bool(ok0[i]), (look, i)
+            if ok0[i]:
+                assert bits_equal(got[i][0], results[0][0][i]), (look, i)
+    assert logs[4] == logs[0] and len(logs[0]) == int((~ok0).sum())
     for stage in (2, 1):
         assert results[stage][2] == results[0][2] and (results[stage][1] == ok0).all(), (stage, results[stage][1], ok0)
         for i in range(len(blobs)):
@@ -417,6 +435,22 @@ def test_reader_gpu_jpeg_on_and_off_give_the_same_images(tmp_path):
     for k, i in enumerate(idx):
         assert bits_equal(loose[k], off[i]), (k, "pageable")
         assert bits_equal(pout.array[k], off[i]), (k, "page-locked")
+    # streams back to back at one pitch in a block that ENDS with the last, shortest stream: the chunk goes up as one strided copy
+    # of the first n-1 rows and the last stream by itself (nothing is read past the caller's block)
+    order = sorted(range(40), key=lambda i: -len(blobs[i]))[:9]
+    pitch = (capi.JPEG_STREAM_HEADER_BYTES + len(blobs[order[0]]) + 64 + 15) & ~15
+    probe = np.zeros(pitch, np.uint8)
+    last_size = capi.jpeg_stream(blobs[order[-1]], probe)[0]
+    tight = capi.PinnedArray(((len(order) - 1) * pitch + last_size,), np.uint8)
+    tsizes = []
+    for k, i in enumerate(order):  # (mdch_jpeg_stream wants room for the file's worst case: written aside, then placed)
+        tsizes.append(capi.jpeg_stream(blobs[i], probe)[0])
+        tight.array[k * pitch: k * pitch + tsizes[-1]] = probe[: tsizes[-1]]
+    assert tsizes[-1] == last_size and last_size < max(tsizes)
+    tout = [np.full(on.shape[1], -7.0, np.float32) for _ in order]
+    assert ctx.process_jpeg_streams_host([tight.array[k * pitch: k * pitch + tsizes[k]] for k in range(len(order))], tsizes, tout, 15) == [0] * len(order)
+    for k, i in enumerate(order):
+        assert bits_equal(tout[k], off[i]), (k, "tight block")
     raw_out = [np.full(w * h, -7.0, np.float32) for _ in range(3)]
     assert ctx.process_jpeg_streams_host(streams[:3], sizes[:3], raw_out, 7) == [0, 0, 0]  # no rectification: W x H results
     for k in range(3):
