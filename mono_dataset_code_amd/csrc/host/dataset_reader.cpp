@@ -110,7 +110,7 @@ struct DatasetReader::State {
   // ring of getImages: chunks of 32 (64 in JPEG stage 2) page-locked frame buffers, 256 in all.  Chunk k is on the GPU while
   // the pool decodes chunks k+1 .. (up to 192 frames in flight): a decode thread that is slow on one frame delays only the
   // chunk that frame is in, not the pipeline (two half-rings of 64 stalled on every straggler: 2.5-2.9 k frames/s)
-  enum { kRingFrames = 256 };  // page-locked decode buffers of getImages (335 MB at 1280x1024, 670 MB in stage 1; first getImages)
+  enum { kRingFrames = 256 };  // page-locked decode buffers of getImages (335 MB at 1280x1024, 670 MB in stage 1 and for calls of > 256 frames in stage 2; first getImages)
   HostBuffer ring_block;               // ONE page-locked block: slot i at ring_block.p + i * ring_stride (a chunk's uploads are
   size_t ring_stride = 0;              // then one strided copy instead of one copy per frame)
   int ring_slots = 0;
@@ -594,7 +594,10 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
   // frames per GPU call / calls in the ring: stage 2 hands over the whole ring at a time -- its host work is ~0.1 ms per
   // frame and thread, and inside the GPU call a 64-frame chunk decodes while the one before it goes out: the longer the call,
   // the less its first decode and last output weigh (128 per call: 16.5 k frames/s, 256: 20+ k)
-  const int C = s.gpu_jpeg >= 2 ? State::kRingFrames : 32, RG = State::kRingFrames / C;
+  // ... and a call longer than that gets a second ring's worth of buffers, so that the pool parses the next 256 files while the
+  // GPU call of the current 256 runs (one ring: parse and GPU call take turns, 22 k frames/s)
+  const int C = s.gpu_jpeg >= 2 ? State::kRingFrames : 32;
+  const int slots = (s.gpu_jpeg >= 2 && count > C) ? 2 * State::kRingFrames : State::kRingFrames, RG = slots / C;
   // coefficient records (include/mdc_hip.h): MCUs are at most 4 x 4 blocks, so a grid rounded up to multiples of 4 blocks
   // holds every sampling layout of a W x H file (the same rule as mdch_jpeg_record_bytes)
   s.rec_pitch = ((s.W + 7) / 8 + 3) & ~3;
@@ -603,10 +606,10 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
   // a ring buffer holds a decoded frame, or (stage 1) a coefficient record -- 2 bytes per pixel --, or (stage 2) a stream: the
   // compressed bytes + 5 KB; a file stage 2 does not take, or whose stream does not fit, is decoded to pixels on the host
   const size_t want_bytes = s.gpu_jpeg == 1 ? std::max(s.frame_bytes(), s.rec_bytes) : s.frame_bytes();
-  if (!s.ring_block.p || s.ring_bytes < want_bytes) {
+  if (!s.ring_block.p || s.ring_bytes < want_bytes || s.ring_slots < slots) {
     s.ring_block.release();
     s.ring_stride = (want_bytes + 4095) & ~(size_t)4095;
-    s.ring_slots = State::kRingFrames;
+    s.ring_slots = slots;
     s.ring_block.alloc(s.ring_stride * (size_t)s.ring_slots);
     s.ring_bytes = want_bytes;
   }

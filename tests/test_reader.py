@@ -457,3 +457,40 @@ def test_reader_gpu_jpeg_on_and_off_give_the_same_images(tmp_path):
         want = np.zeros(w * h, np.float32)
         ctx.process_host(np.ascontiguousarray(capi.decode_gray8(blobs[idx[k]]).reshape(-1)), want, 7)
         assert bits_equal(raw_out[k], want), k
+
+
+def test_image_pool_slabs():
+    """ExposureImage's pool (csrc/host/image_pool.cpp): page-locked blocks come out of slabs of up to 64 images, lowest free
+    address first, so the images made one after the other lie back to back; a block freed twice or a foreign pointer is ignored;
+    slabs whose images are all back are released by the trim."""
+    from mono_dataset_code_amd import capi
+
+    L = capi.host_lib()
+    L.mdch_image_alloc.restype = ctypes.c_void_p
+    L.mdch_image_alloc.argtypes = [ctypes.c_ulong]
+    L.mdch_image_free.argtypes = [ctypes.c_void_p]
+    L.mdch_image_pool_trim()
+    base_idle = L.mdch_image_pool_idle_bytes()
+    n = 640 * 480
+    a = [L.mdch_image_alloc(n) for _ in range(128)]
+    assert len(set(a)) == 128
+    assert all(a[i + 1] - a[i] == n * 4 for i in range(63)), "one slab: 64 images back to back"
+    assert all(a[i + 1] - a[i] == n * 4 for i in range(64, 127)), "the next slab"
+    np.ctypeslib.as_array(ctypes.cast(a[127], ctypes.POINTER(ctypes.c_float)), (n,))[:] = 1.0  # writable to its end
+    L.mdch_image_free(a[10])
+    L.mdch_image_free(a[3])
+    L.mdch_image_free(a[3])  # ignored
+    L.mdch_image_free(a[3] + 64)  # not a block: ignored
+    assert L.mdch_image_alloc(n) == a[3] and L.mdch_image_alloc(n) == a[10]  # (the only free blocks; lowest address first)
+    assert L.mdch_image_pool_idle_bytes() == base_idle  # nothing releasable while images are live
+    for p in a:
+        L.mdch_image_free(p)
+    assert L.mdch_image_pool_idle_bytes() == base_idle + 128 * n * 4
+    L.mdch_image_pool_trim()
+    assert L.mdch_image_pool_idle_bytes() == 0
+    odd = [L.mdch_image_alloc(1001) for _ in range(3)]  # not whole 64-byte lines: blocks keep their alignment, not back to back
+    assert odd[1] - odd[0] == 1008 * 4 and odd[0] % 64 == 0
+    for p in odd:
+        L.mdch_image_free(p)
+    L.mdch_image_pool_trim()
+    assert L.mdch_image_pool_idle_bytes() == 0
