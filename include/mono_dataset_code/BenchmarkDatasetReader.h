@@ -77,9 +77,10 @@ class DatasetReader {
   // on the host.  Same bytes in every stage.  setGpuJpeg(on) = stage 2 / 0; MDC_GPU_JPEG=0|1|2 in the environment.
   void setGpuJpeg(bool on);
   void setGpuJpegStage(int stage);
-  // getImage on a JPEG sequence read in order (stage 2): from the third consecutive id on, the next `frames` results are made
-  // ahead in one pass of the getImages pipeline with the caller's switches and handed out by the following calls (default 64,
-  // 0 = off, also MDC_READER_LOOKAHEAD in the environment).  Another id or other switches drop what was made ahead.
+  // getImage on a JPEG sequence read in order (stage 2): from the third consecutive id on, the next results are made ahead in
+  // one pass of the getImages pipeline with the caller's switches and handed out by the following calls: 64, then 128, then
+  // 256 at a time while the caller keeps reading in order, never more than `frames` (default 256, 0 = off, also
+  // MDC_READER_LOOKAHEAD in the environment).  Another id or other switches drop what was made ahead.
   void setResultLookahead(int frames);
   const char* lastError() const; // why the last getImage / getImages / getImageRaw returned 0 / fewer images
   void getPrefetchStats(long* hits, long* misses) const;  // frames found decoded ahead / decoded by the calling thread

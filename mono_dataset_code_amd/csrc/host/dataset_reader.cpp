@@ -121,7 +121,8 @@ struct DatasetReader::State {
   int gpu_jpeg = 2;  // 0: JPEG decoded on the host; 1: host Huffman + device inverse DCT; 2: device Huffman + inverse DCT
   // getImage on a JPEG sequence read in order: after two consecutive ids the next `lookahead` frames go through the getImages
   // pipeline (Huffman decoding on the device) with the caller's switches, and the following calls hand those results out
-  int lookahead = 64;
+  int lookahead = kRingFrames;  // the most; a run starts with 64 and doubles per batch (the longer the call, the less its fill and drain weigh)
+  int ahead_batch = 64;
   std::vector<ExposureImage*> ahead;
   int ahead_first = -1;
   unsigned ahead_flags = 0;
@@ -131,6 +132,7 @@ struct DatasetReader::State {
     for (ExposureImage* e : ahead) delete e;
     ahead.clear();
     ahead_first = -1;
+    ahead_batch = 64;
   }
   bool is_jpeg_name(size_t id) const {
     const std::string& f = files[id];
@@ -519,7 +521,11 @@ ExposureImage* DatasetReader::getImage(int id, bool rectify, bool removeGamma, b
       if (flags == s.ahead_flags && k >= 0 && k < (int)s.ahead.size() && s.ahead[(size_t)k]) {
         ExposureImage* ret = s.ahead[(size_t)k];
         s.ahead[(size_t)k] = 0;
-        if (k + 1 == (int)s.ahead.size()) s.drop_ahead();
+        if (k + 1 == (int)s.ahead.size()) {  // used up in order: the next batch is twice as long
+          const int grown = std::min(2 * s.ahead_batch, (int)State::kRingFrames);
+          s.drop_ahead();
+          s.ahead_batch = grown;
+        }
         s.seq_run = id == s.seq_last + 1 ? s.seq_run + 1 : 0;
         s.seq_last = id;
         return ret;
@@ -529,7 +535,7 @@ ExposureImage* DatasetReader::getImage(int id, bool rectify, bool removeGamma, b
     s.seq_run = id == s.seq_last + 1 ? s.seq_run + 1 : 0;
     s.seq_last = id;
     if (s.ahead.empty() && s.seq_run >= 2 && s.is_jpeg_name((size_t)id)) {
-      const int n = std::min(s.lookahead, (int)s.files.size() - id);
+      const int n = std::min(std::min(s.lookahead, s.ahead_batch), (int)s.files.size() - id);
       s.ahead.assign((size_t)n, (ExposureImage*)0);
       s.quiet_batch = true;
       getImages(id, n, rectify, removeGamma, removeVignette, nanOverexposed, s.ahead.data());

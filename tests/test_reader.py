@@ -336,6 +336,19 @@ def test_get_image_results_made_ahead_on_jpeg_sequences(tmp_path):
         assert bits_equal(a[0], b[0]), (i, fl)
     r.close()
     ref.close()
+    # the default: batches of 64, 128, 256 while the caller keeps reading in order (here 2 + 64 + 128 + the rest), back to 64 after a jump
+    d2 = os.path.join(str(tmp_path), "long")
+    os.makedirs(d2)
+    make_sequence(d2, frames_for(230, h, w), True, "jpg")
+    ref = capi.DatasetReader(d2)
+    ref.set_lookahead(0)
+    r = capi.DatasetReader(d2)
+    for i in list(range(0, 230)) + list(range(40, 50)):
+        a = r.get_image(i, 1, 1, 1, 1)
+        b = ref.get_image(i, 1, 1, 1, 1)
+        assert a is not None and a[1:] == b[1:] and bits_equal(a[0], b[0]), i
+    r.close()
+    ref.close()
 
 
 def test_reader_gpu_jpeg_stages_agree_on_damaged_and_mixed_files(tmp_path, capfd):
