@@ -1908,14 +1908,17 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
     he = (call);                    \
     if (he != hipSuccess) what = #call; \
   }
-  for (int64_t f0 = 0, k = 0; f0 < nframes && rc == MDC_OK && he == hipSuccess; f0 += chunk, k++) {
+  int n = 0;
+  for (int64_t f0 = 0, k = 0; f0 < nframes && rc == MDC_OK && he == hipSuccess; f0 += n, k++) {
     const int slot = (int)(k & 1);
     // Streams: ALL chunks decode on stream 0 (upload, Huffman kernel, inverse DCT) and go out on stream 1 (fused pass into the
     // caller's images), tied by events -- the Huffman kernel takes ~1.3 ms whatever the frame count (one workgroup per frame)
     // and the output is PCIe-bound, so chunk k+1 decodes while chunk k goes out.  Otherwise chunk k runs on stream k % 2.
     hipStream_t s = strm ? c->pipe_stream[0] : c->pipe_stream[slot];
     hipStream_t s_out = strm ? c->pipe_stream[1] : s;
-    const int n = (int)std::min<int64_t>(chunk, nframes - f0);
+    // (a smaller first chunk, to get the output going earlier, is slower: the Huffman launch takes ~0.75 ms whatever its frame
+    // count, so more chunks only lengthen the decode stream -- profiles/r03_experiments/19_*)
+    n = (int)std::min<int64_t>(chunk, nframes - f0);
     if (k >= 2 && strm) {  // the slot's staging is free again: in stream order ...
       MDC_PIPE(hipStreamWaitEvent(s, c->pipe_done[slot], 0));
     } else if (k >= 2 && !(zc_in && zc_out)) {  // ... or on the host
