@@ -44,6 +44,7 @@ struct Pool {
   static constexpr size_t kMaxIdleBytes = (size_t)2048 << 20;
   static constexpr size_t kSlabBytes = (size_t)96 << 20;
   static constexpr int kSlabImages = 64;
+  static constexpr size_t kPageableSlabBytes = (size_t)16 << 20;  // without a GPU / page-locked memory
   ~Pool() {
     // process exit: the HIP runtime may already be gone -- leave page-locked blocks to the OS
   }
@@ -98,19 +99,20 @@ extern "C" float* mdch_image_alloc(unsigned long nfloats) {
     }
   }
   // a new slab (outside the lock: page-locking takes milliseconds); if that much page-locked memory is not to be had, one image;
-  // without a GPU an ordinary block (a container, not a compute fallback)
+  // without a GPU ordinary memory (a container, not a compute fallback)
   const size_t stride = (nfloats + 15) & ~(size_t)15, bytes = nfloats * sizeof(float);
-  int count = (int)std::max<size_t>(1, std::min<size_t>(Pool::kSlabImages, Pool::kSlabBytes / (stride * sizeof(float))));
+  const int want = (int)std::max<size_t>(1, std::min<size_t>(Pool::kSlabImages, Pool::kSlabBytes / (stride * sizeof(float))));
+  int count = want;
   bool pinned = true;
   float* base = static_cast<float*>(mdc_host_alloc(stride * sizeof(float) * (size_t)count));
   if (!base && count > 1) {
     count = 1;
     base = static_cast<float*>(mdc_host_alloc(bytes));
   }
-  if (!base) {
+  if (!base) {  // the same bookkeeping over ordinary memory, in smaller slabs
     pinned = false;
-    count = 1;
-    base = new float[nfloats];
+    count = (int)std::max<size_t>(1, std::min<size_t>((size_t)want, Pool::kPageableSlabBytes / (stride * sizeof(float))));
+    base = new float[stride * (size_t)count];
   }
   std::lock_guard<std::mutex> lk(P.mu);
   Slab s;
@@ -141,14 +143,12 @@ extern "C" void mdch_image_free(float* b) {
     if (!free_blocks.insert(b).second) return;  // a second free of the same block is ignored
     s.live--;
     P.idle_bytes += s.nfloats * sizeof(float);
-    if (!s.pinned) {
-      P.retire(it, &drop);  // ordinary memory is not kept
-    } else if (P.idle_bytes > Pool::kMaxIdleBytes) {
+    if (P.idle_bytes > Pool::kMaxIdleBytes) {
       // over the cap: slabs without a live image go back (this one first; one with live images cannot)
       if (s.live == 0) P.retire(it, &drop);
       for (auto jt = P.slabs.begin(); jt != P.slabs.end() && P.idle_bytes > Pool::kMaxIdleBytes;) {
         auto cur = jt++;
-        if (cur->second.live == 0 && cur->second.pinned) P.retire(cur, &drop);
+        if (cur->second.live == 0) P.retire(cur, &drop);
       }
     }
   }

@@ -140,6 +140,47 @@ int main(int argc, char** argv) {
     delete b;
     mdch_image_pool_trim();
   }
+  {  // the pool's slabs: blocks back to back (561 floats -> 576 apart), lowest free address first, double and foreign frees ignored
+    mdch_image_pool_trim();
+    std::vector<float*> blk;
+    for (int i = 0; i < 192; i++) {  // three full slabs
+      blk.push_back(mdch_image_alloc(561));
+      blk.back()[0] = blk.back()[560] = (float)i;
+    }
+    int adjacent = 0;
+    for (size_t i = 1; i < blk.size(); i++) adjacent += blk[i] == blk[i - 1] + 576;
+    if (adjacent < 185) {
+      std::printf("image pool: only %d of 191 consecutive blocks lie back to back\n", adjacent);
+      return 1;
+    }
+    mdch_image_free(blk[7]);
+    mdch_image_free(blk[7]);
+    mdch_image_free(blk[7] + 3);
+    float on_stack[4];
+    mdch_image_free(on_stack);
+    mdch_image_free(blk[5]);
+    float* again = mdch_image_alloc(561);
+    float* again2 = mdch_image_alloc(561);
+    if (!((again == blk[5] && again2 == blk[7]) || (again == blk[7] && again2 == blk[5]))) {
+      std::printf("image pool: freed blocks did not come back\n");
+      return 1;
+    }
+    if (mdch_image_pool_idle_bytes() != 0) {
+      std::printf("image pool: releasable bytes while every slab has live images\n");
+      return 1;
+    }
+    for (float* p : blk) mdch_image_free(p);
+    if (mdch_image_pool_idle_bytes() == 0) {
+      std::printf("image pool: nothing releasable after every image came back\n");
+      return 1;
+    }
+    mdch_image_pool_trim();
+    if (mdch_image_pool_idle_bytes() != 0) return 1;
+    float* big = mdch_image_alloc(5u << 20);  // one image larger than a pageable slab
+    big[(5u << 20) - 1] = 1.f;
+    mdch_image_free(big);
+    mdch_image_pool_trim();
+  }
   std::printf("HOST_SANITIZE_OK decoded %ld refused %ld\n", decoded, refused);
   return 0;
 }
