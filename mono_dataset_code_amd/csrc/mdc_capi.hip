@@ -130,6 +130,9 @@ struct mdc_ctx {
   hipStream_t pipe_stream[2] = {nullptr, nullptr};
   hipEvent_t pipe_done[2] = {nullptr, nullptr};
   hipEvent_t pipe_dec[2] = {nullptr, nullptr};  // streams: "chunk decoded" (decode stream -> output stream)
+  hipStream_t pipe_up_stream = nullptr;          // streams: uploads run ahead of the decode stream on their own
+  hipEvent_t pipe_up[2] = {nullptr, nullptr};   // "chunk uploaded" (upload stream -> decode stream)
+  hipEvent_t pipe_huff[2] = {nullptr, nullptr}; // "stream buffer read" (decode stream -> upload stream)
   uint8_t* d_pipe_in[2] = {nullptr, nullptr};
   float* d_pipe_out[2] = {nullptr, nullptr};
   void* d_pipe_rec[2] = {nullptr, nullptr};  // JPEG coefficient records of a chunk (mdc_process_jpeg_frames_host)
@@ -973,6 +976,7 @@ void mdc_destroy(mdc_ctx* c) {
     c->slots.clear();
     for (int k = 0; k < 2; k++)
       if (c->pipe_stream[k]) (void)hipStreamSynchronize(c->pipe_stream[k]);
+    if (c->pipe_up_stream) (void)hipStreamSynchronize(c->pipe_up_stream);
     unpin_all(c);
     free_plan(c);
     void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_vcal_max, c->d_pipe_in[0], c->d_pipe_in[1], c->d_pipe_out[0], c->d_pipe_out[1],
@@ -983,8 +987,11 @@ void mdc_destroy(mdc_ctx* c) {
     for (int k = 0; k < 2; k++) {
       if (c->pipe_done[k]) (void)hipEventDestroy(c->pipe_done[k]);
       if (c->pipe_dec[k]) (void)hipEventDestroy(c->pipe_dec[k]);
+      if (c->pipe_up[k]) (void)hipEventDestroy(c->pipe_up[k]);
+      if (c->pipe_huff[k]) (void)hipEventDestroy(c->pipe_huff[k]);
       if (c->pipe_stream[k]) (void)hipStreamDestroy(c->pipe_stream[k]);
     }
+    if (c->pipe_up_stream) (void)hipStreamDestroy(c->pipe_up_stream);
   }
   if (t_err_ctx == c) t_err_ctx = nullptr;
   delete c;
@@ -1680,6 +1687,7 @@ int mdc_synchronize(mdc_ctx* c) try {
   }
   for (int k = 0; k < 2; k++)
     if (c->pipe_stream[k]) streams.push_back(c->pipe_stream[k]);
+  if (c->pipe_up_stream) streams.push_back(c->pipe_up_stream);
   for (hipStream_t st : streams) MDC_HIP(c, hipStreamSynchronize(st));
   return MDC_OK;
 } MDC_CATCH(c)
@@ -1841,6 +1849,11 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
     MDC_HIP(c, hipHostMalloc((void**)&c->h_pipe_status, cap * sizeof(int), hipHostMallocDefault));
     c->pipe_status_cap = cap;
   }
+  int* d_host_status = nullptr;  // the device's view of h_pipe_status
+  if (strm && status && c->h_pipe_status && hipHostGetDevicePointer((void**)&d_host_status, c->h_pipe_status, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    d_host_status = nullptr;
+  }
   constexpr int kChunk = 16;  // frames per slot: one kernel launch (two with the inverse DCT), 2 x 16 async copies
   // Zero copy (device_view): results go straight into the caller's images when every one of them is mapped page-locked
   // memory, frames are read straight from the caller's buffers when every one of them is (coefficient records are always
@@ -1850,7 +1863,12 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
   auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
   std::vector<float*> z_out((size_t)nframes);
   std::vector<const uint8_t*> z_in((rec || strm) ? 0 : (size_t)nframes);
-  bool zc_out = nframes > 0, zc_in = !rec && !strm && nframes > 0;
+  // Streams: results are staged on the device and leave with ONE copy per run of images that lie back to back (the reader's pool
+  // hands out slabs): while a kernel writes results across PCIe itself, the kernels of other streams make no progress -- the
+  // Huffman launch of the next chunk finished 0.8 ms (its own time) after the output of the current one, however few
+  // workgroups the output launch had --, the copy engine moves the same bytes at the same 52 GB/s and leaves the CUs alone
+  // (256 frames: 10.4 -> 7.5 ms, profiles/r03_experiments/20_*).
+  bool zc_out = nframes > 0 && !strm, zc_in = !rec && !strm && nframes > 0;
   for (int64_t i = 0; i < nframes && zc_out; i++) zc_out = (z_out[(size_t)i] = device_view(c, out[i], n_out * sizeof(float))) != nullptr;
   for (int64_t i = 0; i < nframes && zc_in; i++) zc_in = (z_in[(size_t)i] = device_view(c, raw[i], n_in)) != nullptr;
   if (!zc_out) zc_in = false;  // frames alone: the copy pipeline (one launch per chunk) stays
@@ -1867,7 +1885,8 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
   // frames per slot.  Streams: 64 -- the Huffman kernel's time does not depend on the frame count up to ~64 (one workgroup per
   // frame, 1.3 ms), so small chunks would only repeat that latency; nothing staged: the chunk only alternates the streams
   const int chunk = (zc_in && zc_out) ? 64 : (strm ? 64 : kChunk);
-  const size_t in_need = zc_in ? 0 : chunk * n_in, out_need = zc_out ? 0 : chunk * n_out * sizeof(float);
+  const bool inplace_out = zc_out;
+  const size_t in_need = zc_in ? 0 : chunk * n_in, out_need = inplace_out ? 0 : chunk * n_out * sizeof(float);
   const size_t rec_need = (rec || strm) ? (size_t)chunk * (size_t)record_bytes : 0;
   const size_t strm_need = strm ? (size_t)chunk * strm_stride : 0;
   if (c->pipe_in_cap < in_need || c->pipe_out_cap < out_need || c->pipe_rec_cap < rec_need || c->pipe_strm_cap < strm_need || !c->pipe_stream[0] ||
@@ -1896,6 +1915,13 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
     c->pipe_rec_cap = rec_cap;
     c->pipe_strm_cap = strm_cap;
   }
+  if (strm && !c->pipe_up_stream) {
+    MDC_HIP(c, hipStreamCreateWithFlags(&c->pipe_up_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+      if (!c->pipe_up[k]) MDC_HIP(c, hipEventCreateWithFlags(&c->pipe_up[k], hipEventDisableTiming));
+      if (!c->pipe_huff[k]) MDC_HIP(c, hipEventCreateWithFlags(&c->pipe_huff[k], hipEventDisableTiming));
+    }
+  }
   // chunk k runs entirely on stream k%2 (H2D, kernel(s), D2H in order); the two streams overlap one
   // chunk's copies with the other's kernel.  Re-using a slot waits for its previous chunk.
   // On a failure the loop stops, BOTH streams are drained (asynchronous copies into the caller's buffers
@@ -1909,6 +1935,17 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
     if (he != hipSuccess) what = #call; \
   }
   int n = 0;
+  // MDC_PIPE_TRACE: per chunk 6 time stamps [upload: start, done; decode stream: Huffman done, decoded; output stream: start, done]
+  const int64_t nchunks = (nframes + chunk - 1) / chunk;
+  std::vector<hipEvent_t> tev(trace ? (size_t)nchunks * 6 : 0, (hipEvent_t) nullptr);
+  auto stamp = [&](int64_t kk, int j, hipStream_t st) {
+    if (!trace) return;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) == hipSuccess) {
+      (void)hipEventRecord(e, st);
+      tev[(size_t)kk * 6 + j] = e;
+    }
+  };
   for (int64_t f0 = 0, k = 0; f0 < nframes && rc == MDC_OK && he == hipSuccess; f0 += n, k++) {
     const int slot = (int)(k & 1);
     // Streams: ALL chunks decode on stream 0 (upload, Huffman kernel, inverse DCT) and go out on stream 1 (fused pass into the
@@ -1926,7 +1963,7 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
     }
     // a chunk whose sources lie at one stride in host memory (the reader's ring) goes up as ONE strided copy: 64 separate
     // copies of a 270-KB stream cost the decode stream ~1 ms of the ~2.5 ms a chunk takes
-    auto upload = [&](void* d_dst, size_t d_stride, const void* const* src, const int64_t* bytes, size_t fixed_bytes) {
+    auto upload = [&](int64_t f0, int n, void* d_dst, size_t d_stride, const void* const* src, const int64_t* bytes, size_t fixed_bytes, hipStream_t s) {
       size_t width = fixed_bytes;
       for (int i = 0; i < n && bytes; i++) width = std::max(width, (size_t)bytes[f0 + i]);
       ptrdiff_t pitch = n > 1 ? (const char*)src[f0 + 1] - (const char*)src[f0] : 0;
@@ -1945,24 +1982,51 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
       }
     };
     if (strm) {
-      upload(c->d_pipe_strm[slot], strm_stride, strm, strm_bytes, 0);
+      // Uploads run ahead on their own stream: chunk k+1's streams are ENQUEUED before anything of chunk k (the copy queues
+      // work in submission order -- an upload submitted after chunk k's copy out would wait behind it) and go up as soon as the
+      // Huffman launch of chunk k-1 has read the buffer, i.e. under the decode of chunk k and the output of chunk k-1.
+      auto enqueue_upload = [&](int64_t kk) {
+        const int sl = (int)(kk & 1);
+        const int64_t uf0 = kk * chunk;
+        const int un = (int)std::min<int64_t>(chunk, nframes - uf0);
+        hipStream_t up = c->pipe_up_stream;
+        if (kk >= 2) MDC_PIPE(hipStreamWaitEvent(up, c->pipe_huff[sl], 0));
+        stamp(kk, 0, up);
+        upload(uf0, un, c->d_pipe_strm[sl], strm_stride, strm, strm_bytes, 0, up);
+        MDC_PIPE(hipEventRecord(c->pipe_up[sl], up));
+        stamp(kk, 1, up);
+      };
+      if (k == 0) enqueue_upload(0);
+      if (f0 + n < nframes) enqueue_upload(k + 1);
+      MDC_PIPE(hipStreamWaitEvent(s, c->pipe_up[slot], 0));
+      // the status words land in page-locked host memory directly (a copy would queue behind the results going out)
+      int* d_status = (status && d_host_status) ? d_host_status + f0 : c->d_pipe_status[slot];
       MDC_PIPE(launch_jpeg_huffman(c->d_pipe_strm[slot], (int64_t)strm_stride, c->d_pipe_rec[slot], record_bytes, iw, ih, blocks_w, blocks_rows, n,
-                                   c->d_pipe_status[slot], s));
-      if (status) MDC_PIPE(hipMemcpyAsync(c->h_pipe_status + f0, c->d_pipe_status[slot], (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+                                   d_status, s));
+      MDC_PIPE(hipEventRecord(c->pipe_huff[slot], s));
+      stamp(k, 2, s);
+      if (status && !d_host_status)
+        MDC_PIPE(hipMemcpyAsync(c->h_pipe_status + f0, c->d_pipe_status[slot], (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
       MDC_PIPE(launch_jpeg_idct(c->d_pipe_rec[slot], record_bytes, c->d_pipe_in[slot], iw, ih, blocks_w, blocks_rows, n, s));
     } else if (rec) {
-      upload(c->d_pipe_rec[slot], (size_t)record_bytes, rec, nullptr, (size_t)record_bytes);
+      stamp(k, 0, s);
+      upload(f0, n, c->d_pipe_rec[slot], (size_t)record_bytes, rec, nullptr, (size_t)record_bytes, s);
+      stamp(k, 1, s);
       MDC_PIPE(launch_jpeg_idct(c->d_pipe_rec[slot], record_bytes, c->d_pipe_in[slot], iw, ih, blocks_w, blocks_rows, n, s));
-    } else if (!zc_in) {
-      upload(c->d_pipe_in[slot], n_in, reinterpret_cast<const void* const*>(raw), nullptr, n_in);
+    } else {
+      stamp(k, 0, s);
+      if (!zc_in) upload(f0, n, c->d_pipe_in[slot], n_in, reinterpret_cast<const void* const*>(raw), nullptr, n_in, s);
+      stamp(k, 1, s);
     }
     if (he != hipSuccess) break;
+    stamp(k, 3, s);
     if (strm) {
       MDC_PIPE(hipEventRecord(c->pipe_dec[slot], s));
       MDC_PIPE(hipStreamWaitEvent(s_out, c->pipe_dec[slot], 0));
       if (he != hipSuccess) break;
     }
-    if (zc_out) {  // one launch per run of frames that lie back to back on both sides
+    stamp(k, 4, s_out);
+    if (inplace_out) {  // one launch per run of frames that lie back to back on both sides
       for (int i = 0; i < n && rc == MDC_OK;) {
         const uint8_t* src = zc_in ? z_in[(size_t)(f0 + i)] : c->d_pipe_in[slot] + (size_t)i * n_in;
         float* dst = z_out[(size_t)(f0 + i)];
@@ -1977,13 +2041,25 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
     } else {
       rc = enqueue_process(c, c->d_pipe_in[slot], c->d_pipe_out[slot], n, flags, s_out);
       if (rc != MDC_OK) break;
-      for (int i = 0; i < n; i++)
-        MDC_PIPE(hipMemcpyAsync(out[f0 + i], c->d_pipe_out[slot] + (size_t)i * n_out, n_out * sizeof(float),
+      for (int i = 0; i < n;) {  // one copy per run of images that lie back to back in the caller's memory
+        int run = 1;
+        while (i + run < n && out[f0 + i + run] == out[f0 + i] + (size_t)run * n_out) run++;
+        MDC_PIPE(hipMemcpyAsync(out[f0 + i], c->d_pipe_out[slot] + (size_t)i * n_out, (size_t)run * n_out * sizeof(float),
                                 hipMemcpyDeviceToHost, s_out));
+        i += run;
+      }
     }
     MDC_PIPE(hipEventRecord(c->pipe_done[slot], s_out));
+    stamp(k, 5, s_out);
   }
   const double t_enqueued = since();
+  if (strm && c->pipe_up_stream) {
+    const hipError_t e = hipStreamSynchronize(c->pipe_up_stream);
+    if (he == hipSuccess && e != hipSuccess) {
+      he = e;
+      what = "hipStreamSynchronize(pipe_up_stream)";
+    }
+  }
   for (int k = 0; k < 2; k++) {
     const hipError_t e = hipStreamSynchronize(c->pipe_stream[k]);
     if (he == hipSuccess && e != hipSuccess) {
@@ -1992,6 +2068,18 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
     }
   }
 #undef MDC_PIPE
+  if (trace && !tev.empty() && tev[0] && he == hipSuccess && rc == MDC_OK) {
+    std::fprintf(stderr, "%s: chunks, ms since the first upload [upload from-to | decode: Huffman done, decoded | out: from-to]", who);
+    for (size_t q = 0; q + 5 < tev.size(); q += 6) {
+      float t[6] = {-1, -1, -1, -1, -1, -1};
+      for (int j = 0; j < 6; j++)
+        if (tev[q + j]) (void)hipEventElapsedTime(&t[j], tev[0], tev[q + j]);
+      std::fprintf(stderr, "  [%.2f-%.2f | %.2f, %.2f | %.2f-%.2f]", t[0], t[1], t[2], t[3], t[4], t[5]);
+    }
+    std::fprintf(stderr, "\n");
+  }
+  for (hipEvent_t e : tev)
+    if (e) (void)hipEventDestroy(e);
   if (trace)
     std::fprintf(stderr, "%s: %lld frames: buffer queries %.2f ms, everything enqueued at %.2f ms, streams drained at %.2f ms\n", who, (long long)nframes,
                  t_views, t_enqueued, since());
