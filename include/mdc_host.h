@@ -102,8 +102,7 @@ int mdch_decode_jpeg_record(const unsigned char* data, size_t n, void* record, s
 long long mdch_jpeg_stream(const unsigned char* data, size_t n, void* stream, size_t cap, int wh[2], char* err, size_t errcap);
 
 /* ExposureImage's pixel pool (include/mono_dataset_code/ExposureImage.h): page-locked blocks carved out of slabs of up to 64
- * images, lowest free address first (consecutive images lie back to back: the GPU writes a chunk of results in place with one
- * launch).  mdch_image_pool_trim releases every slab without a live image; mdch_image_pool_idle_bytes = the bytes it would release. */
+ * images, lowest free address first (consecutive images lie back to back: a chunk of results leaves the GPU with one copy).  mdch_image_pool_trim releases every slab without a live image; mdch_image_pool_idle_bytes = the bytes it would release. */
 float* mdch_image_alloc(unsigned long nfloats);
 void mdch_image_free(float* block);
 void mdch_image_pool_trim(void);
