@@ -209,6 +209,8 @@ int mdc_jpeg_idct_batch_device(mdc_ctx* ctx, const void* d_records, int64_t reco
  * mdc_process_jpeg_streams_host: stream i in place of raw frame i.  The device decodes every stream with 1024 threads
  * (subsequences of the bit stream whose entry states are relaxed until they are the sequential decoder's, csrc/mdc_jpeg.hip),
  * then runs the inverse DCT and the fused kernel as for records: the results equal the host decoder's path bit for bit.
+ * Results leave the device with one copy per run of out[] buffers that lie back to back in memory (the ExposureImage pool hands
+ * out such runs): contiguous page-locked outputs go at PCIe rate, scattered ones at about half of it.
  * status[i] (optional): 0 = done, 1 = the stream holds a code no table knows or too few blocks, 2 = header does not describe
  * a frame of this context -- out[i] is then not a result and the caller decodes that file on the host.
  * mdc_jpeg_huffman_batch_device is the device stage alone: nframes streams, stream_stride bytes apart (multiple of 16) ->
