@@ -80,7 +80,8 @@ class DatasetReader {
   // getImage on a JPEG sequence read in order (stage 2): from the third consecutive id on, the next results are made ahead in
   // one pass of the getImages pipeline with the caller's switches and handed out by the following calls: 64, then 128, then
   // 256 at a time while the caller keeps reading in order, never more than `frames` (default 256, 0 = off, also
-  // MDC_READER_LOOKAHEAD in the environment).  Another id or other switches drop what was made ahead.
+  // MDC_READER_LOOKAHEAD in the environment).  Another id or other switches drop what was made ahead.  (256 results of 640x480
+  // are 315 MB of page-locked images held by the reader until they are handed out.)
   void setResultLookahead(int frames);
   const char* lastError() const; // why the last getImage / getImages / getImageRaw returned 0 / fewer images
   void getPrefetchStats(long* hits, long* misses) const;  // frames found decoded ahead / decoded by the calling thread
