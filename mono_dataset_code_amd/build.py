@@ -123,6 +123,17 @@ def build_host_sanitize(out):
     return out
 
 
+def build_host_tsan(out):
+    """tests/native/host_tsan.cpp + the host sources under ThreadSanitizer (tests/test_sanitize.py): the reader's decode pool,
+    several readers, the image pool and the decoders from many threads.  The HIP side is the normal libmdc_hip.so."""
+    build_hip()
+    src = [os.path.join(ROOT, "tests", "native", "host_tsan.cpp")] + HOST_SOURCES
+    _run(["g++", "-O1", "-g", "-std=c++11", "-ffp-contract=off", "-fsanitize=thread", "-fno-omit-frame-pointer", "-Wall", "-I" + INC,
+          "-I" + os.path.join(INC, "mono_dataset_code"), "-I" + HOST, "-I" + eigen_include()] + src +
+         ["-L" + PKG, "-lmdc_hip", "-Wl,-rpath," + PKG, "-lz", "-lpthread", "-o", out])
+    return out
+
+
 def build_variant(name, defines):
     """Experimental build of libmdc_hip with -D switches (see MDC_EXP_* in mdc_kernels.hip);
     loaded by tools/sweep.py --lib.  Lands in mono_dataset_code_amd/variants/."""

@@ -17,17 +17,10 @@ from test_reader_cpu import make_sequence, textured
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_host_layer_under_asan_ubsan(tmp_path):
-    from mono_dataset_code_amd import build, synth
+def make_fixtures(tmp_path):
+    """valid, malformed, truncated and bit-flipped inputs for the harnesses; -> root folder"""
+    from mono_dataset_code_amd import synth
 
-    exe = str(tmp_path / "host_sanitize")
-    # skip only where the toolchain has no sanitizer runtime; a compile error in OUR sources must fail the test
-    probe = tmp_path / "probe.cpp"
-    probe.write_text("int main() { return 0; }\n")
-    if subprocess.run(["g++", "-fsanitize=address,undefined", str(probe), "-o", str(tmp_path / "probe")], stdout=subprocess.PIPE,
-                      stderr=subprocess.STDOUT).returncode != 0:
-        pytest.skip("no sanitizer runtime in this toolchain")
-    build.build_host_sanitize(exe)
     root = tmp_path / "fix"
     for d in ("images_any", "calib", "vignettes", "zips", "sequences"):
         (root / d).mkdir(parents=True)
@@ -133,8 +126,44 @@ def test_host_layer_under_asan_ubsan(tmp_path):
     struct.pack_into("<I", zb, c0 + 24, 0xFFFFFFF0)
     open(zp, "wb").write(bytes(zb))
 
+    return root
+
+
+def test_host_layer_under_asan_ubsan(tmp_path):
+    from mono_dataset_code_amd import build, synth
+
+    exe = str(tmp_path / "host_sanitize")
+    # skip only where the toolchain has no sanitizer runtime; a compile error in OUR sources must fail the test
+    probe = tmp_path / "probe.cpp"
+    probe.write_text("int main() { return 0; }\n")
+    if subprocess.run(["g++", "-fsanitize=address,undefined", str(probe), "-o", str(tmp_path / "probe")], stdout=subprocess.PIPE,
+                      stderr=subprocess.STDOUT).returncode != 0:
+        pytest.skip("no sanitizer runtime in this toolchain")
+    build.build_host_sanitize(exe)
+    root = make_fixtures(tmp_path)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe, str(root)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
     tail = r.stdout[-4000:]
     assert "AddressSanitizer" not in r.stdout and "runtime error" not in r.stdout, tail
     assert r.returncode == 0 and "HOST_SANITIZE_OK" in r.stdout, tail
+
+
+def test_host_threads_under_tsan(tmp_path):
+    """ThreadSanitizer over the host layer's threads (tests/native/host_tsan.cpp): the reader's decode pool with the caller
+    consuming, jumping, resizing the pool and dying with prefetches in flight; four readers on four threads; the ExposureImage
+    pool from eight threads with a concurrent trim; the decoders and mdch_jpeg_stream on shared input."""
+    from mono_dataset_code_amd import build
+
+    probe = tmp_path / "probe.cpp"
+    probe.write_text("#include <thread>\nint main() { std::thread t([] {}); t.join(); return 0; }\n")
+    if subprocess.run(["g++", "-fsanitize=thread", str(probe), "-lpthread", "-o", str(tmp_path / "probe")], stdout=subprocess.PIPE,
+                      stderr=subprocess.STDOUT).returncode != 0 or subprocess.run([str(tmp_path / "probe")]).returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime in this toolchain")
+    exe = str(tmp_path / "host_tsan")
+    build.build_host_tsan(exe)
+    root = make_fixtures(tmp_path)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1")
+    r = subprocess.run([exe, str(root)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
+    tail = r.stdout[-6000:]
+    assert "ThreadSanitizer" not in r.stdout, tail
+    assert r.returncode == 0 and "HOST_TSAN_OK" in r.stdout, tail
