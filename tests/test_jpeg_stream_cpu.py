@@ -181,3 +181,36 @@ def test_stream_refusals_and_small_buffers():
         capi.jpeg_stream(b"\xff\xd8\xff\xd9", big)
     with pytest.raises(ValueError):
         capi.jpeg_stream(b"", big)
+
+
+def test_stream_tables_are_cached_per_table_definition():
+    """mdch_jpeg_stream keeps the device tables of the last table definitions it saw (per thread): files with the encoder's default
+    tables and files with optimised tables in alternation must each get their own tables -- equal to what a first call builds --
+    and decode to the host decoder's record."""
+    from mono_dataset_code_amd import capi
+
+    h, w = 64, 80
+    imgs = [textured(h, w, s) for s in range(3)]
+    files = []
+    for k, img in enumerate(imgs):
+        for kw in ({"quality": 90}, {"quality": 90, "optimize": True}, {"quality": 35, "optimize": True}):
+            b = io.BytesIO()
+            Image.fromarray(img).save(b, "JPEG", **kw)
+            files.append(b.getvalue())
+    rec_bytes, pitch, rows = capi.jpeg_record_bytes(w, h)
+    bw, bh = (w + 7) // 8, (h + 7) // 8
+    first = {}
+    for order in (range(len(files)), reversed(range(len(files))), [0, 0, 1, 0, 4, 4, 8, 1]):
+        for i in order:
+            stream = np.zeros((capi.JPEG_STREAM_HEADER_BYTES + len(files[i]) + 64 + 15) & ~15, np.uint8)
+            used = capi.jpeg_stream(files[i], stream)[0]
+            if i in first:
+                assert np.array_equal(stream[:used], first[i]), i
+                continue
+            first[i] = stream[:used].copy()
+            want = np.zeros(rec_bytes, np.uint8)
+            capi.decode_jpeg_record(files[i], want, pitch)
+            got = sequential_decode(stream, pitch, rows)
+            g = got[128:].view(np.int16).reshape(rows, pitch, 64)[:bh, :bw]
+            e = want[128:rec_bytes].view(np.int16).reshape(rows, pitch, 64)[:bh, :bw]
+            assert np.array_equal(got[:128], want[:128]) and np.array_equal(g, e), i
