@@ -29,6 +29,7 @@ import argparse
 import json
 import os
 import platform
+import socket
 import subprocess
 import sys
 import tempfile
@@ -88,6 +89,10 @@ def parse():
     p.add_argument("--no-tune", action="store_true", help="keep the library's built-in tile shape / frames per workgroup instead "
                                                           "of mdc_tune_device's measured choice (untimed, before the warm-up)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-secondary", action="store_true",
+                   help="only the headline workload (default: after it, the other BASELINE.json configs are timed for "
+                        "--secondary-steps steps each and reported under \"secondary\" in the same line)")
+    p.add_argument("--secondary-steps", type=int, default=20)
     p.add_argument("--no-ceiling", action="store_true", help="skip the same-box linear-mix ceiling")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of the all-core baseline sample")
     p.add_argument("--dump-dir", default="", help="test hook: every rank writes its first --dump-frames outputs here")
@@ -220,44 +225,123 @@ def cpu_baseline(args, calib_dir, rect):
     return out
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
-    # one rank per GPU; MDC_BENCH_BACKEND=gloo lets the tests run several ranks on ONE GPU (RCCL refuses that);
-    # MDC_BENCH_FORCE_DIST=1 makes a single rank go through the process group too (RCCL init, broadcast, barrier,
-    # all-reduce of a world of one) so that the collective branch is executable on a 1-GPU box.
+WORKLOAD_TEXT = {
+    "fused": "configs[2]: fused photometric(g+v+o) + FOV bilinear remap 1280x1024 u8 -> 640x480 f32",
+    "unmap": "configs[1]: unMapImage only (g+v+o) 1280x1024 u8 -> f32",
+    "pyramid": "configs[4]: fused photometric + remap 1280x1024 -> 1280x1024 + 4-level box pyramid",
+    "seq50k": "configs[3]: one %d-frame sequence (fused photometric + remap -> 640x480), frame f on GPU f %% N",
+}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks_if_needed(args):
+    """`python bench.py --gpus N` without a launcher: become N ranks (torch.distributed.run, one per GPU), never a
+    silent single rank.  Fewer than N visible devices is an error unless the collectives run over gloo
+    (MDC_BENCH_BACKEND=gloo: the test mode in which several ranks share one GPU)."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, env_world))
+        return
+    if args.gpus <= 1:
+        return
     backend = os.environ.get("MDC_BENCH_BACKEND", "nccl")
-    use_dist = world > 1 or os.environ.get("MDC_BENCH_FORCE_DIST") == "1"
-    gpu = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(gpu)
-    dev = torch.device("cuda", gpu)
-    coll_dev = dev if backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
-    import torch.distributed as dist
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < args.gpus and backend != "gloo":
+        raise SystemExit("bench.py: --gpus %d but %d GPU(s) visible; one rank per GPU over RCCL needs %d devices "
+                         "(MDC_BENCH_BACKEND=gloo shares devices between ranks, for tests only)" % (args.gpus, ndev, args.gpus))
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
 
+class Dist:
+    """The process group of a run (or its absence): one rank per GPU."""
+
+    def __init__(self, args):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # one rank per GPU; MDC_BENCH_BACKEND=gloo lets the tests run several ranks on ONE GPU (RCCL refuses that);
+        # MDC_BENCH_FORCE_DIST=1 makes a single rank go through the process group too (RCCL init, broadcast, barrier,
+        # all-reduce of a world of one) so that the collective branch is executable on a 1-GPU box.
+        self.backend = os.environ.get("MDC_BENCH_BACKEND", "nccl")
+        self.active = self.world > 1 or os.environ.get("MDC_BENCH_FORCE_DIST") == "1"
+        ndev = torch.cuda.device_count()
+        if self.backend == "nccl" and self.world > 1 and self.local_rank >= ndev:
+            raise SystemExit("bench.py: rank %d (local %d) has no GPU of its own: %d visible" % (self.rank, self.local_rank, ndev))
+        self.gpu = self.local_rank % ndev
+        torch.cuda.set_device(self.gpu)
+        self.dev = torch.device("cuda", self.gpu)
+        self.coll_dev = self.dev if self.backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
+        if self.active:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+            assert dist.get_world_size() == self.world, "process group has %d ranks, WORLD_SIZE says %d" % (dist.get_world_size(), self.world)
+
+    def barrier(self):
+        if self.active:
+            self.dist.barrier()
+
+    def max_over_ranks(self, x):
+        if not self.active:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=self.coll_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, values):
+        """Every rank's list of floats, in rank order."""
+        if not self.active:
+            return [list(values)]
+        got = [torch.zeros(len(values), dtype=torch.float64, device=self.coll_dev) for _ in range(self.world)]
+        self.dist.all_gather(got, torch.tensor(list(values), dtype=torch.float64, device=self.coll_dev))
+        return [[float(x) for x in t.cpu()] for t in got]
+
+    def devices(self):
+        """Per rank: the device ordinal it runs on and that device's PCI bus id -- N ranks must show N different ones."""
+        p = torch.cuda.get_device_properties(self.gpu)
+        bus = float(getattr(p, "pci_bus_id", -1))
+        dom = float(getattr(p, "pci_domain_id", 0))
+        dev = float(getattr(p, "pci_device_id", 0))
+        return [{"rank": r, "device": int(v[0]), "pci": "%04x:%02x:%02x" % (int(v[1]), int(v[2]), int(v[3]))}
+                for r, v in enumerate(self.gather([float(self.gpu), dom, bus, dev]))]
+
+
+def bits_differ(want, have):
+    nw, ng = np.isnan(want), np.isnan(have)
+    return int((nw != ng).sum()) + int((want[~nw & ~ng].view(np.uint32) != have[~nw & ~ng].view(np.uint32)).sum())
+
+
+def run_workload(args, D, wl, frames, steps, warmup, preroll_s, do_ceiling, tune=True, dump=False):
+    """Time `steps` steps of one workload on every rank (barrier + synchronize on both sides, max over ranks); rank 0
+    gets the result dictionary, the others None."""
     from mono_dataset_code_amd import capi, shard, synth
 
+    world, rank, dev = D.world, D.rank, D.dev
     # ---- calibration: rank 0 builds (host C++ classes), everyone imports the blob ----
-    wl = args.workload
     rect = wl != "unmap"
-    ctx = capi.Context(gpu)
-    calib_dir = None
-    blob = None
+    ctx = capi.Context(D.gpu)
+    calib_dir = fov = photo = blob = None
     if rank == 0:
         calib_dir = tempfile.mkdtemp(prefix="mdc_bench_")
         lines = synth.CAMERA_1280_TO_640 if wl != "pyramid" else synth.camera_lines(IN_W, IN_H, IN_W, IN_H)
@@ -269,16 +353,15 @@ def main():
         assert fov.is_valid() and photo.valid() == 3
         blob = capi.pack_tables(fov, photo)  # host-side serialisation of GInv, vignetteInv, remapX/Y
     bcast_ms = None
-    if use_dist:
-        if backend == "nccl":
+    if D.active:
+        if D.backend == "nccl":
             torch.cuda.synchronize()
         t_b = time.perf_counter()
         sent = None if blob is None else blob.copy()
-        blob = shard.broadcast_tables(blob, src=0, device=coll_dev, even_alone=True)  # the only collective: once, over RCCL
-        if backend == "nccl":
+        blob = shard.broadcast_tables(blob, src=0, device=D.coll_dev, even_alone=True)  # the only collective: once, over RCCL
+        if D.backend == "nccl":
             torch.cuda.synchronize()
         bcast_ms = (time.perf_counter() - t_b) * 1e3
-        assert dist.get_world_size() == world, "process group has %d ranks, WORLD_SIZE says %d" % (dist.get_world_size(), world)
         if sent is not None:
             assert np.array_equal(sent, blob), "the broadcast changed the root's own blob"
     ctx.import_tables(blob)  # every rank (rank 0 included) uploads the same bytes
@@ -297,15 +380,13 @@ def main():
 
     # ---- this rank's shard of the synthetic sequence, generated in HBM ----------------
     if wl == "seq50k":
-        total = args.frames * world if args.frames else SEQ50K  # --frames shrinks the sequence for tests
-        mine = shard.frames_of_rank(total, rank, world)
+        total = frames * world if frames else SEQ50K  # --frames shrinks the sequence for tests
     else:
         # pyramid: 1024 frames = 1.3 GB in + 7.1 GB out.  Not fewer: below ~384 frames the raw batch (1.3 MB a frame) partly
         # survives in the 256-MiB Infinity Cache from one step to the next and the rate comes out up to 40 % too high
         # (tools/footprint_curve.py, profiles/r02c_footprint_curve.txt)
-        per = args.frames or (1024 if wl == "pyramid" else 4096)
-        total = per * world
-        mine = shard.frames_of_rank(total, rank, world)
+        total = (frames or (1024 if wl == "pyramid" else 4096)) * world
+    mine = shard.frames_of_rank(total, rank, world)
     B = len(mine)
     npix_in, npix_out = IN_W * IN_H, out_w * out_h
     tstream = torch.cuda.Stream(device=dev)  # every launch and every timing event goes on this stream
@@ -323,7 +404,7 @@ def main():
         d_levels = [torch.empty(B * (out_w >> l) * (out_h >> l), dtype=torch.float32, device=dev) for l in range(1, levels)]
     flags = capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED | (capi.RECTIFY if rect else 0)
     tuned = None
-    if wl in ("fused", "seq50k") and args.kernel == "auto" and not (args.no_tune or args.fpb or args.tile_rows or args.tile_cols or args.nbuf):
+    if tune and wl in ("fused", "seq50k") and args.kernel == "auto" and not (args.no_tune or args.fpb or args.tile_rows or args.tile_cols or args.nbuf):
         # plan selection by measurement, on (a part of) this rank's own batch; untimed set-up like the table build
         t = ctx.tune(d_in.data_ptr(), d_out.data_ptr(), min(B, 4096), flags, stream)
         tuned = {"tile": [t.tile_w, t.tile_h], "frames_per_workgroup": t.frames_per_block, "candidates": t.candidates,
@@ -332,49 +413,39 @@ def main():
     kernel_name = ctx.describe_launch(flags, levels if wl == "pyramid" else 0)
 
     def step():
-        if wl == "pyramid":  # base + levels 1..3 in one launch
+        if wl == "pyramid":  # base + levels 1..3 in one call
             ctx.process_pyramid_batch(d_in.data_ptr(), d_out.data_ptr(), levels, [t.data_ptr() for t in d_levels], B, flags, stream)
         else:
             ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), B, flags, stream)
 
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.preroll_s:  # untimed: bring the clocks to their steady state
+    while time.perf_counter() - t_pre < preroll_s:  # untimed: bring the clocks to their steady state
         for _ in range(3):
             step()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps between barrier+sync on both sides -----------------
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if use_dist:
-        dist.barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for a, b in evs:
         a.record()
         step()
-        b.record()  # brackets the one kernel of a step (same stream as the launch)
+        b.record()  # brackets the launches of a step (same stream as the launch)
     torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
+    D.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(time.perf_counter() - t0)
     ktimes = np.array([a.elapsed_time(b) for a, b in evs], dtype=np.float64)
     kstat = [float(ktimes.mean()), float(np.median(ktimes)), float(ktimes.min())]
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        allk = [torch.zeros(3, dtype=torch.float64, device=coll_dev) for _ in range(world)]
-        dist.all_gather(allk, torch.tensor(kstat, dtype=torch.float64, device=coll_dev))
-        per_rank_kernel_ms = [[round(float(x), 4) for x in t.cpu()] for t in allk]
-    else:
-        per_rank_kernel_ms = [[round(x, 4) for x in kstat]]
+    per_rank_kernel_ms = [[round(x, 4) for x in k] for k in D.gather(kstat)]
 
     # ---- test hook: every rank hands out its first outputs (checked against the oracle per GLOBAL frame index) ----
-    if args.dump_dir and args.dump_frames > 0:
+    if dump and args.dump_dir and args.dump_frames > 0:
         n = min(args.dump_frames, B)
         np.save(os.path.join(args.dump_dir, "rank%d_out.npy" % rank), d_out[: n * npix_out].cpu().numpy().reshape(n, npix_out))
         np.save(os.path.join(args.dump_dir, "rank%d_idx.npy" % rank), np.asarray(mine[:n], dtype=np.int64))
@@ -388,8 +459,10 @@ def main():
         if wl == "pyramid":  # + levels 1..3 written
             alg_write += 4 * sum((out_w >> l) * (out_h >> l) for l in range(1, levels))
     alg_frame = alg_read + alg_write
+    if rank != 0:
+        return None
     ceiling = None
-    if rank == 0 and not args.no_ceiling:
+    if do_ceiling:
         wbytes = min(alg_write * B, d_out.numel() * 4)
         rbytes = min(alg_read * B, d_in.numel()) // 16 * 16
         reps = 12
@@ -416,89 +489,121 @@ def main():
                    "what": "linear 16-B reads + wave-contiguous nt dword writes of the launch's ALGORITHMIC bytes, same process; "
                            "fastest of 6 launch shapes: %d workgroups, %s" % (cblocks, "contiguous span per workgroup" if cspan else "grid-stride")}
 
-    if rank == 0:
-        # spot parity of the benchmarked launch against the C oracle (2 frames; pyramid: every level)
-        parity = None
-        try:
-            from oracle import loader
-            O = loader.Oracle()
-            rx, ry = fov.remap()
-            _, vinv = photo.vignette()
-            got = d_out[: 2 * npix_out].cpu().numpy().reshape(2, npix_out)
-            raw = d_in[: 2 * npix_in].cpu().numpy().reshape(2, npix_in)
-            bad = 0
+    # ---- spot parity of the benchmarked launch against the C oracle (first and last frame; pyramid: every level) ----
+    try:
+        from oracle import loader
+        O = loader.Oracle()
+    except OSError as e:  # no oracle library on this box: say so, never drop the field
+        O = None
+        parity = "unavailable (%s)" % str(e)[:120]
+    if O is not None:
+        rx, ry = fov.remap()
+        _, vinv = photo.vignette()
+        bad = 0
+        checked = sorted({0, B - 1})
+        for f in checked:
+            raw = d_in[f * npix_in:(f + 1) * npix_in].cpu().numpy()
+            assert np.array_equal(raw, synth.noise_frames(int(mine[f]), 1, npix_in)[0]), "frame %d is not global frame %d" % (f, mine[f])
+            want = O.get_image(raw, IN_W, IN_H, out_w, out_h, photo.ginv(), vinv, True, True, rx, ry, rect, True, True, True)
+            bad += bits_differ(want, d_out[f * npix_out:(f + 1) * npix_out].cpu().numpy())
+            src, cw, ch = want, out_w, out_h
+            for t in d_levels:
+                src = O.pyramid_level(src, cw, ch)
+                cw, ch = cw // 2, ch // 2
+                bad += bits_differ(src, t[f * cw * ch:(f + 1) * cw * ch].cpu().numpy())
+        parity = {"frames_checked": len(checked), "levels_checked": 1 + len(d_levels), "mismatching_pixels": bad}
 
-            def diff(want, have):
-                nw, ng = np.isnan(want), np.isnan(have)
-                return int((nw != ng).sum()) + int((want[~nw & ~ng].view(np.uint32) != have[~nw & ~ng].view(np.uint32)).sum())
+    frames_total = total * steps
+    kernel_ms, kernel_med, kernel_min = kstat
+    achieved = alg_frame * B / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_src = traffic_from_profiles(kernel_name, B)
+    roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4), "kernel_ms_median": round(kernel_med, 4),
+            "kernel_ms_min": round(kernel_min, 4), "frac_at_median": round(alg_frame * B / (kernel_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_frame": alg_frame, "algorithmic_read_bytes_per_frame": alg_read,
+            "frames_per_launch": B, "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
+            "tile": [info.tile_w, info.tile_h] if rect and info.tiled else None, "window_buffers": info.window_buffers if rect else None}
+    if wl == "pyramid" and info.prefetch_chunk and B >= 2 * info.prefetch_chunk:
+        # the strip path walks the batch in chunks: per chunk one linear prefetch of the next chunk's source rows into the
+        # Infinity Cache + one remap launch.  kernel_ms is the time of ALL launches of a step (HIP events around the
+        # call); the prefetch's reads are extra traffic, not algorithmic bytes.
+        nchunk = -(-B // info.prefetch_chunk)
+        roof["launches_per_step"] = {"remap_strip_kernel": nchunk, "prefetch_rows_kernel": nchunk, "frames_per_chunk": info.prefetch_chunk,
+                                     "streams": info.prefetch_streams}
+    if ceiling is not None:
+        roof["same_box_mix_ceiling"] = ceiling
+        roof["frac_of_same_box_mix_ceiling"] = round(ceiling["ms_median"] / kernel_med, 4)
+    if D.active:
+        roof["per_rank_kernel_ms_mean_median_min"] = per_rank_kernel_ms
+        roof["per_rank_frac"] = [round(alg_frame * B / (k[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k in per_rank_kernel_ms]
+    text = WORKLOAD_TEXT[wl] % total if wl == "seq50k" else WORKLOAD_TEXT[wl]
+    return {
+        "value": round(frames_total * npix_in / 1e6 / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps,
+        "scaling": "strong" if wl == "seq50k" else "weak", "parity": parity, "roofline": roof,
+        "config": {"workload": text, "frames_per_gpu_per_step": B, "sequence_frames": total if wl == "seq50k" else None,
+                   "preroll_s": preroll_s, "sharding": "round-robin frame f -> rank f %% %d" % world,
+                   "tables": ("rank-0 build + one %s broadcast" % ("RCCL" if D.backend == "nccl" else D.backend)) if D.active else "local build",
+                   "collective_backend": D.backend if D.active else None,
+                   "table_broadcast_ms": round(bcast_ms, 3) if bcast_ms is not None else None,
+                   "table_blob_bytes": int(blob.size),
+                   "plan": tuned if tuned is not None else "built-in",
+                   "frames_per_s": round(frames_total / elapsed, 1),
+                   "out_mpix_per_s": round(frames_total * npix_out / 1e6 / elapsed, 1)},
+        "_calib_dir": calib_dir, "_rect": rect,
+    }
 
-            for f in range(2):
-                assert np.array_equal(raw[f], synth.noise_frames(int(mine[f]), 1, npix_in)[0]), "frame %d is not global frame %d" % (f, mine[f])
-                want = O.get_image(raw[f], IN_W, IN_H, out_w, out_h, photo.ginv(), vinv, True, True, rx, ry, rect, True, True, True)
-                bad += diff(want, got[f])
-                src, cw, ch = want, out_w, out_h
-                for l, t in enumerate(d_levels):
-                    src = O.pyramid_level(src, cw, ch)
-                    cw, ch = cw // 2, ch // 2
-                    bad += diff(src, t[f * cw * ch:(f + 1) * cw * ch].cpu().numpy())
-            parity = {"frames_checked": 2, "levels_checked": 1 + len(d_levels), "mismatching_pixels": bad}
-        except OSError:
-            pass
 
-        frames_total = total * args.steps
-        mpix = frames_total * npix_in / 1e6 / elapsed
-        kernel_ms, kernel_med, kernel_min = kstat
-        achieved = alg_frame * B / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = traffic_from_profiles(kernel_name, B)
-        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4), "kernel_ms_median": round(kernel_med, 4),
-                "kernel_ms_min": round(kernel_min, 4), "frac_at_median": round(alg_frame * B / (kernel_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "algorithmic_bytes_per_frame": alg_frame, "algorithmic_read_bytes_per_frame": alg_read,
-                "frames_per_launch": B, "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
-                "tile": [info.tile_w, info.tile_h] if rect and info.tiled else None, "window_buffers": info.window_buffers if rect else None}
-        if wl == "pyramid" and info.prefetch_chunk and B >= 2 * info.prefetch_chunk:
-            # the strip path walks the batch in chunks: per chunk one linear prefetch of the next chunk's source rows into the
-            # Infinity Cache + one remap launch.  kernel_ms is the time of ALL launches of a step (HIP events around the
-            # call); the prefetch's reads are extra traffic, not algorithmic bytes.
-            nchunk = -(-B // info.prefetch_chunk)
-            roof["launches_per_step"] = {"remap_strip_kernel": nchunk, "prefetch_rows_kernel": nchunk, "frames_per_chunk": info.prefetch_chunk,
-                                         "streams": info.prefetch_streams}
-        if ceiling is not None:
-            roof["same_box_mix_ceiling"] = ceiling
-            roof["frac_of_same_box_mix_ceiling"] = round(ceiling["ms_median"] / kernel_med, 4)
-        if world > 1 or use_dist:
-            roof["per_rank_kernel_ms_mean_median_min"] = per_rank_kernel_ms
-            roof["per_rank_frac"] = [round(alg_frame * B / (k[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k in per_rank_kernel_ms]
+def main():
+    args = parse()
+    launch_ranks_if_needed(args)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
+    D = Dist(args)
+    from mono_dataset_code_amd import capi
+
+    wl = args.workload
+    head = run_workload(args, D, wl, args.frames, args.steps, args.warmup, args.preroll_s, do_ceiling=not args.no_ceiling, dump=True)
+    devices = D.devices() if D.active else [{"rank": 0, "device": D.gpu}]
+    # ---- the other BASELINE.json configs, timed in the same process (same box, same clocks) -------------------------
+    # N = 1: configs[1] unMapImage, configs[4] pyramid, configs[3] as one 50,000-frame sequence on the one GPU.
+    # N > 1: configs[3] as BASELINE.json words it -- the one sequence dealt round-robin over the ranks (strong scaling).
+    secondary = None
+    if wl == "fused" and not args.no_secondary and not args.frames:
+        secondary = {}
+        todo = ("unmap", "pyramid", "seq50k") if D.world == 1 else ("seq50k",)
+        for w2 in todo:
+            torch.cuda.empty_cache()
+            r = run_workload(args, D, w2, 1024 if w2 != "seq50k" else 0, args.secondary_steps, 3, 0.05, do_ceiling=not args.no_ceiling)
+            if r is not None:
+                rf = r["roofline"]
+                secondary[w2] = {"workload": r["config"]["workload"], "value": r["value"], "unit": "Mpix/s", "scaling": r["scaling"],
+                                 "steps": r["steps"], "ms_per_step": r["ms_per_step"], "frames_per_gpu_per_step": r["config"]["frames_per_gpu_per_step"],
+                                 "kernel": rf["kernel"], "kernel_ms": rf["kernel_ms"], "frac": rf["frac"],
+                                 "frac_of_same_box_mix_ceiling": rf.get("frac_of_same_box_mix_ceiling"),
+                                 "algorithmic_bytes_per_frame": rf["algorithmic_bytes_per_frame"],
+                                 "traffic": rf["traffic"], "traffic_source": rf["traffic_source"],
+                                 "launches_per_step": rf.get("launches_per_step"), "per_rank_frac": rf.get("per_rank_frac"),
+                                 "plan": r["config"]["plan"], "parity": r["parity"]}
+    if D.rank == 0:
         out = {
             "metric": "Mpix/s photometric+FOV undistort, 1280x1024 gray",
-            "value": round(mpix, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "strong" if wl == "seq50k" else "weak",
+            "value": head["value"], "unit": "Mpix/s", "n_gpus": D.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"fused": "configs[2]: fused photometric(g+v+o) + FOV bilinear remap 1280x1024 u8 -> 640x480 f32",
-                                    "unmap": "configs[1]: unMapImage only (g+v+o) 1280x1024 u8 -> f32",
-                                    "pyramid": "configs[4]: fused photometric + remap 1280x1024 -> 1280x1024 + 4-level box pyramid",
-                                    "seq50k": "configs[3]: one %d-frame sequence (fused photometric + remap -> 640x480), frame f on GPU f %% N" % total}[wl],
-                       "frames_per_gpu_per_step": B, "sequence_frames": total if wl == "seq50k" else None,
-                       "preroll_s": args.preroll_s, "sharding": "round-robin frame f -> rank f %% %d" % world,
-                       "tables": ("rank-0 build + one %s broadcast" % ("RCCL" if backend == "nccl" else backend)) if use_dist else "local build",
-                       "collective_backend": backend if use_dist else None,
-                       "table_broadcast_ms": round(bcast_ms, 3) if bcast_ms is not None else None,
-                       "table_blob_bytes": int(blob.size),
-                       "plan": tuned if tuned is not None else "built-in",
-                       "frames_per_s": round(frames_total / elapsed, 1),
-                       "out_mpix_per_s": round(frames_total * npix_out / 1e6 / elapsed, 1)},
-            "roofline": roof,
+            "config": head["config"], "roofline": head["roofline"], "parity": head["parity"],
+            "ranks": {"world": D.world, "backend": D.backend if D.active else None,
+                      "rccl_ranks": D.dist.get_world_size() if D.active and D.backend == "nccl" else None, "devices": devices},
+            "build_flags": capi.build_flags(),
         }
-        if parity is not None:
-            out["parity"] = parity
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, calib_dir, rect)
+        if secondary is not None:
+            out["secondary"] = secondary
+        if D.world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, head["_calib_dir"], head["_rect"])
         print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if D.active:
+        D.dist.barrier()
+        D.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -3,7 +3,7 @@
  *
  * NOT part of the product (nothing of the reference corresponds to these; libmdc_hip.so / libmdc_host.so /
  * libmdc_multi.so neither link nor load this library).  Used by bench.py, tools/ and tests/ only.
- * Both functions enqueue on `stream` (hipStream_t as void*, NULL = default stream) of HIP device `device`
+ * The stream functions enqueue on `stream` (hipStream_t as void*, NULL = default stream) of HIP device `device`
  * (-1 = the calling thread's current device) without synchronising; 0 = ok, negative = error.
  */
 #ifndef MDC_BENCH_H
@@ -23,6 +23,12 @@ int mdcb_synth_frames_device(int device, uint8_t* d_out, int64_t first_frame, in
  * the fastest of several (blocks, span) settings. */
 int mdcb_ceiling_mix_device(int device, const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes, int blocks, int span,
                             void* stream);
+
+/* Diagnosis (tools/mall_bracket.py): a device range of repeats * chunk_bytes virtual addresses that all map ONE physical
+ * allocation of chunk_bytes (HIP virtual memory management; chunk_bytes must be a multiple of *out_granularity, which is
+ * also returned on the -3 "not a whole number of pages" error).  Synchronous. */
+int mdcb_alias_alloc(int device, int64_t chunk_bytes, int repeats, void** out_ptr, int64_t* out_granularity);
+int mdcb_alias_free(int device, void* ptr, int64_t chunk_bytes, int repeats);
 
 #ifdef __cplusplus
 }

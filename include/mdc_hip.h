@@ -138,6 +138,10 @@ void mdc_destroy(mdc_ctx* ctx);
 const char* mdc_last_error(const mdc_ctx* ctx); /* never NULL; "" if no error; ctx may be NULL (creation errors) */
 int mdc_get_info(mdc_ctx* ctx, mdc_info* info);
 int mdc_set_option(mdc_ctx* ctx, int option, int value);
+/* Build-time switches of this library that are NOT at their shipped value, "NAME=value ..." (csrc/mdc_build_config.h):
+ * "" for the product build.  Anything else is an experiment / debug / diagnosis build (mono_dataset_code_amd/variants/);
+ * a diagnosis build computes wrong results on purpose and says MDC_DIAGNOSIS_BUILD here.  Never NULL, static storage. */
+const char* mdc_build_flags(void);
 
 /* ---- calibration tables (once per sequence) -------------------------------- */
 

@@ -28,7 +28,7 @@ OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM = 0, -1, -2,
 
 # every symbol include/mdc_hip.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = [
-    "mdc_create", "mdc_destroy", "mdc_last_error", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
+    "mdc_create", "mdc_destroy", "mdc_last_error", "mdc_build_flags", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
     "mdc_set_remap", "mdc_unmap_host", "mdc_undistort_host_f32", "mdc_undistort_host_u8", "mdc_process_host",
     "mdc_host_alloc", "mdc_host_free", "mdc_process_frames_host", "mdc_process_jpeg_frames_host", "mdc_jpeg_idct_batch_device", "mdc_process_jpeg_streams_host", "mdc_jpeg_huffman_batch_device",
     "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
@@ -94,7 +94,7 @@ def _share_hip_runtime_with_torch():
 
 
 LIB_BENCH_PATH = os.path.join(_PKG, "libmdc_bench.so")
-BENCH_SYMBOLS = ["mdcb_synth_frames_device", "mdcb_ceiling_mix_device"]  # include/mdc_bench.h (not the product ABI)
+BENCH_SYMBOLS = ["mdcb_synth_frames_device", "mdcb_ceiling_mix_device", "mdcb_alias_alloc", "mdcb_alias_free"]  # include/mdc_bench.h (not the product ABI)
 _bench = None
 
 
@@ -108,6 +108,8 @@ def bench_lib():
         L = C.CDLL(LIB_BENCH_PATH)
         L.mdcb_synth_frames_device.argtypes = [_i, _vp, _i64, _i64, _i, _u32, _vp]
         L.mdcb_ceiling_mix_device.argtypes = [_i, _vp, C.c_int64, _vp, C.c_int64, _i, _i, _vp]
+        L.mdcb_alias_alloc.argtypes = [_i, C.c_int64, _i, C.POINTER(_vp), C.POINTER(C.c_int64)]
+        L.mdcb_alias_free.argtypes = [_i, _vp, C.c_int64, _i]
         _bench = L
     return _bench
 
@@ -124,6 +126,9 @@ def hip_lib():
         L.mdc_destroy.restype = None
         L.mdc_last_error.argtypes = [_vp]
         L.mdc_last_error.restype = C.c_char_p
+        if hasattr(L, "mdc_build_flags"):  # (absent from libraries built before round 4: tools/sweep.py --libs)
+            L.mdc_build_flags.argtypes = []
+            L.mdc_build_flags.restype = C.c_char_p
         L.mdc_get_info.argtypes = [_vp, C.POINTER(MdcInfo)]
         L.mdc_set_option.argtypes = [_vp, _i, _i]
         L.mdc_set_photometric.argtypes = [_vp, _vp, _vp, _i, _i]
@@ -180,11 +185,17 @@ def hip_lib():
         for n in HIP_SYMBOLS:
             if old_build and not hasattr(L, n):
                 continue
-            if n not in ("mdc_destroy", "mdc_last_error", "mdc_host_alloc", "mdc_host_free", "mdc_vcal_index_destroy",
+            if n not in ("mdc_destroy", "mdc_last_error", "mdc_build_flags", "mdc_host_alloc", "mdc_host_free", "mdc_vcal_index_destroy",
                          "mdc_vcal_index_bytes", "mdc_vcal_index_entries"):
                 getattr(L, n).restype = _i
         _hip = L
     return _hip
+
+
+def build_flags():
+    """Build-time switches of the loaded libmdc_hip.so that are not at their shipped value ("" = the product build)."""
+    L = hip_lib()
+    return L.mdc_build_flags().decode() if hasattr(L, "mdc_build_flags") else "unknown (library predates mdc_build_flags)"
 
 
 def host_lib():

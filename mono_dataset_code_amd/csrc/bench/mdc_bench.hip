@@ -2,6 +2,7 @@
 // reference corresponds to these, the product libraries do not link or load this one.
 //   mdcb_synth_frames_device : the synthetic sequence generator of SURVEY.md 8(d)
 //   mdcb_ceiling_mix_device  : a linear read + write stream of given byte counts (the same-box yardstick of bench.py)
+//   mdcb_alias_alloc / _free : a device range whose virtual pages map ONE physical chunk over and over (tools/mall_bracket.py)
 #include "../../../include/mdc_bench.h"
 
 #include <hip/hip_runtime.h>
@@ -108,6 +109,58 @@ int mdcb_ceiling_mix_device(int device, const void* d_read, int64_t read_bytes, 
   if (span) mix_ceiling_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const u32x4*>(d_read), d_write, n_r, n_w);
   else mix_ceiling_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const u32x4*>(d_read), d_write, n_r, n_w);
   return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// One physical allocation of chunk_bytes mapped `repeats` times back to back into a fresh virtual range: a kernel walking
+// repeats * chunk_bytes of addresses touches only chunk_bytes of memory.  With the chunk below the 256-MiB Infinity Cache
+// every read of the range is served on-die -- the SAME launch (same addresses per workgroup, same instruction stream, same
+// fabric request counts) with and without its reads reaching HBM.
+int mdcb_alias_alloc(int device, int64_t chunk_bytes, int repeats, void** out_ptr, int64_t* out_granularity) {
+  if (chunk_bytes <= 0 || repeats <= 0 || !out_ptr) return -1;
+  DeviceGuard dg(device);
+  int dev = device;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return -4;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) return -4;
+  if (out_granularity) *out_granularity = (int64_t)gran;
+  if ((size_t)chunk_bytes % gran != 0) return -3;  // the caller picks a chunk that is a whole number of pages
+  hipMemGenericAllocationHandle_t h;
+  if (hipMemCreate(&h, (size_t)chunk_bytes, &prop, 0) != hipSuccess) return -4;
+  void* va = nullptr;
+  const size_t total = (size_t)chunk_bytes * (size_t)repeats;
+  if (hipMemAddressReserve(&va, total, gran, nullptr, 0) != hipSuccess) {
+    (void)hipMemRelease(h);
+    return -4;
+  }
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  for (int r = 0; r < repeats; r++) {
+    char* at = static_cast<char*>(va) + (size_t)r * (size_t)chunk_bytes;
+    if (hipMemMap(at, (size_t)chunk_bytes, 0, h, 0) != hipSuccess || hipMemSetAccess(at, (size_t)chunk_bytes, &acc, 1) != hipSuccess) {
+      for (int k = 0; k <= r; k++) (void)hipMemUnmap(static_cast<char*>(va) + (size_t)k * (size_t)chunk_bytes, (size_t)chunk_bytes);
+      (void)hipMemAddressFree(va, total);
+      (void)hipMemRelease(h);
+      return -4;
+    }
+  }
+  (void)hipMemRelease(h);  // the mappings keep the physical memory alive
+  *out_ptr = va;
+  return 0;
+}
+
+int mdcb_alias_free(int device, void* ptr, int64_t chunk_bytes, int repeats) {
+  if (!ptr) return 0;
+  DeviceGuard dg(device);
+  int rc = 0;
+  for (int r = 0; r < repeats; r++)
+    if (hipMemUnmap(static_cast<char*>(ptr) + (size_t)r * (size_t)chunk_bytes, (size_t)chunk_bytes) != hipSuccess) rc = -4;
+  if (hipMemAddressFree(ptr, (size_t)chunk_bytes * (size_t)repeats) != hipSuccess) rc = -4;
+  return rc;
 }
 
 }  // extern "C"

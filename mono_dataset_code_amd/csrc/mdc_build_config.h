@@ -1,0 +1,108 @@
+// Build-time switches of libmdc_hip, in one place.
+//
+// Three kinds:
+//   tuning     the shipped value is the measured best; other values give the SAME results (bit for bit) at another speed
+//   debug      MDC_DEBUG_BOUNDS: every tap / staging chunk / gather index is checked in the kernel, a violation traps
+//   diagnosis  WRONG RESULTS BY DESIGN (a stream compiled out, arithmetic replaced): for taking a kernel apart only
+//
+// A diagnosis switch compiles only under MDC_DIAGNOSIS_BUILD, which mono_dataset_code_amd/build.py:build_variant sets and
+// which puts the library under mono_dataset_code_amd/variants/ -- never next to the product.  mdc_build_flags() (include/mdc_hip.h)
+// returns every switch that is not at its shipped value; the product library must return "" (tests/test_abi.py), and
+// bench.py prints it in its line.
+#pragma once
+#include <string>
+
+// ---- tuning ------------------------------------------------------------------------------------------------------
+#ifndef MDC_EXP_LUT_REP
+#define MDC_EXP_LUT_REP 32  // LDS replicas of the 256-entry response LUT (32 = one per bank, conflict-free)
+#endif
+#ifndef MDC_EXP_STRIP_WAVES
+#define MDC_EXP_STRIP_WAVES 4  // strip kernel: waves (tiles) per workgroup, sharing the LUT replicas
+#endif
+#ifndef MDC_EXP_LOAD_NT
+#define MDC_EXP_LOAD_NT 0   // staging loads: plain (L2-allocating) -- neighbouring tiles re-use halo lines; nt measured slower
+#endif
+#ifndef MDC_EXP_STORE_NT
+#define MDC_EXP_STORE_NT 1  // output stores carry the nontemporal hint
+#endif
+#ifndef MDC_EXP_STRIP_LUT_REP
+#define MDC_EXP_STRIP_LUT_REP 8  // LUT replicas of the strip kernel (8 KiB): its LUT reads are per SOURCE pixel, a few bank conflicts cost little
+#endif
+#ifndef MDC_EXP_STRIP_WAVES_PER_EU
+#define MDC_EXP_STRIP_WAVES_PER_EU 5  // register budget of the strip kernel: 512 / 5 -> 100 VGPRs
+#endif
+#ifndef MDC_EXP_GUESS_DIV
+#define MDC_EXP_GUESS_DIV 4  // device Huffman decoder: the first guess decodes the last 1/4 of the left neighbour's subsequence
+#endif
+// MDC_EXP_STORE_AUX (undefined = follow MDC_EXP_STORE_NT): raw cache-policy bits of the output stores
+
+// ---- debug -------------------------------------------------------------------------------------------------------
+#ifndef MDC_DEBUG_BOUNDS
+#define MDC_DEBUG_BOUNDS 0
+#endif
+
+// ---- diagnosis (wrong results) -------------------------------------------------------------------------------------
+#ifndef MDC_EXP_SKIP_STORE
+#define MDC_EXP_SKIP_STORE 0  // outputs are computed but (practically) never stored -> read side alone
+#endif
+#ifndef MDC_EXP_SKIP_LOAD
+#define MDC_EXP_SKIP_LOAD 0   // every frame re-stages frame 0 (L2 hits) -> write side alone
+#endif
+#ifndef MDC_EXP_FAKE_COMPUTE
+#define MDC_EXP_FAKE_COMPUTE 0  // 1 = one tap + one LUT read per output instead of 4 + 4, 2 = no LDS reads
+#endif
+#ifndef MDC_EXP_STRIP_NOCONVERT
+#define MDC_EXP_STRIP_NOCONVERT 0  // the strip kernel skips its convert phase
+#endif
+#ifndef MDC_EXP_STRIP_NOSAMPLE
+#define MDC_EXP_STRIP_NOSAMPLE 0   // the strip kernel stores a register instead of sampling
+#endif
+#ifndef MDC_EXP_TIMING
+#define MDC_EXP_TIMING 0      // some waves print the cycles their frame loop spent per phase (tools/phase_timing.sh): right results, device printf
+#endif
+// MDC_EXP_HUFF_ROUNDS (undefined): the Huffman kernel reports its relaxation rounds in the status word's upper bits
+
+#if (MDC_EXP_SKIP_STORE || MDC_EXP_SKIP_LOAD || MDC_EXP_FAKE_COMPUTE || MDC_EXP_STRIP_NOCONVERT || MDC_EXP_STRIP_NOSAMPLE || \
+     MDC_EXP_TIMING || defined(MDC_EXP_HUFF_ROUNDS)) && !defined(MDC_DIAGNOSIS_BUILD)
+#error "a diagnosis switch (wrong results / device printf) is set: build through mono_dataset_code_amd/build.py:build_variant, which defines MDC_DIAGNOSIS_BUILD and writes to variants/"
+#endif
+
+// "NAME=value NAME=value ..." of everything that is not at its shipped value ("" for the product build)
+#define MDC_CFG_STR2(x) #x
+#define MDC_CFG_STR(x) MDC_CFG_STR2(x)
+#define MDC_CFG_ITEM(name, shipped) ((name) != (shipped) ? " " #name "=" MDC_CFG_STR(name) : "")
+namespace mdc {
+inline const char* build_flags_string() {
+  static const char* const parts[] = {
+#ifdef MDC_DIAGNOSIS_BUILD
+      " MDC_DIAGNOSIS_BUILD",
+#endif
+      MDC_CFG_ITEM(MDC_EXP_LUT_REP, 32),
+      MDC_CFG_ITEM(MDC_EXP_STRIP_WAVES, 4),
+      MDC_CFG_ITEM(MDC_EXP_LOAD_NT, 0),
+      MDC_CFG_ITEM(MDC_EXP_STORE_NT, 1),
+      MDC_CFG_ITEM(MDC_EXP_STRIP_LUT_REP, 8),
+      MDC_CFG_ITEM(MDC_EXP_STRIP_WAVES_PER_EU, 5),
+      MDC_CFG_ITEM(MDC_EXP_GUESS_DIV, 4),
+#ifdef MDC_EXP_STORE_AUX
+      " MDC_EXP_STORE_AUX=" MDC_CFG_STR(MDC_EXP_STORE_AUX),
+#endif
+      MDC_CFG_ITEM(MDC_DEBUG_BOUNDS, 0),
+      MDC_CFG_ITEM(MDC_EXP_SKIP_STORE, 0),
+      MDC_CFG_ITEM(MDC_EXP_SKIP_LOAD, 0),
+      MDC_CFG_ITEM(MDC_EXP_FAKE_COMPUTE, 0),
+      MDC_CFG_ITEM(MDC_EXP_STRIP_NOCONVERT, 0),
+      MDC_CFG_ITEM(MDC_EXP_STRIP_NOSAMPLE, 0),
+      MDC_CFG_ITEM(MDC_EXP_TIMING, 0),
+#ifdef MDC_EXP_HUFF_ROUNDS
+      " MDC_EXP_HUFF_ROUNDS",
+#endif
+  };
+  static const std::string joined = [] {  // thread-safe one-time initialisation
+    std::string r;
+    for (const char* p : parts) r += (r.empty() && *p == ' ') ? p + 1 : p;
+    return r;
+  }();
+  return joined.c_str();
+}
+}  // namespace mdc

@@ -341,7 +341,7 @@ int upload(mdc_ctx* c, T** dst, const std::vector<T>& v) {
 // frame rows are not whole chunks or a window is too large.
 int plan_source(mdc_ctx* c, int es, int kTileW, int kTileH, mdc_ctx::SrcPlan& pl) {
   const int ow = c->out_w, oh = c->out_h, iw = c->rm_in_w;
-  const int kTileThreads = kTileW * kTileH / 4;
+  const int kTileThreads = tile_threads(kTileW, kTileH);
   pl.staged_bytes = 0;
   const int tx = (ow + kTileW - 1) / kTileW, ty = (oh + kTileH - 1) / kTileH;
   const int n_tiles = tx * ty;
@@ -350,8 +350,9 @@ int plan_source(mdc_ctx* c, int es, int kTileW, int kTileH, mdc_ctx::SrcPlan& pl
   // whole 16-byte chunks per frame row; one frame within the 32-bit lane offsets of the buffer descriptors
   const char* why = "frame rows are not whole chunks / frame too large";
   bool ok = (iw % ppc == 0) && (int64_t)iw * c->rm_in_h * es < (int64_t)kOutside && (int64_t)ow * oh * 4 < (int64_t)kOutside;
+  if (tile_rpt(kTileW, kTileH) != 4 && es != 1) ok = false;  // the 8-rows-per-thread tiles exist for raw u8 frames only
   // the 960-/1024-thread tiles derive the output offsets of rows 1..3 from row 0 (kOutsideLean, mdc_kernels.hip)
-  if (kTileThreads >= 960 && (int64_t)ow * (oh + kTileH) * 4 >= 0xc0000000ll) ok = false;
+  if ((kTileThreads >= 960 || tile_rpt(kTileW, kTileH) > 4) && (int64_t)ow * (oh + kTileH) * 4 >= 0xc0000000ll) ok = false;
   std::vector<std::vector<uint32_t>> chunks(n_tiles);
   std::vector<int> nch(n_tiles, 0);
   std::vector<uint32_t> taps((size_t)ow * oh, 0u);
@@ -421,6 +422,7 @@ int plan_source(mdc_ctx* c, int es, int kTileW, int kTileH, mdc_ctx::SrcPlan& pl
   int nbuf = 2;
   while (nbuf < nbuf_max && tiled_lds_bytes(win_bytes, nbuf + 1, lut) * wg_per_cu <= kLdsPerCU) nbuf++;
   if (c->opt_nbuf >= 2) nbuf = std::min(c->opt_nbuf, nbuf_max);
+  if (tile_rpt(kTileW, kTileH) > 4) nbuf = 3;  // the only instantiation of the 8-rows-per-thread tiles (mdc_kernels.hip: launch_tiled_buf)
   if (tiled_lds_bytes(win_bytes, nbuf, lut) > kLdsPerCU) {
     ok = false;
     why = "windows do not fit LDS";
@@ -571,13 +573,17 @@ int plan_tiles(mdc_ctx* c) {
   // (128 x 16 first: measured 5-7 % faster than 64 x 32 on the bench camera -- a 64-wide tile spans ~86 source
   // bytes, less than one 128-byte line, so nearly every line is fetched by two workgroups; at 128 columns far
   // fewer are.  profiles/r02_experiments/)
-  static const TileShape cand_u8[] = {{128, 16}, {64, 32}, {128, 32}, {64, 64}, {64, 60}, {64, 16}};
-  static const TileShape cand_f32[] = {{128, 16}, {64, 32}, {64, 16}, {128, 32}, {64, 64}, {64, 60}};  // 0.66 / 0.63 / 0.60 / 0.60 / 0.54 of 8 TB/s
+  static const TileShape cand_u8[] = {{128, 16}, {64, 32}, {128, 32}, {64, 64}, {64, 60}, {64, 16}, {320, 16}, {640, 8}};
+  static const TileShape cand_f32[] = {{128, 16}, {64, 32}, {64, 16}, {128, 32}, {64, 64}, {64, 60}, {0, 0}, {0, 0}};  // 0.66 / 0.63 / 0.60 / 0.60 / 0.54 of 8 TB/s
   for (int which = 0; which < 2; which++) {
     const TileShape* cand = which == 0 ? cand_u8 : cand_f32;
-    const bool forced = c->opt_tile_h != 0 || c->opt_tile_w != 0;
-    for (int k = 0; k < 6; k++) {
-      const int tw = c->opt_tile_w ? c->opt_tile_w : cand[k].w, th = c->opt_tile_h ? c->opt_tile_h : cand[k].h;
+    // (a forced wide tile -- 8 rows per thread, raw u8 frames only -- leaves the float plan to its own list)
+    const bool wide = c->opt_tile_w >= 320 || c->opt_tile_h == 8;
+    const int want_w = (which == 1 && wide) ? 0 : c->opt_tile_w, want_h = (which == 1 && wide) ? 0 : c->opt_tile_h;
+    const bool forced = want_h != 0 || want_w != 0;
+    for (int k = 0; k < 8; k++) {
+      if (cand[k].w == 0) break;
+      const int tw = want_w ? want_w : cand[k].w, th = want_h ? want_h : cand[k].h;
       if (forced && (tw != cand[k].w || th != cand[k].h)) continue;  // a forced dimension filters the list
       free_src_plan(c->plan[which]);
       const int rc = plan_source(c, which == 0 ? 1 : 4, tw, th, c->plan[which]);
@@ -997,6 +1003,8 @@ void mdc_destroy(mdc_ctx* c) {
   delete c;
 }
 
+const char* mdc_build_flags(void) { return mdc::build_flags_string(); }
+
 const char* mdc_last_error(const mdc_ctx* c) {
   if (!c) return g_create_err.c_str();
   if (t_err_ctx == c) return t_err.c_str();
@@ -1018,8 +1026,8 @@ int mdc_set_option(mdc_ctx* c, int option, int value) try {
       c->opt_fpb = value;
       return MDC_OK;
     case MDC_OPT_TILE_ROWS: {
-      if (value != 0 && value != 16 && value != 32 && value != 60 && value != 64)
-        return fail(c, MDC_ERR_ARG, "tile rows must be 0 (automatic), 16, 32, 60 or 64");
+      if (value != 0 && value != 8 && value != 16 && value != 32 && value != 60 && value != 64)
+        return fail(c, MDC_ERR_ARG, "tile rows must be 0 (automatic), 8, 16, 32, 60 or 64");
       if (value == c->opt_tile_h) return MDC_OK;
       c->opt_tile_h = value;
       c->tuned_fpb = 0;  // a measured frames-per-workgroup belongs to the plan it was measured on
@@ -1029,7 +1037,8 @@ int mdc_set_option(mdc_ctx* c, int option, int value) try {
       return plan_tiles(c);
     }
     case MDC_OPT_TILE_COLS: {
-      if (value != 0 && value != 64 && value != 128) return fail(c, MDC_ERR_ARG, "tile columns must be 0 (automatic), 64 or 128");
+      if (value != 0 && value != 64 && value != 128 && value != 320 && value != 640)
+        return fail(c, MDC_ERR_ARG, "tile columns must be 0 (automatic), 64, 128, 320 or 640");
       if (value == c->opt_tile_w) return MDC_OK;
       c->opt_tile_w = value;
       c->tuned_fpb = 0;
@@ -1667,7 +1676,7 @@ int mdc_describe_launch(mdc_ctx* c, unsigned flags, int pyramid_levels, char* bu
     const bool pyr = pyramid_levels > 1 && p.tile_w * p.tile_h <= 2048 && p.tile_h % 8 == 0 && c->out_w % p.tile_w == 0 && c->out_h % p.tile_h == 0 &&
                      tiled_lds_bytes(p.win_bytes, p.nbuf, true) + tiled_pyramid_lds_bytes(p.tile_w, p.tile_h) <= kLdsPerCU;
     snprintf(tmp, sizeof tmp, "remap_tiled_kernel<%s, %s, %s, false, %d, %d, %d>", v ? "true" : "false",
-             c->n_black > 0 ? "true" : "false", pyr ? "true" : "false", p.tile_w, p.tile_w * p.tile_h / 4, p.nbuf);
+             c->n_black > 0 ? "true" : "false", pyr ? "true" : "false", p.tile_w, tile_threads(p.tile_w, p.tile_h), p.nbuf);
   } else {
     snprintf(tmp, sizeof tmp, "remap_gather_u8_kernel<%s>", v ? "true" : "false");
   }

@@ -4,25 +4,27 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mdc_build_config.h"
+
 namespace mdc {
 
 // Geometry of the tiled kernel: tile_w x tile_h outputs per workgroup, one lane per output column
-// (tile_w / 64 waves side by side), 4 output rows per thread  ->  tile_w * tile_h / 4 threads.
-// Legal shapes: 64 x {16, 32, 60, 64} (256 / 512 / 960 / 1024 threads), 128 x {16, 32} (512 / 1024).
+// (tile_w / 64 waves side by side), `rpt` vertically consecutive output rows per thread  ->  tile_w * tile_h / rpt threads.
+// Legal shapes: 64 x {16, 32, 60, 64} (256 / 512 / 960 / 1024 threads), 128 x {16, 32} (512 / 1024), 4 rows per thread;
+// 320 x 16 and 640 x 8 (640 threads), 8 rows per thread -- raw u8 frames only, no fused pyramid.
 struct TileShape {
   int w, h;
 };
-constexpr TileShape kTileShapes[] = {{64, 16}, {64, 32}, {64, 60}, {64, 64}, {128, 16}, {128, 32}};
+constexpr TileShape kTileShapes[] = {{64, 16}, {64, 32}, {64, 60}, {64, 64}, {128, 16}, {128, 32}, {320, 16}, {640, 8}};
 constexpr bool tile_shape_ok(int w, int h) {
   for (const TileShape& t : kTileShapes)
     if (t.w == w && t.h == h) return true;
   return false;
 }
+constexpr int tile_rpt(int w, int h) { return w >= 320 ? 8 : 4; }             // output rows per thread
+constexpr int tile_threads(int w, int h) { return w * h / tile_rpt(w, h); }  // workgroup size
 constexpr int kTileMaxChunks = 3;     // 16-byte chunks a thread may stage per frame (raw u8 frames)
 constexpr int kTileMaxChunksF32 = 4;  // same for float frames (a window holds 4x the bytes)
-#ifndef MDC_EXP_LUT_REP
-#define MDC_EXP_LUT_REP 32
-#endif
 constexpr int kLutRep = MDC_EXP_LUT_REP;  // LDS replicas of the 256-entry response LUT (32 = one per bank, conflict-free)
 constexpr uint32_t kOutside = 0xfffffff0u;  // buffer offset beyond any frame: the access is dropped by the range check
 
@@ -61,9 +63,6 @@ struct TilePlan {
 // lut * vignette floats and samples those.  Offsets in d_taps are bytes inside the wave's FLOAT window (4 x the u8 offset).
 constexpr int kStripTileW = 128, kStripTileH = 8;
 constexpr int kStripChunkCap = 128;  // two LDS-DMA instructions per wave and frame at most
-#ifndef MDC_EXP_STRIP_WAVES
-#define MDC_EXP_STRIP_WAVES 4
-#endif
 constexpr int kStripWaves = MDC_EXP_STRIP_WAVES;  // waves (tiles) per workgroup: they share the LUT replicas
 struct StripPlan {
   const uint32_t* d_chunks;  // [n_tiles][kStripChunkCap]

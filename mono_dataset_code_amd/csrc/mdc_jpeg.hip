@@ -319,9 +319,6 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
   // ---- first guesses: only the exit state of a subsequence matters to its right neighbour, and a decoder started anywhere
   // is on the true path after a few hundred bits -- so the guess comes from the LAST quarter (at least 512 bits) of the subsequence alone
   // (a quarter of a full pass; where it is wrong, the relaxation below finds out)
-#ifndef MDC_EXP_GUESS_DIV
-#define MDC_EXP_GUESS_DIV 4
-#endif
   const uint32_t guess_bits = max(512u, S / MDC_EXP_GUESS_DIV);  // (high qualities: ~250 bits per block, 512 bits are two blocks)
   uint32_t in_bit = my0, out_bit = my0;
   int in_z = 0, out_z = 0, nblk = 0, bad = 0;

@@ -27,45 +27,7 @@ namespace mdc {
 namespace {
 
 constexpr int kLutBytes = 256 * kLutRep * 4;
-// Build-time experiment switches (mono_dataset_code_amd/build.py:build_variant + tools/sweep.py --libs for an
-// in-process A/B; defaults are the shipped configuration).
-#ifndef MDC_EXP_LOAD_NT
-#define MDC_EXP_LOAD_NT 0   // staging loads: plain (L2-allocating) -- neighbouring tiles re-use halo lines; nt measured slower
-#endif
-#ifndef MDC_EXP_STORE_NT
-#define MDC_EXP_STORE_NT 1  // output stores carry the nontemporal hint
-#endif
-#ifndef MDC_EXP_SKIP_STORE
-#define MDC_EXP_SKIP_STORE 0  // diagnosis: outputs are computed but (practically) never stored -> read side alone
-#endif
-#ifndef MDC_EXP_FAKE_COMPUTE
-#define MDC_EXP_FAKE_COMPUTE 0  // diagnosis (wrong results): 1 = one tap + one LUT read per output instead of 4 + 4, 2 = no LDS reads
-#endif
-#ifndef MDC_EXP_TIMING
-#define MDC_EXP_TIMING 0      // diagnosis: wave 0 / 5 of some workgroups print the cycles their frame loop spent per phase (tools/phase_timing.sh)
-#endif
-#ifndef MDC_EXP_STRIP_LUT_REP
-#define MDC_EXP_STRIP_LUT_REP 8  // LUT replicas of the strip kernel (8 KiB): its LUT reads are per SOURCE pixel, a few bank conflicts cost little
-#endif
-#ifndef MDC_EXP_STRIP_NOCONVERT
-#define MDC_EXP_STRIP_NOCONVERT 0  // diagnosis (wrong results): the strip kernel skips its convert phase
-#endif
-#ifndef MDC_EXP_STRIP_NOSAMPLE
-#define MDC_EXP_STRIP_NOSAMPLE 0   // diagnosis (wrong results): the strip kernel stores a register instead of sampling
-#endif
-#ifndef MDC_EXP_STRIP_WAVES_PER_EU
-#define MDC_EXP_STRIP_WAVES_PER_EU 5  // register budget of the strip kernel: 512 / 5 -> 100 VGPRs
-#endif
-#ifndef MDC_EXP_SKIP_LOAD
-#define MDC_EXP_SKIP_LOAD 0   // diagnosis: every frame re-stages frame 0 (L2 hits) -> write side alone
-#endif
-
-// Debug build (mono_dataset_code_amd/build.py:build_variant("debug", ["MDC_DEBUG_BOUNDS=1"]), tests/test_gpu_debug.py):
-// every tap, staging destination and gather index is checked against its buffer; a violation traps the kernel
-// (the launch then fails with a HIP error instead of reading or writing out of bounds silently).
-#ifndef MDC_DEBUG_BOUNDS
-#define MDC_DEBUG_BOUNDS 0
-#endif
+// Build-time switches: mdc_build_config.h (tuning / debug / diagnosis; diagnosis builds exist only under variants/).
 #if MDC_DEBUG_BOUNDS
 #define MDC_CHECK(cond)               \
   do {                                \
@@ -338,28 +300,31 @@ constexpr int kLoadAux = 0;
 // frame, +2 VALU per output) and only the first row's output offset is kept, rows 1..3 add the row pitch
 // (rows below the image then lie beyond the frame's descriptor range and are dropped like kOutside).
 constexpr uint32_t kOutsideLean = 0xc0000000u;  // + 3 row pitches still beyond any frame the plan accepts
+// RPT = outputs (vertically consecutive rows of one column) per thread: 4, or 8 for the wide tiles (320 x 16, 640 x 8:
+// 640 threads), which are LEAN as well.
+template <int RPT>
 struct TileThread {
-  Bilin bl[4];           // (!LEAN) weights kept; (LEAN) only the fractional parts are, the weights are redone per frame
-  float fx[4], fy[4];    //  -- the same four IEEE operations either way, so the same bits
-  int off0[4], off1[4];  // LDS byte offsets of taps (xi,yi) and (xi,yi+1) inside the window  (!LEAN)
-  uint32_t tap[4];       // off0 | off1 << 16                                                  (LEAN)
-  uint32_t obyte[4];     // byte offset of the output inside a frame, kOutside if not in the image (LEAN: [0] only)
-  bool black[4];
-  float v00[4], v10[4], v01[4], v11[4];
+  Bilin bl[RPT];             // (!LEAN) weights kept; (LEAN) only the fractional parts are, the weights are redone per frame
+  float fx[RPT], fy[RPT];    //  -- the same four IEEE operations either way, so the same bits
+  int off0[RPT], off1[RPT];  // LDS byte offsets of taps (xi,yi) and (xi,yi+1) inside the window  (!LEAN)
+  uint32_t tap[RPT];         // off0 | off1 << 16                                                  (LEAN)
+  uint32_t obyte[RPT];       // byte offset of the output inside a frame, kOutside if not in the image (LEAN: [0] only)
+  bool black[RPT];
+  float v00[RPT], v10[RPT], v01[RPT], v11[RPT];
   uint32_t p1byte, p2byte;  // fused pyramid: byte offsets of this lane's level-1 / level-2 outputs (p2byte: kOutside if none).
                             // Level 1: even lanes store the box of rows 0-1, odd lanes the box of rows 2-3 of their LEFT neighbour's column pair -- one full store
 };
 
-template <bool VIG, bool BLACK, bool F32, bool LEAN, int B>
-__device__ __forceinline__ void tile_compute(const TileThread& t, lds_u8_ptr w, lds_f32_ptr my_lut, float* dst,
-                                             uint32_t out_bytes, uint32_t row_bytes, float (&res)[4], int win_bytes) {
+template <bool VIG, bool BLACK, bool F32, bool LEAN, int B, int RPT>
+__device__ __forceinline__ void tile_compute(const TileThread<RPT>& t, lds_u8_ptr w, lds_f32_ptr my_lut, float* dst,
+                                             uint32_t out_bytes, uint32_t row_bytes, float (&res)[RPT], int win_bytes) {
 #if __HIP_DEVICE_COMPILE__  // buffer / LDS-DMA builtins exist in the device pass only
   const auto ro = MDC_FRAME_RSRC(dst, out_bytes);
   // Outputs are processed B at a time: all their byte taps are issued, then all their LUT reads, then the
   // arithmetic -- two LDS latencies per batch instead of two per output.  (B = 2 where registers are short:
   // the 64-VGPR LEAN tiles and the fused pyramid.)
 #pragma unroll
-  for (int j0 = 0; j0 < 4; j0 += B) {
+  for (int j0 = 0; j0 < RPT; j0 += B) {
     int off0[B], off1[B];
     Bilin bw[B];
 #pragma unroll
@@ -457,7 +422,7 @@ __device__ __forceinline__ float dpp_quad(float v) {
 }
 
 // levels 1 and 2 of frame `f` from this thread's four outputs; this wave's level-2 row -> s_row
-__device__ __forceinline__ void pyramid_levels12(const TileThread& t, const float (&r)[4], const PyramidOut& py,
+__device__ __forceinline__ void pyramid_levels12(const TileThread<4>& t, const float (&r)[4], const PyramidOut& py,
                                                  long long f, uint32_t l1_bytes, uint32_t l2_bytes, float* s_row,
                                                  int lane) {
 #if __HIP_DEVICE_COMPILE__
@@ -583,8 +548,8 @@ __device__ __forceinline__ void frame_barrier(int rw) {
 
 // Frames [0, nframes) of one tile.  NBUF window buffers, D = NBUF-1 frames staged ahead: the DMA
 // of frame f+D is issued before frame f is computed; one barrier per frame.
-template <bool VIG, bool BLACK, bool PYR, bool F32, int R, int TW, int NT, int NBUF>
-__device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* __restrict__ src,
+template <bool VIG, bool BLACK, bool PYR, bool F32, int R, int TW, int NT, int NBUF, int RPT>
+__device__ __forceinline__ void tile_frames(const TileThread<RPT>& t, const uint8_t* __restrict__ src,
                                             float* __restrict__ dst, uint32_t in_bytes, uint32_t out_bytes,
                                             int nframes, int nch, const uint32_t (&goff_all)[F32 ? kTileMaxChunksF32 : kTileMaxChunks],
                                             lds_u8_ptr s_win, int win_bytes, lds_f32_ptr my_lut, int tid,
@@ -619,7 +584,9 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
   else if (R >= 2 && rw == 2) wait_vm_barrier<(D - 1) * 2>();
   else if (rw == 1) wait_vm_barrier<(D - 1) * 1>();
   else wait_vm_barrier<0>();
-  constexpr int G = NT / TW;        // row groups of the tile (4 output rows each; TW/64 waves side by side)
+  constexpr int G = NT / TW;        // row groups of the tile (RPT output rows each; TW/64 waves side by side)
+  constexpr bool LEAN = NT >= 960 || RPT > 4;
+  static_assert(!PYR || RPT == 4, "the fused pyramid pairs the 4 rows of a thread");
   constexpr int L2W = TW / 4;       // level-2 pixels per tile row
   float* s_pyr = (float*)(s_win + NBUF * win_bytes);  // [2][G][L2W] level-2 rows (PYR only)
   const int pyr_slot = (wave / (TW / 64)) * L2W + (wave % (TW / 64)) * 16;  // this wave's 16 floats inside one [G][L2W] set
@@ -643,9 +610,9 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
 #if MDC_EXP_TIMING
     const unsigned long long t1 = exp_now();
 #endif
-    float res[4];
-    tile_compute<VIG, BLACK, F32, (NT >= 960), ((NT >= 960 || PYR) ? 2 : 4)>(t, w[0], my_lut, dst, out_bytes, row_bytes, res, win_bytes);
-    if (PYR)
+    float res[RPT];
+    tile_compute<VIG, BLACK, F32, LEAN, ((LEAN || PYR) ? 2 : 4), RPT>(t, w[0], my_lut, dst, out_bytes, row_bytes, res, win_bytes);
+    if constexpr (PYR)
       pyramid_levels12(t, res, py, f_first + (long long)f * fstep, l1_bytes, l2_bytes, s_pyr + (f & 1) * G * L2W + pyr_slot,
                        tid & 63);
     dst += out_step;
@@ -653,7 +620,7 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
 #if MDC_EXP_TIMING
     const unsigned long long t2 = exp_now();
     if (PYR && pyr_all_levels) frame_wait_only<D, R, 6>(rw);
-    else frame_wait_only<D, R>(rw);
+    else frame_wait_only<D, R, RPT>(rw);
     const unsigned long long t3 = exp_now();
     asm volatile("s_barrier" ::: "memory");
     const unsigned long long t4 = exp_now();
@@ -667,9 +634,9 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
     // operations follow it than the formula assumes (D = 2, f = 0: rw + S follow, the formula allows rw + 2 S: the wait
     // could pass with DMA(1) still in flight -- never observed, frame 1 has a whole frame's time to land, but not
     // guaranteed).  Those first D-1 iterations wait for everything but the frame's own 4 stores.
-    if (D > 1 && f < D - 1) wait_vm_barrier<4>();
+    if (D > 1 && f < D - 1) wait_vm_barrier<RPT>();
     else if (PYR && pyr_all_levels) frame_barrier<D, R, 6>(rw);
-    else frame_barrier<D, R>(rw);
+    else frame_barrier<D, R, RPT>(rw);
 #endif
     lds_u8_ptr x = w[0];
 #pragma unroll
@@ -689,9 +656,10 @@ __device__ __forceinline__ void tile_frames(const TileThread& t, const uint8_t* 
 // 960/1024 per CU; the register budget follows from that.
 // F32: the frames are floats (UndistorterFOV::undistort<float>, no LUT, no vignette); else raw u8.
 template <bool VIG, bool BLACK, bool PYR, bool F32, int TW, int NT, int NBUF>
-__global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 : 6) : 4)) void remap_tiled_kernel(
+__global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 640 ? 5 : NT == 512 ? (kLutRep < 32 ? 8 : 6) : 4)) void remap_tiled_kernel(
     const uint8_t* __restrict__ in, float* __restrict__ out, RemapArgs a, TilePlan p, PyramidOut py, int nframes, int fpb,
     int interleave, int taper_full, int taper_r) {
+  constexpr int RPT = tile_rpt(TW, 0);  // output rows per thread: 8 for the 320- and 640-wide tiles, else 4 (mdc_internal.h)
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   float* s_lut = reinterpret_cast<float*>(smem);
   lds_u8_ptr s_win = (lds_u8_ptr)smem + (F32 ? 0 : kLutBytes);
@@ -720,10 +688,10 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
 
   const int tid = threadIdx.x;
   const int lane_x = tid % TW;
-  const int row0 = (tid / TW) * 4;
+  const int row0 = (tid / TW) * RPT;
   const int ox = (tile % p.tiles_x) * TW + lane_x;
-  constexpr int kTileRows = NT * 4 / TW;  // 4 output rows per thread, TW lanes per row
-  constexpr bool LEAN = NT >= 960;
+  constexpr int kTileRows = NT * RPT / TW;  // RPT output rows per thread, TW lanes per row
+  constexpr bool LEAN = NT >= 960 || RPT > 4;
   const int oy0 = (tile / p.tiles_x) * kTileRows + row0;
 
   // Prologue, ordered for memory-level parallelism: the workgroup's whole start-up is three dependent
@@ -737,10 +705,10 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
 #pragma unroll
   for (int k = 0; k < RMAX; k++) goff[k] = chunks[tid + k * NT];
 
-  float xx[4], yy[4];
-  uint32_t tp[4];
+  float xx[RPT], yy[RPT];
+  uint32_t tp[RPT];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {  // unconditional loads (index 0 stands in for outputs outside the image): no branches
+  for (int j = 0; j < RPT; j++) {  // unconditional loads (index 0 stands in for outputs outside the image): no branches
     const bool inside = (ox < a.out_w) && (oy0 + j < a.out_h);
     const int oidx = inside ? (oy0 + j) * a.out_w + ox : 0;
     xx[j] = a.rx[oidx];
@@ -750,9 +718,9 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
   if (!F32) fill_lut<NT>(s_lut, a.lut, tid);
   lds_f32_ptr my_lut = (lds_f32_ptr)s_lut + (tid & (kLutRep - 1));
 
-  TileThread t;
+  TileThread<RPT> t;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < RPT; j++) {
     const int oy = oy0 + j;
     const bool inside = (ox < a.out_w) && (oy < a.out_h);
     const int oidx = oy * a.out_w + ox;
@@ -777,7 +745,7 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
     t.off1[j] = (int)(tp[j] >> 16);
   }
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < RPT; j++) {
     t.v00[j] = t.v10[j] = t.v01[j] = t.v11[j] = 1.f;
     if (VIG) {  // unconditional gathers: a black output's factors are never used (its result is forced or dropped)
       const int s = t.black[j] ? 0 : t.bl[j].xi + t.bl[j].yi * a.in_w;
@@ -796,7 +764,7 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
   // tile's level-3 block.  The last wave, not the first: with small windows (a scale-1 remap stages ~160 chunks) only the
   // first waves have LDS-DMA to issue at the top of a frame, and whoever does level 3 there is the wave everybody else
   // waits for at the frame's barrier (tools/phase_timing.sh: 2600 cycles against 170).
-  static_assert((TW / 8) * (kTileRows / 8) <= 64, "level 3 of a tile is one wave's work");
+  static_assert(!PYR || (TW / 8) * (kTileRows / 8) <= 64, "level 3 of a tile is one wave's work");
   const int u3 = tid - (NT - 64);
   uint32_t p3byte = kOutside;
   if (PYR && u3 >= 0 && u3 < (TW / 8) * (kTileRows / 8))
@@ -807,7 +775,7 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
     for (int f = 0; f < nf; f++, dst += (long long)fstep * (out_bytes / 4)) {
       const auto ro = MDC_FRAME_RSRC(dst, out_bytes);
 #pragma unroll
-      for (int j = 0; j < 4; j++)
+      for (int j = 0; j < RPT; j++)
         __builtin_amdgcn_raw_buffer_store_b32(0u, ro, LEAN ? t.obyte[0] + (uint32_t)j * (uint32_t)a.out_w * 4u : t.obyte[j], 0, 0);
       if (PYR) {
         const long long fa = (long long)f0 + (long long)f * fstep;
@@ -825,7 +793,7 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 512 ? (kLutRep < 32 ? 8 
   const int rounds = (nch + NT - 1) / NT;  // workgroup-uniform
   MDC_CHECK(nch * 16 <= p.win_bytes && rounds <= RMAX && (goff[0] == kOutside) == (tid >= nch));  // dense chunk list: the vmcnt allowances count on it
 #define MDC_TILE_RUN(R_)                                                                                              \
-  tile_frames<VIG, BLACK, PYR, F32, R_, TW, NT, NBUF>(t, src, dst, in_bytes, out_bytes, nf, nch, goff, s_win, p.win_bytes, \
+  tile_frames<VIG, BLACK, PYR, F32, R_, TW, NT, NBUF, RPT>(t, src, dst, in_bytes, out_bytes, nf, nch, goff, s_win, p.win_bytes, \
                                              my_lut, tid, py, (long long)f0, fstep, p3byte, (uint32_t)a.out_w * 4u)
   if (rounds == 1) MDC_TILE_RUN(1);
   else if (rounds == 2) MDC_TILE_RUN(2);
@@ -1361,8 +1329,11 @@ static hipError_t launch_tiled_variant(const TiledLaunch& l) {
 
 template <bool VIG, bool BLACK, bool PYR, bool F32, int TW, int NT>
 static hipError_t launch_tiled_buf(const TiledLaunch& l) {
+  constexpr int RPT = tile_rpt(TW, 0);
   switch (l.p.nbuf) {
-    case 2: return launch_tiled_variant<VIG, BLACK, PYR, F32, TW, NT, 2>(l);
+    case 2:  // (the 8-rows-per-thread tiles: 3 buffers only -- with 2 the compiler's schedule needs 97 VGPRs, one more than 5 waves per SIMD leave)
+      if constexpr (RPT == 4) return launch_tiled_variant<VIG, BLACK, PYR, F32, TW, NT, 2>(l);
+      break;
     case 3: return launch_tiled_variant<VIG, BLACK, PYR, F32, TW, NT, 3>(l);
     case 4:
       if constexpr (NT <= 512) return launch_tiled_variant<VIG, BLACK, PYR, F32, TW, NT, 4>(l);  // 4 buffers of a 1024-thread tile never fit
@@ -1388,6 +1359,13 @@ static hipError_t launch_tiled_shape(const TiledLaunch& l) {
     case 128016: return launch_tiled_buf<VIG, BLACK, PYR, F32, 128, 512>(l);
     case 128032:
       if constexpr (!PYR) return launch_tiled_buf<VIG, BLACK, false, F32, 128, 1024>(l);
+      break;
+    // wide tiles, 8 outputs per thread, 640 threads (raw u8 frames only): one x-border inside a 640-wide output / none
+    case 320016:
+      if constexpr (!PYR && !F32) return launch_tiled_buf<VIG, BLACK, false, false, 320, 640>(l);
+      break;
+    case 640008:
+      if constexpr (!PYR && !F32) return launch_tiled_buf<VIG, BLACK, false, false, 640, 640>(l);
       break;
   }
   return hipErrorInvalidValue;

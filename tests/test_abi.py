@@ -69,6 +69,28 @@ def test_headers_compile_as_plain_c_and_cxx(tmp_path):
         assert r.returncode == 0, r.stdout
 
 
+def test_product_library_is_built_with_shipped_switches():
+    """No tuning / debug / diagnosis switch (csrc/mdc_build_config.h) differs from its shipped value in the library next to
+    the package; a diagnosis switch without MDC_DIAGNOSIS_BUILD does not even compile."""
+    import subprocess
+
+    from mono_dataset_code_amd import build, capi
+
+    assert capi.build_flags() == ""
+    cfg = os.path.join(ROOT, "mono_dataset_code_amd", "csrc", "mdc_build_config.h")
+    for sw in ("MDC_EXP_SKIP_STORE=1", "MDC_EXP_FAKE_COMPUTE=2", "MDC_EXP_STRIP_NOSAMPLE=1"):
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", "-D" + sw, cfg], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode != 0 and "diagnosis switch" in r.stdout, (sw, r.stdout)
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", "-DMDC_DIAGNOSIS_BUILD=1", "-D" + sw, cfg], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+    # the debug variant (bounds checks) names itself
+    import ctypes
+
+    dbg = ctypes.CDLL(build.build_debug())
+    dbg.mdc_build_flags.restype = ctypes.c_char_p
+    assert dbg.mdc_build_flags().decode() == "MDC_DEBUG_BOUNDS=1"
+
+
 def test_signatures_have_no_torch_types():
     for h in ("mdc_hip.h", "mdc_host.h"):
         txt = open(os.path.join(ROOT, "include", h)).read()

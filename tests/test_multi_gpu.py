@@ -94,10 +94,10 @@ def test_packed_blob_equals_exported_blob(calib_dirs):
     assert (i1.in_w, i1.out_w, i1.tiled, i1.n_tiles, i1.src_bbox_bytes) == (i2.in_w, i2.out_w, i2.tiled, i2.n_tiles, i2.src_bbox_bytes)
 
 
-def _bench(args, env=None, nproc=0, port=29533, timeout=900):
+def _bench(args, env=None, nproc=0, port=29533, timeout=900, clean_env=False):
     import json
 
-    e = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    e = dict(os.environ, MASTER_ADDR="127.0.0.1") if not clean_env else {}
     e.update(env or {})
     if nproc:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
@@ -148,6 +148,31 @@ def test_bench_two_ranks_on_one_gpu(tmp_path, oracle):
     assert out["config"]["tables"].startswith("rank-0 build") and out["config"]["collective_backend"] == "gloo"
     assert len(out["roofline"]["per_rank_kernel_ms_mean_median_min"]) == 2
     _check_rank_dumps(str(tmp_path), 2, 3, oracle)
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks(tmp_path, oracle):
+    """`python bench.py --gpus 2` WITHOUT torchrun becomes two ranks by itself (gloo here: the two ranks share the test box's one
+    GPU) and says so in its line; without the gloo switch it refuses to run more ranks than there are GPUs -- it never prints
+    n_gpus: 1 for --gpus N."""
+    import torch
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = _bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--frames", "64", "--preroll-s", "0.05", "--dump-dir", str(tmp_path),
+                  "--dump-frames", "2"], env=dict(env, MDC_BENCH_BACKEND="gloo"), clean_env=True)
+    assert out["n_gpus"] == 2 and out["ranks"]["world"] == 2 and out["ranks"]["backend"] == "gloo"
+    assert [d["rank"] for d in out["ranks"]["devices"]] == [0, 1]
+    assert out["parity"]["mismatching_pixels"] == 0 and len(out["roofline"]["per_rank_frac"]) == 2
+    assert out["build_flags"] == ""
+    _check_rank_dumps(str(tmp_path), 2, 2, oracle)
+    want = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--frames", "8", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, MDC_BENCH_BACKEND="nccl"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    # a launcher that disagrees with --gpus is an error as well, whatever the world size
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--frames", "8", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
 
 
 @pytest.mark.gpu

@@ -1,0 +1,81 @@
+#!/bin/bash
+# One runner for the GPU sessions of a round (replaces the per-call scripts of rounds 2 and 3).
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/gpu_session.sh <tag> <stage> [<stage> ...]'
+# Every stage writes under gpurun_out/<tag>/ and prints a short tail; what is judged is copied into profiles/ by hand
+# (tools/collect_profiles.py for the rocprof summaries).  Stages:
+#   tests            the GPU suite, driver style (pytest -x -q -m gpu) + smoke()
+#   tests_new        only the files touched this round (MDC_TESTS="tests/a.py tests/b.py")
+#   shapes           tools/sweep.py over tile shapes / frames per workgroup on the headline batch (SHAPES=..., FPB=..., FRAMES=...)
+#   bracket          tools/mall_bracket.py: the same launch with its reads served by HBM / Infinity Cache / L2
+#   ea               rocprofv3 --pmc passes (fabric read requests: total, DRAM-bound, 32 B / 64 B / 128 B, L2 hit / miss)
+#                    over tools/mall_bracket.py (one launch per variant)
+#   launch_size      bench.py --frames 4096 / 8192 / 16384 (headline only)
+#   bench            plain `python bench.py` (the driver's command) -> bench.json
+#   bench2           `python bench.py --gpus 2` without torchrun (gloo, shared GPU)
+#   profile          tools/profile_bench.sh for the four workloads (rocprofv3 --stats + FETCH_SIZE / WRITE_SIZE passes)
+#   reader / dso / huffman / vcal   the secondary rate tools
+set -u
+TAG=$1; shift
+cd "$GRAFT_REPO_ROOT"
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+export PYTHONUNBUFFERED=1
+for stage in "$@"; do
+  echo "=== stage $stage ($(date +%T))"
+  case $stage in
+    tests)
+      timeout 1500 python -m pytest tests -x -q -m gpu > "$OUT/tests.txt" 2>&1; echo "rc=$?" >> "$OUT/tests.txt"
+      grep -aE "passed|failed|error|rc=" "$OUT/tests.txt" | tail -5
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.txt" 2>&1; grep -a "smoke" "$OUT/smoke.txt" | tail -2 ;;
+    tests_new)
+      timeout 1200 python -m pytest ${MDC_TESTS:-tests/test_gpu_parity.py} -x -q -m gpu > "$OUT/tests_new.txt" 2>&1; echo "rc=$?" >> "$OUT/tests_new.txt"
+      grep -aE "passed|failed|error|rc=|assert" "$OUT/tests_new.txt" | tail -12 ;;
+    shapes)
+      timeout 600 python tools/sweep.py --frames ${FRAMES:-4096} --rounds ${ROUNDS:-4} --iters 4 --shapes ${SHAPES:-128x16,320x16,640x8,128x32} \
+        --fpb ${FPB:-32,64,96} > "$OUT/shapes.txt" 2>&1; cat "$OUT/shapes.txt" | grep -av amdgpu.ids ;;
+    bracket)
+      timeout 600 python tools/mall_bracket.py --shapes ${SHAPES:-128x16,320x16} --rounds ${ROUNDS:-4} > "$OUT/bracket.txt" 2>&1; grep -av amdgpu.ids "$OUT/bracket.txt" ;;
+    ea)
+      ( cd /tmp && export TMPDIR=/tmp; i=0
+        for C in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum" "TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_HIT_sum TCC_MISS_sum" \
+                 "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum" "FETCH_SIZE" "WRITE_SIZE" "TCP_TCC_READ_REQ_sum TCC_READ_sum TCC_REQ_sum"; do
+          i=$((i+1))
+          timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/ea_pass$i" -- python "$GRAFT_REPO_ROOT/tools/mall_bracket.py" \
+            --shapes ${SHAPES:-128x16,320x16} --rounds 1 --iters 1 > "$OUT/ea_pass$i.log" 2>&1
+        done )
+      python3 tools/pmc_table.py "$OUT" ea_pass > "$OUT/ea_summary.txt" 2>&1; cat "$OUT/ea_summary.txt" ;;
+    launch_size)
+      for n in 4096 8192 16384; do
+        timeout 300 python bench.py --frames $n --steps 60 --warmup 10 --no-cpu-baseline > "$OUT/bench_frames_$n.json" 2> "$OUT/bench_frames_$n.err"
+        python3 -c "import json,sys; d=json.loads([l for l in open('$OUT/bench_frames_$n.json') if l.startswith('{')][-1]); r=d['roofline']; print($n, 'frac', r['frac'], 'kernel_ms', r['kernel_ms'], 'of_ceiling', r.get('frac_of_same_box_mix_ceiling'), r['kernel'], d['config']['plan'])"
+      done ;;
+    bench)
+      ( time timeout 1200 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" ) 2>&1 | grep real; tail -c 600 "$OUT/bench.err"
+      python3 - "$OUT/bench.json" <<'PY'
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+r = d["roofline"]
+print("headline", d["value"], "Mpix/s  frac", r["frac"], "kernel_ms", r["kernel_ms"], "of ceiling", r.get("frac_of_same_box_mix_ceiling"), r["kernel"], "parity", d["parity"])
+for k, v in (d.get("secondary") or {}).items():
+    print("secondary", k, "frac", v["frac"], "kernel_ms", v["kernel_ms"], "of ceiling", v["frac_of_same_box_mix_ceiling"], v["kernel"], "parity", v["parity"])
+print("cpu_baseline", {k: d.get("cpu_baseline", {}).get(k) for k in ("value", "cores", "kind")}, "build_flags", repr(d.get("build_flags")), "ranks", d.get("ranks"))
+PY
+      ;;
+    bench2)
+      MDC_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 20 --warmup 3 > "$OUT/bench_gpus2_gloo.json" 2> "$OUT/bench_gpus2_gloo.err"; echo "rc=$?"
+      tail -c 1500 "$OUT/bench_gpus2_gloo.json"; echo
+      timeout 120 python bench.py --gpus 8 > "$OUT/bench_gpus8_refused.txt" 2>&1; echo "--gpus 8 on this box: rc=$?"; tail -2 "$OUT/bench_gpus8_refused.txt" ;;
+    profile)
+      for wl in fused unmap pyramid seq50k; do
+        extra=""; [ $wl = unmap ] && extra="--frames 1024"
+        timeout 600 bash tools/profile_bench.sh ${TAG}_$wl --workload $wl $extra > "$OUT/profile_$wl.txt" 2>&1
+        tail -3 "$OUT/profile_$wl.txt"
+      done ;;
+    reader)  timeout 900 python tools/reader_rate.py ${N:-512} > "$OUT/reader_rates.txt" 2>&1; grep -av amdgpu.ids "$OUT/reader_rates.txt" | tail -30 ;;
+    dso)     timeout 600 python tools/dso_rate.py > "$OUT/dso_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/dso_rate.txt" | tail -20 ;;
+    huffman) timeout 600 python tools/huffman_rate.py > "$OUT/huffman_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/huffman_rate.txt" | tail -20 ;;
+    vcal)    timeout 600 python tools/vcal_rate.py > "$OUT/vcal_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/vcal_rate.txt" | tail -20 ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done
+echo "=== done ($(date +%T))"

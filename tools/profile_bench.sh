@@ -12,7 +12,7 @@ TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --preroll-s 0.05 --no-cpu-baseline --no-ceiling $*"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --preroll-s 0.05 --no-cpu-baseline --no-ceiling --no-secondary $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/bench_under_profiler.json 2> $OUT/stats.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $BENCH > /dev/null 2> $OUT/fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $BENCH > /dev/null 2> $OUT/write.log

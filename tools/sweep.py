@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--lib", default="", help="(compat) single alternative build")
     ap.add_argument("--rows", default="32")
     ap.add_argument("--cols", default="64", help="output tile columns: 64 or 128")
+    ap.add_argument("--shapes", default="", help="tile shapes as COLSxROWS,... (overrides the --cols x --rows product), e.g. 128x16,320x16,640x8")
     ap.add_argument("--pad", default="0", help="LDS row pitch padded to 128 bytes: 0 / 1")
     ap.add_argument("--order", default="0", help="tile placement: 0 bands, 1 whole rows per XCD, 2 identity")
     ap.add_argument("--sched", default="-1", help="frame assignment: -1 library default, 0 consecutive runs, 1 interleaved")
@@ -105,7 +106,12 @@ def main():
     alg = (int(info.src_bbox_bytes) + npo * 4) if a.workload == "fused" else npi * 5
     kmap = {"tiled": capi.KERNEL_TILED, "gather": capi.KERNEL_GATHER, "auto": capi.KERNEL_AUTO}
     ints = lambda x: [int(v) for v in x.split(",")]  # noqa: E731
-    variants = list(itertools.product(libs, a.kernel.split(","), ints(a.fpb), ints(a.rows), ints(a.order), ints(a.sched), ints(a.nbuf), ints(a.cols), ints(a.pad)))
+    if a.shapes:
+        shp = [tuple(int(v) for v in x.split("x")) for x in a.shapes.split(",")]
+        variants = [(l, k, f, r, o, sc, nb, c, pd) for l, k, f, (c, r), o, sc, nb, pd in
+                    itertools.product(libs, a.kernel.split(","), ints(a.fpb), shp, ints(a.order), ints(a.sched), ints(a.nbuf), ints(a.pad))]
+    else:
+        variants = list(itertools.product(libs, a.kernel.split(","), ints(a.fpb), ints(a.rows), ints(a.order), ints(a.sched), ints(a.nbuf), ints(a.cols), ints(a.pad)))
     times = {v: [] for v in variants}
     # DVFS: the first ~30 ms after an idle period run ~15 % slow (profiles/r01_dvfs_warmup_curve.txt)
     m0, c0 = ctxs[libs[0]]
@@ -117,8 +123,9 @@ def main():
             m, ctx = ctxs[v[0]]
             ctx.set_option(m.OPT_KERNEL, kmap[v[1]])
             ctx.set_option(m.OPT_FRAMES_PER_BLOCK, v[2])
-            try_set(m, ctx, "OPT_TILE_COLS", v[7])
+            try_set(m, ctx, "OPT_TILE_COLS", 0)
             try_set(m, ctx, "OPT_TILE_ROWS", v[3])
+            try_set(m, ctx, "OPT_TILE_COLS", v[7])
             try_set(m, ctx, "OPT_TILE_ORDER", v[4])
             if v[5] >= 0:
                 try_set(m, ctx, "OPT_FRAME_INTERLEAVE", v[5])
