@@ -94,8 +94,14 @@ int mdcb_synth_frames_device(int device, uint8_t* d_out, int64_t first_frame, in
   DeviceGuard dg(device);
   const long long n = (long long)nframes * npix;
   if (n <= 0) return 0;
-  synth_kernel<<<ceil_div(n, 1024), 256, 0, (hipStream_t)stream>>>(d_out, first_frame * (long long)npix, n, seed);
-  return hipGetLastError() == hipSuccess ? 0 : -4;
+  // a launch is limited to 2^32 threads in total: sequences beyond 2^34 pixels (a 50,000-frame one is 6.5e10) go in pieces
+  const long long piece = 1ll << 32;  // pixels per launch = 2^30 threads
+  for (long long at = 0; at < n; at += piece) {
+    const long long m = n - at < piece ? n - at : piece;
+    synth_kernel<<<ceil_div(m, 1024), 256, 0, (hipStream_t)stream>>>(d_out + at, first_frame * (long long)npix + at, m, seed);
+    if (hipGetLastError() != hipSuccess) return -4;
+  }
+  return 0;
 }
 
 int mdcb_ceiling_mix_device(int device, const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes, int blocks, int span,

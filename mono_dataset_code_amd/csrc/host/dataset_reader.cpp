@@ -197,6 +197,12 @@ struct DatasetReader::State {
         d.h = sink.h;
         d.rec_rows = sink.blocks_rows;
         d.is_record = true;
+      } else {
+        // a file whose blocks do not fit the record geometry (or that the coefficient path refuses for any other reason)
+        // still decodes to pixels on the host, so that stage 1 gives the same images and the same failures as stages 0 and 2
+        std::string e2;
+        d.ok = mdc_host::decode_gray8(bytes.data(), bytes.size(), d.dst, d.cap, &d.w, &d.h, &e2);
+        if (!d.ok) d.err = e2;
       }
     } else {
       d.ok = mdc_host::decode_gray8(bytes.data(), bytes.size(), d.dst, d.cap, &d.w, &d.h, &d.err);
@@ -606,8 +612,8 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
   const int slots = (s.gpu_jpeg >= 2 && count > C) ? 2 * State::kRingFrames : State::kRingFrames, RG = slots / C;
   // coefficient records (include/mdc_hip.h): MCUs are at most 4 x 4 blocks, so a grid rounded up to multiples of 4 blocks
   // holds every sampling layout of a W x H file (the same rule as mdch_jpeg_record_bytes)
-  s.rec_pitch = ((s.W + 7) / 8 + 3) & ~3;
-  s.rec_rows = ((s.H + 7) / 8 + 3) & ~3;
+  s.rec_pitch = ((s.W + 7) / 8 + 11) / 12 * 12;
+  s.rec_rows = ((s.H + 7) / 8 + 11) / 12 * 12;
   s.rec_bytes = 128 + (size_t)s.rec_pitch * s.rec_rows * 128;
   // a ring buffer holds a decoded frame, or (stage 1) a coefficient record -- 2 bytes per pixel --, or (stage 2) a stream: the
   // compressed bytes + 5 KB; a file stage 2 does not take, or whose stream does not fit, is decoded to pixels on the host
@@ -686,7 +692,13 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
         sdst.push_back(out[i]->image);
         ssize.push_back((int64_t)d.stream_bytes);
         sidx.push_back(i);
-      } else if (d.is_record && d.rec_rows <= s.rec_rows) {
+      } else if (d.is_record) {
+        if (d.rec_rows > s.rec_rows) {  // cannot happen while the decoder checks the sink's capacity: never hand a record on as pixels
+          delete out[i];
+          out[i] = 0;
+          s.err = s.files[(size_t)id] + ": coefficient record larger than the frame's geometry";
+          continue;
+        }
         rsrc.push_back(d.dst);
         rdst.push_back(out[i]->image);
       } else {

@@ -342,6 +342,10 @@ bool jpeg_progressive_gray8(const unsigned char* d, size_t n, unsigned char* out
       lbh = my * vmax;
       lcw = (W + 7) / 8;
       lch = (H + 7) / 8;
+      if (sink) {  // checked BEFORE the scans' coefficient store is sized from the header (65535 x 65535 would ask for 8.6 GB)
+        if (sink->pitch_blocks && sink->pitch_blocks < lbw) return fail(err, "coefficient row pitch too small for this file");
+        if ((size_t)(sink->pitch_blocks ? sink->pitch_blocks : lbw) * lbh > sink->cap_blocks) return fail(err, "frame larger than the coefficient buffer");
+      }
       coef.assign((size_t)lbw * lbh * 64, 0);
       have_sof = true;
     } else if (m == 0xc0 || m == 0xc1 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {

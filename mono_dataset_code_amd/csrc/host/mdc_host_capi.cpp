@@ -1,6 +1,7 @@
 // C facade over the drop-in classes -- see include/mdc_host.h.
 #include "mdc_host.h"
 
+#include <new>
 #include <cstdint>
 #include <cstring>
 
@@ -150,7 +151,7 @@ void mdch_photo_unmap(mdch_photo* p, unsigned char* in, float* out, int n, int g
 
 int mdch_bind(mdc_ctx* ctx, const mdch_fov* fov, const mdch_photo* photo) try {
   return mdc_bind_objects(ctx, fov ? fov->u : 0, photo ? photo->p : 0);
-} catch (...) { return {}; }  // no exception leaves the C facade
+} catch (const std::bad_alloc&) { return MDC_ERR_NOMEM; } catch (...) { return MDC_ERR_HIP; }  // a status, never "0 = ok", for a failed call
 
 // Must stay in step with BlobHeader in csrc/mdc_capi.hip (checked by tests/test_multi_gpu.py
 // on the GPU: pack == export after bind).
@@ -203,7 +204,7 @@ int mdch_pack_tables(const mdch_fov* fov, const mdch_photo* photo, void* blob, s
     memcpy(q + nr * 4, MdcHostAccess::ry(*u), nr * 4);
   }
   return MDC_OK;
-} catch (...) { return {}; }  // no exception leaves the C facade
+} catch (const std::bad_alloc&) { return MDC_ERR_NOMEM; } catch (...) { return MDC_ERR_HIP; }  // (mdch_pack_tables: *size / the blob may be unwritten)
 
 
 // ---- DatasetReader ---------------------------------------------------------------------------------
@@ -274,8 +275,9 @@ const char* mdch_reader_last_error(mdch_reader* h) try { return h->r->lastError(
 void mdch_reader_prefetch_stats(mdch_reader* h, long hm[2]) try { h->r->getPrefetchStats(&hm[0], &hm[1]); } catch (...) {}
 
 size_t mdch_jpeg_record_bytes(int w, int h, int pitch_rows[2]) try {
-  // MCUs are at most 4 x 4 blocks: a pitch / row count rounded up to a multiple of 4 blocks holds every sampling layout
-  const int pitch = ((w + 7) / 8 + 3) & ~3, rows = ((h + 7) / 8 + 3) & ~3;
+  // MCUs are 1..4 x 1..4 blocks: a pitch / row count rounded up to a multiple of 12 blocks (lcm of 1, 2, 3, 4) holds every
+  // sampling layout, a luma factor of 3 included
+  const int pitch = ((w + 7) / 8 + 11) / 12 * 12, rows = ((h + 7) / 8 + 11) / 12 * 12;
   if (pitch_rows) {
     pitch_rows[0] = pitch;
     pitch_rows[1] = rows;

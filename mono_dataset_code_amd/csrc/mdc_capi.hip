@@ -662,6 +662,26 @@ T* device_view(const mdc_ctx* c, T* p, size_t bytes) {
   return (T*)a.devicePointer;
 }
 
+// true when [p, p + bytes) lies inside ONE page-locked allocation the runtime knows (whatever MDC_OPT_ZERO_COPY says): the
+// bytes between two buffers of such a range are readable
+bool one_host_allocation(const void* p, size_t bytes) {
+  if (!p || bytes == 0) return false;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)a.devicePointer) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  const uintptr_t lo = (uintptr_t)a.devicePointer, b0 = (uintptr_t)base;
+  return lo >= b0 && lo + bytes <= b0 + size;
+}
+
 // A slot of the host-pointer calls for the duration of one call (RAII).  s == nullptr: no slot could be made (error set).
 struct SlotLease {
   mdc_ctx* c;
@@ -693,8 +713,14 @@ struct SlotLease {
       c->slot_cv.wait(lk);
     }
   }
+  // Every host call borrows the caller's buffers for its duration only and hands the slot (its stream, its staging
+  // buffers) to the next caller: whatever way the call ends -- an early return after an asynchronous copy was enqueued
+  // included --, nothing of it may still be in flight.  A call that has synchronised successfully says drained().
+  bool in_flight = true;
+  void drained() { in_flight = false; }
   ~SlotLease() {
     if (!s) return;
+    if (in_flight) (void)hipStreamSynchronize(s->stream);
     {
       std::lock_guard<std::mutex> lk(c->slot_mu);
       s->busy = false;
@@ -841,6 +867,7 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
       // stays ordered after the lease ends.  No free slot (every one held by a host call): one stream.  A caller's stream
       // that is being captured into a graph keeps everything on itself (a shared stream must not be drawn into a capture).
       SlotLease side(c, false);
+      side.drained();  // a *_device call stays asynchronous: the lease only covers the enqueueing
       mdc_ctx::HostSlot* h = side.s;
       if (h && !h->ev_fork) {
         if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) h->ev_fork = nullptr;
@@ -1343,6 +1370,7 @@ int mdc_distort_points_host(mdc_ctx* c, const mdc_fov_model* model, float* x, fl
   MDC_HIP(c, hipMemcpyAsync(x, dx, bytes, hipMemcpyDeviceToHost, st));
   MDC_HIP(c, hipMemcpyAsync(y, dy, bytes, hipMemcpyDeviceToHost, st));
   MDC_HIP(c, hipStreamSynchronize(st));
+  slot.drained();
   return MDC_OK;
 } MDC_CATCH(c)
 
@@ -1728,6 +1756,7 @@ int mdc_unmap_host(mdc_ctx* c, const uint8_t* in, float* out, int n, unsigned fl
                           1, 1, st));
   if (!z_out) MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
   MDC_HIP(c, hipStreamSynchronize(st));
+  slot.drained();
   return MDC_OK;
 } MDC_CATCH(c)
 
@@ -1763,6 +1792,7 @@ static int undistort_host(mdc_ctx* c, const void* in, bool is_f32, float* out, i
   }
   if (!z_out) MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, (size_t)n_out * sizeof(float), hipMemcpyDeviceToHost, st));
   MDC_HIP(c, hipStreamSynchronize(st));
+  slot.drained();
   return MDC_OK;
 }
 
@@ -1799,6 +1829,7 @@ int mdc_process_host(mdc_ctx* c, const uint8_t* raw, float* out, unsigned flags)
   }
   if (!z_out) MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, st));
   MDC_HIP(c, hipStreamSynchronize(st));
+  slot.drained();
   return MDC_OK;
 } MDC_CATCH(c)
 
@@ -1978,7 +2009,14 @@ static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const 
       ptrdiff_t pitch = n > 1 ? (const char*)src[f0 + 1] - (const char*)src[f0] : 0;
       for (int i = 2; i < n && pitch > 0; i++)
         if ((const char*)src[f0 + i] - (const char*)src[f0 + i - 1] != pitch) pitch = 0;
-      if (n > 1 && pitch >= (ptrdiff_t)width && width <= d_stride) {
+      // A strided copy reads `width` bytes of every row but the last: beyond a SHORTER stream's own bytes, up to the next
+      // buffer.  The contract only promises bytes[i] readable bytes per stream, so the strided form is taken when every row
+      // is `width` long anyway, or when the whole span is one page-locked allocation (the reader's ring: the gaps are its own
+      // memory); separately allocated buffers that merely happen to sit at equal spacing go up one by one.
+      bool rows_full = true;
+      for (int i = 0; i + 1 < n && bytes; i++) rows_full = rows_full && (size_t)bytes[f0 + i] == width;
+      if (n > 1 && pitch >= (ptrdiff_t)width && width <= d_stride &&
+          (rows_full || one_host_allocation(src[f0], (size_t)pitch * (size_t)(n - 1) + (bytes ? (size_t)bytes[f0 + n - 1] : fixed_bytes)))) {
         // rows of `width` bytes: a shorter source is followed by the next one within the pitch, except the LAST -- it goes up
         // with its own size (nothing is read beyond the end of the caller's last buffer)
         const size_t last = bytes ? (size_t)bytes[f0 + n - 1] : fixed_bytes;
