@@ -574,7 +574,7 @@ def main():
         todo = ("unmap", "pyramid", "seq50k") if D.world == 1 else ("seq50k",)
         for w2 in todo:
             torch.cuda.empty_cache()
-            r = run_workload(args, D, w2, 1024 if w2 != "seq50k" else 0, args.secondary_steps, 3, 0.05, do_ceiling=not args.no_ceiling)
+            r = run_workload(args, D, w2, 1024 if w2 != "seq50k" else 0, args.secondary_steps, 10, args.preroll_s, do_ceiling=not args.no_ceiling)
             if r is not None:
                 rf = r["roofline"]
                 secondary[w2] = {"workload": r["config"]["workload"], "value": r["value"], "unit": "Mpix/s", "scaling": r["scaling"],

@@ -250,6 +250,29 @@ void UndistorterFOV::distortCoordinates(float* in_x, float* in_y, int n) {
     std::printf("ERROR: invalid UndistorterFOV!\n");
     return;
   }
+  // Bulk callers (vignetteCalib: 10^6 plane points per image, src/main_vignetteCalib.cpp:284) go to the device: its kernel
+  // restates the host libm's atanf and gives the same bits (csrc/fov_point_model.h; pinned on the CPU against this very
+  // loop and on the GPU against the host).  Small counts stay here -- a launch and two copies cost more than the loop --,
+  // and so does the constructor's table build, which calls warp_points directly.  MDC_DISTORT_GPU_MIN overrides the
+  // threshold (0 = never on the device).
+  static const long gpu_min = [] {
+    const char* e = std::getenv("MDC_DISTORT_GPU_MIN");
+    return e ? std::atol(e) : 65536l;
+  }();
+  if (gpu_ && gpu_min > 0 && n >= gpu_min) {
+    mdc_fov_model m;
+    for (int i = 0; i < 5; i++) {
+      m.in_calib[i] = calib_in_[i];
+      m.out_calib[i] = calib_out_[i];
+    }
+    m.in_w = in_w_;
+    m.in_h = in_h_;
+    m.out_w = out_w_;
+    m.out_h = out_h_;
+    if (mdc_distort_points_host(gpu_, &m, in_x, in_y, n) == MDC_OK) return;
+    // the call leaves the coordinates untouched when it fails (they are copied back last): say so and do the work here
+    std::fprintf(stderr, "UndistorterFOV::distortCoordinates: the GPU call failed (%s); computing %d points on the host\n", mdc_last_error(gpu_), n);
+  }
   warp_points(calib_in_, in_w_, in_h_, calib_out_, out_w_, out_h_, in_x, in_y, n);
 }
 

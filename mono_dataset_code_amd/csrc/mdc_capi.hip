@@ -573,17 +573,13 @@ int plan_tiles(mdc_ctx* c) {
   // (128 x 16 first: measured 5-7 % faster than 64 x 32 on the bench camera -- a 64-wide tile spans ~86 source
   // bytes, less than one 128-byte line, so nearly every line is fetched by two workgroups; at 128 columns far
   // fewer are.  profiles/r02_experiments/)
-  static const TileShape cand_u8[] = {{128, 16}, {64, 32}, {128, 32}, {64, 64}, {64, 60}, {64, 16}, {320, 16}, {640, 8}};
-  static const TileShape cand_f32[] = {{128, 16}, {64, 32}, {64, 16}, {128, 32}, {64, 64}, {64, 60}, {0, 0}, {0, 0}};  // 0.66 / 0.63 / 0.60 / 0.60 / 0.54 of 8 TB/s
+  static const TileShape cand_u8[] = {{128, 16}, {64, 32}, {128, 32}, {64, 64}, {64, 60}, {64, 16}};
+  static const TileShape cand_f32[] = {{128, 16}, {64, 32}, {64, 16}, {128, 32}, {64, 64}, {64, 60}};  // 0.66 / 0.63 / 0.60 / 0.60 / 0.54 of 8 TB/s
   for (int which = 0; which < 2; which++) {
     const TileShape* cand = which == 0 ? cand_u8 : cand_f32;
-    // (a forced wide tile -- 8 rows per thread, raw u8 frames only -- leaves the float plan to its own list)
-    const bool wide = c->opt_tile_w >= 320 || c->opt_tile_h == 8;
-    const int want_w = (which == 1 && wide) ? 0 : c->opt_tile_w, want_h = (which == 1 && wide) ? 0 : c->opt_tile_h;
-    const bool forced = want_h != 0 || want_w != 0;
-    for (int k = 0; k < 8; k++) {
-      if (cand[k].w == 0) break;
-      const int tw = want_w ? want_w : cand[k].w, th = want_h ? want_h : cand[k].h;
+    const bool forced = c->opt_tile_h != 0 || c->opt_tile_w != 0;
+    for (int k = 0; k < 6; k++) {
+      const int tw = c->opt_tile_w ? c->opt_tile_w : cand[k].w, th = c->opt_tile_h ? c->opt_tile_h : cand[k].h;
       if (forced && (tw != cand[k].w || th != cand[k].h)) continue;  // a forced dimension filters the list
       free_src_plan(c->plan[which]);
       const int rc = plan_source(c, which == 0 ? 1 : 4, tw, th, c->plan[which]);
@@ -1053,8 +1049,8 @@ int mdc_set_option(mdc_ctx* c, int option, int value) try {
       c->opt_fpb = value;
       return MDC_OK;
     case MDC_OPT_TILE_ROWS: {
-      if (value != 0 && value != 8 && value != 16 && value != 32 && value != 60 && value != 64)
-        return fail(c, MDC_ERR_ARG, "tile rows must be 0 (automatic), 8, 16, 32, 60 or 64");
+      if (value != 0 && value != 16 && value != 32 && value != 60 && value != 64)
+        return fail(c, MDC_ERR_ARG, "tile rows must be 0 (automatic), 16, 32, 60 or 64");
       if (value == c->opt_tile_h) return MDC_OK;
       c->opt_tile_h = value;
       c->tuned_fpb = 0;  // a measured frames-per-workgroup belongs to the plan it was measured on
@@ -1064,8 +1060,7 @@ int mdc_set_option(mdc_ctx* c, int option, int value) try {
       return plan_tiles(c);
     }
     case MDC_OPT_TILE_COLS: {
-      if (value != 0 && value != 64 && value != 128 && value != 320 && value != 640)
-        return fail(c, MDC_ERR_ARG, "tile columns must be 0 (automatic), 64, 128, 320 or 640");
+      if (value != 0 && value != 64 && value != 128) return fail(c, MDC_ERR_ARG, "tile columns must be 0 (automatic), 64 or 128");
       if (value == c->opt_tile_w) return MDC_OK;
       c->opt_tile_w = value;
       c->tuned_fpb = 0;
@@ -1326,19 +1321,7 @@ int mdc_process_pyramid_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_b
 // (float products, `- 0.5` in double for the input camera, `- 0.5f`-equivalent narrowing for the output one,
 // double tan narrowed to float -- see DESIGN.md section 2).
 static DistortModel distort_model(const mdc_fov_model* f) {
-  DistortModel m;
-  const float dist = f->in_calib[4];
-  m.omega = dist;
-  m.d2t = 2.0f * ::tan((double)(dist / 2.0f));
-  m.fx = f->in_calib[0] * f->in_w;
-  m.fy = f->in_calib[1] * f->in_h;
-  m.cx = f->in_calib[2] * f->in_w - 0.5;
-  m.cy = f->in_calib[3] * f->in_h - 0.5;
-  m.ofx = f->out_calib[0] * f->out_w;
-  m.ofy = f->out_calib[1] * f->out_h;
-  m.ocx = f->out_calib[2] * f->out_w - 0.5f;
-  m.ocy = f->out_calib[3] * f->out_h - 0.5f;
-  return m;
+  return make_distort_model(f->in_calib, f->in_w, f->in_h, f->out_calib, f->out_w, f->out_h);
 }
 
 int mdc_distort_points_device(mdc_ctx* c, const mdc_fov_model* model, float* d_x, float* d_y, int64_t n, void* stream) try {

@@ -4,18 +4,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fov_point_model.h"
 #include "mdc_build_config.h"
 
 namespace mdc {
 
 // Geometry of the tiled kernel: tile_w x tile_h outputs per workgroup, one lane per output column
 // (tile_w / 64 waves side by side), `rpt` vertically consecutive output rows per thread  ->  tile_w * tile_h / rpt threads.
-// Legal shapes: 64 x {16, 32, 60, 64} (256 / 512 / 960 / 1024 threads), 128 x {16, 32} (512 / 1024), 4 rows per thread;
-// 320 x 16 and 640 x 8 (640 threads), 8 rows per thread -- raw u8 frames only, no fused pyramid.
+// Legal shapes: 64 x {16, 32, 60, 64} (256 / 512 / 960 / 1024 threads), 128 x {16, 32} (512 / 1024), 4 rows per thread.
+// (The kernel is written for `rpt` rows per thread; 320 x 16 and 640 x 8 tiles with 8 rows per thread were built, are bit-identical
+// and 15-20 % slower -- profiles/r04_experiments/01_* -- and are not instantiated.)
 struct TileShape {
   int w, h;
 };
-constexpr TileShape kTileShapes[] = {{64, 16}, {64, 32}, {64, 60}, {64, 64}, {128, 16}, {128, 32}, {320, 16}, {640, 8}};
+constexpr TileShape kTileShapes[] = {{64, 16}, {64, 32}, {64, 60}, {64, 64}, {128, 16}, {128, 32}};
 constexpr bool tile_shape_ok(int w, int h) {
   for (const TileShape& t : kTileShapes)
     if (t.w == w && t.h == h) return true;
@@ -111,11 +113,7 @@ hipError_t launch_prefetch_rows(const uint8_t* d_frames, int64_t frame_bytes, in
 // One 2x2 box level: dst (w/2 x h/2) from src (w x h), nframes images each.
 hipError_t launch_pyramid_level(const float* d_src, float* d_dst, int w, int h, int64_t nframes, hipStream_t s);
 
-// FOV lens model in pixel units, derived on the host exactly as src/FOVUndistorter.cpp:289-301 does.
-struct DistortModel {
-  float fx, fy, cx, cy, omega, d2t;  // input camera; d2t = 2 tan(omega / 2)
-  float ofx, ofy, ocx, ocy;          // rectified (output) camera
-};
+// FOV lens model (struct DistortModel) and its per-point arithmetic: fov_point_model.h
 // (x, y) rectified pixel -> raw pixel, in place (UndistorterFOV::distortCoordinates).
 hipError_t launch_distort_points(float* d_x, float* d_y, int64_t n, const DistortModel& m, hipStream_t s);
 

@@ -1181,68 +1181,19 @@ __global__ __launch_bounds__(256) void pyramid_level_kernel(const float* __restr
 }
 
 // ----------------------------------------------------------------------------
-// UndistorterFOV::distortCoordinates on the device (reference src/FOVUndistorter.cpp:280-319), for
-// callers that warp many points per frame (vignetteCalib: 10^6 per image, src/main_vignetteCalib.cpp:284).
-// Bit-exact with the reference needs the HOST libm's atanf, not the GPU math library's: atanf_host_libm
-// restates the fdlibm single-precision algorithm glibc ships (sysdeps/ieee754/flt-32/s_atanf.c; no FMA
-// variant on x86-64) -- argument reduction to one of four intervals, odd/even split of an 11-term
-// polynomial in x^2, hi/lo table of atan(0.5), atan(1), atan(1.5), pi/2.  Every operation is an IEEE
-// single-precision add / multiply / divide (this file is built with -ffp-contract=off), so the
-// results equal the host's bit for bit; tests compare against the host on 10^7 arguments.
+// UndistorterFOV::distortCoordinates on the device (reference src/FOVUndistorter.cpp:280-319), for callers that warp many
+// points per frame (vignetteCalib: 10^6 per image, src/main_vignetteCalib.cpp:284).  The per-point arithmetic -- with the
+// restatement of the HOST libm's atanf that bit-exactness needs -- lives in fov_point_model.h, a header the host compiler
+// takes as well: tests/test_distort_points_cpu.py pins it to the build box's libm and to the class's host path on the CPU.
 // ----------------------------------------------------------------------------
-__device__ __forceinline__ float atanf_host_libm(float x) {
-  const float hi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
-  const float lo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
-  const float a0 = 3.3333334327e-01f, a1 = -2.0000000298e-01f, a2 = 1.4285714924e-01f, a3 = -1.1111110449e-01f,
-              a4 = 9.0908870101e-02f, a5 = -7.6918758452e-02f, a6 = 6.6610731184e-02f, a7 = -5.8335702866e-02f,
-              a8 = 4.9768779427e-02f, a9 = -3.6531571299e-02f, a10 = 1.6285819933e-02f;
-  const uint32_t hx = __float_as_uint(x), ix = hx & 0x7fffffffu;
-  if (ix >= 0x50800000u) {  // |x| >= 2^34, inf, NaN
-    if (ix > 0x7f800000u) return x + x;
-    return (hx >> 31) ? -hi[3] - lo[3] : hi[3] + lo[3];
-  }
-  int id;
-  if (ix < 0x3ee00000u) {              // |x| < 0.4375
-    if (ix < 0x31000000u) return x;    // |x| < 2^-29
-    id = -1;
-  } else {
-    x = __uint_as_float(ix);           // fabsf
-    if (ix < 0x3f980000u) {            // |x| < 1.1875
-      if (ix < 0x3f300000u) {          // 7/16 <= |x| < 11/16
-        id = 0;
-        x = (2.0f * x - 1.0f) / (2.0f + x);
-      } else {                         // 11/16 <= |x| < 19/16
-        id = 1;
-        x = (x - 1.0f) / (x + 1.0f);
-      }
-    } else if (ix < 0x401c0000u) {     // |x| < 2.4375
-      id = 2;
-      x = (x - 1.5f) / (1.0f + 1.5f * x);
-    } else {                           // 2.4375 <= |x| < 2^34
-      id = 3;
-      x = -1.0f / x;
-    }
-  }
-  const float z = x * x, w = z * z;
-  const float s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
-  const float s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
-  if (id < 0) return x - x * (s1 + s2);
-  const float r = hi[id] - ((x * (s1 + s2) - lo[id]) - x);
-  return (hx >> 31) ? -r : r;
-}
-
 __global__ __launch_bounds__(256) void distort_points_kernel(float* __restrict__ xs, float* __restrict__ ys, long long n,
                                                              DistortModel m) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float ix = (xs[i] - m.ocx) / m.ofx;  // :306-307
-  float iy = (ys[i] - m.ocy) / m.ofy;
-  const float r = sqrtf(ix * ix + iy * iy);  // correctly rounded (no fast-math)
-  const float fac = (r == 0 || m.omega == 0) ? 1 : atanf_host_libm(r * m.d2t) / (m.omega * r);  // :310-311
-  ix = m.fx * fac * ix + m.cx;  // :313-314
-  iy = m.fy * fac * iy + m.cy;
-  xs[i] = ix;
-  ys[i] = iy;
+  float x = xs[i], y = ys[i];
+  fov_distort_point(m, x, y);
+  xs[i] = x;
+  ys[i] = y;
 }
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
@@ -1359,13 +1310,6 @@ static hipError_t launch_tiled_shape(const TiledLaunch& l) {
     case 128016: return launch_tiled_buf<VIG, BLACK, PYR, F32, 128, 512>(l);
     case 128032:
       if constexpr (!PYR) return launch_tiled_buf<VIG, BLACK, false, F32, 128, 1024>(l);
-      break;
-    // wide tiles, 8 outputs per thread, 640 threads (raw u8 frames only): one x-border inside a 640-wide output / none
-    case 320016:
-      if constexpr (!PYR && !F32) return launch_tiled_buf<VIG, BLACK, false, false, 320, 640>(l);
-      break;
-    case 640008:
-      if constexpr (!PYR && !F32) return launch_tiled_buf<VIG, BLACK, false, false, 640, 640>(l);
       break;
   }
   return hipErrorInvalidValue;

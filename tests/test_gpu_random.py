@@ -50,8 +50,8 @@ def test_random_camera_random_options(seed, tmp_path, oracle):
     st = torch.cuda.current_stream().cuda_stream
     want = {}
     for trial in range(6):
-        rows = int(rng.choice([8, 16, 32, 60, 64]))
-        cols = 640 if rows == 8 else int(rng.choice([64, 128, 320])) if rows == 16 else int(rng.choice([64, 128])) if rows == 32 else 64
+        rows = int(rng.choice([16, 32, 60, 64]))
+        cols = int(rng.choice([64, 128])) if rows in (16, 32) else 64
         ctx.set_option(capi.OPT_TILE_COLS, cols)
         ctx.set_option(capi.OPT_TILE_ROWS, rows)
         ctx.set_option(capi.OPT_WINDOW_BUFFERS, int(rng.choice([0, 2, 3, 4])))

@@ -13,7 +13,7 @@
 #   bench            plain `python bench.py` (the driver's command) -> bench.json
 #   bench2           `python bench.py --gpus 2` without torchrun (gloo, shared GPU)
 #   profile          tools/profile_bench.sh for the four workloads (rocprofv3 --stats + FETCH_SIZE / WRITE_SIZE passes)
-#   reader / dso / huffman / vcal   the secondary rate tools
+#   reader / dso / huffman / vcal / distort   the secondary rate tools
 set -u
 TAG=$1; shift
 cd "$GRAFT_REPO_ROOT"
@@ -74,6 +74,7 @@ PY
     reader)  timeout 900 python tools/reader_rate.py ${N:-512} > "$OUT/reader_rates.txt" 2>&1; grep -av amdgpu.ids "$OUT/reader_rates.txt" | tail -30 ;;
     dso)     timeout 600 python tools/dso_rate.py > "$OUT/dso_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/dso_rate.txt" | tail -20 ;;
     huffman) timeout 600 python tools/huffman_rate.py > "$OUT/huffman_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/huffman_rate.txt" | tail -20 ;;
+    distort) timeout 300 python tools/distort_rate.py > "$OUT/distort_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/distort_rate.txt" | tail -5 ;;
     vcal)    timeout 600 python tools/vcal_rate.py > "$OUT/vcal_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/vcal_rate.txt" | tail -20 ;;
     *) echo "unknown stage $stage" ;;
   esac
