@@ -6,159 +6,18 @@
 // host-pointer calls.  There is NO CPU implementation of the per-frame maths in
 // this library: without a HIP device every entry point fails with
 // MDC_ERR_NO_DEVICE.
-#include "../../include/mdc_hip.h"
-#include "mdc_internal.h"
-
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <limits>
-#include <atomic>
-#include <condition_variable>
-#include <mutex>
-#include <shared_mutex>
-#include <string>
-#include <vector>
+#include "mdc_ctx.h"
 
 using namespace mdc;
 
-struct mdc_ctx {
-  int device = 0;
-  // Locking.  `mu` guards the calibration tables, the plans and the options: the entry points that only READ them -- every
-  // per-frame call, host- or device-pointer -- take it shared and run concurrently; the setters (tables, options, tuning)
-  // take it exclusively (and then wait for the whole device, kernels on caller streams may still read the tables).
-  // What the readers do mutate has its own small lock: the last-error string, the list of page-locked caller buffers, the
-  // slots of the host-pointer calls, the pipeline of mdc_process_frames_host.
-  std::shared_timed_mutex mu;
-  mutable std::mutex err_mu;
-  std::string err;
-  std::mutex pin_mu, pipe_mu;
 
-  // Host-pointer calls (mdc_unmap_host, mdc_undistort_host_*, mdc_process_host, mdc_distort_points_host): each call leases a
-  // slot -- its own stream and staging buffers -- so that calls from several host threads overlap their copies and
-  // kernels instead of queueing on one stream.  Slots are created on demand, at most kMaxSlots; a caller beyond that waits.
-  struct HostSlot {
-    hipStream_t stream = nullptr;
-    void* d_in = nullptr;
-    size_t in_cap = 0;
-    float* d_out = nullptr;
-    size_t out_cap = 0;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // the chunked strip path borrows a slot's stream as its second one
-    bool busy = false;
-  };
-  static constexpr int kMaxSlots = 8;
-  std::mutex slot_mu;
-  std::condition_variable slot_cv;
-  std::vector<HostSlot*> slots;
+namespace mdc {
 
-  // photometric tables
-  int in_w = 0, in_h = 0;
-  bool valid_gamma = false, valid_vignette = false;
-  std::vector<float> h_ginv;  // 256
-  std::vector<float> h_vinv;  // in_w*in_h
-  float* d_luts = nullptr;    // 4 x 256: [gamma | kill<<1]
-  float* d_vinv = nullptr;
-
-  // geometric tables
-  bool valid_remap = false;
-  int rm_in_w = 0, rm_in_h = 0, out_w = 0, out_h = 0;
-  std::vector<float> h_rx, h_ry;
-  float *d_rx = nullptr, *d_ry = nullptr;
-
-  // tile plans, see TilePlan (mdc_internal.h): [0] raw u8 frames (fused path), [1] float frames
-  // (undistort<float>).  Each source type has its own tile shape and XCD placement table.
-  struct SrcPlan {
-    uint32_t* d_chunks = nullptr;
-    int* d_nch = nullptr;
-    uint32_t* d_taps = nullptr;
-    int* d_order = nullptr;  // block -> tile placement table (XCD bands)
-    int chunk_cap = 0, win_bytes = 0, nbuf = 2;
-    int tile_w = 0, tile_h = 0, n_tiles = 0, tiles_x = 0, n_blocks = 0;
-    bool tiled = false;
-    int64_t staged_bytes = 0;
-  } plan[2];
-  // wave-private strip kernel (StripPlan, mdc_internal.h): u8 frames, remaps with about one output or more per source pixel
-  struct Strip {
-    uint32_t* d_chunks = nullptr;
-    int* d_nch = nullptr;
-    uint32_t* d_taps = nullptr;
-    int* d_order = nullptr;
-    int n_blocks = 0, n_tiles = 0, tiles_x = 0, win_bytes = 0, passes = 0, nbuf = 2;
-    bool planned = false;
-    int64_t staged_bytes = 0;
-  } strip;
-  int bbox[4] = {0, 0, -1, -1};
-  int64_t n_black = 0;
-
-  // options
-  int opt_kernel = MDC_KERNEL_AUTO;
-  int opt_fpb = 0;
-  int tuned_fpb = 0;        // mdc_tune_device's pick for the u8 tiled plan; applies to launches of >= tuned_min_frames only
-  int64_t tuned_min_frames = 0;
-  int opt_tile_h = 0;  // 0 = automatic: the first shape of the candidate list whose windows fit
-  int opt_tile_w = 0;  // 0 = automatic
-  int opt_order = MDC_ORDER_BANDS;
-  int opt_nbuf = 0;  // 0 = automatic
-  int opt_interleave = 0;
-  int opt_pin_caller = 0;  // MDC_OPT_PIN_CALLER_BUFFERS
-  int opt_taper = 0;             // MDC_OPT_TAIL_TAPER: 0 = automatic (on), 1 = on, 2 = off
-  int opt_zero_copy = 0;         // MDC_OPT_ZERO_COPY: 0 = automatic (on), 1 = on, 2 = off
-  int opt_prefetch_streams = 0;  // MDC_OPT_PREFETCH_STREAMS: 0 = automatic (2), 1, 2
-  int opt_prefetch_chunk = 0;  // MDC_OPT_PREFETCH_CHUNK: frames per prefetched chunk of the strip path; 0 = automatic, -1 = no prefetch
-  int opt_two_stage = 0;   // MDC_OPT_TWO_STAGE: 0 = automatic (strip kernel by source pixels per output), 1 = strip kernel whenever
-                           // plannable, 2 = never
-
-  // Caller buffers page-locked in place (opt-in): the W*H float image that the reference's two-call composition
-  // moves host -> device -> host -> device (DatasetReader::internalTempBuffer, src/BenchmarkDatasetReader.h:145,222).
-  // An entry is made when the same (pointer, size) shows up on two consecutive calls of one role.
-  struct Pinned {
-    const void* p = nullptr;
-    size_t bytes = 0;
-    bool ok = false;  // false = registration was refused (e.g. already page-locked): do not try again
-    uint64_t used = 0;
-  };
-  std::vector<Pinned> pinned;
-  const void* pin_candidate[2] = {nullptr, nullptr};
-  size_t pin_candidate_bytes[2] = {0, 0};
-  uint64_t pin_clock = 0;
-
-  // pipelined host-frame path (mdc_process_frames_host): two chunk slots, each with its own stream
-  hipStream_t pipe_stream[2] = {nullptr, nullptr};
-  hipEvent_t pipe_done[2] = {nullptr, nullptr};
-  hipEvent_t pipe_dec[2] = {nullptr, nullptr};  // streams: "chunk decoded" (decode stream -> output stream)
-  hipStream_t pipe_up_stream = nullptr;          // streams: uploads run ahead of the decode stream on their own
-  hipEvent_t pipe_up[2] = {nullptr, nullptr};   // "chunk uploaded" (upload stream -> decode stream)
-  hipEvent_t pipe_huff[2] = {nullptr, nullptr}; // "stream buffer read" (decode stream -> upload stream)
-  uint8_t* d_pipe_in[2] = {nullptr, nullptr};
-  float* d_pipe_out[2] = {nullptr, nullptr};
-  void* d_pipe_rec[2] = {nullptr, nullptr};  // JPEG coefficient records of a chunk (mdc_process_jpeg_frames_host)
-  void* d_pipe_strm[2] = {nullptr, nullptr};  // JPEG streams of a chunk (mdc_process_jpeg_streams_host)
-  int* d_pipe_status[2] = {nullptr, nullptr}; // their decode status words (one chunk each)
-  int* h_pipe_status = nullptr;               // page-locked landing buffer for them (a whole call)
-  size_t pipe_status_cap = 0;
-  size_t pipe_in_cap = 0, pipe_out_cap = 0, pipe_rec_cap = 0, pipe_strm_cap = 0;
-
-  // vignetteCalib: bit pattern of the largest new vignette factor of ONE vignette step.  A ring of words, one per call:
-  // steps that different threads put on different streams of one context never share a word.
-  static constexpr int kVcalMaxWords = 256;
-  unsigned* d_vcal_max = nullptr;
-  std::atomic<unsigned> vcal_max_next{0};
-
-};
-using ReadLock = std::shared_lock<std::shared_timed_mutex>;
-using WriteLock = std::unique_lock<std::shared_timed_mutex>;
-
-namespace {
-
-thread_local std::string g_create_err;
+static thread_local std::string g_create_err;
 // mdc_last_error(ctx) returns the calling thread's own last failure on that context if it had one (several threads may
 // use one context), else the context's most recent one
-thread_local std::string t_err, t_err_other;
-thread_local const mdc_ctx* t_err_ctx = nullptr;
+static thread_local std::string t_err, t_err_other;
+static thread_local const mdc_ctx* t_err_ctx = nullptr;
 
 int fail(mdc_ctx* c, int code, const char* fmt, ...) {
   char buf[512];
@@ -179,23 +38,7 @@ int fail(mdc_ctx* c, int code, const char* fmt, ...) {
   return code;
 }
 
-#define MDC_HIP(c, call)                                                                      \
-  do {                                                                                        \
-    hipError_t e_ = (call);                                                                   \
-    if (e_ != hipSuccess) return fail((c), MDC_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
-  } while (0)
 
-struct DeviceGuard {
-  int prev = -1;
-  explicit DeviceGuard(int dev) {
-    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-    if (prev != dev) (void)hipSetDevice(dev);
-    else prev = -1;
-  }
-  ~DeviceGuard() {
-    if (prev >= 0) (void)hipSetDevice(prev);
-  }
-};
 
 // The reference's flag degradation, src/PhotometricUndistorter.cpp:173-189.
 void normalise(const mdc_ctx* c, unsigned flags, bool& g, bool& v, bool& o) {
@@ -225,7 +68,7 @@ int upload_luts(mdc_ctx* c) {
   return MDC_OK;
 }
 
-int frames_per_block(const mdc_ctx* c, int64_t nframes, int blocks_per_group, int target_wgs = 4800) {
+int frames_per_block(const mdc_ctx* c, int64_t nframes, int blocks_per_group, int target_wgs) {
   if (c->opt_fpb > 0) return (int)std::min<int64_t>(c->opt_fpb, std::max<int64_t>(nframes, 1));
   // enough workgroups to fill 256 CUs several times over (tail), yet >= 8 frames per
   // workgroup so the per-workgroup table reads stay amortised
@@ -241,509 +84,17 @@ int frames_per_block(const mdc_ctx* c, int64_t nframes, int blocks_per_group, in
   return (int)fpb;
 }
 
-// Placement table of the tiled kernel: entry b = tile run by block b of a frame group, -1 = none.
-// The dispatcher deals blocks round-robin over the 8 XCDs (block b -> XCD b % 8, slot b / 8), so
-// XCD k runs the tiles of entries k, k+8, k+16, ...  Neighbouring tiles share source lines (halo
-// rows, 128-byte lines straddling a tile border); they should meet in ONE XCD's L2.
-//   MDC_ORDER_BANDS     row-major runs of ceil(n/8) tiles per XCD
-//   MDC_ORDER_ROWS      whole tile rows per XCD, as even as the row count allows (no horizontal
-//                       neighbours split; XCDs with a row less idle at the end of a frame group)
-//   MDC_ORDER_IDENTITY  block b = tile b: neighbours land on different XCDs (diagnosis: worst case)
-//   MDC_ORDER_BLOCKS2D  the tile grid cut into 8 rectangles by recursive bisection of the longer side
-//                       (least shared halo perimeter between XCDs; the rectangles differ in size by up to
-//                       one row / column, XCDs with fewer tiles get padding slots)
-static void bisect(int x0, int y0, int x1, int y1, int parts, int tx, std::vector<std::vector<int>>& out) {
-  if (parts == 1) {
-    std::vector<int> v;
-    for (int y = y0; y < y1; y++)
-      for (int x = x0; x < x1; x++) v.push_back(y * tx + x);
-    out.push_back(v);
-    return;
-  }
-  if (x1 - x0 > y1 - y0) {
-    const int xm = x0 + (x1 - x0 + 1) / 2;
-    bisect(x0, y0, xm, y1, parts / 2, tx, out);
-    bisect(xm, y0, x1, y1, parts / 2, tx, out);
-  } else {
-    const int ym = y0 + (y1 - y0 + 1) / 2;
-    bisect(x0, y0, x1, ym, parts / 2, tx, out);
-    bisect(x0, ym, x1, y1, parts / 2, tx, out);
-  }
-}
 
-std::vector<int> tile_order(int tx, int ty, int mode) {
-  const int n = tx * ty;
-  std::vector<std::vector<int>> per_xcd(8);
-  if (mode == MDC_ORDER_BLOCKS2D && tx * ty >= 8) {
-    per_xcd.clear();
-    bisect(0, 0, tx, ty, 8, tx, per_xcd);
-  } else if (mode == MDC_ORDER_IDENTITY) {
-    for (int t = 0; t < n; t++) per_xcd[t % 8].push_back(t);
-  } else if (mode == MDC_ORDER_ROWS && ty >= 8) {
-    int r = 0;
-    for (int k = 0; k < 8; k++) {
-      const int rows = ty / 8 + (k < ty % 8 ? 1 : 0);
-      for (int y = r; y < r + rows; y++)
-        for (int x = 0; x < tx; x++) per_xcd[k].push_back(y * tx + x);
-      r += rows;
-    }
-  } else {
-    const int per = (n + 7) / 8;
-    for (int t = 0; t < n; t++) per_xcd[t / per].push_back(t);
-  }
-  size_t slots = 0;
-  for (const auto& v : per_xcd) slots = std::max(slots, v.size());
-  std::vector<int> order(slots * 8, -1);
-  for (int k = 0; k < 8; k++)
-    for (size_t j = 0; j < per_xcd[k].size(); j++) order[j * 8 + k] = per_xcd[k][j];
-  return order;
-}
 
-// Plan of the tiled kernel (see TilePlan): per tile the exact source window as a list of
-// 16-byte chunks, per output the LDS offsets of its two tap rows.  Fails (tiled = false)
-// when rows of the frame are not whole 16-byte chunks or a window is too large for LDS.
-void free_src_plan(mdc_ctx::SrcPlan& pl) {
-  for (void** p : {(void**)&pl.d_chunks, (void**)&pl.d_nch, (void**)&pl.d_taps, (void**)&pl.d_order})
-    if (*p) {
-      (void)hipFree(*p);
-      *p = nullptr;
-    }
-  pl.tiled = false;
-  pl.staged_bytes = 0;
-  pl.n_tiles = pl.tiles_x = pl.n_blocks = 0;
-}
-void free_strip_plan(mdc_ctx::Strip& st) {
-  for (void** p : {(void**)&st.d_chunks, (void**)&st.d_nch, (void**)&st.d_taps, (void**)&st.d_order})
-    if (*p) {
-      (void)hipFree(*p);
-      *p = nullptr;
-    }
-  st.planned = false;
-  st.staged_bytes = 0;
-  st.n_blocks = st.n_tiles = st.tiles_x = 0;
-}
-void free_plan(mdc_ctx* c) {
-  for (auto& pl : c->plan) {
-    free_src_plan(pl);
-  }
-  free_strip_plan(c->strip);
-}
 
-template <typename T>
-int upload(mdc_ctx* c, T** dst, const std::vector<T>& v) {
-  MDC_HIP(c, hipMalloc(dst, std::max<size_t>(v.size(), 1) * sizeof(T)));
-  if (!v.empty()) MDC_HIP(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-  return MDC_OK;
-}
 
-// The plan for source pixels of `es` bytes (1 = raw u8 frames with the LUT replicas in LDS,
-// 4 = float frames, no LUT): a 16-byte chunk holds 16 / es pixels.  Leaves pl.tiled = false when
-// frame rows are not whole chunks or a window is too large.
-int plan_source(mdc_ctx* c, int es, int kTileW, int kTileH, mdc_ctx::SrcPlan& pl) {
-  const int ow = c->out_w, oh = c->out_h, iw = c->rm_in_w;
-  const int kTileThreads = tile_threads(kTileW, kTileH);
-  pl.staged_bytes = 0;
-  const int tx = (ow + kTileW - 1) / kTileW, ty = (oh + kTileH - 1) / kTileH;
-  const int n_tiles = tx * ty;
-  const int ppc = 16 / es;  // pixels per chunk
-  const bool lut = es == 1;
-  // whole 16-byte chunks per frame row; one frame within the 32-bit lane offsets of the buffer descriptors
-  const char* why = "frame rows are not whole chunks / frame too large";
-  bool ok = (iw % ppc == 0) && (int64_t)iw * c->rm_in_h * es < (int64_t)kOutside && (int64_t)ow * oh * 4 < (int64_t)kOutside;
-  if (tile_rpt(kTileW, kTileH) != 4 && es != 1) ok = false;  // the 8-rows-per-thread tiles exist for raw u8 frames only
-  // the 960-/1024-thread tiles derive the output offsets of rows 1..3 from row 0 (kOutsideLean, mdc_kernels.hip)
-  if ((kTileThreads >= 960 || tile_rpt(kTileW, kTileH) > 4) && (int64_t)ow * (oh + kTileH) * 4 >= 0xc0000000ll) ok = false;
-  std::vector<std::vector<uint32_t>> chunks(n_tiles);
-  std::vector<int> nch(n_tiles, 0);
-  std::vector<uint32_t> taps((size_t)ow * oh, 0u);
-  for (int t = 0; t < n_tiles && ok; t++) {
-    const int bx = (t % tx) * kTileW, by = (t / tx) * kTileH;
-    const int x1 = std::min(bx + kTileW, ow), y1 = std::min(by + kTileH, oh);
-    int y_lo = std::numeric_limits<int>::max(), y_hi = -1;
-    for (int y = by; y < y1; y++)
-      for (int x = bx; x < x1; x++) {
-        const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
-        if (xx < 0) continue;
-        y_lo = std::min(y_lo, (int)yy);
-        y_hi = std::max(y_hi, (int)yy + 1);
-      }
-    if (y_hi < 0) continue;  // every output black: no window
-    // Exact chunk SET per source row (not one run from the leftmost to the rightmost tap: the source footprint of a wide,
-    // flat tile is a bowed band that touches a row in two separate places).  pos[row][chunk] = index of the chunk in the
-    // tile's list, -1 = not staged.  A tap pair (xi, xi+1) marks both bytes' chunks, so chunks that are neighbours in a
-    // frame row and both used are neighbours in the list too: the pair stays contiguous in LDS.
-    const int cpr = iw / ppc;  // chunks per frame row
-    const int nrows = y_hi - y_lo + 1;
-    std::vector<int> pos((size_t)nrows * cpr, -1);
-    for (int y = by; y < y1; y++)
-      for (int x = bx; x < x1; x++) {
-        const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
-        if (xx < 0) continue;
-        const int xi = (int)xx, yi = (int)yy;
-        for (int dy = 0; dy < 2; dy++) {
-          int* pr = &pos[(size_t)(yi + dy - y_lo) * cpr];
-          pr[xi / ppc] = 0;
-          pr[(xi + 1) / ppc] = 0;
-        }
-      }
-    for (int k = 0; k < nrows; k++)
-      for (int ch = 0; ch < cpr; ch++) {
-        int& q = pos[(size_t)k * cpr + ch];
-        if (q < 0) continue;
-        q = (int)chunks[t].size();
-        chunks[t].push_back((uint32_t)(((y_lo + k) * iw + ch * ppc) * es));
-      }
-    nch[t] = (int)chunks[t].size();
-    if (nch[t] > (lut ? kTileMaxChunks : kTileMaxChunksF32) * kTileThreads || nch[t] * 16 > 65535) {
-      ok = false;
-      why = "a window has too many chunks";
-    }
-    pl.staged_bytes += (int64_t)nch[t] * 16;
-    for (int y = by; y < y1 && ok; y++)
-      for (int x = bx; x < x1; x++) {
-        const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
-        if (xx < 0) continue;
-        const int xi = (int)xx, yi = (int)yy;
-        const int p0 = pos[(size_t)(yi - y_lo) * cpr + xi / ppc], p1 = pos[(size_t)(yi + 1 - y_lo) * cpr + xi / ppc];
-        taps[(size_t)y * ow + x] = (uint32_t)(p0 * 16 + (xi % ppc) * es) | ((uint32_t)(p1 * 16 + (xi % ppc) * es) << 16);
-      }
-  }
-  // every tile's chunk list is padded (kOutside) to the kernel's maximum of staging rounds: the kernel loads
-  // all of them unconditionally, first thing, before it knows the tile's chunk count
-  const int cap = (lut ? kTileMaxChunks : kTileMaxChunksF32) * kTileThreads;
-  int nch_max = 1;
-  for (int t = 0; t < n_tiles; t++) nch_max = std::max(nch_max, nch[t]);
-  const int win_bytes = (nch_max * 16 + 1023) & ~1023;  // a wave's DMA destination is 1 KiB aligned
-  // Window buffers: as many frames staged ahead as LDS allows WITHOUT lowering the number of
-  // workgroups per CU that two buffers permit (occupancy first, then depth), at most 4.
-  const int wg_per_cu =
-      std::max<int>(1, std::min<size_t>(kLdsPerCU / tiled_lds_bytes(win_bytes, 2, lut), 2048 / kTileThreads));
-  const int nbuf_max = kTileThreads > 512 ? 3 : 4;
-  int nbuf = 2;
-  while (nbuf < nbuf_max && tiled_lds_bytes(win_bytes, nbuf + 1, lut) * wg_per_cu <= kLdsPerCU) nbuf++;
-  if (c->opt_nbuf >= 2) nbuf = std::min(c->opt_nbuf, nbuf_max);
-  if (tile_rpt(kTileW, kTileH) > 4) nbuf = 3;  // the only instantiation of the 8-rows-per-thread tiles (mdc_kernels.hip: launch_tiled_buf)
-  if (tiled_lds_bytes(win_bytes, nbuf, lut) > kLdsPerCU) {
-    ok = false;
-    why = "windows do not fit LDS";
-  }
-  if (!ok) {
-    if (getenv("MDC_DEBUG_PLAN")) fprintf(stderr, "mdc plan %dx%d (element size %d): not plannable: %s\n", kTileW, kTileH, es, why);
-    return MDC_OK;
-  }
-  std::vector<uint32_t> flat((size_t)n_tiles * cap, kOutside);
-  for (int t = 0; t < n_tiles; t++) std::copy(chunks[t].begin(), chunks[t].end(), flat.begin() + (size_t)t * cap);
-  int rc;
-  if ((rc = upload(c, &pl.d_chunks, flat)) != MDC_OK || (rc = upload(c, &pl.d_nch, nch)) != MDC_OK ||
-      (rc = upload(c, &pl.d_taps, taps)) != MDC_OK)
-    return rc;
-  const std::vector<int> order = tile_order(tx, ty, c->opt_order);
-  if ((rc = upload(c, &pl.d_order, order)) != MDC_OK) return rc;
-  pl.n_blocks = (int)order.size();
-  pl.n_tiles = n_tiles;
-  pl.tiles_x = tx;
-  pl.tile_w = kTileW;
-  pl.tile_h = kTileH;
-  pl.chunk_cap = cap;
-  pl.win_bytes = win_bytes;
-  pl.nbuf = nbuf;
-  pl.tiled = true;
-  return MDC_OK;
-}
 
-// Plan of the wave-private strip kernel (StripPlan): per 128 x 8 output tile the exact source window as a dense list of
-// 16-byte chunks (<= kStripChunkCap), per output the byte offsets of its two tap rows inside the wave's FLOAT window.
-// Planned when the remap stages fewer source pixels than it has outputs (config 5's scale-1 rectification, magnifying
-// remaps) or on request (MDC_OPT_TWO_STAGE = 1); leaves st.planned = false when a window is too large, frame rows are not
-// whole chunks, or the output height is not a multiple of 8 (rows are addressed through the store's scalar offset,
-// which the hardware's range check does not cover).
-int plan_strip(mdc_ctx* c) {
-  mdc_ctx::Strip& st = c->strip;
-  free_strip_plan(st);
-  if (c->opt_two_stage == 2) return MDC_OK;
-  const int ow = c->out_w, oh = c->out_h, iw = c->rm_in_w;
-  constexpr int TW = kStripTileW, TH = kStripTileH;
-  if (iw % 16 != 0 || oh % TH != 0 || (int64_t)iw * c->rm_in_h >= (int64_t)kOutside || (int64_t)ow * (oh + TH) * 4 >= 0xc0000000ll) return MDC_OK;
-  const int tx = (ow + TW - 1) / TW, ty = oh / TH, n_tiles = tx * ty;
-  std::vector<uint32_t> flat((size_t)n_tiles * kStripChunkCap, kOutside);
-  std::vector<int> nch(n_tiles, 0);
-  std::vector<uint32_t> taps((size_t)ow * oh, 0u);
-  struct Row {
-    int lo = std::numeric_limits<int>::max(), hi = -1, x0 = 0, lds = 0;
-  };
-  int nch_max = 1;
-  int64_t staged = 0;
-  for (int t = 0; t < n_tiles; t++) {
-    const int bx = (t % tx) * TW, by = (t / tx) * TH;
-    const int x1 = std::min(bx + TW, ow), y1 = by + TH;
-    int y_lo = std::numeric_limits<int>::max(), y_hi = -1;
-    for (int y = by; y < y1; y++)
-      for (int x = bx; x < x1; x++) {
-        const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
-        if (xx < 0) continue;
-        y_lo = std::min(y_lo, (int)yy);
-        y_hi = std::max(y_hi, (int)yy + 1);
-      }
-    if (y_hi < 0) continue;  // every output black
-    std::vector<Row> rows(y_hi - y_lo + 1);
-    for (int y = by; y < y1; y++)
-      for (int x = bx; x < x1; x++) {
-        const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
-        if (xx < 0) continue;
-        const int xi = (int)xx, yi = (int)yy;
-        for (int dy = 0; dy < 2; dy++) {
-          Row& r = rows[yi + dy - y_lo];
-          r.lo = std::min(r.lo, xi);
-          r.hi = std::max(r.hi, xi + 1);
-        }
-      }
-    int n = 0;
-    for (size_t k = 0; k < rows.size(); k++) {
-      Row& r = rows[k];
-      if (r.hi < 0) continue;
-      r.x0 = r.lo - r.lo % 16;
-      r.lds = n * 16;
-      const int cnt = (r.hi - r.x0) / 16 + 1;
-      if (r.x0 + cnt * 16 > iw || n + cnt > kStripChunkCap) return MDC_OK;  // not plannable: the workgroup kernels keep the job
-      for (int j = 0; j < cnt; j++) flat[(size_t)t * kStripChunkCap + n + j] = (uint32_t)((y_lo + (int)k) * iw + r.x0 + j * 16);
-      n += cnt;
-    }
-    nch[t] = n;
-    nch_max = std::max(nch_max, n);
-    staged += (int64_t)n * 16;
-    for (int y = by; y < y1; y++)
-      for (int x = bx; x < x1; x++) {
-        const float xx = c->h_rx[(size_t)y * ow + x], yy = c->h_ry[(size_t)y * ow + x];
-        if (xx < 0) continue;
-        const int xi = (int)xx, yi = (int)yy;
-        const Row &r0 = rows[yi - y_lo], &r1 = rows[yi + 1 - y_lo];
-        taps[(size_t)y * ow + x] = (uint32_t)(4 * (r0.lds + xi - r0.x0)) | ((uint32_t)(4 * (r1.lds + xi - r1.x0)) << 16);
-      }
-  }
-  const double src_per_out = (double)staged / std::max<double>(1.0, (double)ow * oh);
-  if (c->opt_two_stage != 1 && src_per_out >= 1.0) return MDC_OK;
-  const int win = (nch_max * 16 + 63) & ~63;
-  const int need = (4 * nch_max + 63) / 64;  // convert passes
-  const int passes = need <= 2 ? 2 : need <= 3 ? 3 : need <= 4 ? 4 : need <= 5 ? 5 : 8;
-  const int nbuf = c->opt_nbuf >= 1 && c->opt_nbuf <= 4 ? c->opt_nbuf : 2;
-  if (strip_lds_bytes(win, nbuf, kStripWaves) > kLdsPerCU) return MDC_OK;
-  int rc;
-  if ((rc = upload(c, &st.d_chunks, flat)) != MDC_OK || (rc = upload(c, &st.d_nch, nch)) != MDC_OK || (rc = upload(c, &st.d_taps, taps)) != MDC_OK)
-    return rc;
-  // groups of kStripWaves consecutive tiles (row-major: neighbours along a tile row); XCD placement as for the workgroup tiles
-  const int n_groups = (n_tiles + kStripWaves - 1) / kStripWaves;
-  const int gx = std::max(1, tx / kStripWaves);
-  const std::vector<int> order = (tx % kStripWaves == 0) ? tile_order(gx, n_groups / gx, c->opt_order) : tile_order(n_groups, 1, MDC_ORDER_BANDS);
-  if ((rc = upload(c, &st.d_order, order)) != MDC_OK) return rc;
-  st.n_blocks = (int)order.size();
-  st.n_tiles = n_tiles;
-  st.tiles_x = tx;
-  st.win_bytes = win;
-  st.passes = passes;
-  st.nbuf = nbuf;
-  st.staged_bytes = staged;
-  st.planned = true;
-  return MDC_OK;
-}
 
-// Plans of the tiled kernels for the current remap: tile grid, XCD placement, source bounding
-// box, one SrcPlan per source pixel type.
-int plan_tiles(mdc_ctx* c) {
-  c->n_black = 0;
-  c->bbox[0] = c->bbox[1] = std::numeric_limits<int>::max();
-  c->bbox[2] = c->bbox[3] = -1;
-  free_plan(c);
-  const int ow = c->out_w, oh = c->out_h;
-  for (size_t i = 0; i < (size_t)ow * oh; i++) {
-    const float xx = c->h_rx[i], yy = c->h_ry[i];
-    if (xx < 0) {
-      c->n_black++;
-      continue;
-    }
-    c->bbox[0] = std::min(c->bbox[0], (int)xx);
-    c->bbox[2] = std::max(c->bbox[2], (int)xx + 1);
-    c->bbox[1] = std::min(c->bbox[1], (int)yy);
-    c->bbox[3] = std::max(c->bbox[3], (int)yy + 1);
-  }
-  if (c->bbox[2] < 0) c->bbox[0] = c->bbox[1] = 0;
-  // Tile shape per source type: the requested one, or the first candidate whose windows fit (strongly
-  // distorting cameras need the taller tiles: their windows are too wide for the staging rounds of the
-  // smaller workgroups).  Both lists are in order of measured speed on the bench camera (tools/sweep.py,
-  // tools/rate_undistort_f32.py).
-  // (128 x 16 first: measured 5-7 % faster than 64 x 32 on the bench camera -- a 64-wide tile spans ~86 source
-  // bytes, less than one 128-byte line, so nearly every line is fetched by two workgroups; at 128 columns far
-  // fewer are.  profiles/r02_experiments/)
-  static const TileShape cand_u8[] = {{128, 16}, {64, 32}, {128, 32}, {64, 64}, {64, 60}, {64, 16}};
-  static const TileShape cand_f32[] = {{128, 16}, {64, 32}, {64, 16}, {128, 32}, {64, 64}, {64, 60}};  // 0.66 / 0.63 / 0.60 / 0.60 / 0.54 of 8 TB/s
-  for (int which = 0; which < 2; which++) {
-    const TileShape* cand = which == 0 ? cand_u8 : cand_f32;
-    const bool forced = c->opt_tile_h != 0 || c->opt_tile_w != 0;
-    for (int k = 0; k < 6; k++) {
-      const int tw = c->opt_tile_w ? c->opt_tile_w : cand[k].w, th = c->opt_tile_h ? c->opt_tile_h : cand[k].h;
-      if (forced && (tw != cand[k].w || th != cand[k].h)) continue;  // a forced dimension filters the list
-      free_src_plan(c->plan[which]);
-      const int rc = plan_source(c, which == 0 ? 1 : 4, tw, th, c->plan[which]);
-      if (rc != MDC_OK) return rc;
-      if (c->plan[which].tiled) break;
-    }
-  }
-  return plan_strip(c);
-}
 
-// role 0: image_out of unMapImage, role 1: input of undistort<float>
-void maybe_pin(mdc_ctx* c, int role, const void* p, size_t bytes) {
-  if (!c->opt_pin_caller || bytes < (256u << 10)) return;
-  std::lock_guard<std::mutex> plk(c->pin_mu);
-  for (auto& e : c->pinned)
-    if (e.p == p && e.bytes == bytes) {
-      e.used = ++c->pin_clock;
-      return;
-    }
-  if (c->pin_candidate[role] != p || c->pin_candidate_bytes[role] != bytes) {  // first sighting: remember only
-    c->pin_candidate[role] = p;
-    c->pin_candidate_bytes[role] = bytes;
-    return;
-  }
-  constexpr size_t kMaxEntries = 8;
-  if (c->pinned.size() >= kMaxEntries) {  // least recently used entry goes
-    size_t lru = 0;
-    for (size_t i = 1; i < c->pinned.size(); i++)
-      if (c->pinned[i].used < c->pinned[lru].used) lru = i;
-    if (c->pinned[lru].ok) (void)hipHostUnregister(const_cast<void*>(c->pinned[lru].p));
-    c->pinned.erase(c->pinned.begin() + (long)lru);
-  }
-  for (auto& e : c->pinned)  // an overlapping older registration (the caller re-used part of the range)
-    if (e.ok && (const char*)p < (const char*)e.p + e.bytes && (const char*)e.p < (const char*)p + bytes) {
-      (void)hipHostUnregister(const_cast<void*>(e.p));
-      e.ok = false;
-    }
-  mdc_ctx::Pinned e;
-  e.p = p;
-  e.bytes = bytes;
-  e.ok = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess;
-  if (!e.ok) (void)hipGetLastError();  // refused (already page-locked, ...): plain copies keep working
-  e.used = ++c->pin_clock;
-  c->pinned.push_back(e);
-}
-void unpin_all(mdc_ctx* c) {
-  std::lock_guard<std::mutex> plk(c->pin_mu);
-  for (auto& e : c->pinned)
-    if (e.ok) (void)hipHostUnregister(const_cast<void*>(e.p));
-  c->pinned.clear();
-  c->pin_candidate[0] = c->pin_candidate[1] = nullptr;
-}
 
-// Zero copy (MDC_OPT_ZERO_COPY): a host buffer that is page-locked and mapped into the device's address space (hipHostMalloc
-// -- mdc_host_alloc, the reader's rings and image pool --, hipHostRegister) is handed to the kernels as it is: they read the
-// frame / write the result over PCIe themselves, both directions at once, instead of copy in -> kernel -> copy out.  Returns
-// the device's view of [p, p + bytes) or nullptr (pageable memory, a range that leaves its allocation, zero copy off).
-// Asked of the runtime on every call -- nothing is remembered about a caller's memory.
-template <class T>
-T* device_view(const mdc_ctx* c, T* p, size_t bytes) {
-  if (c->opt_zero_copy == 2 || !p || bytes == 0) return nullptr;
-  hipPointerAttribute_t a;
-  if (hipPointerGetAttributes(&a, (const void*)p) != hipSuccess) {
-    (void)hipGetLastError();  // pageable memory: not an error of ours
-    return nullptr;
-  }
-  if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
-  hipDeviceptr_t base = nullptr;
-  size_t size = 0;
-  if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)a.devicePointer) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  const uintptr_t lo = (uintptr_t)a.devicePointer, b0 = (uintptr_t)base;
-  if (lo < b0 || lo + bytes > b0 + size) return nullptr;
-  return (T*)a.devicePointer;
-}
 
-// true when [p, p + bytes) lies inside ONE page-locked allocation the runtime knows (whatever MDC_OPT_ZERO_COPY says): the
-// bytes between two buffers of such a range are readable
-bool one_host_allocation(const void* p, size_t bytes) {
-  if (!p || bytes == 0) return false;
-  hipPointerAttribute_t a;
-  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-    (void)hipGetLastError();
-    return false;
-  }
-  if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
-  hipDeviceptr_t base = nullptr;
-  size_t size = 0;
-  if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)a.devicePointer) != hipSuccess) {
-    (void)hipGetLastError();
-    return false;
-  }
-  const uintptr_t lo = (uintptr_t)a.devicePointer, b0 = (uintptr_t)base;
-  return lo >= b0 && lo + bytes <= b0 + size;
-}
 
-// A slot of the host-pointer calls for the duration of one call (RAII).  s == nullptr: no slot could be made (error set).
-struct SlotLease {
-  mdc_ctx* c;
-  mdc_ctx::HostSlot* s = nullptr;
-  // wait == false: take a free slot (or make one) or come back empty-handed, without an error
-  explicit SlotLease(mdc_ctx* ctx, bool wait = true) : c(ctx) {
-    std::unique_lock<std::mutex> lk(c->slot_mu);
-    for (;;) {
-      for (mdc_ctx::HostSlot* h : c->slots)
-        if (!h->busy) {
-          h->busy = true;
-          s = h;
-          return;
-        }
-      if ((int)c->slots.size() < mdc_ctx::kMaxSlots) {
-        mdc_ctx::HostSlot* h = new mdc_ctx::HostSlot();
-        const hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) {
-          delete h;
-          if (wait) fail(c, MDC_ERR_HIP, "hipStreamCreateWithFlags: %s", hipGetErrorString(e));
-          return;
-        }
-        h->busy = true;
-        c->slots.push_back(h);
-        s = h;
-        return;
-      }
-      if (!wait) return;
-      c->slot_cv.wait(lk);
-    }
-  }
-  // Every host call borrows the caller's buffers for its duration only and hands the slot (its stream, its staging
-  // buffers) to the next caller: whatever way the call ends -- an early return after an asynchronous copy was enqueued
-  // included --, nothing of it may still be in flight.  A call that has synchronised successfully says drained().
-  bool in_flight = true;
-  void drained() { in_flight = false; }
-  ~SlotLease() {
-    if (!s) return;
-    if (in_flight) (void)hipStreamSynchronize(s->stream);
-    {
-      std::lock_guard<std::mutex> lk(c->slot_mu);
-      s->busy = false;
-    }
-    c->slot_cv.notify_one();
-  }
-  SlotLease(const SlotLease&) = delete;
-  SlotLease& operator=(const SlotLease&) = delete;
-};
 
-int ensure_stage(mdc_ctx* c, mdc_ctx::HostSlot* h, size_t in_bytes, size_t out_bytes) {
-  if (in_bytes > h->in_cap) {
-    if (h->d_in) (void)hipFree(h->d_in);
-    h->d_in = nullptr;
-    h->in_cap = 0;
-    MDC_HIP(c, hipMalloc(&h->d_in, in_bytes));
-    h->in_cap = in_bytes;
-  }
-  if (out_bytes > h->out_cap) {
-    if (h->d_out) (void)hipFree(h->d_out);
-    h->d_out = nullptr;
-    h->out_cap = 0;
-    MDC_HIP(c, hipMalloc(&h->d_out, out_bytes));
-    h->out_cap = out_bytes;
-  }
-  return MDC_OK;
-}
 
 TilePlan tile_plan(const mdc_ctx* c, int which) {
   const mdc_ctx::SrcPlan& pl = c->plan[which];
@@ -807,7 +158,7 @@ int enqueue_undistort_f32(mdc_ctx* c, const float* d_in, float* d_out, int64_t n
 // Enqueue the fused / photometric-only pipeline on `s`.  Lock held by caller.
 // pyr (optional): levels 1..3 of the box pyramid; *pyr_done tells whether the launch wrote them.
 int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, hipStream_t s,
-                    float* const* pyr = nullptr, bool* pyr_done = nullptr) {
+                    float* const* pyr, bool* pyr_done) {
   if (pyr_done) *pyr_done = false;
   bool g, v, o;
   normalise(c, flags, g, v, o);
@@ -939,23 +290,15 @@ struct BlobHeader {
 };
 constexpr uint32_t kMagic = 0x4d444331u;  // "MDC1"
 
-}  // namespace
+DistortModel distort_model(const mdc_fov_model* f) {
+  return make_distort_model(f->in_calib, f->in_w, f->in_h, f->out_calib, f->out_w, f->out_h);
+}
+
+}  // namespace mdc
 
 static int set_photometric_locked(mdc_ctx* c, const float* ginv, const float* vignette_inv, int w, int h);
 static int set_remap_locked(mdc_ctx* c, const float* rx, const float* ry, int in_w, int in_h, int out_w, int out_h);
 
-// No exception leaves the C ABI: allocation failures of the host-side containers (tables, plans, pointer lists) and anything
-// else unexpected become a status + message.
-#define MDC_CATCH(c_)                                                                    \
-  catch (const std::bad_alloc&) {                                                        \
-    return fail((c_), MDC_ERR_NOMEM, "out of host memory");                              \
-  }                                                                                      \
-  catch (const std::exception& e_) {                                                     \
-    return fail((c_), MDC_ERR_HIP, "unexpected exception: %s", e_.what());               \
-  }                                                                                      \
-  catch (...) {                                                                          \
-    return fail((c_), MDC_ERR_HIP, "unexpected exception");                              \
-  }
 
 extern "C" {
 
@@ -1320,9 +663,6 @@ int mdc_process_pyramid_batch_device(mdc_ctx* c, const uint8_t* d_in, float* d_b
 // mdc_fov_model -> pixel-unit lens model, operation for operation as src/FOVUndistorter.cpp:289-301
 // (float products, `- 0.5` in double for the input camera, `- 0.5f`-equivalent narrowing for the output one,
 // double tan narrowed to float -- see DESIGN.md section 2).
-static DistortModel distort_model(const mdc_fov_model* f) {
-  return make_distort_model(f->in_calib, f->in_w, f->in_h, f->out_calib, f->out_w, f->out_h);
-}
 
 int mdc_distort_points_device(mdc_ctx* c, const mdc_fov_model* model, float* d_x, float* d_y, int64_t n, void* stream) try {
   if (!c) return MDC_ERR_ARG;
@@ -1333,29 +673,6 @@ int mdc_distort_points_device(mdc_ctx* c, const mdc_fov_model* model, float* d_x
   return MDC_OK;
 } MDC_CATCH(c)
 
-int mdc_distort_points_host(mdc_ctx* c, const mdc_fov_model* model, float* x, float* y, int64_t n) try {
-  if (!c) return MDC_ERR_ARG;
-  if (!model || n < 0 || (n > 0 && (!x || !y))) return fail(c, MDC_ERR_ARG, "mdc_distort_points_host: bad argument");
-  if (n == 0) return MDC_OK;
-  ReadLock lk(c->mu);
-  DeviceGuard dg(c->device);
-  const size_t bytes = (size_t)n * sizeof(float);
-  SlotLease slot(c);
-  if (!slot.s) return MDC_ERR_HIP;
-  int rc = ensure_stage(c, slot.s, bytes, bytes);
-  if (rc != MDC_OK) return rc;
-  hipStream_t st = slot.s->stream;
-  float* dx = (float*)slot.s->d_in;
-  float* dy = slot.s->d_out;
-  MDC_HIP(c, hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, st));
-  MDC_HIP(c, hipMemcpyAsync(dy, y, bytes, hipMemcpyHostToDevice, st));
-  MDC_HIP(c, launch_distort_points(dx, dy, n, distort_model(model), st));
-  MDC_HIP(c, hipMemcpyAsync(x, dx, bytes, hipMemcpyDeviceToHost, st));
-  MDC_HIP(c, hipMemcpyAsync(y, dy, bytes, hipMemcpyDeviceToHost, st));
-  MDC_HIP(c, hipStreamSynchronize(st));
-  slot.drained();
-  return MDC_OK;
-} MDC_CATCH(c)
 
 int mdc_gradients_batch_device(mdc_ctx* c, const float* d_level, int w, int h, float* d_dI, float* d_abs_squared_grad,
                                int64_t nframes, void* stream) try {
@@ -1714,424 +1031,16 @@ int mdc_synchronize(mdc_ctx* c) try {
 
 // ---- host-pointer single-frame calls ---------------------------------------------
 
-int mdc_unmap_host(mdc_ctx* c, const uint8_t* in, float* out, int n, unsigned flags) try {
-  if (!c) return MDC_ERR_ARG;
-  if (!in || !out || n < 0) return fail(c, MDC_ERR_ARG, "mdc_unmap_host: bad argument");
-  ReadLock lk(c->mu);
-  DeviceGuard dg(c->device);
-  if (n == 0) return MDC_OK;
-  bool g, v, o;
-  normalise(c, flags, g, v, o);
-  // The reference asserts n == w*h (compiled out under NDEBUG, :191) and would read
-  // vignetteMapInv[i] for i < n; with the vignette on we refuse a mismatching n.
-  if (v && (int64_t)n != (int64_t)c->in_w * c->in_h)
-    return fail(c, MDC_ERR_SIZE, "unMapImage: n = %d but the vignette holds %d pixels", n, c->in_w * c->in_h);
-  SlotLease slot(c);
-  if (!slot.s) return MDC_ERR_HIP;
-  maybe_pin(c, 0, out, (size_t)n * sizeof(float));
-  const uint8_t* z_in = device_view(c, in, (size_t)n);
-  float* z_out = device_view(c, out, (size_t)n * sizeof(float));
-  int rc = ensure_stage(c, slot.s, z_in ? 0 : (size_t)n, z_out ? 0 : (size_t)n * sizeof(float));
-  if (rc != MDC_OK) return rc;
-  hipStream_t st = slot.s->stream;
-  if (!z_in) MDC_HIP(c, hipMemcpyAsync(slot.s->d_in, in, (size_t)n, hipMemcpyHostToDevice, st));
-  MDC_HIP(c, launch_unmap(z_in ? z_in : (const uint8_t*)slot.s->d_in, z_out ? z_out : slot.s->d_out, lut_for(c, g, o), v ? c->d_vinv : nullptr, n,
-                          1, 1, st));
-  if (!z_out) MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
-  MDC_HIP(c, hipStreamSynchronize(st));
-  slot.drained();
-  return MDC_OK;
-} MDC_CATCH(c)
 
-static int undistort_host(mdc_ctx* c, const void* in, bool is_f32, float* out, int n_in, int n_out) {
-  if (!c) return MDC_ERR_ARG;
-  if (!in || !out) return fail(c, MDC_ERR_ARG, "undistort: NULL buffer");
-  ReadLock lk(c->mu);
-  DeviceGuard dg(c->device);
-  if (!c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
-  if (n_in != c->rm_in_w * c->rm_in_h)
-    return fail(c, MDC_ERR_SIZE, "undistort called with wrong input image dimensions (expected %d pixel, got %d pixel)",
-                c->rm_in_w * c->rm_in_h, n_in);
-  if (n_out != c->out_w * c->out_h)
-    return fail(c, MDC_ERR_SIZE, "undistort called with wrong output image dimensions (expected %d pixel, got %d pixel)",
-                c->out_w * c->out_h, n_out);
-  const size_t in_bytes = (size_t)n_in * (is_f32 ? 4 : 1);
-  SlotLease slot(c);
-  if (!slot.s) return MDC_ERR_HIP;
-  if (is_f32) maybe_pin(c, 1, in, in_bytes);
-  const void* z_in = device_view(c, in, in_bytes);
-  float* z_out = device_view(c, out, (size_t)n_out * sizeof(float));
-  int rc = ensure_stage(c, slot.s, z_in ? 0 : in_bytes, z_out ? 0 : (size_t)n_out * sizeof(float));
-  if (rc != MDC_OK) return rc;
-  hipStream_t st = slot.s->stream;
-  if (!z_in) MDC_HIP(c, hipMemcpyAsync(slot.s->d_in, in, in_bytes, hipMemcpyHostToDevice, st));
-  const void* src = z_in ? z_in : slot.s->d_in;
-  float* dst = z_out ? z_out : slot.s->d_out;
-  if (is_f32) rc = enqueue_undistort_f32(c, (const float*)src, dst, 1, st);
-  else rc = enqueue_process(c, (const uint8_t*)src, dst, 1, MDC_RECTIFY, st);
-  if (rc != MDC_OK) {
-    (void)hipStreamSynchronize(st);  // the upload borrows the caller's buffer: not in flight after the call
-    return rc;
-  }
-  if (!z_out) MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, (size_t)n_out * sizeof(float), hipMemcpyDeviceToHost, st));
-  MDC_HIP(c, hipStreamSynchronize(st));
-  slot.drained();
-  return MDC_OK;
-}
 
-int mdc_undistort_host_f32(mdc_ctx* c, const float* in, float* out, int n_in, int n_out) try {
-  return undistort_host(c, in, true, out, n_in, n_out);
-} MDC_CATCH(c)
-int mdc_undistort_host_u8(mdc_ctx* c, const uint8_t* in, float* out, int n_in, int n_out) try {
-  return undistort_host(c, in, false, out, n_in, n_out);
-} MDC_CATCH(c)
 
-int mdc_process_host(mdc_ctx* c, const uint8_t* raw, float* out, unsigned flags) try {
-  if (!c) return MDC_ERR_ARG;
-  if (!raw || !out) return fail(c, MDC_ERR_ARG, "mdc_process_host: NULL buffer");
-  ReadLock lk(c->mu);
-  DeviceGuard dg(c->device);
-  const bool rect = (flags & MDC_RECTIFY) != 0;
-  if (rect && !c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
-  const int iw = (rect || c->in_w <= 0) ? c->rm_in_w : c->in_w, ih = (rect || c->in_h <= 0) ? c->rm_in_h : c->in_h;
-  if (iw <= 0 || ih <= 0) return fail(c, MDC_ERR_STATE, "frame size unknown");
-  const size_t n_in = (size_t)iw * ih;
-  const size_t n_out = rect ? (size_t)c->out_w * c->out_h : n_in;
-  SlotLease slot(c);
-  if (!slot.s) return MDC_ERR_HIP;
-  const uint8_t* z_in = device_view(c, raw, n_in);
-  float* z_out = device_view(c, out, n_out * sizeof(float));
-  int rc = ensure_stage(c, slot.s, z_in ? 0 : n_in, z_out ? 0 : n_out * sizeof(float));
-  if (rc != MDC_OK) return rc;
-  hipStream_t st = slot.s->stream;
-  if (!z_in) MDC_HIP(c, hipMemcpyAsync(slot.s->d_in, raw, n_in, hipMemcpyHostToDevice, st));
-  rc = enqueue_process(c, z_in ? z_in : (const uint8_t*)slot.s->d_in, z_out ? z_out : slot.s->d_out, 1, flags, st);
-  if (rc != MDC_OK) {
-    (void)hipStreamSynchronize(st);
-    return rc;
-  }
-  if (!z_out) MDC_HIP(c, hipMemcpyAsync(out, slot.s->d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, st));
-  MDC_HIP(c, hipStreamSynchronize(st));
-  slot.drained();
-  return MDC_OK;
-} MDC_CATCH(c)
 
 // ---- host-pointer, many frames: copies and kernels overlapped ------------------------------
 
-void* mdc_host_alloc(size_t bytes) {
-  void* p = nullptr;
-  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
-  return p;
-}
-void mdc_host_free(void* p) {
-  if (p) (void)hipHostFree(p);
-}
 
-// Common body of the pipelined host calls: frame i comes from raw[i] (bytes), or, with `rec`, from the JPEG coefficient
-// record rec[i] through the device-side inverse DCT, or, with `strm`, from the JPEG stream strm[i] (strm_bytes[i] bytes)
-// through the device-side Huffman decoder and the inverse DCT (status: per-frame decode status, may be NULL).
-static int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const void* const* rec, int64_t record_bytes, int blocks_w,
-                                   int blocks_rows, float* const* out, int64_t nframes, unsigned flags, const char* who,
-                                   const void* const* strm = nullptr, const int64_t* strm_bytes = nullptr, int* status = nullptr) {
-  if (!c) return MDC_ERR_ARG;
-  if (nframes < 0 || (nframes > 0 && ((!raw && !rec && !strm) || !out || (strm && !strm_bytes)))) return fail(c, MDC_ERR_ARG, "%s: bad argument", who);
-  ReadLock lk(c->mu);
-  std::lock_guard<std::mutex> pipe_lk(c->pipe_mu);  // one pipelined call at a time per context (it overlaps internally)
-  DeviceGuard dg(c->device);
-  const bool rect = (flags & MDC_RECTIFY) != 0;
-  if (rect && !c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
-  const int iw = (rect || c->in_w <= 0) ? c->rm_in_w : c->in_w, ih = (rect || c->in_h <= 0) ? c->rm_in_h : c->in_h;
-  if (iw <= 0 || ih <= 0) return fail(c, MDC_ERR_STATE, "frame size unknown");
-  const size_t n_in = (size_t)iw * ih;
-  const size_t n_out = rect ? (size_t)c->out_w * c->out_h : n_in;
-  size_t strm_stride = 0;
-  if (strm) {  // streams are decoded into records of the reader's geometry (block grid rounded up to multiples of 4)
-    blocks_w = ((iw + 7) / 8 + 3) & ~3;
-    blocks_rows = ((ih + 7) / 8 + 3) & ~3;
-    record_bytes = 128 + (int64_t)blocks_w * blocks_rows * 128;
-    for (int64_t i = 0; i < nframes; i++) {
-      if (strm_bytes[i] < (int64_t)sizeof(mdc_jpeg_stream_header) + 17 || strm_bytes[i] > (1ll << 28))
-        return fail(c, MDC_ERR_ARG, "%s: stream %lld has an impossible size", who, (long long)i);
-      strm_stride = std::max(strm_stride, (size_t)strm_bytes[i]);
-    }
-    strm_stride = (strm_stride + 15) & ~(size_t)15;
-  }
-  if ((rec || strm) && (blocks_w < (iw + 7) / 8 || blocks_rows < (ih + 7) / 8 || record_bytes % 16 != 0 ||
-                        record_bytes < 128 + (int64_t)blocks_w * blocks_rows * 128))
-    return fail(c, MDC_ERR_ARG, "%s: coefficient records do not describe a %dx%d frame", who, iw, ih);
-  for (int64_t i = 0; i < nframes; i++)
-    if (!(strm ? strm[i] : rec ? rec[i] : (const void*)raw[i]) || !out[i])
-      return fail(c, MDC_ERR_ARG, "%s: frame %lld has a NULL buffer", who, (long long)i);
-  if (status)
-    for (int64_t i = 0; i < nframes; i++) status[i] = 0;
-  if (strm && status && c->pipe_status_cap < (size_t)nframes) {  // status words come back asynchronously: page-locked landing buffer
-    if (c->h_pipe_status) (void)hipHostFree(c->h_pipe_status);
-    c->h_pipe_status = nullptr;
-    c->pipe_status_cap = 0;
-    const size_t cap = std::max<size_t>(256, (size_t)nframes * 2);
-    MDC_HIP(c, hipHostMalloc((void**)&c->h_pipe_status, cap * sizeof(int), hipHostMallocDefault));
-    c->pipe_status_cap = cap;
-  }
-  int* d_host_status = nullptr;  // the device's view of h_pipe_status
-  if (strm && status && c->h_pipe_status && hipHostGetDevicePointer((void**)&d_host_status, c->h_pipe_status, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    d_host_status = nullptr;
-  }
-  constexpr int kChunk = 16;  // frames per slot: one kernel launch (two with the inverse DCT), 2 x 16 async copies
-  // Zero copy (device_view): results go straight into the caller's images when every one of them is mapped page-locked
-  // memory, frames are read straight from the caller's buffers when every one of them is (coefficient records are always
-  // copied: the inverse DCT reads a record 16 bytes at a time per thread, uncached that would cross PCIe several times).
-  static const bool trace = getenv("MDC_PIPE_TRACE") != nullptr;  // where a pipelined call spends its host time (stderr)
-  const auto t_begin = std::chrono::steady_clock::now();
-  auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-  std::vector<float*> z_out((size_t)nframes);
-  std::vector<const uint8_t*> z_in((rec || strm) ? 0 : (size_t)nframes);
-  // Streams: results are staged on the device and leave with ONE copy per run of images that lie back to back (the reader's pool
-  // hands out slabs): while a kernel writes results across PCIe itself, the kernels of other streams make no progress -- the
-  // Huffman launch of the next chunk finished 0.8 ms (its own time) after the output of the current one, however few
-  // workgroups the output launch had --, the copy engine moves the same bytes at the same 52 GB/s and leaves the CUs alone
-  // (256 frames: 10.4 -> 7.5 ms, profiles/r03_experiments/20_*).
-  bool zc_out = nframes > 0 && !strm, zc_in = !rec && !strm && nframes > 0;
-  for (int64_t i = 0; i < nframes && zc_out; i++) zc_out = (z_out[(size_t)i] = device_view(c, out[i], n_out * sizeof(float))) != nullptr;
-  for (int64_t i = 0; i < nframes && zc_in; i++) zc_in = (z_in[(size_t)i] = device_view(c, raw[i], n_in)) != nullptr;
-  if (!zc_out) zc_in = false;  // frames alone: the copy pipeline (one launch per chunk) stays
-  if (zc_out) {
-    // Zero copy pays here when frames lie back to back (rows of one block: one launch per chunk reads / writes them in place).
-    // Scattered images -- the reader's pool -- would mean one single-frame launch each: measured next to the decode stream
-    // those run at 47 us per frame where one batched launch + the DMA engines' copies out take 25 (experiment 14).
-    int64_t runs = 1;
-    for (int64_t i = 1; i < nframes; i++)
-      if (z_out[(size_t)i] != z_out[(size_t)i - 1] + n_out || (zc_in && z_in[(size_t)i] != z_in[(size_t)i - 1] + n_in)) runs++;
-    if (runs * 8 > nframes && nframes >= 8) zc_out = zc_in = false;
-  }
-  const double t_views = since();
-  // frames per slot.  Streams: 64 -- the Huffman kernel's time does not depend on the frame count up to ~64 (one workgroup per
-  // frame, 1.3 ms), so small chunks would only repeat that latency; nothing staged: the chunk only alternates the streams
-  const int chunk = (zc_in && zc_out) ? 64 : (strm ? 64 : kChunk);
-  const bool inplace_out = zc_out;
-  const size_t in_need = zc_in ? 0 : chunk * n_in, out_need = inplace_out ? 0 : chunk * n_out * sizeof(float);
-  const size_t rec_need = (rec || strm) ? (size_t)chunk * (size_t)record_bytes : 0;
-  const size_t strm_need = strm ? (size_t)chunk * strm_stride : 0;
-  if (c->pipe_in_cap < in_need || c->pipe_out_cap < out_need || c->pipe_rec_cap < rec_need || c->pipe_strm_cap < strm_need || !c->pipe_stream[0] ||
-      !c->pipe_stream[1]) {
-    const size_t in_cap = std::max(in_need, c->pipe_in_cap), out_cap = std::max(out_need, c->pipe_out_cap), rec_cap = std::max(rec_need, c->pipe_rec_cap);
-    const size_t strm_cap = std::max(strm_need + strm_need / 4, c->pipe_strm_cap);  // (stream sizes vary from call to call: some headroom)
-    c->pipe_in_cap = c->pipe_out_cap = c->pipe_rec_cap = c->pipe_strm_cap = 0;  // a failure part-way leaves "no slots", not stale capacities
-    for (int k = 0; k < 2; k++) {
-      if (c->pipe_stream[k]) MDC_HIP(c, hipStreamSynchronize(c->pipe_stream[k]));
-      if (!c->pipe_stream[k]) MDC_HIP(c, hipStreamCreateWithFlags(&c->pipe_stream[k], hipStreamNonBlocking));
-      if (!c->pipe_done[k]) MDC_HIP(c, hipEventCreateWithFlags(&c->pipe_done[k], hipEventDisableTiming));
-      if (!c->pipe_dec[k]) MDC_HIP(c, hipEventCreateWithFlags(&c->pipe_dec[k], hipEventDisableTiming));
-      for (void** p : {(void**)&c->d_pipe_in[k], (void**)&c->d_pipe_out[k], &c->d_pipe_rec[k], &c->d_pipe_strm[k], (void**)&c->d_pipe_status[k]})
-        if (*p) {
-          (void)hipFree(*p);
-          *p = nullptr;
-        }
-      if (in_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_in[k], in_cap));
-      if (out_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_out[k], out_cap));
-      if (rec_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_rec[k], rec_cap));
-      if (strm_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_strm[k], strm_cap));
-      if (strm_cap) MDC_HIP(c, hipMalloc((void**)&c->d_pipe_status[k], 64 * sizeof(int)));
-    }
-    c->pipe_in_cap = in_cap;
-    c->pipe_out_cap = out_cap;
-    c->pipe_rec_cap = rec_cap;
-    c->pipe_strm_cap = strm_cap;
-  }
-  if (strm && !c->pipe_up_stream) {
-    MDC_HIP(c, hipStreamCreateWithFlags(&c->pipe_up_stream, hipStreamNonBlocking));
-    for (int k = 0; k < 2; k++) {
-      if (!c->pipe_up[k]) MDC_HIP(c, hipEventCreateWithFlags(&c->pipe_up[k], hipEventDisableTiming));
-      if (!c->pipe_huff[k]) MDC_HIP(c, hipEventCreateWithFlags(&c->pipe_huff[k], hipEventDisableTiming));
-    }
-  }
-  // chunk k runs entirely on stream k%2 (H2D, kernel(s), D2H in order); the two streams overlap one
-  // chunk's copies with the other's kernel.  Re-using a slot waits for its previous chunk.
-  // On a failure the loop stops, BOTH streams are drained (asynchronous copies into the caller's buffers
-  // may still be in flight) and only then the error is returned.
-  int rc = MDC_OK;
-  hipError_t he = hipSuccess;
-  const char* what = "";
-#define MDC_PIPE(call)              \
-  if (he == hipSuccess) {           \
-    he = (call);                    \
-    if (he != hipSuccess) what = #call; \
-  }
-  int n = 0;
-  // MDC_PIPE_TRACE: per chunk 6 time stamps [upload: start, done; decode stream: Huffman done, decoded; output stream: start, done]
-  const int64_t nchunks = (nframes + chunk - 1) / chunk;
-  std::vector<hipEvent_t> tev(trace ? (size_t)nchunks * 6 : 0, (hipEvent_t) nullptr);
-  auto stamp = [&](int64_t kk, int j, hipStream_t st) {
-    if (!trace) return;
-    hipEvent_t e = nullptr;
-    if (hipEventCreate(&e) == hipSuccess) {
-      (void)hipEventRecord(e, st);
-      tev[(size_t)kk * 6 + j] = e;
-    }
-  };
-  for (int64_t f0 = 0, k = 0; f0 < nframes && rc == MDC_OK && he == hipSuccess; f0 += n, k++) {
-    const int slot = (int)(k & 1);
-    // Streams: ALL chunks decode on stream 0 (upload, Huffman kernel, inverse DCT) and go out on stream 1 (fused pass into the
-    // caller's images), tied by events -- the Huffman kernel takes ~1.3 ms whatever the frame count (one workgroup per frame)
-    // and the output is PCIe-bound, so chunk k+1 decodes while chunk k goes out.  Otherwise chunk k runs on stream k % 2.
-    hipStream_t s = strm ? c->pipe_stream[0] : c->pipe_stream[slot];
-    hipStream_t s_out = strm ? c->pipe_stream[1] : s;
-    // (a smaller first chunk, to get the output going earlier, is slower: the Huffman launch takes ~0.75 ms whatever its frame
-    // count, so more chunks only lengthen the decode stream -- profiles/r03_experiments/19_*)
-    n = (int)std::min<int64_t>(chunk, nframes - f0);
-    if (k >= 2 && strm) {  // the slot's staging is free again: in stream order ...
-      MDC_PIPE(hipStreamWaitEvent(s, c->pipe_done[slot], 0));
-    } else if (k >= 2 && !(zc_in && zc_out)) {  // ... or on the host
-      MDC_PIPE(hipEventSynchronize(c->pipe_done[slot]));
-    }
-    // a chunk whose sources lie at one stride in host memory (the reader's ring) goes up as ONE strided copy: 64 separate
-    // copies of a 270-KB stream cost the decode stream ~1 ms of the ~2.5 ms a chunk takes
-    auto upload = [&](int64_t f0, int n, void* d_dst, size_t d_stride, const void* const* src, const int64_t* bytes, size_t fixed_bytes, hipStream_t s) {
-      size_t width = fixed_bytes;
-      for (int i = 0; i < n && bytes; i++) width = std::max(width, (size_t)bytes[f0 + i]);
-      ptrdiff_t pitch = n > 1 ? (const char*)src[f0 + 1] - (const char*)src[f0] : 0;
-      for (int i = 2; i < n && pitch > 0; i++)
-        if ((const char*)src[f0 + i] - (const char*)src[f0 + i - 1] != pitch) pitch = 0;
-      // A strided copy reads `width` bytes of every row but the last: beyond a SHORTER stream's own bytes, up to the next
-      // buffer.  The contract only promises bytes[i] readable bytes per stream, so the strided form is taken when every row
-      // is `width` long anyway, or when the whole span is one page-locked allocation (the reader's ring: the gaps are its own
-      // memory); separately allocated buffers that merely happen to sit at equal spacing go up one by one.
-      bool rows_full = true;
-      for (int i = 0; i + 1 < n && bytes; i++) rows_full = rows_full && (size_t)bytes[f0 + i] == width;
-      if (n > 1 && pitch >= (ptrdiff_t)width && width <= d_stride &&
-          (rows_full || one_host_allocation(src[f0], (size_t)pitch * (size_t)(n - 1) + (bytes ? (size_t)bytes[f0 + n - 1] : fixed_bytes)))) {
-        // rows of `width` bytes: a shorter source is followed by the next one within the pitch, except the LAST -- it goes up
-        // with its own size (nothing is read beyond the end of the caller's last buffer)
-        const size_t last = bytes ? (size_t)bytes[f0 + n - 1] : fixed_bytes;
-        const int rows2d = last == width ? n : n - 1;
-        MDC_PIPE(hipMemcpy2DAsync(d_dst, d_stride, src[f0], (size_t)pitch, width, (size_t)rows2d, hipMemcpyHostToDevice, s));
-        if (rows2d < n) MDC_PIPE(hipMemcpyAsync((char*)d_dst + (size_t)(n - 1) * d_stride, src[f0 + n - 1], last, hipMemcpyHostToDevice, s));
-      } else {
-        for (int i = 0; i < n; i++)
-          MDC_PIPE(hipMemcpyAsync((char*)d_dst + (size_t)i * d_stride, src[f0 + i], bytes ? (size_t)bytes[f0 + i] : fixed_bytes, hipMemcpyHostToDevice, s));
-      }
-    };
-    if (strm) {
-      // Uploads run ahead on their own stream: chunk k+1's streams are ENQUEUED before anything of chunk k (the copy queues
-      // work in submission order -- an upload submitted after chunk k's copy out would wait behind it) and go up as soon as the
-      // Huffman launch of chunk k-1 has read the buffer, i.e. under the decode of chunk k and the output of chunk k-1.
-      auto enqueue_upload = [&](int64_t kk) {
-        const int sl = (int)(kk & 1);
-        const int64_t uf0 = kk * chunk;
-        const int un = (int)std::min<int64_t>(chunk, nframes - uf0);
-        hipStream_t up = c->pipe_up_stream;
-        if (kk >= 2) MDC_PIPE(hipStreamWaitEvent(up, c->pipe_huff[sl], 0));
-        stamp(kk, 0, up);
-        upload(uf0, un, c->d_pipe_strm[sl], strm_stride, strm, strm_bytes, 0, up);
-        MDC_PIPE(hipEventRecord(c->pipe_up[sl], up));
-        stamp(kk, 1, up);
-      };
-      if (k == 0) enqueue_upload(0);
-      if (f0 + n < nframes) enqueue_upload(k + 1);
-      MDC_PIPE(hipStreamWaitEvent(s, c->pipe_up[slot], 0));
-      // the status words land in page-locked host memory directly (a copy would queue behind the results going out)
-      int* d_status = (status && d_host_status) ? d_host_status + f0 : c->d_pipe_status[slot];
-      MDC_PIPE(launch_jpeg_huffman(c->d_pipe_strm[slot], (int64_t)strm_stride, c->d_pipe_rec[slot], record_bytes, iw, ih, blocks_w, blocks_rows, n,
-                                   d_status, s));
-      MDC_PIPE(hipEventRecord(c->pipe_huff[slot], s));
-      stamp(k, 2, s);
-      if (status && !d_host_status)
-        MDC_PIPE(hipMemcpyAsync(c->h_pipe_status + f0, c->d_pipe_status[slot], (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
-      MDC_PIPE(launch_jpeg_idct(c->d_pipe_rec[slot], record_bytes, c->d_pipe_in[slot], iw, ih, blocks_w, blocks_rows, n, s));
-    } else if (rec) {
-      stamp(k, 0, s);
-      upload(f0, n, c->d_pipe_rec[slot], (size_t)record_bytes, rec, nullptr, (size_t)record_bytes, s);
-      stamp(k, 1, s);
-      MDC_PIPE(launch_jpeg_idct(c->d_pipe_rec[slot], record_bytes, c->d_pipe_in[slot], iw, ih, blocks_w, blocks_rows, n, s));
-    } else {
-      stamp(k, 0, s);
-      if (!zc_in) upload(f0, n, c->d_pipe_in[slot], n_in, reinterpret_cast<const void* const*>(raw), nullptr, n_in, s);
-      stamp(k, 1, s);
-    }
-    if (he != hipSuccess) break;
-    stamp(k, 3, s);
-    if (strm) {
-      MDC_PIPE(hipEventRecord(c->pipe_dec[slot], s));
-      MDC_PIPE(hipStreamWaitEvent(s_out, c->pipe_dec[slot], 0));
-      if (he != hipSuccess) break;
-    }
-    stamp(k, 4, s_out);
-    if (inplace_out) {  // one launch per run of frames that lie back to back on both sides
-      for (int i = 0; i < n && rc == MDC_OK;) {
-        const uint8_t* src = zc_in ? z_in[(size_t)(f0 + i)] : c->d_pipe_in[slot] + (size_t)i * n_in;
-        float* dst = z_out[(size_t)(f0 + i)];
-        int run = 1;
-        while (i + run < n && z_out[(size_t)(f0 + i + run)] == dst + (size_t)run * n_out &&
-               (!zc_in || z_in[(size_t)(f0 + i + run)] == src + (size_t)run * n_in))
-          run++;
-        rc = enqueue_process(c, src, dst, run, flags, s_out);
-        i += run;
-      }
-      if (rc != MDC_OK) break;
-    } else {
-      rc = enqueue_process(c, c->d_pipe_in[slot], c->d_pipe_out[slot], n, flags, s_out);
-      if (rc != MDC_OK) break;
-      for (int i = 0; i < n;) {  // one copy per run of images that lie back to back in the caller's memory
-        int run = 1;
-        while (i + run < n && out[f0 + i + run] == out[f0 + i] + (size_t)run * n_out) run++;
-        MDC_PIPE(hipMemcpyAsync(out[f0 + i], c->d_pipe_out[slot] + (size_t)i * n_out, (size_t)run * n_out * sizeof(float),
-                                hipMemcpyDeviceToHost, s_out));
-        i += run;
-      }
-    }
-    MDC_PIPE(hipEventRecord(c->pipe_done[slot], s_out));
-    stamp(k, 5, s_out);
-  }
-  const double t_enqueued = since();
-  if (strm && c->pipe_up_stream) {
-    const hipError_t e = hipStreamSynchronize(c->pipe_up_stream);
-    if (he == hipSuccess && e != hipSuccess) {
-      he = e;
-      what = "hipStreamSynchronize(pipe_up_stream)";
-    }
-  }
-  for (int k = 0; k < 2; k++) {
-    const hipError_t e = hipStreamSynchronize(c->pipe_stream[k]);
-    if (he == hipSuccess && e != hipSuccess) {
-      he = e;
-      what = "hipStreamSynchronize(pipe_stream)";
-    }
-  }
-#undef MDC_PIPE
-  if (trace && !tev.empty() && tev[0] && he == hipSuccess && rc == MDC_OK) {
-    std::fprintf(stderr, "%s: chunks, ms since the first upload [upload from-to | decode: Huffman done, decoded | out: from-to]", who);
-    for (size_t q = 0; q + 5 < tev.size(); q += 6) {
-      float t[6] = {-1, -1, -1, -1, -1, -1};
-      for (int j = 0; j < 6; j++)
-        if (tev[q + j]) (void)hipEventElapsedTime(&t[j], tev[0], tev[q + j]);
-      std::fprintf(stderr, "  [%.2f-%.2f | %.2f, %.2f | %.2f-%.2f]", t[0], t[1], t[2], t[3], t[4], t[5]);
-    }
-    std::fprintf(stderr, "\n");
-  }
-  for (hipEvent_t e : tev)
-    if (e) (void)hipEventDestroy(e);
-  if (trace)
-    std::fprintf(stderr, "%s: %lld frames: buffer queries %.2f ms, everything enqueued at %.2f ms, streams drained at %.2f ms\n", who, (long long)nframes,
-                 t_views, t_enqueued, since());
-  if (rc != MDC_OK) return rc;
-  if (he != hipSuccess) return fail(c, MDC_ERR_HIP, "%s: %s", what, hipGetErrorString(he));
-  if (strm && status) memcpy(status, c->h_pipe_status, (size_t)nframes * sizeof(int));
-  return MDC_OK;
-}
 
-int mdc_process_frames_host(mdc_ctx* c, const uint8_t* const* raw, float* const* out, int64_t nframes, unsigned flags) try {
-  return process_frames_pipeline(c, raw, nullptr, 0, 0, 0, out, nframes, flags, "mdc_process_frames_host");
-} MDC_CATCH(c)
 
-int mdc_process_jpeg_frames_host(mdc_ctx* c, const void* const* records, int64_t record_bytes, int blocks_w, int blocks_rows,
-                                 float* const* out, int64_t nframes, unsigned flags) try {
-  return process_frames_pipeline(c, nullptr, records, record_bytes, blocks_w, blocks_rows, out, nframes, flags, "mdc_process_jpeg_frames_host");
-} MDC_CATCH(c)
 
-int mdc_process_jpeg_streams_host(mdc_ctx* c, const void* const* streams, const int64_t* stream_bytes, float* const* out, int64_t nframes,
-                                  unsigned flags, int* status) try {
-  return process_frames_pipeline(c, nullptr, nullptr, 0, 0, 0, out, nframes, flags, "mdc_process_jpeg_streams_host", streams, stream_bytes, status);
-} MDC_CATCH(c)
 
 int mdc_jpeg_huffman_batch_device(mdc_ctx* c, const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w, int h,
                                   int blocks_w, int blocks_rows, int64_t nframes, int* d_status, void* stream) try {
