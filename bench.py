@@ -298,6 +298,11 @@ class Dist:
                 dist.init_process_group(self.backend)
             assert dist.get_world_size() == self.world, "process group has %d ranks, WORLD_SIZE says %d" % (dist.get_world_size(), self.world)
 
+    def stream(self):
+        if getattr(self, "_stream", None) is None:
+            self._stream = torch.cuda.Stream(device=self.dev)
+        return self._stream
+
     def barrier(self):
         if self.active:
             self.dist.barrier()
@@ -389,7 +394,10 @@ def run_workload(args, D, wl, frames, steps, warmup, preroll_s, do_ceiling, tune
     mine = shard.frames_of_rank(total, rank, world)
     B = len(mine)
     npix_in, npix_out = IN_W * IN_H, out_w * out_h
-    tstream = torch.cuda.Stream(device=dev)  # every launch and every timing event goes on this stream
+    # every launch and every timing event goes on ONE stream, made once per process and shared by the workloads that follow each
+    # other in it (a caller has one stream; and the chunked strip path of configs[4] alternates between the caller's stream and
+    # one of its own -- on a fresh stream per workload the pair sometimes landed on one hardware queue and ran 18 % slower)
+    tstream = D.stream()
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     d_in = torch.empty(B * npix_in, dtype=torch.uint8, device=dev)

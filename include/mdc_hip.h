@@ -134,6 +134,7 @@ typedef struct mdc_info {
 /* Creates a context on HIP device `device` (-1 = the calling thread's current
  * device).  MDC_ERR_NO_DEVICE if no GPU is visible. */
 int mdc_create(int device, mdc_ctx** out);
+int mdc_device_count(void); /* visible HIP devices (0 without a GPU or a usable runtime) */
 void mdc_destroy(mdc_ctx* ctx);
 const char* mdc_last_error(const mdc_ctx* ctx); /* never NULL; "" if no error; ctx may be NULL (creation errors) */
 int mdc_get_info(mdc_ctx* ctx, mdc_info* info);

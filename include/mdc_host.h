@@ -79,6 +79,8 @@ void mdch_reader_set_lookahead(mdch_reader*, int frames); /* setResultLookahead(
 void mdch_reader_set_gpu_jpeg(mdch_reader*, int stage);   /* setGpuJpegStage(): 0 host, 1 device inverse DCT, 2 (or any other) device Huffman too */
 const char* mdch_reader_last_error(mdch_reader*);
 void mdch_reader_prefetch_stats(mdch_reader*, long hits_misses[2]); /* getPrefetchStats() */
+/* getDeviceStats(lane, ...): device ordinal + frames produced, seconds waiting for the decoders + seconds in GPU calls; 0 = no such lane */
+int mdch_reader_device_stats(mdch_reader*, int lane, int64_t device_frames[2], double wait_gpu_seconds[2]);
 
 /* The reader's frame decoders on a byte string (8-bit gray PNG, PGM P5, baseline JPEG): 1 on success, else 0
  * with the reason in err (errcap bytes).  wh = decoded size (also set when only cap was too small). */

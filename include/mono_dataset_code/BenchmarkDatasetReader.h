@@ -85,6 +85,12 @@ class DatasetReader {
   void setResultLookahead(int frames);
   const char* lastError() const; // why the last getImage / getImages / getImageRaw returned 0 / fewer images
   void getPrefetchStats(long* hits, long* misses) const;  // frames found decoded ahead / decoded by the calling thread
+  // Several GPUs (MDC_DEVICES=all | 0,1,... in the environment, read by the constructor): getImages -- and with it the results
+  // getImage makes ahead -- deals its range to the devices in chunks of >= 64 frames, round-robin; every device holds the same
+  // calibration tables (one RCCL broadcast over xGMI when libmdc_multi.so is there, else uploaded to each), has its own decode
+  // ring and runs its GPU calls from its own host thread; results land in the caller's order, bit-identical to one device.
+  int getDeviceCount() const;  // devices in use (1 without MDC_DEVICES)
+  void getDeviceStats(int lane, int* device, long* frames, double* decoder_wait_s, double* gpu_call_s) const;  // over the reader's life
 
  private:
   DatasetReader(const DatasetReader&);

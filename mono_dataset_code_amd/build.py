@@ -109,7 +109,7 @@ def build_host(force=False):
     if force or _stale(LIB_HOST, HOST_DEPS + [LIB_HIP]):
         _run(["g++"] + HOST_FLAGS + ["-I" + INC, "-I" + os.path.join(INC, "mono_dataset_code"), "-I" + HOST,
                                      "-I" + eigen_include()] + HOST_SOURCES +
-             ["-L" + PKG, "-lmdc_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-lpthread", "-o", LIB_HOST])
+             ["-L" + PKG, "-lmdc_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-lpthread", "-ldl", "-o", LIB_HOST])
     return LIB_HOST
 
 
@@ -146,7 +146,7 @@ def build_host_sanitize(out):
     src = [os.path.join(ROOT, "tests", "native", "host_sanitize.cpp")] + HOST_SOURCES
     _run(["g++", "-O1", "-g", "-std=c++11", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
           "-fno-omit-frame-pointer", "-Wall", "-I" + INC, "-I" + os.path.join(INC, "mono_dataset_code"), "-I" + HOST,
-          "-I" + eigen_include()] + src + ["-L" + PKG, "-lmdc_hip", "-Wl,-rpath," + PKG, "-lz", "-lpthread", "-o", out])
+          "-I" + eigen_include()] + src + ["-L" + PKG, "-lmdc_hip", "-Wl,-rpath," + PKG, "-lz", "-lpthread", "-ldl", "-o", out])
     return out
 
 
@@ -157,7 +157,7 @@ def build_host_tsan(out):
     src = [os.path.join(ROOT, "tests", "native", "host_tsan.cpp")] + HOST_SOURCES
     _run(["g++", "-O1", "-g", "-std=c++11", "-ffp-contract=off", "-fsanitize=thread", "-fno-omit-frame-pointer", "-Wall", "-I" + INC,
           "-I" + os.path.join(INC, "mono_dataset_code"), "-I" + HOST, "-I" + eigen_include()] + src +
-         ["-L" + PKG, "-lmdc_hip", "-Wl,-rpath," + PKG, "-lz", "-lpthread", "-o", out])
+         ["-L" + PKG, "-lmdc_hip", "-Wl,-rpath," + PKG, "-lz", "-lpthread", "-ldl", "-o", out])
     return out
 
 

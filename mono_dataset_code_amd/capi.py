@@ -28,7 +28,7 @@ OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM = 0, -1, -2,
 
 # every symbol include/mdc_hip.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = [
-    "mdc_create", "mdc_destroy", "mdc_last_error", "mdc_build_flags", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
+    "mdc_create", "mdc_destroy", "mdc_device_count", "mdc_last_error", "mdc_build_flags", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
     "mdc_set_remap", "mdc_unmap_host", "mdc_undistort_host_f32", "mdc_undistort_host_u8", "mdc_process_host",
     "mdc_host_alloc", "mdc_host_free", "mdc_process_frames_host", "mdc_process_jpeg_frames_host", "mdc_jpeg_idct_batch_device", "mdc_process_jpeg_streams_host", "mdc_jpeg_huffman_batch_device",
     "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
@@ -46,7 +46,7 @@ HOST_SYMBOLS = [
     "mdch_photo_g", "mdch_photo_vignette", "mdch_photo_unmap", "mdch_bind", "mdch_pack_tables",
     "mdch_reader_create", "mdch_reader_destroy", "mdch_reader_num_images", "mdch_reader_timestamp", "mdch_reader_exposure",
     "mdch_reader_dims", "mdch_reader_get_image", "mdch_reader_get_images", "mdch_reader_get_raw", "mdch_reader_set_threads",
-    "mdch_reader_set_prefetch", "mdch_reader_set_gpu_jpeg", "mdch_reader_set_lookahead", "mdch_reader_last_error", "mdch_reader_prefetch_stats", "mdch_decode_gray8", "mdch_jpeg_record_bytes",
+    "mdch_reader_set_prefetch", "mdch_reader_set_gpu_jpeg", "mdch_reader_set_lookahead", "mdch_reader_last_error", "mdch_reader_prefetch_stats", "mdch_reader_device_stats", "mdch_decode_gray8", "mdch_jpeg_record_bytes",
     "mdch_decode_jpeg_record", "mdch_jpeg_stream", "mdch_image_alloc", "mdch_image_free",
     "mdch_image_pool_trim", "mdch_image_pool_idle_bytes",
 ]
@@ -269,6 +269,7 @@ def host_lib():
         L.mdch_reader_last_error.restype = C.c_char_p
         L.mdch_reader_prefetch_stats.argtypes = [_vp, _vp]
         L.mdch_reader_prefetch_stats.restype = None
+        L.mdch_reader_device_stats.argtypes = [_vp, _i, _vp, _vp]
         L.mdch_decode_gray8.argtypes = [_vp, _sz, _vp, _sz, _vp, C.c_char_p, _sz]
         L.mdch_jpeg_record_bytes.argtypes = [_i, _i, _vp]
         L.mdch_jpeg_record_bytes.restype = _sz
@@ -800,6 +801,18 @@ class DatasetReader:
         hm = np.zeros(2, np.int64)
         self._L.mdch_reader_prefetch_stats(self._h, _np_ptr(hm))
         return int(hm[0]), int(hm[1])
+
+    def device_stats(self):
+        """Per device the reader deals getImages chunks to (MDC_DEVICES): (device ordinal, frames produced, seconds waiting for
+        the decoders, seconds inside the GPU calls), over the reader's life."""
+        res = []
+        for lane in range(64):
+            idf = np.zeros(2, np.int64)
+            t = np.zeros(2, np.float64)
+            if not self._L.mdch_reader_device_stats(self._h, lane, _np_ptr(idf), _np_ptr(t)):
+                break
+            res.append((int(idf[0]), int(idf[1]), float(t[0]), float(t[1])))
+        return res
 
     def set_threads(self, n):
         self._L.mdch_reader_set_threads(self._h, n)

@@ -11,6 +11,7 @@
 
 #include <exception>
 #include <dirent.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <cctype>
 #include <chrono>
@@ -111,9 +112,22 @@ struct DatasetReader::State {
   // the pool decodes chunks k+1 .. (up to 192 frames in flight): a decode thread that is slow on one frame delays only the
   // chunk that frame is in, not the pipeline (two half-rings of 64 stalled on every straggler: 2.5-2.9 k frames/s)
   enum { kRingFrames = 256 };  // page-locked decode buffers of getImages (335 MB at 1280x1024, 670 MB in stage 1 and for calls of > 256 frames in stage 2; first getImages)
-  HostBuffer ring_block;               // ONE page-locked block: slot i at ring_block.p + i * ring_stride (a chunk's uploads are
-  size_t ring_stride = 0;              // then one strided copy instead of one copy per frame)
-  int ring_slots = 0;
+  // One lane per device the reader may use (MDC_DEVICES; lanes[0] is `gpu`): its context and its own decode ring --
+  // ONE page-locked block, slot i at ring_block.p + i * ring_stride (a chunk's uploads are then one strided copy instead of
+  // one copy per frame), ring_bytes per buffer (a frame, or a record when the GPU JPEG stage is on).
+  struct Lane {
+    mdc_ctx* gpu = 0;
+    int device = -1;
+    HostBuffer ring_block;
+    size_t ring_stride = 0, ring_bytes = 0;
+    int ring_slots = 0;
+    long frames = 0;  // statistics over the reader's life: frames produced, seconds waiting for the decoders / inside GPU calls
+    double t_wait = 0, t_gpu = 0;
+  };
+  struct LaneRun;
+  std::vector<Lane> lanes;
+  void* multi = 0;  // libmdc_multi.so's object when the lanes' contexts are its (RCCL table broadcast), else the lanes own theirs
+  std::mutex err_mu, image_mu;
 
   size_t frame_bytes() const { return (size_t)W * H; }
   // GPU JPEG stage of getImages: JPEG frames travel as coefficient records (2 bytes per pixel + table), the inverse DCT runs on
@@ -144,7 +158,136 @@ struct DatasetReader::State {
   }
   int rec_pitch = 0, rec_rows = 0;
   size_t rec_bytes = 0;
-  size_t ring_bytes = 0;  // bytes of one ring buffer (a frame, or a record when the GPU JPEG stage is on)
+
+  // ---- devices ---------------------------------------------------------------------------------
+  // Frames of a sequence are independent (reference src/BenchmarkDatasetReader.h:188-243), so getImages deals its range to
+  // every device listed in MDC_DEVICES in chunks (lane l takes chunks l, l + L, ...).  All lanes hold the SAME tables: with
+  // libmdc_multi.so next to this library and distinct devices, rank 0's tables go out in one RCCL broadcast over xGMI
+  // (mdc_multi_bcast_tables); otherwise (the library is missing, or a device is listed twice -- a test on a one-GPU box) every
+  // context takes them from the host objects directly.  Either way the bytes are the host's.
+  struct MultiApi {
+    void* lib = 0;
+    int (*create)(const int*, int, void**) = 0;
+    void (*destroy)(void*) = 0;
+    mdc_ctx* (*ctx)(void*, int) = 0;
+    int (*bcast)(void*, int) = 0;
+    const char* (*last_error)(const void*) = 0;
+  } mapi;
+  bool load_multi() {
+    if (mapi.lib) return true;
+    Dl_info info;
+    std::string dir;
+    if (dladdr((void*)&mdc_host::open_device_context, &info) && info.dli_fname) {
+      dir = info.dli_fname;
+      const size_t sl = dir.rfind('/');
+      dir = sl == std::string::npos ? std::string() : dir.substr(0, sl + 1);
+    }
+    void* lib = dlopen((dir + "libmdc_multi.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return false;
+    mapi.create = (int (*)(const int*, int, void**))dlsym(lib, "mdc_multi_create");
+    mapi.destroy = (void (*)(void*))dlsym(lib, "mdc_multi_destroy");
+    mapi.ctx = (mdc_ctx * (*)(void*, int)) dlsym(lib, "mdc_multi_ctx");
+    mapi.bcast = (int (*)(void*, int))dlsym(lib, "mdc_multi_bcast_tables");
+    mapi.last_error = (const char* (*)(const void*))dlsym(lib, "mdc_multi_last_error");
+    if (!mapi.create || !mapi.destroy || !mapi.ctx || !mapi.bcast || !mapi.last_error) {
+      dlclose(lib);
+      return false;
+    }
+    mapi.lib = lib;
+    return true;
+  }
+  static std::vector<int> device_list() {
+    std::vector<int> devs;
+    const char* e = std::getenv("MDC_DEVICES");
+    if (!e || !*e) return devs;
+    if (std::string(e) == "all") {
+      const int n = mdc_device_count();
+      for (int i = 0; i < n; i++) devs.push_back(i);
+      return devs;
+    }
+    for (const char* p = e; *p;) {
+      char* end = 0;
+      const long v = std::strtol(p, &end, 10);
+      if (end == p) break;
+      if (v >= 0) devs.push_back((int)v);
+      p = *end == ',' ? end + 1 : end;
+      if (*end && *end != ',') break;
+    }
+    return devs;
+  }
+  void open_devices() {
+    const std::vector<int> devs = device_list();
+    bool distinct = devs.size() > 1;
+    for (size_t i = 0; i < devs.size(); i++)
+      for (size_t j = i + 1; j < devs.size(); j++)
+        if (devs[i] == devs[j]) distinct = false;
+    if (distinct && load_multi()) {  // one RCCL broadcast of rank 0's tables
+      void* m = 0;
+      if (mapi.create(devs.data(), (int)devs.size(), &m) == MDC_OK && m) {
+        mdc_ctx* root = mapi.ctx(m, 0);
+        if (root && mdc_bind_objects(root, fov, photo) == MDC_OK && mapi.bcast(m, 0) == MDC_OK) {
+          multi = m;
+          for (size_t r = 0; r < devs.size(); r++) {
+            Lane ln;
+            ln.gpu = mapi.ctx(m, (int)r);
+            ln.device = devs[r];
+            lanes.push_back(ln);
+          }
+          gpu = lanes[0].gpu;
+          std::printf("DatasetReader: %d devices, calibration tables broadcast over RCCL\n", (int)devs.size());
+          return;
+        }
+        std::fprintf(stderr, "DatasetReader: RCCL table broadcast failed (%s); every device takes the tables from the host\n", mapi.last_error(m));
+        mapi.destroy(m);
+      }
+    }
+    if (devs.size() > 1) {
+      for (size_t r = 0; r < devs.size(); r++) {
+        mdc_ctx* c = 0;
+        if (mdc_create(devs[r], &c) != MDC_OK || mdc_bind_objects(c, fov, photo) != MDC_OK) {
+          std::fprintf(stderr, "DatasetReader: device %d: %s; not used\n", devs[r], mdc_last_error(c));
+          if (c) mdc_destroy(c);
+          continue;
+        }
+        Lane ln;
+        ln.gpu = c;
+        ln.device = devs[r];
+        lanes.push_back(ln);
+      }
+      if (!lanes.empty()) {
+        gpu = lanes[0].gpu;
+        std::printf("DatasetReader: %d devices, calibration tables uploaded to each\n", (int)lanes.size());
+        return;
+      }
+    }
+    gpu = devs.size() == 1 ? 0 : mdc_host::open_device_context("DatasetReader");
+    if (devs.size() == 1 && mdc_create(devs[0], &gpu) != MDC_OK) {
+      std::fprintf(stderr, "DatasetReader: no GPU context on device %d (%s)\n", devs[0], mdc_last_error(0));
+      gpu = 0;
+    }
+    if (gpu && mdc_bind_objects(gpu, fov, photo) != MDC_OK) {
+      std::fprintf(stderr, "DatasetReader: table upload failed: %s\n", mdc_last_error(gpu));
+      mdc_destroy(gpu);
+      gpu = 0;
+    }
+    Lane ln;
+    ln.gpu = gpu;
+    mdc_info inf;
+    ln.device = (gpu && mdc_get_info(gpu, &inf) == MDC_OK) ? inf.device : -1;
+    lanes.push_back(ln);
+  }
+  void close_devices() {
+    for (Lane& ln : lanes) {
+      ln.ring_block.release();
+      if (!multi && ln.gpu) mdc_destroy(ln.gpu);
+    }
+    if (multi) mapi.destroy(multi);
+    multi = 0;
+    lanes.clear();
+    gpu = 0;
+    if (mapi.lib) dlclose(mapi.lib);
+    mapi.lib = 0;
+  }
 
   // ---- decoding (any thread) ------------------------------------------------------------------
   // Never throws: it runs in the decode pool's threads, where an escaping exception (bad_alloc on a corrupt size field,
@@ -447,13 +590,9 @@ DatasetReader::DatasetReader(std::string folder) : s_(new State()) {
   s.w = s.fov->getOutputDims()[0];
   s.h = s.fov->getOutputDims()[1];
 
-  // one context holding BOTH objects' tables: the fused pass needs them together
-  s.gpu = mdc_host::open_device_context("DatasetReader");
-  if (s.gpu && mdc_bind_objects(s.gpu, s.fov, s.photo) != MDC_OK) {
-    std::fprintf(stderr, "DatasetReader: table upload failed: %s\n", mdc_last_error(s.gpu));
-    mdc_destroy(s.gpu);
-    s.gpu = 0;
-  }
+  // one context holding BOTH objects' tables: the fused pass needs them together -- per device the reader may use
+  // (MDC_DEVICES=all | 0,1,...; unset: the one device of $MDC_DEVICE / the calling thread, as before)
+  s.open_devices();
   std::printf("Dataset %s: Got %d files!\n", s.path.c_str(), getNumImages());
 }
 
@@ -462,8 +601,7 @@ DatasetReader::~DatasetReader() {
   s.stop_pool();
   for (auto& m : s.slot_mem) m.release();
   s.drop_ahead();
-  s.ring_block.release();
-  if (s.gpu) mdc_destroy(s.gpu);
+  s.close_devices();
   delete s.fov;
   delete s.photo;
   delete s_;
@@ -478,6 +616,16 @@ const char* DatasetReader::lastError() const { return s_->err.c_str(); }
 void DatasetReader::getPrefetchStats(long* hits, long* misses) const {
   if (hits) *hits = s_->cache_hits;
   if (misses) *misses = s_->cache_misses;
+}
+
+int DatasetReader::getDeviceCount() const { return (int)s_->lanes.size(); }
+void DatasetReader::getDeviceStats(int lane, int* device, long* frames, double* decoder_wait_s, double* gpu_call_s) const {
+  if (lane < 0 || lane >= (int)s_->lanes.size()) return;
+  const State::Lane& ln = s_->lanes[(size_t)lane];
+  if (device) *device = ln.device;
+  if (frames) *frames = ln.frames;
+  if (decoder_wait_s) *decoder_wait_s = ln.t_wait;
+  if (gpu_call_s) *gpu_call_s = ln.t_gpu;
 }
 
 void DatasetReader::setDecodeThreads(int n) {
@@ -588,6 +736,164 @@ ExposureImage* DatasetReader::getImage(int id, bool rectify, bool removeGamma, b
   return ret;
 }
 
+// One device of a sharded getImages call: chunks k = lane, lane + L, lane + 2L, ... of the range, each on the lane's own
+// context, decode ring and GPU calls (reference src/BenchmarkDatasetReader.h:188-243: a frame depends on nothing but itself
+// and the immutable tables, so the chunks of a range are independent).  The decode pool is shared; results land in the
+// caller's order because every chunk writes its own slice of `out`.
+struct DatasetReader::State::LaneRun {
+  State& s;
+  Lane& lane;
+  int first, count, C, RG, L, li;
+  bool rectify;
+  unsigned flags;
+  ExposureImage** out;
+  std::vector<Decode>& rec;
+  int produced = 0;
+  double t_wait = 0, t_gpu = 0;
+  LaneRun(State& s_, Lane& lane_, int first_, int count_, int C_, int RG_, int L_, int li_, bool rectify_, unsigned flags_, ExposureImage** out_,
+          std::vector<Decode>& rec_)
+      : s(s_), lane(lane_), first(first_), count(count_), C(C_), RG(RG_), L(L_), li(li_), rectify(rectify_), flags(flags_), out(out_), rec(rec_) {}
+
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  int nchunks() const { return (count + C - 1) / C; }
+  // the lane's j-th chunk is chunk li + j * L of the range; its buffers are ring position j % RG
+  void submit(int j) {
+    const int k = li + j * L;
+    std::lock_guard<std::mutex> lk(s.mu);
+    for (int i = k * C; i < std::min(count, (k + 1) * C); i++) {
+      Decode& d = rec[(size_t)i];
+      d.id = first + i;
+      d.dst = lane.ring_block.p + (size_t)((j % RG) * C + (i - k * C)) * lane.ring_stride;
+      d.cap = lane.ring_bytes;
+      d.want_record_pitch = (s.gpu_jpeg && lane.ring_bytes >= s.rec_bytes) ? s.rec_pitch : 0;
+      d.want_stream = s.gpu_jpeg >= 2;
+      s.submit(&d);
+    }
+    s.cv_job.notify_all();
+  }
+  void note_error(const std::string& e) {
+    std::lock_guard<std::mutex> lk(s.err_mu);
+    s.err = e;
+  }
+  void bad_frame(int id, int w, int h) {
+    if (!s.quiet_batch)
+      std::printf("ERROR: expected cv-mat to have dimensions %d x %d; found %d x %d (image %s)!\n", s.W, s.H, w, h, s.files[(size_t)id].c_str());
+  }
+
+  void run() {
+    const int mine = (nchunks() - li + L - 1) / L;  // chunks of this lane
+    for (int j = 0; j < std::min(mine, RG); j++) submit(j);
+    std::vector<const uint8_t*> src;
+    std::vector<float*> dst;
+    std::vector<const void*> rsrc;  // frames of the chunk that arrived as JPEG coefficient records
+    std::vector<float*> rdst;
+    std::vector<const void*> ssrc;  // ... as JPEG streams (Huffman decoding on the device)
+    std::vector<float*> sdst;
+    std::vector<int64_t> ssize;
+    std::vector<int> sstatus, sidx;
+    for (int j = 0; j < mine; j++) {
+      const int k = li + j * L, i0 = k * C, i1 = std::min(count, (k + 1) * C);
+      const double tw = now();
+      {
+        std::unique_lock<std::mutex> lk(s.mu);
+        s.cv_done.wait(lk, [&] {
+          for (int i = i0; i < i1; i++)
+            if (!rec[(size_t)i].done) return false;
+          return true;
+        });
+      }
+      t_wait += now() - tw;
+      src.clear();
+      dst.clear();
+      rsrc.clear();
+      rdst.clear();
+      ssrc.clear();
+      sdst.clear();
+      ssize.clear();
+      sidx.clear();
+      {
+        // a chunk's images are made in one go: the pool hands out consecutive blocks of a slab (lowest free address first),
+        // and a chunk whose results lie back to back leaves the device with one copy -- another lane allocating in between
+        // would interleave the two chunks' images
+        std::lock_guard<std::mutex> alk(s.image_mu);
+        for (int i = i0; i < i1; i++) {
+          const Decode& d = rec[(size_t)i];
+          const int id = first + i;
+          if (!d.ok || d.w != s.W || d.h != s.H) {
+            bad_frame(id, d.w, d.h);
+            if (!d.ok) note_error(d.err);
+            continue;
+          }
+          out[i] = rectify ? new ExposureImage(s.w, s.h, s.timestamps[(size_t)id], s.exposures[(size_t)id], id)
+                           : new ExposureImage(s.W, s.H, s.timestamps[(size_t)id], s.exposures[(size_t)id], id);
+          if (d.is_stream) {
+            ssrc.push_back(d.dst);
+            sdst.push_back(out[i]->image);
+            ssize.push_back((int64_t)d.stream_bytes);
+            sidx.push_back(i);
+          } else if (d.is_record) {
+            if (d.rec_rows > s.rec_rows) {  // cannot happen while the decoder checks the sink's capacity: never hand a record on as pixels
+              delete out[i];
+              out[i] = 0;
+              note_error(s.files[(size_t)id] + ": coefficient record larger than the frame's geometry");
+              continue;
+            }
+            rsrc.push_back(d.dst);
+            rdst.push_back(out[i]->image);
+          } else {
+            src.push_back(d.dst);
+            dst.push_back(out[i]->image);
+          }
+        }
+      }
+      // chunk k on the GPU (uploads, kernels and downloads pipelined inside the call) while the pool decodes the next chunks
+      const double tg = now();
+      int refused = 0;  // streams neither the device nor the host decoder could read
+      mdc_ctx* gpu = lane.gpu;
+      int grc = src.empty() ? MDC_OK : mdc_process_frames_host(gpu, src.data(), dst.data(), (int64_t)src.size(), flags);
+      if (grc == MDC_OK && !rsrc.empty())  // records: Huffman-decoded on the host, inverse DCT on the device
+        grc = mdc_process_jpeg_frames_host(gpu, rsrc.data(), (int64_t)s.rec_bytes, s.rec_pitch, s.rec_rows, rdst.data(), (int64_t)rsrc.size(), flags);
+      if (grc == MDC_OK && !ssrc.empty()) {  // streams: Huffman decoding, inverse DCT and the fused pass on the device
+        sstatus.assign(ssrc.size(), 0);
+        grc = mdc_process_jpeg_streams_host(gpu, ssrc.data(), ssize.data(), sdst.data(), (int64_t)ssrc.size(), flags, sstatus.data());
+        for (size_t q = 0; q < ssrc.size() && grc == MDC_OK; q++)
+          if (sstatus[q] != 0) {  // a stream the device could not decode (damaged file): the host decoder has the last word
+            const int i = sidx[q];
+            Decode one;
+            one.id = first + i;
+            one.dst = const_cast<unsigned char*>(static_cast<const unsigned char*>(ssrc[q]));  // the ring buffer of this frame
+            one.cap = lane.ring_bytes;
+            s.decode_now(one);
+            if (one.ok && one.w == s.W && one.h == s.H) {
+              grc = mdc_process_host(gpu, one.dst, out[i]->image, flags);
+            } else {
+              bad_frame(first + i, one.w, one.h);
+              if (!one.ok) note_error(one.err);
+              delete out[i];
+              out[i] = 0;
+              refused++;
+            }
+          }
+      }
+      t_gpu += now() - tg;
+      if (grc != MDC_OK) {
+        note_error(mdc_last_error(gpu));
+        std::fprintf(stderr, "DatasetReader::getImages: %s\n", mdc_last_error(gpu));
+        for (int i = i0; i < i1; i++) {
+          delete out[i];
+          out[i] = 0;
+        }
+      } else {
+        produced += (int)src.size() + (int)rsrc.size() + (int)ssrc.size() - refused;
+      }
+      if (j + RG < mine) submit(j + RG);  // the buffers of the lane's chunk j are free again
+    }
+    lane.frames += produced;
+    lane.t_wait += t_wait;
+    lane.t_gpu += t_gpu;
+  }
+};
+
 int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamma, bool removeVignette, bool nanOverexposed,
                              ExposureImage** out) {
   State& s = *s_;
@@ -603,14 +909,19 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
     std::fprintf(stderr, "DatasetReader::getImages: %s\n", s.err.c_str());
     return 0;
   }
-  // frames per GPU call / calls in the ring: stage 2 hands over the whole ring at a time -- its host work is ~0.1 ms per
-  // frame and thread, and inside the GPU call a 64-frame chunk decodes while the one before it goes out: the longer the call,
-  // the less its first decode and last output weigh (128 per call: 16.5 k frames/s, 256: 20+ k)
-  // ... and a call longer than that gets a second ring's worth of buffers, so that the pool parses the next 256 files while the
-  // GPU call of the current 256 runs (one ring: parse and GPU call take turns, 22 k frames/s)
-  const int C = s.gpu_jpeg >= 2 ? State::kRingFrames : 32;
-  const int slots = (s.gpu_jpeg >= 2 && count > C) ? 2 * State::kRingFrames : State::kRingFrames, RG = slots / C;
-  // coefficient records (include/mdc_hip.h): MCUs are at most 4 x 4 blocks, so a grid rounded up to multiples of 4 blocks
+  // Frames per GPU call / calls in a lane's ring.  Stage 2 hands over up to a whole ring at a time -- its host work is ~0.1 ms
+  // per frame and thread, and inside the GPU call a 64-frame chunk decodes while the one before it goes out: the longer the
+  // call, the less its first decode and last output weigh (128 per call: 16.5 k frames/s, 256: 20+ k) -- and a lane with
+  // more than one call gets a second ring's worth of buffers, so that the pool parses the next files while the GPU call of
+  // the current ones runs (one ring: parse and GPU call take turns, 22 k frames/s).  With several devices (MDC_DEVICES) the
+  // range is dealt to them in chunks of at least 64 frames, round-robin.
+  const int L = (int)s.lanes.size();
+  int C = s.gpu_jpeg >= 2 ? State::kRingFrames : 32;
+  if (L > 1 && s.gpu_jpeg >= 2) C = std::min<int>(State::kRingFrames, std::max(64, ((count + L - 1) / L + 63) / 64 * 64));
+  const int nchunks = (count + C - 1) / C;
+  const int per_lane = (nchunks + L - 1) / L;
+  const int slots = (s.gpu_jpeg >= 2 && per_lane > 1) ? 2 * C : (s.gpu_jpeg >= 2 ? C : State::kRingFrames), RG = slots / C;
+  // coefficient records (include/mdc_hip.h): MCUs are 1..4 x 1..4 blocks, so a grid rounded up to multiples of 12 blocks
   // holds every sampling layout of a W x H file (the same rule as mdch_jpeg_record_bytes)
   s.rec_pitch = ((s.W + 7) / 8 + 11) / 12 * 12;
   s.rec_rows = ((s.H + 7) / 8 + 11) / 12 * 12;
@@ -618,139 +929,33 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
   // a ring buffer holds a decoded frame, or (stage 1) a coefficient record -- 2 bytes per pixel --, or (stage 2) a stream: the
   // compressed bytes + 5 KB; a file stage 2 does not take, or whose stream does not fit, is decoded to pixels on the host
   const size_t want_bytes = s.gpu_jpeg == 1 ? std::max(s.frame_bytes(), s.rec_bytes) : s.frame_bytes();
-  if (!s.ring_block.p || s.ring_bytes < want_bytes || s.ring_slots < slots) {
-    s.ring_block.release();
-    s.ring_stride = (want_bytes + 4095) & ~(size_t)4095;
-    s.ring_slots = slots;
-    s.ring_block.alloc(s.ring_stride * (size_t)s.ring_slots);
-    s.ring_bytes = want_bytes;
+  const int active = std::min(L, nchunks);
+  for (int l = 0; l < active; l++) {
+    State::Lane& ln = s.lanes[(size_t)l];
+    if (!ln.ring_block.p || ln.ring_bytes < want_bytes || ln.ring_slots < slots) {
+      ln.ring_block.release();
+      ln.ring_stride = (want_bytes + 4095) & ~(size_t)4095;
+      ln.ring_slots = slots;
+      ln.ring_block.alloc(ln.ring_stride * (size_t)ln.ring_slots);
+      ln.ring_bytes = want_bytes;
+    }
   }
   s.start_pool();
   std::vector<Decode> rec((size_t)count);
-  const int nchunks = (count + C - 1) / C;
-  auto submit_chunk = [&](int k) {
-    std::lock_guard<std::mutex> lk(s.mu);
-    for (int i = k * C; i < std::min(count, (k + 1) * C); i++) {
-      Decode& d = rec[(size_t)i];
-      d.id = first + i;
-      d.dst = s.ring_block.p + (size_t)((k % RG) * C + (i - k * C)) * s.ring_stride;
-      d.cap = s.ring_bytes;
-      d.want_record_pitch = (s.gpu_jpeg && s.ring_bytes >= s.rec_bytes) ? s.rec_pitch : 0;
-      d.want_stream = s.gpu_jpeg >= 2;
-      s.submit(&d);
-    }
-    s.cv_job.notify_all();
-  };
-  for (int k = 0; k < std::min(nchunks, RG); k++) submit_chunk(k);
   const unsigned flags = flag_word(rectify, removeGamma, removeVignette, nanOverexposed);
   const bool trace = std::getenv("MDC_READER_TRACE") != 0;  // where a getImages call spends its time (stderr)
-  double t_wait = 0, t_gpu = 0;
-  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  std::vector<State::LaneRun> runs;
+  runs.reserve((size_t)active);
+  for (int l = 0; l < active; l++) runs.push_back(State::LaneRun(s, s.lanes[(size_t)l], first, count, C, RG, active, l, rectify, flags, out, rec));
+  std::vector<std::thread> helpers;
+  for (int l = 1; l < active; l++) helpers.emplace_back([&runs, l] { runs[(size_t)l].run(); });
+  runs[0].run();
+  for (std::thread& t : helpers) t.join();
   int produced = 0;
-  std::vector<const uint8_t*> src;
-  std::vector<float*> dst;
-  std::vector<const void*> rsrc;  // frames of the chunk that arrived as JPEG coefficient records
-  std::vector<float*> rdst;
-  std::vector<const void*> ssrc;  // ... as JPEG streams (Huffman decoding on the device)
-  std::vector<float*> sdst;
-  std::vector<int64_t> ssize;
-  std::vector<int> sstatus, sidx;
-  for (int k = 0; k < nchunks; k++) {
-    const int i0 = k * C, i1 = std::min(count, (k + 1) * C);
-    const double tw = now();
-    {
-      std::unique_lock<std::mutex> lk(s.mu);
-      s.cv_done.wait(lk, [&] {
-        for (int i = i0; i < i1; i++)
-          if (!rec[(size_t)i].done) return false;
-        return true;
-      });
-    }
-    t_wait += now() - tw;
-    src.clear();
-    dst.clear();
-    rsrc.clear();
-    rdst.clear();
-    ssrc.clear();
-    sdst.clear();
-    ssize.clear();
-    sidx.clear();
-    for (int i = i0; i < i1; i++) {
-      const Decode& d = rec[(size_t)i];
-      const int id = first + i;
-      if (!d.ok || d.w != s.W || d.h != s.H) {
-        if (!s.quiet_batch)
-          std::printf("ERROR: expected cv-mat to have dimensions %d x %d; found %d x %d (image %s)!\n", s.W, s.H, d.w, d.h,
-                      s.files[(size_t)id].c_str());
-        if (!d.ok) s.err = d.err;
-        continue;
-      }
-      out[i] = rectify ? new ExposureImage(s.w, s.h, s.timestamps[(size_t)id], s.exposures[(size_t)id], id)
-                       : new ExposureImage(s.W, s.H, s.timestamps[(size_t)id], s.exposures[(size_t)id], id);
-      if (d.is_stream) {
-        ssrc.push_back(d.dst);
-        sdst.push_back(out[i]->image);
-        ssize.push_back((int64_t)d.stream_bytes);
-        sidx.push_back(i);
-      } else if (d.is_record) {
-        if (d.rec_rows > s.rec_rows) {  // cannot happen while the decoder checks the sink's capacity: never hand a record on as pixels
-          delete out[i];
-          out[i] = 0;
-          s.err = s.files[(size_t)id] + ": coefficient record larger than the frame's geometry";
-          continue;
-        }
-        rsrc.push_back(d.dst);
-        rdst.push_back(out[i]->image);
-      } else {
-        src.push_back(d.dst);
-        dst.push_back(out[i]->image);
-      }
-    }
-    // chunk k on the GPU (uploads, kernels and downloads pipelined inside the call) while the pool decodes chunk k+1
-    const double tg = now();
-    int refused = 0;  // streams neither the device nor the host decoder could read
-    int grc = src.empty() ? MDC_OK : mdc_process_frames_host(s.gpu, src.data(), dst.data(), (int64_t)src.size(), flags);
-    if (grc == MDC_OK && !rsrc.empty())  // records: Huffman-decoded on the host, inverse DCT on the device
-      grc = mdc_process_jpeg_frames_host(s.gpu, rsrc.data(), (int64_t)s.rec_bytes, s.rec_pitch, s.rec_rows, rdst.data(), (int64_t)rsrc.size(), flags);
-    if (grc == MDC_OK && !ssrc.empty()) {  // streams: Huffman decoding, inverse DCT and the fused pass on the device
-      sstatus.assign(ssrc.size(), 0);
-      grc = mdc_process_jpeg_streams_host(s.gpu, ssrc.data(), ssize.data(), sdst.data(), (int64_t)ssrc.size(), flags, sstatus.data());
-      for (size_t j = 0; j < ssrc.size() && grc == MDC_OK; j++)
-        if (sstatus[j] != 0) {  // a stream the device could not decode (damaged file): the host decoder has the last word
-          const int i = sidx[j];
-          Decode one;
-          one.id = first + i;
-          one.dst = const_cast<unsigned char*>(static_cast<const unsigned char*>(ssrc[j]));  // the ring buffer of this frame
-          one.cap = s.ring_bytes;
-          s.decode_now(one);
-          if (one.ok && one.w == s.W && one.h == s.H) {
-            grc = mdc_process_host(s.gpu, one.dst, out[i]->image, flags);
-          } else {
-            if (!s.quiet_batch)
-              std::printf("ERROR: expected cv-mat to have dimensions %d x %d; found %d x %d (image %s)!\n", s.W, s.H, one.w, one.h,
-                          s.files[(size_t)(first + i)].c_str());
-            if (!one.ok) s.err = one.err;
-            delete out[i];
-            out[i] = 0;
-            refused++;
-          }
-        }
-    }
-    t_gpu += now() - tg;
-    if (grc != MDC_OK) {
-      s.err = mdc_last_error(s.gpu);
-      std::fprintf(stderr, "DatasetReader::getImages: %s\n", s.err.c_str());
-      for (int i = i0; i < i1; i++) {
-        delete out[i];
-        out[i] = 0;
-      }
-    } else {
-      produced += (int)src.size() + (int)rsrc.size() + (int)ssrc.size() - refused;
-    }
-    if (k + RG < nchunks) submit_chunk(k + RG);  // chunk k's buffers are free again
-  }
+  for (const State::LaneRun& r : runs) produced += r.produced;
   if (trace)
-    std::fprintf(stderr, "DatasetReader::getImages: %d frames, %d threads: waited %.1f ms for the decoders, %.1f ms in the GPU calls\n",
-                 count, (int)s.workers.size(), t_wait * 1e3, t_gpu * 1e3);
+    for (const State::LaneRun& r : runs)
+      std::fprintf(stderr, "DatasetReader::getImages: device %d (lane %d of %d): %d of %d frames, %d decode threads: waited %.1f ms for the decoders, %.1f ms in the GPU calls\n",
+                   r.lane.device, r.li, active, r.produced, count, (int)s.workers.size(), r.t_wait * 1e3, r.t_gpu * 1e3);
   return produced;
 }

@@ -273,6 +273,15 @@ void mdch_reader_set_lookahead(mdch_reader* h, int frames) try { h->r->setResult
 void mdch_reader_set_gpu_jpeg(mdch_reader* h, int stage) try { h->r->setGpuJpegStage(stage == 1 ? 1 : (stage ? 2 : 0)); } catch (...) {}
 const char* mdch_reader_last_error(mdch_reader* h) try { return h->r->lastError(); } catch (...) { return {}; }
 void mdch_reader_prefetch_stats(mdch_reader* h, long hm[2]) try { h->r->getPrefetchStats(&hm[0], &hm[1]); } catch (...) {}
+int mdch_reader_device_stats(mdch_reader* h, int lane, int64_t device_frames[2], double wait_gpu_seconds[2]) try {
+  int dev = -1;
+  long frames = 0;
+  if (lane < 0 || lane >= h->r->getDeviceCount()) return 0;
+  h->r->getDeviceStats(lane, &dev, &frames, &wait_gpu_seconds[0], &wait_gpu_seconds[1]);
+  device_frames[0] = dev;
+  device_frames[1] = frames;
+  return 1;
+} catch (...) { return {}; }
 
 size_t mdch_jpeg_record_bytes(int w, int h, int pitch_rows[2]) try {
   // MCUs are 1..4 x 1..4 blocks: a pitch / row count rounded up to a multiple of 12 blocks (lcm of 1, 2, 3, 4) holds every

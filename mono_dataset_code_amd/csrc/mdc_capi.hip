@@ -371,6 +371,15 @@ void mdc_destroy(mdc_ctx* c) {
 
 const char* mdc_build_flags(void) { return mdc::build_flags_string(); }
 
+int mdc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
 const char* mdc_last_error(const mdc_ctx* c) {
   if (!c) return g_create_err.c_str();
   if (t_err_ctx == c) return t_err.c_str();

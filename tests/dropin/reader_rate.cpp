@@ -61,6 +61,15 @@ int main(int argc, char** argv) {
   long hits = 0, misses = 0;
   reader->getPrefetchStats(&hits, &misses);
   std::printf("READER_RATE prefetch: %ld frames found decoded ahead, %ld decoded by the calling thread\n", hits, misses);
+  // per device (MDC_DEVICES): frames it produced over the run (warm-up pass included) and the rate inside its own GPU calls
+  for (int l = 0; l < reader->getDeviceCount(); l++) {
+    int dev = -1;
+    long frames = 0;
+    double wait_s = 0, gpu_s = 0;
+    reader->getDeviceStats(l, &dev, &frames, &wait_s, &gpu_s);
+    std::printf("READER_RATE device %d (lane %d of %d): %ld frames, %.3f s in GPU calls (%.1f frames/s there), %.3f s waiting for the decoders\n", dev, l,
+                reader->getDeviceCount(), frames, gpu_s, gpu_s > 0 ? frames / gpu_s : 0.0, wait_s);
+  }
 #endif
   delete reader;
   return 0;

@@ -94,6 +94,45 @@ def test_get_images_longer_than_the_ring(tmp_path, oracle):
     r.close()
 
 
+def test_reader_shards_getimages_over_devices(tmp_path, monkeypatch):
+    """MDC_DEVICES: getImages (and the results getImage makes ahead) dealt to several devices in chunks, each with its own
+    context, decode ring and host thread -- here two lanes on the test box's one GPU ("0,0": a device listed twice takes the
+    tables from the host objects; distinct devices get them in one RCCL broadcast).  Images, order, metadata and failures are
+    those of the single-device reader, bit for bit, for JPEG streams (device Huffman stage), host-decoded JPEG, and PNG."""
+    from mono_dataset_code_amd import capi
+
+    h, w = 96, 160
+    n = 300
+    for fmt in ("jpg", "png"):
+        d = os.path.join(str(tmp_path), fmt)
+        os.makedirs(d)
+        make_sequence(d, frames_for(n, h, w), True, fmt)
+        monkeypatch.delenv("MDC_DEVICES", raising=False)
+        one = capi.DatasetReader(d)
+        monkeypatch.setenv("MDC_DEVICES", "0,0")
+        two = capi.DatasetReader(d)
+        monkeypatch.delenv("MDC_DEVICES", raising=False)
+        assert len(one.device_stats()) == 1 and len(two.device_stats()) == 2
+        for stage in ((2, 0) if fmt == "jpg" else (2,)):
+            one.set_gpu_jpeg(stage)
+            two.set_gpu_jpeg(stage)
+            for first, count, fl in ((0, n, (1, 1, 1, 1)), (7, 129, (0, 1, 1, 0)), (250, 50, (1, 0, 0, 1)), (3, 40, (1, 1, 1, 1))):
+                a, oka, na = one.get_images(first, count, *fl)
+                b, okb, nb = two.get_images(first, count, *fl)
+                assert na == nb == count and oka.all() and okb.all(), (fmt, stage, first, count)
+                assert bits_equal(a, b), (fmt, stage, first, count)
+        st = two.device_stats()
+        assert all(dev == 0 and frames > 0 for dev, frames, _, _ in st), st  # both lanes produced frames
+        assert sum(f for _, f, _, _ in st) == sum(c for _, c, _ in ((0, n, 0), (7, 129, 0), (250, 50, 0), (3, 40, 0))) * (2 if fmt == "jpg" else 1)
+        # getImage in order: the results made ahead come out of the sharded getImages
+        for i in list(range(0, 150)) + [5, 6, 7]:
+            x = two.get_image(i, 1, 1, 1, 1)
+            y = one.get_image(i, 1, 1, 1, 1)
+            assert x is not None and x[1:] == y[1:] and bits_equal(x[0], y[0]), (fmt, i)
+        one.close()
+        two.close()
+
+
 def parse(path):
     raw = open(path, "rb").read()
     pos, recs = 0, []

@@ -11,6 +11,7 @@
 #                    over tools/mall_bracket.py (one launch per variant)
 #   launch_size      bench.py --frames 4096 / 8192 / 16384 (headline only)
 #   bench            plain `python bench.py` (the driver's command) -> bench.json
+#   pyramid_alone    bench.py --workload pyramid in its own process (against the secondary entry of `bench`)
 #   bench2           `python bench.py --gpus 2` without torchrun (gloo, shared GPU)
 #   profile          tools/profile_bench.sh for the four workloads (rocprofv3 --stats + FETCH_SIZE / WRITE_SIZE passes)
 #   reader / dso / huffman / vcal / distort   the secondary rate tools
@@ -61,6 +62,9 @@ for k, v in (d.get("secondary") or {}).items():
 print("cpu_baseline", {k: d.get("cpu_baseline", {}).get(k) for k in ("value", "cores", "kind")}, "build_flags", repr(d.get("build_flags")), "ranks", d.get("ranks"))
 PY
       ;;
+    pyramid_alone)
+      for i in 1 2; do timeout 300 python bench.py --workload pyramid --no-cpu-baseline > "$OUT/bench_pyramid_alone_$i.json" 2> /dev/null
+        python3 -c "import json; d=json.loads([l for l in open('$OUT/bench_pyramid_alone_$i.json') if l.startswith('{')][-1]); r=d['roofline']; print('pyramid alone: frac', r['frac'], 'kernel_ms', r['kernel_ms'], 'of ceiling', r.get('frac_of_same_box_mix_ceiling'), r.get('launches_per_step'))"; done ;;
     bench2)
       MDC_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 20 --warmup 3 > "$OUT/bench_gpus2_gloo.json" 2> "$OUT/bench_gpus2_gloo.err"; echo "rc=$?"
       tail -c 1500 "$OUT/bench_gpus2_gloo.json"; echo
