@@ -205,14 +205,17 @@ int mdc_process_jpeg_frames_host(mdc_ctx* ctx, const void* const* records, int64
 int mdc_jpeg_idct_batch_device(mdc_ctx* ctx, const void* d_records, int64_t record_bytes, uint8_t* d_frames, int w, int h, int blocks_w,
                                int blocks_rows, int64_t nframes, void* stream);
 
-/* JPEG ingest with the Huffman decoding on the GPU too.  The host only parses the file's markers, builds the two decode
- * tables of the scan and copies the entropy-coded segment with its FF00 byte stuffing removed (mdch_jpeg_stream in
- * include/mdc_host.h: ~0.1 ms per 1280 x 1024 frame against ~2.5 ms for the Huffman decoding) into a STREAM per frame:
- *   mdc_jpeg_stream_header, then ecs_bytes entropy-coded bytes, then at least 16 zero bytes.
- * Single-component (grayscale) baseline / extended-sequential Huffman files without restart markers -- what the TUM mono
- * dataset ships; for anything else mdch_jpeg_stream says no and the caller takes the record path above.
+/* JPEG ingest with the Huffman decoding on the GPU too.  The host only parses the file's markers, builds the decode
+ * tables of the scan and copies the entropy-coded segment with its FF00 byte stuffing and its restart markers removed
+ * (mdch_jpeg_stream in include/mdc_host.h: ~0.1 ms per 1280 x 1024 frame against ~2.5 ms for the Huffman decoding) into a STREAM
+ * per frame (layout: mdc_jpeg_stream_header below).
+ * Baseline / extended-sequential Huffman files of one scan: grayscale (what the TUM mono dataset ships) or YCbCr with the three
+ * components interleaved (any luma sampling up to 4 x 4, chroma 1 x 1 -- 4:4:4, 4:2:2, 4:2:0, ...; only the luma plane is decoded
+ * to samples, which is what cv::imread(..., GRAYSCALE) returns for such a file), with or without restart markers.  Progressive,
+ * multi-scan, arithmetic-coded and subsampled-luma files: mdch_jpeg_stream says no and the caller takes the record path above.
  * mdc_process_jpeg_streams_host: stream i in place of raw frame i.  The device decodes every stream with 1024 threads
- * (subsequences of the bit stream whose entry states are relaxed until they are the sequential decoder's, csrc/mdc_jpeg.hip),
+ * (subsequences of the bit stream whose entry states are relaxed until they are the sequential decoder's; restart intervals
+ * have exact entry states and are decoded one per thread, csrc/mdc_jpeg.hip),
  * then runs the inverse DCT and the fused kernel as for records: the results equal the host decoder's path bit for bit.
  * Results leave the device with one copy per run of out[] buffers that lie back to back in memory (the ExposureImage pool hands
  * out such runs): contiguous page-locked outputs go at PCIe rate, scattered ones at about half of it.
@@ -220,7 +223,7 @@ int mdc_jpeg_idct_batch_device(mdc_ctx* ctx, const void* d_records, int64_t reco
  * a frame of this context -- out[i] is then not a result and the caller decodes that file on the host.
  * mdc_jpeg_huffman_batch_device is the device stage alone: nframes streams, stream_stride bytes apart (multiple of 16) ->
  * nframes records (layout above), d_status[i] as status[i]. */
-#define MDC_JPEG_STREAM_MAGIC 0x32534a4du /* "MJS2" */
+#define MDC_JPEG_STREAM_MAGIC 0x33534a4du /* "MJS3" */
 #define MDC_JPEG_HUFF_SUBTABLES 32
 typedef struct mdc_jpeg_huff {
   /* t1, indexed by the next 11 bits (MSB first): bits 0-4 code length L (1..16; 0 = no such code; 31 = longer than 11 bits:
@@ -232,10 +235,15 @@ typedef struct mdc_jpeg_huff {
 } mdc_jpeg_huff; /* 12288 bytes */
 typedef struct mdc_jpeg_stream_header {
   uint32_t magic, w, h, ecs_bytes;
-  uint32_t reserved[4];
-  uint16_t quant[64]; /* natural order */
-  mdc_jpeg_huff dc, ac;
-} mdc_jpeg_stream_header; /* 24736 bytes */
+  uint32_t restart_interval; /* MCUs per restart interval (DRI), 0 = the scan has no restart markers */
+  uint32_t n_intervals;      /* restart intervals of the scan (1 without restart markers) */
+  uint32_t comp_info;        /* components of the scan (1, or 3: Y Cb Cr interleaved) | luma sampling h << 8 | v << 12 (chroma 1 x 1) */
+  uint32_t ecs_offset;       /* byte offset of the entropy-coded bytes from the start of the stream, a multiple of 16 */
+  uint16_t quant[64];        /* luma quantisation table, natural order */
+  mdc_jpeg_huff dc, ac;      /* luma tables */
+} mdc_jpeg_stream_header; /* 24736 bytes; then, three components only: mdc_jpeg_huff dc_chroma, ac_chroma; then, with restart markers: uint32_t
+                             start_byte[n_intervals] (offset of each interval inside the entropy-coded bytes, markers removed); then padding to
+                             ecs_offset, the entropy-coded bytes, at least 16 zero bytes */
 int mdc_process_jpeg_streams_host(mdc_ctx* ctx, const void* const* streams, const int64_t* stream_bytes, float* const* out, int64_t nframes,
                                   unsigned flags, int* status);
 int mdc_jpeg_huffman_batch_device(mdc_ctx* ctx, const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w,

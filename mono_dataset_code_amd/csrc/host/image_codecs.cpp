@@ -562,13 +562,113 @@ bool decode_jpeg_coefs(const unsigned char* d, size_t n, JpegCoefSink* sink, std
   return jpeg_gray8(d, n, nullptr, 0, &w, &h, err, sink);
 }
 
+namespace {
+
+// The device's form of one Huffman table (mdc_jpeg_huff, include/mdc_hip.h): one lookup of the next 11 bits gives code length,
+// run and size -- and the value itself where the magnitude bits lie inside the window; codes of 12..16 bits go through a
+// 32-entry subtable per prefix.
+bool build_device_table(const Huff& t, bool is_ac, mdc_jpeg_huff* dst, std::string* err) {
+  memset(dst, 0, sizeof *dst);
+  // symbol and length of the code the 16-bit window `w16` starts with (0 = none)
+  auto code_of = [&](int w16, int* sym) {
+    const int e = t.look[w16 >> 7];
+    if (e) {
+      *sym = e & 255;
+      return e >> 8;
+    }
+    for (int l = 10; l <= 16; l++) {
+      const int code = w16 >> (16 - l);
+      if (code <= t.maxcode[l]) {
+        const int idx = code + t.valoff[l];
+        if (idx < 0 || idx > 255) return 0;
+        *sym = t.vals[idx];
+        return l;
+      }
+    }
+    return 0;
+  };
+  const int k = is_ac ? 1 : 0;
+  int nsub = 0;
+  for (int w11 = 0; w11 < 2048; w11++) {
+    int sym = 0;
+    const int l0 = code_of(w11 << 5, &sym);  // (with the 5 bits below the window zero: right for every code of <= 11 bits)
+    uint32_t e = 0;
+    bool is_short = l0 >= 1 && l0 <= 11;
+    if (is_short) {  // confirm: the code must not depend on the bits below the window
+      int sym1 = 0;
+      is_short = code_of(w11 << 5 | 31, &sym1) == l0 && sym1 == sym;
+    }
+    if (is_short) {
+      const int run = k ? sym >> 4 : 0, sz = k ? sym & 15 : sym;
+      if (!k && sym > 15) {
+        dst->t1[w11] = 0;
+        continue;
+      }
+      e = (uint32_t)l0 | (uint32_t)run << 5 | (uint32_t)sz << 9;
+      if (sz && l0 + sz <= 11) {
+        int v = (w11 >> (11 - l0 - sz)) & ((1 << sz) - 1);
+        if (v < (1 << (sz - 1))) v += (int)((~0u) << sz) + 1;  // EXTEND
+        e |= 1u << 13 | (uint32_t)(uint16_t)(int16_t)v << 16;
+      }
+    } else {  // longer codes below this prefix?
+      uint32_t sub[32];
+      bool any = false;
+      for (int sfx = 0; sfx < 32; sfx++) {
+        int s2 = 0;
+        const int l = code_of(w11 << 5 | sfx, &s2);
+        sub[sfx] = 0;
+        if (l >= 12 && l <= 16 && (k || s2 <= 15)) {
+          sub[sfx] = (uint32_t)l | (uint32_t)(k ? s2 >> 4 : 0) << 5 | (uint32_t)(k ? s2 & 15 : s2) << 9;
+          any = true;
+        }
+      }
+      if (any) {
+        if (nsub >= MDC_JPEG_HUFF_SUBTABLES) return fail(err, "JPEG stream: too many long Huffman codes for the device tables");
+        memcpy(dst->t2[nsub], sub, sizeof sub);
+        e = 31u | (uint32_t)nsub << 16;
+        nsub++;
+      }
+    }
+    dst->t1[w11] = e;
+  }
+  return true;
+}
+
+// The files of a sequence carry the same tables (an encoder's defaults): built once per decode thread and table definition, then
+// copied -- building them was 55 of the 86 us jpeg_stream took for a 265-KB file (31 now).  Slots: DC / AC x luma / chroma.
+struct DeviceTableCache {
+  bool valid[4] = {false, false, false, false};
+  int len[4] = {0, 0, 0, 0};
+  unsigned char def[4][16 + 256];
+  mdc_jpeg_huff tab[4];
+};
+bool device_table(const Huff& t, bool is_ac, int slot, mdc_jpeg_huff* dst, std::string* err) {
+  static thread_local DeviceTableCache cache;
+  if (cache.valid[slot] && cache.len[slot] == t.def_len && memcmp(cache.def[slot], t.def, (size_t)t.def_len) == 0) {
+    *dst = cache.tab[slot];
+    return true;
+  }
+  cache.valid[slot] = false;
+  if (!build_device_table(t, is_ac, dst, err)) return false;
+  cache.len[slot] = t.def_len;
+  memcpy(cache.def[slot], t.def, (size_t)t.def_len);
+  cache.tab[slot] = *dst;
+  cache.valid[slot] = true;
+  return true;
+}
+
+}  // namespace
+
 bool jpeg_stream(const unsigned char* d, size_t n, unsigned char* stream, size_t cap, size_t* used, int* w, int* h, std::string* err) {
   if (n < 4 || d[0] != 0xff || d[1] != 0xd8) return fail(err, "not a JPEG file");
   if (!stream || cap < sizeof(mdc_jpeg_stream_header) + 32 || (reinterpret_cast<uintptr_t>(stream) & 3) != 0) return fail(err, "stream buffer too small");
   uint16_t qt[4][64];
   bool have_qt[4] = {false, false, false, false};
   Huff dc[4], ac[4];
-  int W = 0, H = 0, tq = 0;
+  int W = 0, H = 0, ncomp = 0, restart = 0;
+  struct Comp {
+    int id, h, v, tq;
+  } comp[3] = {{0, 1, 1, 0}, {0, 1, 1, 0}, {0, 1, 1, 0}};
   bool have_sof = false;
   size_t p = 2;
   while (p + 4 <= n) {
@@ -577,7 +677,7 @@ bool jpeg_stream(const unsigned char* d, size_t n, unsigned char* stream, size_t
     if (p >= n) break;
     const int m = d[p++];
     if (m == 0xd8 || m == 0x01) continue;
-    if (m >= 0xd0 && m <= 0xd7) return fail(err, "JPEG stream: restart markers");
+    if (m >= 0xd0 && m <= 0xd7) return fail(err, "JPEG: restart marker outside a scan");
     if (m == 0xd9) break;
     if (p + 2 > n) return fail(err, "JPEG: truncated");
     const size_t len = (size_t)d[p] << 8 | d[p + 1];
@@ -610,123 +710,73 @@ bool jpeg_stream(const unsigned char* d, size_t n, unsigned char* stream, size_t
       if (sl < 9 || s[0] != 8) return fail(err, "JPEG: only 8-bit samples are supported");
       H = s[1] << 8 | s[2];
       W = s[3] << 8 | s[4];
-      if (s[5] != 1) return fail(err, "JPEG stream: more than one component");
-      tq = s[8] & 3;
-      if (W <= 0 || H <= 0) return fail(err, "JPEG: unsupported frame header");
+      ncomp = s[5];
+      if ((ncomp != 1 && ncomp != 3) || sl < 6 + 3 * (size_t)ncomp || W <= 0 || H <= 0) return fail(err, "JPEG stream: unsupported frame header");
+      for (int i = 0; i < ncomp; i++) {
+        comp[i].id = s[6 + 3 * i];
+        comp[i].h = s[7 + 3 * i] >> 4;
+        comp[i].v = s[7 + 3 * i] & 15;
+        comp[i].tq = s[8 + 3 * i] & 3;
+        if (comp[i].h < 1 || comp[i].h > 4 || comp[i].v < 1 || comp[i].v > 4) return fail(err, "JPEG: bad sampling factors");
+      }
+      if (ncomp == 1) comp[0].h = comp[0].v = 1;
+      // the device decodes luma h x v + one block of each chroma component per MCU (4:4:4, 4:2:2, 4:2:0, 4:1:1, ...)
+      if (ncomp == 3 && (comp[1].h != 1 || comp[1].v != 1 || comp[2].h != 1 || comp[2].v != 1)) return fail(err, "JPEG stream: chroma sampling is not 1 x 1");
       have_sof = true;
     } else if (m >= 0xc2 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
       return fail(err, "JPEG stream: not a sequential Huffman file");
     } else if (m == 0xdd) {
-      if (sl >= 2 && (s[0] << 8 | s[1]) != 0) return fail(err, "JPEG stream: restart interval");
+      if (sl >= 2) restart = s[0] << 8 | s[1];
     } else if (m == 0xda) {
       if (!have_sof) return fail(err, "JPEG: scan before frame header");
-      if (sl < 6 || s[0] != 1) return fail(err, "JPEG: only single-scan files are supported");
-      const int td = s[2] >> 4, ta = s[2] & 15;
-      if (td > 3 || ta > 3 || !dc[td].present || !ac[ta].present || !have_qt[tq]) return fail(err, "JPEG: scan refers to a missing table");
+      if (sl < 1 || s[0] != ncomp || sl < 1 + 2 * (size_t)ncomp + 3) return fail(err, "JPEG stream: the components are not in one scan");
+      int td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+      for (int i = 0; i < ncomp; i++) {
+        if (s[1 + 2 * i] != comp[i].id) return fail(err, "JPEG stream: scan components out of frame order");
+        td[i] = s[2 + 2 * i] >> 4;
+        ta[i] = s[2 + 2 * i] & 15;
+        if (td[i] > 3 || ta[i] > 3 || !dc[td[i]].present || !ac[ta[i]].present) return fail(err, "JPEG: scan refers to a missing table");
+      }
+      if (!have_qt[comp[0].tq]) return fail(err, "JPEG: scan refers to a missing table");
+      // one table pair for both chroma components (every encoder's choice; two different pairs would need a fifth and sixth table)
+      if (ncomp == 3 && (td[1] != td[2] || ta[1] != ta[2])) return fail(err, "JPEG stream: Cb and Cr use different Huffman tables");
+      const int hY = comp[0].h, vY = comp[0].v;
+      const int mx = (W + 8 * hY - 1) / (8 * hY), my = (H + 8 * vY - 1) / (8 * vY);
+      const long mcus = (long)mx * my;
+      const long n_iv = restart ? (mcus + restart - 1) / restart : 1;
+      if (n_iv >= (1l << 24)) return fail(err, "JPEG stream: too many restart intervals");
       mdc_jpeg_stream_header* hd = reinterpret_cast<mdc_jpeg_stream_header*>(stream);
+      size_t off = sizeof *hd + (ncomp == 3 ? 2 * sizeof(mdc_jpeg_huff) : 0);
+      const size_t starts_off = off;
+      if (restart) off += (size_t)n_iv * 4;
+      off = (off + 15) & ~(size_t)15;
+      if (off + 32 > cap) return fail(err, "JPEG stream: does not fit the buffer");
       memset(hd, 0, sizeof *hd);
       hd->magic = MDC_JPEG_STREAM_MAGIC;
       hd->w = (uint32_t)W;
       hd->h = (uint32_t)H;
-      for (int i = 0; i < 64; i++) hd->quant[i] = qt[tq][i];
-      // the device's tables (mdc_jpeg_huff): one lookup of the next 11 bits gives code length, run and size -- and the value
-      // itself where the magnitude bits lie inside the window; codes of 12..16 bits go through a 32-entry subtable per prefix
-      const Huff* src[2] = {&dc[td], &ac[ta]};
-      mdc_jpeg_huff* dst[2] = {&hd->dc, &hd->ac};
-      // The files of a sequence carry the same two tables (an encoder's defaults): built once per decode thread, then copied --
-      // building them was 55 of the 86 us this function took for a 265-KB file (31 now).
-      struct TableCache {
-        bool valid = false;
-        int len[2] = {0, 0};
-        unsigned char def[2][16 + 256];
-        mdc_jpeg_huff tab[2];
-      };
-      static thread_local TableCache cache;
-      const bool hit = cache.valid && cache.len[0] == src[0]->def_len && cache.len[1] == src[1]->def_len &&
-                       memcmp(cache.def[0], src[0]->def, (size_t)cache.len[0]) == 0 && memcmp(cache.def[1], src[1]->def, (size_t)cache.len[1]) == 0;
-      if (hit) {
-        hd->dc = cache.tab[0];
-        hd->ac = cache.tab[1];
+      hd->restart_interval = (uint32_t)restart;
+      hd->n_intervals = (uint32_t)n_iv;
+      hd->comp_info = (uint32_t)ncomp | (uint32_t)hY << 8 | (uint32_t)vY << 12;
+      hd->ecs_offset = (uint32_t)off;
+      for (int i = 0; i < 64; i++) hd->quant[i] = qt[comp[0].tq][i];
+      if (!device_table(dc[td[0]], false, 0, &hd->dc, err) || !device_table(ac[ta[0]], true, 1, &hd->ac, err)) return false;
+      if (ncomp == 3) {
+        mdc_jpeg_huff* chroma = reinterpret_cast<mdc_jpeg_huff*>(hd + 1);
+        if (!device_table(dc[td[1]], false, 2, &chroma[0], err) || !device_table(ac[ta[1]], true, 3, &chroma[1], err)) return false;
       }
-      for (int k = 0; k < 2 && !hit; k++) {
-        const Huff& t = *src[k];
-        // symbol and length of the code the 16-bit window `w16` starts with (0 = none)
-        auto code_of = [&](int w16, int* sym) {
-          const int e = t.look[w16 >> 7];
-          if (e) {
-            *sym = e & 255;
-            return e >> 8;
-          }
-          for (int l = 10; l <= 16; l++) {
-            const int code = w16 >> (16 - l);
-            if (code <= t.maxcode[l]) {
-              const int idx = code + t.valoff[l];
-              if (idx < 0 || idx > 255) return 0;
-              *sym = t.vals[idx];
-              return l;
-            }
-          }
-          return 0;
-        };
-        int nsub = 0;
-        for (int w11 = 0; w11 < 2048; w11++) {
-          int sym = 0;
-          const int l0 = code_of(w11 << 5, &sym);  // (with the 5 bits below the window zero: right for every code of <= 11 bits)
-          uint32_t e = 0;
-          bool is_short = l0 >= 1 && l0 <= 11;
-          if (is_short) {  // confirm: the code must not depend on the bits below the window
-            int sym1 = 0;
-            is_short = code_of(w11 << 5 | 31, &sym1) == l0 && sym1 == sym;
-          }
-          if (is_short) {
-            const int run = k ? sym >> 4 : 0, sz = k ? sym & 15 : sym;
-            if (!k && sym > 15) {
-              dst[k]->t1[w11] = 0;
-              continue;
-            }
-            e = (uint32_t)l0 | (uint32_t)run << 5 | (uint32_t)sz << 9;
-            if (sz && l0 + sz <= 11) {
-              int v = (w11 >> (11 - l0 - sz)) & ((1 << sz) - 1);
-              if (v < (1 << (sz - 1))) v += (int)((~0u) << sz) + 1;  // EXTEND
-              e |= 1u << 13 | (uint32_t)(uint16_t)(int16_t)v << 16;
-            }
-          } else {  // longer codes below this prefix?
-            uint32_t sub[32];
-            bool any = false;
-            for (int sfx = 0; sfx < 32; sfx++) {
-              int s2 = 0;
-              const int l = code_of(w11 << 5 | sfx, &s2);
-              sub[sfx] = 0;
-              if (l >= 12 && l <= 16 && (k || s2 <= 15)) {
-                sub[sfx] = (uint32_t)l | (uint32_t)(k ? s2 >> 4 : 0) << 5 | (uint32_t)(k ? s2 & 15 : s2) << 9;
-                any = true;
-              }
-            }
-            if (any) {
-              if (nsub >= MDC_JPEG_HUFF_SUBTABLES) return fail(err, "JPEG stream: too many long Huffman codes for the device tables");
-              memcpy(dst[k]->t2[nsub], sub, sizeof sub);
-              e = 31u | (uint32_t)nsub << 16;
-              nsub++;
-            }
-          }
-          dst[k]->t1[w11] = e;
-        }
-      }
-      if (!hit) {
-        cache.valid = false;
-        for (int k = 0; k < 2; k++) {
-          cache.len[k] = src[k]->def_len;
-          memcpy(cache.def[k], src[k]->def, (size_t)src[k]->def_len);
-        }
-        cache.tab[0] = hd->dc;
-        cache.tab[1] = hd->ac;
-        cache.valid = true;
-      }
-      // entropy-coded segment without its byte stuffing; ends at the first marker (EOI)
+      uint32_t* starts = reinterpret_cast<uint32_t*>(stream + starts_off);
+      memset(stream + starts_off, 0, off - starts_off);
+      // entropy-coded segment without its byte stuffing and its restart markers; ends at the first other marker (EOI)
       const unsigned char* q = d + p + len;
       const unsigned char* end = d + n;
-      unsigned char* o = stream + sizeof *hd;
+      unsigned char* const o0 = stream + off;
+      unsigned char* o = o0;
       unsigned char* const o_end = stream + cap - 16;
+      long iv = 0;  // intervals begun
+      int expect_rst = 0;
+      if (restart) starts[iv] = 0;
+      iv = 1;
       while (q < end) {
         const unsigned char* ff = static_cast<const unsigned char*>(memchr(q, 0xff, (size_t)(end - q)));
         const size_t run = ff ? (size_t)(ff - q) : (size_t)(end - q);
@@ -741,16 +791,22 @@ bool jpeg_stream(const unsigned char* d, size_t n, unsigned char* stream, size_t
         } else if (q + 1 < end && q[1] == 0xff) {  // fill byte
           q++;
         } else if (q + 1 < end && q[1] >= 0xd0 && q[1] <= 0xd7) {
-          return fail(err, "JPEG stream: restart markers");
+          // RSTm: the next interval begins at the next byte (what came before it is padded to a byte with 1-bits)
+          if (!restart || q[1] != 0xd0 + expect_rst) return fail(err, "JPEG stream: unexpected restart marker");
+          if (iv >= n_iv) return fail(err, "JPEG stream: more restart intervals than the frame has");
+          expect_rst = (expect_rst + 1) & 7;
+          starts[iv++] = (uint32_t)(o - o0);
+          q += 2;
         } else {
           break;  // EOI (or any other marker): end of the scan
         }
       }
-      const size_t ecs = (size_t)(o - (stream + sizeof *hd));
+      if (restart && iv != n_iv) return fail(err, "JPEG stream: fewer restart intervals than the frame has");
+      const size_t ecs = (size_t)(o - o0);
       if (ecs == 0 || ecs >= (1u << 28)) return fail(err, "JPEG stream: empty scan");
       memset(o, 0, 16);
       hd->ecs_bytes = (uint32_t)ecs;
-      *used = sizeof *hd + ecs + 16;
+      *used = off + ecs + 16;
       *w = W;
       *h = H;
       return true;

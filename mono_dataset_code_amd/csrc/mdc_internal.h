@@ -148,10 +148,12 @@ hipError_t launch_vcal_smooth(const float* d_vig, int wI, int hI, float* d_tt, f
 // JPEG ingest, device half: coefficient records (per frame: 64 x u16 luma quantisation table, then blocks_rows x blocks_w blocks
 // of 64 quantised int16 coefficients, natural order; record_bytes apart) -> 8-bit frames (nframes * w * h), libjpeg's islow
 // inverse DCT (mdc_jpeg.hip)
-// Huffman decoding of single-component baseline JPEG streams (mdc_jpeg_stream_header + unstuffed entropy-coded bytes, one per
-// frame, stream_stride bytes apart) into coefficient records; d_status[f]: 0 decoded, 1 bad code / block count, 2 bad header.
+// Huffman decoding of baseline JPEG streams -- one or three components, with or without restart intervals
+// (mdc_jpeg_stream_header + tables + unstuffed entropy-coded bytes, one per frame, stream_stride bytes apart) -- into LUMA
+// coefficient records; d_status[f]: 0 decoded, 1 bad code / block count, 2 bad header.
+// kinds: which kinds of stream the batch may hold (bit 0: one component, bit 1: three components, bit 2: restart intervals) -- one launch each
 hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w, int h, int blocks_w,
-                               int blocks_rows, int64_t nframes, int* d_status, hipStream_t s);
+                               int blocks_rows, int64_t nframes, int* d_status, hipStream_t s, unsigned kinds = 7u);
 hipError_t launch_jpeg_idct(const void* d_records, int64_t record_bytes, uint8_t* d_frames, int w, int h, int blocks_w, int blocks_rows,
                             int64_t nframes, hipStream_t s);
 

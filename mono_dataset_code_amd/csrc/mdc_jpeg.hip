@@ -131,32 +131,85 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const int16_t* __restric
 
 // ---------------------------------------------------------------------------------------------------------
 // Huffman decoding on the device (the serial half of JPEG decoding, made parallel).  Input: a STREAM per frame
-// (mdc_jpeg_stream_header, include/mdc_hip.h): the host has parsed the file's markers, built the two decode tables of a
-// single-component baseline scan and copied the entropy-coded segment with its FF00 byte stuffing removed -- 0.1 ms per frame,
-// against 2.5 ms for the Huffman decoding itself.  Output: the coefficient record the inverse-DCT kernel above reads.
+// (mdc_jpeg_stream_header, include/mdc_hip.h): the host has parsed the file's markers, built the decode tables of the scan
+// and copied the entropy-coded segment with its FF00 byte stuffing (and its restart markers) removed -- 0.1 ms per frame,
+// against 2.5 ms for the Huffman decoding itself.  Output: the LUMA coefficient record the inverse-DCT kernel above reads
+// (what cv::imread(..., GRAYSCALE) keeps of a colour file: Y).  Three kernels, one per kind of stream; each leaves the
+// frames of the other kinds alone:
 //
-// One workgroup of 1024 threads per frame.  The bit stream is cut into 1024 subsequences of S bits; thread i decodes
-// [i S, (i+1) S) from an entry state (bit position of a symbol boundary, coefficient index z inside the current block;
-// z == 0: a DC symbol comes next).  The true entry state of subsequence i is the exit state of subsequence i-1 -- unknown at
-// first, so every thread starts from a guess (its left neighbour decodes the last 512 bits of its own subsequence from an
-// arbitrary state), and the states are RELAXED: decode, hand the exit state to the right neighbour, decode again where the
-// entry state changed, until nothing changes.  Subsequence 0's entry state (0, 0) is exact,
-// so after k rounds the first k are exact: the fixed point is the sequential decoder's state sequence; and because Huffman
-// streams resynchronise after a few symbols (bit position) and every end-of-block resets z, wrong guesses heal inside one
-// subsequence: 2-3 rounds in practice (the bound, 1024, only costs time).  Then a prefix sum over the blocks each
-// subsequence completed gives every thread its first block, a last pass decodes once more and WRITES the coefficients
-// (the record is zero-filled first; DC differences are written and turned into DC values by a prefix sum over the frame's
-// blocks, as the predictor of a non-interleaved scan runs over all of them).  Integer logic only: the record equals the host
-// decoder's bit for bit; a code no table holds sets the frame's status (the caller falls back to the host decoder).
+//  * jpeg_huffman_kernel<false>: one component, no restart markers (what the TUM mono dataset ships).  One workgroup of
+//    1024 threads per frame.  The bit stream is cut into 1024 subsequences of S bits; thread i decodes [i S, (i+1) S) from an
+//    entry state (bit position of a symbol boundary, coefficient index z inside the current block; z == 0: a DC symbol comes
+//    next).  The true entry state of subsequence i is the exit state of subsequence i-1 -- unknown at first, so every thread
+//    starts from a guess (its left neighbour decodes the last quarter of its own subsequence from an arbitrary state), and the
+//    states are RELAXED: decode, hand the exit state to the right neighbour, decode again where the entry state changed, until
+//    nothing changes.  Subsequence 0's entry state is exact, so after k rounds the first k are exact: the fixed point is the
+//    sequential decoder's state sequence; and because Huffman streams resynchronise after a few symbols (bit position) and
+//    every end-of-block resets z, wrong guesses heal inside one subsequence: 2-3 rounds in practice (the bound, 1024, only
+//    costs time).  Then a prefix sum over the blocks each subsequence completed gives every thread its first block, a last
+//    pass decodes once more and WRITES the coefficients (the record is zero-filled first; DC differences are written and
+//    turned into DC values by a prefix sum over the frame's blocks, as the predictor runs over all of them).
+//  * jpeg_huffman_kernel<true>: three components interleaved in one scan (YCbCr baseline), no restart markers.  The same
+//    relaxation over a larger state: (bit, z, u), u = the block's position inside its MCU (hY x vY luma blocks, then Cb, then
+//    Cr), which picks the table pair; chroma symbols are decoded and dropped, luma blocks are counted and written.
+//  * jpeg_huffman_intervals_kernel: files with restart markers, one or three components.  Every restart interval starts at a
+//    byte the host has recorded, with z = 0 and all predictors 0: exact entry states, no relaxation -- a thread decodes whole
+//    intervals front to back and writes final DC values directly.
+//
+// Integer logic only: the record equals the host decoder's bit for bit; a code no table holds, too few blocks or an interval
+// that runs into the next one set the frame's status (the caller falls back to the host decoder).
 // ---------------------------------------------------------------------------------------------------------
 __device__ __constant__ unsigned char c_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                                       41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                                       30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-struct HuffLds {  // both tables as the kernel uses them (copied from the stream header): [0] DC, [1] AC
-  uint32_t t1[2][2048];
-  uint32_t t2[2][MDC_JPEG_HUFF_SUBTABLES][32];
+// the decode tables as the kernels use them (copied from the stream): [0] DC luma, [1] AC luma, ([2] DC chroma, [3] AC chroma)
+template <int NT>
+struct HuffLds {
+  uint32_t t1[NT][2048];
+  uint32_t t2[NT][MDC_JPEG_HUFF_SUBTABLES][32];
 };
+
+// Geometry of a scan: luma blocks of an MCU (hY x vY), blocks per MCU (luma + 2 chroma for three components), MCUs per row,
+// luma blocks in all, record pitch in blocks.
+struct ScanGeo {
+  int hY, vY, hv, nb, mx, nluma, pitch;
+};
+__device__ __forceinline__ ScanGeo scan_geo(const mdc_jpeg_stream_header* hd, int W, int H, int pitch) {
+  ScanGeo g;
+  const int ncomp = (int)(hd->comp_info & 255u);
+  g.hY = ncomp == 3 ? (int)((hd->comp_info >> 8) & 15u) : 1;
+  g.vY = ncomp == 3 ? (int)((hd->comp_info >> 12) & 15u) : 1;
+  g.hv = g.hY * g.vY;
+  g.nb = ncomp == 3 ? g.hv + 2 : 1;
+  g.mx = (W + 8 * g.hY - 1) / (8 * g.hY);
+  const int my = (H + 8 * g.vY - 1) / (8 * g.vY);
+  g.nluma = g.mx * my * g.hv;
+  g.pitch = pitch;
+  return g;
+}
+// the q-th luma block of the scan (MCU by MCU, inside an MCU row by row) -> its place in the record
+__device__ __forceinline__ int16_t* luma_block(int16_t* coef, int q, const ScanGeo& g) {
+  const int m = q / g.hv, uu = q - m * g.hv;
+  const int mcu_y = m / g.mx, mcu_x = m - mcu_y * g.mx;
+  const int bx = mcu_x * g.hY + uu % g.hY, by = mcu_y * g.vY + uu / g.hY;
+  return coef + ((long long)by * g.pitch + bx) * 64;
+}
+// which kernel a stream is for: 0 = one component, relaxed; 1 = three components, relaxed; 2 = restart intervals; -1 = none (bad header)
+__device__ __forceinline__ int stream_kind(const mdc_jpeg_stream_header* hd, int W, int H, int pitch, int rows, long long stream_stride) {
+  const uint32_t ecs_bytes = hd->ecs_bytes, ncomp = hd->comp_info & 255u, hY = (hd->comp_info >> 8) & 15u, vY = (hd->comp_info >> 12) & 15u;
+  const uint32_t base = (uint32_t)sizeof(mdc_jpeg_stream_header) + (ncomp == 3 ? 2u * (uint32_t)sizeof(mdc_jpeg_huff) : 0u);
+  const bool ok = hd->magic == MDC_JPEG_STREAM_MAGIC && (int)hd->w == W && (int)hd->h == H && ecs_bytes > 0 && ecs_bytes < (1u << 28) &&
+                  (ncomp == 1 || (ncomp == 3 && hY >= 1 && hY <= 4 && vY >= 1 && vY <= 4)) && hd->n_intervals >= 1 && hd->n_intervals < (1u << 24) &&
+                  hd->ecs_offset % 16 == 0 && hd->ecs_offset >= base + ((hd->restart_interval ? hd->n_intervals * 4u : 0u)) &&
+                  (long long)hd->ecs_offset + ecs_bytes + 16 <= stream_stride && (hd->restart_interval != 0 || hd->n_intervals == 1);
+  if (!ok) return -1;
+  // the luma grid of the MCU-padded scan must fit the record
+  const int h = ncomp == 3 ? (int)hY : 1, v = ncomp == 3 ? (int)vY : 1;
+  if ((W + 8 * h - 1) / (8 * h) * h > pitch || (H + 8 * v - 1) / (8 * v) * v > rows) return -1;
+  if (hd->restart_interval) return 2;
+  return ncomp == 3 ? 1 : 0;
+}
 
 struct BitReader {
   const uint32_t* base;  // entropy-coded bytes, 4-byte aligned, zero-padded past the end
@@ -198,63 +251,81 @@ struct BitReader {
 
 __device__ __forceinline__ int huff_extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
 
-// Decodes from (bit, z) until a symbol boundary at or past `end`.  WRITE: coefficients of blocks [blk, nblocks) go to the
-// record.  Returns the exit state; *nblk += blocks completed; *bad set when a code is in no table.
-// One code path for every symbol: the table (DC when z == 0, else AC) is picked by address, one lookup of the next 11 bits
-// gives length, run, size and -- mostly -- the value; lanes of a wave are at different symbols anyway, so every branch that
-// some lane takes costs all of them.
-template <bool WRITE>
-__device__ __forceinline__ void huff_run(BitReader& b, const HuffLds& T, uint32_t bit, int z, uint32_t end, uint32_t* out_bit, int* out_z, int* nblk,
-                                         int* bad, int16_t* coef, int blk, int nblocks, int bw_used, int pitch) {
+// One symbol at the reader's position with table pair `tab` (0 luma, 2 chroma), DC when z == 0 else AC: -> coefficient index
+// the symbol writes (0: the DC difference; -1: none) and its value; z advanced (>= 64: the block is complete); *wrong set for a
+// code no table holds, a DC category above 11 (the host decoder refuses those too) or a run past the block.
+// One code path for every symbol: the table is picked by address, one lookup of the next 11 bits gives length, run, size and
+// -- mostly -- the value; lanes of a wave are at different symbols anyway, so every branch that some lane takes costs all of them.
+template <int NT>
+__device__ __forceinline__ int huff_symbol(BitReader& b, const HuffLds<NT>& T, int tab, int& z, int* value, bool* wrong_out) {
+  const int ac = z != 0;
+  uint32_t e = T.t1[tab + ac][b.peek(11)];
+  if ((e & 31u) == 31u) e = T.t2[tab + ac][(e >> 16) & (MDC_JPEG_HUFF_SUBTABLES - 1)][(uint32_t)(b.acc >> 48) & 31u];  // bits 11..15 of the window
+  const int len = (int)(e & 31u), run = (int)((e >> 5) & 15u), size = (int)((e >> 9) & 15u);
+  bool wrong = len == 0 || len > 16 || (!ac && size > 11);
+  int v = 0;
+  if (wrong) {
+    b.skip(1);  // (speculative rounds run through garbage: keep moving)
+  } else if (e & (1u << 13)) {
+    b.skip(len + size);
+    v = (int)(int16_t)(e >> 16);
+  } else {
+    b.skip(len);
+    if (size) v = huff_extend(b.get(size), size);
+  }
+  int at = 0;
+  if (!ac) {
+    z = 1;
+    if (wrong) v = 0;
+  } else if (wrong) {
+    at = -1;
+  } else if (size == 0) {
+    z = run == 15 ? z + 16 : 64;  // ZRL / EOB
+    at = -1;
+  } else {
+    z += run;
+    at = z;
+    if (z > 63) {
+      wrong = true;
+      at = -1;
+    }
+    z++;
+  }
+  *value = v;
+  *wrong_out = wrong;
+  return at;
+}
+
+// Decodes from the state (bit, z, u) until a symbol boundary at or past `end`.  WRITE: coefficients of luma blocks [q, nluma)
+// go to the record.  Returns the exit state; *nblk += luma blocks completed; *bad set when a code is in no table.
+template <bool WRITE, bool COLOR, int NT>
+__device__ __forceinline__ void huff_run(BitReader& b, const HuffLds<NT>& T, uint32_t bit, int z, int u, uint32_t end, uint32_t* out_bit, int* out_z,
+                                         int* out_u, int* nblk, int* bad, int16_t* coef, int q, const ScanGeo& g) {
   b.start(bit);
   int done = 0;
   uint32_t p = bit;
+  bool luma = !COLOR || u < g.hv;
   int16_t* cur = nullptr;
-  if (WRITE && blk < nblocks) cur = coef + ((long long)(blk / bw_used) * pitch + blk % bw_used) * 64;
+  if (WRITE && luma && q < g.nluma) cur = luma_block(coef, q, g);
   while (p < end) {
     b.refill();
-    const int ac = z != 0;
-    uint32_t e = T.t1[ac][b.peek(11)];
-    if ((e & 31u) == 31u) e = T.t2[ac][(e >> 16) & (MDC_JPEG_HUFF_SUBTABLES - 1)][(uint32_t)(b.acc >> 48) & 31u];  // bits 11..15 of the window
-    const int len = (int)(e & 31u), run = (int)((e >> 5) & 15u), size = (int)((e >> 9) & 15u);
-    bool wrong = len == 0 || len > 16 || (!ac && size > 11);  // (the host decoder refuses DC categories above 11 too)
-    int v = 0;
-    if (wrong) {
-      b.skip(1);  // (speculative rounds run through garbage: keep moving)
-    } else if (e & (1u << 13)) {
-      b.skip(len + size);
-      v = (int)(int16_t)(e >> 16);
-    } else {
-      b.skip(len);
-      if (size) v = huff_extend(b.get(size), size);
-    }
-    int at = 0;  // coefficient index this symbol writes (0: the DC difference), -1: none
-    if (!ac) {
-      z = 1;
-      if (wrong) v = 0;
-    } else if (wrong) {
-      at = -1;
-    } else if (size == 0) {
-      z = run == 15 ? z + 16 : 64;  // ZRL / EOB
-      at = -1;
-    } else {
-      z += run;
-      at = z;
-      if (z > 63) {
-        wrong = true;
-        at = -1;
-      }
-      z++;
-    }
-    if (wrong && (!WRITE || cur)) *bad = 1;  // (past the last block: the padding bits, not an error)
+    int v;
+    bool wrong;
+    const int at = huff_symbol(b, T, (COLOR && !luma) ? 2 : 0, z, &v, &wrong);
+    // (past the last luma block: the padding bits, not an error; chroma symbols count like luma ones)
+    if (wrong && (!WRITE || cur || (COLOR && !luma && q < g.nluma))) *bad = 1;
     if (WRITE && cur && at >= 0) cur[c_zigzag[at]] = (int16_t)v;
     if (z >= 64) {
       z = 0;
-      done++;
-      if (WRITE) {
-        blk++;
-        cur = blk < nblocks ? coef + ((long long)(blk / bw_used) * pitch + blk % bw_used) * 64 : nullptr;
+      if (luma) {
+        done++;
+        if (WRITE) q++;
       }
+      if (COLOR) {
+        u = u + 1 == g.nb ? 0 : u + 1;
+        luma = u < g.hv;
+      }
+      if (WRITE) cur = (luma && q < g.nluma) ? luma_block(coef, q, g) : nullptr;
     }
     const uint32_t np = b.pos();
     if (np <= p) {  // a table entry of length 0 (never built by the host, but a stream may come from anywhere): keep moving
@@ -267,17 +338,39 @@ __device__ __forceinline__ void huff_run(BitReader& b, const HuffLds& T, uint32_
   }
   *out_bit = p;
   *out_z = z;
+  *out_u = u;
   *nblk += done;
 }
 
 constexpr int kHuffThreads = 1024;
 
+// tables -> LDS (NT of them: luma pair in the header, chroma pair right behind it)
+template <int NT, int THREADS>
+__device__ __forceinline__ void load_tables(HuffLds<NT>& T, const mdc_jpeg_stream_header* hd, int tid) {
+  const mdc_jpeg_huff* chroma = reinterpret_cast<const mdc_jpeg_huff*>(hd + 1);
+  for (int k = 0; k < NT; k++) {
+    const mdc_jpeg_huff* h = k == 0 ? &hd->dc : k == 1 ? &hd->ac : &chroma[k - 2];
+    for (int i = tid; i < 2048; i += THREADS) T.t1[k][i] = h->t1[i];
+    for (int i = tid; i < MDC_JPEG_HUFF_SUBTABLES * 32; i += THREADS) (&T.t2[k][0][0])[i] = (&h->t2[0][0])[i];
+  }
+}
+// quantisation table -> record; record body zero-filled
+template <int THREADS>
+__device__ __forceinline__ void init_record(int16_t* rec, const mdc_jpeg_stream_header* hd, int pitch, int rows, int tid) {
+  if (tid < 64) reinterpret_cast<uint16_t*>(rec)[tid] = hd->quant[tid];
+  i32x4* body = reinterpret_cast<i32x4*>(rec + 64);
+  const long long n16 = (long long)pitch * rows * 8;  // 16-byte pieces
+  for (long long i = tid; i < n16; i += THREADS) body[i] = i32x4{0, 0, 0, 0};
+}
+
+template <bool COLOR>
 __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
                                                                     int16_t* __restrict__ records, long long rec_i16, int W, int H, int pitch,
-                                                                    int rows, int* __restrict__ status) {
-  __shared__ HuffLds s_t;
+                                                                    int rows, int* __restrict__ status, unsigned kinds) {
+  constexpr int NT = COLOR ? 4 : 2;
+  __shared__ HuffLds<NT> s_t;
   __shared__ uint32_t s_bit[kHuffThreads];
-  __shared__ int s_z[kHuffThreads];
+  __shared__ unsigned short s_zu[kHuffThreads];  // z | u << 8
   __shared__ int s_scan[kHuffThreads / 64 + 1];
   __shared__ int s_flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -285,35 +378,26 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
   const unsigned char* st = streams + f * stream_stride;
   const mdc_jpeg_stream_header* hd = reinterpret_cast<const mdc_jpeg_stream_header*>(st);
   int16_t* rec = records + f * rec_i16;
-  const int bw_used = (W + 7) / 8, bh_used = (H + 7) / 8, nblocks = bw_used * bh_used;
-  // header checks (uniform): anything off -> status 2, record untouched
-  const uint32_t ecs_bytes = hd->ecs_bytes;
-  const bool ok_hdr = hd->magic == MDC_JPEG_STREAM_MAGIC && (int)hd->w == W && (int)hd->h == H && ecs_bytes > 0 &&
-                      (long long)sizeof(mdc_jpeg_stream_header) + ecs_bytes + 16 <= stream_stride && ecs_bytes < (1u << 28);
-  if (!ok_hdr) {
-    if (tid == 0) status[f] = 2;
+  // header checks (uniform): anything off -> status 2, record untouched; a stream of another kind: not this kernel's
+  const int kind = stream_kind(hd, W, H, pitch, rows, stream_stride);
+  if (kind != (COLOR ? 1 : 0)) {
+    // (this kernel -- the one that always runs -- reports the streams nobody decodes: a header no kernel takes, or a kind whose
+    // kernel the caller did not ask for)
+    if (!COLOR && tid == 0 && (kind < 0 || !((kinds >> kind) & 1u))) status[f] = 2;
     return;
   }
-  // tables -> LDS; quantisation table -> record; record body zero-filled
-  {
-    for (int k = 0; k < 2; k++) {
-      const mdc_jpeg_huff* h = k ? &hd->ac : &hd->dc;
-      for (int i = tid; i < 2048; i += kHuffThreads) s_t.t1[k][i] = h->t1[i];
-      for (int i = tid; i < MDC_JPEG_HUFF_SUBTABLES * 32; i += kHuffThreads) (&s_t.t2[k][0][0])[i] = (&h->t2[0][0])[i];
-    }
-    if (tid < 64) reinterpret_cast<uint16_t*>(rec)[tid] = hd->quant[tid];
-    i32x4* body = reinterpret_cast<i32x4*>(rec + 64);
-    const long long n16 = (long long)pitch * rows * 8;  // 16-byte pieces
-    for (long long i = tid; i < n16; i += kHuffThreads) body[i] = i32x4{0, 0, 0, 0};
-    if (tid == 0) s_flag = 0;
-  }
+  const ScanGeo g = scan_geo(hd, W, H, pitch);
+  const uint32_t ecs_bytes = hd->ecs_bytes;
+  load_tables<NT, kHuffThreads>(s_t, hd, tid);
+  init_record<kHuffThreads>(rec, hd, pitch, rows, tid);
+  if (tid == 0) s_flag = 0;
   __syncthreads();
   const uint32_t nbits = ecs_bytes * 8u;
   uint32_t S = (nbits + kHuffThreads - 1) / kHuffThreads;
   S = max(256u, (S + 31u) & ~31u);
   const uint32_t my0 = min(nbits, (uint32_t)tid * S), my1 = min(nbits, my0 + S);
   BitReader b;
-  b.base = reinterpret_cast<const uint32_t*>(st + sizeof(mdc_jpeg_stream_header));
+  b.base = reinterpret_cast<const uint32_t*>(st + hd->ecs_offset);
   b.last = (ecs_bytes + 3) / 4 + 2;  // the host pads 16 zero bytes
   int16_t* coef = rec + 64;
   // ---- first guesses: only the exit state of a subsequence matters to its right neighbour, and a decoder started anywhere
@@ -321,16 +405,17 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
   // (a quarter of a full pass; where it is wrong, the relaxation below finds out)
   const uint32_t guess_bits = max(512u, S / MDC_EXP_GUESS_DIV);  // (high qualities: ~250 bits per block, 512 bits are two blocks)
   uint32_t in_bit = my0, out_bit = my0;
-  int in_z = 0, out_z = 0, nblk = 0, bad = 0;
+  int in_z = 0, out_z = 0, in_u = 0, out_u = 0, nblk = 0, bad = 0;
   if (my0 < my1) {
     const uint32_t from = my1 - my0 > guess_bits ? my1 - guess_bits : my0;
-    huff_run<false>(b, s_t, from, 0, my1, &out_bit, &out_z, &nblk, &bad, nullptr, 0, 0, 1, 1);
+    huff_run<false, COLOR>(b, s_t, from, 0, 0, my1, &out_bit, &out_z, &out_u, &nblk, &bad, nullptr, 0, g);
   }
   s_bit[tid] = out_bit;
-  s_z[tid] = out_z;
+  s_zu[tid] = (unsigned short)(out_z | out_u << 8);
   __syncthreads();
   in_bit = tid ? s_bit[tid - 1] : 0u;
-  in_z = tid ? s_z[tid - 1] : 0;
+  in_z = tid ? (s_zu[tid - 1] & 255) : 0;
+  in_u = tid ? (s_zu[tid - 1] >> 8) : 0;
   __syncthreads();
   // ---- relaxation
   bool dirty = true;
@@ -342,19 +427,21 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
       bad = 0;
       out_bit = in_bit;
       out_z = in_z;
-      if (in_bit < my1) huff_run<false>(b, s_t, in_bit, in_z, my1, &out_bit, &out_z, &nblk, &bad, nullptr, 0, 0, 1, 1);
+      out_u = in_u;
+      if (in_bit < my1) huff_run<false, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &out_bit, &out_z, &out_u, &nblk, &bad, nullptr, 0, g);
     }
     s_bit[tid] = out_bit;
-    s_z[tid] = out_z;
+    s_zu[tid] = (unsigned short)(out_z | out_u << 8);
     __syncthreads();
     const uint32_t nb = tid ? s_bit[tid - 1] : 0u;
-    const int nz = tid ? s_z[tid - 1] : 0;
-    dirty = (nb != in_bit || nz != in_z) && my0 < nbits;  // (threads past the end of the stream decode nothing: they just follow)
+    const int nz = tid ? (s_zu[tid - 1] & 255) : 0, nu = tid ? (s_zu[tid - 1] >> 8) : 0;
+    dirty = (nb != in_bit || nz != in_z || nu != in_u) && my0 < nbits;  // (threads past the end of the stream decode nothing: they just follow)
     in_bit = nb;
     in_z = nz;
+    in_u = nu;
     if (!__syncthreads_or(dirty ? 1 : 0)) break;
   }
-  // ---- first block of every subsequence: exclusive prefix sum of nblk
+  // ---- first luma block of every subsequence: exclusive prefix sum of nblk
   int incl = nblk;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -378,20 +465,19 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
   // ---- write pass (the true states)
   int bad_w = 0;
   if (in_bit < my1) {
-    int dummy = 0;
+    int dummy = 0, oz, ou;
     uint32_t ob;
-    int oz;
-    huff_run<true>(b, s_t, in_bit, in_z, my1, &ob, &oz, &dummy, &bad_w, coef, first, nblocks, bw_used, pitch);
+    huff_run<true, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bad_w, coef, first, g);
   }
   // fewer blocks than the frame has: truncated or damaged.  More: the 1..7 padding bits after the last block can parse as
   // another (short-coded) block; those are never written.
-  if (bad_w || (tid == 0 && total < nblocks)) s_flag = 1;  // (benign race: every writer writes 1)
+  if (bad_w || (tid == 0 && total < g.nluma)) s_flag = 1;  // (benign race: every writer writes 1)
   __syncthreads();
-  // ---- DC differences -> DC values: prefix sum over the frame's blocks in scan order
-  const int per = (nblocks + kHuffThreads - 1) / kHuffThreads;
-  const int b0 = min(nblocks, tid * per), b1 = min(nblocks, b0 + per);
+  // ---- DC differences -> DC values: prefix sum over the frame's luma blocks in scan order
+  const int per = (g.nluma + kHuffThreads - 1) / kHuffThreads;
+  const int b0 = min(g.nluma, tid * per), b1 = min(g.nluma, b0 + per);
   int sum = 0;
-  for (int k = b0; k < b1; k++) sum += coef[((long long)(k / bw_used) * pitch + k % bw_used) * 64];
+  for (int k = b0; k < b1; k++) sum += luma_block(coef, k, g)[0];
   int inc2 = sum;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -412,7 +498,7 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
   __syncthreads();
   int pred = s_scan[wave] + inc2 - sum;
   for (int k = b0; k < b1; k++) {
-    int16_t* c0 = coef + ((long long)(k / bw_used) * pitch + k % bw_used) * 64;
+    int16_t* c0 = luma_block(coef, k, g);
     pred += c0[0];
     c0[0] = (int16_t)pred;
   }
@@ -424,19 +510,124 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
 #endif
 }
 
+// Restart intervals: interval i holds MCUs [i Ri, (i+1) Ri) and begins, byte aligned, at the offset the host recorded, with
+// every predictor 0.  A thread decodes whole intervals front to back (no guesses), four table pairs or two.
+constexpr int kIntervalThreads = 256;
+__global__ __launch_bounds__(kIntervalThreads) void jpeg_huffman_intervals_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
+                                                                                  int16_t* __restrict__ records, long long rec_i16, int W, int H,
+                                                                                  int pitch, int rows, int* __restrict__ status) {
+  __shared__ HuffLds<4> s_t;
+  __shared__ int s_flag;
+  const int tid = threadIdx.x;
+  const long long f = blockIdx.x;
+  const unsigned char* st = streams + f * stream_stride;
+  const mdc_jpeg_stream_header* hd = reinterpret_cast<const mdc_jpeg_stream_header*>(st);
+  if (stream_kind(hd, W, H, pitch, rows, stream_stride) != 2) return;
+  int16_t* rec = records + f * rec_i16;
+  const ScanGeo g = scan_geo(hd, W, H, pitch);
+  const bool color = g.nb > 1;
+  if (color) load_tables<4, kIntervalThreads>(s_t, hd, tid);
+  else load_tables<2, kIntervalThreads>(reinterpret_cast<HuffLds<2>&>(s_t), hd, tid);
+  init_record<kIntervalThreads>(rec, hd, pitch, rows, tid);
+  if (tid == 0) s_flag = 0;
+  __syncthreads();
+  // (HuffLds<2> is a prefix of HuffLds<4> only table by table: index through the layout that was filled)
+  const uint32_t* t1 = color ? &s_t.t1[0][0] : &reinterpret_cast<HuffLds<2>&>(s_t).t1[0][0];
+  const uint32_t* t2 = color ? &s_t.t2[0][0][0] : &reinterpret_cast<HuffLds<2>&>(s_t).t2[0][0][0];
+  const int ri = (int)hd->restart_interval, n_iv = (int)hd->n_intervals;
+  const int mcus = g.nluma / g.hv;
+  const uint32_t* starts = reinterpret_cast<const uint32_t*>(st + sizeof(mdc_jpeg_stream_header) + (color ? 2 * sizeof(mdc_jpeg_huff) : 0));
+  const uint32_t ecs_bytes = hd->ecs_bytes;
+  BitReader b;
+  b.base = reinterpret_cast<const uint32_t*>(st + hd->ecs_offset);
+  b.last = (ecs_bytes + 3) / 4 + 2;
+  int16_t* coef = rec + 64;
+  int bad = 0;
+  if ((long long)(n_iv - 1) * ri >= mcus || (long long)n_iv * ri < mcus) bad = 1;  // the interval table does not describe this frame
+  for (int iv = tid; iv < n_iv && !bad; iv += kIntervalThreads) {
+    const uint32_t b0 = starts[iv], b1 = iv + 1 < n_iv ? starts[iv + 1] : ecs_bytes;
+    if (b0 > b1 || b1 > ecs_bytes) {
+      bad = 1;
+      break;
+    }
+    const int m0 = iv * ri, m1 = min(mcus, m0 + ri);
+    b.start(b0 * 8u);
+    int pred = 0;
+    for (int m = m0; m < m1; m++) {
+      for (int u = 0; u < g.nb; u++) {
+        const bool luma = u < g.hv;
+        int16_t* cur = luma ? luma_block(coef, m * g.hv + u, g) : nullptr;
+        const int tab = luma ? 0 : 2;
+        int z = 0;
+        while (z < 64) {
+          b.refill();
+          // (the symbol decoder of the relaxed kernels, inlined on raw table pointers: the LDS layout depends on the table count)
+          const int ac = z != 0;
+          uint32_t e = t1[(tab + ac) * 2048 + b.peek(11)];
+          if ((e & 31u) == 31u) e = t2[((tab + ac) * MDC_JPEG_HUFF_SUBTABLES + ((e >> 16) & (MDC_JPEG_HUFF_SUBTABLES - 1))) * 32 + ((uint32_t)(b.acc >> 48) & 31u)];
+          const int len = (int)(e & 31u), run = (int)((e >> 5) & 15u), size = (int)((e >> 9) & 15u);
+          if (len == 0 || len > 16 || (!ac && size > 11)) {
+            bad = 1;
+            break;
+          }
+          int v = 0;
+          if (e & (1u << 13)) {
+            b.skip(len + size);
+            v = (int)(int16_t)(e >> 16);
+          } else {
+            b.skip(len);
+            if (size) v = huff_extend(b.get(size), size);
+          }
+          if (!ac) {
+            z = 1;
+            if (luma) {
+              pred += v;
+              cur[0] = (int16_t)pred;
+            }
+          } else if (size == 0) {
+            z = run == 15 ? z + 16 : 64;
+          } else {
+            z += run;
+            if (z > 63) {
+              bad = 1;
+              break;
+            }
+            if (luma) cur[c_zigzag[z]] = (int16_t)v;
+            z++;
+          }
+        }
+        if (bad) break;
+      }
+      if (bad) break;
+    }
+    if (!bad && b.pos() > b1 * 8u) bad = 1;  // ran into the next interval: damaged
+  }
+  if (bad) s_flag = 1;
+  __syncthreads();
+  if (tid == 0) status[f] = s_flag ? 1 : 0;
+}
+
 }  // namespace
 
 hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w, int h, int blocks_w,
-                               int blocks_rows, int64_t nframes, int* d_status, hipStream_t s) {
+                               int blocks_rows, int64_t nframes, int* d_status, hipStream_t s, unsigned kinds) {
   if (nframes <= 0) return hipSuccess;
   const int bw_used = (w + 7) / 8, bh_used = (h + 7) / 8;
   if (w <= 0 || h <= 0 || blocks_w < bw_used || blocks_rows < bh_used || record_bytes % 16 != 0 || stream_stride % 16 != 0 ||
       stream_stride < (int64_t)sizeof(mdc_jpeg_stream_header) + 32 || record_bytes < 128 + (int64_t)blocks_w * blocks_rows * 128 ||
       ((reinterpret_cast<uintptr_t>(d_records) | reinterpret_cast<uintptr_t>(d_streams)) & 15) != 0 || nframes > (1ll << 30))
     return hipErrorInvalidValue;
-  jpeg_huffman_kernel<<<(unsigned)nframes, kHuffThreads, 0, s>>>(static_cast<const unsigned char*>(d_streams), stream_stride,
-                                                                 static_cast<int16_t*>(d_records), record_bytes / 2, w, h, blocks_w, blocks_rows,
-                                                                 d_status);
+  // One launch per kind of stream in the batch (`kinds`: bit 0 one component, bit 1 three components, bit 2 restart intervals;
+  // a caller that cannot look into the streams passes all three): a workgroup whose frame is of another kind leaves at once.
+  // The one-component kernel always runs: it is the one that reports headers no kernel takes.
+  const unsigned char* st = static_cast<const unsigned char*>(d_streams);
+  int16_t* rec = static_cast<int16_t*>(d_records);
+  kinds |= 1u;
+  jpeg_huffman_kernel<false><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, record_bytes / 2, w, h, blocks_w, blocks_rows, d_status, kinds);
+  if (kinds & 2u)
+    jpeg_huffman_kernel<true><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, record_bytes / 2, w, h, blocks_w, blocks_rows, d_status, kinds);
+  if (kinds & 4u)
+    jpeg_huffman_intervals_kernel<<<(unsigned)nframes, kIntervalThreads, 0, s>>>(st, stream_stride, rec, record_bytes / 2, w, h, blocks_w, blocks_rows, d_status);
   return hipGetLastError();
 }
 

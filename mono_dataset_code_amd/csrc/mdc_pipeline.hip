@@ -69,7 +69,7 @@ struct PipelineCall {
     }
   }
 
-  // Arguments and geometry.  Streams are decoded into records of the reader's geometry (block grid rounded up to multiples of 4).
+  // Arguments and geometry.  Streams are decoded into records of the reader's geometry (block grid rounded up to multiples of 12).
   int validate() {
     if (nframes < 0 || (nframes > 0 && ((!raw && !rec && !strm) || !out || (strm && !strm_bytes)))) return fail(c, MDC_ERR_ARG, "%s: bad argument", who);
     const bool rect = (flags & MDC_RECTIFY) != 0;
@@ -80,8 +80,8 @@ struct PipelineCall {
     n_in = (size_t)iw * ih;
     n_out = rect ? (size_t)c->out_w * c->out_h : n_in;
     if (strm) {
-      blocks_w = ((iw + 7) / 8 + 3) & ~3;
-      blocks_rows = ((ih + 7) / 8 + 3) & ~3;
+      blocks_w = ((iw + 7) / 8 + 11) / 12 * 12;  // (MCUs are 1..4 x 1..4 luma blocks: a multiple of 12 holds every MCU-padded luma grid)
+      blocks_rows = ((ih + 7) / 8 + 11) / 12 * 12;
       record_bytes = 128 + (int64_t)blocks_w * blocks_rows * 128;
       for (int64_t i = 0; i < nframes; i++) {
         if (strm_bytes[i] < (int64_t)sizeof(mdc_jpeg_stream_header) + 17 || strm_bytes[i] > (1ll << 28))
@@ -240,7 +240,14 @@ struct PipelineCall {
     MDC_PIPE(hipStreamWaitEvent(s, c->pipe_up[slot], 0));
     // the status words land in page-locked host memory directly (a copy would queue behind the results going out)
     int* d_status = (status && d_host_status) ? d_host_status + f0 : c->d_pipe_status[slot];
-    MDC_PIPE(launch_jpeg_huffman(c->d_pipe_strm[slot], (int64_t)strm_stride, c->d_pipe_rec[slot], record_bytes, iw, ih, blocks_w, blocks_rows, n, d_status, s));
+    // which decode kernels this chunk needs (the headers are the caller's host memory: one component / three / restart intervals)
+    unsigned kinds = 0;
+    for (int i = 0; i < n; i++) {
+      const mdc_jpeg_stream_header* hd = static_cast<const mdc_jpeg_stream_header*>(strm[f0 + i]);
+      kinds |= hd->restart_interval ? 4u : ((hd->comp_info & 255u) == 3 ? 2u : 1u);
+    }
+    MDC_PIPE(launch_jpeg_huffman(c->d_pipe_strm[slot], (int64_t)strm_stride, c->d_pipe_rec[slot], record_bytes, iw, ih, blocks_w, blocks_rows, n, d_status, s,
+                                 kinds));
     MDC_PIPE(hipEventRecord(c->pipe_huff[slot], s));
     stamp(k, 2, s);
     if (status && !d_host_status)

@@ -1,5 +1,5 @@
-"""mdch_jpeg_stream (the host half of the device Huffman path: markers parsed, the two decode tables built, byte stuffing
-removed) checked WITHOUT a GPU: a plain sequential decoder written here from the table format include/mdc_hip.h documents
+"""mdch_jpeg_stream (the host half of the device Huffman path: markers parsed, the decode tables built, byte stuffing and
+restart markers removed, restart intervals located; one component or YCbCr interleaved) checked WITHOUT a GPU: a plain sequential decoder written here from the table format include/mdc_hip.h documents
 (mdc_jpeg_huff: t1 by the next 11 bits, 32-entry subtables for the codes of 12..16 bits) turns the stream back into a
 coefficient record, which must equal the host decoder's record (mdch_decode_jpeg_record, itself pinned on libjpeg by
 tests/test_reader_cpu.py) byte for byte.  The kernel (csrc/mdc_jpeg.hip) reads the same tables with the same rules; its own
@@ -22,67 +22,90 @@ def textured(h, w, seed=0):
 
 
 def parse_header(stream):
+    """-> dict of the header fields, the decode tables ([0] DC luma, [1] AC luma, [2] DC chroma, [3] AC chroma) and the restart
+    intervals' start bytes (include/mdc_hip.h: mdc_jpeg_stream_header and what follows it)."""
     from mono_dataset_code_amd import capi
 
     u32 = stream[:32].view(np.uint32)
-    magic, w, h, ecs = (int(x) for x in u32[:4])
-    assert magic == 0x32534A4D and not u32[4:8].any()
+    magic, w, h, ecs, ri, n_iv, comp_info, ecs_off = (int(x) for x in u32[:8])
+    assert magic == 0x33534A4D
+    ncomp, hy, vy = comp_info & 255, (comp_info >> 8) & 15, (comp_info >> 12) & 15
+    assert ncomp in (1, 3) and (ncomp == 3 or (hy, vy) == (1, 1)) and ecs_off % 16 == 0 and n_iv >= 1 and (ri or n_iv == 1)
     quant = stream[32:160].view(np.uint16).copy()
-    tabs = stream[160:capi.JPEG_STREAM_HEADER_BYTES].view(np.uint32).reshape(2, 2048 + 32 * 32)
-    t1 = [tabs[k, :2048] for k in range(2)]
-    t2 = [tabs[k, 2048:].reshape(32, 32) for k in range(2)]
-    return w, h, ecs, quant, t1, t2
+    ntab = 4 if ncomp == 3 else 2
+    assert capi.JPEG_STREAM_HEADER_BYTES == 160 + 2 * 12288
+    tabs = stream[160:160 + ntab * 12288].view(np.uint32).reshape(ntab, 2048 + 32 * 32)
+    t1 = [tabs[k, :2048] for k in range(ntab)]
+    t2 = [tabs[k, 2048:].reshape(32, 32) for k in range(ntab)]
+    at = 160 + ntab * 12288
+    starts = [int(x) for x in stream[at:at + 4 * n_iv].view(np.uint32)] if ri else [0]
+    assert ecs_off >= at + (4 * n_iv if ri else 0) and ecs_off - (at + (4 * n_iv if ri else 0)) < 16
+    return dict(w=w, h=h, ecs=ecs, ri=ri, n_iv=n_iv, ncomp=ncomp, hy=hy, vy=vy, ecs_off=ecs_off, quant=quant, t1=t1, t2=t2, starts=starts)
 
 
 def sequential_decode(stream, pitch, rows):
-    """-> record (uint8) decoded one symbol after the other with the stream's own tables."""
-    from mono_dataset_code_amd import capi
-
-    w, h, ecs, quant, t1, t2 = parse_header(stream)
-    hdr = capi.JPEG_STREAM_HEADER_BYTES
-    assert not stream[hdr + ecs: hdr + ecs + 16].any(), "16 zero bytes follow the entropy-coded segment"
-    data = bytes(stream[hdr: hdr + ecs + 16])
+    """-> luma record (uint8) decoded one symbol after the other with the stream's own tables: MCU by MCU (hY x vY luma blocks,
+    then Cb, then Cr for three components), restart interval by restart interval (each from its recorded start byte, predictors 0)."""
+    H = parse_header(stream)
+    w, h, ecs, t1, t2 = H["w"], H["h"], H["ecs"], H["t1"], H["t2"]
+    off = H["ecs_off"]
+    assert not stream[off + ecs: off + ecs + 16].any(), "16 zero bytes follow the entropy-coded segment"
+    data = bytes(stream[off: off + ecs + 16])
     total = len(data) * 8
     val = int.from_bytes(data, "big")
 
     def peek(p, n):
         return (val >> (total - p - n)) & ((1 << n) - 1) if n else 0
 
-    bw, bh = (w + 7) // 8, (h + 7) // 8
+    hy, vy = H["hy"], H["vy"]
+    mx, my = (w + 8 * hy - 1) // (8 * hy), (h + 8 * vy - 1) // (8 * vy)
+    nb = hy * vy + (2 if H["ncomp"] == 3 else 0)
     rec = np.zeros(128 + rows * pitch * 128, np.uint8)
-    rec[:128] = quant.view(np.uint8)
+    rec[:128] = H["quant"].view(np.uint8)
     coef = rec[128:].view(np.int16).reshape(rows, pitch, 64)
-    p, dc = 0, 0
-    for blk in range(bw * bh):
-        out = coef[blk // bw, blk % bw]
-        z = 0
-        while z < 64:
-            ac = 1 if z else 0
-            e = int(t1[ac][peek(p, 11)])
-            if e & 31 == 31:
-                e = int(t2[ac][(e >> 16) & 31][peek(p + 11, 5)])
-            ln, run, size = e & 31, (e >> 5) & 15, (e >> 9) & 15
-            assert 1 <= ln <= 16, (blk, z, hex(e))
-            if e & (1 << 13):
-                v = (e >> 16) - (1 << 16) if e >> 31 else e >> 16
-                p += ln + size
-            else:
-                p += ln
-                bits = peek(p, size)
-                p += size
-                v = bits if size == 0 or bits >> (size - 1) else bits - (1 << size) + 1
-            if not ac:
-                dc += v
-                out[0] = dc
-                z = 1
-            elif size == 0:
-                z = z + 16 if run == 15 else 64
-            else:
-                z += run
-                assert z < 64
-                out[ZIGZAG[z]] = v
-                z += 1
-    assert p <= ecs * 8 and ecs * 8 - p < 8 + 8, "the scan ends inside the last byte (padding bits only)"
+    scratch = np.zeros(64, np.int16)
+    mcus = mx * my
+    ri = H["ri"] or mcus
+    assert H["n_iv"] == (mcus + ri - 1) // ri
+    p = 0
+    for iv in range(H["n_iv"]):
+        p = H["starts"][iv] * 8
+        end = (H["starts"][iv + 1] if iv + 1 < H["n_iv"] else ecs) * 8
+        dc = [0, 0, 0]
+        for m in range(iv * ri, min(mcus, (iv + 1) * ri)):
+            for u in range(nb):
+                luma = u < hy * vy
+                c = 0 if luma else 1 + (u - hy * vy)
+                tab = 0 if luma else 2
+                out = coef[(m // mx) * vy + u // hy, (m % mx) * hy + u % hy] if luma else scratch
+                z = 0
+                while z < 64:
+                    ac = 1 if z else 0
+                    e = int(t1[tab + ac][peek(p, 11)])
+                    if e & 31 == 31:
+                        e = int(t2[tab + ac][(e >> 16) & 31][peek(p + 11, 5)])
+                    ln, run, size = e & 31, (e >> 5) & 15, (e >> 9) & 15
+                    assert 1 <= ln <= 16, (m, u, z, hex(e))
+                    if e & (1 << 13):
+                        v = (e >> 16) - (1 << 16) if e >> 31 else e >> 16
+                        p += ln + size
+                    else:
+                        p += ln
+                        bits = peek(p, size)
+                        p += size
+                        v = bits if size == 0 or bits >> (size - 1) else bits - (1 << size) + 1
+                    if not ac:
+                        dc[c] += v
+                        out[0] = dc[c]
+                        z = 1
+                    elif size == 0:
+                        z = z + 16 if run == 15 else 64
+                    else:
+                        z += run
+                        assert z < 64
+                        out[ZIGZAG[z]] = v
+                        z += 1
+        assert p <= end and end - p < 8 + 8, "an interval ends inside its last byte (padding bits only)"
     return rec
 
 
@@ -96,13 +119,21 @@ def test_stream_tables_decode_to_the_host_decoders_record(size):
     rec_bytes, pitch, rows = capi.jpeg_record_bytes(w, h)
     bw, bh = (w + 7) // 8, (h + 7) // 8
     for k, img in enumerate(imgs):
-        for kw in ({"quality": 5}, {"quality": 50}, {"quality": 92}, {"quality": 100}, {"quality": 75, "optimize": True}):
+        rgb = np.stack([img, np.roll(img, 3, 1), 255 - img], -1)
+        for kw in ({"quality": 5}, {"quality": 50}, {"quality": 92}, {"quality": 100}, {"quality": 75, "optimize": True},
+                   # restart intervals (DRI + RSTn markers), one component and three
+                   {"quality": 80, "restart_marker_blocks": 7}, {"quality": 90, "restart_marker_rows": 1}, {"quality": 60, "restart_marker_blocks": 1},
+                   # YCbCr, the three components interleaved: 4:4:4, 4:2:2, 4:2:0 -- only the luma plane is decoded
+                   {"quality": 88, "subsampling": 0, "rgb": 1}, {"quality": 70, "subsampling": 1, "rgb": 1}, {"quality": 93, "subsampling": 2, "rgb": 1},
+                   {"quality": 85, "subsampling": 2, "rgb": 1, "restart_marker_rows": 1}, {"quality": 40, "subsampling": 1, "rgb": 1, "restart_marker_blocks": 3, "optimize": True}):
+            kw = dict(kw)
+            src = rgb if kw.pop("rgb", 0) else img
             b = io.BytesIO()
-            Image.fromarray(img).save(b, "JPEG", **kw)
+            Image.fromarray(src).save(b, "JPEG", **kw)
             data = b.getvalue()
             want = np.zeros(rec_bytes, np.uint8)
             assert capi.decode_jpeg_record(data, want, pitch)[:3] == (w, h, pitch)
-            stream = np.full((capi.JPEG_STREAM_HEADER_BYTES + len(data) + 64 + 15) & ~15, 0xA5, np.uint8)
+            stream = np.full((2 * capi.JPEG_STREAM_HEADER_BYTES + 4 * bw * bh + len(data) + 64 + 15) & ~15, 0xA5, np.uint8)
             used, sw, sh = capi.jpeg_stream(data, stream)
             assert (sw, sh) == (w, h) and used <= stream.size
             assert (stream[used:] == 0xA5).all(), "nothing written beyond the bytes reported"
@@ -126,7 +157,8 @@ def test_stream_table_entries_are_well_formed():
         Image.fromarray(img).save(b, "JPEG", **kw)
         stream = np.zeros((capi.JPEG_STREAM_HEADER_BYTES + len(b.getvalue()) + 64 + 15) & ~15, np.uint8)
         capi.jpeg_stream(b.getvalue(), stream)
-        _, _, _, _, t1, t2 = parse_header(stream)
+        hdr = parse_header(stream)
+        t1, t2 = hdr["t1"], hdr["t2"]
         for ac in (0, 1):
             subs = set()
             for idx in range(2048):
@@ -159,11 +191,19 @@ def test_stream_refusals_and_small_buffers():
     img = textured(48, 40, 2)
     rgb = np.stack([img, np.roll(img, 3, 1), 255 - img], -1)
     big = np.zeros(1 << 17, np.uint8)
-    for im, kw in ((rgb, {"quality": 88}), (img, {"quality": 85, "progressive": True}), (img, {"quality": 80, "restart_marker_blocks": 7})):
+    # refused (the caller takes the host decoders): progressive files; restart markers that do not count up
+    for im, kw in ((rgb, {"quality": 88, "progressive": True}), (img, {"quality": 85, "progressive": True})):
         b = io.BytesIO()
         Image.fromarray(im).save(b, "JPEG", **kw)
         with pytest.raises(ValueError):
             capi.jpeg_stream(b.getvalue(), big)
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, "JPEG", quality=80, restart_marker_blocks=2)
+    bad = bytearray(b.getvalue())
+    at = bad.index(b"\xff\xd1")
+    bad[at + 1] = 0xD5
+    with pytest.raises(ValueError):
+        capi.jpeg_stream(bytes(bad), big)
     b = io.BytesIO()
     Image.fromarray(img).save(b, "JPEG", quality=90)
     data = b.getvalue()
@@ -176,7 +216,7 @@ def test_stream_refusals_and_small_buffers():
     # file to the host decoder, tests/test_reader.py::test_reader_gpu_jpeg_stages_agree_on_damaged_and_mixed_files)
     cut = np.zeros(1 << 17, np.uint8)
     capi.jpeg_stream(data[: len(data) - 200], cut)
-    assert parse_header(cut)[2] < parse_header(big)[2]
+    assert parse_header(cut)["ecs"] < parse_header(big)["ecs"]
     with pytest.raises(ValueError):
         capi.jpeg_stream(b"\xff\xd8\xff\xd9", big)
     with pytest.raises(ValueError):

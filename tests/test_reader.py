@@ -217,8 +217,10 @@ def test_gpu_huffman_stage_equals_the_host_decoder(size):
     host; mdc_jpeg_huffman_batch_device: 1024 threads per stream, subsequence states relaxed to the sequential decoder's):
     the coefficient RECORD equals the host decoder's record byte for byte -- quantisation table, every coefficient of every
     block, DC prediction -- for textures, noise (long codes, few zero runs), flat images (blocks of one EOB), qualities 5..100,
-    optimised Huffman tables, sizes that are not whole blocks; then the device inverse DCT gives the host decoder's pixels.
-    Files the device does not take (colour, progressive, restart markers) are refused by mdch_jpeg_stream."""
+    optimised Huffman tables, sizes that are not whole blocks; files with restart intervals (each interval decoded from its
+    exact entry state) and YCbCr files with the three components interleaved (4:4:4, 4:2:2, 4:2:0: the luma plane is what
+    cv::imread(..., GRAYSCALE) keeps), all kinds mixed in one batch; then the device inverse DCT gives the host decoder's
+    pixels.  Files the device does not take (progressive) are refused by mdch_jpeg_stream."""
     import torch
 
     from mono_dataset_code_amd import capi
@@ -229,16 +231,23 @@ def test_gpu_huffman_stage_equals_the_host_decoder(size):
             (np.add.outer(np.arange(h), np.arange(w)) % 256).astype(np.uint8)]
     files = []
     for k, img in enumerate(imgs):
-        for kw in ({"quality": 5}, {"quality": 50}, {"quality": 92}, {"quality": 100}, {"quality": 75, "optimize": True}):
+        rgb = np.stack([img, np.roll(img, 3, 1), 255 - img], -1)
+        for kw in ({"quality": 5}, {"quality": 50}, {"quality": 92}, {"quality": 100}, {"quality": 75, "optimize": True},
+                   {"quality": 92, "restart_marker_blocks": 7}, {"quality": 60, "restart_marker_rows": 1}, {"quality": 95, "restart_marker_blocks": 1},
+                   {"quality": 92, "subsampling": 0, "rgb": 1}, {"quality": 70, "subsampling": 1, "rgb": 1}, {"quality": 100, "subsampling": 2, "rgb": 1},
+                   {"quality": 85, "subsampling": 2, "rgb": 1, "restart_marker_rows": 1}, {"quality": 30, "subsampling": 1, "rgb": 1, "optimize": True,
+                                                                                         "restart_marker_blocks": 3}):
             if h * w > 500000 and kw["quality"] not in (92, 100):
                 continue
+            kw = dict(kw)
+            src = rgb if kw.pop("rgb", 0) else img
             b = io.BytesIO()
-            Image.fromarray(img).save(b, "JPEG", **kw)
+            Image.fromarray(src).save(b, "JPEG", **kw)
             files.append(b.getvalue())
     rec_bytes, pitch, rows = capi.jpeg_record_bytes(w, h)
     n = len(files)
     want = np.zeros((n, rec_bytes), np.uint8)
-    cap = (capi.JPEG_STREAM_HEADER_BYTES + max(len(f) for f in files) + 64 + 15) & ~15
+    cap = (2 * capi.JPEG_STREAM_HEADER_BYTES + 4 * ((w + 7) // 8) * ((h + 7) // 8) + max(len(f) for f in files) + 64 + 15) & ~15
     streams = np.zeros((n, cap), np.uint8)
     for i, data in enumerate(files):
         dims = capi.decode_jpeg_record(data, want[i], pitch)
@@ -265,13 +274,13 @@ def test_gpu_huffman_stage_equals_the_host_decoder(size):
         assert np.array_equal(d_frames[i].cpu().numpy().reshape(h, w), capi.decode_gray8(files[i])), i
     # what the device decoder does not take is refused on the host
     rgb = np.stack([imgs[0], np.roll(imgs[0], 3, 1), 255 - imgs[0]], -1)
-    for img, kw in ((rgb, {"quality": 88}), (imgs[0], {"quality": 85, "progressive": True}), (imgs[0], {"quality": 80, "restart_marker_blocks": 7})):
+    for img, kw in ((rgb, {"quality": 88, "progressive": True}), (imgs[0], {"quality": 85, "progressive": True})):
         b = io.BytesIO()
         Image.fromarray(img).save(b, "JPEG", **kw)
         with pytest.raises(ValueError):
-            capi.jpeg_stream(b.getvalue(), streams[0])
+            capi.jpeg_stream(b.getvalue(), streams[0].copy())
     # a stream whose bits were damaged is reported, not decoded into something
-    bad = streams[:2].copy()
+    bad = streams[:2].copy()  # (the first two files: one component, no restart markers -- the stream body follows the header directly)
     bad[0, capi.JPEG_STREAM_HEADER_BYTES + 40: capi.JPEG_STREAM_HEADER_BYTES + 60] ^= 0xFF
     bad[1, 4] ^= 1  # header: another width
     d_bad = torch.from_numpy(bad).cuda()
@@ -293,7 +302,8 @@ def test_gpu_huffman_stage_equals_the_host_decoder(size):
 
 
 def test_gpu_huffman_stage_random_files():
-    """300 random files -- sizes 1x1 .. 97x131, qualities 1..100, optimised tables or the standard ones, content from flat
+    """300 random files -- sizes 1x1 .. 97x131, qualities 1..100, optimised tables or the standard ones, one component or YCbCr
+    (4:4:4 / 4:2:2 / 4:2:0), with or without restart intervals of 1..11 MCUs, content from flat
     through gradients and sparse dots to noise (the long codes, ZRL runs, 63-coefficient blocks and one-symbol blocks the
     tables can produce; streams with many FF bytes to unstuff) -- each through the device Huffman decoder and the host
     decoder: identical records, file by file (streams padded to one stride, one launch per size)."""
@@ -323,13 +333,20 @@ def test_gpu_huffman_stage_random_files():
                 img = (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)
             else:
                 img = np.clip(rng.normal(128, float(rng.integers(1, 90)), (h, w)), 0, 255).astype(np.uint8)
+            kw = {"quality": int(rng.integers(1, 101)), "optimize": bool(rng.integers(0, 2))}
+            flavour = int(rng.integers(0, 4))  # plain / restart intervals / YCbCr / both
+            if flavour & 1:
+                kw["restart_marker_blocks"] = int(rng.integers(1, 12))
+            if flavour & 2:
+                img = np.stack([img, np.roll(img, 1, 0), 255 - img], -1)
+                kw["subsampling"] = int(rng.integers(0, 3))
             b = io.BytesIO()
-            Image.fromarray(img).save(b, "JPEG", quality=int(rng.integers(1, 101)), optimize=bool(rng.integers(0, 2)))
+            Image.fromarray(img).save(b, "JPEG", **kw)
             files.append(b.getvalue())
         n = len(files)
         rec_bytes, pitch, rows = capi.jpeg_record_bytes(w, h)
         want = np.zeros((n, rec_bytes), np.uint8)
-        cap = (capi.JPEG_STREAM_HEADER_BYTES + max(len(f) for f in files) + 64 + 15) & ~15
+        cap = (2 * capi.JPEG_STREAM_HEADER_BYTES + 4 * ((w + 7) // 8) * ((h + 7) // 8) + max(len(f) for f in files) + 64 + 15) & ~15
         streams = np.zeros((n, cap), np.uint8)
         for i, data in enumerate(files):
             capi.decode_jpeg_record(data, want[i], pitch)
