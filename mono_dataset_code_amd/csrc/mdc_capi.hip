@@ -352,7 +352,7 @@ void mdc_destroy(mdc_ctx* c) {
     unpin_all(c);
     free_plan(c);
     void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_vcal_max, c->d_pipe_in[0], c->d_pipe_in[1], c->d_pipe_out[0], c->d_pipe_out[1],
-                    c->d_pipe_rec[0], c->d_pipe_rec[1], c->d_pipe_strm[0], c->d_pipe_strm[1], c->d_pipe_status[0], c->d_pipe_status[1]};
+                    c->d_pipe_rec[0], c->d_pipe_rec[1], c->d_pipe_strm[0], c->d_pipe_strm[1], c->d_pipe_status[0], c->d_pipe_status[1], c->d_pipe_seg[0], c->d_pipe_seg[1]};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     if (c->h_pipe_status) (void)hipHostFree(c->h_pipe_status);
@@ -1057,7 +1057,17 @@ int mdc_jpeg_huffman_batch_device(mdc_ctx* c, const void* d_streams, int64_t str
   if (!d_streams || !d_records || !d_status || nframes < 0 || w <= 0 || h <= 0) return fail(c, MDC_ERR_ARG, "mdc_jpeg_huffman_batch_device: bad argument");
   ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
-  MDC_HIP(c, launch_jpeg_huffman(d_streams, stream_stride, d_records, record_bytes, w, h, blocks_w, blocks_rows, nframes, d_status, (hipStream_t)stream));
+  // small batches spread a frame's stream over several workgroups, which talk through a scratch buffer: stream-ordered
+  // allocation (nothing is shared between concurrent calls)
+  void* scratch = nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  if (jpeg_huffman_segments(nframes) > 1 && hipMallocAsync(&scratch, jpeg_huffman_scratch_bytes(nframes), s) != hipSuccess) {
+    (void)hipGetLastError();
+    scratch = nullptr;  // (no pool: one workgroup per frame, as for large batches)
+  }
+  const hipError_t e = launch_jpeg_huffman(d_streams, stream_stride, d_records, record_bytes, w, h, blocks_w, blocks_rows, nframes, d_status, s, 7u, scratch);
+  if (scratch) (void)hipFreeAsync(scratch, s);
+  MDC_HIP(c, e);
   return MDC_OK;
 } MDC_CATCH(c)
 

@@ -136,6 +136,7 @@ struct mdc_ctx {
   void* d_pipe_rec[2] = {nullptr, nullptr};  // JPEG coefficient records of a chunk (mdc_process_jpeg_frames_host)
   void* d_pipe_strm[2] = {nullptr, nullptr};  // JPEG streams of a chunk (mdc_process_jpeg_streams_host)
   int* d_pipe_status[2] = {nullptr, nullptr}; // their decode status words (one chunk each)
+  void* d_pipe_seg[2] = {nullptr, nullptr};   // ... and the segment states of the Huffman decoder's several workgroups per frame
   int* h_pipe_status = nullptr;               // page-locked landing buffer for them (a whole call)
   size_t pipe_status_cap = 0;
   size_t pipe_in_cap = 0, pipe_out_cap = 0, pipe_rec_cap = 0, pipe_strm_cap = 0;

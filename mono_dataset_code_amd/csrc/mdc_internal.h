@@ -153,7 +153,11 @@ hipError_t launch_vcal_smooth(const float* d_vig, int wI, int hI, float* d_tt, f
 // coefficient records; d_status[f]: 0 decoded, 1 bad code / block count, 2 bad header.
 // kinds: which kinds of stream the batch may hold (bit 0: one component, bit 1: three components, bit 2: restart intervals) -- one launch each
 hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w, int h, int blocks_w,
-                               int blocks_rows, int64_t nframes, int* d_status, hipStream_t s, unsigned kinds = 7u);
+                               int blocks_rows, int64_t nframes, int* d_status, hipStream_t s, unsigned kinds = 7u, void* d_scratch = nullptr);
+// d_scratch (optional, jpeg_huffman_scratch_bytes(nframes) bytes): lets a small batch spread every frame's stream over
+// jpeg_huffman_segments(nframes) workgroups that hand their exit states on through it
+size_t jpeg_huffman_scratch_bytes(int64_t nframes);
+int jpeg_huffman_segments(int64_t nframes);
 hipError_t launch_jpeg_idct(const void* d_records, int64_t record_bytes, uint8_t* d_frames, int w, int h, int blocks_w, int blocks_rows,
                             int64_t nframes, hipStream_t s);
 

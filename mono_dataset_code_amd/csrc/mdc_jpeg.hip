@@ -12,6 +12,8 @@
 #include "../../include/mdc_hip.h"
 #include "mdc_internal.h"
 
+#include <algorithm>
+
 namespace mdc {
 namespace {
 
@@ -510,6 +512,237 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The relaxed decoder spread over G workgroups per frame (small batches: a 64-frame chunk of the reader's pipeline would keep
+// 64 of the chip's 256 CUs busy with one workgroup per frame).  Segment g of a frame = subsequences [1024 g, 1024 (g+1)) of
+// 1024 G; a workgroup relaxes its segment exactly as the one-workgroup kernel does, with a GUESSED entry state for its first
+// subsequence, then takes the true one from its left neighbour's published exit state (a decoupled look-back through global
+// memory: block f G + g only ever waits for block f G + g - 1, which was dispatched before it; the wait is bounded -- if the
+// neighbour does not show up the frame is reported as not decoded and the caller's host decoder takes it) and relaxes again
+// where that changed something -- a few subsequences, Huffman streams resynchronise.  Block counts travel with the state, so
+// the write pass needs no further exchange.  Three launches: jpeg_record_init_kernel (quantisation table, zero-fill -- the
+// segments' write passes must find the whole record cleared), jpeg_huffman_split_kernel, jpeg_dc_finish_kernel (DC
+// differences -> DC values over the frame, the frame's status).
+// ---------------------------------------------------------------------------------------------------------
+struct SegState {  // one per (frame, segment), zeroed before the launch
+  uint32_t bit;     // exit state of the segment's last subsequence
+  uint32_t zu;
+  int blocks_incl;  // luma blocks completed in segments 0..g
+  int flag;         // 0 = not yet, 1 = final; bit 1: the segment met a bad code (set after the write pass)
+};
+constexpr int kHuffMaxSegments = 4;
+
+__global__ __launch_bounds__(256) void jpeg_record_init_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
+                                                               int16_t* __restrict__ records, long long rec_i16, int pitch, int rows, int parts) {
+  const long long f = blockIdx.x / parts;
+  const int part = blockIdx.x % parts;
+  const mdc_jpeg_stream_header* hd = reinterpret_cast<const mdc_jpeg_stream_header*>(streams + f * stream_stride);
+  int16_t* rec = records + f * rec_i16;
+  if (part == 0 && threadIdx.x < 64) reinterpret_cast<uint16_t*>(rec)[threadIdx.x] = hd->quant[threadIdx.x];
+  i32x4* body = reinterpret_cast<i32x4*>(rec + 64);
+  const long long n16 = (long long)pitch * rows * 8, per = (n16 + parts - 1) / parts;
+  const long long i0 = part * per, i1 = min(n16, i0 + per);
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) body[i] = i32x4{0, 0, 0, 0};
+}
+
+template <bool COLOR>
+__global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
+                                                                          int16_t* __restrict__ records, long long rec_i16, int W, int H, int pitch,
+                                                                          int rows, SegState* __restrict__ seg, int G) {
+  constexpr int NT = COLOR ? 4 : 2;
+  __shared__ HuffLds<NT> s_t;
+  __shared__ uint32_t s_bit[kHuffThreads];
+  __shared__ unsigned short s_zu[kHuffThreads];
+  __shared__ int s_scan[kHuffThreads / 64 + 1];
+  __shared__ uint32_t s_entry[4];  // the left segment's published state: bit, zu, blocks_incl, ok
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long f = blockIdx.x / G;
+  const int sg = blockIdx.x % G;
+  const unsigned char* st = streams + f * stream_stride;
+  const mdc_jpeg_stream_header* hd = reinterpret_cast<const mdc_jpeg_stream_header*>(st);
+  SegState* my_seg = seg + f * G + sg;
+  const int kind = stream_kind(hd, W, H, pitch, rows, stream_stride);
+  if (kind != (COLOR ? 1 : 0)) {  // not this kernel's frame: say so to whoever waits (a final state with no blocks), leave
+    if (tid == 0) {
+      my_seg->blocks_incl = 0;
+      __threadfence();
+      atomicExch(&my_seg->flag, 1 | 4);  // bit 2: "no decode here" (the finish kernel leaves such frames to the other kernels' status)
+    }
+    return;
+  }
+  int16_t* rec = records + f * rec_i16;
+  const ScanGeo g = scan_geo(hd, W, H, pitch);
+  const uint32_t ecs_bytes = hd->ecs_bytes;
+  load_tables<NT, kHuffThreads>(s_t, hd, tid);
+  __syncthreads();
+  const uint32_t nbits = ecs_bytes * 8u;
+  const uint32_t nsub = (uint32_t)G * kHuffThreads;
+  uint32_t S = (nbits + nsub - 1) / nsub;
+  S = max(256u, (S + 31u) & ~31u);
+  const uint32_t gi = (uint32_t)sg * kHuffThreads + (uint32_t)tid;  // this thread's subsequence of the frame
+  const uint32_t my0 = (uint32_t)min((unsigned long long)nbits, (unsigned long long)gi * S), my1 = min(nbits, my0 + S);
+  BitReader b;
+  b.base = reinterpret_cast<const uint32_t*>(st + hd->ecs_offset);
+  b.last = (ecs_bytes + 3) / 4 + 2;
+  int16_t* coef = rec + 64;
+  const uint32_t guess_bits = max(512u, S / MDC_EXP_GUESS_DIV);
+  uint32_t in_bit = my0, out_bit = my0;
+  int in_z = 0, out_z = 0, in_u = 0, out_u = 0, nblk = 0, bad = 0;
+  if (my0 < my1) {
+    const uint32_t from = my1 - my0 > guess_bits ? my1 - guess_bits : my0;
+    huff_run<false, COLOR>(b, s_t, from, 0, 0, my1, &out_bit, &out_z, &out_u, &nblk, &bad, nullptr, 0, g);
+  }
+  // entry of the segment's first subsequence: exact for segment 0, a guess (its own start, z = 0) otherwise
+  uint32_t e_bit = my0;
+  int e_z = 0, e_u = 0;
+  int base_blocks = 0;
+  bool entry_ok = true;
+  for (int pass = 0; pass < 2; pass++) {
+    // ---- relaxation inside the segment (pass 1: again, from the true entry state, where it changes anything)
+    s_bit[tid] = out_bit;
+    s_zu[tid] = (unsigned short)(out_z | out_u << 8);
+    __syncthreads();
+    bool dirty = pass == 0;
+    {
+      const uint32_t nb = tid ? s_bit[tid - 1] : e_bit;
+      const int nz = tid ? (s_zu[tid - 1] & 255) : e_z, nu = tid ? (s_zu[tid - 1] >> 8) : e_u;
+      if (pass == 1) dirty = (nb != in_bit || nz != in_z || nu != in_u) && my0 < nbits;
+      in_bit = nb;
+      in_z = nz;
+      in_u = nu;
+    }
+    __syncthreads();
+    for (int round = 0; round <= kHuffThreads; round++) {
+      if (dirty) {
+        nblk = 0;
+        bad = 0;
+        out_bit = in_bit;
+        out_z = in_z;
+        out_u = in_u;
+        if (in_bit < my1) huff_run<false, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &out_bit, &out_z, &out_u, &nblk, &bad, nullptr, 0, g);
+      }
+      s_bit[tid] = out_bit;
+      s_zu[tid] = (unsigned short)(out_z | out_u << 8);
+      __syncthreads();
+      const uint32_t nb = tid ? s_bit[tid - 1] : e_bit;
+      const int nz = tid ? (s_zu[tid - 1] & 255) : e_z, nu = tid ? (s_zu[tid - 1] >> 8) : e_u;
+      dirty = (nb != in_bit || nz != in_z || nu != in_u) && my0 < nbits;
+      in_bit = nb;
+      in_z = nz;
+      in_u = nu;
+      if (!__syncthreads_or(dirty ? 1 : 0)) break;
+    }
+    if (pass == 1 || sg == 0) break;
+    // ---- the true entry state: the left segment's final exit state (bounded wait)
+    if (tid == 0) {
+      const SegState* left = my_seg - 1;
+      int fl = 0;
+      for (int spin = 0; spin < (1 << 20); spin++) {
+        fl = __hip_atomic_load(&left->flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (fl & 1) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      s_entry[3] = (fl & 1) && !(fl & 4);
+      s_entry[0] = __hip_atomic_load(&left->bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_entry[1] = __hip_atomic_load(&left->zu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_entry[2] = (uint32_t)__hip_atomic_load(&left->blocks_incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    entry_ok = s_entry[3] != 0;
+    e_bit = s_entry[0];
+    e_z = (int)(s_entry[1] & 255u);
+    e_u = (int)(s_entry[1] >> 8);
+    base_blocks = (int)s_entry[2];
+    __syncthreads();
+  }
+  // ---- first luma block of every subsequence: the left segments' count + exclusive prefix sum of nblk
+  int incl = nblk;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) s_scan[wave] = incl;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int w = 0; w < kHuffThreads / 64; w++) {
+      const int v = s_scan[w];
+      s_scan[w] = acc;
+      acc += v;
+    }
+    s_scan[kHuffThreads / 64] = acc;
+  }
+  __syncthreads();
+  const int first = base_blocks + s_scan[wave] + incl - nblk;
+  const int total = s_scan[kHuffThreads / 64];
+  // ---- publish: the exit state of the last subsequence + blocks so far (the right neighbour waits for this)
+  if (tid == kHuffThreads - 1) {
+    my_seg->bit = out_bit;
+    my_seg->zu = (uint32_t)(out_z | out_u << 8);
+    my_seg->blocks_incl = base_blocks + total;
+    __threadfence();
+    __hip_atomic_store(&my_seg->flag, entry_ok ? 1 : (1 | 4), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- write pass (the true states)
+  int bad_w = entry_ok ? 0 : 1;
+  if (entry_ok && in_bit < my1) {
+    int dummy = 0, oz, ou;
+    uint32_t ob;
+    huff_run<true, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bad_w, coef, first, g);
+  }
+  if (__syncthreads_or(bad_w) && tid == 0) atomicOr(&my_seg->flag, 2);
+}
+
+// After the split kernel: DC differences -> DC values over the frame's luma blocks in scan order, and the frame's status.
+template <bool COLOR>
+__global__ __launch_bounds__(kHuffThreads) void jpeg_dc_finish_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
+                                                                      int16_t* __restrict__ records, long long rec_i16, int W, int H, int pitch, int rows,
+                                                                      const SegState* __restrict__ seg, int G, int* __restrict__ status, unsigned kinds) {
+  __shared__ int s_scan[kHuffThreads / 64 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long f = blockIdx.x;
+  const mdc_jpeg_stream_header* hd = reinterpret_cast<const mdc_jpeg_stream_header*>(streams + f * stream_stride);
+  const int kind = stream_kind(hd, W, H, pitch, rows, stream_stride);
+  if (kind != (COLOR ? 1 : 0)) {
+    if (!COLOR && tid == 0 && (kind < 0 || !((kinds >> kind) & 1u))) status[f] = 2;
+    return;
+  }
+  const ScanGeo g = scan_geo(hd, W, H, pitch);
+  int16_t* coef = records + f * rec_i16 + 64;
+  int flags = 0;
+  for (int k = 0; k < G; k++) flags |= seg[f * G + k].flag;
+  const bool failed = (flags & (2 | 4)) != 0 || !(flags & 1) || seg[f * G + G - 1].blocks_incl < g.nluma;
+  const int per = (g.nluma + kHuffThreads - 1) / kHuffThreads;
+  const int b0 = min(g.nluma, tid * per), b1 = min(g.nluma, b0 + per);
+  int sum = 0;
+  for (int k = b0; k < b1; k++) sum += luma_block(coef, k, g)[0];
+  int inc2 = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(inc2, d, 64);
+    if (lane >= d) inc2 += up;
+  }
+  if (lane == 63) s_scan[wave] = inc2;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int w = 0; w < kHuffThreads / 64; w++) {
+      const int v = s_scan[w];
+      s_scan[w] = acc;
+      acc += v;
+    }
+  }
+  __syncthreads();
+  int pred = s_scan[wave] + inc2 - sum;
+  for (int k = b0; k < b1; k++) {
+    int16_t* c0 = luma_block(coef, k, g);
+    pred += c0[0];
+    c0[0] = (int16_t)pred;
+  }
+  if (tid == 0) status[f] = failed ? 1 : 0;
+}
+
 // Restart intervals: interval i holds MCUs [i Ri, (i+1) Ri) and begins, byte aligned, at the offset the host recorded, with
 // every predictor 0.  A thread decodes whole intervals front to back (no guesses), four table pairs or two.
 constexpr int kIntervalThreads = 256;
@@ -609,8 +842,14 @@ __global__ __launch_bounds__(kIntervalThreads) void jpeg_huffman_intervals_kerne
 
 }  // namespace
 
+size_t jpeg_huffman_scratch_bytes(int64_t nframes) { return (size_t)nframes * kHuffMaxSegments * sizeof(SegState); }
+int jpeg_huffman_segments(int64_t nframes) {
+  // workgroups the chip holds at once: 256 CUs x 2 of 1024 threads; below that, a frame's stream is spread over several
+  return (int)std::max<int64_t>(1, std::min<int64_t>(kHuffMaxSegments, 512 / std::max<int64_t>(1, nframes)));
+}
+
 hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w, int h, int blocks_w,
-                               int blocks_rows, int64_t nframes, int* d_status, hipStream_t s, unsigned kinds) {
+                               int blocks_rows, int64_t nframes, int* d_status, hipStream_t s, unsigned kinds, void* d_scratch) {
   if (nframes <= 0) return hipSuccess;
   const int bw_used = (w + 7) / 8, bh_used = (h + 7) / 8;
   if (w <= 0 || h <= 0 || blocks_w < bw_used || blocks_rows < bh_used || record_bytes % 16 != 0 || stream_stride % 16 != 0 ||
@@ -623,11 +862,27 @@ hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, voi
   const unsigned char* st = static_cast<const unsigned char*>(d_streams);
   int16_t* rec = static_cast<int16_t*>(d_records);
   kinds |= 1u;
-  jpeg_huffman_kernel<false><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, record_bytes / 2, w, h, blocks_w, blocks_rows, d_status, kinds);
-  if (kinds & 2u)
-    jpeg_huffman_kernel<true><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, record_bytes / 2, w, h, blocks_w, blocks_rows, d_status, kinds);
+  const int G = d_scratch ? jpeg_huffman_segments(nframes) : 1;
+  const long long rec_i16 = record_bytes / 2;
+  if (G > 1) {  // small batch: several workgroups per frame (d_scratch: jpeg_huffman_scratch_bytes(nframes), any content)
+    SegState* seg = static_cast<SegState*>(d_scratch);
+    hipError_t e = hipMemsetAsync(seg, 0, (size_t)nframes * G * sizeof(SegState), s);
+    if (e != hipSuccess) return e;
+    jpeg_record_init_kernel<<<(unsigned)(nframes * 8), 256, 0, s>>>(st, stream_stride, rec, rec_i16, blocks_w, blocks_rows, 8);
+    jpeg_huffman_split_kernel<false><<<(unsigned)(nframes * G), kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G);
+    jpeg_dc_finish_kernel<false><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G, d_status, kinds);
+    if (kinds & 2u) {
+      e = hipMemsetAsync(seg, 0, (size_t)nframes * G * sizeof(SegState), s);
+      if (e != hipSuccess) return e;
+      jpeg_huffman_split_kernel<true><<<(unsigned)(nframes * G), kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G);
+      jpeg_dc_finish_kernel<true><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G, d_status, kinds);
+    }
+  } else {
+    jpeg_huffman_kernel<false><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, d_status, kinds);
+    if (kinds & 2u) jpeg_huffman_kernel<true><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, d_status, kinds);
+  }
   if (kinds & 4u)
-    jpeg_huffman_intervals_kernel<<<(unsigned)nframes, kIntervalThreads, 0, s>>>(st, stream_stride, rec, record_bytes / 2, w, h, blocks_w, blocks_rows, d_status);
+    jpeg_huffman_intervals_kernel<<<(unsigned)nframes, kIntervalThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, d_status);
   return hipGetLastError();
 }
 

@@ -165,7 +165,7 @@ struct PipelineCall {
         if (!c->pipe_stream[k]) MDC_HIP(c, hipStreamCreateWithFlags(&c->pipe_stream[k], hipStreamNonBlocking));
         if (!c->pipe_done[k]) MDC_HIP(c, hipEventCreateWithFlags(&c->pipe_done[k], hipEventDisableTiming));
         if (!c->pipe_dec[k]) MDC_HIP(c, hipEventCreateWithFlags(&c->pipe_dec[k], hipEventDisableTiming));
-        for (void** p : {(void**)&c->d_pipe_in[k], (void**)&c->d_pipe_out[k], &c->d_pipe_rec[k], &c->d_pipe_strm[k], (void**)&c->d_pipe_status[k]})
+        for (void** p : {(void**)&c->d_pipe_in[k], (void**)&c->d_pipe_out[k], &c->d_pipe_rec[k], &c->d_pipe_strm[k], (void**)&c->d_pipe_status[k], &c->d_pipe_seg[k]})
           if (*p) {
             (void)hipFree(*p);
             *p = nullptr;
@@ -175,6 +175,7 @@ struct PipelineCall {
         if (rec_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_rec[k], rec_cap));
         if (strm_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_strm[k], strm_cap));
         if (strm_cap) MDC_HIP(c, hipMalloc((void**)&c->d_pipe_status[k], 64 * sizeof(int)));
+        if (strm_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_seg[k], jpeg_huffman_scratch_bytes(64)));
       }
       c->pipe_in_cap = in_cap;
       c->pipe_out_cap = out_cap;
@@ -246,8 +247,9 @@ struct PipelineCall {
       const mdc_jpeg_stream_header* hd = static_cast<const mdc_jpeg_stream_header*>(strm[f0 + i]);
       kinds |= hd->restart_interval ? 4u : ((hd->comp_info & 255u) == 3 ? 2u : 1u);
     }
+    // (a chunk of <= 64 frames: each frame's stream goes over several workgroups, through the slot's segment states)
     MDC_PIPE(launch_jpeg_huffman(c->d_pipe_strm[slot], (int64_t)strm_stride, c->d_pipe_rec[slot], record_bytes, iw, ih, blocks_w, blocks_rows, n, d_status, s,
-                                 kinds));
+                                 kinds, c->d_pipe_seg[slot]));
     MDC_PIPE(hipEventRecord(c->pipe_huff[slot], s));
     stamp(k, 2, s);
     if (status && !d_host_status)
