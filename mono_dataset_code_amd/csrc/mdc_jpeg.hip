@@ -533,9 +533,11 @@ struct SegState {  // one per (frame, segment), zeroed before the launch
 constexpr int kHuffMaxSegments = 4;
 
 __global__ __launch_bounds__(256) void jpeg_record_init_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
-                                                               int16_t* __restrict__ records, long long rec_i16, int pitch, int rows, int parts) {
+                                                               int16_t* __restrict__ records, long long rec_i16, int pitch, int rows, int parts,
+                                                               SegState* __restrict__ seg, int G) {
   const long long f = blockIdx.x / parts;
   const int part = blockIdx.x % parts;
+  if (part == 0 && (int)threadIdx.x < G) seg[f * G + threadIdx.x] = SegState{0u, 0u, 0, 0};  // (the split kernel is the next launch on the stream)
   const mdc_jpeg_stream_header* hd = reinterpret_cast<const mdc_jpeg_stream_header*>(streams + f * stream_stride);
   int16_t* rec = records + f * rec_i16;
   if (part == 0 && threadIdx.x < 64) reinterpret_cast<uint16_t*>(rec)[threadIdx.x] = hd->quant[threadIdx.x];
@@ -555,6 +557,8 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
   __shared__ unsigned short s_zu[kHuffThreads];
   __shared__ int s_scan[kHuffThreads / 64 + 1];
   __shared__ uint32_t s_entry[4];  // the left segment's published state: bit, zu, blocks_incl, ok
+  // (dynamic LDS, never touched: the launch asks for enough of it that a CU takes ONE workgroup while the grid has no more
+  // workgroups than the chip has CUs -- the decoder is bound by instruction issue, two workgroups sharing a CU run at half speed each)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long f = blockIdx.x / G;
   const int sg = blockIdx.x % G;
@@ -866,15 +870,22 @@ hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, voi
   const long long rec_i16 = record_bytes / 2;
   if (G > 1) {  // small batch: several workgroups per frame (d_scratch: jpeg_huffman_scratch_bytes(nframes), any content)
     SegState* seg = static_cast<SegState*>(d_scratch);
-    hipError_t e = hipMemsetAsync(seg, 0, (size_t)nframes * G * sizeof(SegState), s);
-    if (e != hipSuccess) return e;
-    jpeg_record_init_kernel<<<(unsigned)(nframes * 8), 256, 0, s>>>(st, stream_stride, rec, rec_i16, blocks_w, blocks_rows, 8);
-    jpeg_huffman_split_kernel<false><<<(unsigned)(nframes * G), kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G);
+    // one workgroup per CU while the grid fits the chip's 256 CUs (LDS padding: a CU has 160 KiB, two of these would need 2 x 88)
+    const size_t pad = nframes * G <= 256 ? 88 * 1024 : 0;
+    hipError_t e = hipSuccess;
+    if (pad) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jpeg_huffman_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+      if (e == hipSuccess && (kinds & 2u))
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jpeg_huffman_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+      if (e != hipSuccess) return e;
+    }
+    jpeg_record_init_kernel<<<(unsigned)(nframes * 8), 256, 0, s>>>(st, stream_stride, rec, rec_i16, blocks_w, blocks_rows, 8, seg, G);
+    jpeg_huffman_split_kernel<false><<<(unsigned)(nframes * G), kHuffThreads, pad, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G);
     jpeg_dc_finish_kernel<false><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G, d_status, kinds);
     if (kinds & 2u) {
       e = hipMemsetAsync(seg, 0, (size_t)nframes * G * sizeof(SegState), s);
       if (e != hipSuccess) return e;
-      jpeg_huffman_split_kernel<true><<<(unsigned)(nframes * G), kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G);
+      jpeg_huffman_split_kernel<true><<<(unsigned)(nframes * G), kHuffThreads, pad ? pad - 24 * 1024 : 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G);
       jpeg_dc_finish_kernel<true><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G, d_status, kinds);
     }
   } else {
