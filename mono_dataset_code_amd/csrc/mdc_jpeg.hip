@@ -848,8 +848,10 @@ __global__ __launch_bounds__(kIntervalThreads) void jpeg_huffman_intervals_kerne
 
 size_t jpeg_huffman_scratch_bytes(int64_t nframes) { return (size_t)nframes * kHuffMaxSegments * sizeof(SegState); }
 int jpeg_huffman_segments(int64_t nframes) {
-  // workgroups the chip holds at once: 256 CUs x 2 of 1024 threads; below that, a frame's stream is spread over several
-  return (int)std::max<int64_t>(1, std::min<int64_t>(kHuffMaxSegments, 512 / std::max<int64_t>(1, nframes)));
+  // up to 64 frames (the reader's chunk): 4 workgroups per frame, one per CU -- measured on 265-KB streams (profiles/r04_experiments/04_*):
+  // 0.80 -> 0.38 ms for one frame, 0.89 -> 0.48 for 32, 0.91 -> 0.71 for 64; from 128 frames on one workgroup per frame fills
+  // the chip and the split only adds its hand-overs (256 frames: 2.31 -> 2.51 ms)
+  return nframes <= 64 ? (int)std::max<int64_t>(1, std::min<int64_t>(kHuffMaxSegments, 256 / std::max<int64_t>(1, nframes))) : 1;
 }
 
 hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w, int h, int blocks_w,

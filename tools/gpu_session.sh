@@ -9,6 +9,7 @@
 #   bracket          tools/mall_bracket.py: the same launch with its reads served by HBM / Infinity Cache / L2
 #   ea               rocprofv3 --pmc passes (fabric read requests: total, DRAM-bound, 32 B / 64 B / 128 B, L2 hit / miss)
 #                    over tools/mall_bracket.py (one launch per variant)
+#   pmc_sq           SQ / TCC / TCP counter passes over tools/sweep.py (PMC_ARGS="--shapes 128x16 --fpb 64")
 #   launch_size      bench.py --frames 4096 / 8192 / 16384 (headline only)
 #   bench            plain `python bench.py` (the driver's command) -> bench.json
 #   pyramid_alone    bench.py --workload pyramid in its own process (against the secondary entry of `bench`)
@@ -46,6 +47,17 @@ for stage in "$@"; do
             --shapes ${SHAPES:-128x16,320x16} --rounds 1 --iters 1 > "$OUT/ea_pass$i.log" 2>&1
         done )
       python3 tools/pmc_table.py "$OUT" ea_pass > "$OUT/ea_summary.txt" 2>&1; cat "$OUT/ea_summary.txt" ;;
+    pmc_sq)
+      # SQ / TCC / TCP counter passes of one kernel configuration (each its own rocprofv3 run, --kernel-trace only): PMC_ARGS = sweep.py arguments
+      ( cd /tmp && export TMPDIR=/tmp; i=0
+        for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
+                 "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_VALU" \
+                 "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_LDS_ADDR_CONFLICT" \
+                 "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+          i=$((i+1))
+          timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/sq_pass$i" -- python "$GRAFT_REPO_ROOT/tools/sweep.py" --rounds 1 --iters 2 ${PMC_ARGS:-} > "$OUT/sq_pass$i.log" 2>&1
+        done )
+      python3 tools/pmc_table.py "$OUT" sq_pass > "$OUT/sq_summary.txt" 2>&1; tail -8 "$OUT/sq_summary.txt" ;;
     launch_size)
       for n in 4096 8192 16384; do
         timeout 300 python bench.py --frames $n --steps 60 --warmup 10 --no-cpu-baseline > "$OUT/bench_frames_$n.json" 2> "$OUT/bench_frames_$n.err"
