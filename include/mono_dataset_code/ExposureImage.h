@@ -8,7 +8,9 @@
 // csrc/host/image_pool.cpp) instead of a fresh `new float[w*h]` per frame: the GPU writes results
 // into it at PCIe rate, and a caller that deletes each image after use (as playDataset does) gets
 // the same block back for the next frame -- no page faults, no re-pinning.  Without a GPU the pool
-// hands out ordinary heap memory.
+// hands out ordinary heap memory.  Code that frees or replaces `image` itself (`delete[] img->image`,
+// legal against the reference's type) sets MDC_IMAGE_POOL=0 in the environment: the block is then a
+// plain `new float[w*h]` released with `delete[]`, as in the reference.
 #pragma once
 
 extern "C" {

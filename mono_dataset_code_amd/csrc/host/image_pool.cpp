@@ -11,8 +11,13 @@
 // chunk of results with ONE copy -- or one kernel launch writing them in place -- instead of one copy per image
 // (64 copies of 1.2 MB: 25 GB/s; one of 79 MB: 54).  It also page-locks once per slab instead of once per image
 // (~0.4 ms each).
+//
+// Opt-out: MDC_IMAGE_POOL=0 in the environment makes the block what the reference's is -- `new float[w*h]`, released with
+// `delete[]` -- for downstream code that frees or swaps `image` itself (legal against src/ExposureImage.h:42-50).  The GPU then
+// reaches the images through staging copies instead of writing them in place; same values.
 #include <algorithm>
 #include <cstddef>
+#include <cstdlib>
 #include <cstdint>
 #include <map>
 #include <mutex>
@@ -75,6 +80,14 @@ Pool& pool() {
   return *p;
 }
 
+bool pool_off() {
+  static const bool off = [] {
+    const char* e = std::getenv("MDC_IMAGE_POOL");
+    return e && e[0] == '0';
+  }();
+  return off;
+}
+
 void release(const std::vector<std::pair<float*, bool>>& drop) {
   for (const auto& d : drop) {
     if (d.second) mdc_host_free(d.first);
@@ -86,6 +99,7 @@ void release(const std::vector<std::pair<float*, bool>>& drop) {
 
 extern "C" float* mdch_image_alloc(unsigned long nfloats) {
   if (nfloats == 0) nfloats = 1;
+  if (pool_off()) return new (std::nothrow) float[nfloats];
   Pool& P = pool();
   {
     std::lock_guard<std::mutex> lk(P.mu);
@@ -132,6 +146,10 @@ extern "C" float* mdch_image_alloc(unsigned long nfloats) {
 
 extern "C" void mdch_image_free(float* b) {
   if (!b) return;
+  if (pool_off()) {  // whatever the pointer holds now is a `new float[]` block (ours, or one the caller swapped in)
+    delete[] b;
+    return;
+  }
   Pool& P = pool();
   std::vector<std::pair<float*, bool>> drop;
   {

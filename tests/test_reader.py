@@ -315,10 +315,12 @@ def test_gpu_huffman_stage_random_files():
     ctx = capi.Context(0)
     st = torch.cuda.current_stream().cuda_stream
     checked = 0
-    for trial in range(30):
+    for trial in range(32):
         h, w = int(rng.integers(1, 98)), int(rng.integers(1, 132))
+        if trial >= 30:  # ... and the sizes sequences really have: every flavour once more at 640 x 480 and 1280 x 1024
+            h, w = ((480, 640), (1024, 1280))[trial - 30]
         files = []
-        for k in range(10):
+        for k in range(10 if trial < 30 else 4):
             kind = int(rng.integers(0, 6))
             if kind == 0:
                 img = np.full((h, w), int(rng.integers(0, 256)), np.uint8)
@@ -334,7 +336,7 @@ def test_gpu_huffman_stage_random_files():
             else:
                 img = np.clip(rng.normal(128, float(rng.integers(1, 90)), (h, w)), 0, 255).astype(np.uint8)
             kw = {"quality": int(rng.integers(1, 101)), "optimize": bool(rng.integers(0, 2))}
-            flavour = int(rng.integers(0, 4))  # plain / restart intervals / YCbCr / both
+            flavour = int(rng.integers(0, 4)) if trial < 30 else k  # plain / restart intervals / YCbCr / both
             if flavour & 1:
                 kw["restart_marker_blocks"] = int(rng.integers(1, 12))
             if flavour & 2:
@@ -365,7 +367,7 @@ def test_gpu_huffman_stage_random_files():
             e = want[i, 128:].view(np.int16).reshape(rows, pitch, 64)[:bh, :bw]
             assert np.array_equal(g, e), (trial, i, h, w, len(files[i]))
             checked += 1
-    assert checked == 300
+    assert checked == 308
 
 
 def test_get_image_results_made_ahead_on_jpeg_sequences(tmp_path):

@@ -358,3 +358,39 @@ def test_get_image_raw_internal_is_there_for_opencv_callers(tmp_path):
     assert len(rows) == 5
     for i, r in enumerate(rows):
         assert [int(x) for x in r[1:]] == [i, 48, 64, 0, int(frames[i].astype(np.uint64).sum())]
+
+
+def test_exposure_image_pool_opt_out():
+    """MDC_IMAGE_POOL=0: ExposureImage::image is the reference's `new float[w*h]` (src/ExposureImage.h:45,49) -- nothing is kept
+    by the pool after a free, and a block the caller swapped in (`new float[]` of its own) is released by the destructor."""
+    import subprocess
+    import sys
+
+    code = r"""
+import ctypes, os, sys
+sys.path.insert(0, %r)
+from mono_dataset_code_amd import capi
+L = capi.host_lib()
+L.mdch_image_alloc.restype = ctypes.c_void_p
+L.mdch_image_alloc.argtypes = [ctypes.c_ulong]
+L.mdch_image_free.argtypes = [ctypes.c_void_p]
+L.mdch_image_pool_idle_bytes.restype = ctypes.c_size_t
+a = L.mdch_image_alloc(640 * 480)
+b = L.mdch_image_alloc(640 * 480)
+assert a and b and a != b
+ctypes.memset(a, 0x11, 640 * 480 * 4)
+L.mdch_image_free(a)
+L.mdch_image_free(b)
+print("idle", L.mdch_image_pool_idle_bytes())
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env, want_idle in (({"MDC_IMAGE_POOL": "0"}, "idle 0"), ({}, None)):
+        e = dict(os.environ)
+        e.pop("MDC_IMAGE_POOL", None)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("idle")][-1]
+        if want_idle:
+            assert line == want_idle
+        else:
+            assert int(line.split()[1]) >= 2 * 640 * 480 * 4  # the pool keeps freed blocks for the next images
