@@ -133,6 +133,41 @@ def test_reader_shards_getimages_over_devices(tmp_path, monkeypatch):
         two.close()
 
 
+def test_reader_with_the_image_pool_switched_off(tmp_path):
+    """MDC_IMAGE_POOL=0 (ExposureImage::image = new float[], the reference's own allocation): getImage / getImages give the same
+    images; the GPU reaches them through staging copies instead of writing page-locked slabs in place."""
+    import subprocess
+    import sys
+
+    from mono_dataset_code_amd import capi
+
+    h, w = 96, 160
+    d = str(tmp_path)
+    make_sequence(d, frames_for(70, h, w), True, "jpg")
+    r = capi.DatasetReader(d)
+    want, ok, n = r.get_images(0, 70, 1, 1, 1, 1)
+    one = r.get_image(11, 1, 1, 0, 1)
+    r.close()
+    assert n == 70 and ok.all()
+    np.save(os.path.join(d, "want.npy"), want)
+    np.save(os.path.join(d, "one.npy"), one[0])
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from mono_dataset_code_amd import capi
+r = capi.DatasetReader(%r)
+got, ok, n = r.get_images(0, 70, 1, 1, 1, 1)
+one = r.get_image(11, 1, 1, 0, 1)
+assert n == 70 and ok.all()
+want = np.load(%r); w1 = np.load(%r)
+eq = lambda a, b: np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32))
+assert eq(got, want) and eq(one[0], w1)
+print("POOL_OFF_OK")
+""" % (ROOT, d, os.path.join(d, "want.npy"), os.path.join(d, "one.npy"))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MDC_IMAGE_POOL="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0 and "POOL_OFF_OK" in p.stdout, p.stderr[-2000:]
+
+
 def parse(path):
     raw = open(path, "rb").read()
     pos, recs = 0, []
