@@ -221,7 +221,10 @@ struct DatasetReader::State {
     for (size_t i = 0; i < devs.size(); i++)
       for (size_t j = i + 1; j < devs.size(); j++)
         if (devs[i] == devs[j]) distinct = false;
-    if (distinct && load_multi()) {  // one RCCL broadcast of rank 0's tables
+    // (MDC_READER_FORCE_RCCL=1: take the RCCL path for a single listed device too -- a world of one --, so that a one-GPU box
+    // executes the dlopen, the communicator set-up, the broadcast and the lanes on libmdc_multi's contexts)
+    const bool force_rccl = std::getenv("MDC_READER_FORCE_RCCL") != 0 && devs.size() == 1;
+    if ((distinct || force_rccl) && load_multi()) {  // one RCCL broadcast of rank 0's tables
       void* m = 0;
       if (mapi.create(devs.data(), (int)devs.size(), &m) == MDC_OK && m) {
         mdc_ctx* root = mapi.ctx(m, 0);

@@ -133,6 +133,35 @@ def test_reader_shards_getimages_over_devices(tmp_path, monkeypatch):
         two.close()
 
 
+def test_reader_lanes_on_libmdc_multi_contexts(tmp_path, monkeypatch, capfd):
+    """The reader's multi-device set-up as it runs with distinct devices -- libmdc_multi.so found next to libmdc_host.so and
+    dlopen'ed, one communicator per device, rank 0's tables out in one RCCL broadcast, the lanes on libmdc_multi's contexts --
+    executed on the test box's one GPU with a world of one (MDC_READER_FORCE_RCCL=1): same images as the plain reader."""
+    from mono_dataset_code_amd import capi
+
+    h, w = 96, 160
+    d = str(tmp_path)
+    make_sequence(d, frames_for(40, h, w), True, "jpg")
+    plain = capi.DatasetReader(d)
+    monkeypatch.setenv("MDC_DEVICES", "0")
+    monkeypatch.setenv("MDC_READER_FORCE_RCCL", "1")
+    capfd.readouterr()
+    rccl = capi.DatasetReader(d)
+    ctypes.CDLL(None).fflush(None)
+    out = capfd.readouterr().out
+    monkeypatch.delenv("MDC_DEVICES")
+    monkeypatch.delenv("MDC_READER_FORCE_RCCL")
+    assert "calibration tables broadcast over RCCL" in out, out[-800:]
+    a, oka, na = plain.get_images(0, 40, 1, 1, 1, 1)
+    b, okb, nb = rccl.get_images(0, 40, 1, 1, 1, 1)
+    assert na == nb == 40 and oka.all() and okb.all() and bits_equal(a, b)
+    x, y = plain.get_image(7, 0, 1, 1, 0), rccl.get_image(7, 0, 1, 1, 0)
+    assert x[1:] == y[1:] and bits_equal(x[0], y[0])
+    assert rccl.device_stats()[0][0] == 0
+    plain.close()
+    rccl.close()
+
+
 def test_reader_with_the_image_pool_switched_off(tmp_path):
     """MDC_IMAGE_POOL=0 (ExposureImage::image = new float[], the reference's own allocation): getImage / getImages give the same
     images; the GPU reaches them through staging copies instead of writing page-locked slabs in place."""
