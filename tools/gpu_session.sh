@@ -15,6 +15,7 @@
 #   pyramid_alone    bench.py --workload pyramid in its own process (against the secondary entry of `bench`)
 #   bench2           `python bench.py --gpus 2` without torchrun (gloo, shared GPU)
 #   profile          tools/profile_bench.sh for the four workloads (rocprofv3 --stats + FETCH_SIZE / WRITE_SIZE passes)
+#   pipe_trace       per-chunk time stamps of the JPEG-stream pipeline (upload / Huffman done / decoded / output) on a 256-frame getImages
 #   reader2          the reader's rates with two lanes on the one GPU (MDC_DEVICES=0,0)
 #   reader / dso / huffman / vcal / distort   the secondary rate tools
 set -u
@@ -88,6 +89,9 @@ PY
         timeout 600 bash tools/profile_bench.sh ${TAG}_$wl --workload $wl $extra > "$OUT/profile_$wl.txt" 2>&1
         tail -3 "$OUT/profile_$wl.txt"
       done ;;
+    pipe_trace)
+      MDC_TRACE_ENV=MDC_PIPE_TRACE=1 timeout 600 python tools/reader_trace.py 256 3 batch > "$OUT/pipe_trace.txt" 2>&1
+      grep -a "chunks, ms since" "$OUT/pipe_trace.txt" | tail -3; grep -a "READER_RATE /\|READER_RATE r" "$OUT/pipe_trace.txt" | tail -2 ;;
     reader2) MDC_DEVICES=0,0 MDC_RATE_KINDS=zip_jpg timeout 900 python tools/reader_rate.py ${N:-512} > "$OUT/reader_rates_two_lanes.txt" 2>&1; grep -av amdgpu.ids "$OUT/reader_rates_two_lanes.txt" | tail -30 ;;
     reader)  timeout 900 python tools/reader_rate.py ${N:-512} > "$OUT/reader_rates.txt" 2>&1; grep -av amdgpu.ids "$OUT/reader_rates.txt" | tail -30 ;;
     dso)     timeout 600 python tools/dso_rate.py > "$OUT/dso_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/dso_rate.txt" | tail -20 ;;
