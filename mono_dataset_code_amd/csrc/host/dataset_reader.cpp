@@ -950,10 +950,40 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
   std::vector<State::LaneRun> runs;
   runs.reserve((size_t)active);
   for (int l = 0; l < active; l++) runs.push_back(State::LaneRun(s, s.lanes[(size_t)l], first, count, C, RG, active, l, rectify, flags, out, rec));
+  // every lane runs to its end whatever happens in another one (an exception -- out of memory for a list of pointers -- ends
+  // that lane's chunks with an error, not the process: a std::thread must not be left joinable, a lane's images must not leak)
+  auto run_lane = [&runs, &s](int l) {
+    try {
+      runs[(size_t)l].run();
+    } catch (const std::exception& e) {
+      std::lock_guard<std::mutex> lk(s.err_mu);
+      s.err = std::string("getImages: lane failed: ") + e.what();
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(s.err_mu);
+      s.err = "getImages: lane failed";
+    }
+  };
   std::vector<std::thread> helpers;
-  for (int l = 1; l < active; l++) helpers.emplace_back([&runs, l] { runs[(size_t)l].run(); });
-  runs[0].run();
-  for (std::thread& t : helpers) t.join();
+  for (int l = 1; l < active; l++) {
+    try {
+      helpers.emplace_back(run_lane, l);
+    } catch (...) {  // no thread to be had: the lane's chunks run here, after lane 0's
+      helpers.emplace_back();
+    }
+  }
+  run_lane(0);
+  for (int l = 1; l < active; l++) {
+    if (helpers[(size_t)(l - 1)].joinable()) helpers[(size_t)(l - 1)].join();
+    else run_lane(l);
+  }
+  {  // `rec` dies with this call: no decode job may still point into it (a lane that ended early leaves some queued)
+    std::unique_lock<std::mutex> lk(s.mu);
+    s.cv_done.wait(lk, [&] {
+      for (const Decode& d : rec)
+        if (!d.done) return false;
+      return true;
+    });
+  }
   int produced = 0;
   for (const State::LaneRun& r : runs) produced += r.produced;
   if (trace)
