@@ -220,7 +220,14 @@ struct BitReader {
   uint32_t widx;         // next word to fetch
   uint32_t next;         // that word, already loaded (one refill ahead: the load's latency hides behind ~5 symbols)
   uint32_t last;         // index of the last word that may be read
-  __device__ __forceinline__ uint32_t word(uint32_t i) const { return __builtin_bswap32(base[min(i, last)]); }
+  // optional: words [lds_lo, lds_hi) of the stream staged in LDS (the split kernel: a segment's bytes, copied once with coalesced
+  // loads -- every refill is otherwise a 64-way divergent 4-byte load over a working set beyond the L1)
+  const uint32_t* lds = nullptr;
+  uint32_t lds_lo = 0, lds_hi = 0;
+  __device__ __forceinline__ uint32_t word(uint32_t i) const {
+    const uint32_t j = min(i, last);
+    return __builtin_bswap32((j >= lds_lo && j < lds_hi) ? lds[j - lds_lo] : base[j]);
+  }
   __device__ __forceinline__ void start(uint32_t bit) {
     widx = bit >> 5;
     const uint64_t w0 = word(widx), w1 = word(widx + 1);
@@ -550,15 +557,15 @@ __global__ __launch_bounds__(256) void jpeg_record_init_kernel(const unsigned ch
 template <bool COLOR>
 __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
                                                                           int16_t* __restrict__ records, long long rec_i16, int W, int H, int pitch,
-                                                                          int rows, SegState* __restrict__ seg, int G) {
+                                                                          int rows, SegState* __restrict__ seg, int G, uint32_t lds_stream_bytes) {
   constexpr int NT = COLOR ? 4 : 2;
   __shared__ HuffLds<NT> s_t;
   __shared__ uint32_t s_bit[kHuffThreads];
   __shared__ unsigned short s_zu[kHuffThreads];
   __shared__ int s_scan[kHuffThreads / 64 + 1];
   __shared__ uint32_t s_entry[4];  // the left segment's published state: bit, zu, blocks_incl, ok
-  // (dynamic LDS, never touched: the launch asks for enough of it that a CU takes ONE workgroup while the grid has no more
-  // workgroups than the chip has CUs -- the decoder is bound by instruction issue, two workgroups sharing a CU run at half speed each)
+  // dynamic LDS: the segment's stream words (one workgroup per CU with it)
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_stream[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long f = blockIdx.x / G;
   const int sg = blockIdx.x % G;
@@ -581,13 +588,29 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
   __syncthreads();
   const uint32_t nbits = ecs_bytes * 8u;
   const uint32_t nsub = (uint32_t)G * kHuffThreads;
-  uint32_t S = (nbits + nsub - 1) / nsub;
-  S = max(256u, (S + 31u) & ~31u);
+  // subsequences of an ODD number of 32-bit words: thread t starts at word t * sw, and an odd stride puts the 64 lanes of a
+  // wave on 64 different LDS banks
+  uint32_t sw = ((nbits + nsub - 1) / nsub + 31u) / 32u;
+  sw = max(9u, sw | 1u);
+  const uint32_t S = sw * 32u;
   const uint32_t gi = (uint32_t)sg * kHuffThreads + (uint32_t)tid;  // this thread's subsequence of the frame
   const uint32_t my0 = (uint32_t)min((unsigned long long)nbits, (unsigned long long)gi * S), my1 = min(nbits, my0 + S);
   BitReader b;
   b.base = reinterpret_cast<const uint32_t*>(st + hd->ecs_offset);
   b.last = (ecs_bytes + 3) / 4 + 2;
+  {  // the segment's words (+ a margin: a subsequence's last symbol and the reader's look-ahead run past its end) -> LDS
+    const uint32_t w0 = (uint32_t)sg * kHuffThreads * sw, want = kHuffThreads * sw + 64u;
+    const uint32_t have = min(want, b.last + 1u > w0 ? b.last + 1u - w0 : 0u);
+    if (have * 4u <= lds_stream_bytes) {
+      const i32x4* src = reinterpret_cast<const i32x4*>(b.base + w0);  // (w0 * 4 is a multiple of 16: sw * 1024 words per segment)
+      for (uint32_t i = tid; i < have / 4u; i += kHuffThreads) reinterpret_cast<i32x4*>(s_stream)[i] = src[i];
+      if ((uint32_t)tid < (have & 3u)) s_stream[(have & ~3u) + tid] = b.base[w0 + (have & ~3u) + tid];  // (never past the stream's last word)
+      b.lds = s_stream;
+      b.lds_lo = w0;
+      b.lds_hi = w0 + have;
+    }
+  }
+  __syncthreads();
   int16_t* coef = rec + 64;
   const uint32_t guess_bits = max(512u, S / MDC_EXP_GUESS_DIV);
   uint32_t in_bit = my0, out_bit = my0;
@@ -872,22 +895,25 @@ hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, voi
   const long long rec_i16 = record_bytes / 2;
   if (G > 1) {  // small batch: several workgroups per frame (d_scratch: jpeg_huffman_scratch_bytes(nframes), any content)
     SegState* seg = static_cast<SegState*>(d_scratch);
-    // one workgroup per CU while the grid fits the chip's 256 CUs (LDS padding: a CU has 160 KiB, two of these would need 2 x 88)
-    const size_t pad = nframes * G <= 256 ? 88 * 1024 : 0;
+    // dynamic LDS for a segment's stream bytes (a 265-KB stream: 70 KB per segment); a stream too long for it is read from
+    // global memory as before
+    const size_t pad = 96 * 1024;
     hipError_t e = hipSuccess;
-    if (pad) {
+    {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jpeg_huffman_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
       if (e == hipSuccess && (kinds & 2u))
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jpeg_huffman_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
       if (e != hipSuccess) return e;
     }
     jpeg_record_init_kernel<<<(unsigned)(nframes * 8), 256, 0, s>>>(st, stream_stride, rec, rec_i16, blocks_w, blocks_rows, 8, seg, G);
-    jpeg_huffman_split_kernel<false><<<(unsigned)(nframes * G), kHuffThreads, pad, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G);
+    jpeg_huffman_split_kernel<false><<<(unsigned)(nframes * G), kHuffThreads, pad, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G,
+                                                                                        (uint32_t)pad);
     jpeg_dc_finish_kernel<false><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G, d_status, kinds);
     if (kinds & 2u) {
       e = hipMemsetAsync(seg, 0, (size_t)nframes * G * sizeof(SegState), s);
       if (e != hipSuccess) return e;
-      jpeg_huffman_split_kernel<true><<<(unsigned)(nframes * G), kHuffThreads, pad ? pad - 24 * 1024 : 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G);
+      jpeg_huffman_split_kernel<true><<<(unsigned)(nframes * G), kHuffThreads, pad - 24 * 1024, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg,
+                                                                                                        G, (uint32_t)(pad - 24 * 1024));
       jpeg_dc_finish_kernel<true><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G, d_status, kinds);
     }
   } else {
