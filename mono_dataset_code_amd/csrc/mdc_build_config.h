@@ -61,9 +61,10 @@
 #define MDC_EXP_TIMING 0      // some waves print the cycles their frame loop spent per phase (tools/phase_timing.sh): right results, device printf
 #endif
 // MDC_EXP_HUFF_ROUNDS (undefined): the Huffman kernel reports its relaxation rounds in the status word's upper bits
+// MDC_EXP_HUFF_NOSTORE (undefined): the Huffman kernels' write pass stores DC terms only (what do the scattered 2-byte stores cost?)
 
 #if (MDC_EXP_SKIP_STORE || MDC_EXP_SKIP_LOAD || MDC_EXP_FAKE_COMPUTE || MDC_EXP_STRIP_NOCONVERT || MDC_EXP_STRIP_NOSAMPLE || \
-     MDC_EXP_TIMING || defined(MDC_EXP_HUFF_ROUNDS)) && !defined(MDC_DIAGNOSIS_BUILD)
+     MDC_EXP_TIMING || defined(MDC_EXP_HUFF_ROUNDS) || defined(MDC_EXP_HUFF_NOSTORE)) && !defined(MDC_DIAGNOSIS_BUILD)
 #error "a diagnosis switch (wrong results / device printf) is set: build through mono_dataset_code_amd/build.py:build_variant, which defines MDC_DIAGNOSIS_BUILD and writes to variants/"
 #endif
 
@@ -96,6 +97,9 @@ inline const char* build_flags_string() {
       MDC_CFG_ITEM(MDC_EXP_TIMING, 0),
 #ifdef MDC_EXP_HUFF_ROUNDS
       " MDC_EXP_HUFF_ROUNDS",
+#endif
+#ifdef MDC_EXP_HUFF_NOSTORE
+      " MDC_EXP_HUFF_NOSTORE",
 #endif
   };
   static const std::string joined = [] {  // thread-safe one-time initialisation

@@ -307,15 +307,49 @@ __device__ __forceinline__ int huff_symbol(BitReader& b, const HuffLds<NT>& T, i
 
 // Decodes from the state (bit, z, u) until a symbol boundary at or past `end`.  WRITE: coefficients of luma blocks [q, nluma)
 // go to the record.  Returns the exit state; *nblk += luma blocks completed; *bad set when a code is in no table.
+// Block staging (WRITE, `stage` != nullptr): the coefficients of a block this thread starts AND finishes are collected in LDS --
+// dword p of the block at stage[p * kHuffThreads] (the pointer is already offset by the thread: a wave's lanes sit on 64 different
+// banks) -- and leave as whole 16-byte rows when the block is complete: 3-4 full stores per block instead of ~12 scattered 2-byte ones
+// (the L2's partial-write rate bounded the whole decoder at ~110 k frames/s; profiles/r04_experiments/05_*).  A block that straddles
+// two subsequences is written coefficient by coefficient, as before, by both sides -- their coefficient sets are disjoint.
+constexpr int kHuffThreads = 1024;
+__device__ __forceinline__ void stage_flush_rows(uint32_t* stage, int16_t* cur, unsigned long long cmask) {
+#pragma unroll 1
+  for (int r = 0; r < 8; r++) {
+    if (!((cmask >> (8 * r)) & 0xffull)) continue;
+    i32x4 v;
+    v.x = (int)stage[(4 * r + 0) * kHuffThreads];
+    v.y = (int)stage[(4 * r + 1) * kHuffThreads];
+    v.z = (int)stage[(4 * r + 2) * kHuffThreads];
+    v.w = (int)stage[(4 * r + 3) * kHuffThreads];
+    *reinterpret_cast<i32x4*>(cur + 8 * r) = v;
+    stage[(4 * r + 0) * kHuffThreads] = 0u;
+    stage[(4 * r + 1) * kHuffThreads] = 0u;
+    stage[(4 * r + 2) * kHuffThreads] = 0u;
+    stage[(4 * r + 3) * kHuffThreads] = 0u;
+  }
+}
+__device__ __forceinline__ void stage_flush_scattered(uint32_t* stage, int16_t* cur, unsigned long long cmask) {
+  while (cmask) {  // an unfinished block at the end of the subsequence: its other coefficients are the next thread's
+    const int n = __ffsll((long long)cmask) - 1;
+    cmask &= cmask - 1;
+    int16_t* h = reinterpret_cast<int16_t*>(stage + (n >> 1) * kHuffThreads) + (n & 1);
+    cur[n] = *h;
+    *h = 0;
+  }
+}
+
 template <bool WRITE, bool COLOR, int NT>
 __device__ __forceinline__ void huff_run(BitReader& b, const HuffLds<NT>& T, uint32_t bit, int z, int u, uint32_t end, uint32_t* out_bit, int* out_z,
-                                         int* out_u, int* nblk, int* bad, int16_t* coef, int q, const ScanGeo& g) {
+                                         int* out_u, int* nblk, int* bad, int16_t* coef, int q, const ScanGeo& g, uint32_t* stage = nullptr) {
   b.start(bit);
   int done = 0;
   uint32_t p = bit;
   bool luma = !COLOR || u < g.hv;
   int16_t* cur = nullptr;
   if (WRITE && luma && q < g.nluma) cur = luma_block(coef, q, g);
+  bool staged = WRITE && stage && z == 0;  // (z != 0: the block was begun by the left neighbour)
+  unsigned long long cmask = 0;
   while (p < end) {
     b.refill();
     int v;
@@ -323,8 +357,23 @@ __device__ __forceinline__ void huff_run(BitReader& b, const HuffLds<NT>& T, uin
     const int at = huff_symbol(b, T, (COLOR && !luma) ? 2 : 0, z, &v, &wrong);
     // (past the last luma block: the padding bits, not an error; chroma symbols count like luma ones)
     if (wrong && (!WRITE || cur || (COLOR && !luma && q < g.nluma))) *bad = 1;
-    if (WRITE && cur && at >= 0) cur[c_zigzag[at]] = (int16_t)v;
+#ifdef MDC_EXP_HUFF_NOSTORE  // diagnosis (wrong results): the write pass decodes but stores only DC terms
+    if (WRITE && cur && at == 0) cur[0] = (int16_t)v;
+#else
+    if (WRITE && cur && at >= 0) {
+      const int n = c_zigzag[at];
+      if (staged) {
+        reinterpret_cast<int16_t*>(stage + (n >> 1) * kHuffThreads)[n & 1] = (int16_t)v;
+        cmask |= 1ull << n;
+      } else {
+        cur[n] = (int16_t)v;
+      }
+    }
+#endif
     if (z >= 64) {
+      if (WRITE && staged && cur && cmask) stage_flush_rows(stage, cur, cmask);
+      staged = WRITE && stage;
+      cmask = 0;
       z = 0;
       if (luma) {
         done++;
@@ -345,13 +394,12 @@ __device__ __forceinline__ void huff_run(BitReader& b, const HuffLds<NT>& T, uin
       p = np;
     }
   }
+  if (WRITE && staged && cur && cmask) stage_flush_scattered(stage, cur, cmask);
   *out_bit = p;
   *out_z = z;
   *out_u = u;
   *nblk += done;
 }
-
-constexpr int kHuffThreads = 1024;
 
 // tables -> LDS (NT of them: luma pair in the header, chroma pair right behind it)
 template <int NT, int THREADS>
@@ -375,13 +423,14 @@ __device__ __forceinline__ void init_record(int16_t* rec, const mdc_jpeg_stream_
 template <bool COLOR>
 __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
                                                                     int16_t* __restrict__ records, long long rec_i16, int W, int H, int pitch,
-                                                                    int rows, int* __restrict__ status, unsigned kinds) {
+                                                                    int rows, int* __restrict__ status, unsigned kinds, uint32_t stage_bytes) {
   constexpr int NT = COLOR ? 4 : 2;
   __shared__ HuffLds<NT> s_t;
   __shared__ uint32_t s_bit[kHuffThreads];
   __shared__ unsigned short s_zu[kHuffThreads];  // z | u << 8
   __shared__ int s_scan[kHuffThreads / 64 + 1];
   __shared__ int s_flag;
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // block staging of the write pass (stage_bytes of it, or none)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long f = blockIdx.x;
   const unsigned char* st = streams + f * stream_stride;
@@ -399,6 +448,11 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
   const uint32_t ecs_bytes = hd->ecs_bytes;
   load_tables<NT, kHuffThreads>(s_t, hd, tid);
   init_record<kHuffThreads>(rec, hd, pitch, rows, tid);
+  uint32_t* stage = nullptr;
+  if (stage_bytes >= 32u * kHuffThreads * 4u) {
+    stage = s_dyn + tid;
+    for (int k = 0; k < 32; k++) stage[k * kHuffThreads] = 0u;
+  }
   if (tid == 0) s_flag = 0;
   __syncthreads();
   const uint32_t nbits = ecs_bytes * 8u;
@@ -476,7 +530,7 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
   if (in_bit < my1) {
     int dummy = 0, oz, ou;
     uint32_t ob;
-    huff_run<true, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bad_w, coef, first, g);
+    huff_run<true, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bad_w, coef, first, g, stage);
   }
   // fewer blocks than the frame has: truncated or damaged.  More: the 1..7 padding bits after the last block can parse as
   // another (short-coded) block; those are never written.
@@ -564,7 +618,8 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
   __shared__ unsigned short s_zu[kHuffThreads];
   __shared__ int s_scan[kHuffThreads / 64 + 1];
   __shared__ uint32_t s_entry[4];  // the left segment's published state: bit, zu, blocks_incl, ok
-  // dynamic LDS: the segment's stream words (one workgroup per CU with it)
+  // dynamic LDS: block staging of the write pass (one component: 128 KB), or the segment's stream words (three components: the
+  // four tables leave no room for the blocks) -- one workgroup per CU either way
   extern __shared__ __attribute__((aligned(16))) uint32_t s_stream[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long f = blockIdx.x / G;
@@ -585,6 +640,11 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
   const ScanGeo g = scan_geo(hd, W, H, pitch);
   const uint32_t ecs_bytes = hd->ecs_bytes;
   load_tables<NT, kHuffThreads>(s_t, hd, tid);
+  uint32_t* stage = nullptr;
+  if (!COLOR && lds_stream_bytes >= 32u * kHuffThreads * 4u) {
+    stage = s_stream + tid;
+    for (int k = 0; k < 32; k++) stage[k * kHuffThreads] = 0u;
+  }
   __syncthreads();
   const uint32_t nbits = ecs_bytes * 8u;
   const uint32_t nsub = (uint32_t)G * kHuffThreads;
@@ -601,7 +661,7 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
   {  // the segment's words (+ a margin: a subsequence's last symbol and the reader's look-ahead run past its end) -> LDS
     const uint32_t w0 = (uint32_t)sg * kHuffThreads * sw, want = kHuffThreads * sw + 64u;
     const uint32_t have = min(want, b.last + 1u > w0 ? b.last + 1u - w0 : 0u);
-    if (have * 4u <= lds_stream_bytes) {
+    if (COLOR && have * 4u <= lds_stream_bytes) {
       const i32x4* src = reinterpret_cast<const i32x4*>(b.base + w0);  // (w0 * 4 is a multiple of 16: sw * 1024 words per segment)
       for (uint32_t i = tid; i < have / 4u; i += kHuffThreads) reinterpret_cast<i32x4*>(s_stream)[i] = src[i];
       if ((uint32_t)tid < (have & 3u)) s_stream[(have & ~3u) + tid] = b.base[w0 + (have & ~3u) + tid];  // (never past the stream's last word)
@@ -716,7 +776,7 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
   if (entry_ok && in_bit < my1) {
     int dummy = 0, oz, ou;
     uint32_t ob;
-    huff_run<true, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bad_w, coef, first, g);
+    huff_run<true, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bad_w, coef, first, g, stage);
   }
   if (__syncthreads_or(bad_w) && tid == 0) atomicOr(&my_seg->flag, 2);
 }
@@ -895,14 +955,14 @@ hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, voi
   const long long rec_i16 = record_bytes / 2;
   if (G > 1) {  // small batch: several workgroups per frame (d_scratch: jpeg_huffman_scratch_bytes(nframes), any content)
     SegState* seg = static_cast<SegState*>(d_scratch);
-    // dynamic LDS for a segment's stream bytes (a 265-KB stream: 70 KB per segment); a stream too long for it is read from
-    // global memory as before
-    const size_t pad = 96 * 1024;
+    // dynamic LDS: one component -- 128 KB of block staging for the write pass; three components -- 72 KB for the segment's stream
+    // bytes (a stream too long for it is read from global memory)
+    const size_t pad = 128 * 1024;
     hipError_t e = hipSuccess;
     {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jpeg_huffman_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
       if (e == hipSuccess && (kinds & 2u))
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jpeg_huffman_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jpeg_huffman_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
       if (e != hipSuccess) return e;
     }
     jpeg_record_init_kernel<<<(unsigned)(nframes * 8), 256, 0, s>>>(st, stream_stride, rec, rec_i16, blocks_w, blocks_rows, 8, seg, G);
@@ -912,13 +972,18 @@ hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, voi
     if (kinds & 2u) {
       e = hipMemsetAsync(seg, 0, (size_t)nframes * G * sizeof(SegState), s);
       if (e != hipSuccess) return e;
-      jpeg_huffman_split_kernel<true><<<(unsigned)(nframes * G), kHuffThreads, pad - 24 * 1024, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg,
-                                                                                                        G, (uint32_t)(pad - 24 * 1024));
+      jpeg_huffman_split_kernel<true><<<(unsigned)(nframes * G), kHuffThreads, 72 * 1024, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G,
+                                                                                                 (uint32_t)(72 * 1024));
       jpeg_dc_finish_kernel<true><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G, d_status, kinds);
     }
   } else {
-    jpeg_huffman_kernel<false><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, d_status, kinds);
-    if (kinds & 2u) jpeg_huffman_kernel<true><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, d_status, kinds);
+    const size_t stage = 128 * 1024;  // block staging of the one-component kernel's write pass (one workgroup per CU)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jpeg_huffman_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage);
+    if (e != hipSuccess) return e;
+    jpeg_huffman_kernel<false><<<(unsigned)nframes, kHuffThreads, stage, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, d_status, kinds,
+                                                                              (uint32_t)stage);
+    if (kinds & 2u)
+      jpeg_huffman_kernel<true><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, d_status, kinds, 0u);
   }
   if (kinds & 4u)
     jpeg_huffman_intervals_kernel<<<(unsigned)nframes, kIntervalThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, d_status);
