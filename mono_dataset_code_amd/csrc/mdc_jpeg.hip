@@ -611,7 +611,8 @@ __global__ __launch_bounds__(256) void jpeg_record_init_kernel(const unsigned ch
 template <bool COLOR>
 __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
                                                                           int16_t* __restrict__ records, long long rec_i16, int W, int H, int pitch,
-                                                                          int rows, SegState* __restrict__ seg, int G, uint32_t lds_stream_bytes) {
+                                                                          int rows, SegState* __restrict__ seg, int G, uint32_t lds_stream_bytes,
+                                                                          int stage_blocks) {
   constexpr int NT = COLOR ? 4 : 2;
   __shared__ HuffLds<NT> s_t;
   __shared__ uint32_t s_bit[kHuffThreads];
@@ -640,8 +641,11 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
   const ScanGeo g = scan_geo(hd, W, H, pitch);
   const uint32_t ecs_bytes = hd->ecs_bytes;
   load_tables<NT, kHuffThreads>(s_t, hd, tid);
+  // (the dynamic LDS holds EITHER the staged blocks of the write pass -- large grids, where the L2's partial-write rate binds -- OR
+  // the segment's stream words -- small grids, where the divergent stream loads weigh more: the launcher decides)
+  const bool block_staging = !COLOR && stage_blocks != 0 && lds_stream_bytes >= 32u * kHuffThreads * 4u;
   uint32_t* stage = nullptr;
-  if (!COLOR && lds_stream_bytes >= 32u * kHuffThreads * 4u) {
+  if (block_staging) {
     stage = s_stream + tid;
     for (int k = 0; k < 32; k++) stage[k * kHuffThreads] = 0u;
   }
@@ -661,7 +665,7 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
   {  // the segment's words (+ a margin: a subsequence's last symbol and the reader's look-ahead run past its end) -> LDS
     const uint32_t w0 = (uint32_t)sg * kHuffThreads * sw, want = kHuffThreads * sw + 64u;
     const uint32_t have = min(want, b.last + 1u > w0 ? b.last + 1u - w0 : 0u);
-    if (COLOR && have * 4u <= lds_stream_bytes) {
+    if (!block_staging && have * 4u <= lds_stream_bytes) {
       const i32x4* src = reinterpret_cast<const i32x4*>(b.base + w0);  // (w0 * 4 is a multiple of 16: sw * 1024 words per segment)
       for (uint32_t i = tid; i < have / 4u; i += kHuffThreads) reinterpret_cast<i32x4*>(s_stream)[i] = src[i];
       if ((uint32_t)tid < (have & 3u)) s_stream[(have & ~3u) + tid] = b.base[w0 + (have & ~3u) + tid];  // (never past the stream's last word)
@@ -931,10 +935,9 @@ __global__ __launch_bounds__(kIntervalThreads) void jpeg_huffman_intervals_kerne
 
 size_t jpeg_huffman_scratch_bytes(int64_t nframes) { return (size_t)nframes * kHuffMaxSegments * sizeof(SegState); }
 int jpeg_huffman_segments(int64_t nframes) {
-  // up to 64 frames (the reader's chunk): 4 workgroups per frame, one per CU -- measured on 265-KB streams (profiles/r04_experiments/04_*):
-  // 0.80 -> 0.38 ms for one frame, 0.89 -> 0.48 for 32, 0.91 -> 0.71 for 64; from 128 frames on one workgroup per frame fills
-  // the chip and the split only adds its hand-overs (256 frames: 2.31 -> 2.51 ms)
-  return nframes <= 64 ? (int)std::max<int64_t>(1, std::min<int64_t>(kHuffMaxSegments, 256 / std::max<int64_t>(1, nframes))) : 1;
+  // up to 64 frames (the reader's chunk): 4 workgroups per frame, one per CU; up to 128: 2; beyond, one workgroup per frame fills
+  // the chip (profiles/r04_experiments/04_*, 05_*)
+  return nframes <= 64 ? (int)std::max<int64_t>(1, std::min<int64_t>(kHuffMaxSegments, 256 / std::max<int64_t>(1, nframes))) : nframes <= 128 ? 2 : 1;
 }
 
 hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w, int h, int blocks_w,
@@ -955,25 +958,27 @@ hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, voi
   const long long rec_i16 = record_bytes / 2;
   if (G > 1) {  // small batch: several workgroups per frame (d_scratch: jpeg_huffman_scratch_bytes(nframes), any content)
     SegState* seg = static_cast<SegState*>(d_scratch);
-    // dynamic LDS: one component -- 128 KB of block staging for the write pass; three components -- 72 KB for the segment's stream
-    // bytes (a stream too long for it is read from global memory)
-    const size_t pad = 128 * 1024;
+    // dynamic LDS: one component, >= 48 frames -- 128 KB of block staging for the write pass (0.66 -> 0.55 ms per 64 frames; below
+    // that it costs more than it saves: 0.46 -> 0.52 ms for 32); else the segment's stream bytes (96 KB; 72 with four tables; a
+    // stream too long for it is read from global memory)
+    const int stage_blocks = nframes >= 48 ? 1 : 0;
+    const size_t pad = stage_blocks ? 128 * 1024 : 96 * 1024;
     hipError_t e = hipSuccess;
     {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jpeg_huffman_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jpeg_huffman_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
       if (e == hipSuccess && (kinds & 2u))
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jpeg_huffman_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
       if (e != hipSuccess) return e;
     }
     jpeg_record_init_kernel<<<(unsigned)(nframes * 8), 256, 0, s>>>(st, stream_stride, rec, rec_i16, blocks_w, blocks_rows, 8, seg, G);
     jpeg_huffman_split_kernel<false><<<(unsigned)(nframes * G), kHuffThreads, pad, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G,
-                                                                                        (uint32_t)pad);
+                                                                                        (uint32_t)pad, stage_blocks);
     jpeg_dc_finish_kernel<false><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G, d_status, kinds);
     if (kinds & 2u) {
       e = hipMemsetAsync(seg, 0, (size_t)nframes * G * sizeof(SegState), s);
       if (e != hipSuccess) return e;
       jpeg_huffman_split_kernel<true><<<(unsigned)(nframes * G), kHuffThreads, 72 * 1024, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G,
-                                                                                                 (uint32_t)(72 * 1024));
+                                                                                                 (uint32_t)(72 * 1024), 0);
       jpeg_dc_finish_kernel<true><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G, d_status, kinds);
     }
   } else {
