@@ -470,18 +470,20 @@ __device__ __forceinline__ void pyramid_level3(const PyramidOut& py, long long f
 #endif
 }
 
-// One staging pass: the window of the frame at `src` -> LDS buffer `win`.  R = rounds of NT chunks.
-// Lanes past the window (goff == kOutside) are masked off: they neither fetch nor write LDS, so a
-// buffer holds exactly the tile's chunks.
+// One staging pass: the window of the frame at `src` -> LDS buffer `win`.  R = rounds of NT chunks, of which this wave issues
+// the first `rw` (the rounds in which its first lane has a chunk: the chunk list is dense).  The condition is WAVE-uniform -- a
+// scalar branch, no exec-mask juggling around every load: the lanes of a wave's last, partial round that lie past the window
+// carry goff == kOutside, which the descriptor's range check answers with zeros (no memory traffic), written behind the window's
+// last chunk -- still inside the buffer, whose size is a whole number of 64-chunk wave rounds (plan_source: win_bytes).
 template <int R, int NT>
 __device__ __forceinline__ void stage_window(const uint8_t* src, uint32_t in_bytes, lds_u8_ptr win,
-                                             const uint32_t (&goff)[R], int wave) {
+                                             const uint32_t (&goff)[R], int wave, int rw) {
 #if __HIP_DEVICE_COMPILE__
   const auto ri = MDC_FRAME_RSRC(src, in_bytes);
 #pragma unroll
   for (int k = 0; k < R; k++)
-    if (goff[k] != kOutside) {
-      MDC_CHECK(goff[k] + 16u <= in_bytes && (goff[k] & 15u) == 0);
+    if (k < rw) {
+      MDC_CHECK(goff[k] == kOutside || (goff[k] + 16u <= in_bytes && (goff[k] & 15u) == 0));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (lds_void_ptr)(win + (k * NT + wave * 64) * 16), 16, goff[k], 0,
                                                0, kLoadAux);
     }
@@ -539,6 +541,11 @@ __device__ __forceinline__ void frame_wait_only(int rw) {
 #endif
 template <int D, int R, int S = 4>
 __device__ __forceinline__ void frame_barrier(int rw) {
+  if constexpr (D == 1) {  // two buffers: the allowance does not depend on rw -- ONE barrier, not a branch maze around five copies of it
+    (void)rw;
+    wait_vm_barrier<S>();
+    return;
+  }
   if (R >= 4 && rw >= 4) wait_vm_barrier<(D - 1) * (4 + S) + S>();
   else if (R >= 3 && rw == 3) wait_vm_barrier<(D - 1) * (3 + S) + S>();
   else if (R >= 2 && rw == 2) wait_vm_barrier<(D - 1) * (2 + S) + S>();
@@ -573,9 +580,9 @@ __device__ __forceinline__ void tile_frames(const TileThread<RPT>& t, const uint
 #pragma unroll
   for (int d = 0; d < D; d++) {
 #if MDC_EXP_SKIP_LOAD
-    stage_window<R, NT>(src, in_bytes, w[d], goff, wave);
+    stage_window<R, NT>(src, in_bytes, w[d], goff, wave, rw);
 #else
-    stage_window<R, NT>(src + min(d, last) * in_step, in_bytes, w[d], goff, wave);
+    stage_window<R, NT>(src + min(d, last) * in_step, in_bytes, w[d], goff, wave, rw);
 #endif
   }
   // frame 0 landed: only the D-1 later DMA groups may still be in flight
@@ -596,6 +603,9 @@ __device__ __forceinline__ void tile_frames(const TileThread<RPT>& t, const uint
   unsigned long long tp[4] = {0, 0, 0, 0};
   const unsigned long long t_begin = exp_now();
 #endif
+  // the frame staged in iteration f is frame min(f + D, last): a running pointer (one scalar add per frame) instead of a 64-bit
+  // multiply per frame
+  const uint8_t* stg = src + (long long)min(D, last) * in_step;
   for (int f = 0; f <= last; f++) {
 #if MDC_EXP_TIMING
     const unsigned long long t0 = exp_now();
@@ -603,9 +613,10 @@ __device__ __forceinline__ void tile_frames(const TileThread<RPT>& t, const uint
     if (PYR && f > 0)
       pyramid_level3<G, TW>(py, f_first + (long long)(f - 1) * fstep, l3_bytes, s_pyr + ((f - 1) & 1) * G * L2W, p3byte, tid - (NT - 64));
 #if MDC_EXP_SKIP_LOAD
-    stage_window<R, NT>(src, in_bytes, w[D], goff, wave);
+    stage_window<R, NT>(src, in_bytes, w[D], goff, wave, rw);
 #else
-    stage_window<R, NT>(src + min(f + D, last) * in_step, in_bytes, w[D], goff, wave);
+    stage_window<R, NT>(stg, in_bytes, w[D], goff, wave, rw);
+    if (f + D < last) stg += in_step;
 #endif
 #if MDC_EXP_TIMING
     const unsigned long long t1 = exp_now();
