@@ -296,7 +296,7 @@ constexpr int kLoadAux = 0;
   __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(base)), 0, (int)(bytes), (int)kRsrcWord3)
 
 // Per-thread, frame-invariant state.  The 1024-/960-thread tiles must fit 64 VGPRs (two workgroups per
-// CU): their instantiations are LEAN -- the two tap offsets stay packed in one register (unpacked per
+// CU): their instantiations -- all but the plain two-buffer one (no black outputs, no pyramid, u8 frames), which fits as it is -- are LEAN -- the two tap offsets stay packed in one register (unpacked per
 // frame, +2 VALU per output) and only the first row's output offset is kept, rows 1..3 add the row pitch
 // (rows below the image then lie beyond the frame's descriptor range and are dropped like kOutside).
 constexpr uint32_t kOutsideLean = 0xc0000000u;  // + 3 row pitches still beyond any frame the plan accepts
@@ -592,7 +592,7 @@ __device__ __forceinline__ void tile_frames(const TileThread<RPT>& t, const uint
   else if (rw == 1) wait_vm_barrier<(D - 1) * 1>();
   else wait_vm_barrier<0>();
   constexpr int G = NT / TW;        // row groups of the tile (RPT output rows each; TW/64 waves side by side)
-  constexpr bool LEAN = NT >= 960 || RPT > 4;
+  constexpr bool LEAN = (NT >= 960 && (NBUF != 2 || BLACK || PYR || F32)) || RPT > 4;
   static_assert(!PYR || RPT == 4, "the fused pyramid pairs the 4 rows of a thread");
   constexpr int L2W = TW / 4;       // level-2 pixels per tile row
   float* s_pyr = (float*)(s_win + NBUF * win_bytes);  // [2][G][L2W] level-2 rows (PYR only)
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 640 ? 5 : NT == 512 ? (k
   const int row0 = (tid / TW) * RPT;
   const int ox = (tile % p.tiles_x) * TW + lane_x;
   constexpr int kTileRows = NT * RPT / TW;  // RPT output rows per thread, TW lanes per row
-  constexpr bool LEAN = NT >= 960 || RPT > 4;
+  constexpr bool LEAN = (NT >= 960 && (NBUF != 2 || BLACK || PYR || F32)) || RPT > 4;
   const int oy0 = (tile / p.tiles_x) * kTileRows + row0;
 
   // Prologue, ordered for memory-level parallelism: the workgroup's whole start-up is three dependent

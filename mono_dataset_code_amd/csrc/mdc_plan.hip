@@ -182,9 +182,11 @@ int plan_source(mdc_ctx* c, int es, int kTileW, int kTileH, mdc_ctx::SrcPlan& pl
   // workgroups per CU that two buffers permit (occupancy first, then depth), at most 4.
   const int wg_per_cu =
       std::max<int>(1, std::min<size_t>(kLdsPerCU / tiled_lds_bytes(win_bytes, 2, lut), 2048 / kTileThreads));
+  // (the 960- / 1024-thread tiles stay at two buffers unless asked otherwise: their two-buffer instantiation keeps the bilinear weights
+  // in registers -- exactly 64 VGPRs --, the three-buffer one has to redo them per frame (LEAN): 3.8 % slower, profiles/r04_experiments/06_*)
   const int nbuf_max = kTileThreads > 512 ? 3 : 4;
   int nbuf = 2;
-  while (nbuf < nbuf_max && tiled_lds_bytes(win_bytes, nbuf + 1, lut) * wg_per_cu <= kLdsPerCU) nbuf++;
+  while (kTileThreads <= 512 && nbuf < nbuf_max && tiled_lds_bytes(win_bytes, nbuf + 1, lut) * wg_per_cu <= kLdsPerCU) nbuf++;
   if (c->opt_nbuf >= 2) nbuf = std::min(c->opt_nbuf, nbuf_max);
   if (tile_rpt(kTileW, kTileH) > 4) nbuf = 3;  // the only instantiation of the 8-rows-per-thread tiles (mdc_kernels.hip: launch_tiled_buf)
   if (tiled_lds_bytes(win_bytes, nbuf, lut) > kLdsPerCU) {

@@ -99,7 +99,7 @@ def test_tiled_and_gather_kernels_agree(name, setups, oracle, torch_cuda):
         for rows, order, nbuf, cols in (((32, capi.ORDER_BANDS, 0, 64), (16, capi.ORDER_ROWS, 4, 64), (32, capi.ORDER_IDENTITY, 3, 64), (60, capi.ORDER_BANDS, 0, 64),
                                    (64, capi.ORDER_ROWS, 2, 64), (16, capi.ORDER_BANDS, 2, 64), (32, capi.ORDER_ROWS, 4, 64), (60, capi.ORDER_ROWS, 2, 64),
                                    (32, capi.ORDER_BLOCKS2D, 0, 128), (16, capi.ORDER_BANDS, 4, 128), (32, capi.ORDER_ROWS, 3, 128), (16, capi.ORDER_BLOCKS2D, 2, 128),
-                                   (32, capi.ORDER_BLOCKS2D, 2, 64))
+                                   (32, capi.ORDER_BLOCKS2D, 2, 64), (32, capi.ORDER_BANDS, 2, 128), (60, capi.ORDER_BANDS, 3, 64))
                                   if k == capi.KERNEL_TILED else ((32, capi.ORDER_BANDS, 0, 64),)):
           s.ctx.set_option(capi.OPT_TILE_COLS, cols)
           s.ctx.set_option(capi.OPT_TILE_ROWS, rows)
