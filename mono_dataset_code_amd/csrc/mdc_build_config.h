@@ -57,6 +57,9 @@
 #ifndef MDC_EXP_STRIP_NOSAMPLE
 #define MDC_EXP_STRIP_NOSAMPLE 0   // the strip kernel stores a register instead of sampling
 #endif
+#ifndef MDC_EXP_PAD_VALU
+#define MDC_EXP_PAD_VALU 0    // N dummy VALU instructions per wave and frame in the tiled kernel's loop (right results): the cost of one instruction
+#endif
 #ifndef MDC_EXP_TIMING
 #define MDC_EXP_TIMING 0      // some waves print the cycles their frame loop spent per phase (tools/phase_timing.sh): right results, device printf
 #endif
@@ -64,7 +67,7 @@
 // MDC_EXP_HUFF_NOSTORE (undefined): the Huffman kernels' write pass stores DC terms only (what do the scattered 2-byte stores cost?)
 
 #if (MDC_EXP_SKIP_STORE || MDC_EXP_SKIP_LOAD || MDC_EXP_FAKE_COMPUTE || MDC_EXP_STRIP_NOCONVERT || MDC_EXP_STRIP_NOSAMPLE || \
-     MDC_EXP_TIMING || defined(MDC_EXP_HUFF_ROUNDS) || defined(MDC_EXP_HUFF_NOSTORE)) && !defined(MDC_DIAGNOSIS_BUILD)
+     MDC_EXP_TIMING || MDC_EXP_PAD_VALU || defined(MDC_EXP_HUFF_ROUNDS) || defined(MDC_EXP_HUFF_NOSTORE)) && !defined(MDC_DIAGNOSIS_BUILD)
 #error "a diagnosis switch (wrong results / device printf) is set: build through mono_dataset_code_amd/build.py:build_variant, which defines MDC_DIAGNOSIS_BUILD and writes to variants/"
 #endif
 
@@ -95,6 +98,7 @@ inline const char* build_flags_string() {
       MDC_CFG_ITEM(MDC_EXP_STRIP_NOCONVERT, 0),
       MDC_CFG_ITEM(MDC_EXP_STRIP_NOSAMPLE, 0),
       MDC_CFG_ITEM(MDC_EXP_TIMING, 0),
+      MDC_CFG_ITEM(MDC_EXP_PAD_VALU, 0),
 #ifdef MDC_EXP_HUFF_ROUNDS
       " MDC_EXP_HUFF_ROUNDS",
 #endif

@@ -622,6 +622,13 @@ __device__ __forceinline__ void tile_frames(const TileThread<RPT>& t, const uint
     const unsigned long long t1 = exp_now();
 #endif
     float res[RPT];
+#if MDC_EXP_PAD_VALU  // diagnosis (right results): N extra VALU instructions per wave and frame -- what does one instruction of the loop cost?
+    {
+      int pad_v = tid;
+#pragma unroll
+      for (int q = 0; q < MDC_EXP_PAD_VALU; q++) asm volatile("v_add_u32 %0, %0, %0" : "+v"(pad_v));
+    }
+#endif
     tile_compute<VIG, BLACK, F32, LEAN, ((LEAN || PYR) ? 2 : 4), RPT>(t, w[0], my_lut, dst, out_bytes, row_bytes, res, win_bytes);
     if constexpr (PYR)
       pyramid_levels12(t, res, py, f_first + (long long)f * fstep, l1_bytes, l2_bytes, s_pyr + (f & 1) * G * L2W + pyr_slot,
