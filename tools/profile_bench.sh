@@ -13,6 +13,17 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --preroll-s 0.05 --no-cpu-baseline --no-ceiling --no-secondary $*"
+# The tuner's trial launches (3 shapes x 4 frames-per-workgroup settings) would be averaged into the per-kernel statistics: pick the
+# plan first, unprofiled, then profile a run that is told that plan and launches nothing else.
+PLAN=$($BENCH --steps 2 --warmup 1 2> /dev/null | python3 -c "
+import json, sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        p = json.loads(l)['config']['plan']
+        if isinstance(p, dict): print('--tile-cols %d --tile-rows %d --fpb %d' % (p['tile'][0], p['tile'][1], p['frames_per_workgroup']))
+")
+BENCH="$BENCH $PLAN"
+echo "profiled command: $BENCH" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/bench_under_profiler.json 2> $OUT/stats.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $BENCH > /dev/null 2> $OUT/fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $BENCH > /dev/null 2> $OUT/write.log
