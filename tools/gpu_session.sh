@@ -16,6 +16,7 @@
 #   bench2           `python bench.py --gpus 2` without torchrun (gloo, shared GPU)
 #   profile          tools/profile_bench.sh for the four workloads (rocprofv3 --stats + FETCH_SIZE / WRITE_SIZE passes)
 #   pipe_trace       per-chunk time stamps of the JPEG-stream pipeline (upload / Huffman done / decoded / output) on a 256-frame getImages
+#   soak             reader soak (one lane, two lanes), tiled-kernel soak, 8-thread soak
 #   reader2          the reader's rates with two lanes on the one GPU (MDC_DEVICES=0,0)
 #   reader / dso / huffman / vcal / distort   the secondary rate tools
 set -u
@@ -92,6 +93,11 @@ PY
     pipe_trace)
       MDC_TRACE_ENV=MDC_PIPE_TRACE=1 timeout 600 python tools/reader_trace.py 256 3 batch > "$OUT/pipe_trace.txt" 2>&1
       grep -a "chunks, ms since" "$OUT/pipe_trace.txt" | tail -3; grep -a "READER_RATE /\|READER_RATE r" "$OUT/pipe_trace.txt" | tail -2 ;;
+    soak)
+      timeout 200 python tools/reader_soak.py ${SOAK_S:-40} 1 > "$OUT/reader_soak.txt" 2>&1; grep -av amdgpu.ids "$OUT/reader_soak.txt" | tail -3
+      MDC_DEVICES=0,0 timeout 200 python tools/reader_soak.py ${SOAK_S:-40} 2 > "$OUT/reader_soak_two_lanes.txt" 2>&1; grep -av amdgpu.ids "$OUT/reader_soak_two_lanes.txt" | tail -3
+      timeout 300 python tools/soak.py 60 > "$OUT/soak.txt" 2>&1; tail -2 "$OUT/soak.txt"
+      timeout 400 bash tools/soak_threads.sh 800 > "$OUT/thread_soak.txt" 2>&1; tail -4 "$OUT/thread_soak.txt" ;;
     reader2) MDC_DEVICES=0,0 MDC_RATE_KINDS=zip_jpg timeout 900 python tools/reader_rate.py ${N:-512} > "$OUT/reader_rates_two_lanes.txt" 2>&1; grep -av amdgpu.ids "$OUT/reader_rates_two_lanes.txt" | tail -30 ;;
     reader)  timeout 900 python tools/reader_rate.py ${N:-512} > "$OUT/reader_rates.txt" 2>&1; grep -av amdgpu.ids "$OUT/reader_rates.txt" | tail -30 ;;
     dso)     timeout 600 python tools/dso_rate.py > "$OUT/dso_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/dso_rate.txt" | tail -20 ;;
