@@ -7,7 +7,7 @@
 //
 // Blocks are carved out of SLABS -- one page-locked allocation holding up to 64 images back to back -- and the
 // lowest free address is handed out first: the images a getImages call makes one after the other lie back to
-// back in memory, which is what lets the pipelined GPU call (csrc/mdc_capi.hip process_frames_pipeline) move a whole
+// back in memory, which is what lets the pipelined GPU call (csrc/mdc_pipeline.hip) move a whole
 // chunk of results with ONE copy -- or one kernel launch writing them in place -- instead of one copy per image
 // (64 copies of 1.2 MB: 25 GB/s; one of 79 MB: 54).  It also page-locks once per slab instead of once per image
 // (~0.4 ms each).

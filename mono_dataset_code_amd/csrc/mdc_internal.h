@@ -1,4 +1,4 @@
-// Internal interface between the C-ABI layer (mdc_capi.hip) and the gfx950
+// Internal interface between the C-ABI layer (mdc_capi.hip, mdc_plan.hip, mdc_host_calls.hip, mdc_pipeline.hip) and the gfx950
 // kernels (mdc_kernels.hip).  Not installed; see include/mdc_hip.h for the ABI.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -38,7 +38,7 @@ struct RemapArgs {
   int in_w, in_h, out_w, out_h;
 };
 
-// Plan of the tiled kernel for one remap (built on the host by plan_tiles, mdc_capi.hip).
+// Plan of the tiled kernel for one remap (built on the host by plan_tiles, mdc_plan.hip).
 // The source window of an output tile is the exact set of raw-frame bytes its bilinear taps
 // touch, row by row: for every source row the run [x0, x0 + 16 n) of aligned 16-byte chunks
 // covering the taps of that row (x0 % 16 == 0).  Chunks are numbered row by row; chunk c is
