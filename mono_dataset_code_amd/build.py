@@ -180,12 +180,19 @@ def build_debug():
     return build_variant("debug", ["MDC_DEBUG_BOUNDS=1"])
 
 
+def build_fault_injection():
+    """libmdc_hip with MDC_EXP_HUFF_BAD_PROVISIONAL: the split Huffman kernel's segments publish wrong provisional exit states, so every
+    right neighbour takes the path that relaxes a third time from the final state (tests/test_reader.py); right results, slower."""
+    return build_variant("badprov", ["MDC_EXP_HUFF_BAD_PROVISIONAL=1"])
+
+
 def build_all(force=False):
     build_hip(force)
     build_host(force)
     build_multi(force)
     build_bench(force)
     build_debug()
+    build_fault_injection()
     return LIB_HIP, LIB_HOST, LIB_MULTI
 
 

@@ -34,6 +34,12 @@
 #ifndef MDC_EXP_GUESS_DIV
 #define MDC_EXP_GUESS_DIV 4  // device Huffman decoder: the first guess decodes the last 1/4 of the left neighbour's subsequence
 #endif
+#ifndef MDC_EXP_HUFF_MAX_SEGMENTS
+#define MDC_EXP_HUFF_MAX_SEGMENTS 8  // device Huffman decoder, small batches: workgroups per frame at most (8 up to 32 frames, 4 up to 64, 2 up to 128)
+#endif
+#ifndef MDC_EXP_HUFF_PROVISIONAL
+#define MDC_EXP_HUFF_PROVISIONAL 1  // ... segments hand on a provisional exit state first (0: the final one only, one relaxation after the other down the chain)
+#endif
 // MDC_EXP_STORE_AUX (undefined = follow MDC_EXP_STORE_NT): raw cache-policy bits of the output stores
 
 // ---- debug -------------------------------------------------------------------------------------------------------
@@ -64,10 +70,12 @@
 #define MDC_EXP_TIMING 0      // some waves print the cycles their frame loop spent per phase (tools/phase_timing.sh): right results, device printf
 #endif
 // MDC_EXP_HUFF_ROUNDS (undefined): the Huffman kernel reports its relaxation rounds in the status word's upper bits
+// MDC_EXP_HUFF_VERIFY (undefined): the split Huffman kernel re-decodes every subsequence before the write pass and counts disagreements into the status word
+// MDC_EXP_HUFF_BAD_PROVISIONAL (undefined): fault injection -- the split Huffman kernel publishes wrong provisional states (right results, slower)
 // MDC_EXP_HUFF_NOSTORE (undefined): the Huffman kernels' write pass stores DC terms only (what do the scattered 2-byte stores cost?)
 
 #if (MDC_EXP_SKIP_STORE || MDC_EXP_SKIP_LOAD || MDC_EXP_FAKE_COMPUTE || MDC_EXP_STRIP_NOCONVERT || MDC_EXP_STRIP_NOSAMPLE || \
-     MDC_EXP_TIMING || MDC_EXP_PAD_VALU || defined(MDC_EXP_HUFF_ROUNDS) || defined(MDC_EXP_HUFF_NOSTORE)) && !defined(MDC_DIAGNOSIS_BUILD)
+     MDC_EXP_TIMING || MDC_EXP_PAD_VALU || defined(MDC_EXP_HUFF_ROUNDS) || defined(MDC_EXP_HUFF_NOSTORE) || defined(MDC_EXP_HUFF_VERIFY) || defined(MDC_EXP_HUFF_BAD_PROVISIONAL)) && !defined(MDC_DIAGNOSIS_BUILD)
 #error "a diagnosis switch (wrong results / device printf) is set: build through mono_dataset_code_amd/build.py:build_variant, which defines MDC_DIAGNOSIS_BUILD and writes to variants/"
 #endif
 
@@ -88,6 +96,8 @@ inline const char* build_flags_string() {
       MDC_CFG_ITEM(MDC_EXP_STRIP_LUT_REP, 8),
       MDC_CFG_ITEM(MDC_EXP_STRIP_WAVES_PER_EU, 5),
       MDC_CFG_ITEM(MDC_EXP_GUESS_DIV, 4),
+      MDC_CFG_ITEM(MDC_EXP_HUFF_MAX_SEGMENTS, 8),
+      MDC_CFG_ITEM(MDC_EXP_HUFF_PROVISIONAL, 1),
 #ifdef MDC_EXP_STORE_AUX
       " MDC_EXP_STORE_AUX=" MDC_CFG_STR(MDC_EXP_STORE_AUX),
 #endif
@@ -104,6 +114,12 @@ inline const char* build_flags_string() {
 #endif
 #ifdef MDC_EXP_HUFF_NOSTORE
       " MDC_EXP_HUFF_NOSTORE",
+#endif
+#ifdef MDC_EXP_HUFF_VERIFY
+      " MDC_EXP_HUFF_VERIFY",
+#endif
+#ifdef MDC_EXP_HUFF_BAD_PROVISIONAL
+      " MDC_EXP_HUFF_BAD_PROVISIONAL",
 #endif
   };
   static const std::string joined = [] {  // thread-safe one-time initialisation

@@ -148,9 +148,9 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const int16_t* __restric
 //    nothing changes.  Subsequence 0's entry state is exact, so after k rounds the first k are exact: the fixed point is the
 //    sequential decoder's state sequence; and because Huffman streams resynchronise after a few symbols (bit position) and
 //    every end-of-block resets z, wrong guesses heal inside one subsequence: 2-3 rounds in practice (the bound, 1024, only
-//    costs time).  Then a prefix sum over the blocks each subsequence completed gives every thread its first block, a last
-//    pass decodes once more and WRITES the coefficients (the record is zero-filled first; DC differences are written and
-//    turned into DC values by a prefix sum over the frame's blocks, as the predictor runs over all of them).
+//    costs time).  Then prefix sums over the blocks each subsequence completed and over the DC differences it met give every
+//    thread its first block and its DC predictor, and a last pass decodes once more and WRITES the coefficients (the record
+//    is zero-filled first), DC terms as final values.
 //  * jpeg_huffman_kernel<true>: three components interleaved in one scan (YCbCr baseline), no restart markers.  The same
 //    relaxation over a larger state: (bit, z, u), u = the block's position inside its MCU (hY x vY luma blocks, then Cb, then
 //    Cr), which picks the table pair; chroma symbols are decoded and dropped, luma blocks are counted and written.
@@ -218,31 +218,32 @@ struct BitReader {
   uint64_t acc;          // next bits, MSB first
   int cnt;               // valid bits in acc
   uint32_t widx;         // next word to fetch
-  uint32_t next;         // that word, already loaded (one refill ahead: the load's latency hides behind ~5 symbols)
+  uint32_t next;         // that word as loaded, bytes not yet swapped: the swap at the point of USE lets the load stay in flight until
+                         // the next refill (~5 symbols) -- swapped at once, every refill waited for its own load
   uint32_t last;         // index of the last word that may be read
   // optional: words [lds_lo, lds_hi) of the stream staged in LDS (the split kernel: a segment's bytes, copied once with coalesced
   // loads -- every refill is otherwise a 64-way divergent 4-byte load over a working set beyond the L1)
   const uint32_t* lds = nullptr;
   uint32_t lds_lo = 0, lds_hi = 0;
-  __device__ __forceinline__ uint32_t word(uint32_t i) const {
+  __device__ __forceinline__ uint32_t raw(uint32_t i) const {
     const uint32_t j = min(i, last);
-    return __builtin_bswap32((j >= lds_lo && j < lds_hi) ? lds[j - lds_lo] : base[j]);
+    return (j >= lds_lo && j < lds_hi) ? lds[j - lds_lo] : base[j];
   }
   __device__ __forceinline__ void start(uint32_t bit) {
     widx = bit >> 5;
-    const uint64_t w0 = word(widx), w1 = word(widx + 1);
+    const uint64_t w0 = __builtin_bswap32(raw(widx)), w1 = __builtin_bswap32(raw(widx + 1));
     const int sh = (int)(bit & 31);
     acc = (w0 << 32 | w1) << sh;
     cnt = 64 - sh;
     widx += 2;
-    next = word(widx);
+    next = raw(widx);
   }
   __device__ __forceinline__ void refill() {  // afterwards cnt > 32
     if (cnt <= 32) {
-      acc |= (uint64_t)next << (32 - cnt);
+      acc |= (uint64_t)__builtin_bswap32(next) << (32 - cnt);
       cnt += 32;
       widx++;
-      next = word(widx);
+      next = raw(widx);
     }
   }
   __device__ __forceinline__ uint32_t pos() const { return widx * 32u - (uint32_t)cnt; }
@@ -263,50 +264,39 @@ __device__ __forceinline__ int huff_extend(int v, int t) { return v < (1 << (t -
 // One symbol at the reader's position with table pair `tab` (0 luma, 2 chroma), DC when z == 0 else AC: -> coefficient index
 // the symbol writes (0: the DC difference; -1: none) and its value; z advanced (>= 64: the block is complete); *wrong set for a
 // code no table holds, a DC category above 11 (the host decoder refuses those too) or a run past the block.
-// One code path for every symbol: the table is picked by address, one lookup of the next 11 bits gives length, run, size and
-// -- mostly -- the value; lanes of a wave are at different symbols anyway, so every branch that some lane takes costs all of them.
+// One code path for every symbol, selects instead of branches: the table is picked by address, one lookup of the next 11 bits gives
+// length, run, size and -- mostly -- the value; lanes of a wave are at different symbols anyway, so every branch that some lane takes
+// costs all of them (the branchy form of this function was ~130 instructions per symbol).  Every symbol consumes at least one bit.
 template <int NT>
 __device__ __forceinline__ int huff_symbol(BitReader& b, const HuffLds<NT>& T, int tab, int& z, int* value, bool* wrong_out) {
-  const int ac = z != 0;
-  uint32_t e = T.t1[tab + ac][b.peek(11)];
-  if ((e & 31u) == 31u) e = T.t2[tab + ac][(e >> 16) & (MDC_JPEG_HUFF_SUBTABLES - 1)][(uint32_t)(b.acc >> 48) & 31u];  // bits 11..15 of the window
+  const bool ac = z != 0;
+  uint32_t e = T.t1[tab + (ac ? 1 : 0)][b.peek(11)];
+  if ((e & 31u) == 31u) e = T.t2[tab + (ac ? 1 : 0)][(e >> 16) & (MDC_JPEG_HUFF_SUBTABLES - 1)][(uint32_t)(b.acc >> 48) & 31u];  // bits 11..15 of the window
   const int len = (int)(e & 31u), run = (int)((e >> 5) & 15u), size = (int)((e >> 9) & 15u);
-  bool wrong = len == 0 || len > 16 || (!ac && size > 11);
-  int v = 0;
-  if (wrong) {
-    b.skip(1);  // (speculative rounds run through garbage: keep moving)
-  } else if (e & (1u << 13)) {
-    b.skip(len + size);
-    v = (int)(int16_t)(e >> 16);
-  } else {
-    b.skip(len);
-    if (size) v = huff_extend(b.get(size), size);
-  }
-  int at = 0;
-  if (!ac) {
-    z = 1;
-    if (wrong) v = 0;
-  } else if (wrong) {
-    at = -1;
-  } else if (size == 0) {
-    z = run == 15 ? z + 16 : 64;  // ZRL / EOB
-    at = -1;
-  } else {
-    z += run;
-    at = z;
-    if (z > 63) {
-      wrong = true;
-      at = -1;
-    }
-    z++;
-  }
+  bool wrong = (unsigned)(len - 1) > 15u || (!ac && size > 11);
+  // the value: in the entry (short code + short value), or the `size` bits behind the code, extended
+  const uint64_t behind = b.acc << len;                       // (len <= 31)
+  const int rawv = (int)((behind >> 1) >> (63 - size));       // size 0 -> 0
+  const int half = (1 << size) >> 1;
+  const int ext = rawv < half ? rawv - (1 << size) + 1 : rawv;  // size 0 -> 0
+  int v = (e & (1u << 13)) ? (int)(int16_t)(e >> 16) : ext;
+  v = wrong ? 0 : v;
+  b.skip(wrong ? 1 : len + size);  // (speculative rounds run through garbage: keep moving)
+  const int zr = z + run;
+  const bool coef = ac && !wrong && size != 0;
+  const bool over = coef && zr > 63;
+  const int at = !ac ? 0 : (coef && !over) ? zr : -1;
+  z = !ac ? 1 : wrong ? z : size == 0 ? (run == 15 ? z + 16 : 64) : zr + 1;  // ZRL / EOB / a coefficient
   *value = v;
-  *wrong_out = wrong;
+  *wrong_out = wrong || over;
   return at;
 }
 
 // Decodes from the state (bit, z, u) until a symbol boundary at or past `end`.  WRITE: coefficients of luma blocks [q, nluma)
 // go to the record.  Returns the exit state; *nblk += luma blocks completed; *bad set when a code is in no table.
+// *dc: the luma DC predictor.  A counting pass adds the DC differences it meets (the sum over a subsequence; an exclusive prefix sum
+// over the subsequences is then every thread's predictor at its entry -- DC symbols come in block order); the write pass starts from
+// that and writes final DC values, as the sequential decoder does (no pass over the record afterwards).
 // Block staging (WRITE, `stage` != nullptr): the coefficients of a block this thread starts AND finishes are collected in LDS --
 // dword p of the block at stage[p * kHuffThreads] (the pointer is already offset by the thread: a wave's lanes sit on 64 different
 // banks) -- and leave as whole 16-byte rows when the block is complete: 3-4 full stores per block instead of ~12 scattered 2-byte ones
@@ -341,22 +331,29 @@ __device__ __forceinline__ void stage_flush_scattered(uint32_t* stage, int16_t* 
 
 template <bool WRITE, bool COLOR, int NT>
 __device__ __forceinline__ void huff_run(BitReader& b, const HuffLds<NT>& T, uint32_t bit, int z, int u, uint32_t end, uint32_t* out_bit, int* out_z,
-                                         int* out_u, int* nblk, int* bad, int16_t* coef, int q, const ScanGeo& g, uint32_t* stage = nullptr) {
+                                         int* out_u, int* nblk, int* bad, int* dc, int16_t* coef, int q, const ScanGeo& g, uint32_t* stage = nullptr) {
   b.start(bit);
   int done = 0;
   uint32_t p = bit;
-  bool luma = !COLOR || u < g.hv;
   int16_t* cur = nullptr;
-  if (WRITE && luma && q < g.nluma) cur = luma_block(coef, q, g);
+  if (WRITE && (!COLOR || u < g.hv) && q < g.nluma) cur = luma_block(coef, q, g);
   bool staged = WRITE && stage && z == 0;  // (z != 0: the block was begun by the left neighbour)
   unsigned long long cmask = 0;
   while (p < end) {
     b.refill();
+    // Luma or chroma is read off u at every symbol.  (Carried from block to block as a per-lane flag it came out wrong in some builds
+    // of the three-component split kernel -- DC terms of colour frames off from some block on, depending on unrelated lines of this
+    // function; profiles/r04_experiments/08_*.  tests/test_reader.py runs the colour cases on the product and the fault-injection build.)
+    const bool luma = !COLOR || u < g.hv;
     int v;
     bool wrong;
-    const int at = huff_symbol(b, T, (COLOR && !luma) ? 2 : 0, z, &v, &wrong);
+    const int at = huff_symbol(b, T, luma ? 0 : 2, z, &v, &wrong);
     // (past the last luma block: the padding bits, not an error; chroma symbols count like luma ones)
     if (wrong && (!WRITE || cur || (COLOR && !luma && q < g.nluma))) *bad = 1;
+    if (at == 0 && luma) {
+      *dc += v;
+      v = *dc;
+    }
 #ifdef MDC_EXP_HUFF_NOSTORE  // diagnosis (wrong results): the write pass decodes but stores only DC terms
     if (WRITE && cur && at == 0) cur[0] = (int16_t)v;
 #else
@@ -379,14 +376,11 @@ __device__ __forceinline__ void huff_run(BitReader& b, const HuffLds<NT>& T, uin
         done++;
         if (WRITE) q++;
       }
-      if (COLOR) {
-        u = u + 1 == g.nb ? 0 : u + 1;
-        luma = u < g.hv;
-      }
-      if (WRITE) cur = (luma && q < g.nluma) ? luma_block(coef, q, g) : nullptr;
+      if (COLOR) u = u + 1 == g.nb ? 0 : u + 1;
+      if (WRITE) cur = ((!COLOR || u < g.hv) && q < g.nluma) ? luma_block(coef, q, g) : nullptr;
     }
     const uint32_t np = b.pos();
-    if (np <= p) {  // a table entry of length 0 (never built by the host, but a stream may come from anywhere): keep moving
+    if (np <= p) {  // no progress: cannot happen (every symbol consumes at least one bit) -- kept as the loop's own guarantee that it ends
       if (!WRITE || cur) *bad = 1;
       b.skip(1);
       p = p + 1;
@@ -420,6 +414,42 @@ __device__ __forceinline__ void init_record(int16_t* rec, const mdc_jpeg_stream_
   for (long long i = tid; i < n16; i += THREADS) body[i] = i32x4{0, 0, 0, 0};
 }
 
+// Exclusive prefix sums of two per-thread counts over the workgroup's kHuffThreads threads, and their totals (s_scan: 2 x 17 ints)
+__device__ __forceinline__ void scan_pair(int a, int c, int* s_scan, int tid, int* ex_a, int* ex_c, int* tot_a, int* tot_c) {
+  constexpr int NW = kHuffThreads / 64;
+  const int lane = tid & 63, wave = tid >> 6;
+  int ia = a, ic = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int ua = __shfl_up(ia, d, 64), uc = __shfl_up(ic, d, 64);
+    if (lane >= d) {
+      ia += ua;
+      ic += uc;
+    }
+  }
+  __syncthreads();  // (s_scan may still be read from an earlier call)
+  if (lane == 63) {
+    s_scan[wave] = ia;
+    s_scan[NW + 1 + wave] = ic;
+  }
+  __syncthreads();
+  if (tid < 2) {
+    int* t = s_scan + tid * (NW + 1);
+    int acc = 0;
+    for (int w = 0; w < NW; w++) {
+      const int v = t[w];
+      t[w] = acc;
+      acc += v;
+    }
+    t[NW] = acc;
+  }
+  __syncthreads();
+  *ex_a = s_scan[wave] + ia - a;
+  *ex_c = s_scan[NW + 1 + wave] + ic - c;
+  *tot_a = s_scan[NW];
+  *tot_c = s_scan[2 * NW + 1];
+}
+
 template <bool COLOR>
 __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
                                                                     int16_t* __restrict__ records, long long rec_i16, int W, int H, int pitch,
@@ -428,10 +458,10 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
   __shared__ HuffLds<NT> s_t;
   __shared__ uint32_t s_bit[kHuffThreads];
   __shared__ unsigned short s_zu[kHuffThreads];  // z | u << 8
-  __shared__ int s_scan[kHuffThreads / 64 + 1];
+  __shared__ int s_scan[2 * (kHuffThreads / 64 + 1)];
   __shared__ int s_flag;
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // block staging of the write pass (stage_bytes of it, or none)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const long long f = blockIdx.x;
   const unsigned char* st = streams + f * stream_stride;
   const mdc_jpeg_stream_header* hd = reinterpret_cast<const mdc_jpeg_stream_header*>(st);
@@ -468,10 +498,10 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
   // (a quarter of a full pass; where it is wrong, the relaxation below finds out)
   const uint32_t guess_bits = max(512u, S / MDC_EXP_GUESS_DIV);  // (high qualities: ~250 bits per block, 512 bits are two blocks)
   uint32_t in_bit = my0, out_bit = my0;
-  int in_z = 0, out_z = 0, in_u = 0, out_u = 0, nblk = 0, bad = 0;
+  int in_z = 0, out_z = 0, in_u = 0, out_u = 0, nblk = 0, bad = 0, dcsum = 0;
   if (my0 < my1) {
     const uint32_t from = my1 - my0 > guess_bits ? my1 - guess_bits : my0;
-    huff_run<false, COLOR>(b, s_t, from, 0, 0, my1, &out_bit, &out_z, &out_u, &nblk, &bad, nullptr, 0, g);
+    huff_run<false, COLOR>(b, s_t, from, 0, 0, my1, &out_bit, &out_z, &out_u, &nblk, &bad, &dcsum, nullptr, 0, g);
   }
   s_bit[tid] = out_bit;
   s_zu[tid] = (unsigned short)(out_z | out_u << 8);
@@ -488,10 +518,11 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
     if (dirty) {
       nblk = 0;
       bad = 0;
+      dcsum = 0;
       out_bit = in_bit;
       out_z = in_z;
       out_u = in_u;
-      if (in_bit < my1) huff_run<false, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &out_bit, &out_z, &out_u, &nblk, &bad, nullptr, 0, g);
+      if (in_bit < my1) huff_run<false, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &out_bit, &out_z, &out_u, &nblk, &bad, &dcsum, nullptr, 0, g);
     }
     s_bit[tid] = out_bit;
     s_zu[tid] = (unsigned short)(out_z | out_u << 8);
@@ -504,67 +535,21 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
     in_u = nu;
     if (!__syncthreads_or(dirty ? 1 : 0)) break;
   }
-  // ---- first luma block of every subsequence: exclusive prefix sum of nblk
-  int incl = nblk;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int up = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += up;
-  }
-  if (lane == 63) s_scan[wave] = incl;
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int w = 0; w < kHuffThreads / 64; w++) {
-      const int v = s_scan[w];
-      s_scan[w] = acc;
-      acc += v;
-    }
-    s_scan[kHuffThreads / 64] = acc;
-  }
-  __syncthreads();
-  const int first = s_scan[wave] + incl - nblk;
-  const int total = s_scan[kHuffThreads / 64];
+  // ---- first luma block and DC predictor of every subsequence: exclusive prefix sums of the blocks completed / the DC differences met
+  int first, pred, total, total_dc;
+  scan_pair(nblk, dcsum, s_scan, tid, &first, &pred, &total, &total_dc);
+  (void)total_dc;
   // ---- write pass (the true states)
   int bad_w = 0;
   if (in_bit < my1) {
     int dummy = 0, oz, ou;
     uint32_t ob;
-    huff_run<true, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bad_w, coef, first, g, stage);
+    huff_run<true, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bad_w, &pred, coef, first, g, stage);
   }
   // fewer blocks than the frame has: truncated or damaged.  More: the 1..7 padding bits after the last block can parse as
   // another (short-coded) block; those are never written.
   if (bad_w || (tid == 0 && total < g.nluma)) s_flag = 1;  // (benign race: every writer writes 1)
   __syncthreads();
-  // ---- DC differences -> DC values: prefix sum over the frame's luma blocks in scan order
-  const int per = (g.nluma + kHuffThreads - 1) / kHuffThreads;
-  const int b0 = min(g.nluma, tid * per), b1 = min(g.nluma, b0 + per);
-  int sum = 0;
-  for (int k = b0; k < b1; k++) sum += luma_block(coef, k, g)[0];
-  int inc2 = sum;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int up = __shfl_up(inc2, d, 64);
-    if (lane >= d) inc2 += up;
-  }
-  __syncthreads();  // s_scan is reused
-  if (lane == 63) s_scan[wave] = inc2;
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int w = 0; w < kHuffThreads / 64; w++) {
-      const int v = s_scan[w];
-      s_scan[w] = acc;
-      acc += v;
-    }
-  }
-  __syncthreads();
-  int pred = s_scan[wave] + inc2 - sum;
-  for (int k = b0; k < b1; k++) {
-    int16_t* c0 = luma_block(coef, k, g);
-    pred += c0[0];
-    c0[0] = (int16_t)pred;
-  }
 #ifdef MDC_EXP_HUFF_ROUNDS  // experiment build: relaxation rounds in the status word's upper bits
   if (tid == 0) status[f] = (s_flag ? 1 : 0) | rounds << 8;
 #else
@@ -580,25 +565,30 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
 // subsequence, then takes the true one from its left neighbour's published exit state (a decoupled look-back through global
 // memory: block f G + g only ever waits for block f G + g - 1, which was dispatched before it; the wait is bounded -- if the
 // neighbour does not show up the frame is reported as not decoded and the caller's host decoder takes it) and relaxes again
-// where that changed something -- a few subsequences, Huffman streams resynchronise.  Block counts travel with the state, so
-// the write pass needs no further exchange.  Three launches: jpeg_record_init_kernel (quantisation table, zero-fill -- the
-// segments' write passes must find the whole record cleared), jpeg_huffman_split_kernel, jpeg_dc_finish_kernel (DC
-// differences -> DC values over the frame, the frame's status).
+// where that changed something -- a few subsequences, Huffman streams resynchronise.  Block counts and DC sums travel with the
+// state, so the write pass needs no further exchange.  Three launches: jpeg_record_init_kernel (quantisation table, zero-fill
+// -- the segments' write passes must find the whole record cleared), jpeg_huffman_split_kernel, jpeg_split_status_kernel (the
+// frame's status from its segments' flags).
 // ---------------------------------------------------------------------------------------------------------
 struct SegState {  // one per (frame, segment), zeroed before the launch
-  uint32_t bit;     // exit state of the segment's last subsequence
+  uint32_t bit;     // FINAL exit state of the segment's last subsequence (flag bit 0)
   uint32_t zu;
   int blocks_incl;  // luma blocks completed in segments 0..g
-  int flag;         // 0 = not yet, 1 = final; bit 1: the segment met a bad code (set after the write pass)
+  int flag;         // bit 0: final; bit 1: the segment met a bad code (set after the write pass); bit 2: no decode here; bit 3: provisional
+  uint32_t pbit;    // PROVISIONAL exit state (flag bit 3): the segment relaxed from a guessed entry state -- almost always the final one
+  uint32_t pzu;
+  int dc_incl;      // sum of the luma DC differences met in segments 0..g: the right neighbour's predictor at its entry (final, like blocks_incl)
+  uint32_t pad;
 };
-constexpr int kHuffMaxSegments = 4;
+constexpr int kHuffMaxSegments = MDC_EXP_HUFF_MAX_SEGMENTS;
+static_assert(kHuffMaxSegments == 1 || kHuffMaxSegments == 2 || kHuffMaxSegments == 4 || kHuffMaxSegments == 8, "segments per frame: a power of two up to 8");
 
 __global__ __launch_bounds__(256) void jpeg_record_init_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
                                                                int16_t* __restrict__ records, long long rec_i16, int pitch, int rows, int parts,
                                                                SegState* __restrict__ seg, int G) {
   const long long f = blockIdx.x / parts;
   const int part = blockIdx.x % parts;
-  if (part == 0 && (int)threadIdx.x < G) seg[f * G + threadIdx.x] = SegState{0u, 0u, 0, 0};  // (the split kernel is the next launch on the stream)
+  if (part == 0 && (int)threadIdx.x < G) seg[f * G + threadIdx.x] = SegState{0u, 0u, 0, 0, 0u, 0u, 0, 0u};  // (the split kernel is the next launch on the stream)
   const mdc_jpeg_stream_header* hd = reinterpret_cast<const mdc_jpeg_stream_header*>(streams + f * stream_stride);
   int16_t* rec = records + f * rec_i16;
   if (part == 0 && threadIdx.x < 64) reinterpret_cast<uint16_t*>(rec)[threadIdx.x] = hd->quant[threadIdx.x];
@@ -617,12 +607,12 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
   __shared__ HuffLds<NT> s_t;
   __shared__ uint32_t s_bit[kHuffThreads];
   __shared__ unsigned short s_zu[kHuffThreads];
-  __shared__ int s_scan[kHuffThreads / 64 + 1];
-  __shared__ uint32_t s_entry[4];  // the left segment's published state: bit, zu, blocks_incl, ok
+  __shared__ int s_scan[2 * (kHuffThreads / 64 + 1)];
+  __shared__ uint32_t s_entry[5];  // the left segment's published state: bit, zu, blocks_incl, ok | final << 1, dc_incl
   // dynamic LDS: block staging of the write pass (one component: 128 KB), or the segment's stream words (three components: the
   // four tables leave no room for the blocks) -- one workgroup per CU either way
   extern __shared__ __attribute__((aligned(16))) uint32_t s_stream[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const long long f = blockIdx.x / G;
   const int sg = blockIdx.x % G;
   const unsigned char* st = streams + f * stream_stride;
@@ -678,18 +668,22 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
   int16_t* coef = rec + 64;
   const uint32_t guess_bits = max(512u, S / MDC_EXP_GUESS_DIV);
   uint32_t in_bit = my0, out_bit = my0;
-  int in_z = 0, out_z = 0, in_u = 0, out_u = 0, nblk = 0, bad = 0;
+  int in_z = 0, out_z = 0, in_u = 0, out_u = 0, nblk = 0, bad = 0, dcsum = 0;
   if (my0 < my1) {
     const uint32_t from = my1 - my0 > guess_bits ? my1 - guess_bits : my0;
-    huff_run<false, COLOR>(b, s_t, from, 0, 0, my1, &out_bit, &out_z, &out_u, &nblk, &bad, nullptr, 0, g);
+    huff_run<false, COLOR>(b, s_t, from, 0, 0, my1, &out_bit, &out_z, &out_u, &nblk, &bad, &dcsum, nullptr, 0, g);
   }
   // entry of the segment's first subsequence: exact for segment 0, a guess (its own start, z = 0) otherwise
   uint32_t e_bit = my0;
   int e_z = 0, e_u = 0;
-  int base_blocks = 0;
+  int base_blocks = 0, base_dc = 0;
   bool entry_ok = true;
-  for (int pass = 0; pass < 2; pass++) {
-    // ---- relaxation inside the segment (pass 1: again, from the true entry state, where it changes anything)
+  // Segment g > 0 relaxes up to three times: from the guess; from its left neighbour's PROVISIONAL exit state (what that one
+  // reached from ITS guess -- published by all segments at about the same time, so these second relaxations run side by side
+  // instead of one after the other down the chain); and, only if the neighbour's final state turns out to differ from the
+  // provisional one, from that.  What travels down the chain serially is then a comparison and the block count.
+  bool have_final = sg == 0;
+  for (int pass = 0; pass < 3; pass++) {
     s_bit[tid] = out_bit;
     s_zu[tid] = (unsigned short)(out_z | out_u << 8);
     __syncthreads();
@@ -697,7 +691,7 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
     {
       const uint32_t nb = tid ? s_bit[tid - 1] : e_bit;
       const int nz = tid ? (s_zu[tid - 1] & 255) : e_z, nu = tid ? (s_zu[tid - 1] >> 8) : e_u;
-      if (pass == 1) dirty = (nb != in_bit || nz != in_z || nu != in_u) && my0 < nbits;
+      if (pass >= 1) dirty = (nb != in_bit || nz != in_z || nu != in_u) && my0 < nbits;
       in_bit = nb;
       in_z = nz;
       in_u = nu;
@@ -707,10 +701,11 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
       if (dirty) {
         nblk = 0;
         bad = 0;
+        dcsum = 0;
         out_bit = in_bit;
         out_z = in_z;
         out_u = in_u;
-        if (in_bit < my1) huff_run<false, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &out_bit, &out_z, &out_u, &nblk, &bad, nullptr, 0, g);
+        if (in_bit < my1) huff_run<false, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &out_bit, &out_z, &out_u, &nblk, &bad, &dcsum, nullptr, 0, g);
       }
       s_bit[tid] = out_bit;
       s_zu[tid] = (unsigned short)(out_z | out_u << 8);
@@ -723,115 +718,120 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
       in_u = nu;
       if (!__syncthreads_or(dirty ? 1 : 0)) break;
     }
-    if (pass == 1 || sg == 0) break;
-    // ---- the true entry state: the left segment's final exit state (bounded wait)
+    if (have_final) break;
+    if (MDC_EXP_HUFF_PROVISIONAL && pass == 0 && tid == kHuffThreads - 1) {  // provisional exit state for the right neighbour
+#ifdef MDC_EXP_HUFF_BAD_PROVISIONAL  // fault injection: every provisional state is wrong -- the right neighbour must relax a third time
+      my_seg->pbit = out_bit + 9u;
+#else
+      my_seg->pbit = out_bit;
+#endif
+      my_seg->pzu = (uint32_t)(out_z | out_u << 8);
+      __threadfence();
+      __hip_atomic_fetch_or(&my_seg->flag, 8, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- the left segment's exit state: provisional or final after the first relaxation, final after the second (bounded waits)
     if (tid == 0) {
       const SegState* left = my_seg - 1;
+      const int want = (MDC_EXP_HUFF_PROVISIONAL && pass == 0) ? (1 | 8) : 1;
       int fl = 0;
       for (int spin = 0; spin < (1 << 20); spin++) {
         fl = __hip_atomic_load(&left->flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        if (fl & 1) break;
+        if (fl & want) break;
         __builtin_amdgcn_s_sleep(8);
       }
-      s_entry[3] = (fl & 1) && !(fl & 4);
-      s_entry[0] = __hip_atomic_load(&left->bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_entry[1] = __hip_atomic_load(&left->zu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_entry[2] = (uint32_t)__hip_atomic_load(&left->blocks_incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool fin = (fl & 1) != 0;
+      s_entry[3] = (uint32_t)(((fl & want) != 0 && !(fl & 4)) ? 1 : 0) | (fin ? 2u : 0u);
+      s_entry[0] = __hip_atomic_load(fin ? &left->bit : &left->pbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_entry[1] = __hip_atomic_load(fin ? &left->zu : &left->pzu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_entry[2] = fin ? (uint32_t)__hip_atomic_load(&left->blocks_incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      s_entry[4] = fin ? (uint32_t)__hip_atomic_load(&left->dc_incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     }
     __syncthreads();
-    entry_ok = s_entry[3] != 0;
-    e_bit = s_entry[0];
-    e_z = (int)(s_entry[1] & 255u);
-    e_u = (int)(s_entry[1] >> 8);
+    entry_ok = (s_entry[3] & 1u) != 0;
+    have_final = (s_entry[3] & 2u) != 0 || !entry_ok;  // (a neighbour that never showed up ends the exchange: the frame goes to the host decoder)
+    const uint32_t n_bit = s_entry[0];
+    const int n_z = (int)(s_entry[1] & 255u), n_u = (int)(s_entry[1] >> 8);
     base_blocks = (int)s_entry[2];
+    base_dc = (int)s_entry[4];
     __syncthreads();
+    const bool same = pass >= 1 && n_bit == e_bit && n_z == e_z && n_u == e_u;
+    e_bit = n_bit;
+    e_z = n_z;
+    e_u = n_u;
+    if (same && have_final) break;  // the provisional state was the final one: nothing to relax again
   }
-  // ---- first luma block of every subsequence: the left segments' count + exclusive prefix sum of nblk
-  int incl = nblk;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int up = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += up;
-  }
-  if (lane == 63) s_scan[wave] = incl;
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int w = 0; w < kHuffThreads / 64; w++) {
-      const int v = s_scan[w];
-      s_scan[w] = acc;
-      acc += v;
+#if defined(MDC_EXP_HUFF_VERIFY) && MDC_EXP_HUFF_VERIFY == 1  // diagnosis: is every thread's (blocks, DC sum, exit state) what a decode from its entry state gives?
+  {
+    int nb2 = 0, bad2 = 0, dc2 = 0, oz2 = in_z, ou2 = in_u;
+    uint32_t ob2 = in_bit;
+    if (in_bit < my1) huff_run<false, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &ob2, &oz2, &ou2, &nb2, &bad2, &dc2, nullptr, 0, g);
+    if (my0 < nbits) {
+      unsigned m = 0;
+      if (dc2 != dcsum) m += 1u;
+      if (nb2 != nblk) m += 1u << 10;
+      if (ob2 != out_bit || oz2 != out_z || ou2 != out_u) m += 1u << 20;
+      if (m) atomicAdd(&my_seg->pad, m);
     }
-    s_scan[kHuffThreads / 64] = acc;
   }
-  __syncthreads();
-  const int first = base_blocks + s_scan[wave] + incl - nblk;
-  const int total = s_scan[kHuffThreads / 64];
+#endif
+  // ---- first luma block and DC predictor of every subsequence: the left segments' totals + exclusive prefix sums over this one
+  int first, pred, total, total_dc;
+  scan_pair(nblk, dcsum, s_scan, tid, &first, &pred, &total, &total_dc);
+  first += base_blocks;
+  pred += base_dc;
   // ---- publish: the exit state of the last subsequence + blocks so far (the right neighbour waits for this)
   if (tid == kHuffThreads - 1) {
     my_seg->bit = out_bit;
     my_seg->zu = (uint32_t)(out_z | out_u << 8);
     my_seg->blocks_incl = base_blocks + total;
+    my_seg->dc_incl = base_dc + total_dc;
     __threadfence();
     __hip_atomic_store(&my_seg->flag, entry_ok ? 1 : (1 | 4), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- write pass (the true states)
   int bad_w = entry_ok ? 0 : 1;
+#if defined(MDC_EXP_HUFF_VERIFY) && MDC_EXP_HUFF_VERIFY == 2
+  const int pred_in = pred;
+#endif
   if (entry_ok && in_bit < my1) {
     int dummy = 0, oz, ou;
     uint32_t ob;
-    huff_run<true, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bad_w, coef, first, g, stage);
+    huff_run<true, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bad_w, &pred, coef, first, g, stage);
+#if defined(MDC_EXP_HUFF_VERIFY) && MDC_EXP_HUFF_VERIFY == 2  // diagnosis: the write pass against the counting pass of the same subsequence
+    unsigned m = 0;
+    if (pred - pred_in != dcsum) m += 1u;
+    if (dummy != nblk) m += 1u << 10;
+    if (ob != out_bit || oz != out_z || ou != out_u) m += 1u << 20;
+    if (m) atomicAdd(&my_seg->pad, m);
+#endif
   }
   if (__syncthreads_or(bad_w) && tid == 0) atomicOr(&my_seg->flag, 2);
 }
 
-// After the split kernel: DC differences -> DC values over the frame's luma blocks in scan order, and the frame's status.
+// After the split kernel: the frame's status from its segments' flags (one thread per frame).
 template <bool COLOR>
-__global__ __launch_bounds__(kHuffThreads) void jpeg_dc_finish_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
-                                                                      int16_t* __restrict__ records, long long rec_i16, int W, int H, int pitch, int rows,
-                                                                      const SegState* __restrict__ seg, int G, int* __restrict__ status, unsigned kinds) {
-  __shared__ int s_scan[kHuffThreads / 64 + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long long f = blockIdx.x;
+__global__ __launch_bounds__(64) void jpeg_split_status_kernel(const unsigned char* __restrict__ streams, long long stream_stride, int W, int H, int pitch,
+                                                               int rows, const SegState* __restrict__ seg, int G, int* __restrict__ status, unsigned kinds,
+                                                               int nframes) {
+  const long long f = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (f >= nframes) return;
   const mdc_jpeg_stream_header* hd = reinterpret_cast<const mdc_jpeg_stream_header*>(streams + f * stream_stride);
   const int kind = stream_kind(hd, W, H, pitch, rows, stream_stride);
   if (kind != (COLOR ? 1 : 0)) {
-    if (!COLOR && tid == 0 && (kind < 0 || !((kinds >> kind) & 1u))) status[f] = 2;
+    if (!COLOR && (kind < 0 || !((kinds >> kind) & 1u))) status[f] = 2;
     return;
   }
   const ScanGeo g = scan_geo(hd, W, H, pitch);
-  int16_t* coef = records + f * rec_i16 + 64;
   int flags = 0;
   for (int k = 0; k < G; k++) flags |= seg[f * G + k].flag;
   const bool failed = (flags & (2 | 4)) != 0 || !(flags & 1) || seg[f * G + G - 1].blocks_incl < g.nluma;
-  const int per = (g.nluma + kHuffThreads - 1) / kHuffThreads;
-  const int b0 = min(g.nluma, tid * per), b1 = min(g.nluma, b0 + per);
-  int sum = 0;
-  for (int k = b0; k < b1; k++) sum += luma_block(coef, k, g)[0];
-  int inc2 = sum;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int up = __shfl_up(inc2, d, 64);
-    if (lane >= d) inc2 += up;
-  }
-  if (lane == 63) s_scan[wave] = inc2;
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int w = 0; w < kHuffThreads / 64; w++) {
-      const int v = s_scan[w];
-      s_scan[w] = acc;
-      acc += v;
-    }
-  }
-  __syncthreads();
-  int pred = s_scan[wave] + inc2 - sum;
-  for (int k = b0; k < b1; k++) {
-    int16_t* c0 = luma_block(coef, k, g);
-    pred += c0[0];
-    c0[0] = (int16_t)pred;
-  }
-  if (tid == 0) status[f] = failed ? 1 : 0;
+#ifdef MDC_EXP_HUFF_VERIFY
+  unsigned mism = 0;
+  for (int k = 0; k < G; k++) mism += seg[f * G + k].pad;
+  status[f] = (failed ? 1 : 0) | (int)((mism & 0xff) | ((mism >> 10) & 0xff) << 8 | ((mism >> 20) & 0xff) << 16) << 8;
+#else
+  status[f] = failed ? 1 : 0;
+#endif
 }
 
 // Restart intervals: interval i holds MCUs [i Ri, (i+1) Ri) and begins, byte aligned, at the offset the host recorded, with
@@ -934,10 +934,12 @@ __global__ __launch_bounds__(kIntervalThreads) void jpeg_huffman_intervals_kerne
 }  // namespace
 
 size_t jpeg_huffman_scratch_bytes(int64_t nframes) { return (size_t)nframes * kHuffMaxSegments * sizeof(SegState); }
+static_assert(sizeof(SegState) == 32, "SegState: two per 64-byte line");
 int jpeg_huffman_segments(int64_t nframes) {
-  // up to 64 frames (the reader's chunk): 4 workgroups per frame, one per CU; up to 128: 2; beyond, one workgroup per frame fills
-  // the chip (profiles/r04_experiments/04_*, 05_*)
-  return nframes <= 64 ? (int)std::max<int64_t>(1, std::min<int64_t>(kHuffMaxSegments, 256 / std::max<int64_t>(1, nframes))) : nframes <= 128 ? 2 : 1;
+  // 8 workgroups per frame up to 16 frames, 4 up to 64 (the reader's chunk: one workgroup per CU), 2 up to 128; beyond, one
+  // workgroup per frame fills the chip (profiles/r04_experiments/04_*, 05_*, 08_*: 8 x 32 workgroups were slower than 4 x 32)
+  const int g = nframes <= 16 ? 8 : nframes <= 64 ? 4 : nframes <= 128 ? 2 : 1;
+  return g < kHuffMaxSegments ? g : kHuffMaxSegments;
 }
 
 hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w, int h, int blocks_w,
@@ -973,13 +975,13 @@ hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, voi
     jpeg_record_init_kernel<<<(unsigned)(nframes * 8), 256, 0, s>>>(st, stream_stride, rec, rec_i16, blocks_w, blocks_rows, 8, seg, G);
     jpeg_huffman_split_kernel<false><<<(unsigned)(nframes * G), kHuffThreads, pad, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G,
                                                                                         (uint32_t)pad, stage_blocks);
-    jpeg_dc_finish_kernel<false><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G, d_status, kinds);
+    jpeg_split_status_kernel<false><<<(unsigned)((nframes + 63) / 64), 64, 0, s>>>(st, stream_stride, w, h, blocks_w, blocks_rows, seg, G, d_status, kinds, (int)nframes);
     if (kinds & 2u) {
       e = hipMemsetAsync(seg, 0, (size_t)nframes * G * sizeof(SegState), s);
       if (e != hipSuccess) return e;
       jpeg_huffman_split_kernel<true><<<(unsigned)(nframes * G), kHuffThreads, 72 * 1024, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G,
                                                                                                  (uint32_t)(72 * 1024), 0);
-      jpeg_dc_finish_kernel<true><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G, d_status, kinds);
+      jpeg_split_status_kernel<true><<<(unsigned)((nframes + 63) / 64), 64, 0, s>>>(st, stream_stride, w, h, blocks_w, blocks_rows, seg, G, d_status, kinds, (int)nframes);
     }
   } else {
     const size_t stage = 128 * 1024;  // block staging of the one-component kernel's write pass (one workgroup per CU)

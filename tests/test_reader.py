@@ -365,6 +365,85 @@ def test_gpu_huffman_stage_equals_the_host_decoder(size):
     assert int(d_status[0]) == 1
 
 
+def huffman_batches_equal_the_host_decoder(capi_dev, size, batch_sizes):
+    """Records of mdc_jpeg_huffman_batch_device (through `capi_dev`: the product library or a variant build) against the host
+    decoder's, for batches of one-component and interleaved YCbCr files, every batch twice on the same buffers."""
+    import torch
+
+    from mono_dataset_code_amd import capi
+
+    h, w = size
+    rng = np.random.default_rng(h + w)
+    files = []
+    for k in range(6):
+        img = textured(h, w, k) if k % 3 != 2 else rng.integers(0, 256, (h, w), dtype=np.uint8)
+        if k >= 4:
+            img = np.stack([img, np.roll(img, 3, 1), 255 - img], -1)
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, "JPEG", quality=(35, 90, 97, 75, 88, 60)[k], **({"subsampling": 2} if k == 5 else {}))
+        files.append(b.getvalue())
+    rec_bytes, pitch, rows = capi.jpeg_record_bytes(w, h)
+    cap = (2 * capi.JPEG_STREAM_HEADER_BYTES + 4 * ((w + 7) // 8) * ((h + 7) // 8) + max(len(f) for f in files) + 64 + 15) & ~15
+    want = np.zeros((len(files), rec_bytes), np.uint8)
+    one = np.zeros((len(files), cap), np.uint8)
+    for i, data in enumerate(files):
+        capi.decode_jpeg_record(data, want[i], pitch)
+        capi.jpeg_stream(data, one[i])
+    used = 128 + rows * pitch * 128
+    bw, bh = (w + 7) // 8, (h + 7) // 8
+    d_want = torch.from_numpy(want).cuda()[:, 128:used].view(torch.int16).reshape(len(files), rows, pitch, 64)[:, :bh, :bw]
+    d_quant = torch.from_numpy(want).cuda()[:, :128]
+    d_one = torch.from_numpy(one).cuda()
+    ctx = capi_dev.Context(0)
+    st = torch.cuda.current_stream().cuda_stream
+    nmax = max(batch_sizes)
+    d_rec = torch.empty((nmax, rec_bytes), dtype=torch.uint8, device="cuda")
+    d_status = torch.empty((nmax,), dtype=torch.int32, device="cuda")
+    for n in batch_sizes:
+        idx = (torch.arange(n, device="cuda") * 5 + n) % len(files)  # another order of the files for every batch size
+        d_streams = d_one[idx].contiguous()
+        for call in range(2):
+            d_rec.fill_(0x5A)
+            d_status.fill_(-1)
+            ctx.jpeg_huffman_batch(d_streams.data_ptr(), cap, d_rec.data_ptr(), rec_bytes, w, h, pitch, rows, n, d_status.data_ptr(), st)
+            torch.cuda.synchronize()
+            assert bool((d_status[:n] == 0).all()), (n, call, d_status[:n].cpu().tolist())
+            got = d_rec[:n, 128:used].view(torch.int16).reshape(n, rows, pitch, 64)[:, :bh, :bw]
+            assert torch.equal(got, d_want[idx]), (n, call, torch.nonzero((got != d_want[idx]).any(-1))[:4].cpu().tolist())
+            assert torch.equal(d_rec[:n, :128], d_quant[idx]), (n, call)
+
+
+@pytest.mark.parametrize("size", [(1024, 1280), (480, 640), (40, 56)])
+def test_gpu_huffman_every_number_of_workgroups_per_frame(size):
+    """Small batches spread a frame's stream over 8 / 4 / 2 workgroups that hand provisional, then final exit states on
+    (jpeg_huffman_split_kernel); large ones take one workgroup per frame: the record is the host decoder's whatever the
+    batch size -- 1, 3, 16 (8 per frame), 17, 33, 64 (4), 65, 100 (2), 130 (1) -- for one-component and interleaved YCbCr files in
+    one batch, and a second call on the same buffers gives the same bytes (the segment states are re-initialised per call)."""
+    from mono_dataset_code_amd import capi
+
+    huffman_batches_equal_the_host_decoder(capi, size, (1, 3, 16, 17, 33, 64, 65, 100, 130))
+
+
+@pytest.mark.parametrize("size", [(1024, 1280), (100, 130)])
+def test_gpu_huffman_with_wrong_provisional_states(size):
+    """Fault injection (mono_dataset_code_amd/build.py:build_fault_injection, -DMDC_EXP_HUFF_BAD_PROVISIONAL): every segment
+    publishes a WRONG provisional exit state, so every right neighbour relaxes from it, finds the final state different and
+    relaxes a third time -- the path a product run takes only when a guessed entry state never resynchronises (one-component
+    files: practically never; colour files: the position in the MCU is part of the state and mostly guessed wrong).  Same
+    records as the host decoder."""
+    import importlib.util
+
+    from mono_dataset_code_amd import build
+
+    path = build.build_fault_injection()
+    spec = importlib.util.spec_from_file_location("capi_badprov", os.path.join(ROOT, "mono_dataset_code_amd", "capi.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    m.LIB_HIP_PATH = path
+    assert "MDC_EXP_HUFF_BAD_PROVISIONAL" in m.build_flags()
+    huffman_batches_equal_the_host_decoder(m, size, (2, 16, 20, 64, 100))
+
+
 def test_gpu_huffman_stage_random_files():
     """300 random files -- sizes 1x1 .. 97x131, qualities 1..100, optimised tables or the standard ones, one component or YCbCr
     (4:4:4 / 4:2:2 / 4:2:0), with or without restart intervals of 1..11 MCUs, content from flat

@@ -18,7 +18,7 @@
 #   pipe_trace       per-chunk time stamps of the JPEG-stream pipeline (upload / Huffman done / decoded / output) on a 256-frame getImages
 #   soak             reader soak (one lane, two lanes), tiled-kernel soak, 8-thread soak
 #   reader2          the reader's rates with two lanes on the one GPU (MDC_DEVICES=0,0)
-#   reader / dso / huffman / vcal / distort   the secondary rate tools
+#   reader / dso / huffman / vcal / distort   the secondary rate tools; huffman_ab: the Huffman decoder per library build (LIBS=...)
 set -u
 TAG=$1; shift
 cd "$GRAFT_REPO_ROOT"
@@ -102,6 +102,16 @@ PY
     reader)  timeout 900 python tools/reader_rate.py ${N:-512} > "$OUT/reader_rates.txt" 2>&1; grep -av amdgpu.ids "$OUT/reader_rates.txt" | tail -30 ;;
     dso)     timeout 600 python tools/dso_rate.py > "$OUT/dso_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/dso_rate.txt" | tail -20 ;;
     huffman) timeout 600 python tools/huffman_rate.py > "$OUT/huffman_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/huffman_rate.txt" | tail -20 ;;
+    huffman_ab)  # the one-component decoder per library build (LIBS="product huffseg4 ...": mono_dataset_code_amd/variants/libmdc_hip_<name>.so), two rounds
+      for r in 1 2; do for l in ${LIBS:-product}; do
+        lib=""; [ $l != product ] && lib="$GRAFT_REPO_ROOT/mono_dataset_code_amd/variants/libmdc_hip_$l.so"
+        echo "--- $l (round $r)" >> "$OUT/huffman_ab.txt"
+        MDC_LIB_HIP=$lib HUFF_KINDS=gray REPS=20 timeout 300 python tools/huffman_rate.py 2>&1 | grep -a "^n " >> "$OUT/huffman_ab.txt"
+      done; done; cat "$OUT/huffman_ab.txt" ;;
+    huffman_trace)  # per-kernel times of the one-component decoder at COUNTS streams per call
+      ( cd /tmp && export TMPDIR=/tmp
+        HUFF_KINDS=gray REPS=20 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/huff_trace" -- python "$GRAFT_REPO_ROOT/tools/huffman_rate.py" > "$OUT/huffman_trace.log" 2>&1 )
+      f=$(find "$OUT/huff_trace" -name "*kernel_stats.csv" | head -1); cut -d, -f1-7 "$f" | grep -a "jpeg\|Name" | cut -c1-150 ;;
     distort) timeout 300 python tools/distort_rate.py > "$OUT/distort_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/distort_rate.txt" | tail -5 ;;
     vcal)    timeout 600 python tools/vcal_rate.py > "$OUT/vcal_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/vcal_rate.txt" | tail -20 ;;
     *) echo "unknown stage $stage" ;;

@@ -27,9 +27,12 @@ rec_bytes, pitch, rows = capi.jpeg_record_bytes(w, h)
 ctx = capi.Context(0)
 st = torch.cuda.current_stream().cuda_stream
 N = 256
+REPS = int(os.environ.get("REPS", "5"))
 
 
 def run(label, save_kw, rgb=False, counts=(1, 4, 16, 32, 64, 128, 256)):
+    if os.environ.get("COUNTS"):
+        counts = tuple(int(v) for v in os.environ["COUNTS"].split(","))
     files = []
     for s in range(8):
         img = textured(s)
@@ -63,14 +66,14 @@ def run(label, save_kw, rgb=False, counts=(1, 4, 16, 32, 64, 128, 256)):
             ctx.jpeg_huffman_batch(d_streams.data_ptr(), cap, d_rec.data_ptr(), rec_bytes, w, h, pitch, rows, n, d_status.data_ptr(), st)
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
-        for _ in range(5):
+        for _ in range(REPS):
             ctx.jpeg_huffman_batch(d_streams.data_ptr(), cap, d_rec.data_ptr(), rec_bytes, w, h, pitch, rows, n, d_status.data_ptr(), st)
         e1.record()
         for _ in range(5):
             ctx.jpeg_idct_batch(d_rec.data_ptr(), rec_bytes, d_frames.data_ptr(), w, h, pitch, rows, n, st)
         e2.record()
         torch.cuda.synchronize()
-        th, ti = e0.elapsed_time(e1) / 5, e1.elapsed_time(e2) / 5
+        th, ti = e0.elapsed_time(e1) / REPS, e1.elapsed_time(e2) / 5
         print("n %3d: Huffman launches %8.3f ms (%6.1f us per frame, %7.0f frames/s) | inverse DCT %7.3f ms | status ok: %s" %
               (n, th, th / n * 1e3, n / th * 1e3, ti, bool(((d_status[:n] & 255) == 0).all())), flush=True)
     r = (d_status[:8] >> 8).cpu().numpy().tolist()
@@ -80,7 +83,14 @@ def run(label, save_kw, rgb=False, counts=(1, 4, 16, 32, 64, 128, 256)):
 
 # (the device-pointer entry point cannot look into the streams: it launches the kernels of all three kinds of stream; the
 # reader's pipeline launches only the ones a chunk needs)
-run("one component (what the TUM mono dataset ships)", {})
+if os.environ.get("HUFF_KINDS") != "color":
+    run("one component (what the TUM mono dataset ships)", {})
+if os.environ.get("HUFF_KINDS") == "gray":
+    sys.exit(0)
+if os.environ.get("HUFF_KINDS") == "color":
+    run("YCbCr 4:2:0, interleaved", {"subsampling": 2}, rgb=True, counts=(16, 64, 256))
+    run("YCbCr 4:4:4, interleaved", {"subsampling": 0}, rgb=True, counts=(16, 64, 256))
+    sys.exit(0)
 run("one component, a restart interval per MCU row", {"restart_marker_rows": 1}, counts=(16, 64, 256))
 run("YCbCr 4:2:0, interleaved", {"subsampling": 2}, rgb=True, counts=(16, 64, 256))
 run("YCbCr 4:2:0, a restart interval per MCU row", {"subsampling": 2, "restart_marker_rows": 1}, rgb=True, counts=(64,))
