@@ -34,6 +34,9 @@
 #ifndef MDC_EXP_GUESS_DIV
 #define MDC_EXP_GUESS_DIV 4  // device Huffman decoder: the first guess decodes the last 1/4 of the left neighbour's subsequence
 #endif
+#ifndef MDC_EXP_GUESS_MIN_BITS
+#define MDC_EXP_GUESS_MIN_BITS 512  // ... but at least this many bits (high qualities: ~250 bits per block, 512 bits are two blocks)
+#endif
 #ifndef MDC_EXP_HUFF_MAX_SEGMENTS
 #define MDC_EXP_HUFF_MAX_SEGMENTS 8  // device Huffman decoder, small batches: workgroups per frame at most (8 up to 32 frames, 4 up to 64, 2 up to 128)
 #endif
@@ -96,6 +99,7 @@ inline const char* build_flags_string() {
       MDC_CFG_ITEM(MDC_EXP_STRIP_LUT_REP, 8),
       MDC_CFG_ITEM(MDC_EXP_STRIP_WAVES_PER_EU, 5),
       MDC_CFG_ITEM(MDC_EXP_GUESS_DIV, 4),
+      MDC_CFG_ITEM(MDC_EXP_GUESS_MIN_BITS, 512),
       MDC_CFG_ITEM(MDC_EXP_HUFF_MAX_SEGMENTS, 8),
       MDC_CFG_ITEM(MDC_EXP_HUFF_PROVISIONAL, 1),
 #ifdef MDC_EXP_STORE_AUX

@@ -221,14 +221,12 @@ struct BitReader {
   uint32_t next;         // that word as loaded, bytes not yet swapped: the swap at the point of USE lets the load stay in flight until
                          // the next refill (~5 symbols) -- swapped at once, every refill waited for its own load
   uint32_t last;         // index of the last word that may be read
-  // optional: words [lds_lo, lds_hi) of the stream staged in LDS (the split kernel: a segment's bytes, copied once with coalesced
-  // loads -- every refill is otherwise a 64-way divergent 4-byte load over a working set beyond the L1)
-  const uint32_t* lds = nullptr;
-  uint32_t lds_lo = 0, lds_hi = 0;
-  __device__ __forceinline__ uint32_t raw(uint32_t i) const {
-    const uint32_t j = min(i, last);
-    return (j >= lds_lo && j < lds_hi) ? lds[j - lds_lo] : base[j];
-  }
+  // Where the words are read: `base` itself, or -- the split kernel: a segment's words [lo, ...) copied to LDS once with coalesced
+  // loads (every refill is otherwise a 64-way divergent 4-byte load over a working set beyond the L1) -- that copy, as a generic
+  // pointer.  One or the other for the whole workgroup: no choice per access.
+  const uint32_t* src = nullptr;
+  uint32_t lo = 0;
+  __device__ __forceinline__ uint32_t raw(uint32_t i) const { return src[max(min(i, last), lo) - lo]; }  // (clamped both ways: an entry state may come from anywhere)
   __device__ __forceinline__ void start(uint32_t bit) {
     widx = bit >> 5;
     const uint64_t w0 = __builtin_bswap32(raw(widx)), w1 = __builtin_bswap32(raw(widx + 1));
@@ -270,23 +268,28 @@ __device__ __forceinline__ int huff_extend(int v, int t) { return v < (1 << (t -
 template <int NT>
 __device__ __forceinline__ int huff_symbol(BitReader& b, const HuffLds<NT>& T, int tab, int& z, int* value, bool* wrong_out) {
   const bool ac = z != 0;
-  uint32_t e = T.t1[tab + (ac ? 1 : 0)][b.peek(11)];
-  if ((e & 31u) == 31u) e = T.t2[tab + (ac ? 1 : 0)][(e >> 16) & (MDC_JPEG_HUFF_SUBTABLES - 1)][(uint32_t)(b.acc >> 48) & 31u];  // bits 11..15 of the window
+  const uint32_t hi = (uint32_t)(b.acc >> 32);  // the next 32 bits (the reader keeps more than 32 valid): all a symbol can need
+  uint32_t e = T.t1[tab + (ac ? 1 : 0)][hi >> 21];
+  if ((e & 31u) == 31u) e = T.t2[tab + (ac ? 1 : 0)][(e >> 16) & (MDC_JPEG_HUFF_SUBTABLES - 1)][(hi >> 16) & 31u];  // bits 11..15 of the window
   const int len = (int)(e & 31u), run = (int)((e >> 5) & 15u), size = (int)((e >> 9) & 15u);
-  bool wrong = (unsigned)(len - 1) > 15u || (!ac && size > 11);
-  // the value: in the entry (short code + short value), or the `size` bits behind the code, extended
-  const uint64_t behind = b.acc << len;                       // (len <= 31)
-  const int rawv = (int)((behind >> 1) >> (63 - size));       // size 0 -> 0
+  const bool wrong = (unsigned)(len - 1) > 15u || (!ac && size > 11);
+  // the value: in the entry (short code + short value), or the `size` bits behind the code, extended (len + size <= 31)
+  const uint32_t behind = hi << len;
+  const int rawv = (int)((behind >> 1) >> (31 - size));       // size 0 -> 0
   const int half = (1 << size) >> 1;
   const int ext = rawv < half ? rawv - (1 << size) + 1 : rawv;  // size 0 -> 0
   int v = (e & (1u << 13)) ? (int)(int16_t)(e >> 16) : ext;
   v = wrong ? 0 : v;
   b.skip(wrong ? 1 : len + size);  // (speculative rounds run through garbage: keep moving)
+  // z: DC -> 1; a wrong AC code leaves it; EOB -> 64, ZRL -> z + 16; a coefficient at z + run -> z + run + 1
   const int zr = z + run;
   const bool coef = ac && !wrong && size != 0;
   const bool over = coef && zr > 63;
   const int at = !ac ? 0 : (coef && !over) ? zr : -1;
-  z = !ac ? 1 : wrong ? z : size == 0 ? (run == 15 ? z + 16 : 64) : zr + 1;  // ZRL / EOB / a coefficient
+  const int z_nocoef = run == 15 ? z + 16 : 64;
+  int zn = size != 0 ? zr + 1 : z_nocoef;
+  zn = wrong ? z : zn;
+  z = ac ? zn : 1;
   *value = v;
   *wrong_out = wrong || over;
   return at;
@@ -379,14 +382,7 @@ __device__ __forceinline__ void huff_run(BitReader& b, const HuffLds<NT>& T, uin
       if (COLOR) u = u + 1 == g.nb ? 0 : u + 1;
       if (WRITE) cur = ((!COLOR || u < g.hv) && q < g.nluma) ? luma_block(coef, q, g) : nullptr;
     }
-    const uint32_t np = b.pos();
-    if (np <= p) {  // no progress: cannot happen (every symbol consumes at least one bit) -- kept as the loop's own guarantee that it ends
-      if (!WRITE || cur) *bad = 1;
-      b.skip(1);
-      p = p + 1;
-    } else {
-      p = np;
-    }
+    p = b.pos();  // (every symbol consumes at least one bit: the loop ends whatever the tables hold)
   }
   if (WRITE && staged && cur && cmask) stage_flush_scattered(stage, cur, cmask);
   *out_bit = p;
@@ -491,12 +487,13 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
   const uint32_t my0 = min(nbits, (uint32_t)tid * S), my1 = min(nbits, my0 + S);
   BitReader b;
   b.base = reinterpret_cast<const uint32_t*>(st + hd->ecs_offset);
+  b.src = b.base;
   b.last = (ecs_bytes + 3) / 4 + 2;  // the host pads 16 zero bytes
   int16_t* coef = rec + 64;
   // ---- first guesses: only the exit state of a subsequence matters to its right neighbour, and a decoder started anywhere
   // is on the true path after a few hundred bits -- so the guess comes from the LAST quarter (at least 512 bits) of the subsequence alone
   // (a quarter of a full pass; where it is wrong, the relaxation below finds out)
-  const uint32_t guess_bits = max(512u, S / MDC_EXP_GUESS_DIV);  // (high qualities: ~250 bits per block, 512 bits are two blocks)
+  const uint32_t guess_bits = max((uint32_t)MDC_EXP_GUESS_MIN_BITS, S / MDC_EXP_GUESS_DIV);  // (high qualities: ~250 bits per block, 512 bits are two blocks)
   uint32_t in_bit = my0, out_bit = my0;
   int in_z = 0, out_z = 0, in_u = 0, out_u = 0, nblk = 0, bad = 0, dcsum = 0;
   if (my0 < my1) {
@@ -651,6 +648,7 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
   const uint32_t my0 = (uint32_t)min((unsigned long long)nbits, (unsigned long long)gi * S), my1 = min(nbits, my0 + S);
   BitReader b;
   b.base = reinterpret_cast<const uint32_t*>(st + hd->ecs_offset);
+  b.src = b.base;
   b.last = (ecs_bytes + 3) / 4 + 2;
   {  // the segment's words (+ a margin: a subsequence's last symbol and the reader's look-ahead run past its end) -> LDS
     const uint32_t w0 = (uint32_t)sg * kHuffThreads * sw, want = kHuffThreads * sw + 64u;
@@ -659,14 +657,13 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
       const i32x4* src = reinterpret_cast<const i32x4*>(b.base + w0);  // (w0 * 4 is a multiple of 16: sw * 1024 words per segment)
       for (uint32_t i = tid; i < have / 4u; i += kHuffThreads) reinterpret_cast<i32x4*>(s_stream)[i] = src[i];
       if ((uint32_t)tid < (have & 3u)) s_stream[(have & ~3u) + tid] = b.base[w0 + (have & ~3u) + tid];  // (never past the stream's last word)
-      b.lds = s_stream;
-      b.lds_lo = w0;
-      b.lds_hi = w0 + have;
+      b.src = s_stream;  // (every word a thread of this segment reads lies in [w0, w0 + have): its subsequence, the reader's look-ahead)
+      b.lo = w0;
     }
   }
   __syncthreads();
   int16_t* coef = rec + 64;
-  const uint32_t guess_bits = max(512u, S / MDC_EXP_GUESS_DIV);
+  const uint32_t guess_bits = max((uint32_t)MDC_EXP_GUESS_MIN_BITS, S / MDC_EXP_GUESS_DIV);
   uint32_t in_bit = my0, out_bit = my0;
   int in_z = 0, out_z = 0, in_u = 0, out_u = 0, nblk = 0, bad = 0, dcsum = 0;
   if (my0 < my1) {
@@ -864,6 +861,7 @@ __global__ __launch_bounds__(kIntervalThreads) void jpeg_huffman_intervals_kerne
   const uint32_t ecs_bytes = hd->ecs_bytes;
   BitReader b;
   b.base = reinterpret_cast<const uint32_t*>(st + hd->ecs_offset);
+  b.src = b.base;
   b.last = (ecs_bytes + 3) / 4 + 2;
   int16_t* coef = rec + 64;
   int bad = 0;
