@@ -18,7 +18,9 @@
 #   pipe_trace       per-chunk time stamps of the JPEG-stream pipeline (upload / Huffman done / decoded / output) on a 256-frame getImages
 #   soak             reader soak (one lane, two lanes), tiled-kernel soak, 8-thread soak
 #   reader2          the reader's rates with two lanes on the one GPU (MDC_DEVICES=0,0)
-#   reader / dso / huffman / vcal / distort   the secondary rate tools; huffman_ab: the Huffman decoder per library build (LIBS=...)
+#   reader / dso / huffman / vcal / distort   the secondary rate tools
+#   huffman_ab       the one-component Huffman decoder per library build (LIBS="product <variant> ...", mono_dataset_code_amd/variants/)
+#   huffman_trace    rocprofv3 --kernel-trace --stats of tools/huffman_rate.py (COUNTS=64: streams per call)
 set -u
 TAG=$1; shift
 cd "$GRAFT_REPO_ROOT"
