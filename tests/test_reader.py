@@ -708,3 +708,98 @@ def test_image_pool_slabs():
         L.mdch_image_free(p)
     L.mdch_image_pool_trim()
     assert L.mdch_image_pool_idle_bytes() == 0
+
+
+def islow_idct_reference(record, w, h, pitch, rows):
+    """jidctint.c's `islow` inverse DCT on a coefficient record, restated with 64-bit numpy integers (the host decoder's
+    arithmetic): quantisation table at the record's head, blocks of 64 int16 behind it -> h x w uint8."""
+    q = record[:128].view(np.uint16).astype(np.int64).reshape(8, 8)
+    blocks = record[128:128 + rows * pitch * 128].view(np.int16).reshape(rows, pitch, 8, 8).astype(np.int64) * q
+
+    def one_d(c, shift):  # c[..., 8] along the last axis -> outputs along the last axis
+        F = dict(a=2446, b=3196, c=4433, d=6270, e=7373, f=9633, g=12299, h=15137, i=16069, j=16819, k=20995, l=25172)
+        z2, z3 = c[..., 2], c[..., 6]
+        z1 = (z2 + z3) * F["c"]
+        tmp2, tmp3 = z1 + z3 * -F["h"], z1 + z2 * F["d"]
+        tmp0, tmp1 = (c[..., 0] + c[..., 4]) << 13, (c[..., 0] - c[..., 4]) << 13
+        t10, t13, t11, t12 = tmp0 + tmp3, tmp0 - tmp3, tmp1 + tmp2, tmp1 - tmp2
+        tmp0, tmp1, tmp2, tmp3 = c[..., 7], c[..., 5], c[..., 3], c[..., 1]
+        z1, z2, z3, z4 = tmp0 + tmp3, tmp1 + tmp2, tmp0 + tmp2, tmp1 + tmp3
+        z5 = (z3 + z4) * F["f"]
+        tmp0, tmp1, tmp2, tmp3 = tmp0 * F["a"], tmp1 * F["j"], tmp2 * F["l"], tmp3 * F["g"]
+        z1, z2, z3, z4 = z1 * -F["e"], z2 * -F["k"], z3 * -F["i"] + z5, z4 * -F["b"] + z5
+        tmp0, tmp1, tmp2, tmp3 = tmp0 + z1 + z3, tmp1 + z2 + z4, tmp2 + z2 + z3, tmp3 + z1 + z4
+        outs = [t10 + tmp3, t11 + tmp2, t12 + tmp1, t13 + tmp0, t13 - tmp0, t12 - tmp1, t11 - tmp2, t10 - tmp3]
+        r = np.stack([(o + (1 << (shift - 1))) >> shift for o in outs], -1)
+        return r.astype(np.int32).astype(np.int64)  # (the workspace is `int`: a 64-bit value is cut to 32 bits there, as on the host)
+
+    ws = one_d(blocks.swapaxes(-1, -2), 11).swapaxes(-1, -2)  # pass 1 on columns
+    px = np.clip(one_d(ws, 18) + 128, 0, 255).astype(np.uint8)  # pass 2 on rows
+    img = px.transpose(0, 2, 1, 3).reshape(rows * 8, pitch * 8)
+    return img[:h, :w]
+
+
+@pytest.mark.parametrize("size", [(64, 96), (37, 70)])
+def test_gpu_idct_on_coefficients_of_any_magnitude(size):
+    """The device inverse DCT computes in 32 bits where no intermediate can leave them (inputs up to 35079: every real image) and
+    in the host decoder's 64 bits otherwise.  A numpy restatement of the islow transform with 64-bit integers is first pinned to
+    the host decoder on a real file, then both paths are driven with crafted records: coefficients and quantisation tables up to
+    the full 16-bit range, magnitudes around the switch-over, single large terms among small ones."""
+    import torch
+
+    from mono_dataset_code_amd import capi
+
+    h, w = size
+    rec_bytes, pitch, rows = capi.jpeg_record_bytes(w, h)
+    rng = np.random.default_rng(h * 131 + w)
+    b = io.BytesIO()
+    Image.fromarray(textured(h, w, 3)).save(b, "JPEG", quality=93)
+    real = np.zeros(rec_bytes, np.uint8)
+    capi.decode_jpeg_record(b.getvalue(), real, pitch)
+    assert np.array_equal(islow_idct_reference(real, w, h, pitch, rows), capi.decode_gray8(b.getvalue()))
+    recs = [real]
+    nb = rows * pitch * 64
+    for kind in range(8):
+        r = np.zeros(rec_bytes, np.uint8)
+        q = r[:128].view(np.uint16)
+        c = r[128:128 + 2 * nb].view(np.int16)
+        if kind == 0:    # everything anywhere
+            q[:] = rng.integers(1, 65536, 64)
+            c[:] = rng.integers(-32768, 32768, nb)
+        elif kind == 1:  # around the switch-over: |coefficient * q| near 35079
+            q[:] = 1
+            c[:] = rng.integers(-32768, 32768, nb)
+            c[rng.random(nb) < 0.5] //= 2
+        elif kind == 2:  # small blocks with one huge term
+            q[:] = rng.integers(1, 256, 64)
+            c[:] = rng.integers(-20, 21, nb)
+            idx = rng.integers(0, nb, nb // 40)
+            c[idx] = rng.integers(-32768, 32768, len(idx))
+        elif kind == 3:  # the largest magnitudes, all signs alike
+            q[:] = 65535
+            c[:] = 32767
+        elif kind == 4:
+            q[:] = 65535
+            c[:] = -32768
+        elif kind == 5:  # workspace values beyond the bound from coefficients below it
+            q[:] = 8
+            c[:] = rng.integers(-4300, 4301, nb)
+        elif kind == 6:  # sparse blocks, as decoders mostly see them
+            q[:] = rng.integers(1, 100, 64)
+            c[:] = 0
+            idx = rng.integers(0, nb, nb // 16)
+            c[idx] = rng.integers(-300, 301, len(idx))
+        else:            # alternating signs at full scale
+            q[:] = 255
+            c[:] = np.where(np.arange(nb) % 2 == 0, 2047, -2047)
+        recs.append(r)
+    n = len(recs)
+    d_rec = torch.from_numpy(np.stack(recs)).cuda()
+    d_frames = torch.full((n, h * w), 77, dtype=torch.uint8, device="cuda")
+    ctx = capi.Context(0)
+    ctx.jpeg_idct_batch(d_rec.data_ptr(), rec_bytes, d_frames.data_ptr(), w, h, pitch, rows, n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_frames.cpu().numpy().reshape(n, h, w)
+    for i in range(n):
+        want = islow_idct_reference(recs[i], w, h, pitch, rows)
+        assert np.array_equal(got[i], want), (i, int((got[i] != want).sum()), np.argwhere(got[i] != want)[:3].tolist())
