@@ -36,6 +36,9 @@ def test_register_budgets(kernels):
     assert by["remap_strip_kernel<true, true, 2, 5, 4>"]["vgpr"] <= 128
     # the device Huffman decoder: a 1024-thread workgroup per frame, two of them per CU (<= 64 VGPRs)
     assert by["jpeg_huffman_kernel<false>"]["vgpr"] <= 64 and by["jpeg_huffman_kernel<true>"]["vgpr"] <= 64
+    assert by["jpeg_huffman_split_kernel<false>"]["vgpr"] <= 64 and by["jpeg_huffman_split_kernel<true>"]["vgpr"] <= 64
+    # the inverse DCT: eight threads per block (one thread per block needed 280 registers and ran at one wave per SIMD)
+    assert by["jpeg_idct_kernel"]["vgpr"] <= 64
     # the hot kernels use the LDS-DMA path and contain no MFMA (no contraction on this path)
     fused = by["remap_tiled_kernel<true, false, false, false, 128, 512, 2>"]["counts"]
     assert sum(v for n, v in fused.items() if n.startswith("buffer_load_dwordx4")) >= 1
