@@ -161,9 +161,9 @@ __global__ __launch_bounds__(kIdctThreads) void jpeg_idct_kernel(const int16_t* 
 //  * jpeg_huffman_kernel<true>: three components interleaved in one scan (YCbCr baseline), no restart markers.  The same
 //    relaxation over a larger state: (bit, z, u), u = the block's position inside its MCU (hY x vY luma blocks, then Cb, then
 //    Cr), which picks the table pair; chroma symbols are decoded and dropped, luma blocks are counted and written.
-//  * jpeg_huffman_intervals_kernel: files with restart markers, one or three components.  Every restart interval starts at a
-//    byte the host has recorded, with z = 0 and all predictors 0: exact entry states, no relaxation -- a thread decodes whole
-//    intervals front to back and writes final DC values directly.
+//  * jpeg_huffman_intervals_kernel<C>: files with restart markers, one or three components.  Every restart interval starts at a
+//    byte the host has recorded, with z = 0 and all predictors 0: exact entry states -- a thread decodes whole short intervals
+//    front to back and writes final DC values directly; long intervals are cut into parts that relax inside a wave.
 //
 // Integer logic only: the record equals the host decoder's bit for bit; a code no table holds, too few blocks or an interval
 // that runs into the next one set the frame's status (the caller falls back to the host decoder).
@@ -252,19 +252,11 @@ struct BitReader {
     }
   }
   __device__ __forceinline__ uint32_t pos() const { return widx * 32u - (uint32_t)cnt; }
-  __device__ __forceinline__ int peek(int n) const { return (int)(acc >> (64 - n)); }
   __device__ __forceinline__ void skip(int n) {
     acc <<= n;
     cnt -= n;
   }
-  __device__ __forceinline__ int get(int n) {  // n in 1..16
-    const int v = peek(n);
-    skip(n);
-    return v;
-  }
 };
-
-__device__ __forceinline__ int huff_extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
 
 // One symbol at the reader's position with table pair `tab` (0 luma, 2 chroma), DC when z == 0 else AC: -> coefficient index
 // the symbol writes (0: the DC difference; -1: none) and its value; z advanced (>= 64: the block is complete); *wrong set for a
@@ -838,33 +830,56 @@ __global__ __launch_bounds__(64) void jpeg_split_status_kernel(const unsigned ch
 #endif
 }
 
-// Restart intervals: interval i holds MCUs [i Ri, (i+1) Ri) and begins, byte aligned, at the offset the host recorded, with
-// every predictor 0.  A thread decodes whole intervals front to back (no guesses), four table pairs or two.
-constexpr int kIntervalThreads = 256;
-__global__ __launch_bounds__(kIntervalThreads) void jpeg_huffman_intervals_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
-                                                                                  int16_t* __restrict__ records, long long rec_i16, int W, int H,
-                                                                                  int pitch, int rows, int* __restrict__ status) {
-  __shared__ HuffLds<4> s_t;
+// Restart intervals: interval i holds MCUs [i Ri, (i+1) Ri) and begins, byte aligned, at the offset the host recorded, with every
+// predictor 0 -- an exact entry state per interval, no exchange between intervals.  Short intervals (a few MCUs) are decoded by one
+// thread each, front to back, straight into the record.  Long ones (one per MCU row is what hardware encoders write: 128 intervals
+// of 2 KB in a 1280 x 1024 frame) would leave most of a workgroup idle: they are cut into T parts (a power of two <= 64, parts of at
+// least ~400 bits), the parts of an interval sit in neighbouring lanes of one wave and relax their entry states as the subsequences
+// of the other kernels do -- part 0 exact, the others from a guess, states handed on by lane shuffles, no barrier --, a prefix sum
+// over the group gives first block and DC predictor, a last pass writes.  The padding bits at an interval's end may parse as more
+// symbols: blocks beyond the interval's last are neither written nor an error; too few blocks are.
+// (launched before it: the records of the restart-interval frames cleared, their status 0 -- the decoding workgroups only ever set it)
+__global__ __launch_bounds__(256) void jpeg_intervals_init_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
+                                                                  int16_t* __restrict__ records, long long rec_i16, int W, int H, int pitch, int rows,
+                                                                  int parts, int* __restrict__ status) {
+  const long long f = blockIdx.x / parts;
+  const int part = blockIdx.x % parts;
+  const mdc_jpeg_stream_header* hd = reinterpret_cast<const mdc_jpeg_stream_header*>(streams + f * stream_stride);
+  if (stream_kind(hd, W, H, pitch, rows, stream_stride) != 2) return;
+  int16_t* rec = records + f * rec_i16;
+  if (part == 0 && threadIdx.x < 64) reinterpret_cast<uint16_t*>(rec)[threadIdx.x] = hd->quant[threadIdx.x];
+  if (part == 0 && threadIdx.x == 64) status[f] = 0;
+  i32x4* body = reinterpret_cast<i32x4*>(rec + 64);
+  const long long n16 = (long long)pitch * rows * 8, per = (n16 + parts - 1) / parts;
+  const long long i0 = part * per, i1 = min(n16, i0 + per);
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) body[i] = i32x4{0, 0, 0, 0};
+}
+
+template <bool COLOR>
+__global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_intervals_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
+                                                                              int16_t* __restrict__ records, long long rec_i16, int W, int H, int pitch,
+                                                                              int rows, int* __restrict__ status, int slices) {
+  constexpr int NT = COLOR ? 4 : 2;
+  __shared__ HuffLds<NT> s_t;
   __shared__ int s_flag;
   const int tid = threadIdx.x;
-  const long long f = blockIdx.x;
+  const long long f = blockIdx.x / slices;  // `slices` workgroups per frame take the chunks of 1024 parts in turn: intervals are independent
+  const int slice = blockIdx.x % slices;
   const unsigned char* st = streams + f * stream_stride;
   const mdc_jpeg_stream_header* hd = reinterpret_cast<const mdc_jpeg_stream_header*>(st);
   if (stream_kind(hd, W, H, pitch, rows, stream_stride) != 2) return;
-  int16_t* rec = records + f * rec_i16;
   const ScanGeo g = scan_geo(hd, W, H, pitch);
-  const bool color = g.nb > 1;
-  if (color) load_tables<4, kIntervalThreads>(s_t, hd, tid);
-  else load_tables<2, kIntervalThreads>(reinterpret_cast<HuffLds<2>&>(s_t), hd, tid);
-  init_record<kIntervalThreads>(rec, hd, pitch, rows, tid);
+  if ((g.nb > 1) != COLOR) return;  // (the other instantiation's frame)
+  int16_t* rec = records + f * rec_i16;
+  const int ri = (int)hd->restart_interval, n_iv = (int)hd->n_intervals;
+  int lT = 0;  // log2 of the parts per interval
+  while (lT < 6 && (hd->ecs_bytes * 8u / (uint32_t)n_iv) >> (lT + 1) >= 384u) lT++;
+  if (slice && (long long)slice * kHuffThreads >= ((long long)n_iv << lT)) return;  // (more workgroups than chunks)
+  load_tables<NT, kHuffThreads>(s_t, hd, tid);
   if (tid == 0) s_flag = 0;
   __syncthreads();
-  // (HuffLds<2> is a prefix of HuffLds<4> only table by table: index through the layout that was filled)
-  const uint32_t* t1 = color ? &s_t.t1[0][0] : &reinterpret_cast<HuffLds<2>&>(s_t).t1[0][0];
-  const uint32_t* t2 = color ? &s_t.t2[0][0][0] : &reinterpret_cast<HuffLds<2>&>(s_t).t2[0][0][0];
-  const int ri = (int)hd->restart_interval, n_iv = (int)hd->n_intervals;
   const int mcus = g.nluma / g.hv;
-  const uint32_t* starts = reinterpret_cast<const uint32_t*>(st + sizeof(mdc_jpeg_stream_header) + (color ? 2 * sizeof(mdc_jpeg_huff) : 0));
+  const uint32_t* starts = reinterpret_cast<const uint32_t*>(st + sizeof(mdc_jpeg_stream_header) + (COLOR ? 2 * sizeof(mdc_jpeg_huff) : 0));
   const uint32_t ecs_bytes = hd->ecs_bytes;
   BitReader b;
   b.base = reinterpret_cast<const uint32_t*>(st + hd->ecs_offset);
@@ -872,68 +887,86 @@ __global__ __launch_bounds__(kIntervalThreads) void jpeg_huffman_intervals_kerne
   b.last = (ecs_bytes + 3) / 4 + 2;
   int16_t* coef = rec + 64;
   int bad = 0;
-  if ((long long)(n_iv - 1) * ri >= mcus || (long long)n_iv * ri < mcus) bad = 1;  // the interval table does not describe this frame
-  for (int iv = tid; iv < n_iv && !bad; iv += kIntervalThreads) {
+  const bool table_ok = !((long long)(n_iv - 1) * ri >= mcus || (long long)n_iv * ri < mcus);  // the interval table describes this frame
+  if (!table_ok) bad = 1;
+  const int T = 1 << lT;
+  const long long nparts = table_ok ? (long long)n_iv << lT : 0;
+  for (long long base = (long long)slice * kHuffThreads; base < nparts; base += (long long)slices * kHuffThreads) {  // (uniform over the workgroup)
+    const long long id = base + tid;
+    bool live = id < nparts;
+    const int iv = live ? (int)(id >> lT) : 0, j = (int)(id & (T - 1));
     const uint32_t b0 = starts[iv], b1 = iv + 1 < n_iv ? starts[iv + 1] : ecs_bytes;
-    if (b0 > b1 || b1 > ecs_bytes) {
+    if (live && (b0 > b1 || b1 > ecs_bytes)) {
       bad = 1;
-      break;
+      live = false;
     }
+    const uint32_t lo = b0 * 8u, hi = live ? b1 * 8u : lo;
     const int m0 = iv * ri, m1 = min(mcus, m0 + ri);
-    b.start(b0 * 8u);
-    int pred = 0;
-    for (int m = m0; m < m1; m++) {
-      for (int u = 0; u < g.nb; u++) {
-        const bool luma = u < g.hv;
-        int16_t* cur = luma ? luma_block(coef, m * g.hv + u, g) : nullptr;
-        const int tab = luma ? 0 : 2;
-        int z = 0;
-        while (z < 64) {
-          b.refill();
-          // (the symbol decoder of the relaxed kernels, inlined on raw table pointers: the LDS layout depends on the table count)
-          const int ac = z != 0;
-          uint32_t e = t1[(tab + ac) * 2048 + b.peek(11)];
-          if ((e & 31u) == 31u) e = t2[((tab + ac) * MDC_JPEG_HUFF_SUBTABLES + ((e >> 16) & (MDC_JPEG_HUFF_SUBTABLES - 1))) * 32 + ((uint32_t)(b.acc >> 48) & 31u)];
-          const int len = (int)(e & 31u), run = (int)((e >> 5) & 15u), size = (int)((e >> 9) & 15u);
-          if (len == 0 || len > 16 || (!ac && size > 11)) {
-            bad = 1;
-            break;
-          }
-          int v = 0;
-          if (e & (1u << 13)) {
-            b.skip(len + size);
-            v = (int)(int16_t)(e >> 16);
-          } else {
-            b.skip(len);
-            if (size) v = huff_extend(b.get(size), size);
-          }
-          if (!ac) {
-            z = 1;
-            if (luma) {
-              pred += v;
-              cur[0] = (int16_t)pred;
-            }
-          } else if (size == 0) {
-            z = run == 15 ? z + 16 : 64;
-          } else {
-            z += run;
-            if (z > 63) {
-              bad = 1;
-              break;
-            }
-            if (luma) cur[c_zigzag[z]] = (int16_t)v;
-            z++;
-          }
-        }
-        if (bad) break;
-      }
-      if (bad) break;
+    ScanGeo gi = g;
+    gi.nluma = m1 * g.hv;  // blocks past the interval's last are nobody's
+    const int first_block = m0 * g.hv, expected = (m1 - m0) * g.hv;
+    if (lT == 0) {  // one thread per interval: exact entry state, one pass
+      int nb = 0, bw = 0, pred = 0, oz, ou;
+      uint32_t ob = lo;
+      oz = 0;
+      if (lo < hi) huff_run<true, COLOR>(b, s_t, lo, 0, 0, hi, &ob, &oz, &ou, &nb, &bw, &pred, coef, first_block, gi);
+      // too few blocks, or the last one completed by a symbol that reaches into the next interval: damaged
+      if (live && (bw || nb < expected || (nb == expected && ob > hi && oz == 0))) bad = 1;
+      continue;
     }
-    if (!bad && b.pos() > b1 * 8u) bad = 1;  // ran into the next interval: damaged
+    uint32_t S = (((hi - lo) + (uint32_t)T - 1u) >> lT) + 31u & ~31u;
+    S = max(S, 32u);
+    const uint32_t my0 = (uint32_t)min((unsigned long long)hi, (unsigned long long)lo + (unsigned long long)j * S), my1 = min(hi, my0 + S);
+    uint32_t in_bit = my0, out_bit = my0;
+    int in_z = 0, out_z = 0, in_u = 0, out_u = 0, nblk = 0, badc = 0, dcsum = 0;
+    if (my0 < my1) {  // the guess: what the last quarter of the part gives its right neighbour
+      const uint32_t guess_bits = max((uint32_t)MDC_EXP_GUESS_MIN_BITS, S / MDC_EXP_GUESS_DIV);
+      const uint32_t from = my1 - my0 > guess_bits ? my1 - guess_bits : my0;
+      huff_run<false, COLOR>(b, s_t, from, 0, 0, my1, &out_bit, &out_z, &out_u, &nblk, &badc, &dcsum, nullptr, 0, gi);
+    }
+    for (int round = 0; round <= T; round++) {  // (every lane of the wave walks the same rounds: the shuffles need them all)
+      uint32_t nb = __shfl_up(out_bit, 1, T);
+      int nz = __shfl_up(out_z, 1, T), nu = __shfl_up(out_u, 1, T);
+      if (j == 0) {
+        nb = lo;
+        nz = 0;
+        nu = 0;
+      }
+      const bool changed = (round == 0 || nb != in_bit || nz != in_z || nu != in_u) && my0 < hi;
+      in_bit = nb;
+      in_z = nz;
+      in_u = nu;
+      if (!__any(changed ? 1 : 0)) break;
+      if (changed) {
+        nblk = 0;
+        badc = 0;
+        dcsum = 0;
+        out_bit = in_bit;
+        out_z = in_z;
+        out_u = in_u;
+        if (in_bit < my1) huff_run<false, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &out_bit, &out_z, &out_u, &nblk, &badc, &dcsum, nullptr, 0, gi);
+      }
+    }
+    // first block and DC predictor of every part: exclusive prefix sums over the interval's parts
+    int ia = nblk, ic = dcsum;
+    for (int d = 1; d < T; d <<= 1) {
+      const int ua = __shfl_up(ia, d, T), uc = __shfl_up(ic, d, T);
+      if (j >= d) {
+        ia += ua;
+        ic += uc;
+      }
+    }
+    const int total = __shfl(ia, T - 1, T);
+    const uint32_t end_bit = __shfl(out_bit, T - 1, T);
+    const int end_z = __shfl(out_z, T - 1, T);
+    int bw = 0, pred = ic - dcsum, dummy = 0, oz, ou;
+    uint32_t ob;
+    if (in_bit < my1) huff_run<true, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bw, &pred, coef, first_block + ia - nblk, gi);
+    if (live && (bw || total < expected || (total == expected && end_bit > hi && end_z == 0))) bad = 1;  // (as above)
   }
-  if (bad) s_flag = 1;
+  if (bad) s_flag = 1;  // (benign race: every writer writes 1)
   __syncthreads();
-  if (tid == 0) status[f] = s_flag ? 1 : 0;
+  if (tid == 0 && s_flag) atomicOr(&status[f], 1);
 }
 
 }  // namespace
@@ -997,8 +1030,12 @@ hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, voi
     if (kinds & 2u)
       jpeg_huffman_kernel<true><<<(unsigned)nframes, kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, d_status, kinds, 0u);
   }
-  if (kinds & 4u)
-    jpeg_huffman_intervals_kernel<<<(unsigned)nframes, kIntervalThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, d_status);
+  if (kinds & 4u) {  // (a frame is taken by the instantiation for its component count; small batches: several workgroups per frame)
+    const int slices = (int)std::max<int64_t>(1, std::min<int64_t>(8, 256 / nframes));
+    jpeg_intervals_init_kernel<<<(unsigned)(nframes * 8), 256, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, 8, d_status);
+    jpeg_huffman_intervals_kernel<false><<<(unsigned)(nframes * slices), kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, d_status, slices);
+    jpeg_huffman_intervals_kernel<true><<<(unsigned)(nframes * slices), kHuffThreads, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, d_status, slices);
+  }
   return hipGetLastError();
 }
 
