@@ -75,10 +75,11 @@
 // MDC_EXP_HUFF_ROUNDS (undefined): the Huffman kernel reports its relaxation rounds in the status word's upper bits
 // MDC_EXP_HUFF_VERIFY (undefined): the split Huffman kernel re-decodes every subsequence before the write pass and counts disagreements into the status word
 // MDC_EXP_HUFF_BAD_PROVISIONAL (undefined): fault injection -- the split Huffman kernel publishes wrong provisional states (right results, slower)
+// MDC_EXP_HUFF_FAKE_STREAM (undefined): the Huffman kernels' refills read one of 64 words (what do the divergent stream loads cost?)
 // MDC_EXP_HUFF_NOSTORE (undefined): the Huffman kernels' write pass stores DC terms only (what do the scattered 2-byte stores cost?)
 
 #if (MDC_EXP_SKIP_STORE || MDC_EXP_SKIP_LOAD || MDC_EXP_FAKE_COMPUTE || MDC_EXP_STRIP_NOCONVERT || MDC_EXP_STRIP_NOSAMPLE || \
-     MDC_EXP_TIMING || MDC_EXP_PAD_VALU || defined(MDC_EXP_HUFF_ROUNDS) || defined(MDC_EXP_HUFF_NOSTORE) || defined(MDC_EXP_HUFF_VERIFY) || defined(MDC_EXP_HUFF_BAD_PROVISIONAL)) && !defined(MDC_DIAGNOSIS_BUILD)
+     MDC_EXP_TIMING || MDC_EXP_PAD_VALU || defined(MDC_EXP_HUFF_ROUNDS) || defined(MDC_EXP_HUFF_NOSTORE) || defined(MDC_EXP_HUFF_FAKE_STREAM) || defined(MDC_EXP_HUFF_VERIFY) || defined(MDC_EXP_HUFF_BAD_PROVISIONAL)) && !defined(MDC_DIAGNOSIS_BUILD)
 #error "a diagnosis switch (wrong results / device printf) is set: build through mono_dataset_code_amd/build.py:build_variant, which defines MDC_DIAGNOSIS_BUILD and writes to variants/"
 #endif
 
@@ -118,6 +119,9 @@ inline const char* build_flags_string() {
 #endif
 #ifdef MDC_EXP_HUFF_NOSTORE
       " MDC_EXP_HUFF_NOSTORE",
+#endif
+#ifdef MDC_EXP_HUFF_FAKE_STREAM
+      " MDC_EXP_HUFF_FAKE_STREAM",
 #endif
 #ifdef MDC_EXP_HUFF_VERIFY
       " MDC_EXP_HUFF_VERIFY",

@@ -233,7 +233,11 @@ struct BitReader {
   // pointer.  One or the other for the whole workgroup: no choice per access.
   const uint32_t* src = nullptr;
   uint32_t lo = 0;
+#ifdef MDC_EXP_HUFF_FAKE_STREAM  // diagnosis (wrong results): every refill reads one of 64 words -- what do the stream loads cost?
+  __device__ __forceinline__ uint32_t raw(uint32_t i) const { return src[(max(min(i, last), lo) - lo) & 63u]; }
+#else
   __device__ __forceinline__ uint32_t raw(uint32_t i) const { return src[max(min(i, last), lo) - lo]; }  // (clamped both ways: an entry state may come from anywhere)
+#endif
   __device__ __forceinline__ void start(uint32_t bit) {
     widx = bit >> 5;
     const uint64_t w0 = __builtin_bswap32(raw(widx)), w1 = __builtin_bswap32(raw(widx + 1));
@@ -301,14 +305,19 @@ __device__ __forceinline__ int huff_symbol(BitReader& b, const HuffLds<NT>& T, i
 // that and writes final DC values, as the sequential decoder does (no pass over the record afterwards).
 // Block staging (WRITE, `stage` != nullptr): the coefficients of a block this thread starts AND finishes are collected in LDS --
 // dword p of the block at stage[p * kHuffThreads] (the pointer is already offset by the thread: a wave's lanes sit on 64 different
-// banks) -- and leave as whole 16-byte rows when the block is complete: 3-4 full stores per block instead of ~12 scattered 2-byte ones
-// (the L2's partial-write rate bounded the whole decoder at ~110 k frames/s; profiles/r04_experiments/05_*).  A block that straddles
-// two subsequences is written coefficient by coefficient, as before, by both sides -- their coefficient sets are disjoint.
+// banks) -- and leave as eight 16-byte rows when the block is complete instead of ~12 scattered 2-byte stores (the L2's partial-write
+// rate bounded the whole decoder at ~110 k frames/s; profiles/r04_experiments/05_*, 08_*).  A block that straddles two subsequences
+// is written coefficient by coefficient by both sides -- their coefficient sets are disjoint -- into a block the thread that BEGINS
+// it has cleared before anybody's write pass (clear_shared_block): with that, the record needs no zero-fill.
 constexpr int kHuffThreads = 1024;
+// WHOLE: ALL eight rows -- the block's 128-byte line is written whole (the L2 merges the eight stores; a line written in part is
+// read and modified in memory: non-zero rows only were 5 % slower at 256 frames per launch although 2.3 x fewer stores), and nobody has
+// to clear it beforehand.  Otherwise the non-zero rows only, into a record that was cleared (small launches: 7 % faster at 64 frames).
+template <bool WHOLE>
 __device__ __forceinline__ void stage_flush_rows(uint32_t* stage, int16_t* cur, unsigned long long cmask) {
 #pragma unroll 1
   for (int r = 0; r < 8; r++) {
-    if (!((cmask >> (8 * r)) & 0xffull)) continue;
+    if (!WHOLE && !((cmask >> (8 * r)) & 0xffull)) continue;
     i32x4 v;
     v.x = (int)stage[(4 * r + 0) * kHuffThreads];
     v.y = (int)stage[(4 * r + 1) * kHuffThreads];
@@ -331,7 +340,7 @@ __device__ __forceinline__ void stage_flush_scattered(uint32_t* stage, int16_t* 
   }
 }
 
-template <bool WRITE, bool COLOR, int NT>
+template <bool WRITE, bool COLOR, bool WHOLE = false, int NT = 2>
 __device__ __forceinline__ void huff_run(BitReader& b, const HuffLds<NT>& T, uint32_t bit, int z, int u, uint32_t end, uint32_t* out_bit, int* out_z,
                                          int* out_u, int* nblk, int* bad, int* dc, int16_t* coef, int q, const ScanGeo& g, uint32_t* stage = nullptr) {
   b.start(bit);
@@ -370,7 +379,7 @@ __device__ __forceinline__ void huff_run(BitReader& b, const HuffLds<NT>& T, uin
     }
 #endif
     if (z >= 64) {
-      if (WRITE && staged && cur && cmask) stage_flush_rows(stage, cur, cmask);
+      if (WRITE && staged && cur && cmask) stage_flush_rows<WHOLE>(stage, cur, cmask);
       staged = WRITE && stage;
       cmask = 0;
       z = 0;
@@ -398,6 +407,16 @@ __device__ __forceinline__ void load_tables(HuffLds<NT>& T, const mdc_jpeg_strea
     const mdc_jpeg_huff* h = k == 0 ? &hd->dc : k == 1 ? &hd->ac : &chroma[k - 2];
     for (int i = tid; i < 2048; i += THREADS) T.t1[k][i] = h->t1[i];
     for (int i = tid; i < MDC_JPEG_HUFF_SUBTABLES * 32; i += THREADS) (&T.t2[k][0][0])[i] = (&h->t2[0][0])[i];
+  }
+}
+// The block a subsequence begins and leaves to its right neighbours, cleared by the thread that begins it (block index = blocks
+// completed before and in the subsequence; an inherited block -- entered at z != 0, none completed -- is its beginner's).
+__device__ __forceinline__ void clear_shared_block(int16_t* coef, int first, int nblk, int in_z, int out_z, const ScanGeo& g) {
+  const int tb = first + nblk;
+  if (out_z != 0 && (nblk > 0 || in_z == 0) && tb < g.nluma) {
+    i32x4* blk = reinterpret_cast<i32x4*>(luma_block(coef, tb, g));
+#pragma unroll
+    for (int r = 0; r < 8; r++) blk[r] = i32x4{0, 0, 0, 0};
   }
 }
 // quantisation table -> record; record body zero-filled
@@ -472,12 +491,15 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
   const ScanGeo g = scan_geo(hd, W, H, pitch);
   const uint32_t ecs_bytes = hd->ecs_bytes;
   load_tables<NT, kHuffThreads>(s_t, hd, tid);
-  init_record<kHuffThreads>(rec, hd, pitch, rows, tid);
   uint32_t* stage = nullptr;
   if (stage_bytes >= 32u * kHuffThreads * 4u) {
     stage = s_dyn + tid;
     for (int k = 0; k < 32; k++) stage[k * kHuffThreads] = 0u;
   }
+  // with block staging every block leaves as a whole line or is cleared by the thread that begins it: no zero-fill of the record
+  const bool sparse_fill = !COLOR && stage != nullptr;
+  if (!sparse_fill) init_record<kHuffThreads>(rec, hd, pitch, rows, tid);
+  else if (tid < 64) reinterpret_cast<uint16_t*>(rec)[tid] = hd->quant[tid];
   if (tid == 0) s_flag = 0;
   __syncthreads();
   const uint32_t nbits = ecs_bytes * 8u;
@@ -535,12 +557,17 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(const unsign
   int first, pred, total, total_dc;
   scan_pair(nblk, dcsum, s_scan, tid, &first, &pred, &total, &total_dc);
   (void)total_dc;
+  if (sparse_fill) {
+    clear_shared_block(coef, first, nblk, in_z, out_z, g);
+    __syncthreads();
+  }
   // ---- write pass (the true states)
   int bad_w = 0;
   if (in_bit < my1) {
     int dummy = 0, oz, ou;
     uint32_t ob;
-    huff_run<true, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bad_w, &pred, coef, first, g, stage);
+    if (sparse_fill) huff_run<true, COLOR, true>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bad_w, &pred, coef, first, g, stage);
+    else huff_run<true, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bad_w, &pred, coef, first, g, stage);
   }
   // fewer blocks than the frame has: truncated or damaged.  More: the 1..7 padding bits after the last block can parse as
   // another (short-coded) block; those are never written.
@@ -580,14 +607,18 @@ constexpr int kHuffMaxSegments = MDC_EXP_HUFF_MAX_SEGMENTS;
 static_assert(kHuffMaxSegments == 1 || kHuffMaxSegments == 2 || kHuffMaxSegments == 4 || kHuffMaxSegments == 8, "segments per frame: a power of two up to 8");
 
 __global__ __launch_bounds__(256) void jpeg_record_init_kernel(const unsigned char* __restrict__ streams, long long stream_stride,
-                                                               int16_t* __restrict__ records, long long rec_i16, int pitch, int rows, int parts,
-                                                               SegState* __restrict__ seg, int G) {
+                                                               int16_t* __restrict__ records, long long rec_i16, int W, int H, int pitch, int rows,
+                                                               int parts, SegState* __restrict__ seg, int G, int stage_blocks) {
   const long long f = blockIdx.x / parts;
   const int part = blockIdx.x % parts;
   if (part == 0 && (int)threadIdx.x < G) seg[f * G + threadIdx.x] = SegState{0u, 0u, 0, 0, 0u, 0u, 0, 0u};  // (the split kernel is the next launch on the stream)
   const mdc_jpeg_stream_header* hd = reinterpret_cast<const mdc_jpeg_stream_header*>(streams + f * stream_stride);
   int16_t* rec = records + f * rec_i16;
   if (part == 0 && threadIdx.x < 64) reinterpret_cast<uint16_t*>(rec)[threadIdx.x] = hd->quant[threadIdx.x];
+  // (one-component frames with block staging clear what they must themselves; frames of the other kinds are left to their own kernels,
+  // but the three-component split kernel, which has no block staging, wants its record cleared here)
+  const int kind = stream_kind(hd, W, H, pitch, rows, stream_stride);
+  if (kind != 1 && !(kind == 0 && stage_blocks != 2)) return;
   i32x4* body = reinterpret_cast<i32x4*>(rec + 64);
   const long long n16 = (long long)pitch * rows * 8, per = (n16 + parts - 1) / parts;
   const long long i0 = part * per, i1 = min(n16, i0 + per);
@@ -630,6 +661,7 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
   // (the dynamic LDS holds EITHER the staged blocks of the write pass -- large grids, where the L2's partial-write rate binds -- OR
   // the segment's stream words -- small grids, where the divergent stream loads weigh more: the launcher decides)
   const bool block_staging = !COLOR && stage_blocks != 0 && lds_stream_bytes >= 32u * kHuffThreads * 4u;
+  const bool sparse_fill = block_staging && stage_blocks == 2;  // (whole blocks, no zero-fill: see stage_flush_rows)
   uint32_t* stage = nullptr;
   if (block_staging) {
     stage = s_stream + tid;
@@ -775,6 +807,10 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
   scan_pair(nblk, dcsum, s_scan, tid, &first, &pred, &total, &total_dc);
   first += base_blocks;
   pred += base_dc;
+  if (sparse_fill) {  // (before the publish: the right neighbour's write pass comes after its acquire of our final state)
+    if (entry_ok) clear_shared_block(coef, first, nblk, in_z, out_z, g);
+    __syncthreads();
+  }
   // ---- publish: the exit state of the last subsequence + blocks so far (the right neighbour waits for this)
   if (tid == kHuffThreads - 1) {
     my_seg->bit = out_bit;
@@ -792,7 +828,8 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_split_kernel(const 
   if (entry_ok && in_bit < my1) {
     int dummy = 0, oz, ou;
     uint32_t ob;
-    huff_run<true, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bad_w, &pred, coef, first, g, stage);
+    if (sparse_fill) huff_run<true, COLOR, true>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bad_w, &pred, coef, first, g, stage);
+    else huff_run<true, COLOR>(b, s_t, in_bit, in_z, in_u, my1, &ob, &oz, &ou, &dummy, &bad_w, &pred, coef, first, g, stage);
 #if defined(MDC_EXP_HUFF_VERIFY) && MDC_EXP_HUFF_VERIFY == 2  // diagnosis: the write pass against the counting pass of the same subsequence
     unsigned m = 0;
     if (pred - pred_in != dcsum) m += 1u;
@@ -1001,7 +1038,7 @@ hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, voi
     // dynamic LDS: one component, >= 48 frames -- 128 KB of block staging for the write pass (0.66 -> 0.55 ms per 64 frames; below
     // that it costs more than it saves: 0.46 -> 0.52 ms for 32); else the segment's stream bytes (96 KB; 72 with four tables; a
     // stream too long for it is read from global memory)
-    const int stage_blocks = nframes >= 48 ? 1 : 0;
+    const int stage_blocks = nframes > 64 ? 2 : nframes >= 48 ? 1 : 0;  // (2: whole blocks, no zero-fill of one-component records)
     const size_t pad = stage_blocks ? 128 * 1024 : 96 * 1024;
     hipError_t e = hipSuccess;
     {
@@ -1010,7 +1047,7 @@ hipError_t launch_jpeg_huffman(const void* d_streams, int64_t stream_stride, voi
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&jpeg_huffman_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
       if (e != hipSuccess) return e;
     }
-    jpeg_record_init_kernel<<<(unsigned)(nframes * 8), 256, 0, s>>>(st, stream_stride, rec, rec_i16, blocks_w, blocks_rows, 8, seg, G);
+    jpeg_record_init_kernel<<<(unsigned)(nframes * 8), 256, 0, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, 8, seg, G, stage_blocks);
     jpeg_huffman_split_kernel<false><<<(unsigned)(nframes * G), kHuffThreads, pad, s>>>(st, stream_stride, rec, rec_i16, w, h, blocks_w, blocks_rows, seg, G,
                                                                                         (uint32_t)pad, stage_blocks);
     jpeg_split_status_kernel<false><<<(unsigned)((nframes + 63) / 64), 64, 0, s>>>(st, stream_stride, w, h, blocks_w, blocks_rows, seg, G, d_status, kinds, (int)nframes);
