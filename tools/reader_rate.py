@@ -2,7 +2,8 @@
 """End-to-end sequence-reader rates on this box (decode + photometric + rectify, 1280x1024 -> 640x480, flags r+g+v+o):
 the reference reader as shipped (CPU, one thread), the reference's unmodified reader on this repo's drop-in classes,
 this repo's reader frame by frame (getImage) and batched (getImages), from an images/ folder of PNGs, from a zip of
-PNGs and from a zip of JPEGs.  usage: python tools/reader_rate.py [frames] (default 256)"""
+PNGs and from a zip of JPEGs (MDC_RATE_KINDS=folder_png,zip_png,zip_jpg; also zip_jpg_rst: restart intervals, zip_jpg_420 /
+zip_jpg_444: colour files).  usage: python tools/reader_rate.py [frames] (default 256)"""
 import io
 import os
 import subprocess
@@ -36,6 +37,11 @@ def make(kind):
         b = io.BytesIO()
         if kind == "zip_jpg":
             Image.fromarray(base[i % 8]).save(b, "JPEG", quality=90)
+        elif kind == "zip_jpg_rst":  # a restart interval per MCU row, as hardware encoders write them
+            Image.fromarray(base[i % 8]).save(b, "JPEG", quality=90, restart_marker_rows=1)
+        elif kind in ("zip_jpg_420", "zip_jpg_444"):  # colour files (cv::imread(..., GRAYSCALE) keeps the luma plane)
+            g = base[i % 8]
+            Image.fromarray(np.stack([g, np.roll(g, 5, 1), 255 - g], -1)).save(b, "JPEG", quality=90, subsampling=2 if kind == "zip_jpg_420" else 0)
         else:
             Image.fromarray(base[i % 8]).save(b, "PNG", compress_level=1)
         blobs.append(b.getvalue())
@@ -46,7 +52,7 @@ def make(kind):
     else:
         with zipfile.ZipFile(os.path.join(d, "images.zip"), "w", zipfile.ZIP_STORED) as z:
             for i, b in enumerate(blobs):
-                z.writestr("%05d.%s" % (i, "jpg" if kind == "zip_jpg" else "png"), b)
+                z.writestr("%05d.%s" % (i, "jpg" if kind.startswith("zip_jpg") else "png"), b)
     return d, sum(len(b) for b in blobs) / N
 
 
@@ -63,11 +69,11 @@ def run(binary, folder, passes, *extra, env=None):
 for kind in os.environ.get("MDC_RATE_KINDS", "folder_png,zip_png,zip_jpg").split(","):
     d, avg = make(kind)
     print("== %s: %d frames 1280x1024, %.0f KB/frame on disk" % (kind, N, avg / 1e3), flush=True)
-    if kind != "zip_jpg":  # the test shim's imread / imdecode stand-ins decode PNG (libpng), not JPEG
+    if not kind.startswith("zip_jpg"):  # the test shim's imread / imdecode stand-ins decode PNG (libpng), not JPEG
         print(run("reader_rate_ref", d, 1), flush=True)
         print(run("reader_rate_mdc", d, 2), flush=True)
     print(run("reader_rate_fast", d, 3), flush=True)
-    if kind == "zip_jpg":  # getImages: whole decode on the host vs Huffman on the host + inverse DCT on the GPU
+    if kind.startswith("zip_jpg"):  # getImages: whole decode on the host vs Huffman on the host + inverse DCT on the GPU
         print("-- getImages, JPEG decoded entirely on the host (MDC_GPU_JPEG=0):", flush=True)
         print(run("reader_rate_fast", d, 3, "batch", env={"MDC_GPU_JPEG": "0"}), flush=True)
         print("-- getImages, GPU JPEG stage 1 (host: Huffman decoding; device: dequantisation + inverse DCT; MDC_GPU_JPEG=1):", flush=True)
