@@ -34,6 +34,9 @@
 #ifndef MDC_EXP_GUESS_DIV
 #define MDC_EXP_GUESS_DIV 4  // device Huffman decoder: the first guess decodes the last 1/4 of the left neighbour's subsequence
 #endif
+#ifndef MDC_EXP_GRAD_ROWS
+#define MDC_EXP_GRAD_ROWS 8  // gradient kernel: rows per wave (its two halo rows are read again by the neighbouring bands)
+#endif
 #ifndef MDC_EXP_GUESS_MIN_BITS
 #define MDC_EXP_GUESS_MIN_BITS 512  // ... but at least this many bits (high qualities: ~250 bits per block, 512 bits are two blocks)
 #endif
@@ -75,11 +78,12 @@
 // MDC_EXP_HUFF_ROUNDS (undefined): the Huffman kernel reports its relaxation rounds in the status word's upper bits
 // MDC_EXP_HUFF_VERIFY (undefined): the split Huffman kernel re-decodes every subsequence before the write pass and counts disagreements into the status word
 // MDC_EXP_HUFF_BAD_PROVISIONAL (undefined): fault injection -- the split Huffman kernel publishes wrong provisional states (right results, slower)
+// MDC_EXP_GRAD_FAKE_READ (undefined): the gradient kernel reads the levels from a frame's first 16 KB (what does re-reading the levels cost the DSO path?)
 // MDC_EXP_HUFF_FAKE_STREAM (undefined): the Huffman kernels' refills read one of 64 words (what do the divergent stream loads cost?)
 // MDC_EXP_HUFF_NOSTORE (undefined): the Huffman kernels' write pass stores DC terms only (what do the scattered 2-byte stores cost?)
 
 #if (MDC_EXP_SKIP_STORE || MDC_EXP_SKIP_LOAD || MDC_EXP_FAKE_COMPUTE || MDC_EXP_STRIP_NOCONVERT || MDC_EXP_STRIP_NOSAMPLE || \
-     MDC_EXP_TIMING || MDC_EXP_PAD_VALU || defined(MDC_EXP_HUFF_ROUNDS) || defined(MDC_EXP_HUFF_NOSTORE) || defined(MDC_EXP_HUFF_FAKE_STREAM) || defined(MDC_EXP_HUFF_VERIFY) || defined(MDC_EXP_HUFF_BAD_PROVISIONAL)) && !defined(MDC_DIAGNOSIS_BUILD)
+     MDC_EXP_TIMING || MDC_EXP_PAD_VALU || defined(MDC_EXP_HUFF_ROUNDS) || defined(MDC_EXP_HUFF_NOSTORE) || defined(MDC_EXP_GRAD_FAKE_READ) || defined(MDC_EXP_HUFF_FAKE_STREAM) || defined(MDC_EXP_HUFF_VERIFY) || defined(MDC_EXP_HUFF_BAD_PROVISIONAL)) && !defined(MDC_DIAGNOSIS_BUILD)
 #error "a diagnosis switch (wrong results / device printf) is set: build through mono_dataset_code_amd/build.py:build_variant, which defines MDC_DIAGNOSIS_BUILD and writes to variants/"
 #endif
 
@@ -100,6 +104,7 @@ inline const char* build_flags_string() {
       MDC_CFG_ITEM(MDC_EXP_STRIP_LUT_REP, 8),
       MDC_CFG_ITEM(MDC_EXP_STRIP_WAVES_PER_EU, 5),
       MDC_CFG_ITEM(MDC_EXP_GUESS_DIV, 4),
+      MDC_CFG_ITEM(MDC_EXP_GRAD_ROWS, 8),
       MDC_CFG_ITEM(MDC_EXP_GUESS_MIN_BITS, 512),
       MDC_CFG_ITEM(MDC_EXP_HUFF_MAX_SEGMENTS, 8),
       MDC_CFG_ITEM(MDC_EXP_HUFF_PROVISIONAL, 1),
@@ -119,6 +124,9 @@ inline const char* build_flags_string() {
 #endif
 #ifdef MDC_EXP_HUFF_NOSTORE
       " MDC_EXP_HUFF_NOSTORE",
+#endif
+#ifdef MDC_EXP_GRAD_FAKE_READ
+      " MDC_EXP_GRAD_FAKE_READ",
 #endif
 #ifdef MDC_EXP_HUFF_FAKE_STREAM
       " MDC_EXP_HUFF_FAKE_STREAM",

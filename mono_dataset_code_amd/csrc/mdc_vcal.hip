@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void vcal_smooth_pass_kernel(const float* __re
 // of three stores at a 12-byte stride.  Up to four pyramid levels of a chunk of frames in ONE launch
 // (mdc_process_pyramid_gradients_batch_device): a workgroup finds its level from the first-block table.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kGradRows = 8, kGradThreads = 128;
+constexpr int kGradRows = MDC_EXP_GRAD_ROWS, kGradThreads = 128;
 struct GradLevels {
   const float* src[4];
   float* dI[4];
@@ -498,14 +498,26 @@ __global__ __launch_bounds__(kGradThreads) void gradients_levels_kernel(GradLeve
   const int npx = w * h;
   const float* p = g.src[l] + (long long)f * npx;
   float c[R + 2], lf[R], rt[R];
+#ifdef MDC_EXP_GRAD_FAKE_READ  // diagnosis (wrong results): every read of the levels comes from the frame's first 16 KB -- what do these reads cost?
+#define MDC_GRAD_IDX(i) ((i) & 4095)
+#else
+#define MDC_GRAD_IDX(i) (i)
+#endif
 #pragma unroll
-  for (int r = -1; r <= R; r++) c[r + 1] = p[min(max(y0 + r, 0), h - 1) * w + x];
+  for (int r = -1; r <= R; r++) c[r + 1] = p[MDC_GRAD_IDX(min(max(y0 + r, 0), h - 1) * w + x)];
+  // left / right neighbours (linear index +-1): the neighbouring lanes' centre values; only the wave's first lane and its last valid
+  // one load theirs (one instruction with two active lanes per row instead of two unaligned row loads)
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const int idx = min(y0 + r, h - 1) * w + x;
-    lf[r] = p[max(idx - 1, 0)];
-    rt[r] = p[min(idx + 1, npx - 1)];
+    float le = 0.f, re = 0.f;
+    if (lane == 0) le = p[MDC_GRAD_IDX(max(idx - 1, 0))];
+    if (lane == nvalid - 1) re = p[MDC_GRAD_IDX(min(idx + 1, npx - 1))];
+    const float up = __shfl_up(c[r + 1], 1), dn = __shfl_down(c[r + 1], 1);
+    lf[r] = lane == 0 ? le : up;
+    rt[r] = lane == nvalid - 1 ? re : dn;
   }
+#undef MDC_GRAD_IDX
   float* dI = g.dI[l] + ((long long)f * npx + (long long)y0 * w + x0) * 3;
   float* abs2 = g.abs2[l] + (long long)f * npx + (long long)y0 * w + x0;
 #pragma unroll
