@@ -289,11 +289,11 @@ int mdc_gradients_batch_device(mdc_ctx* ctx, const float* d_level, int w, int h,
 /* The DSO-style preprocessing of a batch in ONE call: base as mdc_process_batch_device, levels
  * 1..levels-1 as mdc_process_pyramid_batch_device, and for EVERY level l (0 = the base) the gradient images of
  * mdc_gradients_batch_device in d_dI[l] / d_abs_squared_grad[l] (nframes * (w>>l) * (h>>l) triples / floats) -- bit-identical
- * to the separate calls.  The batch is walked in chunks of frames (chunk_frames = 0: automatic, ~90 at 1280 x 1024): per
- * chunk one launch writes base + levels and ONE launch turns all levels of the chunk into gradient images while the tail of
- * them is still in the 256-MiB Infinity Cache.  (Gradients cannot come out of the
- * pyramid launch itself: a level-l pixel's neighbours lie up to 2^l base pixels outside the tile that produced it, in
- * other workgroups' registers) */
+ * to the separate calls.  The batch is walked in chunks of frames (chunk_frames = 0: automatic, 96 at 1280 x 1024): per
+ * chunk one launch writes base + levels and ONE launch turns all levels of the chunk into gradient images (chunks only bound
+ * the launch sizes: small ones lose to their tails).  (Gradients do not come out of the pyramid launch itself: a level-l
+ * pixel's neighbours lie up to 2^l base pixels outside the tile that produced it, in other workgroups' registers; what a
+ * fused launch could win is measured in DESIGN.md section 5.5.) */
 int mdc_process_pyramid_gradients_batch_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_base, int levels, float* const* d_levels,
                                                float* const* d_dI, float* const* d_abs_squared_grad, int64_t nframes, unsigned flags,
                                                int chunk_frames, void* stream);

@@ -722,8 +722,13 @@ int mdc_process_pyramid_gradients_batch_device(mdc_ctx* c, const uint8_t* d_in, 
   // 5.0 ms, 24: 4.2, 96: 3.85-3.89, separate launches over the whole batch: 3.87-3.95 -- the levels are NOT read back from the
   // Infinity Cache (the remap's stores are nontemporal: plain ones evict its prefetched source rows and measured slower in
   // total, experiment 11), the whole path runs at what the memory system gives 34.8 MB of writes + 7.6 MB of reads per
-  // frame; chunks exist to bound the launch sizes, and below ~100 frames they lose to their tails.
-  int64_t chunk = chunk_frames > 0 ? chunk_frames : std::max<int64_t>(1, (int64_t)((640u << 20) / level_bytes));
+  // frame; chunks exist to bound the launch sizes, and below ~100 frames they lose to their tails.  Round 4, frames/s by chunk:
+  // 91: 130.6 k, 6 x 86: 133 k, 96: 137-140 k, one chunk of 512: 134-137 k -- the automatic choice is 96 at 1280 x 1024.
+  int64_t chunk = chunk_frames;
+  if (chunk <= 0) {  // ~96 frames' worth at 1280 x 1024, a multiple of 32 (the remap launch's frames per workgroup divide it)
+    chunk = (int64_t)((672ull << 20) / level_bytes);
+    chunk = chunk >= 32 ? chunk / 32 * 32 : std::max<int64_t>(1, chunk);
+  }
   {  // a gradient launch holds a chunk's workgroups of up to four levels: fewer than 2^31 (128 x 8 pixels each)
     int64_t wgs = 0;
     for (int l = 0; l < std::min(levels, 4); l++) wgs += (int64_t)((lw[l] + 127) / 128) * ((lh[l] + 7) / 8);
