@@ -367,7 +367,8 @@ def test_gpu_huffman_stage_equals_the_host_decoder(size):
 
 def huffman_batches_equal_the_host_decoder(capi_dev, size, batch_sizes):
     """Records of mdc_jpeg_huffman_batch_device (through `capi_dev`: the product library or a variant build) against the host
-    decoder's, for batches of one-component and interleaved YCbCr files, every batch twice on the same buffers."""
+    decoder's, for batches of one-component and interleaved YCbCr files, with and without restart intervals (long ones: cut into
+    parts that relax inside a wave, several workgroups per frame in small batches), every batch twice on the same buffers."""
     import torch
 
     from mono_dataset_code_amd import capi
@@ -375,12 +376,15 @@ def huffman_batches_equal_the_host_decoder(capi_dev, size, batch_sizes):
     h, w = size
     rng = np.random.default_rng(h + w)
     files = []
-    for k in range(6):
+    for k in range(8):  # 0-3 one component, 4 / 5 YCbCr 4:4:4 / 4:2:0, 6 / 7 a restart interval per MCU row (one component / 4:2:0)
         img = textured(h, w, k) if k % 3 != 2 else rng.integers(0, 256, (h, w), dtype=np.uint8)
-        if k >= 4:
+        if k in (4, 5, 7):
             img = np.stack([img, np.roll(img, 3, 1), 255 - img], -1)
+        kw = {"subsampling": 2} if k in (5, 7) else {}
+        if k >= 6:
+            kw["restart_marker_rows"] = 1
         b = io.BytesIO()
-        Image.fromarray(img).save(b, "JPEG", quality=(35, 90, 97, 75, 88, 60)[k], **({"subsampling": 2} if k == 5 else {}))
+        Image.fromarray(img).save(b, "JPEG", quality=(35, 90, 97, 75, 88, 60, 90, 80)[k], **kw)
         files.append(b.getvalue())
     rec_bytes, pitch, rows = capi.jpeg_record_bytes(w, h)
     cap = (2 * capi.JPEG_STREAM_HEADER_BYTES + 4 * ((w + 7) // 8) * ((h + 7) // 8) + max(len(f) for f in files) + 64 + 15) & ~15
