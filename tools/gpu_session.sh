@@ -21,6 +21,7 @@
 #   reader / dso / huffman / vcal / distort   the secondary rate tools
 #   huffman_ab       the one-component Huffman decoder per library build (LIBS="product <variant> ...", mono_dataset_code_amd/variants/)
 #   huffman_trace    rocprofv3 --kernel-trace --stats of tools/huffman_rate.py (COUNTS=64: streams per call)
+#   reader_jpeg_trace  the same of the reader's getImages on a zip of N JPEGs (oracle/_ref/reader_rate_fast ... batch)
 set -u
 TAG=$1; shift
 cd "$GRAFT_REPO_ROOT"
@@ -114,6 +115,30 @@ PY
       ( cd /tmp && export TMPDIR=/tmp
         HUFF_KINDS=gray REPS=20 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/huff_trace" -- python "$GRAFT_REPO_ROOT/tools/huffman_rate.py" > "$OUT/huffman_trace.log" 2>&1 )
       f=$(find "$OUT/huff_trace" -name "*kernel_stats.csv" | head -1); cut -d, -f1-7 "$f" | grep -a "jpeg\|Name" | cut -c1-150 ;;
+    reader_jpeg_trace)  # rocprofv3 --kernel-trace --stats of the reader's JPEG path: getImages on a zip of N JPEGs, 6 passes
+      python3 - "$OUT" ${N:-1024} <<'PY' > "$OUT/reader_jpeg_make.txt" 2>&1
+import os, sys
+sys.argv = ["reader_rate.py", sys.argv[2]]
+os.environ["MDC_RATE_KINDS"] = ""
+sys.path.insert(0, os.path.join(os.environ["GRAFT_REPO_ROOT"], "tools"))
+src = open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "tools", "reader_rate.py")).read().split("\nfor kind in os.environ.get")[0]
+exec(compile(src, "reader_rate_head", "exec"))
+d, avg = make("zip_jpg")
+print("DATASET", d)
+PY
+      D=$(grep -a "^DATASET" "$OUT/reader_jpeg_make.txt" | cut -d" " -f2)
+      ( cd /tmp && export TMPDIR=/tmp
+        timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/reader_jpeg_trace" -- "$GRAFT_REPO_ROOT/oracle/_ref/reader_rate_fast" "$D" 1111 6 batch > "$OUT/reader_jpeg_trace.log" 2>&1 )
+      grep -a "READER_RATE reader" "$OUT/reader_jpeg_trace.log" | tail -1
+      f=$(find "$OUT/reader_jpeg_trace" -name "*kernel_stats.csv" | head -1); python3 - "$f" <<'PY'
+import csv, re, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+for r in rows:
+    m = re.search(r"(\w+_kernel)(<[^>]*>)?", r["Name"])
+    print("%-62s calls %5s  avg %8.1f us  total %8.2f ms  %5.1f %%" % (m.group(0) if m else r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, 100 * float(r["TotalDurationNs"]) / tot))
+PY
+      ;;
     distort) timeout 300 python tools/distort_rate.py > "$OUT/distort_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/distort_rate.txt" | tail -5 ;;
     vcal)    timeout 600 python tools/vcal_rate.py > "$OUT/vcal_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/vcal_rate.txt" | tail -20 ;;
     *) echo "unknown stage $stage" ;;
