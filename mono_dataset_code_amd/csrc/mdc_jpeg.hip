@@ -143,8 +143,8 @@ __global__ __launch_bounds__(kIdctThreads) void jpeg_idct_kernel(const int16_t* 
 // (mdc_jpeg_stream_header, include/mdc_hip.h): the host has parsed the file's markers, built the decode tables of the scan
 // and copied the entropy-coded segment with its FF00 byte stuffing (and its restart markers) removed -- 0.1 ms per frame,
 // against 2.5 ms for the Huffman decoding itself.  Output: the LUMA coefficient record the inverse-DCT kernel above reads
-// (what cv::imread(..., GRAYSCALE) keeps of a colour file: Y).  Three kernels, one per kind of stream; each leaves the
-// frames of the other kinds alone:
+// (what cv::imread(..., GRAYSCALE) keeps of a colour file: Y).  Three kernels, one per kind of stream, each leaves the
+// frames of the other kinds alone; launches of up to 128 frames spread a frame over several workgroups (further down):
 //
 //  * jpeg_huffman_kernel<false>: one component, no restart markers (what the TUM mono dataset ships).  One workgroup of
 //    1024 threads per frame.  The bit stream is cut into 1024 subsequences of S bits; thread i decodes [i S, (i+1) S) from an
@@ -156,11 +156,13 @@ __global__ __launch_bounds__(kIdctThreads) void jpeg_idct_kernel(const int16_t* 
 //    sequential decoder's state sequence; and because Huffman streams resynchronise after a few symbols (bit position) and
 //    every end-of-block resets z, wrong guesses heal inside one subsequence: 2-3 rounds in practice (the bound, 1024, only
 //    costs time).  Then prefix sums over the blocks each subsequence completed and over the DC differences it met give every
-//    thread its first block and its DC predictor, and a last pass decodes once more and WRITES the coefficients (the record
-//    is zero-filled first), DC terms as final values.
+//    thread its first block and its DC predictor, and a last pass decodes once more and WRITES the coefficients, DC terms as
+//    final values: a block a thread begins and finishes leaves LDS as its whole 128-byte line, a block two subsequences share
+//    is cleared by the thread that begins it and filled coefficient by coefficient (no zero-fill of the record).
 //  * jpeg_huffman_kernel<true>: three components interleaved in one scan (YCbCr baseline), no restart markers.  The same
 //    relaxation over a larger state: (bit, z, u), u = the block's position inside its MCU (hY x vY luma blocks, then Cb, then
-//    Cr), which picks the table pair; chroma symbols are decoded and dropped, luma blocks are counted and written.
+//    Cr), which picks the table pair; chroma symbols are decoded and dropped, luma blocks are counted and written (into a
+//    zero-filled record).  4:2:0 files need 6-8 rounds: a wrong u only heals when it happens to become right.
 //  * jpeg_huffman_intervals_kernel<C>: files with restart markers, one or three components.  Every restart interval starts at a
 //    byte the host has recorded, with z = 0 and all predictors 0: exact entry states -- a thread decodes whole short intervals
 //    front to back and writes final DC values directly; long intervals are cut into parts that relax inside a wave.
