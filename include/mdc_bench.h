@@ -10,25 +10,32 @@
 #define MDC_BENCH_H
 #include <stddef.h>
 #include <stdint.h>
+#ifndef MDC_API
+#if defined(__GNUC__) || defined(__clang__)
+#define MDC_API __attribute__((visibility("default")))
+#else
+#define MDC_API
+#endif
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
 
 /* Synthetic sequence generator: byte i of frame f = fmix32(seed + (first_frame+f)*npix + i) >> 24. */
-int mdcb_synth_frames_device(int device, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix, uint32_t seed, void* stream);
+MDC_API int mdcb_synth_frames_device(int device, uint8_t* d_out, int64_t first_frame, int64_t nframes, int npix, uint32_t seed, void* stream);
 
 /* A linear, arithmetic-free stream reading read_bytes from d_read (16-byte aligned) while writing write_bytes to d_write
  * with `blocks` workgroups of 256 (span = 0: grid-stride; 1: each workgroup walks its own contiguous span) -- the rate the
  * memory system of THIS box gives to a kernel's traffic mix, to normalise the kernel's own rate against; bench.py takes
  * the fastest of several (blocks, span) settings. */
-int mdcb_ceiling_mix_device(int device, const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes, int blocks, int span,
+MDC_API int mdcb_ceiling_mix_device(int device, const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes, int blocks, int span,
                             void* stream);
 
 /* Diagnosis (tools/mall_bracket.py): a device range of repeats * chunk_bytes virtual addresses that all map ONE physical
  * allocation of chunk_bytes (HIP virtual memory management; chunk_bytes must be a multiple of *out_granularity, which is
  * also returned on the -3 "not a whole number of pages" error).  Synchronous. */
-int mdcb_alias_alloc(int device, int64_t chunk_bytes, int repeats, void** out_ptr, int64_t* out_granularity);
-int mdcb_alias_free(int device, void* ptr, int64_t chunk_bytes, int repeats);
+MDC_API int mdcb_alias_alloc(int device, int64_t chunk_bytes, int repeats, void** out_ptr, int64_t* out_granularity);
+MDC_API int mdcb_alias_free(int device, void* ptr, int64_t chunk_bytes, int repeats);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,16 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The libraries are built with -fvisibility=hidden: the entry points marked MDC_API are the whole dynamic symbol table
+ * (tests/test_abi.py compares `nm -D` with this header, exactly). */
+#ifndef MDC_API
+#if defined(__GNUC__) || defined(__clang__)
+#define MDC_API __attribute__((visibility("default")))
+#else
+#define MDC_API
+#endif
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -133,46 +143,50 @@ typedef struct mdc_info {
 
 /* Creates a context on HIP device `device` (-1 = the calling thread's current
  * device).  MDC_ERR_NO_DEVICE if no GPU is visible. */
-int mdc_create(int device, mdc_ctx** out);
-int mdc_device_count(void); /* visible HIP devices (0 without a GPU or a usable runtime) */
-void mdc_destroy(mdc_ctx* ctx);
-const char* mdc_last_error(const mdc_ctx* ctx); /* never NULL; "" if no error; ctx may be NULL (creation errors) */
-int mdc_get_info(mdc_ctx* ctx, mdc_info* info);
-int mdc_set_option(mdc_ctx* ctx, int option, int value);
+MDC_API int mdc_create(int device, mdc_ctx** out);
+MDC_API int mdc_device_count(void); /* visible HIP devices (0 without a GPU or a usable runtime) */
+MDC_API void mdc_destroy(mdc_ctx* ctx);
+MDC_API const char* mdc_last_error(const mdc_ctx* ctx); /* never NULL; "" if no error; ctx may be NULL (creation errors) */
+MDC_API int mdc_get_info(mdc_ctx* ctx, mdc_info* info);
+MDC_API int mdc_set_option(mdc_ctx* ctx, int option, int value);
 /* Build-time switches of this library that are NOT at their shipped value, "NAME=value ..." (csrc/mdc_build_config.h):
  * "" for the product build.  Anything else is an experiment / debug / diagnosis build (mono_dataset_code_amd/variants/);
  * a diagnosis build computes wrong results on purpose and says MDC_DIAGNOSIS_BUILD here.  Never NULL, static storage. */
-const char* mdc_build_flags(void);
+MDC_API const char* mdc_build_flags(void);
+/* Identity of the kernel build: 16 hex digits of a SHA-256 over the library's sources, shared headers and compile flags,
+ * generated by the build recipe (mono_dataset_code_amd/build.py) and linked in.  Measurements recorded per kernel NAME
+ * (profiles/hbm_traffic.json) carry it, so that a changed kernel under an unchanged name cannot inherit stale figures. */
+MDC_API const char* mdc_code_id(void);
 
 /* ---- calibration tables (once per sequence) -------------------------------- */
 
 /* Uploads what PhotometricUndistorter's constructor builds
  * (src/PhotometricUndistorter.cpp:42-157): ginv = GInv[256] (NULL = validGamma
  * false), vignette_inv = vignetteMapInv[w*h] (NULL = validVignette false). */
-int mdc_set_photometric(mdc_ctx* ctx, const float* ginv, const float* vignette_inv, int w, int h);
+MDC_API int mdc_set_photometric(mdc_ctx* ctx, const float* ginv, const float* vignette_inv, int w, int h);
 
 /* Uploads what UndistorterFOV's constructor builds (src/FOVUndistorter.cpp:223-251):
  * remap_x/remap_y[out_w*out_h] in source pixels, (-1,-1) = black.  Plans the
  * tiled kernel (source window per output tile).  NULL tables clear the remap. */
-int mdc_set_remap(mdc_ctx* ctx, const float* remap_x, const float* remap_y, int in_w, int in_h, int out_w, int out_h);
+MDC_API int mdc_set_remap(mdc_ctx* ctx, const float* remap_x, const float* remap_y, int in_w, int in_h, int out_w, int out_h);
 
 /* ---- host-pointer, single-frame: under the reference's class methods -------- */
 
 /* PhotometricUndistorter::unMapImage(image_in, image_out, n, g, v, o)
  * (src/PhotometricUndistorter.cpp:165-212). */
-int mdc_unmap_host(mdc_ctx* ctx, const uint8_t* image_in, float* image_out, int n, unsigned flags);
+MDC_API int mdc_unmap_host(mdc_ctx* ctx, const uint8_t* image_in, float* image_out, int n, unsigned flags);
 
 /* UndistorterFOV::undistort<float> / <unsigned char>(input, output, nPixIn, nPixOut)
  * (src/FOVUndistorter.cpp:322-370).  MDC_ERR_STATE without a remap (the reference
  * returns silently, :325), MDC_ERR_SIZE on a pixel-count mismatch (:327-338);
  * `output` is untouched in both cases. */
-int mdc_undistort_host_f32(mdc_ctx* ctx, const float* input, float* output, int n_in, int n_out);
-int mdc_undistort_host_u8(mdc_ctx* ctx, const uint8_t* input, float* output, int n_in, int n_out);
+MDC_API int mdc_undistort_host_f32(mdc_ctx* ctx, const float* input, float* output, int n_in, int n_out);
+MDC_API int mdc_undistort_host_u8(mdc_ctx* ctx, const uint8_t* input, float* output, int n_in, int n_out);
 
 /* The whole of DatasetReader::getImage after decode (src/BenchmarkDatasetReader.h:207-241)
  * in one fused pass -- no W*H float intermediate (internalTempBuffer, :145,:222).
  * `out` holds out_w*out_h floats with MDC_RECTIFY, else in_w*in_h. */
-int mdc_process_host(mdc_ctx* ctx, const uint8_t* raw, float* out, unsigned flags);
+MDC_API int mdc_process_host(mdc_ctx* ctx, const uint8_t* raw, float* out, unsigned flags);
 
 /* ---- host-pointer, many frames: a sequence through PCIe ---------------------- */
 
@@ -180,15 +194,15 @@ int mdc_process_host(mdc_ctx* ctx, const uint8_t* raw, float* out, unsigned flag
  * to it run asynchronously at PCIe rate, so a reader that keeps its decoded frames and its
  * ExposureImage::image buffers (src/ExposureImage.h:45) in such memory overlaps transfers with
  * the kernels.  NULL on failure. */
-void* mdc_host_alloc(size_t bytes);
-void mdc_host_free(void* p);
+MDC_API void* mdc_host_alloc(size_t bytes);
+MDC_API void mdc_host_free(void* p);
 
 /* DatasetReader::getImage (src/BenchmarkDatasetReader.h:207-241, after decode) for nframes frames
  * in one call: raw[i] -> out[i], results identical to nframes mdc_process_host calls.  Frames go
  * through the GPU in chunks on two streams, so the upload of one chunk, the kernel of the next and
  * the download of the previous one overlap.  Any host memory works; pageable buffers make the HIP
  * runtime stage every copy (a few GB/s), mdc_host_alloc'ed ones reach the PCIe rate.  Blocking. */
-int mdc_process_frames_host(mdc_ctx* ctx, const uint8_t* const* raw, float* const* out, int64_t nframes,
+MDC_API int mdc_process_frames_host(mdc_ctx* ctx, const uint8_t* const* raw, float* const* out, int64_t nframes,
                             unsigned flags);
 
 /* JPEG ingest with the inverse DCT on the GPU.  The host does the serial half of JPEG decoding
@@ -200,9 +214,9 @@ int mdc_process_frames_host(mdc_ctx* ctx, const uint8_t* const* raw, float* cons
  * buffer the fused kernel reads, results come back as before.  Identical to decoding on the host and calling
  * mdc_process_frames_host, bit for bit (integer arithmetic).  mdc_jpeg_idct_batch_device is the device stage alone:
  * nframes records, record_bytes apart (multiple of 16), -> nframes * w * h bytes. */
-int mdc_process_jpeg_frames_host(mdc_ctx* ctx, const void* const* records, int64_t record_bytes, int blocks_w, int blocks_rows,
+MDC_API int mdc_process_jpeg_frames_host(mdc_ctx* ctx, const void* const* records, int64_t record_bytes, int blocks_w, int blocks_rows,
                                  float* const* out, int64_t nframes, unsigned flags);
-int mdc_jpeg_idct_batch_device(mdc_ctx* ctx, const void* d_records, int64_t record_bytes, uint8_t* d_frames, int w, int h, int blocks_w,
+MDC_API int mdc_jpeg_idct_batch_device(mdc_ctx* ctx, const void* d_records, int64_t record_bytes, uint8_t* d_frames, int w, int h, int blocks_w,
                                int blocks_rows, int64_t nframes, void* stream);
 
 /* JPEG ingest with the Huffman decoding on the GPU too.  The host only parses the file's markers, builds the decode
@@ -244,29 +258,29 @@ typedef struct mdc_jpeg_stream_header {
 } mdc_jpeg_stream_header; /* 24736 bytes; then, three components only: mdc_jpeg_huff dc_chroma, ac_chroma; then, with restart markers: uint32_t
                              start_byte[n_intervals] (offset of each interval inside the entropy-coded bytes, markers removed); then padding to
                              ecs_offset, the entropy-coded bytes, at least 16 zero bytes */
-int mdc_process_jpeg_streams_host(mdc_ctx* ctx, const void* const* streams, const int64_t* stream_bytes, float* const* out, int64_t nframes,
+MDC_API int mdc_process_jpeg_streams_host(mdc_ctx* ctx, const void* const* streams, const int64_t* stream_bytes, float* const* out, int64_t nframes,
                                   unsigned flags, int* status);
-int mdc_jpeg_huffman_batch_device(mdc_ctx* ctx, const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w,
+MDC_API int mdc_jpeg_huffman_batch_device(mdc_ctx* ctx, const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w,
                                   int h, int blocks_w, int blocks_rows, int64_t nframes, int* d_status, void* stream);
 
 /* ---- device-pointer, batched: the throughput path --------------------------- */
 
 /* unMapImage over nframes back-to-back frames (in: nframes*w*h u8; out: same count f32). */
-int mdc_unmap_batch_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags,
+MDC_API int mdc_unmap_batch_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags,
                            void* stream);
 
 /* getImage over nframes frames, fused photometric + remap when MDC_RECTIFY is set
  * (out: nframes*out_w*out_h f32), else identical to mdc_unmap_batch_device. */
-int mdc_process_batch_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags,
+MDC_API int mdc_process_batch_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags,
                              void* stream);
 
 /* undistort<float> over nframes float frames (in: nframes*in_w*in_h f32). */
-int mdc_undistort_batch_device_f32(mdc_ctx* ctx, const float* d_in, float* d_out, int64_t nframes, void* stream);
+MDC_API int mdc_undistort_batch_device_f32(mdc_ctx* ctx, const float* d_in, float* d_out, int64_t nframes, void* stream);
 
 /* 2x2 box pyramid (BASELINE.json config 5; NOT in the reference -- definition in
  * DESIGN.md): for each of nframes w*h f32 images writes levels 1..levels-1 into
  * d_levels[l-1] (each nframes*(w>>l)*(h>>l) f32).  levels counts level 0. */
-int mdc_pyramid_batch_device(mdc_ctx* ctx, const float* d_base, int w, int h, int levels, float* const* d_levels,
+MDC_API int mdc_pyramid_batch_device(mdc_ctx* ctx, const float* d_base, int w, int h, int levels, float* const* d_levels,
                              int64_t nframes, void* stream);
 
 /* getImage + box pyramid in ONE pass over the raw frames (config 5, the DSO-style preprocessing path):
@@ -274,7 +288,7 @@ int mdc_pyramid_batch_device(mdc_ctx* ctx, const float* d_base, int w, int h, in
  * would derive them from d_base -- bit-identical results.  With MDC_RECTIFY and an output made of whole
  * tiles (out_w % 64 == 0, out_h % tile rows == 0) levels 1..3 come out of the remap kernel's registers
  * (no re-read of the base); other geometries and levels >= 4 fall back to one pass per level. */
-int mdc_process_pyramid_batch_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_base, int levels,
+MDC_API int mdc_process_pyramid_batch_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_base, int levels,
                                      float* const* d_levels, int64_t nframes, unsigned flags, void* stream);
 
 /* DSO hand-off of one pyramid level (NOT in the reference: the per-level loop of DSO's
@@ -283,7 +297,7 @@ int mdc_process_pyramid_batch_device(mdc_ctx* ctx, const uint8_t* d_in, float* d
  *   d_dI                : nframes*w*h triples (I, dx, dy), dx = 0.5f*(I[i+1]-I[i-1]), dy = 0.5f*(I[i+w]-I[i-w]) over
  *                         the linear index range [w, w*(h-1)), non-finite differences -> 0, first / last row -> 0;
  *   d_abs_squared_grad  : nframes*w*h floats dx*dx + dy*dy. */
-int mdc_gradients_batch_device(mdc_ctx* ctx, const float* d_level, int w, int h, float* d_dI, float* d_abs_squared_grad,
+MDC_API int mdc_gradients_batch_device(mdc_ctx* ctx, const float* d_level, int w, int h, float* d_dI, float* d_abs_squared_grad,
                                int64_t nframes, void* stream);
 
 /* The DSO-style preprocessing of a batch in ONE call: base as mdc_process_batch_device, levels
@@ -294,7 +308,7 @@ int mdc_gradients_batch_device(mdc_ctx* ctx, const float* d_level, int w, int h,
  * the launch sizes: small ones lose to their tails).  (Gradients do not come out of the pyramid launch itself: a level-l
  * pixel's neighbours lie up to 2^l base pixels outside the tile that produced it, in other workgroups' registers; what a
  * fused launch could win is measured in DESIGN.md section 5.5.) */
-int mdc_process_pyramid_gradients_batch_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_base, int levels, float* const* d_levels,
+MDC_API int mdc_process_pyramid_gradients_batch_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_base, int levels, float* const* d_levels,
                                                float* const* d_dI, float* const* d_abs_squared_grad, int64_t nframes, unsigned flags,
                                                int chunk_frames, void* stream);
 
@@ -317,8 +331,8 @@ typedef struct mdc_fov_model {
  * reference built against glibc's libm: the kernel restates that library's fdlibm atanf, it does not
  * call the GPU math library's (which differs in the last bit).  The class method itself keeps running
  * on the host (it builds the remap tables); this entry point is the opt-in. */
-int mdc_distort_points_device(mdc_ctx* ctx, const mdc_fov_model* model, float* d_x, float* d_y, int64_t n, void* stream);
-int mdc_distort_points_host(mdc_ctx* ctx, const mdc_fov_model* model, float* x, float* y, int64_t n);
+MDC_API int mdc_distort_points_device(mdc_ctx* ctx, const mdc_fov_model* model, float* d_x, float* d_y, int64_t n, void* stream);
+MDC_API int mdc_distort_points_host(mdc_ctx* ctx, const mdc_fov_model* model, float* x, float* y, int64_t n);
 
 /* ---- vignetteCalib solver (src/main_vignetteCalib.cpp:395-527) ----------------------------------- */
 
@@ -331,14 +345,14 @@ int mdc_distort_points_host(mdc_ctx* ctx, const mdc_fov_model* model, float* x, 
  * Samples whose 2x2 footprint would leave the image -- the reference relies on its caller's mask (:345-357,
  * mdc_vcal_mask_coords_device) and would read out of bounds -- are skipped, in this step, in the atomic vignette step
  * and in the contribution index alike: all three always see the same sample set. */
-int mdc_vcal_plane_step_device(mdc_ctx* ctx, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
+MDC_API int mdc_vcal_plane_step_device(mdc_ctx* ctx, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
                                int n_plane, float* d_plane_color, const float* d_vignette_factor, int oth2, float* d_ff,
                                float* d_fc, double* d_er, void* stream);
 /* One "optimize vignette" half-iteration (:455-527): bilinear scatter of the plane colours into the image grid
  * (d_tt, d_ct: w*h floats, overwritten), new factor CT / TT (NaN where TT < 1) normalised to a maximum of 1 in
  * d_vignette_factor (read first for the residual test).  A scatter-add by concurrent float atomics: equal to the
  * reference to ~1e-6 relative, not bitwise (the reference sums sequentially). */
-int mdc_vcal_vignette_step_device(mdc_ctx* ctx, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w,
+MDC_API int mdc_vcal_vignette_step_device(mdc_ctx* ctx, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w,
                                   int h, int n_plane, const float* d_plane_color, float* d_vignette_factor, int oth2, float* d_tt,
                                   float* d_ct, double* d_er, void* stream);
 
@@ -352,12 +366,12 @@ int mdc_vcal_vignette_step_device(mdc_ctx* ctx, const float* d_images, const flo
  * synchronises `stream`.  Samples whose 2x2 footprint leaves the image (the reference's caller excludes them, :283-300)
  * are dropped instead of written out of bounds.  d_er = {E, R} as above (E in tree order). */
 typedef struct mdc_vcal_index mdc_vcal_index;
-int mdc_vcal_index_create(mdc_ctx* ctx, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
+MDC_API int mdc_vcal_index_create(mdc_ctx* ctx, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
                           int n_plane, void* stream, mdc_vcal_index** out);
-void mdc_vcal_index_destroy(mdc_vcal_index* index);
-int64_t mdc_vcal_index_bytes(const mdc_vcal_index* index);   /* device bytes of the contribution lists */
-int64_t mdc_vcal_index_entries(const mdc_vcal_index* index); /* list entries = 4 x valid samples */
-int mdc_vcal_vignette_step_indexed_device(mdc_ctx* ctx, const mdc_vcal_index* index, const float* d_plane_color,
+MDC_API void mdc_vcal_index_destroy(mdc_vcal_index* index);
+MDC_API int64_t mdc_vcal_index_bytes(const mdc_vcal_index* index);   /* device bytes of the contribution lists */
+MDC_API int64_t mdc_vcal_index_entries(const mdc_vcal_index* index); /* list entries = 4 x valid samples */
+MDC_API int mdc_vcal_vignette_step_indexed_device(mdc_ctx* ctx, const mdc_vcal_index* index, const float* d_plane_color,
                                           float* d_vignette_factor, int oth2, float* d_tt, float* d_ct, double* d_er, void* stream);
 
 /* The whole iteration loop :395-527 in one call: builds the contribution index, then max_iterations times the plane step
@@ -368,7 +382,7 @@ int mdc_vcal_vignette_step_indexed_device(mdc_ctx* ctx, const mdc_vcal_index* in
  * :391) are updated in place and end up bit-identical to the reference's arrays after the same iterations from the
  * same start.  er_out (host, may be NULL): max_iterations x {E, R of the plane step, E, R of the vignette step} -- what
  * the reference prints as "R residual terms => sqrtf(E/R)" (:449, :523). */
-int mdc_vcal_solve_device(mdc_ctx* ctx, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
+MDC_API int mdc_vcal_solve_device(mdc_ctx* ctx, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,
                           int n_plane, float* d_plane_color, float* d_vignette_factor, int max_iterations, int outlier_th,
                           double* er_out, void* stream);
 
@@ -376,27 +390,27 @@ int mdc_vcal_solve_device(mdc_ctx* ctx, const float* d_images, const float* d_p2
  * (an exposure of 0 counts as 1), in place on n_images stacked images of npix floats -- e.g. the output of
  * mdc_unmap_batch_device with MDC_GAMMA only, which is getImage(i, false, true, false, false) of :265.
  * d_exposure_times: n_images floats on the device. */
-int mdc_vcal_scale_images_device(mdc_ctx* ctx, float* d_images, int n_images, int64_t npix, float mean_exposure,
+MDC_API int mdc_vcal_scale_images_device(mdc_ctx* ctx, float* d_images, int n_images, int64_t npix, float mean_exposure,
                                  const float* d_exposure_times, void* stream);
 
 /* The gradient mask of the calibration images (:293-301; max_abs_grad = the reference's int maxAbsGrad, :130, default
  * 255): a pixel and a 5 x 5 neighbour that differ by more than max_abs_grad both become NaN, in place, with the
  * reference's raster-order semantics (a masked pixel no longer takes part) -- replayed exactly as a skewed wavefront,
  * one workgroup per image, n_images stacked w x h float images side by side.  Bit-identical to the reference. */
-int mdc_vcal_gradient_mask_device(mdc_ctx* ctx, float* d_images, int n_images, int w, int h, int max_abs_grad, void* stream);
+MDC_API int mdc_vcal_gradient_mask_device(mdc_ctx* ctx, float* d_images, int n_images, int w, int h, int max_abs_grad, void* stream);
 
 /* The step between distortCoordinates and the solver (:345-357): plane points whose image position, rounded as
  * (int)(v + 0.5), is not strictly inside (1, w-2) x (1, h-2) get NaN coordinates -- the "outside this image" marker the
  * two half-iterations test for (:409, :468).  In place on n coordinate pairs (n_images x n_plane in one call is fine: the
  * rule does not depend on the image).  With mdc_distort_points_device before it, the plane -> image coordinates never
  * leave the device. */
-int mdc_vcal_mask_coords_device(mdc_ctx* ctx, float* d_x, float* d_y, int64_t n, int w, int h, void* stream);
+MDC_API int mdc_vcal_mask_coords_device(mdc_ctx* ctx, float* d_x, float* d_y, int64_t n, int w, int h, void* stream);
 
 /* "dilate & smoothe vignette by 4 pixel for output" (:541-566): four passes of a NaN-aware 3 x 3 mean over the w x h
  * factor map (what the reference writes as vignetteSmoothed.png, i.e. the vignette image PhotometricUndistorter reads).
  * d_smoothed (result) and d_scratch are w*h floats each, distinct from each other; d_vignette_factor is not modified and
  * must not be d_scratch.  Bit-identical to the reference. */
-int mdc_vcal_smooth_device(mdc_ctx* ctx, const float* d_vignette_factor, int w, int h, float* d_smoothed, float* d_scratch,
+MDC_API int mdc_vcal_smooth_device(mdc_ctx* ctx, const float* d_vignette_factor, int w, int h, float* d_smoothed, float* d_scratch,
                            void* stream);
 
 /* Plan selection by measurement.  Which tile shape and workgroup length is fastest depends on the remap (window sizes)
@@ -413,7 +427,7 @@ typedef struct mdc_tune_result {
   float ms;        /* median launch time of the winner over the given batch */
   int candidates;  /* configurations that could be planned and timed */
 } mdc_tune_result;
-int mdc_tune_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, void* stream,
+MDC_API int mdc_tune_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, void* stream,
                     mdc_tune_result* result);
 
 /* Diagnostics: the kernel instantiation mdc_process_batch_device (pyramid_levels <= 1) or
@@ -421,7 +435,7 @@ int mdc_tune_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_out, int64_t nfr
  * options, spelt as rocprofv3 prints it without namespaces -- so a profile line can be matched to the kernel that ran.
  * (Measurement utilities -- the synthetic sequence generator, the linear-stream yardstick -- live in libmdc_bench.so,
  * include/mdc_bench.h: they are not part of this ABI.) */
-int mdc_describe_launch(mdc_ctx* ctx, unsigned flags, int pyramid_levels, char* buf, size_t cap);
+MDC_API int mdc_describe_launch(mdc_ctx* ctx, unsigned flags, int pyramid_levels, char* buf, size_t cap);
 
 /* ---- calibration hand-over between ranks (multi-GPU) ------------------------ */
 
@@ -429,11 +443,11 @@ int mdc_describe_launch(mdc_ctx* ctx, unsigned flags, int pyramid_levels, char* 
  * into one flat blob so that rank 0 can broadcast it (RCCL / gloo -- the caller's
  * collective) and the other ranks import it bit-identically.
  * mdc_export_tables(ctx, NULL, 0, &n) returns the size. */
-int mdc_export_tables(mdc_ctx* ctx, void* blob, size_t cap, size_t* size);
-int mdc_import_tables(mdc_ctx* ctx, const void* blob, size_t size);
+MDC_API int mdc_export_tables(mdc_ctx* ctx, void* blob, size_t cap, size_t* size);
+MDC_API int mdc_import_tables(mdc_ctx* ctx, const void* blob, size_t size);
 
 /* Blocks until the context's own streams (used by the *_host calls) are idle. */
-int mdc_synchronize(mdc_ctx* ctx);
+MDC_API int mdc_synchronize(mdc_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,14 @@
 #include "FOVUndistorter.h"
 #include "PhotometricUndistorter.h"
 
-class DatasetReader {
+#ifndef MDC_API  /* the libraries are built with -fvisibility=hidden: this marks what they export */
+#if defined(__GNUC__) || defined(__clang__)
+#define MDC_API __attribute__((visibility("default")))
+#else
+#define MDC_API
+#endif
+#endif
+class MDC_API DatasetReader {
  public:
   // `folder` with trailing slash, holding camera.txt, pcalib.txt, vignette.png, times.txt and either
   // images/ or images.zip (reference :86-148).  Prints the reference's log lines.

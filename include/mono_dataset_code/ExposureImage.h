@@ -13,12 +13,19 @@
 // plain `new float[w*h]` released with `delete[]`, as in the reference.
 #pragma once
 
+#ifndef MDC_API  /* the libraries are built with -fvisibility=hidden: this marks what they export */
+#if defined(__GNUC__) || defined(__clang__)
+#define MDC_API __attribute__((visibility("default")))
+#else
+#define MDC_API
+#endif
+#endif
 extern "C" {
-float* mdch_image_alloc(unsigned long nfloats);
-void mdch_image_free(float* block);
+MDC_API float* mdch_image_alloc(unsigned long nfloats);
+MDC_API void mdch_image_free(float* block);
 }
 
-class ExposureImage {
+class MDC_API ExposureImage {
  public:
   float* image;         // w*h irradiance / intensity values, row-major, owned
   double timestamp;     // seconds, from times.txt

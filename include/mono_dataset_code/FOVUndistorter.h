@@ -15,7 +15,14 @@
 struct mdc_ctx;
 struct MdcHostAccess;
 
-class UndistorterFOV {
+#ifndef MDC_API  /* the libraries are built with -fvisibility=hidden: this marks what they export */
+#if defined(__GNUC__) || defined(__clang__)
+#define MDC_API __attribute__((visibility("default")))
+#else
+#define MDC_API
+#endif
+#endif
+class MDC_API UndistorterFOV {
  public:
   UndistorterFOV(const char* configFileName);           // parses camera.txt, builds + uploads the remap
   UndistorterFOV();                                     // invalid object (reference :39-44)

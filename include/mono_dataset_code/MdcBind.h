@@ -16,7 +16,7 @@
 
 // Uploads the tables of the two objects (either may be NULL) into `ctx`.  Returns MDC_OK or the
 // status of mdc_set_photometric / mdc_set_remap.
-int mdc_bind_objects(mdc_ctx* ctx, const UndistorterFOV* fov, const PhotometricUndistorter* photo);
+MDC_API int mdc_bind_objects(mdc_ctx* ctx, const UndistorterFOV* fov, const PhotometricUndistorter* photo);
 
 // The lens model of `fov` for mdc_distort_points_* (distortCoordinates on the GPU).
-void mdc_fov_model_of(const UndistorterFOV& fov, mdc_fov_model* model);
+MDC_API void mdc_fov_model_of(const UndistorterFOV& fov, mdc_fov_model* model);

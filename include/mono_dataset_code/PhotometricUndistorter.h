@@ -12,7 +12,14 @@
 struct mdc_ctx;
 struct MdcHostAccess;
 
-class PhotometricUndistorter {
+#ifndef MDC_API  /* the libraries are built with -fvisibility=hidden: this marks what they export */
+#if defined(__GNUC__) || defined(__clang__)
+#define MDC_API __attribute__((visibility("default")))
+#else
+#define MDC_API
+#endif
+#endif
+class MDC_API PhotometricUndistorter {
  public:
   PhotometricUndistorter(std::string file, std::string vignetteImage, int w, int h);
   ~PhotometricUndistorter();

@@ -23,11 +23,11 @@ LIB_HOST = os.path.join(PKG, "libmdc_host.so")
 
 HIP_SOURCES = [os.path.join(CSRC, f) for f in ("mdc_kernels.hip", "mdc_vcal.hip", "mdc_jpeg.hip", "mdc_capi.hip", "mdc_plan.hip", "mdc_host_calls.hip",
                                                 "mdc_pipeline.hip")]
-HIP_DEPS = HIP_SOURCES + [os.path.join(CSRC, "mdc_internal.h"), os.path.join(CSRC, "mdc_ctx.h"), os.path.join(CSRC, "mdc_build_config.h"), os.path.join(CSRC, "fov_point_model.h"), os.path.join(INC, "mdc_hip.h")]
+HIP_DEPS = HIP_SOURCES + [os.path.join(CSRC, "mdc_exports.map"), os.path.join(CSRC, "mdc_internal.h"), os.path.join(CSRC, "mdc_ctx.h"), os.path.join(CSRC, "mdc_build_config.h"), os.path.join(CSRC, "fov_point_model.h"), os.path.join(INC, "mdc_hip.h")]
 HOST_SOURCES = [os.path.join(HOST, f) for f in (
     "fov_undistorter.cpp", "photometric_undistorter.cpp", "gray_png.cpp", "host_device.cpp", "mdc_host_capi.cpp",
     "image_codecs.cpp", "image_codecs_ext.cpp", "zip_reader.cpp", "image_pool.cpp", "dataset_reader.cpp")]
-HOST_DEPS = HOST_SOURCES + [os.path.join(HOST, "gray_png.h"), os.path.join(HOST, "host_device.h"),
+HOST_DEPS = HOST_SOURCES + [os.path.join(HOST, "mdc_host_exports.map"), os.path.join(HOST, "gray_png.h"), os.path.join(HOST, "host_device.h"),
                             os.path.join(HOST, "image_codecs.h"), os.path.join(HOST, "image_codecs_internal.h"), os.path.join(HOST, "zip_reader.h"),
                             os.path.join(INC, "mono_dataset_code", "BenchmarkDatasetReader.h"),
                             os.path.join(INC, "mdc_hip.h"), os.path.join(INC, "mdc_host.h"),
@@ -37,9 +37,13 @@ HOST_DEPS = HOST_SOURCES + [os.path.join(HOST, "gray_png.h"), os.path.join(HOST,
                             os.path.join(INC, "mono_dataset_code", "MdcBind.h")]
 
 # -ffp-contract=off: the reference is built without FMA; contraction would break bit parity.
+# -fvisibility=hidden: only what include/mdc_hip.h marks MDC_API is exported (tests/test_abi.py: exported set == header set).
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-             "-fno-fast-math", "-Wall", "-Wno-unused-function"]
-HOST_FLAGS = ["-O2", "-std=c++11", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
+             "-fno-fast-math", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wall", "-Wno-unused-function"]
+HOST_FLAGS = ["-O2", "-std=c++11", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wall"]
+HOST_EXPORT_MAP = os.path.join(HOST, "mdc_host_exports.map")
+# what still leaks through -fvisibility=hidden (libstdc++ template instantiations are declared with default visibility): made local
+EXPORT_MAP = os.path.join(CSRC, "mdc_exports.map")
 
 
 def _stale(target, deps):
@@ -72,6 +76,23 @@ def eigen_include():
     return EIGEN_STUB
 
 
+def code_id(defines=()):
+    """16 hex digits over everything the kernels are made of: sources, shared headers, compile flags, -D list, compiler version."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sorted(HIP_DEPS):
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(HIP_FLAGS + sorted(defines)).encode())
+    try:
+        h.update(subprocess.run([hipcc(), "--version"], stdout=subprocess.PIPE).stdout)
+    except OSError:
+        pass
+    return h.hexdigest()[:16]
+
+
 def _compile_link_hip(out, defines=(), objdir_tag="product"):
     """Every .hip translation unit -> its own object, in parallel (the kernels TU alone takes a minute), then one link.
     An object is redone when its source, a shared header or the -D list changed."""
@@ -93,7 +114,13 @@ def _compile_link_hip(out, defines=(), objdir_tag="product"):
     with open(stamp, "w") as f:
         f.write(" ".join(flags))
     objs = [os.path.join(objdir, os.path.basename(src) + ".o") for src in HIP_SOURCES]
-    _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
+    # mdc_code_id(): the identity of this build (include/mdc_hip.h), a generated one-line translation unit
+    idsrc = os.path.join(objdir, "mdc_code_id.cpp")
+    with open(idsrc, "w") as f:
+        f.write('#include "mdc_hip.h"\nextern "C" const char* mdc_code_id(void) { return "%s"; }\n' % code_id(defines))
+    idobj = idsrc + ".o"
+    _run(["g++", "-O1", "-fPIC", "-fvisibility=hidden", "-I" + INC, "-c", idsrc, "-o", idobj])
+    _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + EXPORT_MAP] + objs + [idobj, "-o", out])
 
 
 def build_hip(force=False):
@@ -109,7 +136,7 @@ def build_host(force=False):
     if force or _stale(LIB_HOST, HOST_DEPS + [LIB_HIP]):
         _run(["g++"] + HOST_FLAGS + ["-I" + INC, "-I" + os.path.join(INC, "mono_dataset_code"), "-I" + HOST,
                                      "-I" + eigen_include()] + HOST_SOURCES +
-             ["-L" + PKG, "-lmdc_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-lpthread", "-ldl", "-o", LIB_HOST])
+             ["-L" + PKG, "-lmdc_hip", "-Wl,-rpath,$ORIGIN", "-Wl,--version-script=" + HOST_EXPORT_MAP, "-lz", "-lpthread", "-ldl", "-o", LIB_HOST])
     return LIB_HOST
 
 
@@ -119,8 +146,9 @@ BENCH_SOURCE = os.path.join(CSRC, "bench", "mdc_bench.hip")
 
 def build_bench(force=False):
     """libmdc_bench.so: measurement / test utilities (include/mdc_bench.h) -- not part of the product, not linked by it."""
-    if force or _stale(LIB_BENCH, [BENCH_SOURCE, os.path.join(INC, "mdc_bench.h")]):
-        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + INC, BENCH_SOURCE, "-o", LIB_BENCH])
+    if force or _stale(LIB_BENCH, [BENCH_SOURCE, os.path.join(INC, "mdc_bench.h"), EXPORT_MAP]):
+        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-I" + INC, BENCH_SOURCE,
+              "-Wl,--version-script=" + EXPORT_MAP, "-o", LIB_BENCH])
     return LIB_BENCH
 
 
@@ -131,9 +159,10 @@ MULTI_SOURCE = os.path.join(CSRC, "mdc_multi.hip")
 def build_multi(force=False):
     """libmdc_multi.so: one process, N GPUs, RCCL table broadcast (include/mdc_multi.h)."""
     build_hip(force)
-    if force or _stale(LIB_MULTI, [MULTI_SOURCE, os.path.join(INC, "mdc_multi.h"), os.path.join(INC, "mdc_hip.h"), LIB_HIP]):
+    if force or _stale(LIB_MULTI, [MULTI_SOURCE, os.path.join(INC, "mdc_multi.h"), os.path.join(INC, "mdc_hip.h"), LIB_HIP, EXPORT_MAP]):
         rocm = os.path.dirname(os.path.dirname(os.path.realpath(hipcc())))
-        _run([hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + INC, MULTI_SOURCE,
+        _run([hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-I" + INC, MULTI_SOURCE,
+              "-Wl,--version-script=" + EXPORT_MAP,
               "-L" + PKG, "-lmdc_hip", "-L" + os.path.join(rocm, "lib"), "-lrccl", "-lpthread",
               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", LIB_MULTI])
     return LIB_MULTI

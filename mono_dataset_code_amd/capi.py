@@ -28,7 +28,7 @@ OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM = 0, -1, -2,
 
 # every symbol include/mdc_hip.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = [
-    "mdc_create", "mdc_destroy", "mdc_device_count", "mdc_last_error", "mdc_build_flags", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
+    "mdc_create", "mdc_destroy", "mdc_device_count", "mdc_last_error", "mdc_build_flags", "mdc_code_id", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
     "mdc_set_remap", "mdc_unmap_host", "mdc_undistort_host_f32", "mdc_undistort_host_u8", "mdc_process_host",
     "mdc_host_alloc", "mdc_host_free", "mdc_process_frames_host", "mdc_process_jpeg_frames_host", "mdc_jpeg_idct_batch_device", "mdc_process_jpeg_streams_host", "mdc_jpeg_huffman_batch_device",
     "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
@@ -129,6 +129,9 @@ def hip_lib():
         if hasattr(L, "mdc_build_flags"):  # (absent from libraries built before round 4: tools/sweep.py --libs)
             L.mdc_build_flags.argtypes = []
             L.mdc_build_flags.restype = C.c_char_p
+        if hasattr(L, "mdc_code_id"):  # (absent from libraries built before round 5)
+            L.mdc_code_id.argtypes = []
+            L.mdc_code_id.restype = C.c_char_p
         L.mdc_get_info.argtypes = [_vp, C.POINTER(MdcInfo)]
         L.mdc_set_option.argtypes = [_vp, _i, _i]
         L.mdc_set_photometric.argtypes = [_vp, _vp, _vp, _i, _i]
@@ -185,7 +188,7 @@ def hip_lib():
         for n in HIP_SYMBOLS:
             if old_build and not hasattr(L, n):
                 continue
-            if n not in ("mdc_destroy", "mdc_last_error", "mdc_build_flags", "mdc_host_alloc", "mdc_host_free", "mdc_vcal_index_destroy",
+            if n not in ("mdc_destroy", "mdc_last_error", "mdc_build_flags", "mdc_code_id", "mdc_host_alloc", "mdc_host_free", "mdc_vcal_index_destroy",
                          "mdc_vcal_index_bytes", "mdc_vcal_index_entries"):
                 getattr(L, n).restype = _i
         _hip = L
@@ -196,6 +199,12 @@ def build_flags():
     """Build-time switches of the loaded libmdc_hip.so that are not at their shipped value ("" = the product build)."""
     L = hip_lib()
     return L.mdc_build_flags().decode() if hasattr(L, "mdc_build_flags") else "unknown (library predates mdc_build_flags)"
+
+
+def code_id():
+    """Identity of the loaded libmdc_hip.so's kernel build (hash of sources + flags, include/mdc_hip.h: mdc_code_id)."""
+    L = hip_lib()
+    return L.mdc_code_id().decode() if hasattr(L, "mdc_code_id") else None
 
 
 def host_lib():

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "mdc_hip.h"
+#include "mdc_host.h"  // the MDC_API (exported) declarations of the mdch_image_* functions defined below
 
 namespace {
 

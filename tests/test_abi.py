@@ -27,6 +27,74 @@ def test_libmdc_hip_exports_header():
         assert hasattr(lib, n), n
 
 
+def exported(lib):
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], stdout=subprocess.PIPE, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
+def test_exported_symbols_are_exactly_the_headers():
+    """-fvisibility=hidden + MDC_API + a version script: the dynamic symbol table of every C-ABI library is the set of functions its
+    header declares, nothing more (round 4 exported ~70 internal mdc:: C++ symbols beside the ABI)."""
+    import subprocess
+
+    from mono_dataset_code_amd import build
+
+    assert exported(build.LIB_HIP) == declared("mdc_hip.h", "mdc_")
+    assert exported(build.LIB_MULTI) == declared("mdc_multi.h", "mdc_multi_")
+    assert exported(build.LIB_BENCH) == declared("mdc_bench.h", "mdcb_")
+    # the host library: the C facade + the reference's classes and the two binding helpers (C++ linkage), nothing internal
+    host = exported(build.LIB_HOST)
+    assert sorted(n for n in host if not n.startswith("_Z")) == declared("mdc_host.h", "mdch_")
+    dem = subprocess.run(["c++filt"], input="\n".join(n for n in host if n.startswith("_Z")), stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines()
+    for d in dem:
+        assert re.match(r"(void )?(UndistorterFOV|PhotometricUndistorter|DatasetReader|ExposureImage)::|mdc_bind_objects\(|mdc_fov_model_of\(", d), d
+    for txt in (open(os.path.join(ROOT, "include", h)).read() for h in ("mdc_hip.h", "mdc_host.h", "mdc_multi.h", "mdc_bench.h")):
+        for line in txt.splitlines():  # every declaration carries the marker
+            if re.match(r"(const char\*|int64_t|int|void\*?|long long|float\*?|unsigned long|size_t|double|mdch?_\w+\*)\s+mdc\w+\(", line):
+                raise AssertionError("declaration without MDC_API: " + line)
+
+
+def test_code_id_names_the_build():
+    """mdc_code_id(): the hash of sources + flags the library was made from == what the build recipe computes for the tree."""
+    from mono_dataset_code_amd import build, capi
+
+    assert re.fullmatch(r"[0-9a-f]{16}", capi.code_id())
+    assert capi.code_id() == build.code_id()
+    import ctypes
+
+    dbg = ctypes.CDLL(build.build_debug())
+    dbg.mdc_code_id.restype = ctypes.c_char_p
+    assert dbg.mdc_code_id().decode() == build.code_id(["MDC_DEBUG_BOUNDS=1"]) != capi.code_id()
+
+
+def test_stale_traffic_entries_are_refused(tmp_path):
+    """bench.py quotes profiles/hbm_traffic.json only for the kernel instantiation AND the build it was measured on."""
+    import json
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    p = tmp_path / "hbm_traffic.json"
+    p.write_text(json.dumps({"fused:k<1>": {"kernel": "k<1>", "bytes_per_frame": 100.0, "code_id": "aaaaaaaaaaaaaaaa", "source": "profiles/x.json"},
+                             "old:k<2>": {"kernel": "k<2>", "bytes_per_frame": 7.0, "source": "profiles/old.json"}}))
+    assert bench.traffic_from_profiles("k<1>", 10, "aaaaaaaaaaaaaaaa", str(p)) == (1000, "profiles/x.json")
+    t, why = bench.traffic_from_profiles("k<1>", 10, "bbbbbbbbbbbbbbbb", str(p))
+    assert t is None and "stale" in why and "aaaaaaaaaaaaaaaa" in why and "bbbbbbbbbbbbbbbb" in why
+    t, why = bench.traffic_from_profiles("k<2>", 10, "bbbbbbbbbbbbbbbb", str(p))  # recorded before builds were identified: refused too
+    assert t is None and "unrecorded" in why
+    assert bench.traffic_from_profiles("k<3>", 10, "bbbbbbbbbbbbbbbb", str(p)) == (None, None)
+    # the committed file: whatever it holds for the current build is quoted, anything else is not
+    from mono_dataset_code_amd import capi
+
+    for e in json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).values():
+        t, why = bench.traffic_from_profiles(e["kernel"], 1, capi.code_id())
+        assert (t is not None) == any(x.get("kernel") == e["kernel"] and x.get("code_id") == capi.code_id()
+                                      for x in json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).values())
+
+
 def test_bench_utilities_are_not_in_the_product_abi():
     """The synthetic frame generator and the linear-stream yardstick live in libmdc_bench.so (include/mdc_bench.h); the
     product libraries neither export nor import them."""

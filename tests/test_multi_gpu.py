@@ -140,7 +140,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path, oracle):
     shard, barrier + max-over-ranks timing, one JSON line from rank 0) with two ranks sharing the one GPU
     of the test box: gloo carries the collectives there (RCCL wants one device per rank).  EVERY rank's first
     three outputs are compared with the oracle for their global frame indices."""
-    out = _bench(["--gpus", "2", "--steps", "5", "--warmup", "2", "--frames", "64", "--preroll-s", "0.05",
+    out = _bench(["--gpus", "2", "--steps", "5", "--warmup", "2", "--frames", "64", "--preroll-s", "0.05", "--preroll-max-s", "0.2",
                   "--dump-dir", str(tmp_path), "--dump-frames", "3"], env={"MDC_BENCH_BACKEND": "gloo"}, nproc=2)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 5
     assert out["config"]["frames_per_gpu_per_step"] == 64 and "cpu_baseline" not in out
@@ -158,7 +158,7 @@ def test_bench_launches_its_own_ranks(tmp_path, oracle):
     import torch
 
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    out = _bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--frames", "64", "--preroll-s", "0.05", "--dump-dir", str(tmp_path),
+    out = _bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--frames", "64", "--preroll-s", "0.05", "--preroll-max-s", "0.2", "--dump-dir", str(tmp_path),
                   "--dump-frames", "2"], env=dict(env, MDC_BENCH_BACKEND="gloo"), clean_env=True)
     assert out["n_gpus"] == 2 and out["ranks"]["world"] == 2 and out["ranks"]["backend"] == "gloo"
     assert [d["rank"] for d in out["ranks"]["devices"]] == [0, 1]
@@ -179,7 +179,7 @@ def test_bench_launches_its_own_ranks(tmp_path, oracle):
 def test_bench_seq50k_sharding_two_ranks(tmp_path, oracle):
     """BASELINE.json configs[3] (one sequence, frame f on GPU f % N), shrunk to 2 x 40 frames: strong scaling line,
     per-rank outputs equal to the oracle for the global indices."""
-    out = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "seq50k", "--frames", "40", "--preroll-s", "0.05",
+    out = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "seq50k", "--frames", "40", "--preroll-s", "0.05", "--preroll-max-s", "0.2",
                   "--dump-dir", str(tmp_path), "--dump-frames", "2", "--no-ceiling"], env={"MDC_BENCH_BACKEND": "gloo"}, nproc=2, port=29537)
     assert out["scaling"] == "strong" and out["config"]["sequence_frames"] == 80 and out["config"]["frames_per_gpu_per_step"] == 40
     assert out["parity"]["mismatching_pixels"] == 0
@@ -190,7 +190,7 @@ def test_bench_seq50k_sharding_two_ranks(tmp_path, oracle):
 def test_bench_rccl_branch_executes_with_a_world_of_one(tmp_path):
     """The "nccl" (= RCCL) branch of bench.py on the one GPU of the test box: process-group init on the device, the
     table broadcast, the barriers and the all-reduce / all-gather all run through RCCL with world size 1."""
-    out = _bench(["--gpus", "1", "--steps", "4", "--warmup", "1", "--frames", "128", "--preroll-s", "0.05", "--no-cpu-baseline"],
+    out = _bench(["--gpus", "1", "--steps", "4", "--warmup", "1", "--frames", "128", "--preroll-s", "0.05", "--preroll-max-s", "0.2", "--no-cpu-baseline"],
                  env={"MDC_BENCH_FORCE_DIST": "1", "MDC_BENCH_BACKEND": "nccl", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
                       "MASTER_PORT": "29539"})
     assert out["n_gpus"] == 1 and out["config"]["collective_backend"] == "nccl"
@@ -204,6 +204,6 @@ def test_bench_rccl_branch_executes_with_a_world_of_one(tmp_path):
 
 @pytest.mark.gpu
 def test_bench_pyramid_checks_every_level():
-    out = _bench(["--steps", "3", "--warmup", "1", "--workload", "pyramid", "--frames", "16", "--preroll-s", "0.05", "--no-cpu-baseline"])
+    out = _bench(["--steps", "3", "--warmup", "1", "--workload", "pyramid", "--frames", "16", "--preroll-s", "0.05", "--preroll-max-s", "0.2", "--no-cpu-baseline"])
     assert out["parity"] == {"frames_checked": 2, "levels_checked": 4, "mismatching_pixels": 0}
     assert out["roofline"]["kernel"].startswith("remap_strip_kernel<true, true")  # the strip kernel with the fused pyramid ran

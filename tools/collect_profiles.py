@@ -22,10 +22,11 @@ for wl, kname in WORKLOADS.items():
         shutil.copy(f, os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, wl)))
     s = json.load(open(os.path.join(d, "summary.json")))
     # frames per launch: what bench.py said under the profiler (its JSON line is kept next to the stats)
-    frames = None
+    frames = code_id = None
     try:
         line = [l for l in open(os.path.join(d, "bench_under_profiler.json")) if l.startswith("{")][-1]
         frames = json.loads(line)["roofline"]["frames_per_launch"]
+        code_id = json.loads(line).get("code_id")  # mdc_code_id() of the library that ran under the profiler: bench.py refuses the entry for any other build
     except (OSError, IndexError, KeyError, ValueError):
         pass
     if not frames or wl == "seq50k":
@@ -52,7 +53,7 @@ for wl, kname in WORKLOADS.items():
                 "bytes_per_frame": (rd + wr + pre_rd) / nsteps / frames,
                 "read_bytes_per_frame": (rd + pre_rd) / nsteps / frames, "write_bytes_per_frame": wr / nsteps / frames,
                 "of_which_prefetch_read_bytes_per_frame": pre_rd / nsteps / frames,
-                "kernel": k, "avg_us_under_profiler": v["avg_us"], "frames_per_launch": frames, "launches_per_step": lps,
+                "kernel": k, "code_id": code_id, "avg_us_under_profiler": v["avg_us"], "frames_per_launch": frames, "launches_per_step": lps,
                 "source": "profiles/%s_%s_summary.json" % (tag, wl),
                 "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 half-count, verified profiles/r01_fetch_calibration.txt) + WRITE_SIZE KiB x1024; all "
                               "launches of a step (chunked remap + prefetch) summed",
@@ -65,7 +66,7 @@ for wl, kname in WORKLOADS.items():
                 "bytes_per_frame": v["hbm_bytes_per_launch"] / frames,
                 "read_bytes_per_frame": v["hbm_read_bytes_per_launch"] / frames,
                 "write_bytes_per_frame": v["hbm_write_bytes_per_launch"] / frames,
-                "kernel": k, "avg_us_under_profiler": v["avg_us"], "frames_per_launch": frames,
+                "kernel": k, "code_id": code_id, "avg_us_under_profiler": v["avg_us"], "frames_per_launch": frames,
                 "source": "profiles/%s_%s_summary.json" % (tag, wl),
                 "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 half-count, verified profiles/r01_fetch_calibration.txt) + WRITE_SIZE KiB x1024",
             }

@@ -68,6 +68,21 @@ for stage in "$@"; do
         timeout 300 python bench.py --frames $n --steps 60 --warmup 10 --no-cpu-baseline > "$OUT/bench_frames_$n.json" 2> "$OUT/bench_frames_$n.err"
         python3 -c "import json,sys; d=json.loads([l for l in open('$OUT/bench_frames_$n.json') if l.startswith('{')][-1]); r=d['roofline']; print($n, 'frac', r['frac'], 'kernel_ms', r['kernel_ms'], 'of_ceiling', r.get('frac_of_same_box_mix_ceiling'), r['kernel'], d['config']['plan'])"
       done ;;
+    probe)   # why the same launch ran 8 % apart within one process: launch time against clocks / idle gaps / placement
+      timeout 300 python tools/clock_probe.py ${PROBE_ARGS:-12 4 3} > "$OUT/clock_probe.txt" 2>&1; grep -a "===\|^A \|^B \|plan:\|idle snapshot" -A0 "$OUT/clock_probe.txt" | tail -8 ;;
+    bench_driver)  # exactly what the driver runs at round end
+      ( time timeout 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver.json" 2> "$OUT/bench_driver.err" ) 2>&1 | grep real; tail -c 400 "$OUT/bench_driver.err"
+      python3 - "$OUT/bench_driver.json" <<'PY'
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+r = d["roofline"]
+print("headline", d["value"], "Mpix/s  frac", r["frac"], "again", r.get("frac_again"), "kernel_ms", r["kernel_ms"], "of ceiling", r.get("frac_of_same_box_mix_ceiling"), r["kernel"], "parity", d["parity"])
+print("preroll", d["config"]["preroll"], "again", d.get("again"))
+print("clocks idle", d.get("clocks_idle_at_start"), "after", r.get("clocks_after_timed_region"), "traffic", r["traffic"], r["traffic_source"])
+for k, v in (d.get("secondary") or {}).items():
+    print("secondary", k, "frac", v["frac"], "kernel_ms", v["kernel_ms"], "of ceiling", v["frac_of_same_box_mix_ceiling"], v["kernel"], "preroll s", v["preroll"]["seconds"], "parity", v["parity"] if isinstance(v["parity"], str) else v["parity"]["mismatching_pixels"])
+PY
+      ;;
     bench)
       ( time timeout 1200 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" ) 2>&1 | grep real; tail -c 600 "$OUT/bench.err"
       python3 - "$OUT/bench.json" <<'PY'
