@@ -133,23 +133,31 @@ def traffic_from_profiles(kernel_name, frames_per_launch, code_id=None, path=Non
     return None, stale
 
 
+def gpu_sysfs_dir(index=0):
+    """sysfs directory of HIP device `index`, found by its PCI address (a container sees every card of the node under
+    /sys/class/drm, in another order than HIP's ordinals: card0 is usually somebody else's GPU)."""
+    import glob
+
+    try:
+        p = torch.cuda.get_device_properties(index)
+        d = "/sys/bus/pci/devices/%04x:%02x:%02x.0" % (int(getattr(p, "pci_domain_id", 0)), int(p.pci_bus_id), int(getattr(p, "pci_device_id", 0)))
+        if os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+            return d
+    except (AttributeError, RuntimeError, AssertionError, ValueError):
+        pass
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+    return os.path.dirname(cards[index]) if len(cards) == 1 and index == 0 else None  # never guess among several cards
+
+
 def gpu_clock_snapshot(index=0):
-    """Current clocks / power / temperature of GPU `index` from sysfs (amdgpu: the starred level of pp_dpm_*, hwmon),
+    """Current clocks / power / temperature of HIP device `index` from sysfs (amdgpu: the starred level of pp_dpm_*, hwmon),
     best effort: {} where the files are not there.  Cheap enough to call between timed regions."""
     import glob
 
-    cards = []
-    for d in glob.glob("/sys/class/drm/card[0-9]*/device"):
-        if os.path.exists(os.path.join(d, "pp_dpm_sclk")):
-            try:
-                cards.append((int(os.path.basename(os.path.dirname(d))[4:]), d))
-            except ValueError:
-                pass
-    cards.sort()
-    if index >= len(cards):
+    d = gpu_sysfs_dir(index)
+    if d is None:
         return {}
-    d = cards[index][1]
-    out = {}
+    out = {"pci": os.path.basename(d)}
     for name in ("sclk", "mclk", "fclk", "socclk"):
         try:
             for line in open(os.path.join(d, "pp_dpm_" + name)):
@@ -580,6 +588,7 @@ class Workload:
             a.record()
             self.step()
             b.record()  # brackets the launches of a step (same stream as the launch)
+        clocks = gpu_clock_snapshot(D.gpu)  # host-side file reads while the queued steps run: the clocks UNDER LOAD
         torch.cuda.synchronize()
         D.barrier()
         torch.cuda.synchronize()
@@ -587,7 +596,7 @@ class Workload:
         ktimes = np.array([a.elapsed_time(b) for a, b in evs], dtype=np.float64)
         kstat = [float(ktimes.mean()), float(np.median(ktimes)), float(ktimes.min())]
         per_rank = [[round(x, 4) for x in k] for k in D.gather(kstat)]
-        return {"elapsed": elapsed, "steps": steps, "kstat": kstat, "per_rank_kernel_ms": per_rank, "clocks": gpu_clock_snapshot(D.gpu)}
+        return {"elapsed": elapsed, "steps": steps, "kstat": kstat, "per_rank_kernel_ms": per_rank, "clocks": clocks}
 
     def dump(self):
         """test hook: every rank hands out its first outputs (checked against the oracle per GLOBAL frame index)"""
@@ -696,7 +705,7 @@ class Workload:
                 "algorithmic_bytes_per_frame": self.alg_frame, "algorithmic_read_bytes_per_frame": self.alg_read,
                 "frames_per_launch": B, "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
                 "tile": [info.tile_w, info.tile_h] if self.rect and info.tiled else None, "window_buffers": info.window_buffers if self.rect else None,
-                "clocks_after_timed_region": timing["clocks"] or None}
+                "clocks_in_timed_region": timing["clocks"] or None}
         if self.wl == "dso":
             roof["launches_per_step"] = "per chunk of frames: one remap launch (base + levels 1-3) + one gradients_levels_kernel launch over all levels"
         if self.wl == "pyramid" and info.prefetch_chunk and B >= 2 * info.prefetch_chunk:
@@ -793,7 +802,7 @@ def main():
             again = {"value": round(H.total * t2["steps"] * H.npix_in / 1e6 / t2["elapsed"], 1), "ms_per_step": round(t2["elapsed"] / t2["steps"] * 1e3, 4),
                      "kernel_ms": round(k2[0], 4), "kernel_ms_median": round(k2[1], 4), "frac": round(H.frac_of(k2[0]), 4),
                      "frac_of_same_box_mix_ceiling": round(c2["ms_median"] / k2[1], 4) if c2 else None,
-                     "same_box_mix_ceiling_ms": c2["ms_median"] if c2 else None, "preroll": pre2, "clocks_after_timed_region": t2["clocks"] or None,
+                     "same_box_mix_ceiling_ms": c2["ms_median"] if c2 else None, "preroll": pre2, "clocks_in_timed_region": t2["clocks"] or None,
                      "seconds_after_first": None}
     if D.rank == 0:
         out = {

@@ -205,6 +205,59 @@ def test_cxx_classes_match_reference(calib_dirs, ref, oracle):
     assert np.all(a2 == 5.0)
 
 
+@pytest.mark.parametrize("name", ["full_1280_to_640", "full_1280_to_1280"])
+def test_full_size_flag_matrix_against_the_reference_build(name, calib_dirs, ref, torch_cuda):
+    """All 16 getImage switch combinations (src/BenchmarkDatasetReader.h:207-241) x {noise, smooth + saturated blobs, all-255, all-0}
+    at 1280x1024 -> 640x480 and -> 1280x1024, through mdc_process_batch_device AND through the class methods, compared straight with
+    the REFERENCE BUILD (oracle/_ref/libmdc_ref.so: its own classes, its own tables from the same calibration files) -- not with
+    the C restatement fed with our tables."""
+    from mono_dataset_code_amd import capi
+
+    torch = torch_cuda
+    d = calib_dirs[name]
+    cam, pc, vg = os.path.join(d, "camera.txt"), os.path.join(d, "pcalib.txt"), os.path.join(d, "vignette.png")
+    rfov = ref.fov(cam)
+    W, H, w, h = rfov.dims()
+    assert (W, H) == (1280, 1024)
+    rphoto = ref.photo(pc, vg, W, H)
+    fov, photo = capi.UndistorterFOV(cam), capi.PhotometricUndistorter(pc, vg, W, H)
+    assert fov.has_gpu() and photo.has_gpu()
+    ctx = capi.Context(0)
+    ctx.bind(fov, photo)
+    frames = np.stack(make_frames(W, H, n_noise=1))  # noise, smooth + blobs, all-255, all-0
+    n = len(frames)
+    assert n == 4
+    d_in = torch.from_numpy(frames).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    for rect, g, v, o in itertools.product((0, 1), repeat=4):
+        flags = (capi.RECTIFY * rect) | (capi.GAMMA * g) | (capi.VIGNETTE * v) | (capi.KILL_OVEREXPOSED * o)
+        nout = w * h if rect else W * H
+        d_out = torch.full((n, nout), -7.0, dtype=torch.float32, device="cuda")
+        ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, flags, st)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        for f in range(n):
+            want = ref.get_image(rfov, rphoto, frames[f].copy(), rect, g, v, o)
+            assert bits_equal(got[f], want), (name, "batch", f, rect, g, v, o)
+    # the class methods, composed as the reference's reader composes them (:212-233)
+    for f in range(n):
+        for g, v, o in itertools.product((0, 1), repeat=3):
+            a, b = np.zeros(W * H, np.float32), np.zeros(W * H, np.float32)
+            photo.unmap(frames[f], a, g, v, o)
+            rphoto.unmap(frames[f].copy(), b, g, v, o)
+            assert bits_equal(a, b), (name, "unMapImage", f, g, v, o)
+            if (g, v, o) in ((1, 1, 1), (0, 0, 1), (1, 0, 0)):
+                a2, b2 = np.zeros(w * h, np.float32), np.zeros(w * h, np.float32)
+                fov.undistort(a, a2)
+                rfov.undistort(b, b2)
+                assert bits_equal(a2, b2), (name, "undistort<float>", f, g, v, o)
+        a2, b2 = np.zeros(w * h, np.float32), np.zeros(w * h, np.float32)
+        fov.undistort(frames[f], a2)
+        rfov.undistort(frames[f], b2)
+        assert bits_equal(a2, b2), (name, "undistort<unsigned char>", f)
+    ctx.close()
+
+
 def test_full_size_config_and_properties(setups, oracle, torch_cuda):
     """BASELINE.json configs[1]/[2] at full size: oracle on 3 frames, then
     size-independent properties on a 64-frame batch."""

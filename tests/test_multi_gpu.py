@@ -205,5 +205,7 @@ def test_bench_rccl_branch_executes_with_a_world_of_one(tmp_path):
 @pytest.mark.gpu
 def test_bench_pyramid_checks_every_level():
     out = _bench(["--steps", "3", "--warmup", "1", "--workload", "pyramid", "--frames", "16", "--preroll-s", "0.05", "--preroll-max-s", "0.2", "--no-cpu-baseline"])
-    assert out["parity"] == {"frames_checked": 2, "levels_checked": 4, "mismatching_pixels": 0}
+    par = out["parity"]
+    assert (par["frames_checked"], par["levels_checked"], par["mismatching_pixels"]) == (16, 4, 0)  # --frames 16: every frame of the launch
+    assert "libmdc_ref.so" in par["against"] and "unpinned" in par["pinned"]  # base against the reference build; the levels' definition is ours
     assert out["roofline"]["kernel"].startswith("remap_strip_kernel<true, true")  # the strip kernel with the fused pyramid ran

@@ -44,9 +44,10 @@ def run_phase(name, launch, seconds, t_origin):
                 launch()
                 b.record()
                 evs.append((a, b))
+            snap = bench.gpu_clock_snapshot(0)  # while the 8 launches are in flight: the clocks under load, not after the queue drained
             torch.cuda.synchronize()
         ms = np.array([a.elapsed_time(b) for a, b in evs])
-        rows.append((time.perf_counter() - t_origin, float(ms.mean()), float(ms.min()), len(ms), bench.gpu_clock_snapshot(0)))
+        rows.append((time.perf_counter() - t_origin, float(ms.mean()), float(ms.min()), len(ms), snap))
     print("--- phase %s" % name)
     for t, mean, mn, n, snap in rows:
         print("t %6.2f s  launch mean %.4f min %.4f ms (%3d)  %s" % (t, mean, mn, n, bench.format_clock_snapshot(snap)))

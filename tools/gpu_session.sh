@@ -68,6 +68,15 @@ for stage in "$@"; do
         timeout 300 python bench.py --frames $n --steps 60 --warmup 10 --no-cpu-baseline > "$OUT/bench_frames_$n.json" 2> "$OUT/bench_frames_$n.err"
         python3 -c "import json,sys; d=json.loads([l for l in open('$OUT/bench_frames_$n.json') if l.startswith('{')][-1]); r=d['roofline']; print($n, 'frac', r['frac'], 'kernel_ms', r['kernel_ms'], 'of_ceiling', r.get('frac_of_same_box_mix_ceiling'), r['kernel'], d['config']['plan'])"
       done ;;
+    ab)      # same-box A/B of library builds / knobs on the headline batch: tools/sweep.py with AB_ARGS (interleaved rounds, outputs compared bit for bit)
+      timeout 900 python tools/sweep.py --frames ${FRAMES:-4096} --rounds ${ROUNDS:-5} --iters 4 ${AB_ARGS:-} > "$OUT/ab_${AB_NAME:-sweep}.txt" 2>&1; grep -av amdgpu.ids "$OUT/ab_${AB_NAME:-sweep}.txt" | tail -40 ;;
+    pmc_rd)  # fabric read requests and L2 hits per variant of the same sweep (one launch each): separate --pmc passes, --kernel-trace only
+      ( cd /tmp && export TMPDIR=/tmp; i=0
+        for C in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCC_READ_sum"; do
+          i=$((i+1))
+          timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/rd_pass$i" -- python "$GRAFT_REPO_ROOT/tools/sweep.py" --frames ${FRAMES:-4096} --rounds 1 --iters 1 ${AB_ARGS:-} > "$OUT/rd_pass$i.log" 2>&1
+        done )
+      python3 tools/pmc_table.py "$OUT" rd_pass > "$OUT/rd_summary.txt" 2>&1; tail -${RD_TAIL:-30} "$OUT/rd_summary.txt" | cut -c1-260 ;;
     probe)   # why the same launch ran 8 % apart within one process: launch time against clocks / idle gaps / placement
       timeout 300 python tools/clock_probe.py ${PROBE_ARGS:-12 4 3} > "$OUT/clock_probe.txt" 2>&1; grep -a "===\|^A \|^B \|plan:\|idle snapshot" -A0 "$OUT/clock_probe.txt" | tail -8 ;;
     bench_driver)  # exactly what the driver runs at round end
@@ -78,7 +87,7 @@ d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 r = d["roofline"]
 print("headline", d["value"], "Mpix/s  frac", r["frac"], "again", r.get("frac_again"), "kernel_ms", r["kernel_ms"], "of ceiling", r.get("frac_of_same_box_mix_ceiling"), r["kernel"], "parity", d["parity"])
 print("preroll", d["config"]["preroll"], "again", d.get("again"))
-print("clocks idle", d.get("clocks_idle_at_start"), "after", r.get("clocks_after_timed_region"), "traffic", r["traffic"], r["traffic_source"])
+print("clocks idle", d.get("clocks_idle_at_start"), "after", r.get("clocks_in_timed_region"), "traffic", r["traffic"], r["traffic_source"])
 for k, v in (d.get("secondary") or {}).items():
     print("secondary", k, "frac", v["frac"], "kernel_ms", v["kernel_ms"], "of ceiling", v["frac_of_same_box_mix_ceiling"], v["kernel"], "preroll s", v["preroll"]["seconds"], "parity", v["parity"] if isinstance(v["parity"], str) else v["parity"]["mismatching_pixels"])
 PY

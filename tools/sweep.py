@@ -113,6 +113,7 @@ def main():
     else:
         variants = list(itertools.product(libs, a.kernel.split(","), ints(a.fpb), ints(a.rows), ints(a.order), ints(a.sched), ints(a.nbuf), ints(a.cols), ints(a.pad)))
     times = {v: [] for v in variants}
+    same, ref_out = {}, None
     # DVFS: the first ~30 ms after an idle period run ~15 % slow (profiles/r01_dvfs_warmup_curve.txt)
     m0, c0 = ctxs[libs[0]]
     for _ in range(200):
@@ -132,6 +133,14 @@ def main():
             try_set(m, ctx, "OPT_WINDOW_BUFFERS", v[6])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), B, flags, s)
+            if r == 0:  # every variant's output against the first variant's, bit for bit (tuning variants must not change results)
+                torch.cuda.synchronize()
+                if ref_out is None:
+                    ref_out = d_out.clone()
+                    same[v] = True
+                else:
+                    same[v] = bool(torch.equal(d_out.view(torch.int32), ref_out.view(torch.int32)))
+                d_out.zero_()
             e0.record()
             for _ in range(a.iters):
                 ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), B, flags, s)
@@ -139,11 +148,14 @@ def main():
             torch.cuda.synchronize()
             if r:
                 times[v].append(e0.elapsed_time(e1) / a.iters)
-    print("%-28s %-7s %5s %4s %4s %3s %3s %3s %3s %10s %10s %9s %7s" % ("lib", "kernel", "fpb", "cols", "rows", "ord", "sch", "buf", "pad", "median_ms", "min_ms", "GB/s", "frac8T"))
+    print("%-28s %-7s %5s %4s %4s %3s %3s %3s %3s %10s %10s %9s %7s" % ("lib", "kernel", "fpb", "cols", "rows", "ord", "sch", "buf", "pad", "median_ms", "min_ms", "GB/s", "frac8T") + "  ==first")
     for v in variants:
         med, mn = float(np.median(times[v])), float(np.min(times[v]))
         gbs = alg * B / (med * 1e-3) / 1e9
-        print("%-28s %-7s %5d %4d %4d %3d %3d %3d %3d %10.4f %10.4f %9.1f %7.3f" % (os.path.basename(v[0])[-28:], v[1], v[2], v[7], v[3], v[4], v[5], v[6], v[8], med, mn, gbs, gbs / 8000), flush=True)
+        print("%-28s %-7s %5d %4d %4d %3d %3d %3d %3d %10.4f %10.4f %9.1f %7.3f" % (os.path.basename(v[0])[-28:], v[1], v[2], v[7], v[3], v[4], v[5], v[6], v[8], med, mn, gbs, gbs / 8000) + "  " + str(same.get(v)), flush=True)
+    if not all(same.values()):
+        print("RESULTS DIFFER between variants")
+        sys.exit(1)
 
 
 if __name__ == "__main__":
