@@ -414,8 +414,10 @@ def spot_frames(B, fpb, n):
     mid = (B // 2) // fpb * fpb
     cand = [0, B - 1, fpb - 1, fpb, B - 2, mid, mid - 1, mid + fpb - 1, B - max(fpb // 8, 1), B - max(fpb // 8, 1) - 1,
             B - max(fpb // 4, 1), B - max(fpb // 2, 1), B - fpb, B - fpb - 1, 2 * fpb - 1, 2 * fpb, 1, B - 3, mid + 1, 3 * fpb]
+    if B <= n:
+        return list(range(B))
     out = []
-    for f in cand:
+    for f in cand + [int(round(k * (B - 1) / max(n - 1, 1))) for k in range(n)]:  # (small launches: the candidates collapse; fill up evenly)
         if 0 <= f < B and f not in out:
             out.append(f)
         if len(out) >= n:

@@ -263,6 +263,34 @@ MDC_API int mdc_process_jpeg_streams_host(mdc_ctx* ctx, const void* const* strea
 MDC_API int mdc_jpeg_huffman_batch_device(mdc_ctx* ctx, const void* d_streams, int64_t stream_stride, void* d_records, int64_t record_bytes, int w,
                                   int h, int blocks_w, int blocks_rows, int64_t nframes, int* d_status, void* stream);
 
+/* ---- host frames in, results LEFT ON THE DEVICE ------------------------------------
+ * The three pipelined calls above with a device-resident end: frames (raw / JPEG coefficient records / JPEG streams) come from
+ * host memory, go through the same upload -> (Huffman ->) (inverse DCT ->) fused-pass pipeline, and the results -- the processed
+ * frame and, on request, its box-pyramid levels and DSO-style gradient images (mdc_process_pyramid_gradients_batch_device) -- stay in
+ * HBM for a GPU consumer; nothing crosses PCIe on the way out (the host-output calls top out at ~31 k frames/s of 640x480 floats).
+ * Reference call site: DatasetReader::getImage, src/BenchmarkDatasetReader.h:188-243, whose `new ExposureImage` + host float
+ * block this replaces for callers that keep working on the device.
+ * `out` describes device arrays for a whole sequence; frame i of the call lands at position frame_index[i] of every array
+ * (frame_index == NULL: position i).  Same bytes as the host-output call followed by a copy up.  Blocking: on return the
+ * results are complete in device memory.  status as for mdc_process_jpeg_streams_host (the arrays' entries of a frame with
+ * status != 0 are not results).  mdc_device_alloc / _free / mdc_copy_to_host: for callers without a HIP toolchain of their own. */
+typedef struct mdc_device_outputs {
+  float* base;                /* positions x (w x h) floats: the processed frames (rectified size with MDC_RECTIFY); required */
+  int levels;                 /* 1 = base only; 2..4 = + box levels 1..levels-1 (level l: (w >> l) x (h >> l)) */
+  float* level[3];            /* levels 1..3, positions x level size each; NULL beyond `levels` */
+  float* dI[4];               /* optional, all NULL = none: (I, dx, dy) triples of level l, positions x 3 x level size */
+  float* abs_squared_grad[4]; /* with dI: dx^2 + dy^2 of level l */
+} mdc_device_outputs;
+MDC_API int mdc_process_frames_host_to_device(mdc_ctx* ctx, const uint8_t* const* raw, int64_t nframes, unsigned flags,
+                                              const mdc_device_outputs* out, const int64_t* frame_index);
+MDC_API int mdc_process_jpeg_frames_host_to_device(mdc_ctx* ctx, const void* const* records, int64_t record_bytes, int blocks_w, int blocks_rows,
+                                                   int64_t nframes, unsigned flags, const mdc_device_outputs* out, const int64_t* frame_index);
+MDC_API int mdc_process_jpeg_streams_host_to_device(mdc_ctx* ctx, const void* const* streams, const int64_t* stream_bytes, int64_t nframes,
+                                                    unsigned flags, const mdc_device_outputs* out, const int64_t* frame_index, int* status);
+MDC_API int mdc_device_alloc(mdc_ctx* ctx, size_t bytes, void** d_ptr); /* device memory on the context's GPU (hipMalloc) */
+MDC_API void mdc_device_free(mdc_ctx* ctx, void* d_ptr);
+MDC_API int mdc_copy_to_host(mdc_ctx* ctx, void* dst, const void* d_src, size_t bytes); /* blocking device -> host copy */
+
 /* ---- device-pointer, batched: the throughput path --------------------------- */
 
 /* unMapImage over nframes back-to-back frames (in: nframes*w*h u8; out: same count f32). */

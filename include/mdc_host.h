@@ -72,6 +72,12 @@ MDC_API int mdch_reader_get_image(mdch_reader*, int id, int rectify, int g, int 
  * Returns the number produced. */
 MDC_API int mdch_reader_get_images(mdch_reader*, int first, int count, int rectify, int g, int v, int o, float* out,
                            long frame_floats, unsigned char* ok);
+/* getImagesDevice(first, count, ..., out, valid): results stay in the caller's DEVICE arrays (include/mdc_hip.h: mdc_device_outputs;
+ * frame first + i at position i), on the device of mdch_reader_device(); mdch_reader_context() = getContext().  Returns the number produced. */
+MDC_API int mdch_reader_get_images_device(mdch_reader*, int first, int count, int rectify, int g, int v, int o, const mdc_device_outputs* out,
+                                  unsigned char* valid);
+MDC_API mdc_ctx* mdch_reader_context(mdch_reader*);
+MDC_API int mdch_reader_device(mdch_reader*);
 MDC_API int mdch_reader_get_raw(mdch_reader*, int id, unsigned char* out, long cap, int wh[2]); /* getImageRaw(); 1 / 0 */
 MDC_API void mdch_reader_set_threads(mdch_reader*, int n);       /* setDecodeThreads() */
 MDC_API void mdch_reader_set_prefetch(mdch_reader*, int frames); /* setPrefetch() */

@@ -64,6 +64,19 @@ class MDC_API DatasetReader {
   int getImages(int first, int count, bool rectify, bool removeGamma, bool removeVignette, bool nanOverexposed,
                 ExposureImage** out);
 
+  // The same frames with a DEVICE-RESIDENT end (include/mdc_hip.h: mdc_device_outputs): files are parsed / decoded by the thread
+  // pool, go up, and the processed frame -- plus, on request, box-pyramid levels 1..3 and DSO-style gradient images of every
+  // level -- is left in the caller's device arrays, frame first+i at position i of each; nothing comes back over PCIe (getImages
+  // tops out at ~31 k frames/s of 640x480 float results; this path is bound by the JPEG decode).  valid[i] (optional, `count`
+  // bytes) = 1 where position i holds a result (0: wrong size / undecodable, as getImage's 0).  The arrays live on the device
+  // of getDevice(): hipMalloc / torch on that device, or mdc_device_alloc(getContext(), ...).  Returns the number of frames
+  // produced.  Same bytes as getImages followed by a copy to the device.  With several devices (MDC_DEVICES) the call runs on
+  // the first one: shard with one reader per device, frame f on device f % N.
+  int getImagesDevice(int first, int count, bool rectify, bool removeGamma, bool removeVignette, bool nanOverexposed,
+                      const struct mdc_device_outputs* out, unsigned char* valid);
+  struct mdc_ctx* getContext();  // the GPU context behind getImage / getImages / getImagesDevice (0 without a GPU)
+  int getDevice() const;         // its HIP device ordinal (-1 without a GPU)
+
   // The decoded 8-bit frame (what cv::imread / cv::imdecode give the reference, :247-276); the
   // pointer stays valid until the next call on this object.  0 on failure.
   const unsigned char* getImageRaw(int id, int* width, int* height);
@@ -102,6 +115,8 @@ class MDC_API DatasetReader {
  private:
   DatasetReader(const DatasetReader&);
   DatasetReader& operator=(const DatasetReader&);
+  int run_batch(int first, int count, bool rectify, bool removeGamma, bool removeVignette, bool nanOverexposed, ExposureImage** out,
+                const struct mdc_device_outputs* dev, unsigned char* valid);
   struct State;
   State* s_;
 };

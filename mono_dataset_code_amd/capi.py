@@ -30,6 +30,7 @@ OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM = 0, -1, -2,
 HIP_SYMBOLS = [
     "mdc_create", "mdc_destroy", "mdc_device_count", "mdc_last_error", "mdc_build_flags", "mdc_code_id", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
     "mdc_set_remap", "mdc_unmap_host", "mdc_undistort_host_f32", "mdc_undistort_host_u8", "mdc_process_host",
+    "mdc_process_frames_host_to_device", "mdc_process_jpeg_frames_host_to_device", "mdc_process_jpeg_streams_host_to_device", "mdc_device_alloc", "mdc_device_free", "mdc_copy_to_host",
     "mdc_host_alloc", "mdc_host_free", "mdc_process_frames_host", "mdc_process_jpeg_frames_host", "mdc_jpeg_idct_batch_device", "mdc_process_jpeg_streams_host", "mdc_jpeg_huffman_batch_device",
     "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
     "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device",
@@ -45,7 +46,7 @@ HOST_SYMBOLS = [
     "mdch_photo_create", "mdch_photo_destroy", "mdch_photo_valid", "mdch_photo_has_gpu", "mdch_photo_ginv",
     "mdch_photo_g", "mdch_photo_vignette", "mdch_photo_unmap", "mdch_bind", "mdch_pack_tables",
     "mdch_reader_create", "mdch_reader_destroy", "mdch_reader_num_images", "mdch_reader_timestamp", "mdch_reader_exposure",
-    "mdch_reader_dims", "mdch_reader_get_image", "mdch_reader_get_images", "mdch_reader_get_raw", "mdch_reader_set_threads",
+    "mdch_reader_dims", "mdch_reader_get_image", "mdch_reader_get_images", "mdch_reader_get_images_device", "mdch_reader_context", "mdch_reader_device", "mdch_reader_get_raw", "mdch_reader_set_threads",
     "mdch_reader_set_prefetch", "mdch_reader_set_gpu_jpeg", "mdch_reader_set_lookahead", "mdch_reader_last_error", "mdch_reader_prefetch_stats", "mdch_reader_device_stats", "mdch_decode_gray8", "mdch_jpeg_record_bytes",
     "mdch_decode_jpeg_record", "mdch_jpeg_stream", "mdch_image_alloc", "mdch_image_free",
     "mdch_image_pool_trim", "mdch_image_pool_idle_bytes",
@@ -64,6 +65,23 @@ class MdcInfo(C.Structure):
                 ("window_buffers", C.c_int), ("f32_tiled", C.c_int), ("f32_tile_w", C.c_int), ("f32_tile_h", C.c_int),
                 ("src_bbox", C.c_int * 4), ("src_bbox_bytes", C.c_int64), ("src_staged_bytes", C.c_int64),
                 ("n_black", C.c_int64), ("two_stage", C.c_int), ("prefetch_chunk", C.c_int), ("prefetch_streams", C.c_int)]
+
+
+class DeviceOutputs(C.Structure):
+    """include/mdc_hip.h: mdc_device_outputs -- device arrays the *_to_device calls / DatasetReader.get_images_device fill."""
+    _fields_ = [("base", C.c_void_p), ("levels", C.c_int), ("level", C.c_void_p * 3), ("dI", C.c_void_p * 4), ("abs_squared_grad", C.c_void_p * 4)]
+
+    @classmethod
+    def make(cls, base, levels=1, level=(), dI=(), abs2=()):
+        o = cls()
+        o.base, o.levels = base, levels
+        for i, p in enumerate(level):
+            o.level[i] = p
+        for i, p in enumerate(dI):
+            o.dI[i] = p
+        for i, p in enumerate(abs2):
+            o.abs_squared_grad[i] = p
+        return o
 
 
 class TuneResult(C.Structure):
@@ -150,6 +168,15 @@ def hip_lib():
             L.mdc_jpeg_idct_batch_device.argtypes = [_vp, _vp, _i64, _vp, _i, _i, _i, _i, _i64, _vp]
             L.mdc_process_jpeg_streams_host.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_int64), C.POINTER(_vp), _i64, C.c_uint, C.POINTER(C.c_int)]
             L.mdc_jpeg_huffman_batch_device.argtypes = [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i64, _vp, _vp]
+        if hasattr(L, "mdc_process_jpeg_streams_host_to_device"):  # (absent from libraries built before round 5)
+            L.mdc_process_frames_host_to_device.argtypes = [_vp, C.POINTER(_vp), _i64, C.c_uint, C.POINTER(DeviceOutputs), C.POINTER(C.c_int64)]
+            L.mdc_process_jpeg_frames_host_to_device.argtypes = [_vp, C.POINTER(_vp), _i64, _i, _i, _i64, C.c_uint, C.POINTER(DeviceOutputs), C.POINTER(C.c_int64)]
+            L.mdc_process_jpeg_streams_host_to_device.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_int64), _i64, C.c_uint, C.POINTER(DeviceOutputs),
+                                                                  C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+            L.mdc_device_alloc.argtypes = [_vp, _sz, C.POINTER(_vp)]
+            L.mdc_device_free.argtypes = [_vp, _vp]
+            L.mdc_device_free.restype = None
+            L.mdc_copy_to_host.argtypes = [_vp, _vp, _vp, _sz]
         L.mdc_unmap_batch_device.argtypes = [_vp, _vp, _vp, _i64, C.c_uint, _vp]
         L.mdc_process_batch_device.argtypes = [_vp, _vp, _vp, _i64, C.c_uint, _vp]
         L.mdc_undistort_batch_device_f32.argtypes = [_vp, _vp, _vp, _i64, _vp]
@@ -188,7 +215,7 @@ def hip_lib():
         for n in HIP_SYMBOLS:
             if old_build and not hasattr(L, n):
                 continue
-            if n not in ("mdc_destroy", "mdc_last_error", "mdc_build_flags", "mdc_code_id", "mdc_host_alloc", "mdc_host_free", "mdc_vcal_index_destroy",
+            if n not in ("mdc_destroy", "mdc_last_error", "mdc_build_flags", "mdc_code_id", "mdc_device_free", "mdc_host_alloc", "mdc_host_free", "mdc_vcal_index_destroy",
                          "mdc_vcal_index_bytes", "mdc_vcal_index_entries"):
                 getattr(L, n).restype = _i
         _hip = L
@@ -267,6 +294,10 @@ def host_lib():
         L.mdch_reader_dims.restype = None
         L.mdch_reader_get_image.argtypes = [_vp, _i, _i, _i, _i, _i, _vp, C.c_long, _vp, C.POINTER(C.c_double), C.POINTER(C.c_float)]
         L.mdch_reader_get_images.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, C.c_long, _vp]
+        L.mdch_reader_get_images_device.argtypes = [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(DeviceOutputs), _vp]
+        L.mdch_reader_context.argtypes = [_vp]
+        L.mdch_reader_context.restype = _vp
+        L.mdch_reader_device.argtypes = [_vp]
         L.mdch_reader_get_raw.argtypes = [_vp, _i, _vp, C.c_long, _vp]
         L.mdch_reader_set_threads.argtypes = [_vp, _i]
         L.mdch_reader_set_threads.restype = None
@@ -425,6 +456,22 @@ class Context:
         sz = (C.c_int64 * max(1, n))(*[int(x) for x in sizes])
         st = (C.c_int * max(1, n))()
         self._chk(self._L.mdc_process_jpeg_streams_host(self._h, a, sz, b, n, flags, st))
+        return [int(st[i]) for i in range(n)]
+
+    def process_frames_host_to_device(self, raws, flags, outputs, frame_index=None):
+        """raw u8 frames (numpy) -> the device arrays of `outputs` (DeviceOutputs); frame i at position frame_index[i] (None: i)."""
+        n = len(raws)
+        a = (_vp * max(1, n))(*[_np_ptr(r) for r in raws])
+        idx = None if frame_index is None else (C.c_int64 * max(1, n))(*[int(x) for x in frame_index])
+        self._chk(self._L.mdc_process_frames_host_to_device(self._h, a, n, flags, C.byref(outputs), idx))
+
+    def process_jpeg_streams_host_to_device(self, streams, sizes, flags, outputs, frame_index=None):
+        n = len(streams)
+        a = (_vp * max(1, n))(*[_np_ptr(r) for r in streams])
+        sz = (C.c_int64 * max(1, n))(*[int(x) for x in sizes])
+        idx = None if frame_index is None else (C.c_int64 * max(1, n))(*[int(x) for x in frame_index])
+        st = (C.c_int * max(1, n))()
+        self._chk(self._L.mdc_process_jpeg_streams_host_to_device(self._h, a, sz, n, flags, C.byref(outputs), idx, st))
         return [int(st[i]) for i in range(n)]
 
     def jpeg_huffman_batch(self, d_streams, stream_stride, d_records, record_bytes, w, h, blocks_w, blocks_rows, nframes, d_status, stream=0):
@@ -855,6 +902,15 @@ class DatasetReader:
         ok = np.zeros(count, np.uint8)
         got = self._L.mdch_reader_get_images(self._h, first, count, int(rectify), int(g), int(v), int(o), _np_ptr(out), n, _np_ptr(ok))
         return out, ok.astype(bool), got
+
+    def get_images_device(self, first, count, rectify, g, v, o, outputs):
+        """getImagesDevice: results into the device arrays of `outputs` (DeviceOutputs; frame first + i at position i) -> (valid mask, number produced)."""
+        valid = np.zeros(count, np.uint8)
+        got = self._L.mdch_reader_get_images_device(self._h, first, count, int(rectify), int(g), int(v), int(o), C.byref(outputs), _np_ptr(valid))
+        return valid.astype(bool), got
+
+    def device(self):
+        return int(self._L.mdch_reader_device(self._h))
 
     def get_raw(self, i):
         out = np.empty(self.in_w * self.in_h * 4 + 16, np.uint8)

@@ -182,7 +182,7 @@ struct DatasetReader::State {
       const size_t sl = dir.rfind('/');
       dir = sl == std::string::npos ? std::string() : dir.substr(0, sl + 1);
     }
-    void* lib = dlopen((dir + "libmdc_multi.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+    void* lib = dlopen((dir + "libmdc_multi.so").c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_NODELETE);  // RCCL keeps static state and helper threads: never unmapped again
     if (!lib) return false;
     mapi.create = (int (*)(const int*, int, void**))dlsym(lib, "mdc_multi_create");
     mapi.destroy = (void (*)(void*))dlsym(lib, "mdc_multi_destroy");
@@ -288,7 +288,8 @@ struct DatasetReader::State {
     multi = 0;
     lanes.clear();
     gpu = 0;
-    if (mapi.lib) dlclose(mapi.lib);
+    // (no dlclose: libmdc_multi.so pulls in librccl, whose static state and helper threads must outlive this reader -- unloading it
+    // mid-process risks a crash at exit or when the next reader loads it again; the handle is RTLD_NODELETE and simply dropped)
     mapi.lib = 0;
   }
 
@@ -752,6 +753,9 @@ struct DatasetReader::State::LaneRun {
   ExposureImage** out;
   std::vector<Decode>& rec;
   int produced = 0;
+  const mdc_device_outputs* dev = nullptr;  // getImagesDevice: results stay in the caller's device arrays (out == 0)
+  unsigned char* valid = nullptr;           // ... position i holds a result
+  int cur_i0 = 0, cur_i1 = 0;  // the chunk in flight: images allocated, pixels not (yet) written -- see drop_chunk_in_flight()
   double t_wait = 0, t_gpu = 0;
   LaneRun(State& s_, Lane& lane_, int first_, int count_, int C_, int RG_, int L_, int li_, bool rectify_, unsigned flags_, ExposureImage** out_,
           std::vector<Decode>& rec_)
@@ -783,6 +787,19 @@ struct DatasetReader::State::LaneRun {
       std::printf("ERROR: expected cv-mat to have dimensions %d x %d; found %d x %d (image %s)!\n", s.W, s.H, w, h, s.files[(size_t)id].c_str());
   }
 
+  // run() threw (out of memory for an image or a list of pointers): the images it had made for the current chunk hold no
+  // pixels yet and are not counted in `produced` -- a caller walking out[] for non-null entries must not meet them
+  void drop_chunk_in_flight() {
+    for (int i = cur_i0; i < cur_i1; i++) {
+      if (out) {
+        delete out[i];
+        out[i] = 0;
+      }
+      if (valid) valid[i] = 0;
+    }
+    cur_i0 = cur_i1 = 0;
+  }
+
   void run() {
     const int mine = (nchunks() - li + L - 1) / L;  // chunks of this lane
     for (int j = 0; j < std::min(mine, RG); j++) submit(j);
@@ -794,6 +811,7 @@ struct DatasetReader::State::LaneRun {
     std::vector<float*> sdst;
     std::vector<int64_t> ssize;
     std::vector<int> sstatus, sidx;
+    std::vector<int64_t> pidx, ridx, spos;  // getImagesDevice: positions (in the caller's device arrays) of the chunk's plain / record / stream frames
     for (int j = 0; j < mine; j++) {
       const int k = li + j * L, i0 = k * C, i1 = std::min(count, (k + 1) * C);
       const double tw = now();
@@ -806,6 +824,8 @@ struct DatasetReader::State::LaneRun {
         });
       }
       t_wait += now() - tw;
+      cur_i0 = i0;
+      cur_i1 = i1;
       src.clear();
       dst.clear();
       rsrc.clear();
@@ -814,6 +834,9 @@ struct DatasetReader::State::LaneRun {
       sdst.clear();
       ssize.clear();
       sidx.clear();
+      pidx.clear();
+      ridx.clear();
+      spos.clear();
       {
         // a chunk's images are made in one go: the pool hands out consecutive blocks of a slab (lowest free address first),
         // and a chunk whose results lie back to back leaves the device with one copy -- another lane allocating in between
@@ -827,25 +850,33 @@ struct DatasetReader::State::LaneRun {
             if (!d.ok) note_error(d.err);
             continue;
           }
-          out[i] = rectify ? new ExposureImage(s.w, s.h, s.timestamps[(size_t)id], s.exposures[(size_t)id], id)
-                           : new ExposureImage(s.W, s.H, s.timestamps[(size_t)id], s.exposures[(size_t)id], id);
+          if (!dev)
+            out[i] = rectify ? new ExposureImage(s.w, s.h, s.timestamps[(size_t)id], s.exposures[(size_t)id], id)
+                             : new ExposureImage(s.W, s.H, s.timestamps[(size_t)id], s.exposures[(size_t)id], id);
+          if (valid) valid[i] = 1;
           if (d.is_stream) {
             ssrc.push_back(d.dst);
-            sdst.push_back(out[i]->image);
+            if (!dev) sdst.push_back(out[i]->image);
+            spos.push_back(i);
             ssize.push_back((int64_t)d.stream_bytes);
             sidx.push_back(i);
           } else if (d.is_record) {
             if (d.rec_rows > s.rec_rows) {  // cannot happen while the decoder checks the sink's capacity: never hand a record on as pixels
-              delete out[i];
-              out[i] = 0;
+              if (!dev) {
+                delete out[i];
+                out[i] = 0;
+              }
+              if (valid) valid[i] = 0;
               note_error(s.files[(size_t)id] + ": coefficient record larger than the frame's geometry");
               continue;
             }
             rsrc.push_back(d.dst);
-            rdst.push_back(out[i]->image);
+            if (!dev) rdst.push_back(out[i]->image);
+            ridx.push_back(i);
           } else {
             src.push_back(d.dst);
-            dst.push_back(out[i]->image);
+            if (!dev) dst.push_back(out[i]->image);
+            pidx.push_back(i);
           }
         }
       }
@@ -853,12 +884,17 @@ struct DatasetReader::State::LaneRun {
       const double tg = now();
       int refused = 0;  // streams neither the device nor the host decoder could read
       mdc_ctx* gpu = lane.gpu;
-      int grc = src.empty() ? MDC_OK : mdc_process_frames_host(gpu, src.data(), dst.data(), (int64_t)src.size(), flags);
+      int grc = MDC_OK;
+      if (!src.empty())
+        grc = dev ? mdc_process_frames_host_to_device(gpu, src.data(), (int64_t)src.size(), flags, dev, pidx.data())
+                  : mdc_process_frames_host(gpu, src.data(), dst.data(), (int64_t)src.size(), flags);
       if (grc == MDC_OK && !rsrc.empty())  // records: Huffman-decoded on the host, inverse DCT on the device
-        grc = mdc_process_jpeg_frames_host(gpu, rsrc.data(), (int64_t)s.rec_bytes, s.rec_pitch, s.rec_rows, rdst.data(), (int64_t)rsrc.size(), flags);
+        grc = dev ? mdc_process_jpeg_frames_host_to_device(gpu, rsrc.data(), (int64_t)s.rec_bytes, s.rec_pitch, s.rec_rows, (int64_t)rsrc.size(), flags, dev, ridx.data())
+                  : mdc_process_jpeg_frames_host(gpu, rsrc.data(), (int64_t)s.rec_bytes, s.rec_pitch, s.rec_rows, rdst.data(), (int64_t)rsrc.size(), flags);
       if (grc == MDC_OK && !ssrc.empty()) {  // streams: Huffman decoding, inverse DCT and the fused pass on the device
         sstatus.assign(ssrc.size(), 0);
-        grc = mdc_process_jpeg_streams_host(gpu, ssrc.data(), ssize.data(), sdst.data(), (int64_t)ssrc.size(), flags, sstatus.data());
+        grc = dev ? mdc_process_jpeg_streams_host_to_device(gpu, ssrc.data(), ssize.data(), (int64_t)ssrc.size(), flags, dev, spos.data(), sstatus.data())
+                  : mdc_process_jpeg_streams_host(gpu, ssrc.data(), ssize.data(), sdst.data(), (int64_t)ssrc.size(), flags, sstatus.data());
         for (size_t q = 0; q < ssrc.size() && grc == MDC_OK; q++)
           if (sstatus[q] != 0) {  // a stream the device could not decode (damaged file): the host decoder has the last word
             const int i = sidx[q];
@@ -868,12 +904,17 @@ struct DatasetReader::State::LaneRun {
             one.cap = lane.ring_bytes;
             s.decode_now(one);
             if (one.ok && one.w == s.W && one.h == s.H) {
-              grc = mdc_process_host(gpu, one.dst, out[i]->image, flags);
+              const uint8_t* one_src = one.dst;
+              const int64_t one_pos = i;
+              grc = dev ? mdc_process_frames_host_to_device(gpu, &one_src, 1, flags, dev, &one_pos) : mdc_process_host(gpu, one.dst, out[i]->image, flags);
             } else {
               bad_frame(first + i, one.w, one.h);
               if (!one.ok) note_error(one.err);
-              delete out[i];
-              out[i] = 0;
+              if (!dev) {
+                delete out[i];
+                out[i] = 0;
+              }
+              if (valid) valid[i] = 0;
               refused++;
             }
           }
@@ -883,12 +924,16 @@ struct DatasetReader::State::LaneRun {
         note_error(mdc_last_error(gpu));
         std::fprintf(stderr, "DatasetReader::getImages: %s\n", mdc_last_error(gpu));
         for (int i = i0; i < i1; i++) {
-          delete out[i];
-          out[i] = 0;
+          if (!dev) {
+            delete out[i];
+            out[i] = 0;
+          }
+          if (valid) valid[i] = 0;
         }
       } else {
         produced += (int)src.size() + (int)rsrc.size() + (int)ssrc.size() - refused;
       }
+      cur_i0 = cur_i1 = 0;  // the chunk is settled: its images are results (or gone)
       if (j + RG < mine) submit(j + RG);  // the buffers of the lane's chunk j are free again
     }
     lane.frames += produced;
@@ -899,10 +944,29 @@ struct DatasetReader::State::LaneRun {
 
 int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamma, bool removeVignette, bool nanOverexposed,
                              ExposureImage** out) {
+  if (!out || count <= 0) return 0;
+  return run_batch(first, count, rectify, removeGamma, removeVignette, nanOverexposed, out, 0, 0);
+}
+
+int DatasetReader::getImagesDevice(int first, int count, bool rectify, bool removeGamma, bool removeVignette, bool nanOverexposed,
+                                   const mdc_device_outputs* out, unsigned char* valid) {
+  if (!out || !out->base || count <= 0) {
+    s_->err = "getImagesDevice: no device outputs";
+    return 0;
+  }
+  return run_batch(first, count, rectify, removeGamma, removeVignette, nanOverexposed, 0, out, valid);
+}
+
+mdc_ctx* DatasetReader::getContext() { return s_->gpu; }
+int DatasetReader::getDevice() const { return s_->lanes.empty() || !s_->gpu ? -1 : s_->lanes[0].device; }
+
+// getImages (out) / getImagesDevice (dev, valid): the decode pool -> per-device lanes -> pipelined GPU calls
+int DatasetReader::run_batch(int first, int count, bool rectify, bool removeGamma, bool removeVignette, bool nanOverexposed, ExposureImage** out,
+                             const mdc_device_outputs* dev, unsigned char* valid) {
   State& s = *s_;
   s.err.clear();
-  if (!out || count <= 0) return 0;
-  for (int i = 0; i < count; i++) out[i] = 0;
+  for (int i = 0; i < count && out; i++) out[i] = 0;
+  for (int i = 0; i < count && valid; i++) valid[i] = 0;
   if (first < 0 || first + count > (int)s.files.size()) {
     s.err = "frame range outside the sequence";
     return 0;
@@ -918,7 +982,7 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
   // more than one call gets a second ring's worth of buffers, so that the pool parses the next files while the GPU call of
   // the current ones runs (one ring: parse and GPU call take turns, 22 k frames/s).  With several devices (MDC_DEVICES) the
   // range is dealt to them in chunks of at least 64 frames, round-robin.
-  const int L = (int)s.lanes.size();
+  const int L = dev ? 1 : (int)s.lanes.size();  // device outputs live on ONE device: the first lane's
   int C = s.gpu_jpeg >= 2 ? State::kRingFrames : 32;
   if (L > 1 && s.gpu_jpeg >= 2) C = std::min<int>(State::kRingFrames, std::max(64, ((count + L - 1) / L + 63) / 64 * 64));
   const int nchunks = (count + C - 1) / C;
@@ -949,16 +1013,22 @@ int DatasetReader::getImages(int first, int count, bool rectify, bool removeGamm
   const bool trace = std::getenv("MDC_READER_TRACE") != 0;  // where a getImages call spends its time (stderr)
   std::vector<State::LaneRun> runs;
   runs.reserve((size_t)active);
-  for (int l = 0; l < active; l++) runs.push_back(State::LaneRun(s, s.lanes[(size_t)l], first, count, C, RG, active, l, rectify, flags, out, rec));
+  for (int l = 0; l < active; l++) {
+    runs.push_back(State::LaneRun(s, s.lanes[(size_t)l], first, count, C, RG, active, l, rectify, flags, out, rec));
+    runs.back().dev = dev;
+    runs.back().valid = valid;
+  }
   // every lane runs to its end whatever happens in another one (an exception -- out of memory for a list of pointers -- ends
   // that lane's chunks with an error, not the process: a std::thread must not be left joinable, a lane's images must not leak)
   auto run_lane = [&runs, &s](int l) {
     try {
       runs[(size_t)l].run();
     } catch (const std::exception& e) {
+      runs[(size_t)l].drop_chunk_in_flight();
       std::lock_guard<std::mutex> lk(s.err_mu);
       s.err = std::string("getImages: lane failed: ") + e.what();
     } catch (...) {
+      runs[(size_t)l].drop_chunk_in_flight();
       std::lock_guard<std::mutex> lk(s.err_mu);
       s.err = "getImages: lane failed";
     }

@@ -19,6 +19,7 @@
 
 #include "mdc_hip.h"
 #include "host_device.h"
+#include "../fov_point_model.h"  // atanf_host_libm: the restatement the device runs, checked against THIS process's libm below
 
 namespace {
 
@@ -259,7 +260,24 @@ void UndistorterFOV::distortCoordinates(float* in_x, float* in_y, int n) {
     const char* e = std::getenv("MDC_DISTORT_GPU_MIN");
     return e ? std::atol(e) : 65536l;
   }();
-  if (gpu_ && gpu_min > 0 && n >= gpu_min) {
+  // The device's atanf is a restatement of ONE libm's algorithm (glibc's fdlibm atanf).  A process linked against another libm
+  // -- a newer glibc whose atanf is correctly rounded, musl, a vendor libm -- would get last-bit differences between small
+  // calls (host loop, ::atanf) and large ones (device): checked once against the libm this process really runs, on a spread of
+  // arguments through every interval of the algorithm; on any difference bulk calls stay on the host, like the small ones.
+  static const bool libm_is_the_restated_one = [] {
+    uint32_t bad = 0;
+    for (uint32_t u = 0x30000000u; u < 0x4d800000u && !bad; u += 9973u) {  // 2^-31 .. 2^28, ~49,000 arguments, both signs
+      const float x = mdc::fov_float(u);
+      if (mdc::fov_bits(mdc::atanf_host_libm(x)) != mdc::fov_bits(::atanf(x)) ||
+          mdc::fov_bits(mdc::atanf_host_libm(-x)) != mdc::fov_bits(::atanf(-x)))
+        bad = u;
+    }
+    if (bad)
+      std::fprintf(stderr, "UndistorterFOV: this process's atanf differs from the algorithm the GPU kernel restates (first at %a): "
+                           "distortCoordinates stays on the host for every point count\n", mdc::fov_float(bad));
+    return bad == 0;
+  }();
+  if (gpu_ && gpu_min > 0 && n >= gpu_min && libm_is_the_restated_one) {
     mdc_fov_model m;
     for (int i = 0; i < 5; i++) {
       m.in_calib[i] = calib_in_[i];

@@ -380,6 +380,7 @@ bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap
   int ncomp = 0, W = 0, H = 0, restart = 0;
   size_t p = 2;
   bool have_sof = false;
+  JpegColorMarkers color;
   while (p + 4 <= n) {
     if (d[p] != 0xff) return fail(err, "JPEG: marker expected");
     while (p < n && d[p] == 0xff) p++;  // fill bytes
@@ -392,6 +393,7 @@ bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap
     if (len < 2 || p + len > n) return fail(err, "JPEG: bad segment length");
     const unsigned char* s = d + p + 2;
     const size_t sl = len - 2;
+    color.see(m, s, sl);
     if (m == 0xdb) {  // DQT
       size_t q = 0;
       while (q < sl) {
@@ -454,11 +456,16 @@ bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap
       const int vmax = ncomp == 1 ? 1 : std::max(comp[0].v, std::max(comp[1].v, comp[2].v));
       const int yh = ncomp == 1 ? 1 : comp[0].h, yv = ncomp == 1 ? 1 : comp[0].v;
       if (ncomp == 3 && (yh != hmax || yv != vmax)) return fail(err, "JPEG: luma is subsampled; unsupported");
+      // An RGB-encoded file (Adobe transform 0, or component ids R G B): gray is a weighted sum of ALL three components, not
+      // component 0 -- no luma record for the device, and on the host every component is inverted (1 x 1 sampling only).
+      const bool rgb = color.is_rgb(ncomp, comp[0].id, comp[1].id, comp[2].id);
+      if (rgb && sink) return fail(err, "JPEG: RGB-encoded file: no luma coefficient record");
+      if (rgb && (hmax != 1 || vmax != 1)) return fail(err, "JPEG: RGB-encoded file with subsampled components is not supported");
       const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
       const int mx = (W + mcu_w - 1) / mcu_w, my = (H + mcu_h - 1) / mcu_h;
       const size_t pw = (size_t)mx * mcu_w;  // padded luma row (luma has the full resolution)
       static thread_local std::vector<unsigned char> rows;
-      if (!sink) rows.resize(pw * mcu_h);
+      if (!sink) rows.resize(pw * mcu_h * (rgb ? 3 : 1));  // rgb: the R, G and B block rows one after the other
       if (sink) {  // coefficient output: quantised luma coefficients, natural order, [block row][block][64]; no inverse DCT here
         sink->w = W;
         sink->h = H;
@@ -486,7 +493,7 @@ bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap
           for (int c = 0; c < ncomp; c++) {
             const int nb = ncomp == 1 ? 1 : comp[c].h * comp[c].v;
             for (int k = 0; k < nb; k++) {
-              const bool luma = c == 0;
+              const bool luma = c == 0 || rgb;  // the component is kept (rgb: all three; then sink == nullptr)
               int16_t* blk = nullptr;  // (coefficient output) this luma block
               if (luma && sink) {
                 const int bx = ncomp == 1 ? 0 : k % comp[c].h, by = ncomp == 1 ? 0 : k / comp[c].h;
@@ -534,15 +541,21 @@ bool jpeg_gray8(const unsigned char* d, size_t n, unsigned char* out, size_t cap
               }
               if (luma && !sink) {
                 const int bx = ncomp == 1 ? 0 : k % comp[c].h, by = ncomp == 1 ? 0 : k / comp[c].h;
-                idct_islow(coef, rows.data() + (size_t)by * 8 * pw + (size_t)x * mcu_w + (size_t)bx * 8, pw, dc_only);
+                idct_islow(coef, rows.data() + (rgb ? (size_t)c * pw * mcu_h : 0) + (size_t)by * 8 * pw + (size_t)x * mcu_w + (size_t)bx * 8, pw, dc_only);
               }
             }
           }
           if (restart) to_restart--;
         }
         const int y0 = y * mcu_h, ny = std::min(mcu_h, H - y0);
-        if (!sink)
+        if (!sink && !rgb)
           for (int r = 0; r < ny; r++) memcpy(out + (size_t)(y0 + r) * W, rows.data() + (size_t)r * pw, (size_t)W);
+        if (!sink && rgb)  // libjpeg's rgb_gray_convert (jdcolor.c): (FIX(0.299) R + FIX(0.587) G + FIX(0.114) B + ONE_HALF) >> 16
+          for (int r = 0; r < ny; r++) {
+            const unsigned char *R = rows.data() + (size_t)r * pw, *G = R + pw * mcu_h, *B = G + pw * mcu_h;
+            unsigned char* o = out + (size_t)(y0 + r) * W;
+            for (int xx = 0; xx < W; xx++) o[xx] = (unsigned char)((19595 * R[xx] + 38470 * G[xx] + 7471 * B[xx] + 32768) >> 16);
+          }
       }
       return true;
     }
@@ -670,6 +683,7 @@ bool jpeg_stream(const unsigned char* d, size_t n, unsigned char* stream, size_t
     int id, h, v, tq;
   } comp[3] = {{0, 1, 1, 0}, {0, 1, 1, 0}, {0, 1, 1, 0}};
   bool have_sof = false;
+  JpegColorMarkers color;
   size_t p = 2;
   while (p + 4 <= n) {
     if (d[p] != 0xff) return fail(err, "JPEG: marker expected");
@@ -684,6 +698,7 @@ bool jpeg_stream(const unsigned char* d, size_t n, unsigned char* stream, size_t
     if (len < 2 || p + len > n) return fail(err, "JPEG: bad segment length");
     const unsigned char* s = d + p + 2;
     const size_t sl = len - 2;
+    color.see(m, s, sl);
     if (m == 0xdb) {
       size_t q = 0;
       while (q < sl) {
@@ -730,6 +745,8 @@ bool jpeg_stream(const unsigned char* d, size_t n, unsigned char* stream, size_t
     } else if (m == 0xda) {
       if (!have_sof) return fail(err, "JPEG: scan before frame header");
       if (sl < 1 || s[0] != ncomp || sl < 1 + 2 * (size_t)ncomp + 3) return fail(err, "JPEG stream: the components are not in one scan");
+      // the device keeps component 0 only: right for Y Cb Cr, wrong for an RGB-encoded file (gray = weighted sum of R, G, B) -> host decoder
+      if (color.is_rgb(ncomp, comp[0].id, comp[1].id, comp[2].id)) return fail(err, "JPEG stream: RGB-encoded file (no luma component)");
       int td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
       for (int i = 0; i < ncomp; i++) {
         if (s[1 + 2 * i] != comp[i].id) return fail(err, "JPEG stream: scan components out of frame order");

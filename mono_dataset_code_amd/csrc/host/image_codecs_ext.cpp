@@ -284,6 +284,7 @@ bool jpeg_progressive_gray8(const unsigned char* d, size_t n, unsigned char* out
   int lbw = 0, lbh = 0;                    // luma blocks: allocated grid (MCU padded)
   int lcw = 0, lch = 0;                    // luma blocks a non-interleaved luma scan covers
   std::vector<int16_t> coef;               // luma coefficients, [block][64] natural order
+  JpegColorMarkers color;
   size_t p = 2;
   while (p + 4 <= n) {
     if (d[p] != 0xff) return fail(err, "JPEG: marker expected");
@@ -297,6 +298,10 @@ bool jpeg_progressive_gray8(const unsigned char* d, size_t n, unsigned char* out
     if (len < 2 || p + len > n) return fail(err, "JPEG: bad segment length");
     const unsigned char* s = d + p + 2;
     const size_t sl = len - 2;
+    color.see(m, s, sl);
+    // only component 0 is kept below: wrong for an RGB-encoded file (cv::imread weighs R, G and B) -> refused, loudly
+    if (m == 0xda && color.is_rgb(ncomp, comp[0].id, comp[1].id, comp[2].id))
+      return fail(err, "JPEG: progressive RGB-encoded files (Adobe transform 0 / component ids R G B) are not supported");
     if (m == 0xdb) {
       size_t q = 0;
       while (q < sl) {

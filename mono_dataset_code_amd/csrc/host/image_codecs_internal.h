@@ -37,6 +37,27 @@ bool decode_jpeg_coefs(const unsigned char* data, size_t n, JpegCoefSink* sink, 
 // lossless files, restart intervals, 16-bit quantisation values above what a record holds, a stream that does not fit.
 bool jpeg_stream(const unsigned char* data, size_t n, unsigned char* stream, size_t cap, size_t* used, int* w, int* h, std::string* err);
 
+// Colour space of a three-component file as libjpeg decides it (jdapimin.c: default_decompress_parms): a JFIF marker means YCbCr;
+// else an Adobe marker's transform byte (0 = RGB, 1 = YCbCr); else the component ids (1 2 3 = YCbCr, 'R' 'G' 'B' = RGB); else YCbCr.
+// For an RGB file cv::imread(..., GRAYSCALE) returns 0.299 R + 0.587 G + 0.114 B (libjpeg's rgb_gray_convert), not component 0.
+struct JpegColorMarkers {
+  bool jfif = false, adobe = false;
+  int adobe_transform = 0;
+  void see(int marker, const unsigned char* s, size_t sl) {
+    if (marker == 0xe0 && sl >= 14 && s[0] == 'J' && s[1] == 'F' && s[2] == 'I' && s[3] == 'F' && s[4] == 0) jfif = true;
+    if (marker == 0xee && sl >= 12 && s[0] == 'A' && s[1] == 'd' && s[2] == 'o' && s[3] == 'b' && s[4] == 'e') {
+      adobe = true;
+      adobe_transform = s[11];
+    }
+  }
+  bool is_rgb(int ncomp, int id0, int id1, int id2) const {
+    if (ncomp != 3) return false;
+    if (jfif) return false;
+    if (adobe) return adobe_transform == 0;
+    return id0 == 'R' && id1 == 'G' && id2 == 'B';
+  }
+};
+
 bool jpeg_progressive_gray8(const unsigned char* data, size_t n, unsigned char* out, size_t cap, int* w, int* h, std::string* err,
                             JpegCoefSink* sink = nullptr);
 // libjpeg's islow inverse DCT on dequantised coefficients in natural order (image_codecs.cpp)

@@ -244,6 +244,12 @@ int mdch_reader_get_image(mdch_reader* h, int id, int rectify, int g, int v, int
   delete img;  // caller owns the ExposureImage (main_playbackDataset.cpp:82,116)
   return ok;
 } catch (...) { return {}; }  // no exception leaves the C facade
+int mdch_reader_get_images_device(mdch_reader* h, int first, int count, int rectify, int g, int v, int o, const mdc_device_outputs* out,
+                                  unsigned char* valid) try {
+  return h->r->getImagesDevice(first, count, rectify != 0, g != 0, v != 0, o != 0, out, valid);
+} catch (...) { return 0; }
+mdc_ctx* mdch_reader_context(mdch_reader* h) { return h->r->getContext(); }
+int mdch_reader_device(mdch_reader* h) { return h->r->getDevice(); }
 int mdch_reader_get_images(mdch_reader* h, int first, int count, int rectify, int g, int v, int o, float* out,
                            long frame_floats, unsigned char* ok) try {
   if (count <= 0) return 0;

@@ -46,9 +46,6 @@
 #ifndef MDC_EXP_HUFF_PROVISIONAL
 #define MDC_EXP_HUFF_PROVISIONAL 1  // ... segments hand on a provisional exit state first (0: the final one only, one relaxation after the other down the chain)
 #endif
-#ifndef MDC_EXP_BURST
-#define MDC_EXP_BURST 1  // tiled kernel, 512-thread tiles: K > 1 = LDS-DMA of K frames back to back, then K frames computed and stored back to back (2 K windows); 1 = frame by frame
-#endif
 // MDC_EXP_STORE_AUX (undefined = follow MDC_EXP_STORE_NT): raw cache-policy bits of the output stores
 
 // ---- debug -------------------------------------------------------------------------------------------------------
@@ -111,7 +108,6 @@ inline const char* build_flags_string() {
       MDC_CFG_ITEM(MDC_EXP_GUESS_MIN_BITS, 512),
       MDC_CFG_ITEM(MDC_EXP_HUFF_MAX_SEGMENTS, 8),
       MDC_CFG_ITEM(MDC_EXP_HUFF_PROVISIONAL, 1),
-      MDC_CFG_ITEM(MDC_EXP_BURST, 1),
 #ifdef MDC_EXP_STORE_AUX
       " MDC_EXP_STORE_AUX=" MDC_CFG_STR(MDC_EXP_STORE_AUX),
 #endif

@@ -283,6 +283,72 @@ int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
   return MDC_OK;
 }
 
+// base + box levels (+ gradient images when d_dI / d_abs_squared_grad are given) of nframes device-resident raw frames, in chunks;
+// lock held by the caller (mdc_process_pyramid_gradients_batch_device and the *_to_device pipeline, mdc_pipeline.hip)
+int enqueue_pyramid_gradients(mdc_ctx* c, const uint8_t* d_in, float* d_base, int levels, float* const* d_levels, float* const* d_dI,
+                              float* const* d_abs_squared_grad, int64_t nframes, unsigned flags, int chunk_frames, hipStream_t s) {
+  const bool with_gradients = d_dI != nullptr && d_abs_squared_grad != nullptr;
+  const bool rect = (flags & MDC_RECTIFY) != 0;
+  if (rect && !c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
+  const int w0 = rect ? c->out_w : (c->in_w > 0 ? c->in_w : c->rm_in_w), h0 = rect ? c->out_h : (c->in_h > 0 ? c->in_h : c->rm_in_h);
+  const int iw = (rect || c->in_w <= 0) ? c->rm_in_w : c->in_w, ih = (rect || c->in_h <= 0) ? c->rm_in_h : c->in_h;
+  if (w0 <= 0 || h0 <= 0 || iw <= 0 || ih <= 0) return fail(c, MDC_ERR_STATE, "frame size unknown");
+  int lw[8], lh[8];
+  size_t level_bytes = 0;
+  for (int l = 0; l < levels; l++) {
+    lw[l] = w0 >> l;
+    lh[l] = h0 >> l;
+    if (lw[l] < 1 || lh[l] < 1) return fail(c, MDC_ERR_ARG, "level %d of a %dx%d image is empty", l, w0, h0);
+    level_bytes += (size_t)lw[l] * lh[l] * sizeof(float);
+  }
+  // Frames per chunk.  Measured (tools/dso_rate.py, 1280 x 1024, 512 frames, profiles/r03_dso_rate.txt): 8 frames per chunk
+  // 5.0 ms, 24: 4.2, 96: 3.85-3.89, separate launches over the whole batch: 3.87-3.95 -- the levels are NOT read back from the
+  // Infinity Cache (the remap's stores are nontemporal: plain ones evict its prefetched source rows and measured slower in
+  // total, experiment 11), the whole path runs at what the memory system gives 34.8 MB of writes + 7.6 MB of reads per
+  // frame; chunks exist to bound the launch sizes, and below ~100 frames they lose to their tails.  Round 4, frames/s by chunk:
+  // 91: 130.6 k, 6 x 86: 133 k, 96: 137-140 k, one chunk of 512: 134-137 k -- the automatic choice is 96 at 1280 x 1024.
+  int64_t chunk = chunk_frames;
+  if (chunk <= 0) {  // ~96 frames' worth at 1280 x 1024, a multiple of 32 (the remap launch's frames per workgroup divide it)
+    chunk = (int64_t)((672ull << 20) / level_bytes);
+    chunk = chunk >= 32 ? chunk / 32 * 32 : std::max<int64_t>(1, chunk);
+  }
+  {  // a gradient launch holds a chunk's workgroups of up to four levels: fewer than 2^31 (128 x 8 pixels each)
+    int64_t wgs = 0;
+    for (int l = 0; l < std::min(levels, 4); l++) wgs += (int64_t)((lw[l] + 127) / 128) * ((lh[l] + 7) / 8);
+    chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, ((1ll << 31) - 1) / std::max<int64_t>(1, wgs)));
+  }
+  const size_t npi = (size_t)iw * ih;
+  for (int64_t f0 = 0; f0 < nframes; f0 += chunk) {
+    const int64_t n = std::min<int64_t>(chunk, nframes - f0);
+    float* lv[8];
+    for (int l = 1; l < levels; l++) lv[l - 1] = d_levels[l - 1] + (size_t)f0 * lw[l] * lh[l];
+    float* base = d_base + (size_t)f0 * w0 * h0;
+    float* pyr[3] = {levels > 1 ? lv[0] : nullptr, levels > 2 ? lv[1] : nullptr, levels > 3 ? lv[2] : nullptr};
+    bool fused = false;
+    int rc = enqueue_process(c, d_in + (size_t)f0 * npi, base, n, flags, s, levels > 1 ? pyr : nullptr, &fused);
+    if (rc != MDC_OK) return rc;
+    const int first = fused ? std::min(levels, 4) : 1;
+    const float* src = first == 1 ? base : lv[first - 2];
+    for (int l = first; l < levels; l++) {
+      MDC_HIP(c, launch_pyramid_level(src, lv[l - 1], lw[l - 1], lh[l - 1], n, s));
+      src = lv[l - 1];
+    }
+    for (int l0 = 0; l0 < levels && with_gradients; l0 += 4) {  // gradients: four levels per launch
+      const int nl = std::min(4, levels - l0);
+      const float* gs[4];
+      float *gd[4], *ga[4];
+      for (int k = 0; k < nl; k++) {
+        const int l = l0 + k;
+        gs[k] = l == 0 ? base : lv[l - 1];
+        gd[k] = d_dI[l] + (size_t)f0 * lw[l] * lh[l] * 3;
+        ga[k] = d_abs_squared_grad[l] + (size_t)f0 * lw[l] * lh[l];
+      }
+      MDC_HIP(c, launch_gradients_levels(nl, gs, gd, ga, lw + l0, lh + l0, n, s));
+    }
+  }
+  return MDC_OK;
+}
+
 struct BlobHeader {
   uint32_t magic, version;
   int32_t in_w, in_h, rm_in_w, rm_in_h, out_w, out_h;
@@ -704,66 +770,7 @@ int mdc_process_pyramid_gradients_batch_device(mdc_ctx* c, const uint8_t* d_in, 
     if ((l && !d_levels[l - 1]) || !d_dI[l] || !d_abs_squared_grad[l]) return fail(c, MDC_ERR_ARG, "level %d has a NULL buffer", l);
   ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
-  hipStream_t s = (hipStream_t)stream;
-  const bool rect = (flags & MDC_RECTIFY) != 0;
-  if (rect && !c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
-  const int w0 = rect ? c->out_w : (c->in_w > 0 ? c->in_w : c->rm_in_w), h0 = rect ? c->out_h : (c->in_h > 0 ? c->in_h : c->rm_in_h);
-  const int iw = (rect || c->in_w <= 0) ? c->rm_in_w : c->in_w, ih = (rect || c->in_h <= 0) ? c->rm_in_h : c->in_h;
-  if (w0 <= 0 || h0 <= 0 || iw <= 0 || ih <= 0) return fail(c, MDC_ERR_STATE, "frame size unknown");
-  int lw[8], lh[8];
-  size_t level_bytes = 0;
-  for (int l = 0; l < levels; l++) {
-    lw[l] = w0 >> l;
-    lh[l] = h0 >> l;
-    if (lw[l] < 1 || lh[l] < 1) return fail(c, MDC_ERR_ARG, "level %d of a %dx%d image is empty", l, w0, h0);
-    level_bytes += (size_t)lw[l] * lh[l] * sizeof(float);
-  }
-  // Frames per chunk.  Measured (tools/dso_rate.py, 1280 x 1024, 512 frames, profiles/r03_dso_rate.txt): 8 frames per chunk
-  // 5.0 ms, 24: 4.2, 96: 3.85-3.89, separate launches over the whole batch: 3.87-3.95 -- the levels are NOT read back from the
-  // Infinity Cache (the remap's stores are nontemporal: plain ones evict its prefetched source rows and measured slower in
-  // total, experiment 11), the whole path runs at what the memory system gives 34.8 MB of writes + 7.6 MB of reads per
-  // frame; chunks exist to bound the launch sizes, and below ~100 frames they lose to their tails.  Round 4, frames/s by chunk:
-  // 91: 130.6 k, 6 x 86: 133 k, 96: 137-140 k, one chunk of 512: 134-137 k -- the automatic choice is 96 at 1280 x 1024.
-  int64_t chunk = chunk_frames;
-  if (chunk <= 0) {  // ~96 frames' worth at 1280 x 1024, a multiple of 32 (the remap launch's frames per workgroup divide it)
-    chunk = (int64_t)((672ull << 20) / level_bytes);
-    chunk = chunk >= 32 ? chunk / 32 * 32 : std::max<int64_t>(1, chunk);
-  }
-  {  // a gradient launch holds a chunk's workgroups of up to four levels: fewer than 2^31 (128 x 8 pixels each)
-    int64_t wgs = 0;
-    for (int l = 0; l < std::min(levels, 4); l++) wgs += (int64_t)((lw[l] + 127) / 128) * ((lh[l] + 7) / 8);
-    chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, ((1ll << 31) - 1) / std::max<int64_t>(1, wgs)));
-  }
-  const size_t npi = (size_t)iw * ih;
-  for (int64_t f0 = 0; f0 < nframes; f0 += chunk) {
-    const int64_t n = std::min<int64_t>(chunk, nframes - f0);
-    float* lv[8];
-    for (int l = 1; l < levels; l++) lv[l - 1] = d_levels[l - 1] + (size_t)f0 * lw[l] * lh[l];
-    float* base = d_base + (size_t)f0 * w0 * h0;
-    float* pyr[3] = {levels > 1 ? lv[0] : nullptr, levels > 2 ? lv[1] : nullptr, levels > 3 ? lv[2] : nullptr};
-    bool fused = false;
-    int rc = enqueue_process(c, d_in + (size_t)f0 * npi, base, n, flags, s, levels > 1 ? pyr : nullptr, &fused);
-    if (rc != MDC_OK) return rc;
-    const int first = fused ? std::min(levels, 4) : 1;
-    const float* src = first == 1 ? base : lv[first - 2];
-    for (int l = first; l < levels; l++) {
-      MDC_HIP(c, launch_pyramid_level(src, lv[l - 1], lw[l - 1], lh[l - 1], n, s));
-      src = lv[l - 1];
-    }
-    for (int l0 = 0; l0 < levels; l0 += 4) {  // gradients: four levels per launch
-      const int nl = std::min(4, levels - l0);
-      const float* gs[4];
-      float *gd[4], *ga[4];
-      for (int k = 0; k < nl; k++) {
-        const int l = l0 + k;
-        gs[k] = l == 0 ? base : lv[l - 1];
-        gd[k] = d_dI[l] + (size_t)f0 * lw[l] * lh[l] * 3;
-        ga[k] = d_abs_squared_grad[l] + (size_t)f0 * lw[l] * lh[l];
-      }
-      MDC_HIP(c, launch_gradients_levels(nl, gs, gd, ga, lw + l0, lh + l0, n, s));
-    }
-  }
-  return MDC_OK;
+  return enqueue_pyramid_gradients(c, d_in, d_base, levels, d_levels, d_dI, d_abs_squared_grad, nframes, flags, chunk_frames, (hipStream_t)stream);
 } MDC_CATCH(c)
 
 int mdc_vcal_plane_step_device(mdc_ctx* c, const float* d_images, const float* d_p2x, const float* d_p2y, int n_images, int w, int h,

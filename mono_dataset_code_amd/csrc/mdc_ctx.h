@@ -196,6 +196,8 @@ RemapArgs remap_args(const mdc_ctx* c, const float* lut, const float* vinv);
 // the fused pass (or unMapImage alone) over device frames, on stream s; pyr: levels 1..3 wanted (-> *pyr_done: written by this launch)
 int enqueue_process(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, hipStream_t s, float* const* pyr = nullptr,
                     bool* pyr_done = nullptr);
+int enqueue_pyramid_gradients(mdc_ctx* c, const uint8_t* d_in, float* d_base, int levels, float* const* d_levels, float* const* d_dI,
+                              float* const* d_abs_squared_grad, int64_t nframes, unsigned flags, int chunk_frames, hipStream_t s);
 int enqueue_undistort_f32(mdc_ctx* c, const float* d_in, float* d_out, int64_t nframes, hipStream_t s);
 DistortModel distort_model(const mdc_fov_model* f);
 

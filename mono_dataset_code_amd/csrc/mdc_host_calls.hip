@@ -173,10 +173,15 @@ int mdc_distort_points_host(mdc_ctx* c, const mdc_fov_model* model, float* x, fl
   MDC_HIP(c, hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, st));
   MDC_HIP(c, hipMemcpyAsync(dy, y, bytes, hipMemcpyHostToDevice, st));
   MDC_HIP(c, launch_distort_points(dx, dy, n, distort_model(model), st));
-  MDC_HIP(c, hipMemcpyAsync(x, dx, bytes, hipMemcpyDeviceToHost, st));
-  MDC_HIP(c, hipMemcpyAsync(y, dy, bytes, hipMemcpyDeviceToHost, st));
+  // Results reach the caller's arrays only after everything succeeded: a failure half way (x copied back, y not) would leave a
+  // caller that falls back to its own loop (UndistorterFOV::distortCoordinates) distorting x a second time.
+  std::vector<float> hx((size_t)n), hy((size_t)n);
+  MDC_HIP(c, hipMemcpyAsync(hx.data(), dx, bytes, hipMemcpyDeviceToHost, st));
+  MDC_HIP(c, hipMemcpyAsync(hy.data(), dy, bytes, hipMemcpyDeviceToHost, st));
   MDC_HIP(c, hipStreamSynchronize(st));
   slot.drained();
+  memcpy(x, hx.data(), bytes);
+  memcpy(y, hy.data(), bytes);
   return MDC_OK;
 } MDC_CATCH(c)
 

@@ -553,55 +553,6 @@ __device__ __forceinline__ void frame_barrier(int rw) {
   else wait_vm_barrier<S>();
 }
 
-// Burst grouping (MDC_EXP_BURST = K > 1, experiment r05/02): 2 K window buffers in two halves.  The LDS-DMA of K frames is issued back to
-// back, then those K frames are computed and stored back to back, ONE barrier per K frames -- longer read bursts and longer write
-// bursts at the memory system than "one DMA set, four stores" per frame, which is what any NBUF depth of the loop below interleaves.
-// Same arithmetic on the same windows: bit-identical.  Group g's DMA is issued at the top of iteration g-1, behind the barrier that
-// ended iteration g-2's reads of that half; the wait at the end of iteration g-1 lets the K * RPT stores issued after it stay in flight.
-template <bool VIG, bool BLACK, int R, int TW, int NT, int K, int RPT>
-__device__ __forceinline__ void tile_frames_burst(const TileThread<RPT>& t, const uint8_t* __restrict__ src, float* __restrict__ dst,
-                                                  uint32_t in_bytes, uint32_t out_bytes, int nframes, int nch,
-                                                  const uint32_t (&goff_all)[kTileMaxChunks], lds_u8_ptr s_win, int win_bytes, lds_f32_ptr my_lut,
-                                                  int tid, int fstep, uint32_t row_bytes) {
-  const long long in_step = (long long)fstep * in_bytes;
-  const long long out_step = (long long)fstep * (out_bytes / 4);
-  uint32_t goff[R];
-#pragma unroll
-  for (int k = 0; k < R; k++) goff[k] = goff_all[k];
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int rw = 0;
-#pragma unroll
-  for (int k = 0; k < R; k++) rw += (wave * 64 + k * NT < nch) ? 1 : 0;
-  const int last = nframes - 1;
-  const int ngroups = (nframes + K - 1) / K;
-#pragma unroll
-  for (int d = 0; d < K; d++) stage_window<R, NT>(src + (long long)min(d, last) * in_step, in_bytes, s_win + d * win_bytes, goff, wave, rw);
-  wait_vm_barrier<0>();
-  int half = 0;
-  const uint8_t* stg = src + (long long)K * in_step;  // first frame of the NEXT group
-  for (int g = 0; g < ngroups; g++) {
-    const int fb = g * K;
-    const bool more = g + 1 < ngroups;  // workgroup-uniform
-    if (more) {
-#pragma unroll
-      for (int d = 0; d < K; d++)  // (frames past the end: the last frame once more -- its window is never sampled)
-        stage_window<R, NT>(stg + (long long)min(d, last - fb - K) * in_step, in_bytes, s_win + ((half ^ 1) * K + d) * win_bytes, goff, wave, rw);
-      stg += (long long)K * in_step;
-    }
-#pragma unroll
-    for (int d = 0; d < K; d++) {
-      if (fb + d <= last) {
-        float res[RPT];
-        tile_compute<VIG, BLACK, false, false, 4, RPT>(t, s_win + (half * K + d) * win_bytes, my_lut, dst, out_bytes, row_bytes, res, win_bytes);
-        dst += out_step;
-      }
-    }
-    // a group with a successor is full: exactly K * RPT stores were issued behind the successor's DMA
-    if (more) wait_vm_barrier<K * RPT>();
-    half ^= 1;
-  }
-}
-
 // Frames [0, nframes) of one tile.  NBUF window buffers, D = NBUF-1 frames staged ahead: the DMA
 // of frame f+D is issued before frame f is computed; one barrier per frame.
 template <bool VIG, bool BLACK, bool PYR, bool F32, int R, int TW, int NT, int NBUF, int RPT>
@@ -612,11 +563,6 @@ __device__ __forceinline__ void tile_frames(const TileThread<RPT>& t, const uint
                                             const PyramidOut& py, long long f_first, int fstep, uint32_t p3byte,
                                             uint32_t row_bytes) {
   // iteration i works on frame f_first + i*fstep; src / dst point at that workgroup's first frame
-  if constexpr (MDC_EXP_BURST > 1 && NBUF == 2 * MDC_EXP_BURST && NT <= 512 && !PYR && !F32 && RPT == 4) {
-    tile_frames_burst<VIG, BLACK, R, TW, NT, MDC_EXP_BURST, RPT>(t, src, dst, in_bytes, out_bytes, nframes, nch, goff_all, s_win, win_bytes, my_lut, tid,
-                                                                 fstep, row_bytes);
-    return;
-  }
   constexpr int D = NBUF - 1;
   const long long in_step = (long long)fstep * in_bytes;
   const long long out_step = (long long)fstep * (out_bytes / 4);
@@ -1361,11 +1307,6 @@ static hipError_t launch_tiled_buf(const TiledLaunch& l) {
     case 4:
       if constexpr (NT <= 512) return launch_tiled_variant<VIG, BLACK, PYR, F32, TW, NT, 4>(l);  // 4 buffers of a 1024-thread tile never fit
       break;
-#if MDC_EXP_BURST == 3
-    case 6:  // burst grouping of 3 frames: two halves of three windows
-      if constexpr (NT <= 512 && !PYR && !F32) return launch_tiled_variant<VIG, BLACK, PYR, F32, TW, NT, 6>(l);
-      break;
-#endif
   }
   return hipErrorInvalidValue;
 }

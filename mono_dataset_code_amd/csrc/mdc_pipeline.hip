@@ -39,6 +39,8 @@ struct PipelineCall {
   int* status;
   int64_t record_bytes;
   int blocks_w, blocks_rows;
+  const mdc_device_outputs* dev = nullptr;  // results stay on the device (the *_to_device calls): `out` is not used
+  const int64_t* dev_index = nullptr;       // frame i -> position in dev's arrays (nullptr: i)
   // ---- geometry
   int iw = 0, ih = 0;
   size_t n_in = 0, n_out = 0, strm_stride = 0;
@@ -71,7 +73,15 @@ struct PipelineCall {
 
   // Arguments and geometry.  Streams are decoded into records of the reader's geometry (block grid rounded up to multiples of 12).
   int validate() {
-    if (nframes < 0 || (nframes > 0 && ((!raw && !rec && !strm) || !out || (strm && !strm_bytes)))) return fail(c, MDC_ERR_ARG, "%s: bad argument", who);
+    if (nframes < 0 || (nframes > 0 && ((!raw && !rec && !strm) || (!out && !dev) || (strm && !strm_bytes)))) return fail(c, MDC_ERR_ARG, "%s: bad argument", who);
+    if (dev) {
+      if (!dev->base || dev->levels < 1 || dev->levels > 4) return fail(c, MDC_ERR_ARG, "%s: device outputs need a base array and 1..4 levels", who);
+      const bool grads = dev->dI[0] != nullptr;
+      for (int l = 0; l < dev->levels; l++)
+        if ((l && !dev->level[l - 1]) || (grads && (!dev->dI[l] || !dev->abs_squared_grad[l]))) return fail(c, MDC_ERR_ARG, "%s: level %d has a NULL device array", who, l);
+      for (int64_t i = 0; i < nframes && dev_index; i++)
+        if (dev_index[i] < 0) return fail(c, MDC_ERR_ARG, "%s: negative frame index", who);
+    }
     const bool rect = (flags & MDC_RECTIFY) != 0;
     if (rect && !c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
     iw = (rect || c->in_w <= 0) ? c->rm_in_w : c->in_w;
@@ -94,7 +104,7 @@ struct PipelineCall {
                           record_bytes < 128 + (int64_t)blocks_w * blocks_rows * 128))
       return fail(c, MDC_ERR_ARG, "%s: coefficient records do not describe a %dx%d frame", who, iw, ih);
     for (int64_t i = 0; i < nframes; i++)
-      if (!(strm ? strm[i] : rec ? rec[i] : (const void*)raw[i]) || !out[i])
+      if (!(strm ? strm[i] : rec ? rec[i] : (const void*)raw[i]) || (!dev && !out[i]))
         return fail(c, MDC_ERR_ARG, "%s: frame %lld has a NULL buffer", who, (long long)i);
     if (status)
       for (int64_t i = 0; i < nframes; i++) status[i] = 0;
@@ -131,6 +141,11 @@ struct PipelineCall {
   void choose_mode() {
     z_out.assign((size_t)nframes, nullptr);
     z_in.assign((rec || strm) ? 0 : (size_t)nframes, nullptr);
+    if (dev) {  // results stay in HBM: nothing to map, frames go up by copy; raw frames in chunks of 64 (the way out costs nothing now)
+      zc_in = zc_out = false;
+      chunk = 64;
+      return;
+    }
     zc_out = nframes > 0 && !strm;
     zc_in = !rec && !strm && nframes > 0;
     for (int64_t i = 0; i < nframes && zc_out; i++) zc_out = (z_out[(size_t)i] = device_view(c, out[i], n_out * sizeof(float))) != nullptr;
@@ -152,7 +167,7 @@ struct PipelineCall {
 
   // Two chunk slots of staging buffers, the two streams (+ the upload stream of the JPEG-stream mode) and their events.
   int ensure_buffers() {
-    const size_t in_need = zc_in ? 0 : chunk * n_in, out_need = zc_out ? 0 : chunk * n_out * sizeof(float);
+    const size_t in_need = zc_in ? 0 : chunk * n_in, out_need = (zc_out || dev) ? 0 : chunk * n_out * sizeof(float);
     const size_t rec_need = (rec || strm) ? (size_t)chunk * (size_t)record_bytes : 0;
     const size_t strm_need = strm ? (size_t)chunk * strm_stride : 0;
     if (c->pipe_in_cap < in_need || c->pipe_out_cap < out_need || c->pipe_rec_cap < rec_need || c->pipe_strm_cap < strm_need || !c->pipe_stream[0] ||
@@ -272,6 +287,32 @@ struct PipelineCall {
 
   // The fused pass of one chunk and its way out, on s_out.
   void emit(int64_t f0, int n, int slot, hipStream_t s_out) {
+    if (dev) {  // straight into the caller's device arrays: one launch set per run of frames with consecutive positions
+      const bool rect = (flags & MDC_RECTIFY) != 0;
+      const int w0 = rect ? c->out_w : iw, h0 = rect ? c->out_h : ih;
+      const bool grads = dev->dI[0] != nullptr;
+      for (int i = 0; i < n && rc == MDC_OK;) {
+        const int64_t pos = dev_index ? dev_index[f0 + i] : f0 + i;
+        int run = 1;
+        while (i + run < n && (dev_index ? dev_index[f0 + i + run] : f0 + i + run) == pos + run) run++;
+        const uint8_t* src = c->d_pipe_in[slot] + (size_t)i * n_in;
+        float* base = dev->base + (size_t)pos * n_out;
+        if (dev->levels == 1 && !grads) {
+          rc = enqueue_process(c, src, base, run, flags, s_out);
+        } else {
+          float *lv[3] = {nullptr, nullptr, nullptr}, *gi[4], *ga[4];
+          for (int l = 0; l < dev->levels; l++) {
+            const size_t npl = (size_t)(w0 >> l) * (size_t)(h0 >> l);
+            if (l) lv[l - 1] = dev->level[l - 1] + (size_t)pos * npl;
+            gi[l] = grads ? dev->dI[l] + (size_t)pos * npl * 3 : nullptr;
+            ga[l] = grads ? dev->abs_squared_grad[l] + (size_t)pos * npl : nullptr;
+          }
+          rc = enqueue_pyramid_gradients(c, src, base, dev->levels, lv, grads ? gi : nullptr, grads ? ga : nullptr, run, flags, 0, s_out);
+        }
+        i += run;
+      }
+      return;
+    }
     if (zc_out) {  // in place: one launch per run of frames that lie back to back on both sides
       for (int i = 0; i < n && rc == MDC_OK;) {
         const uint8_t* src = zc_in ? z_in[(size_t)(f0 + i)] : c->d_pipe_in[slot] + (size_t)i * n_in;
@@ -386,12 +427,13 @@ struct PipelineCall {
 
 int process_frames_pipeline(mdc_ctx* c, const uint8_t* const* raw, const void* const* rec, int64_t record_bytes, int blocks_w, int blocks_rows,
                             float* const* out, int64_t nframes, unsigned flags, const char* who, const void* const* strm = nullptr,
-                            const int64_t* strm_bytes = nullptr, int* status = nullptr) {
+                            const int64_t* strm_bytes = nullptr, int* status = nullptr, const mdc_device_outputs* dev = nullptr,
+                            const int64_t* dev_index = nullptr) {
   if (!c) return MDC_ERR_ARG;
   ReadLock lk(c->mu);
   std::lock_guard<std::mutex> pipe_lk(c->pipe_mu);  // one pipelined call at a time per context (it overlaps internally)
   DeviceGuard dg(c->device);
-  PipelineCall p{c, who, raw, rec, strm, strm_bytes, out, nframes, flags, status, record_bytes, blocks_w, blocks_rows};
+  PipelineCall p{c, who, raw, rec, strm, strm_bytes, out, nframes, flags, status, record_bytes, blocks_w, blocks_rows, dev, dev_index};
   return p.run();
 }
 
@@ -411,6 +453,49 @@ int mdc_process_jpeg_frames_host(mdc_ctx* c, const void* const* records, int64_t
 int mdc_process_jpeg_streams_host(mdc_ctx* c, const void* const* streams, const int64_t* stream_bytes, float* const* out, int64_t nframes,
                                   unsigned flags, int* status) try {
   return process_frames_pipeline(c, nullptr, nullptr, 0, 0, 0, out, nframes, flags, "mdc_process_jpeg_streams_host", streams, stream_bytes, status);
+} MDC_CATCH(c)
+
+int mdc_process_frames_host_to_device(mdc_ctx* c, const uint8_t* const* raw, int64_t nframes, unsigned flags, const mdc_device_outputs* out,
+                                      const int64_t* frame_index) try {
+  if (c && !out) return fail(c, MDC_ERR_ARG, "mdc_process_frames_host_to_device: no device outputs");
+  return process_frames_pipeline(c, raw, nullptr, 0, 0, 0, nullptr, nframes, flags, "mdc_process_frames_host_to_device", nullptr, nullptr, nullptr, out, frame_index);
+} MDC_CATCH(c)
+
+int mdc_process_jpeg_frames_host_to_device(mdc_ctx* c, const void* const* records, int64_t record_bytes, int blocks_w, int blocks_rows, int64_t nframes,
+                                           unsigned flags, const mdc_device_outputs* out, const int64_t* frame_index) try {
+  if (c && !out) return fail(c, MDC_ERR_ARG, "mdc_process_jpeg_frames_host_to_device: no device outputs");
+  return process_frames_pipeline(c, nullptr, records, record_bytes, blocks_w, blocks_rows, nullptr, nframes, flags, "mdc_process_jpeg_frames_host_to_device", nullptr,
+                                 nullptr, nullptr, out, frame_index);
+} MDC_CATCH(c)
+
+int mdc_process_jpeg_streams_host_to_device(mdc_ctx* c, const void* const* streams, const int64_t* stream_bytes, int64_t nframes, unsigned flags,
+                                            const mdc_device_outputs* out, const int64_t* frame_index, int* status) try {
+  if (c && !out) return fail(c, MDC_ERR_ARG, "mdc_process_jpeg_streams_host_to_device: no device outputs");
+  return process_frames_pipeline(c, nullptr, nullptr, 0, 0, 0, nullptr, nframes, flags, "mdc_process_jpeg_streams_host_to_device", streams, stream_bytes, status, out,
+                                 frame_index);
+} MDC_CATCH(c)
+
+int mdc_device_alloc(mdc_ctx* c, size_t bytes, void** d_ptr) try {
+  if (!c) return MDC_ERR_ARG;
+  if (!d_ptr) return fail(c, MDC_ERR_ARG, "mdc_device_alloc: bad argument");
+  *d_ptr = nullptr;
+  DeviceGuard dg(c->device);
+  MDC_HIP(c, hipMalloc(d_ptr, std::max<size_t>(bytes, 1)));
+  return MDC_OK;
+} MDC_CATCH(c)
+
+void mdc_device_free(mdc_ctx* c, void* d_ptr) {
+  if (!c || !d_ptr) return;
+  DeviceGuard dg(c->device);
+  (void)hipFree(d_ptr);
+}
+
+int mdc_copy_to_host(mdc_ctx* c, void* dst, const void* d_src, size_t bytes) try {
+  if (!c) return MDC_ERR_ARG;
+  if (bytes && (!dst || !d_src)) return fail(c, MDC_ERR_ARG, "mdc_copy_to_host: bad argument");
+  DeviceGuard dg(c->device);
+  MDC_HIP(c, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return MDC_OK;
 } MDC_CATCH(c)
 
 }  // extern "C"

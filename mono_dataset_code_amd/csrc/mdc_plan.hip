@@ -188,7 +188,6 @@ int plan_source(mdc_ctx* c, int es, int kTileW, int kTileH, mdc_ctx::SrcPlan& pl
   int nbuf = 2;
   while (kTileThreads <= 512 && nbuf < nbuf_max && tiled_lds_bytes(win_bytes, nbuf + 1, lut) * wg_per_cu <= kLdsPerCU) nbuf++;
   if (c->opt_nbuf >= 2) nbuf = std::min(c->opt_nbuf, nbuf_max);
-  if (MDC_EXP_BURST > 1 && kTileThreads <= 512 && lut) nbuf = 2 * MDC_EXP_BURST;  // burst grouping (experiment build): two halves of K windows
   if (tile_rpt(kTileW, kTileH) > 4) nbuf = 3;  // the only instantiation of the 8-rows-per-thread tiles (mdc_kernels.hip: launch_tiled_buf)
   if (tiled_lds_bytes(win_bytes, nbuf, lut) > kLdsPerCU) {
     ok = false;

@@ -807,3 +807,88 @@ def test_gpu_idct_on_coefficients_of_any_magnitude(size):
     for i in range(n):
         want = islow_idct_reference(recs[i], w, h, pitch, rows)
         assert np.array_equal(got[i], want), (i, int((got[i] != want).sum()), np.argwhere(got[i] != want)[:3].tolist())
+
+
+@pytest.mark.parametrize("fmt,stage", [("jpg", 2), ("jpg", 1), ("jpg", 0), ("png", 2)])
+def test_get_images_device_equals_get_images(tmp_path, oracle, fmt, stage):
+    """DatasetReader::getImagesDevice (row f1/f2/f4 with a device-resident end): files -> decode pool -> upload -> (Huffman ->) (inverse
+    DCT ->) fused pass, results LEFT IN HBM in the caller's arrays.  After a copy back: the same bytes as getImages, for every JPEG
+    stage and for PNG, sub-ranges included; with levels = 4 and gradient arrays: == mdc_process_pyramid_gradients_batch_device on the
+    decoded frames == the oracle's chain (box levels and gradients: own definition, parity unpinned)."""
+    import torch
+
+    from mono_dataset_code_amd import capi
+
+    h, w = 256, 320
+    n = 70  # more than one 64-frame chunk of the stream pipeline
+    frames = frames_for(n, h, w)
+    names, blobs = make_sequence(str(tmp_path), frames, True, fmt)
+    r = capi.DatasetReader(str(tmp_path))
+    r.set_gpu_jpeg(stage)
+    assert r.device() == 0
+    ow, oh = r.out_w, r.out_h
+    for first, count, fl in ((0, n, (1, 1, 1, 1)), (5, 40, (0, 1, 1, 0)), (3, 66, (1, 0, 0, 1))):
+        want, ok, got = r.get_images(first, count, *fl)
+        assert got == count and ok.all()
+        npo = ow * oh if fl[0] else w * h
+        d_base = torch.full((count, npo), -3.0, dtype=torch.float32, device="cuda")
+        outs = capi.DeviceOutputs.make(d_base.data_ptr())
+        valid, got_d = r.get_images_device(first, count, *fl, outs)
+        assert got_d == count and valid.all(), r.last_error()
+        assert bits_equal(d_base.cpu().numpy(), want), (fmt, stage, first, count, fl)
+    # base + levels 1..3 + gradient images of every level, rectified
+    count, fl = n, (1, 1, 1, 1)
+    dims = [(ow >> l, oh >> l) for l in range(4)]
+    d_base = torch.zeros((count, ow * oh), dtype=torch.float32, device="cuda")
+    d_lv = [torch.zeros((count, a * b), dtype=torch.float32, device="cuda") for a, b in dims[1:]]
+    d_dI = [torch.zeros((count, a * b * 3), dtype=torch.float32, device="cuda") for a, b in dims]
+    d_ab = [torch.zeros((count, a * b), dtype=torch.float32, device="cuda") for a, b in dims]
+    outs = capi.DeviceOutputs.make(d_base.data_ptr(), 4, [t.data_ptr() for t in d_lv], [t.data_ptr() for t in d_dI], [t.data_ptr() for t in d_ab])
+    valid, got_d = r.get_images_device(0, count, *fl, outs)
+    assert got_d == count and valid.all(), r.last_error()
+    want, ok, got = r.get_images(0, count, *fl)
+    assert bits_equal(d_base.cpu().numpy(), want)
+    for f in (0, 63, 64, n - 1):
+        src, cw, ch = want[f], ow, oh
+        for l in range(4):
+            if l:
+                src = oracle.pyramid_level(src, cw, ch)
+                cw, ch = cw // 2, ch // 2
+                assert bits_equal(d_lv[l - 1][f].cpu().numpy(), src), (f, l)
+            w_dI, w_abs = oracle.gradients(src, cw, ch)
+            assert bits_equal(d_dI[l][f].cpu().numpy(), w_dI.reshape(-1)), (f, l, "dI")
+            assert bits_equal(d_ab[l][f].cpu().numpy(), w_abs), (f, l, "abs")
+    r.close()
+
+
+def test_process_frames_host_to_device_with_frame_index(tmp_path, oracle):
+    """mdc_process_frames_host_to_device through the C ABI: raw host frames -> device array positions given by frame_index (scattered,
+    runs of consecutive positions batched); mdc_device_alloc / mdc_copy_to_host for callers without a HIP toolchain."""
+    from mono_dataset_code_amd import capi, synth
+
+    d = synth.write_sequence_calibration(str(tmp_path), synth.camera_lines(320, 256, 160, 120))
+    fov = capi.UndistorterFOV(os.path.join(d, "camera.txt"))
+    photo = capi.PhotometricUndistorter(os.path.join(d, "pcalib.txt"), os.path.join(d, "vignette.png"), 320, 256)
+    ctx = capi.Context(0)
+    ctx.bind(fov, photo)
+    n, npi, npo = 9, 320 * 256, 160 * 120
+    raws = [f for f in synth.noise_frames(0, n, npi)]
+    flags = capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED | capi.RECTIFY
+    L = capi.hip_lib()
+    d_ptr = ctypes.c_void_p()
+    positions = 12
+    assert L.mdc_device_alloc(ctx.handle(), positions * npo * 4, ctypes.byref(d_ptr)) == 0
+    index = [3, 4, 5, 0, 11, 10, 7, 8, 1]
+    ctx.process_frames_host_to_device(raws, flags, capi.DeviceOutputs.make(d_ptr.value), index)
+    got = np.zeros((positions, npo), np.float32)
+    assert L.mdc_copy_to_host(ctx.handle(), got.ctypes.data_as(ctypes.c_void_p), d_ptr, got.nbytes) == 0
+    rx, ry = fov.remap()
+    for i, pos in enumerate(index):
+        want = oracle.get_image(raws[i], 320, 256, 160, 120, photo.ginv(), photo.vignette()[1], True, True, rx, ry, 1, 1, 1, 1)
+        assert bits_equal(got[pos], want), (i, pos)
+    L.mdc_device_free(ctx.handle(), d_ptr)
+    with pytest.raises(capi.MdcError):  # no outputs / a negative position: refused
+        ctx.process_frames_host_to_device(raws, flags, capi.DeviceOutputs.make(0))
+    with pytest.raises(capi.MdcError):
+        ctx.process_frames_host_to_device(raws[:1], flags, capi.DeviceOutputs.make(1), [-1])
+    ctx.close()

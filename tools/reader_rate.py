@@ -80,3 +80,11 @@ for kind in os.environ.get("MDC_RATE_KINDS", "folder_png,zip_png,zip_jpg").split
         print(run("reader_rate_fast", d, 3, "batch", env={"MDC_GPU_JPEG": "1"}), flush=True)
         print("-- getImages, GPU JPEG stage 2 (host: markers + byte stuffing only; device: Huffman decoding + inverse DCT; the default):", flush=True)
     print(run("reader_rate_fast", d, 3, "batch"), flush=True)
+    print("-- getImagesDevice: the same pipeline, results LEFT IN HBM (nothing crosses PCIe on the way out):", flush=True)
+    print(run("reader_rate_fast", d, 5, "device"), flush=True)
+    print("-- getImagesDevice + box levels 1-3 + gradient images of every level (DSO hand-off), all left in HBM:", flush=True)
+    print(run("reader_rate_fast", d, 5, "device_dso"), flush=True)
+    for t in os.environ.get("MDC_RATE_THREADS", "").split(","):  # decode threads sweep of the device path (what binds it?)
+        if t:
+            print("-- getImagesDevice with %s decode threads:" % t, flush=True)
+            print(run("reader_rate_fast", d, 5, "device", env={"MDC_READER_THREADS": t}), flush=True)
