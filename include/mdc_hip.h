@@ -145,6 +145,9 @@ typedef struct mdc_info {
  * device).  MDC_ERR_NO_DEVICE if no GPU is visible. */
 MDC_API int mdc_create(int device, mdc_ctx** out);
 MDC_API int mdc_device_count(void); /* visible HIP devices (0 without a GPU or a usable runtime) */
+/* PCI address of the context's GPU, "0000:8b:00.0" (sysfs: /sys/bus/pci/devices/<that>/{local_cpulist, numa_node, pp_dpm_sclk}):
+ * what a multi-GPU host side pins its per-device threads by. */
+MDC_API int mdc_device_pci_bus_id(mdc_ctx* ctx, char* buf, size_t cap);
 MDC_API void mdc_destroy(mdc_ctx* ctx);
 MDC_API const char* mdc_last_error(const mdc_ctx* ctx); /* never NULL; "" if no error; ctx may be NULL (creation errors) */
 MDC_API int mdc_get_info(mdc_ctx* ctx, mdc_info* info);

@@ -28,7 +28,7 @@ OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM = 0, -1, -2,
 
 # every symbol include/mdc_hip.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = [
-    "mdc_create", "mdc_destroy", "mdc_device_count", "mdc_last_error", "mdc_build_flags", "mdc_code_id", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
+    "mdc_create", "mdc_destroy", "mdc_device_count", "mdc_device_pci_bus_id", "mdc_last_error", "mdc_build_flags", "mdc_code_id", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
     "mdc_set_remap", "mdc_unmap_host", "mdc_undistort_host_f32", "mdc_undistort_host_u8", "mdc_process_host",
     "mdc_process_frames_host_to_device", "mdc_process_jpeg_frames_host_to_device", "mdc_process_jpeg_streams_host_to_device", "mdc_device_alloc", "mdc_device_free", "mdc_copy_to_host",
     "mdc_host_alloc", "mdc_host_free", "mdc_process_frames_host", "mdc_process_jpeg_frames_host", "mdc_jpeg_idct_batch_device", "mdc_process_jpeg_streams_host", "mdc_jpeg_huffman_batch_device",
@@ -187,6 +187,8 @@ def hip_lib():
         L.mdc_export_tables.argtypes = [_vp, _vp, _sz, C.POINTER(_sz)]
         L.mdc_import_tables.argtypes = [_vp, _vp, _sz]
         L.mdc_synchronize.argtypes = [_vp]
+        if hasattr(L, "mdc_device_pci_bus_id"):
+            L.mdc_device_pci_bus_id.argtypes = [_vp, C.c_char_p, _sz]
         old_build = LIB_HIP_PATH != os.path.join(_PKG, "libmdc_hip.so")  # tools/sweep.py --libs: A/B against earlier builds
         if not old_build or hasattr(L, "mdc_describe_launch"):
             L.mdc_describe_launch.argtypes = [_vp, C.c_uint, _i, C.c_char_p, _sz]
@@ -535,6 +537,11 @@ class Context:
 
     def synchronize(self):
         self._chk(self._L.mdc_synchronize(self._h))
+
+    def pci_bus_id(self):
+        buf = C.create_string_buffer(32)
+        self._chk(self._L.mdc_device_pci_bus_id(self._h, buf, 32))
+        return buf.value.decode()
 
     def describe_launch(self, flags, pyramid_levels=0):
         buf = C.create_string_buffer(256)

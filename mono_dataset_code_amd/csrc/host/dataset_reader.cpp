@@ -740,6 +740,46 @@ ExposureImage* DatasetReader::getImage(int id, bool rectify, bool removeGamma, b
   return ret;
 }
 
+// A lane's host thread issues its device's copies and launches: it belongs on the CPUs next to that GPU (on a two-socket 8-GPU node
+// half of the devices hang off the other socket; a thread there pays the socket hop on every doorbell and staging copy).
+// /sys/bus/pci/devices/<pci>/local_cpulist ("0-63,128-191") -> sched_setaffinity of the calling thread.  MDC_NUMA_PIN=0 turns it off;
+// any failure (no sysfs, empty list, a cpuset that excludes those CPUs) leaves the thread where it is.
+std::vector<int> parse_cpulist(const std::string& text) {
+  std::vector<int> cpus;
+  size_t i = 0;
+  while (i < text.size()) {
+    while (i < text.size() && !isdigit((unsigned char)text[i])) i++;
+    if (i >= text.size()) break;
+    int a = 0, b;
+    while (i < text.size() && isdigit((unsigned char)text[i])) a = a * 10 + (text[i++] - '0');
+    b = a;
+    if (i < text.size() && text[i] == '-') {
+      i++;
+      b = 0;
+      while (i < text.size() && isdigit((unsigned char)text[i])) b = b * 10 + (text[i++] - '0');
+    }
+    for (int c = a; c <= b && c < CPU_SETSIZE && cpus.size() < 4096; c++) cpus.push_back(c);
+  }
+  return cpus;
+}
+void pin_thread_near_device(mdc_ctx* gpu) {
+  static const bool enabled = [] {
+    const char* e = std::getenv("MDC_NUMA_PIN");
+    return !e || std::atoi(e) != 0;
+  }();
+  char pci[32];
+  if (!enabled || !gpu || mdc_device_pci_bus_id(gpu, pci, sizeof pci) != MDC_OK) return;
+  std::ifstream f(std::string("/sys/bus/pci/devices/") + pci + "/local_cpulist");
+  std::string line;
+  if (!f || !std::getline(f, line)) return;
+  const std::vector<int> cpus = parse_cpulist(line);
+  if (cpus.empty()) return;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  for (int c : cpus) CPU_SET(c, &set);
+  (void)sched_setaffinity(0, sizeof set, &set);  // refused (cpuset): stay
+}
+
 // One device of a sharded getImages call: chunks k = lane, lane + L, lane + 2L, ... of the range, each on the lane's own
 // context, decode ring and GPU calls (reference src/BenchmarkDatasetReader.h:188-243: a frame depends on nothing but itself
 // and the immutable tables, so the chunks of a range are independent).  The decode pool is shared; results land in the
@@ -982,7 +1022,13 @@ int DatasetReader::run_batch(int first, int count, bool rectify, bool removeGamm
   // more than one call gets a second ring's worth of buffers, so that the pool parses the next files while the GPU call of
   // the current ones runs (one ring: parse and GPU call take turns, 22 k frames/s).  With several devices (MDC_DEVICES) the
   // range is dealt to them in chunks of at least 64 frames, round-robin.
-  const int L = dev ? 1 : (int)s.lanes.size();  // device outputs live on ONE device: the first lane's
+  // device outputs live on ONE device, the first lane's: the lanes on that device take part (MDC_DEVICES=0,0: two lanes on one GPU --
+  // two host threads whose pipelined calls overlap, one lane's fill and drain under the other's decode)
+  int L = (int)s.lanes.size();
+  if (dev) {
+    L = 1;
+    while (L < (int)s.lanes.size() && s.lanes[(size_t)L].device == s.lanes[0].device && s.lanes[(size_t)L].gpu) L++;
+  }
   int C = s.gpu_jpeg >= 2 ? State::kRingFrames : 32;
   if (L > 1 && s.gpu_jpeg >= 2) C = std::min<int>(State::kRingFrames, std::max(64, ((count + L - 1) / L + 63) / 64 * 64));
   const int nchunks = (count + C - 1) / C;
@@ -1022,6 +1068,7 @@ int DatasetReader::run_batch(int first, int count, bool rectify, bool removeGamm
   // that lane's chunks with an error, not the process: a std::thread must not be left joinable, a lane's images must not leak)
   auto run_lane = [&runs, &s](int l) {
     try {
+      if (l > 0) pin_thread_near_device(runs[(size_t)l].lane.gpu);  // a helper thread of this call: the caller's own thread (lane 0) keeps its affinity
       runs[(size_t)l].run();
     } catch (const std::exception& e) {
       runs[(size_t)l].drop_chunk_in_flight();

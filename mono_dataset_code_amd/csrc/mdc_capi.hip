@@ -454,6 +454,16 @@ const char* mdc_last_error(const mdc_ctx* c) {
   return t_err_other.c_str();
 }
 
+int mdc_device_pci_bus_id(mdc_ctx* c, char* buf, size_t cap) try {
+  if (!c) return MDC_ERR_ARG;
+  if (!buf || cap < 13) return fail(c, MDC_ERR_ARG, "mdc_device_pci_bus_id: buffer of >= 13 bytes expected");
+  char tmp[64] = {0};
+  MDC_HIP(c, hipDeviceGetPCIBusId(tmp, (int)sizeof tmp, c->device));
+  for (char* q = tmp; *q; q++) *q = (char)tolower((unsigned char)*q);  // sysfs spells the address in lower case
+  snprintf(buf, cap, "%s", tmp);
+  return MDC_OK;
+} MDC_CATCH(c)
+
 int mdc_set_option(mdc_ctx* c, int option, int value) try {
   if (!c) return MDC_ERR_ARG;
   WriteLock lk(c->mu);

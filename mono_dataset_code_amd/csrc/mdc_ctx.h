@@ -139,6 +139,7 @@ struct mdc_ctx {
   void* d_pipe_seg[2] = {nullptr, nullptr};   // ... and the segment states of the Huffman decoder's several workgroups per frame
   int* h_pipe_status = nullptr;               // page-locked landing buffer for them (a whole call)
   size_t pipe_status_cap = 0;
+  int pipe_chunk_cap = 0;  // frames d_pipe_status / d_pipe_seg are sized for
   size_t pipe_in_cap = 0, pipe_out_cap = 0, pipe_rec_cap = 0, pipe_strm_cap = 0;
 
   // vignetteCalib: bit pattern of the largest new vignette factor of ONE vignette step.  A ring of words, one per call:

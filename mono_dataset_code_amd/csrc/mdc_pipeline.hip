@@ -141,9 +141,14 @@ struct PipelineCall {
   void choose_mode() {
     z_out.assign((size_t)nframes, nullptr);
     z_in.assign((rec || strm) ? 0 : (size_t)nframes, nullptr);
-    if (dev) {  // results stay in HBM: nothing to map, frames go up by copy; raw frames in chunks of 64 (the way out costs nothing now)
+    if (dev) {  // results stay in HBM: nothing to map, frames go up by copy; chunks of 64 frames (MDC_PIPE_DEV_CHUNK: 16..256) -- the
+      // way out costs nothing now, and the Huffman launch's time per frame falls with the frames per launch (6.7 us at 64, 4.1 at 256)
       zc_in = zc_out = false;
-      chunk = 64;
+      static const int dev_chunk = [] {
+        const char* e = getenv("MDC_PIPE_DEV_CHUNK");
+        return e ? std::max(16, std::min(256, atoi(e))) : 64;
+      }();
+      chunk = dev_chunk;
       return;
     }
     zc_out = nframes > 0 && !strm;
@@ -170,11 +175,14 @@ struct PipelineCall {
     const size_t in_need = zc_in ? 0 : chunk * n_in, out_need = (zc_out || dev) ? 0 : chunk * n_out * sizeof(float);
     const size_t rec_need = (rec || strm) ? (size_t)chunk * (size_t)record_bytes : 0;
     const size_t strm_need = strm ? (size_t)chunk * strm_stride : 0;
-    if (c->pipe_in_cap < in_need || c->pipe_out_cap < out_need || c->pipe_rec_cap < rec_need || c->pipe_strm_cap < strm_need || !c->pipe_stream[0] ||
-        !c->pipe_stream[1]) {
+    const int chunk_need = strm ? std::max(64, chunk) : 0;
+    if (c->pipe_in_cap < in_need || c->pipe_out_cap < out_need || c->pipe_rec_cap < rec_need || c->pipe_strm_cap < strm_need || c->pipe_chunk_cap < chunk_need ||
+        !c->pipe_stream[0] || !c->pipe_stream[1]) {
       const size_t in_cap = std::max(in_need, c->pipe_in_cap), out_cap = std::max(out_need, c->pipe_out_cap), rec_cap = std::max(rec_need, c->pipe_rec_cap);
       const size_t strm_cap = std::max(strm_need + strm_need / 4, c->pipe_strm_cap);  // (stream sizes vary from call to call: some headroom)
+      const int chunk_cap = std::max(std::max(64, chunk_need), c->pipe_chunk_cap);
       c->pipe_in_cap = c->pipe_out_cap = c->pipe_rec_cap = c->pipe_strm_cap = 0;  // a failure part-way leaves "no slots", not stale capacities
+      c->pipe_chunk_cap = 0;
       for (int k = 0; k < 2; k++) {
         if (c->pipe_stream[k]) MDC_HIP(c, hipStreamSynchronize(c->pipe_stream[k]));
         if (!c->pipe_stream[k]) MDC_HIP(c, hipStreamCreateWithFlags(&c->pipe_stream[k], hipStreamNonBlocking));
@@ -189,9 +197,10 @@ struct PipelineCall {
         if (out_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_out[k], out_cap));
         if (rec_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_rec[k], rec_cap));
         if (strm_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_strm[k], strm_cap));
-        if (strm_cap) MDC_HIP(c, hipMalloc((void**)&c->d_pipe_status[k], 64 * sizeof(int)));
-        if (strm_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_seg[k], jpeg_huffman_scratch_bytes(64)));
+        if (strm_cap) MDC_HIP(c, hipMalloc((void**)&c->d_pipe_status[k], (size_t)chunk_cap * sizeof(int)));
+        if (strm_cap) MDC_HIP(c, hipMalloc(&c->d_pipe_seg[k], jpeg_huffman_scratch_bytes(chunk_cap)));
       }
+      c->pipe_chunk_cap = strm_cap ? chunk_cap : 0;
       c->pipe_in_cap = in_cap;
       c->pipe_out_cap = out_cap;
       c->pipe_rec_cap = rec_cap;

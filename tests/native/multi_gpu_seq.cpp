@@ -107,8 +107,8 @@ int main(int argc, char** argv) {
   for (int k = 0; k < passes; k++) CHECK(mdc_multi_process_sequence_device(m, d_in.data(), d_out.data(), total, flags));
   CHECK(mdc_multi_synchronize(m));
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  std::printf("MULTI_GPU_SEQ devices %d frames %lld passes %d seconds %.6f frames_per_s %.1f mpix_per_s %.1f tables_bit_equal 1\n", n,
-              total, passes, dt, total * (double)passes / dt, total * (double)passes * npi / dt / 1e6);
+  std::printf("MULTI_GPU_SEQ devices %d frames %lld passes %d seconds %.6f frames_per_s %.1f mpix_per_s %.1f tables_bit_equal 1 rccl_ranks %d\n", n,
+              total, passes, dt, total * (double)passes / dt, total * (double)passes * npi / dt / 1e6, mdc_multi_comm_count(m, 0));
 
   if (dump)
     for (int r = 0; r < n; r++) {

@@ -209,3 +209,33 @@ def test_bench_pyramid_checks_every_level():
     assert (par["frames_checked"], par["levels_checked"], par["mismatching_pixels"]) == (16, 4, 0)  # --frames 16: every frame of the launch
     assert "libmdc_ref.so" in par["against"] and "unpinned" in par["pinned"]  # base against the reference build; the levels' definition is ours
     assert out["roofline"]["kernel"].startswith("remap_strip_kernel<true, true")  # the strip kernel with the fused pyramid ran
+
+
+@pytest.mark.gpu
+def test_bench_over_rccl_on_real_devices(tmp_path, oracle):
+    """The first run on a multi-GPU node must need no edits: with >= 2 visible devices, `python bench.py --gpus N` (the driver's
+    form: it launches its own ranks) runs N = 2 and N = all over RCCL -- every rank on a device of its own (distinct PCI
+    addresses), rccl_ranks == N, every rank's outputs == the oracle for their GLOBAL frame indices f = rank + i * N --, and the one
+    50,000-frame-style sequence (configs[3], shrunk) is dealt round-robin with every rank reporting.  Skips on one device, where
+    test_bench_two_ranks_on_one_gpu (gloo, shared GPU) and test_bench_rccl_world_of_one cover the same code."""
+    import torch
+
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip("one visible device: RCCL across devices needs two")
+    for n in sorted({2, ndev}):
+        dump = tmp_path / ("dump%d" % n)
+        dump.mkdir()
+        out = _bench(["--gpus", str(n), "--steps", "5", "--warmup", "2", "--frames", "256", "--preroll-s", "0.05", "--preroll-max-s", "0.3",
+                      "--dump-dir", str(dump), "--dump-frames", "3", "--no-cpu-baseline"], clean_env=False, timeout=1200)
+        ranks = out["ranks"]
+        assert out["n_gpus"] == n and ranks["world"] == n and ranks["backend"] == "nccl" and ranks["rccl_ranks"] == n
+        assert [d["device"] for d in ranks["devices"]] == list(range(n))
+        assert len({d["pci"] for d in ranks["devices"]}) == n, ranks["devices"]  # N ranks, N different GPUs
+        assert out["parity"]["mismatching_pixels"] == 0 and len(out["roofline"]["per_rank_frac"]) == n
+        assert out["config"]["tables"] == "rank-0 build + one RCCL broadcast" and out["config"]["table_broadcast_ms"] > 0
+        _check_rank_dumps(str(dump), n, 3, oracle)
+        seq = _bench(["--gpus", str(n), "--steps", "3", "--warmup", "1", "--workload", "seq50k", "--frames", "96", "--preroll-s", "0.05", "--preroll-max-s",
+                      "0.3", "--no-cpu-baseline"], timeout=1200)
+        assert seq["scaling"] == "strong" and seq["config"]["sequence_frames"] == 96 * n and seq["parity"]["mismatching_pixels"] == 0
+        assert seq["ranks"]["rccl_ranks"] == n and len(seq["roofline"]["per_rank_frac"]) == n

@@ -53,6 +53,8 @@ def test_sequence_over_all_devices_equals_oracle(tmp_path, oracle):
     line = [l for l in r.stdout.splitlines() if l.startswith("MULTI_GPU_SEQ")][-1].split()
     kv = dict(zip(line[1::2], line[2::2]))
     assert int(kv["devices"]) == ndev and int(kv["frames"]) == total and kv["tables_bit_equal"] == "1"
+    if "rccl_ranks" in kv:  # the communicator really spans every device of the node
+        assert int(kv["rccl_ranks"]) == ndev
     # expected tables from the ORACLE's own table builders (oracle/mdc_oracle.c, pinned to the reference build), not from
     # the product's classes: the comparison below is then product (classes + RCCL broadcast + kernels) vs oracle end to end
     cam = oracle.parse_camera(os.path.join(d, "camera.txt"))

@@ -877,16 +877,16 @@ def test_process_frames_host_to_device_with_frame_index(tmp_path, oracle):
     L = capi.hip_lib()
     d_ptr = ctypes.c_void_p()
     positions = 12
-    assert L.mdc_device_alloc(ctx.handle(), positions * npo * 4, ctypes.byref(d_ptr)) == 0
+    assert L.mdc_device_alloc(ctx.handle, positions * npo * 4, ctypes.byref(d_ptr)) == 0
     index = [3, 4, 5, 0, 11, 10, 7, 8, 1]
     ctx.process_frames_host_to_device(raws, flags, capi.DeviceOutputs.make(d_ptr.value), index)
     got = np.zeros((positions, npo), np.float32)
-    assert L.mdc_copy_to_host(ctx.handle(), got.ctypes.data_as(ctypes.c_void_p), d_ptr, got.nbytes) == 0
+    assert L.mdc_copy_to_host(ctx.handle, got.ctypes.data_as(ctypes.c_void_p), d_ptr, got.nbytes) == 0
     rx, ry = fov.remap()
     for i, pos in enumerate(index):
         want = oracle.get_image(raws[i], 320, 256, 160, 120, photo.ginv(), photo.vignette()[1], True, True, rx, ry, 1, 1, 1, 1)
         assert bits_equal(got[pos], want), (i, pos)
-    L.mdc_device_free(ctx.handle(), d_ptr)
+    L.mdc_device_free(ctx.handle, d_ptr)
     with pytest.raises(capi.MdcError):  # no outputs / a negative position: refused
         ctx.process_frames_host_to_device(raws, flags, capi.DeviceOutputs.make(0))
     with pytest.raises(capi.MdcError):

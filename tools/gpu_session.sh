@@ -125,6 +125,9 @@ PY
       MDC_DEVICES=0,0 timeout 200 python tools/reader_soak.py ${SOAK_S:-40} 2 > "$OUT/reader_soak_two_lanes.txt" 2>&1; grep -av amdgpu.ids "$OUT/reader_soak_two_lanes.txt" | tail -3
       timeout 300 python tools/soak.py 60 > "$OUT/soak.txt" 2>&1; tail -2 "$OUT/soak.txt"
       timeout 400 bash tools/soak_threads.sh 800 > "$OUT/thread_soak.txt" 2>&1; tail -4 "$OUT/thread_soak.txt" ;;
+    reader_device)  # getImagesDevice on a zipped JPEG sequence: lanes per device / frames per pipeline chunk (RATE_ENVS="A=1 B=2;A=3")
+      MDC_RATE_ONLY=device MDC_RATE_KINDS=${KINDS:-zip_jpg} MDC_RATE_ENVS="${RATE_ENVS:-MDC_DEVICES=0,0}" timeout 900 python tools/reader_rate.py ${N:-1024} > "$OUT/reader_device_rates.txt" 2>&1
+      grep -a "^==\|^--\|READER_RATE reader\|READER_RATE device [0-9]" "$OUT/reader_device_rates.txt" | cut -c1-200 ;;
     reader2) MDC_DEVICES=0,0 MDC_RATE_KINDS=zip_jpg timeout 900 python tools/reader_rate.py ${N:-512} > "$OUT/reader_rates_two_lanes.txt" 2>&1; grep -av amdgpu.ids "$OUT/reader_rates_two_lanes.txt" | tail -30 ;;
     reader)  timeout 900 python tools/reader_rate.py ${N:-512} > "$OUT/reader_rates.txt" 2>&1; grep -av amdgpu.ids "$OUT/reader_rates.txt" | tail -30 ;;
     dso)     timeout 600 python tools/dso_rate.py > "$OUT/dso_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/dso_rate.txt" | tail -20 ;;

@@ -66,9 +66,18 @@ def run(binary, folder, passes, *extra, env=None):
     return "\n".join(l.replace(BIN + "/", "") for l in lines) if lines else "%s failed: %s" % (binary, r.stdout[-300:])
 
 
+ONLY_DEVICE = os.environ.get("MDC_RATE_ONLY") == "device"  # only the device-resident runs (+ MDC_RATE_ENVS: "A=1 B=2;A=3" -> one run per set)
 for kind in os.environ.get("MDC_RATE_KINDS", "folder_png,zip_png,zip_jpg").split(","):
     d, avg = make(kind)
     print("== %s: %d frames 1280x1024, %.0f KB/frame on disk" % (kind, N, avg / 1e3), flush=True)
+    if ONLY_DEVICE:
+        print(run("reader_rate_fast", d, 3, "batch"), flush=True)
+        for envs in [""] + [e for e in os.environ.get("MDC_RATE_ENVS", "").split(";") if e]:
+            env = dict(kv.split("=", 1) for kv in envs.split())
+            for mode in ("device", "device_dso"):
+                print("-- getImagesDevice (%s), %s:" % (mode, envs or "defaults"), flush=True)
+                print(run("reader_rate_fast", d, 8, mode, env=env), flush=True)
+        continue
     if not kind.startswith("zip_jpg"):  # the test shim's imread / imdecode stand-ins decode PNG (libpng), not JPEG
         print(run("reader_rate_ref", d, 1), flush=True)
         print(run("reader_rate_mdc", d, 2), flush=True)
