@@ -108,6 +108,8 @@ enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2 /* frames a workgroup lo
           of the runtime per call): the kernel reads the frame / writes the result over PCIe itself, both directions at once,
           instead of copy in -> kernel -> copy out.  Pageable buffers go through the staging copies as before.
           0 = automatic (on), 1 = on, 2 = off */,
+       MDC_OPT_DEVICE_PIPELINE_CHUNK = 16 /* tuning: frames per chunk of the device-output pipeline (mdc_process_*_host_to_device:
+          upload || decode || fused pass), 16..256; 0 = automatic (64, or MDC_PIPE_DEV_CHUNK in the environment) */,
        MDC_OPT_TAIL_TAPER = 15 /* tuning: a large launch of the tiled kernel ends on frame groups of 1/2, 1/4 and 1/8 of the
           frames per workgroup, so the slots that free up when its last long workgroups finish do not idle for a long
           workgroup's time: 0 = automatic (on), 1 = on, 2 = off */ };

@@ -118,6 +118,7 @@ struct DatasetReader::State {
   struct Lane {
     mdc_ctx* gpu = 0;
     int device = -1;
+    bool twin = false;  // a second context on lane 0's device, made for getImagesDevice (ensure_device_lanes); owned by the reader
     HostBuffer ring_block;
     size_t ring_stride = 0, ring_bytes = 0;
     int ring_slots = 0;
@@ -279,10 +280,40 @@ struct DatasetReader::State {
     ln.device = (gpu && mdc_get_info(gpu, &inf) == MDC_OK) ? inf.device : -1;
     lanes.push_back(ln);
   }
+  // getImagesDevice: its results cross no bus on the way out, so what limits one pipelined call is its own fill and drain (upload of
+  // the first chunk, fused pass of the last).  Two calls from two host threads on two contexts of the SAME device overlap them:
+  // measured on a zipped 1280x1024 JPEG sequence 99.6 k frames/s with one lane, 126 k with two lanes and 128-frame chunks, 109 k with
+  // three (profiles/r05_reader_device_rates.txt).  The twin is made at the first getImagesDevice call (MDC_DEVICE_LANES=1: never).
+  int host_lanes = 0;  // lanes getImages deals its range to (what open_devices made)
+  void ensure_device_lanes() {
+    if (!host_lanes) host_lanes = (int)lanes.size();
+    static const int want = [] {
+      const char* e = std::getenv("MDC_DEVICE_LANES");
+      return e ? std::max(1, std::min(4, std::atoi(e))) : 2;
+    }();
+    if (lanes.empty() || !lanes[0].gpu) return;
+    int have = 0;
+    for (const Lane& ln : lanes) have += ln.device == lanes[0].device && ln.gpu ? 1 : 0;
+    for (; have < want; have++) {
+      mdc_ctx* c = 0;
+      if (mdc_create(lanes[0].device, &c) != MDC_OK || mdc_bind_objects(c, fov, photo) != MDC_OK) {
+        if (c) mdc_destroy(c);
+        return;  // one lane does the work
+      }
+      Lane ln;
+      ln.gpu = c;
+      ln.device = lanes[0].device;
+      ln.twin = true;
+      lanes.push_back(ln);
+    }
+    if (have >= 2)  // with a second call to hide a chunk's fill and drain behind, longer chunks win (Huffman: 5.3 us per frame at 128, 6.7 at 64)
+      for (Lane& ln : lanes)
+        if (ln.device == lanes[0].device && ln.gpu) (void)mdc_set_option(ln.gpu, MDC_OPT_DEVICE_PIPELINE_CHUNK, 128);
+  }
   void close_devices() {
     for (Lane& ln : lanes) {
       ln.ring_block.release();
-      if (!multi && ln.gpu) mdc_destroy(ln.gpu);
+      if ((!multi || ln.twin) && ln.gpu) mdc_destroy(ln.gpu);
     }
     if (multi) mapi.destroy(multi);
     multi = 0;
@@ -1024,10 +1055,16 @@ int DatasetReader::run_batch(int first, int count, bool rectify, bool removeGamm
   // range is dealt to them in chunks of at least 64 frames, round-robin.
   // device outputs live on ONE device, the first lane's: the lanes on that device take part (MDC_DEVICES=0,0: two lanes on one GPU --
   // two host threads whose pipelined calls overlap, one lane's fill and drain under the other's decode)
-  int L = (int)s.lanes.size();
+  if (!s.host_lanes) s.host_lanes = (int)s.lanes.size();
+  int L = s.host_lanes;  // (twin lanes made for getImagesDevice take no part in getImages)
+  std::vector<State::Lane*> use;
   if (dev) {
-    L = 1;
-    while (L < (int)s.lanes.size() && s.lanes[(size_t)L].device == s.lanes[0].device && s.lanes[(size_t)L].gpu) L++;
+    s.ensure_device_lanes();
+    for (State::Lane& ln : s.lanes)
+      if (ln.device == s.lanes[0].device && ln.gpu) use.push_back(&ln);
+    L = (int)use.size();
+  } else {
+    for (int l = 0; l < L; l++) use.push_back(&s.lanes[(size_t)l]);
   }
   int C = s.gpu_jpeg >= 2 ? State::kRingFrames : 32;
   if (L > 1 && s.gpu_jpeg >= 2) C = std::min<int>(State::kRingFrames, std::max(64, ((count + L - 1) / L + 63) / 64 * 64));
@@ -1044,7 +1081,7 @@ int DatasetReader::run_batch(int first, int count, bool rectify, bool removeGamm
   const size_t want_bytes = s.gpu_jpeg == 1 ? std::max(s.frame_bytes(), s.rec_bytes) : s.frame_bytes();
   const int active = std::min(L, nchunks);
   for (int l = 0; l < active; l++) {
-    State::Lane& ln = s.lanes[(size_t)l];
+    State::Lane& ln = *use[(size_t)l];
     if (!ln.ring_block.p || ln.ring_bytes < want_bytes || ln.ring_slots < slots) {
       ln.ring_block.release();
       ln.ring_stride = (want_bytes + 4095) & ~(size_t)4095;
@@ -1060,7 +1097,7 @@ int DatasetReader::run_batch(int first, int count, bool rectify, bool removeGamm
   std::vector<State::LaneRun> runs;
   runs.reserve((size_t)active);
   for (int l = 0; l < active; l++) {
-    runs.push_back(State::LaneRun(s, s.lanes[(size_t)l], first, count, C, RG, active, l, rectify, flags, out, rec));
+    runs.push_back(State::LaneRun(s, *use[(size_t)l], first, count, C, RG, active, l, rectify, flags, out, rec));
     runs.back().dev = dev;
     runs.back().valid = valid;
   }

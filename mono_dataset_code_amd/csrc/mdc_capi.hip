@@ -518,6 +518,10 @@ int mdc_set_option(mdc_ctx* c, int option, int value) try {
       MDC_HIP(c, hipDeviceSynchronize());
       return plan_tiles(c);
     }
+    case MDC_OPT_DEVICE_PIPELINE_CHUNK:
+      if (value != 0 && (value < 16 || value > 256)) return fail(c, MDC_ERR_ARG, "device pipeline chunk must be 0 (automatic) or 16..256 frames");
+      c->opt_dev_chunk = value;
+      return MDC_OK;
     case MDC_OPT_TAIL_TAPER:
       if (value < 0 || value > 2) return fail(c, MDC_ERR_ARG, "tail taper selector must be 0 (automatic), 1 (on) or 2 (off)");
       c->opt_taper = value;

@@ -148,7 +148,7 @@ struct PipelineCall {
         const char* e = getenv("MDC_PIPE_DEV_CHUNK");
         return e ? std::max(16, std::min(256, atoi(e))) : 64;
       }();
-      chunk = dev_chunk;
+      chunk = c->opt_dev_chunk ? c->opt_dev_chunk : dev_chunk;
       return;
     }
     zc_out = nframes > 0 && !strm;

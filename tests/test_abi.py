@@ -202,3 +202,24 @@ def test_product_does_not_reference_the_oracle():
                     if re.search(r"oracle[/.]|liboracle|libmdc_ref|orc_\w+\(|ref_\w+\(", txt) and "oracle/Makefile" not in txt.replace("oracle's", ""):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_every_environment_variable_is_documented():
+    """One table of every MDC_* environment variable: a getenv / os.environ read in the product that the table
+    does not name fails here."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = doc[doc.index("## Environment"):doc.index("## Build")]
+    used = set()
+    for base in ("mono_dataset_code_amd", "include"):
+        for dp, dn, fs in os.walk(os.path.join(ROOT, base)):
+            dn[:] = [d for d in dn if d not in ("build", "variants", "__pycache__")]
+            for f in fs:
+                if f.endswith((".py", ".h", ".hip", ".cpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    used |= set(re.findall(r'getenv\("(MDC_[A-Z0-9_]+)"\)', txt))
+                    used |= set(re.findall(r'environ(?:\.get)?[\[(]"(MDC_[A-Z0-9_]+)"', txt))
+    txt = open(os.path.join(ROOT, "bench.py")).read()
+    used |= set(re.findall(r'environ(?:\.get)?[\[(]"(MDC_[A-Z0-9_]+)"', txt))
+    assert len(used) >= 15, used
+    missing = sorted(v for v in used if ("`%s" % v) not in table)
+    assert not missing, "undocumented environment variables: %s" % missing

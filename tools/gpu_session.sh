@@ -131,6 +131,12 @@ PY
     reader2) MDC_DEVICES=0,0 MDC_RATE_KINDS=zip_jpg timeout 900 python tools/reader_rate.py ${N:-512} > "$OUT/reader_rates_two_lanes.txt" 2>&1; grep -av amdgpu.ids "$OUT/reader_rates_two_lanes.txt" | tail -30 ;;
     reader)  timeout 900 python tools/reader_rate.py ${N:-512} > "$OUT/reader_rates.txt" 2>&1; grep -av amdgpu.ids "$OUT/reader_rates.txt" | tail -30 ;;
     dso)     timeout 600 python tools/dso_rate.py > "$OUT/dso_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/dso_rate.txt" | tail -20 ;;
+    dso_ab)  # the DSO hand-off per library build (LIBS="product <variant> ...", chunk sizes swept inside tools/dso_rate.py), two rounds each
+      for r in 1 2; do for l in ${LIBS:-product}; do
+        lib=""; [ $l != product ] && lib="$GRAFT_REPO_ROOT/mono_dataset_code_amd/variants/libmdc_hip_$l.so"
+        echo "--- $l (round $r)" >> "$OUT/dso_ab.txt"
+        MDC_LIB_HIP=$lib timeout 300 python tools/dso_rate.py 2>&1 | grep -av amdgpu.ids | grep -a "launches\|chunks\|bit for bit" >> "$OUT/dso_ab.txt"
+      done; done; cat "$OUT/dso_ab.txt" ;;
     huffman) timeout 600 python tools/huffman_rate.py > "$OUT/huffman_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/huffman_rate.txt" | tail -20 ;;
     huffman_ab)  # the one-component decoder per library build (LIBS="product huffseg4 ...": mono_dataset_code_amd/variants/libmdc_hip_<name>.so), two rounds
       for r in 1 2; do for l in ${LIBS:-product}; do
