@@ -99,7 +99,7 @@ int frames_per_block(const mdc_ctx* c, int64_t nframes, int blocks_per_group, in
 TilePlan tile_plan(const mdc_ctx* c, int which) {
   const mdc_ctx::SrcPlan& pl = c->plan[which];
   return TilePlan{pl.d_chunks, pl.d_nch, pl.d_taps, pl.d_order, pl.n_blocks, pl.n_tiles, pl.tiles_x, pl.tile_w, pl.tile_h,
-                  pl.chunk_cap, pl.win_bytes, pl.nbuf, c->n_black > 0, c->opt_interleave != 0, c->opt_taper != 2, pl.pair_rem};
+                  pl.chunk_cap, pl.win_bytes, pl.nbuf, c->n_black > 0, c->opt_interleave != 0, c->opt_taper != 2};
 }
 
 RemapArgs remap_args(const mdc_ctx* c, const float* lut, const float* vinv) {
@@ -488,7 +488,7 @@ int mdc_set_option(mdc_ctx* c, int option, int value) try {
       return plan_tiles(c);
     }
     case MDC_OPT_TILE_COLS: {
-      if (value != 0 && value != 64 && value != 128 && value != 256) return fail(c, MDC_ERR_ARG, "tile columns must be 0 (automatic), 64, 128 or 256 (paired tiles, 16 rows)");
+      if (value != 0 && value != 64 && value != 128) return fail(c, MDC_ERR_ARG, "tile columns must be 0 (automatic), 64 or 128");
       if (value == c->opt_tile_w) return MDC_OK;
       c->opt_tile_w = value;
       c->tuned_fpb = 0;
@@ -957,7 +957,7 @@ int mdc_tune_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
   DeviceGuard dg(c->device);
   if (!(flags & MDC_RECTIFY) || !c->valid_remap) return fail(c, MDC_ERR_STATE, "mdc_tune_device: needs a remap and MDC_RECTIFY");
   hipStream_t s = (hipStream_t)stream;
-  static const TileShape shapes[] = {{128, 16}, {64, 32}, {128, 32}, {256, 16}};
+  static const TileShape shapes[] = {{128, 16}, {64, 32}, {128, 32}};
   static const int fpbs[] = {32, 64, 96, 128};  // (with the tapered tail the longer workgroups pay: 96 measured 1.8 % ahead of 64)
   hipEvent_t e0, e1;
   MDC_HIP(c, hipEventCreate(&e0));

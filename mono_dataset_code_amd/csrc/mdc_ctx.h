@@ -75,7 +75,7 @@ struct mdc_ctx {
     uint32_t* d_taps = nullptr;
     int* d_order = nullptr;  // block -> tile placement table (XCD bands)
     int chunk_cap = 0, win_bytes = 0, nbuf = 2;
-    int tile_w = 0, tile_h = 0, n_tiles = 0, tiles_x = 0, n_blocks = 0, pair_rem = 0;
+    int tile_w = 0, tile_h = 0, n_tiles = 0, tiles_x = 0, n_blocks = 0;
     bool tiled = false;
     int64_t staged_bytes = 0;
   } plan[2];

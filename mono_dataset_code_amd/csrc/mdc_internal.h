@@ -17,22 +17,7 @@ namespace mdc {
 struct TileShape {
   int w, h;
 };
-// 256 x 16 = PAIRED tiles (1024 threads): two horizontally neighbouring 128 x 16 tiles in one workgroup with ONE source window -- the
-// 128-byte lines the two halves share (one per window row) are fetched once.  An output whose width leaves a last column band of at
-// most 128 columns (640 = 2 x 256 + 128) gets 128 x 32 tiles there -- the same 1024 threads, no idle lanes: per band of 32 output
-// rows 2 x nfull tiles of 256 x 16 and one of 128 x 32 (pair_tile_geometry below, shared by the host plan and the kernel).
-constexpr TileShape kTileShapes[] = {{64, 16}, {64, 32}, {64, 60}, {64, 64}, {128, 16}, {128, 32}, {256, 16}};
-struct PairTile {
-  int x0, y0, w, h;
-};
-// tile t of a paired tiling with `nfull` 256-wide columns (+ a 128-wide remainder column if `rem`)
-__host__ __device__ inline PairTile pair_tile_geometry(int t, int nfull, int rem) {
-  const int per_band = 2 * nfull + rem;
-  const int band = t / per_band, q = t - band * per_band;
-  if (q >= 2 * nfull) return PairTile{nfull * 256, band * 32, 128, 32};
-  const int rib = q / nfull;
-  return PairTile{(q - rib * nfull) * 256, band * 32 + rib * 16, 256, 16};
-}
+constexpr TileShape kTileShapes[] = {{64, 16}, {64, 32}, {64, 60}, {64, 64}, {128, 16}, {128, 32}};
 constexpr bool tile_shape_ok(int w, int h) {
   for (const TileShape& t : kTileShapes)
     if (t.w == w && t.h == h) return true;
@@ -64,8 +49,8 @@ struct TilePlan {
   const uint32_t* d_taps;    // [out_w*out_h] LDS byte offset of tap (xi,yi) | offset of tap (xi,yi+1) << 16
   const int* d_order;        // block -> tile (or -1), n_blocks entries, n_blocks % 8 == 0: block b runs on XCD b % 8
   int n_blocks;
-  int n_tiles, tiles_x;  // (paired tiles: tiles_x = 256-wide columns, pair_rem = 1 if a 128-wide remainder column follows)
-  int tile_w;      // output columns per tile: 64, 128 or 256 (paired)
+  int n_tiles, tiles_x;
+  int tile_w;      // output columns per tile: 64 or 128
   int tile_h;      // output rows per tile: 16, 32, 60 or 64 (see kTileShapes)
   int chunk_cap;   // row length of d_chunks: kTileMaxChunks (F32: kTileMaxChunksF32) x threads, padded with kOutside
   int win_bytes;   // LDS bytes of one window buffer: 16 * max nch, rounded up to 1 KiB
@@ -73,7 +58,6 @@ struct TilePlan {
   bool has_black;  // some output carries the (-1,-1) sentinel
   bool interleave; // frame groups take every G-th frame instead of fpb consecutive ones
   bool taper = true;  // large launches end on frame groups of fpb/2, fpb/4, fpb/8 (MDC_OPT_TAIL_TAPER)
-  int pair_rem = 0;   // paired tiles (tile_w == 256): the output ends on a column band of <= 128 columns, tiled 128 x 32
 };
 
 // Plan of the wave-private strip kernel (remap_strip_kernel): a WAVE owns a 128 x 8 output tile (lane l: columns l and

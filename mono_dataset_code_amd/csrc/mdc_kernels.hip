@@ -705,22 +705,12 @@ __global__ __launch_bounds__(NT, (NT >= 960 ? 8 : NT == 640 ? 5 : NT == 512 ? (k
   if (nf <= 0) return;
 
   const int tid = threadIdx.x;
+  const int lane_x = tid % TW;
+  const int row0 = (tid / TW) * RPT;
+  const int ox = (tile % p.tiles_x) * TW + lane_x;
   constexpr int kTileRows = NT * RPT / TW;  // RPT output rows per thread, TW lanes per row
   constexpr bool LEAN = (NT >= 960 && (NBUF != 2 || BLACK || PYR || F32)) || RPT > 4;
-  int lane_x, row0, ox, oy0;
-  if constexpr (TW == 256) {  // paired tiles: 256 x 16, or 128 x 32 in the output's last, narrower column band (pair_tile_geometry, mdc_internal.h)
-    const PairTile g = pair_tile_geometry(tile, p.tiles_x, p.pair_rem);  // workgroup-uniform
-    const int tw_log = g.w == 256 ? 8 : 7;
-    lane_x = tid & (g.w - 1);
-    row0 = (tid >> tw_log) * RPT;
-    ox = g.x0 + lane_x;
-    oy0 = g.y0 + row0;
-  } else {
-    lane_x = tid % TW;
-    row0 = (tid / TW) * RPT;
-    ox = (tile % p.tiles_x) * TW + lane_x;
-    oy0 = (tile / p.tiles_x) * kTileRows + row0;
-  }
+  const int oy0 = (tile / p.tiles_x) * kTileRows + row0;
 
   // Prologue, ordered for memory-level parallelism: the workgroup's whole start-up is three dependent
   // round trips -- (1) tile id -> (2) chunk list + remap + tap offsets + LUT, all in flight together ->
@@ -1338,9 +1328,6 @@ static hipError_t launch_tiled_shape(const TiledLaunch& l) {
     case 128016: return launch_tiled_buf<VIG, BLACK, PYR, F32, 128, 512>(l);
     case 128032:
       if constexpr (!PYR) return launch_tiled_buf<VIG, BLACK, false, F32, 128, 1024>(l);
-      break;
-    case 256016:  // paired tiles (raw u8 frames, no fused pyramid)
-      if constexpr (!PYR && !F32) return launch_tiled_buf<VIG, BLACK, false, false, 256, 1024>(l);
       break;
   }
   return hipErrorInvalidValue;

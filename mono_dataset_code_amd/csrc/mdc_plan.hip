@@ -107,36 +107,22 @@ int plan_source(mdc_ctx* c, int es, int kTileW, int kTileH, mdc_ctx::SrcPlan& pl
   const int ow = c->out_w, oh = c->out_h, iw = c->rm_in_w;
   const int kTileThreads = tile_threads(kTileW, kTileH);
   pl.staged_bytes = 0;
-  // paired tiles (256 x 16): nfull columns of 256 + a remainder column of <= 128 outputs tiled 128 x 32 (mdc_internal.h)
-  const bool paired = kTileW == 256;
-  int pair_rem = 0;
-  int tx = (ow + kTileW - 1) / kTileW, ty = (oh + kTileH - 1) / kTileH;
-  if (paired) {
-    const int rest = ow % 256;
-    pair_rem = rest > 0 && rest <= 128 && ow > 256 ? 1 : 0;  // (an output no wider than 128 columns keeps plain 256-wide tiles: tx >= 1)
-    tx = pair_rem ? ow / 256 : (ow + 255) / 256;
-    ty = (oh + 31) / 32;  // bands of 32 output rows
-  }
-  const int n_tiles = paired ? ty * (2 * tx + pair_rem) : tx * ty;
-  auto rect_of = [&](int t) {
-    if (paired) return pair_tile_geometry(t, tx, pair_rem);
-    return PairTile{(t % tx) * kTileW, (t / tx) * kTileH, kTileW, kTileH};
-  };
+  const int tx = (ow + kTileW - 1) / kTileW, ty = (oh + kTileH - 1) / kTileH;
+  const int n_tiles = tx * ty;
   const int ppc = 16 / es;  // pixels per chunk
   const bool lut = es == 1;
   // whole 16-byte chunks per frame row; one frame within the 32-bit lane offsets of the buffer descriptors
   const char* why = "frame rows are not whole chunks / frame too large";
   bool ok = (iw % ppc == 0) && (int64_t)iw * c->rm_in_h * es < (int64_t)kOutside && (int64_t)ow * oh * 4 < (int64_t)kOutside;
-  if ((tile_rpt(kTileW, kTileH) != 4 || paired) && es != 1) ok = false;  // the 8-rows-per-thread and the paired tiles exist for raw u8 frames only
+  if (tile_rpt(kTileW, kTileH) != 4 && es != 1) ok = false;  // the 8-rows-per-thread tiles exist for raw u8 frames only
   // the 960-/1024-thread tiles derive the output offsets of rows 1..3 from row 0 (kOutsideLean, mdc_kernels.hip)
-  if ((kTileThreads >= 960 || tile_rpt(kTileW, kTileH) > 4) && (int64_t)ow * (oh + (paired ? 32 : kTileH)) * 4 >= 0xc0000000ll) ok = false;
+  if ((kTileThreads >= 960 || tile_rpt(kTileW, kTileH) > 4) && (int64_t)ow * (oh + kTileH) * 4 >= 0xc0000000ll) ok = false;
   std::vector<std::vector<uint32_t>> chunks(n_tiles);
   std::vector<int> nch(n_tiles, 0);
   std::vector<uint32_t> taps((size_t)ow * oh, 0u);
   for (int t = 0; t < n_tiles && ok; t++) {
-    const PairTile rc_ = rect_of(t);
-    const int bx = rc_.x0, by = rc_.y0;
-    const int x1 = std::min(bx + rc_.w, ow), y1 = std::min(by + rc_.h, oh);
+    const int bx = (t % tx) * kTileW, by = (t / tx) * kTileH;
+    const int x1 = std::min(bx + kTileW, ow), y1 = std::min(by + kTileH, oh);
     int y_lo = std::numeric_limits<int>::max(), y_hi = -1;
     for (int y = by; y < y1; y++)
       for (int x = bx; x < x1; x++) {
@@ -217,13 +203,11 @@ int plan_source(mdc_ctx* c, int es, int kTileW, int kTileH, mdc_ctx::SrcPlan& pl
   if ((rc = upload(c, &pl.d_chunks, flat)) != MDC_OK || (rc = upload(c, &pl.d_nch, nch)) != MDC_OK ||
       (rc = upload(c, &pl.d_taps, taps)) != MDC_OK)
     return rc;
-  // (paired tiles are numbered band by band: row-major runs of that list are bands of whole 32-row strips per XCD)
-  const std::vector<int> order = paired ? tile_order(n_tiles, 1, MDC_ORDER_BANDS) : tile_order(tx, ty, c->opt_order);
+  const std::vector<int> order = tile_order(tx, ty, c->opt_order);
   if ((rc = upload(c, &pl.d_order, order)) != MDC_OK) return rc;
   pl.n_blocks = (int)order.size();
   pl.n_tiles = n_tiles;
   pl.tiles_x = tx;
-  pl.pair_rem = pair_rem;
   pl.tile_w = kTileW;
   pl.tile_h = kTileH;
   pl.chunk_cap = cap;
@@ -355,13 +339,12 @@ int plan_tiles(mdc_ctx* c) {
   // (128 x 16 first: measured 5-7 % faster than 64 x 32 on the bench camera -- a 64-wide tile spans ~86 source
   // bytes, less than one 128-byte line, so nearly every line is fetched by two workgroups; at 128 columns far
   // fewer are.  profiles/r02_experiments/)
-  static const TileShape cand_u8[] = {{128, 16}, {64, 32}, {128, 32}, {64, 64}, {64, 60}, {64, 16}, {256, 16}};  // (256 x 16: on request / by the tuner only)
-  static const TileShape cand_f32[] = {{128, 16}, {64, 32}, {64, 16}, {128, 32}, {64, 64}, {64, 60}, {256, 16}};  // 0.66 / 0.63 / 0.60 / 0.60 / 0.54 of 8 TB/s; 256 x 16 never plans for floats
+  static const TileShape cand_u8[] = {{128, 16}, {64, 32}, {128, 32}, {64, 64}, {64, 60}, {64, 16}};
+  static const TileShape cand_f32[] = {{128, 16}, {64, 32}, {64, 16}, {128, 32}, {64, 64}, {64, 60}};  // 0.66 / 0.63 / 0.60 / 0.60 / 0.54 of 8 TB/s
   for (int which = 0; which < 2; which++) {
     const TileShape* cand = which == 0 ? cand_u8 : cand_f32;
     const bool forced = c->opt_tile_h != 0 || c->opt_tile_w != 0;
-    for (int k = 0; k < 7; k++) {
-      if (!forced && cand[k].w == 256) continue;  // paired tiles are never the automatic choice
+    for (int k = 0; k < 6; k++) {
       const int tw = c->opt_tile_w ? c->opt_tile_w : cand[k].w, th = c->opt_tile_h ? c->opt_tile_h : cand[k].h;
       if (forced && (tw != cand[k].w || th != cand[k].h)) continue;  // a forced dimension filters the list
       free_src_plan(c->plan[which]);

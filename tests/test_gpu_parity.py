@@ -99,8 +99,7 @@ def test_tiled_and_gather_kernels_agree(name, setups, oracle, torch_cuda):
         for rows, order, nbuf, cols in (((32, capi.ORDER_BANDS, 0, 64), (16, capi.ORDER_ROWS, 4, 64), (32, capi.ORDER_IDENTITY, 3, 64), (60, capi.ORDER_BANDS, 0, 64),
                                    (64, capi.ORDER_ROWS, 2, 64), (16, capi.ORDER_BANDS, 2, 64), (32, capi.ORDER_ROWS, 4, 64), (60, capi.ORDER_ROWS, 2, 64),
                                    (32, capi.ORDER_BLOCKS2D, 0, 128), (16, capi.ORDER_BANDS, 4, 128), (32, capi.ORDER_ROWS, 3, 128), (16, capi.ORDER_BLOCKS2D, 2, 128),
-                                   (32, capi.ORDER_BLOCKS2D, 2, 64), (32, capi.ORDER_BANDS, 2, 128), (60, capi.ORDER_BANDS, 3, 64),
-                                   (16, capi.ORDER_BANDS, 2, 256), (16, capi.ORDER_BANDS, 3, 256))  # 256 x 16: paired tiles
+                                   (32, capi.ORDER_BLOCKS2D, 2, 64), (32, capi.ORDER_BANDS, 2, 128), (60, capi.ORDER_BANDS, 3, 64))
                                   if k == capi.KERNEL_TILED else ((32, capi.ORDER_BANDS, 0, 64),)):
           s.ctx.set_option(capi.OPT_TILE_COLS, cols)
           s.ctx.set_option(capi.OPT_TILE_ROWS, rows)
@@ -257,46 +256,6 @@ def test_full_size_flag_matrix_against_the_reference_build(name, calib_dirs, ref
         rfov.undistort(frames[f], b2)
         assert bits_equal(a2, b2), (name, "undistort<unsigned char>", f)
     ctx.close()
-
-
-def test_paired_tiles_at_full_size(setups, oracle, torch_cuda):
-    """256 x 16 paired tiles (two 128 x 16 tiles with one source window in a 1024-thread workgroup; 640 = 2 x 256 + 128: the last
-    column band runs as 128 x 32 tiles) on the bench camera and on the 1280-wide one: same bytes as the default plan and as the
-    oracle, ragged frame counts and frames-per-workgroup included."""
-    from mono_dataset_code_amd import capi, synth
-
-    torch = torch_cuda
-    st = torch.cuda.current_stream().cuda_stream
-    flags = capi.RECTIFY | capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED
-    for name, n in (("full_1280_to_640", 70), ("full_1280_to_1280", 9)):
-        s = setups(name)
-        npix, nout = s.W * s.H, s.w * s.h
-        d_in = torch.empty(n * npix, dtype=torch.uint8, device="cuda")
-        s.ctx.synth_frames(d_in.data_ptr(), 7, n, npix, synth.SEED, st)
-        s.ctx.set_option(capi.OPT_KERNEL, capi.KERNEL_GATHER)
-        d_ref = torch.empty(n * nout, dtype=torch.float32, device="cuda")
-        s.ctx.process_batch(d_in.data_ptr(), d_ref.data_ptr(), n, flags, st)
-        torch.cuda.synchronize()
-        s.ctx.set_option(capi.OPT_KERNEL, capi.KERNEL_TILED)
-        s.ctx.set_option(capi.OPT_TILE_COLS, 256)
-        s.ctx.set_option(capi.OPT_TILE_ROWS, 16)
-        info = s.ctx.info()
-        assert info.tiled and (info.tile_w, info.tile_h) == (256, 16), (name, info.tile_w, info.tile_h)
-        assert "256, 1024" in s.ctx.describe_launch(flags, 0)
-        for fpb in (0, 7, 32):
-            s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, fpb)
-            d_out = torch.full((n * nout,), -7.0, dtype=torch.float32, device="cuda")
-            s.ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, flags, st)
-            torch.cuda.synchronize()
-            assert torch.equal(d_out.view(torch.int32), d_ref.view(torch.int32)), (name, fpb)
-        frames = d_in.view(n, npix).cpu().numpy()
-        got = d_out.view(n, nout).cpu().numpy()
-        for f in (0, n - 1):
-            assert bits_equal(got[f], s.want(oracle, frames[f], 1, 1, 1, 1)), (name, f)
-        s.ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, 0)
-        s.ctx.set_option(capi.OPT_TILE_COLS, 0)
-        s.ctx.set_option(capi.OPT_TILE_ROWS, 0)
-        s.ctx.set_option(capi.OPT_KERNEL, capi.KERNEL_AUTO)
 
 
 def test_full_size_config_and_properties(setups, oracle, torch_cuda):
