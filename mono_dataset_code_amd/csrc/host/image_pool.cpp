@@ -46,8 +46,16 @@ struct Pool {
   // beyond this, slabs whose images have all come back go to the system.  Page-locking is slow (a fresh 1.2-MB block: ~0.4 ms,
   // twenty times the GPU's time for the frame it will hold): a caller that keeps 768 images of a getImages call alive and then
   // deletes them ran at 4.3 k frames/s with a 512-MiB stock and at 20 k with one that holds them all (mdch_image_pool_trim
-  // releases it)
-  static constexpr size_t kMaxIdleBytes = (size_t)2048 << 20;
+  // releases it).  MDC_IMAGE_POOL_MAX_MB in the environment moves the limit (a caller that holds 2048 results of 640x480 at a time and
+  // deletes them together needs 2.5 GB of stock to get the same blocks back: 13 k frames/s with the default, 35 k with 4096).
+  static size_t max_idle_bytes() {
+    static const size_t v = [] {
+      const char* e = std::getenv("MDC_IMAGE_POOL_MAX_MB");
+      const long mb = e ? std::atol(e) : 2048;
+      return (size_t)std::max(64l, std::min(mb, 1l << 20)) << 20;
+    }();
+    return v;
+  }
   static constexpr size_t kSlabBytes = (size_t)96 << 20;
   static constexpr int kSlabImages = 64;
   static constexpr size_t kPageableSlabBytes = (size_t)16 << 20;  // without a GPU / page-locked memory
@@ -162,10 +170,10 @@ extern "C" void mdch_image_free(float* b) {
     if (!free_blocks.insert(b).second) return;  // a second free of the same block is ignored
     s.live--;
     P.idle_bytes += s.nfloats * sizeof(float);
-    if (P.idle_bytes > Pool::kMaxIdleBytes) {
+    if (P.idle_bytes > Pool::max_idle_bytes()) {
       // over the cap: slabs without a live image go back (this one first; one with live images cannot)
       if (s.live == 0) P.retire(it, &drop);
-      for (auto jt = P.slabs.begin(); jt != P.slabs.end() && P.idle_bytes > Pool::kMaxIdleBytes;) {
+      for (auto jt = P.slabs.begin(); jt != P.slabs.end() && P.idle_bytes > Pool::max_idle_bytes();) {
         auto cur = jt++;
         if (cur->second.live == 0) P.retire(cur, &drop);
       }
