@@ -77,6 +77,8 @@ for stage in "$@"; do
           timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/rd_pass$i" -- python "$GRAFT_REPO_ROOT/tools/sweep.py" --frames ${FRAMES:-4096} --rounds 1 --iters 1 ${AB_ARGS:-} > "$OUT/rd_pass$i.log" 2>&1
         done )
       python3 tools/pmc_table.py "$OUT" rd_pass > "$OUT/rd_summary.txt" 2>&1; tail -${RD_TAIL:-30} "$OUT/rd_summary.txt" | cut -c1-260 ;;
+    placement)  # the headline launch on buffers at different places: fresh pairs, offsets inside one arena, a sequence-sized pair
+      timeout 600 python tools/placement_probe.py ${ROUNDS:-4} > "$OUT/placement_probe.txt" 2>&1; grep -av amdgpu.ids "$OUT/placement_probe.txt" | tail -40 ;;
     probe)   # why the same launch ran 8 % apart within one process: launch time against clocks / idle gaps / placement
       timeout 300 python tools/clock_probe.py ${PROBE_ARGS:-12 4 3} > "$OUT/clock_probe.txt" 2>&1; grep -a "===\|^A \|^B \|plan:\|idle snapshot" -A0 "$OUT/clock_probe.txt" | tail -8 ;;
     bench_driver)  # exactly what the driver runs at round end
