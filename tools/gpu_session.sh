@@ -79,6 +79,8 @@ for stage in "$@"; do
       python3 tools/pmc_table.py "$OUT" rd_pass > "$OUT/rd_summary.txt" 2>&1; tail -${RD_TAIL:-30} "$OUT/rd_summary.txt" | cut -c1-260 ;;
     placement)  # the headline launch on buffers at different places: fresh pairs, offsets inside one arena, a sequence-sized pair
       timeout 600 python tools/placement_probe.py ${ROUNDS:-4} > "$OUT/placement_probe.txt" 2>&1; grep -av amdgpu.ids "$OUT/placement_probe.txt" | tail -40 ;;
+    alloc)   # linear write / read rate per allocation (does the rate depend on where a buffer lies?)
+      timeout 600 python tools/alloc_probe.py ${ALLOC_ARGS:-32 5} > "$OUT/alloc_probe.txt" 2>&1; grep -av amdgpu.ids "$OUT/alloc_probe.txt" | tail -70 ;;
     probe)   # why the same launch ran 8 % apart within one process: launch time against clocks / idle gaps / placement
       timeout 300 python tools/clock_probe.py ${PROBE_ARGS:-12 4 3} > "$OUT/clock_probe.txt" 2>&1; grep -a "===\|^A \|^B \|plan:\|idle snapshot" -A0 "$OUT/clock_probe.txt" | tail -8 ;;
     bench_driver)  # exactly what the driver runs at round end
