@@ -80,6 +80,27 @@ def main():
         bufs[i] = p
         w = rate(p, "w")
         print("re-alloc in place of %2d  va 0x%012x  write %.4f ms = %.2f TB/s   (was %.4f)" % (i, p, w, SIZE / w / 1e9, first[i]), flush=True)
+    # physically contiguous allocations (hipExtMallocWithFlags(hipDeviceMallocContiguous)): is "fast" = "contiguous"?
+    for i in range(len(bufs)):
+        if bufs[i]:
+            L.mdc_device_free(ctx.handle, C.c_void_p(bufs[i]))
+    path = [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][0]
+    hip = C.CDLL(path)
+    hip.hipExtMallocWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    hip.hipFree.argtypes = [C.c_void_p]
+    for flag, name in ((0x4, "contiguous"), (0x0, "default")):
+        got = []
+        for i in range(int(os.environ.get("ALLOC_CONTIG_N", "16"))):
+            p = C.c_void_p()
+            rc = hip.hipExtMallocWithFlags(C.byref(p), SIZE, flag)
+            if rc != 0:
+                print("hipExtMallocWithFlags(%s) %d failed: %d" % (name, i, rc))
+                break
+            got.append(p.value)
+        ws = [rate(p, "w") for p in got]
+        print("hipExtMallocWithFlags(%s): write ms per allocation: %s" % (name, " ".join("%.3f" % w for w in ws)))
+        for p in got:
+            hip.hipFree(C.c_void_p(p))
     # the same through torch's caching allocator
     t = [torch.empty(SIZE, dtype=torch.uint8, device="cuda") for _ in range(3)]
     for i, x in enumerate(t):
