@@ -36,6 +36,9 @@ MDC_API int mdcb_ceiling_mix_device(int device, const void* d_read, int64_t read
  * also returned on the -3 "not a whole number of pages" error).  Synchronous. */
 MDC_API int mdcb_alias_alloc(int device, int64_t chunk_bytes, int repeats, void** out_ptr, int64_t* out_granularity);
 MDC_API int mdcb_alias_free(int device, void* ptr, int64_t chunk_bytes, int repeats);
+/* Experiment (tools/alloc_probe.py): n physical chunks of chunk_bytes created one after the other and mapped into one range, chunk i of
+ * the range = the (i * stride mod n)-th created (stride 1: in order).  Freed with mdcb_alias_free(device, ptr, chunk_bytes, n). */
+MDC_API int mdcb_chunked_alloc(int device, int64_t chunk_bytes, int n, int stride, void** out_ptr);
 
 #ifdef __cplusplus
 }

@@ -112,7 +112,7 @@ def _share_hip_runtime_with_torch():
 
 
 LIB_BENCH_PATH = os.path.join(_PKG, "libmdc_bench.so")
-BENCH_SYMBOLS = ["mdcb_synth_frames_device", "mdcb_ceiling_mix_device", "mdcb_alias_alloc", "mdcb_alias_free"]  # include/mdc_bench.h (not the product ABI)
+BENCH_SYMBOLS = ["mdcb_synth_frames_device", "mdcb_ceiling_mix_device", "mdcb_alias_alloc", "mdcb_alias_free", "mdcb_chunked_alloc"]  # include/mdc_bench.h (not the product ABI)
 _bench = None
 
 
@@ -128,6 +128,7 @@ def bench_lib():
         L.mdcb_ceiling_mix_device.argtypes = [_i, _vp, C.c_int64, _vp, C.c_int64, _i, _i, _vp]
         L.mdcb_alias_alloc.argtypes = [_i, C.c_int64, _i, C.POINTER(_vp), C.POINTER(C.c_int64)]
         L.mdcb_alias_free.argtypes = [_i, _vp, C.c_int64, _i]
+        L.mdcb_chunked_alloc.argtypes = [_i, C.c_int64, _i, _i, C.POINTER(_vp)]
         _bench = L
     return _bench
 

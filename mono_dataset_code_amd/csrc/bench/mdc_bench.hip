@@ -169,4 +169,48 @@ int mdcb_alias_free(int device, void* ptr, int64_t chunk_bytes, int repeats) {
   return rc;
 }
 
+// Experiment (tools/alloc_probe.py): a device range of n * chunk_bytes built from n separately created physical chunks (hipMemCreate),
+// mapped in the order of creation (stride = 1) or so that chunk i of the range is the (i * stride mod n)-th chunk created: neighbouring
+// pieces of the range then lie far apart physically.  What does the placement of a buffer's pieces do to a linear stream's rate?
+int mdcb_chunked_alloc(int device, int64_t chunk_bytes, int n, int stride, void** out_ptr) {
+  if (chunk_bytes <= 0 || n <= 0 || stride <= 0 || !out_ptr) return -1;
+  DeviceGuard dg(device);
+  int dev = device;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return -4;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) return -4;
+  if ((size_t)chunk_bytes % gran != 0) return -3;
+  void* va = nullptr;
+  const size_t total = (size_t)chunk_bytes * (size_t)n;
+  if (hipMemAddressReserve(&va, total, gran, nullptr, 0) != hipSuccess) return -4;
+  hipMemGenericAllocationHandle_t* h = new hipMemGenericAllocationHandle_t[n];
+  int made = 0;
+  for (; made < n; made++)
+    if (hipMemCreate(&h[made], (size_t)chunk_bytes, &prop, 0) != hipSuccess) break;
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  int rc = made == n ? 0 : -4;
+  int mapped = 0;
+  for (; mapped < n && rc == 0; mapped++) {
+    char* at = static_cast<char*>(va) + (size_t)mapped * (size_t)chunk_bytes;
+    const int src = (int)(((long long)mapped * stride) % n);  // a permutation when gcd(stride, n) == 1
+    if (hipMemMap(at, (size_t)chunk_bytes, 0, h[src], 0) != hipSuccess) rc = -4;
+  }
+  if (rc == 0 && hipMemSetAccess(va, total, &acc, 1) != hipSuccess) rc = -4;
+  for (int k = 0; k < made; k++) (void)hipMemRelease(h[k]);  // the mappings keep the memory
+  delete[] h;
+  if (rc != 0) {
+    for (int k = 0; k < mapped; k++) (void)hipMemUnmap(static_cast<char*>(va) + (size_t)k * (size_t)chunk_bytes, (size_t)chunk_bytes);
+    (void)hipMemAddressFree(va, total);
+    return rc;
+  }
+  *out_ptr = va;
+  return 0;
+}
+
 }  // extern "C"

@@ -54,6 +54,18 @@ def main():
                 ts.append(e0.elapsed_time(e1))
         return float(np.median(ts))
 
+    def rate_bytes(ptr, nbytes):
+        ts = []
+        for k in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            assert B.mdcb_ceiling_mix_device(0, None, 0, ptr, nbytes, 65536, 0, s) == 0
+            e1.record()
+            torch.cuda.synchronize()
+            if k:
+                ts.append(e0.elapsed_time(e1))
+        return float(np.median(ts))
+
     bufs = []
     for i in range(N):
         p = alloc()
@@ -90,7 +102,7 @@ def main():
     hip.hipFree.argtypes = [C.c_void_p]
     for flag, name in ((0x4, "contiguous"), (0x0, "default")):
         got = []
-        for i in range(int(os.environ.get("ALLOC_CONTIG_N", "16"))):
+        for i in range(int(os.environ.get("ALLOC_CONTIG_N", "8"))):
             p = C.c_void_p()
             rc = hip.hipExtMallocWithFlags(C.byref(p), SIZE, flag)
             if rc != 0:
@@ -101,6 +113,24 @@ def main():
         print("hipExtMallocWithFlags(%s): write ms per allocation: %s" % (name, " ".join("%.3f" % w for w in ws)))
         for p in got:
             hip.hipFree(C.c_void_p(p))
+    # a range mapped from separately created physical chunks, in order and permuted (mdcb_chunked_alloc): does SPREADING a buffer's pieces
+    # over the physical address space make the fast class?
+    for chunk_mib in (2, 32, 256, 1024):
+        cb = chunk_mib << 20
+        n = SIZE // cb
+        for stride in (1, 7, 61, 1021):
+            if stride >= n and stride != 1:
+                continue
+            ws = []
+            for rep in range(3):
+                p = C.c_void_p()
+                rc = B.mdcb_chunked_alloc(0, cb, n, stride, C.byref(p))
+                if rc != 0:
+                    ws.append(float("nan"))
+                    break
+                ws.append(n * cb / rate_bytes(p.value, n * cb) / 1e9)
+                B.mdcb_alias_free(0, p, cb, n)
+            print("chunked range: %4d-MiB chunks x %5d, mapped with stride %4d: write TB/s %s" % (chunk_mib, n, stride, " ".join("%.2f" % w for w in ws)), flush=True)
     # the same through torch's caching allocator
     t = [torch.empty(SIZE, dtype=torch.uint8, device="cuda") for _ in range(3)]
     for i, x in enumerate(t):
