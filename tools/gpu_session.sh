@@ -78,7 +78,10 @@ for stage in "$@"; do
         done )
       python3 tools/pmc_table.py "$OUT" rd_pass > "$OUT/rd_summary.txt" 2>&1; tail -${RD_TAIL:-30} "$OUT/rd_summary.txt" | cut -c1-260 ;;
     placement)  # the headline launch on buffers at different places: fresh pairs, offsets inside one arena, a sequence-sized pair
-      timeout 600 python tools/placement_probe.py ${ROUNDS:-4} > "$OUT/placement_probe.txt" 2>&1; grep -av amdgpu.ids "$OUT/placement_probe.txt" | tail -40 ;;
+      timeout 600 python tools/placement_probe.py ${ROUNDS:-4} > "$OUT/placement_probe.txt" 2>&1; grep -av amdgpu.ids "$OUT/placement_probe.txt" | tail -40
+      # the same with PyTorch's allocator on expandable segments (its own use of hipMemCreate / hipMemMap)
+      PYTORCH_HIP_ALLOC_CONF=expandable_segments:True PYTORCH_CUDA_ALLOC_CONF=expandable_segments:True timeout 300 python tools/alloc_probe.py 2 5 > "$OUT/alloc_probe_expandable.txt" 2>&1
+      grep -a "torch.empty\|Error\|error" "$OUT/alloc_probe_expandable.txt" | tail -5 ;;
     alloc)   # linear write / read rate per allocation (does the rate depend on where a buffer lies?)
       timeout 600 python tools/alloc_probe.py ${ALLOC_ARGS:-32 5} > "$OUT/alloc_probe.txt" 2>&1; grep -av amdgpu.ids "$OUT/alloc_probe.txt" | tail -70 ;;
     probe)   # why the same launch ran 8 % apart within one process: launch time against clocks / idle gaps / placement
