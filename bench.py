@@ -82,6 +82,10 @@ def parse():
     p.add_argument("--preroll-window-s", type=float, default=0.05)
     p.add_argument("--preroll-windows", type=int, default=5)
     p.add_argument("--preroll-tol", type=float, default=0.01)
+    p.add_argument("--placement-candidates", type=int, default=6,
+                   help="buffers are chosen among this many allocations by a linear read / write pass over each (mdc_stream_rate_device): on "
+                        "MI355X a stream's rate depends on the allocation it runs on by up to 24 %% (profiles/r05_experiments/05_*, 06_*); "
+                        "1 = take the first allocation as it comes")
     p.add_argument("--no-again", action="store_true", help="do not time the headline a second time after the secondary workloads")
     p.add_argument("--parity-frames", type=int, default=16, help="frames of the benchmarked launch compared with the oracle")
     p.add_argument("--frames", type=int, default=0,
@@ -425,12 +429,37 @@ def spot_frames(B, fpb, n):
     return sorted(out)
 
 
+def pick_placement(ctx, nbytes, kind, candidates, dev, stream):
+    """Up to `candidates` allocations of nbytes, a linear pass over each (reads for input frames, writes for outputs), the fastest
+    is kept, the others go back to the driver.  -> (uint8 tensor, report, the FIRST allocation if it is not the one kept, else None)"""
+    from mono_dataset_code_amd import capi
+
+    free_b = torch.cuda.mem_get_info(dev)[0]
+    n = max(1, min(candidates, int(free_b * 0.45 // max(nbytes, 1))))  # all candidates are held at once
+    if nbytes < (256 << 20):
+        n = 1  # a pass over less than the Infinity Cache says nothing about the memory behind it
+    tens, rates = [], []
+    for _ in range(n):
+        try:
+            t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        except RuntimeError:
+            break
+        tens.append(t)
+        rates.append(ctx.stream_rate(t.data_ptr(), nbytes // 16 * 16, kind, stream) if n > 1 else 0.0)
+    best = int(np.argmax(rates)) if n > 1 else 0
+    keep, first = tens[best], (tens[0] if best != 0 else None)
+    rep = {"candidates": len(tens), "probe": "linear %s pass (mdc_stream_rate_device)" % ("read" if kind == capi.PLACE_READ else "write"),
+           "tbps": [round(r, 2) for r in rates] if n > 1 else None, "picked": best}
+    del tens
+    return keep, rep, first
+
+
 class Workload:
     """One BASELINE.json config set up on every rank: context + tables, this rank's shard of the synthetic sequence in HBM, the
     tuned plan, `step()` = one pass of the hot path over the shard.  Kept alive so that the SAME launch (same context, same
     buffers, same plan) can be timed again later in the process."""
 
-    def __init__(self, args, D, wl, frames, tune=True):
+    def __init__(self, args, D, wl, frames, tune=True, keep_first=False):
         from mono_dataset_code_amd import capi, shard, synth
 
         self.args, self.D, self.wl = args, D, wl
@@ -495,8 +524,15 @@ class Workload:
         tstream = D.stream()
         torch.cuda.set_stream(tstream)
         self.stream = stream = tstream.cuda_stream
-        self.d_in = torch.empty(B * self.npix_in, dtype=torch.uint8, device=dev)
-        self.d_out = torch.empty(B * self.npix_out, dtype=torch.float32, device=dev)
+        K = max(1, args.placement_candidates)
+        self.placement = {}
+        d_in8, self.placement["in"], self.first_in = pick_placement(ctx, B * self.npix_in, capi.PLACE_READ, K, dev, stream)
+        d_out8, self.placement["out"], self.first_out = pick_placement(ctx, B * self.npix_out * 4, capi.PLACE_WRITE, K, dev, stream)
+        self.d_in = d_in8
+        self.d_out = d_out8.view(torch.float32)
+        if not (keep_first and wl == "fused" and world == 1):
+            self.first_in = self.first_out = None
+        torch.cuda.empty_cache()
         if world == 1:
             ctx.synth_frames(self.d_in.data_ptr(), 0, B, self.npix_in, synth.SEED, stream)
         else:
@@ -504,11 +540,18 @@ class Workload:
                 ctx.synth_frames(self.d_in.data_ptr() + i * self.npix_in, int(f), 1, self.npix_in, synth.SEED, stream)
         self.levels, self.d_levels = 4, []
         self.d_dI, self.d_abs = [], []
+        def out_floats(count, tag):  # the other output arrays: placed like the base output
+            t, rep, _ = pick_placement(ctx, count * 4, capi.PLACE_WRITE, min(K, 4), dev, stream)
+            if rep["tbps"]:
+                self.placement[tag] = rep
+            return t.view(torch.float32)
+
         if wl in ("pyramid", "dso"):
-            self.d_levels = [torch.empty(B * (self.out_w >> l) * (self.out_h >> l), dtype=torch.float32, device=dev) for l in range(1, self.levels)]
+            self.d_levels = [out_floats(B * (self.out_w >> l) * (self.out_h >> l), "level%d" % l) for l in range(1, self.levels)]
         if wl == "dso":  # per level: (I, dx, dy) triples + absSquaredGrad
-            self.d_dI = [torch.empty(B * (self.out_w >> l) * (self.out_h >> l) * 3, dtype=torch.float32, device=dev) for l in range(self.levels)]
-            self.d_abs = [torch.empty(B * (self.out_w >> l) * (self.out_h >> l), dtype=torch.float32, device=dev) for l in range(self.levels)]
+            self.d_dI = [out_floats(B * (self.out_w >> l) * (self.out_h >> l) * 3, "dI%d" % l) for l in range(self.levels)]
+            self.d_abs = [out_floats(B * (self.out_w >> l) * (self.out_h >> l), "abs%d" % l) for l in range(self.levels)]
+        torch.cuda.empty_cache()
         self.flags = capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED | (capi.RECTIFY if rect else 0)
         self.tuned = None
         if tune and wl in ("fused", "seq50k") and args.kernel == "auto" and not (args.no_tune or args.fpb or args.tile_rows or args.tile_cols or args.nbuf):
@@ -541,7 +584,7 @@ class Workload:
             self.ctx.process_batch(self.d_in.data_ptr(), self.d_out.data_ptr(), self.B, self.flags, self.stream)
 
     def free(self):
-        self.d_in = self.d_out = None
+        self.d_in = self.d_out = self.first_in = self.first_out = None
         self.d_levels, self.d_dI, self.d_abs = [], [], []
         self.ctx.close()
         torch.cuda.empty_cache()
@@ -599,6 +642,26 @@ class Workload:
         kstat = [float(ktimes.mean()), float(np.median(ktimes)), float(ktimes.min())]
         per_rank = [[round(x, 4) for x in k] for k in D.gather(kstat)]
         return {"elapsed": elapsed, "steps": steps, "kstat": kstat, "per_rank_kernel_ms": per_rank, "clocks": clocks}
+
+    def timed_on_first_allocation(self, steps, warmup):
+        """The same launch on the buffers a caller gets who takes the first allocation as it comes (kept by pick_placement when another
+        candidate won): what the placement is worth, in the same process.  -> kernel ms (mean) or None if the first allocations won."""
+        from mono_dataset_code_amd import synth
+
+        if self.first_in is None and self.first_out is None:
+            return None
+        keep = (self.d_in, self.d_out)
+        if self.first_in is not None:
+            self.ctx.synth_frames(self.first_in.data_ptr(), 0, self.B, self.npix_in, synth.SEED, self.stream)
+            self.d_in = self.first_in
+        if self.first_out is not None:
+            self.d_out = self.first_out.view(torch.float32)
+        self.preroll()
+        t = self.timed(steps, warmup)
+        self.d_in, self.d_out = keep
+        self.first_in = self.first_out = None
+        torch.cuda.empty_cache()
+        return t["kstat"][0]
 
     def dump(self):
         """test hook: every rank hands out its first outputs (checked against the oracle per GLOBAL frame index)"""
@@ -739,6 +802,7 @@ class Workload:
                        "table_broadcast_ms": round(self.bcast_ms, 3) if self.bcast_ms is not None else None,
                        "table_blob_bytes": self.blob_bytes,
                        "plan": self.tuned if self.tuned is not None else "built-in",
+                       "placement": self.placement,
                        "frames_per_s": round(frames_total / elapsed, 1),
                        "out_mpix_per_s": round(frames_total * self.npix_out / 1e6 / elapsed, 1)},
         }
@@ -767,8 +831,15 @@ def main():
     wl = args.workload
     do_ceiling = not args.no_ceiling
     clocks_idle = gpu_clock_snapshot(D.gpu)
-    H = Workload(args, D, wl, args.frames)
+    H = Workload(args, D, wl, args.frames, keep_first=True)
     head = measure(H, args.steps, args.warmup, do_ceiling, args.parity_frames, dump=True)
+    first_ms = H.timed_on_first_allocation(args.steps, args.warmup) if D.world == 1 else None
+    if D.rank == 0:
+        head["roofline"]["placement"] = {
+            "buffers": "chosen among %d allocations each by a linear pass (config.placement); a stream's rate depends on the allocation "
+                       "it runs on (profiles/r05_experiments/05_*, 06_*)" % max(1, args.placement_candidates),
+            "kernel_ms_on_first_allocation": round(first_ms, 4) if first_ms else None,
+            "frac_on_first_allocation": round(H.frac_of(first_ms), 4) if first_ms else None}
     devices = D.devices() if D.active else [{"rank": 0, "device": D.gpu}]
     # ---- the other BASELINE.json configs, timed in the same process (same box, same clocks) -------------------------
     # N = 1: configs[1] unMapImage, configs[4] pyramid, configs[3] as one 50,000-frame sequence on the one GPU.

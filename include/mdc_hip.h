@@ -293,6 +293,18 @@ MDC_API int mdc_process_jpeg_frames_host_to_device(mdc_ctx* ctx, const void* con
 MDC_API int mdc_process_jpeg_streams_host_to_device(mdc_ctx* ctx, const void* const* streams, const int64_t* stream_bytes, int64_t nframes,
                                                     unsigned flags, const mdc_device_outputs* out, const int64_t* frame_index, int* status);
 MDC_API int mdc_device_alloc(mdc_ctx* ctx, size_t bytes, void** d_ptr); /* device memory on the context's GPU (hipMalloc) */
+/* PLACEMENT-AWARE allocation.  On MI355X the rate a kernel reaches on a buffer is a property of the ALLOCATION (of the physical pages
+ * behind it), not only of the kernel: a linear stream of nontemporal stores runs at 6.4-6.9 TB/s into some hipMalloc'ed ranges and at
+ * 5.3-5.6 TB/s into others of the same size in the same process (24 % apart; reads: a few per cent) -- and this path's kernels, which
+ * write two thirds of their bytes, follow: 1.48 vs 1.61 ms for the same launch (profiles/r05_experiments/05_*, 06_*).
+ * mdc_device_alloc_fast allocates up to `candidates` ranges of `bytes`, times a linear pass over each (mdc_stream_rate_device: writes
+ * for MDC_PLACE_WRITE -- output buffers --, reads for MDC_PLACE_READ -- input frames), keeps the fastest and frees the others; *tbps
+ * (optional) = the winner's rate.  Buffers below 256 MiB (a probe would measure the Infinity Cache) and candidates <= 1 are plain
+ * allocations.  Blocking, ~1 ms per candidate and 5 GB.  The contents of the returned range are unspecified.
+ * mdc_stream_rate_device: the probe alone on a caller's own device range (any allocator's): MDC_PLACE_WRITE OVERWRITES it. */
+enum { MDC_PLACE_WRITE = 0, MDC_PLACE_READ = 1 };
+MDC_API int mdc_device_alloc_fast(mdc_ctx* ctx, size_t bytes, int kind, int candidates, void** d_ptr, double* tbps);
+MDC_API int mdc_stream_rate_device(mdc_ctx* ctx, void* d_ptr, size_t bytes, int kind, void* stream, double* tbps);
 MDC_API void mdc_device_free(mdc_ctx* ctx, void* d_ptr);
 MDC_API int mdc_copy_to_host(mdc_ctx* ctx, void* dst, const void* d_src, size_t bytes); /* blocking device -> host copy */
 

@@ -69,7 +69,7 @@ class MDC_API DatasetReader {
   // level -- is left in the caller's device arrays, frame first+i at position i of each; nothing comes back over PCIe (getImages
   // tops out at ~31 k frames/s of 640x480 float results; this path is bound by the JPEG decode).  valid[i] (optional, `count`
   // bytes) = 1 where position i holds a result (0: wrong size / undecodable, as getImage's 0).  The arrays live on the device
-  // of getDevice(): hipMalloc / torch on that device, or mdc_device_alloc(getContext(), ...).  Returns the number of frames
+  // of getDevice(): any device allocation there (hipMalloc, a framework tensor), or mdc_device_alloc(getContext(), ...).  Returns the number of frames
   // produced.  Same bytes as getImages followed by a copy to the device.  With several devices (MDC_DEVICES) the call runs on
   // the first one: shard with one reader per device, frame f on device f % N.
   int getImagesDevice(int first, int count, bool rectify, bool removeGamma, bool removeVignette, bool nanOverexposed,

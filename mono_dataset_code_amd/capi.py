@@ -24,13 +24,14 @@ OPT_PREFETCH_STREAMS = 13
 OPT_ZERO_COPY = 14
 OPT_TAIL_TAPER = 15
 ORDER_BANDS, ORDER_ROWS, ORDER_IDENTITY, ORDER_BLOCKS2D = 0, 1, 2, 3
+PLACE_WRITE, PLACE_READ = 0, 1
 OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/mdc_hip.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = [
     "mdc_create", "mdc_destroy", "mdc_device_count", "mdc_device_pci_bus_id", "mdc_last_error", "mdc_build_flags", "mdc_code_id", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
     "mdc_set_remap", "mdc_unmap_host", "mdc_undistort_host_f32", "mdc_undistort_host_u8", "mdc_process_host",
-    "mdc_process_frames_host_to_device", "mdc_process_jpeg_frames_host_to_device", "mdc_process_jpeg_streams_host_to_device", "mdc_device_alloc", "mdc_device_free", "mdc_copy_to_host",
+    "mdc_process_frames_host_to_device", "mdc_process_jpeg_frames_host_to_device", "mdc_process_jpeg_streams_host_to_device", "mdc_device_alloc", "mdc_device_alloc_fast", "mdc_stream_rate_device", "mdc_device_free", "mdc_copy_to_host",
     "mdc_host_alloc", "mdc_host_free", "mdc_process_frames_host", "mdc_process_jpeg_frames_host", "mdc_jpeg_idct_batch_device", "mdc_process_jpeg_streams_host", "mdc_jpeg_huffman_batch_device",
     "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
     "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device",
@@ -175,6 +176,8 @@ def hip_lib():
             L.mdc_process_jpeg_streams_host_to_device.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_int64), _i64, C.c_uint, C.POINTER(DeviceOutputs),
                                                                   C.POINTER(C.c_int64), C.POINTER(C.c_int)]
             L.mdc_device_alloc.argtypes = [_vp, _sz, C.POINTER(_vp)]
+            L.mdc_device_alloc_fast.argtypes = [_vp, _sz, _i, _i, C.POINTER(_vp), C.POINTER(C.c_double)]
+            L.mdc_stream_rate_device.argtypes = [_vp, _vp, _sz, _i, _vp, C.POINTER(C.c_double)]
             L.mdc_device_free.argtypes = [_vp, _vp]
             L.mdc_device_free.restype = None
             L.mdc_copy_to_host.argtypes = [_vp, _vp, _vp, _sz]
@@ -538,6 +541,12 @@ class Context:
 
     def synchronize(self):
         self._chk(self._L.mdc_synchronize(self._h))
+
+    def stream_rate(self, d_ptr, nbytes, kind, stream=0):
+        """TB/s of a linear pass over a device range (kind PLACE_WRITE overwrites it, PLACE_READ reads it): include/mdc_hip.h."""
+        r = C.c_double(0)
+        self._chk(self._L.mdc_stream_rate_device(self._h, d_ptr, nbytes, kind, stream if stream else None, C.byref(r)))
+        return r.value
 
     def pci_bus_id(self):
         buf = C.create_string_buffer(32)

@@ -967,3 +967,33 @@ def test_error_codes(setups):
     assert "wrong input image" in s.ctx.last_error()
     with pytest.raises(capi.MdcError):
         c.set_remap(np.array([5.0], np.float32), np.array([500.0], np.float32), 16, 16, 1, 1)
+
+
+def test_placement_aware_allocation(setups, torch_cuda):
+    """mdc_stream_rate_device / mdc_device_alloc_fast (include/mdc_hip.h): the linear-pass probe gives a plausible rate for writes and
+    reads on a caller's range, the allocator returns a usable range that is at least as fast as the slowest of its candidates, small
+    requests are plain allocations, bad arguments are refused."""
+    import ctypes
+
+    from mono_dataset_code_amd import capi
+
+    torch = torch_cuda
+    s = setups("small_explicit")
+    L = capi.hip_lib()
+    n = 1 << 30
+    t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    w = s.ctx.stream_rate(t.data_ptr(), n, capi.PLACE_WRITE)
+    r = s.ctx.stream_rate(t.data_ptr(), n, capi.PLACE_READ)
+    assert 1.0 < w < 9.0 and 1.0 < r < 9.0, (w, r)  # TB/s on an MI355X (8 TB/s peak; a 1-GB pass is partly served by the Infinity Cache)
+    assert int(t[:4096].sum()) == 0  # the write pass stores zeros over the whole range
+    with pytest.raises(capi.MdcError):
+        s.ctx.stream_rate(t.data_ptr() + 4, n - 16, capi.PLACE_READ)  # unaligned
+    p, rate = ctypes.c_void_p(), ctypes.c_double(0)
+    assert L.mdc_device_alloc_fast(s.ctx.handle, 2 << 30, capi.PLACE_WRITE, 4, ctypes.byref(p), ctypes.byref(rate)) == 0
+    assert p.value and 1.0 < rate.value < 9.0
+    assert abs(s.ctx.stream_rate(p.value, 2 << 30, capi.PLACE_WRITE) / rate.value - 1) < 0.2  # the rate is the range's own, again
+    L.mdc_device_free(s.ctx.handle, p)
+    assert L.mdc_device_alloc_fast(s.ctx.handle, 1 << 20, capi.PLACE_READ, 4, ctypes.byref(p), ctypes.byref(rate)) == 0  # small: plain, no probe
+    assert p.value and rate.value == 0.0
+    L.mdc_device_free(s.ctx.handle, p)
+    assert L.mdc_device_alloc_fast(s.ctx.handle, 1 << 20, 7, 4, ctypes.byref(p), None) != 0

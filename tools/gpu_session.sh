@@ -94,6 +94,7 @@ d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 r = d["roofline"]
 print("headline", d["value"], "Mpix/s  frac", r["frac"], "again", r.get("frac_again"), "kernel_ms", r["kernel_ms"], "of ceiling", r.get("frac_of_same_box_mix_ceiling"), r["kernel"], "parity", d["parity"])
 print("preroll", d["config"]["preroll"], "again", d.get("again"))
+print("placement", d["config"].get("placement"), r.get("placement"))
 print("clocks idle", d.get("clocks_idle_at_start"), "after", r.get("clocks_in_timed_region"), "traffic", r["traffic"], r["traffic_source"])
 for k, v in (d.get("secondary") or {}).items():
     print("secondary", k, "frac", v["frac"], "kernel_ms", v["kernel_ms"], "of ceiling", v["frac_of_same_box_mix_ceiling"], v["kernel"], "preroll s", v["preroll"]["seconds"], "parity", v["parity"] if isinstance(v["parity"], str) else v["parity"]["mismatching_pixels"])
