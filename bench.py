@@ -82,7 +82,7 @@ def parse():
     p.add_argument("--preroll-window-s", type=float, default=0.05)
     p.add_argument("--preroll-windows", type=int, default=5)
     p.add_argument("--preroll-tol", type=float, default=0.01)
-    p.add_argument("--placement-candidates", type=int, default=6,
+    p.add_argument("--placement-candidates", type=int, default=8,
                    help="buffers are chosen among this many allocations by a linear read / write pass over each (mdc_stream_rate_device): on "
                         "MI355X a stream's rate depends on the allocation it runs on by up to 24 %% (profiles/r05_experiments/05_*, 06_*); "
                         "1 = take the first allocation as it comes")
@@ -429,29 +429,34 @@ def spot_frames(B, fpb, n):
     return sorted(out)
 
 
-def pick_placement(ctx, nbytes, kind, candidates, dev, stream):
-    """Up to `candidates` allocations of nbytes, a linear pass over each (reads for input frames, writes for outputs), the fastest
-    is kept, the others go back to the driver.  -> (uint8 tensor, report, the FIRST allocation if it is not the one kept, else None)"""
+def pick_placements(ctx, specs, candidates, dev, stream):
+    """For every (nbytes, kind) of `specs`: up to `candidates` allocations, a linear pass over each (reads for input frames, writes for
+    outputs; mdc_stream_rate_device), the fastest is kept.  ALL candidates of ALL buffers are held until the choice is made -- a range
+    given back would be handed out again, and the first tens of GB of a fresh device are often the slow ones -- then the losers go
+    back to the driver.  -> [(uint8 tensor, report, the FIRST allocation if it is not the one kept, else None)]"""
     from mono_dataset_code_amd import capi
 
+    total = sum(n for n, _ in specs)
     free_b = torch.cuda.mem_get_info(dev)[0]
-    n = max(1, min(candidates, int(free_b * 0.45 // max(nbytes, 1))))  # all candidates are held at once
-    if nbytes < (256 << 20):
-        n = 1  # a pass over less than the Infinity Cache says nothing about the memory behind it
-    tens, rates = [], []
-    for _ in range(n):
-        try:
-            t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        except RuntimeError:
-            break
-        tens.append(t)
-        rates.append(ctx.stream_rate(t.data_ptr(), nbytes // 16 * 16, kind, stream) if n > 1 else 0.0)
-    best = int(np.argmax(rates)) if n > 1 else 0
-    keep, first = tens[best], (tens[0] if best != 0 else None)
-    rep = {"candidates": len(tens), "probe": "linear %s pass (mdc_stream_rate_device)" % ("read" if kind == capi.PLACE_READ else "write"),
-           "tbps": [round(r, 2) for r in rates] if n > 1 else None, "picked": best}
-    del tens
-    return keep, rep, first
+    k_all = max(1, min(candidates, int(free_b * 0.45 // max(total, 1))))
+    held, out = [], []
+    for nbytes, kind in specs:
+        n = k_all if nbytes >= (256 << 20) else 1  # a pass over less than the Infinity Cache says nothing about the memory behind it
+        tens, rates = [], []
+        for _ in range(n):
+            try:
+                t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            except RuntimeError:
+                break
+            tens.append(t)
+            rates.append(ctx.stream_rate(t.data_ptr(), nbytes // 16 * 16, kind, stream) if n > 1 else 0.0)
+        best = int(np.argmax(rates)) if n > 1 else 0
+        rep = {"candidates": len(tens), "probe": "linear %s pass (mdc_stream_rate_device)" % ("read" if kind == capi.PLACE_READ else "write"),
+               "tbps": [round(r, 2) for r in rates] if n > 1 else None, "picked": best}
+        out.append((tens[best], rep, tens[0] if best != 0 else None))
+        held.append(tens)
+    del held, tens
+    return out
 
 
 class Workload:
@@ -526,8 +531,8 @@ class Workload:
         self.stream = stream = tstream.cuda_stream
         K = max(1, args.placement_candidates)
         self.placement = {}
-        d_in8, self.placement["in"], self.first_in = pick_placement(ctx, B * self.npix_in, capi.PLACE_READ, K, dev, stream)
-        d_out8, self.placement["out"], self.first_out = pick_placement(ctx, B * self.npix_out * 4, capi.PLACE_WRITE, K, dev, stream)
+        (d_in8, self.placement["in"], self.first_in), (d_out8, self.placement["out"], self.first_out) = pick_placements(
+            ctx, [(B * self.npix_in, capi.PLACE_READ), (B * self.npix_out * 4, capi.PLACE_WRITE)], K, dev, stream)
         self.d_in = d_in8
         self.d_out = d_out8.view(torch.float32)
         if not (keep_first and wl == "fused" and world == 1):
@@ -541,7 +546,7 @@ class Workload:
         self.levels, self.d_levels = 4, []
         self.d_dI, self.d_abs = [], []
         def out_floats(count, tag):  # the other output arrays: placed like the base output
-            t, rep, _ = pick_placement(ctx, count * 4, capi.PLACE_WRITE, min(K, 4), dev, stream)
+            (t, rep, _), = pick_placements(ctx, [(count * 4, capi.PLACE_WRITE)], min(K, 4), dev, stream)
             if rep["tbps"]:
                 self.placement[tag] = rep
             return t.view(torch.float32)
