@@ -429,34 +429,38 @@ def spot_frames(B, fpb, n):
     return sorted(out)
 
 
-def pick_placements(ctx, specs, candidates, dev, stream):
-    """For every (nbytes, kind) of `specs`: up to `candidates` allocations, a linear pass over each (reads for input frames, writes for
-    outputs; mdc_stream_rate_device), the fastest is kept.  ALL candidates of ALL buffers are held until the choice is made -- a range
-    given back would be handed out again, and the first tens of GB of a fresh device are often the slow ones -- then the losers go
-    back to the driver.  -> [(uint8 tensor, report, the FIRST allocation if it is not the one kept, else None)]"""
-    from mono_dataset_code_amd import capi
+class Buf:
+    """A device buffer of the bench: memory from the library's placement-aware allocator (mdc_device_alloc_fast: the fastest of K candidate
+    ranges -- hipMalloc'ed ones and ranges made with HIP's virtual memory management -- for a linear write / read pass), or, with
+    --placement-candidates 1 and for buffers below 256 MiB, a plain torch allocation."""
 
-    total = sum(n for n, _ in specs)
-    free_b = torch.cuda.mem_get_info(dev)[0]
-    k_all = max(1, min(candidates, int(free_b * 0.45 // max(total, 1))))
-    held, out = [], []
-    for nbytes, kind in specs:
-        n = k_all if nbytes >= (256 << 20) else 1  # a pass over less than the Infinity Cache says nothing about the memory behind it
-        tens, rates = [], []
-        for _ in range(n):
-            try:
-                t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            except RuntimeError:
-                break
-            tens.append(t)
-            rates.append(ctx.stream_rate(t.data_ptr(), nbytes // 16 * 16, kind, stream) if n > 1 else 0.0)
-        best = int(np.argmax(rates)) if n > 1 else 0
-        rep = {"candidates": len(tens), "probe": "linear %s pass (mdc_stream_rate_device)" % ("read" if kind == capi.PLACE_READ else "write"),
-               "tbps": [round(r, 2) for r in rates] if n > 1 else None, "picked": best}
-        out.append((tens[best], rep, tens[0] if best != 0 else None))
-        held.append(tens)
-    del held, tens
-    return out
+    def __init__(self, ctx, nbytes, kind, candidates, dev, plain=False):
+        from mono_dataset_code_amd import capi
+
+        self.nbytes = int(nbytes)
+        self.t = self.d = None
+        if plain or candidates <= 1 or nbytes < (256 << 20):
+            self.t = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
+            self.tbps = None
+        else:
+            self.d = capi.DeviceBuffer(ctx, self.nbytes, kind, candidates)
+            self.tbps = round(self.d.tbps, 2)
+
+    def data_ptr(self):
+        return self.t.data_ptr() if self.t is not None else self.d.data_ptr()
+
+    def read(self, offset_bytes, count, dtype):
+        """count elements of dtype from byte offset, as a numpy array"""
+        if self.t is not None:
+            nb = count * np.dtype(dtype).itemsize
+            return self.t[offset_bytes:offset_bytes + nb].cpu().numpy().view(dtype)
+        return self.d.read(offset_bytes, count, dtype)
+
+    def free(self):
+        self.t = None
+        if self.d is not None:
+            self.d.free()
+            self.d = None
 
 
 class Workload:
@@ -530,14 +534,18 @@ class Workload:
         torch.cuda.set_stream(tstream)
         self.stream = stream = tstream.cuda_stream
         K = max(1, args.placement_candidates)
-        self.placement = {}
-        (d_in8, self.placement["in"], self.first_in), (d_out8, self.placement["out"], self.first_out) = pick_placements(
-            ctx, [(B * self.npix_in, capi.PLACE_READ), (B * self.npix_out * 4, capi.PLACE_WRITE)], K, dev, stream)
-        self.d_in = d_in8
-        self.d_out = d_out8.view(torch.float32)
-        if not (keep_first and wl == "fused" and world == 1):
-            self.first_in = self.first_out = None
-        torch.cuda.empty_cache()
+        # what a caller gets who takes the first allocations of a fresh device as they come: kept for the headline, timed beside it
+        self.first_in = self.first_out = None
+        if keep_first and wl == "fused" and world == 1 and K > 1:
+            self.first_in = Buf(ctx, B * self.npix_in, capi.PLACE_READ, 1, dev, plain=True)
+            self.first_out = Buf(ctx, B * self.npix_out * 4, capi.PLACE_WRITE, 1, dev, plain=True)
+        self.d_in = Buf(ctx, B * self.npix_in, capi.PLACE_READ, K, dev)
+        self.d_out = Buf(ctx, B * self.npix_out * 4, capi.PLACE_WRITE, K, dev)
+        self.placement = {"allocator": "mdc_device_alloc_fast: the fastest of %d candidate ranges by a linear pass" % K if K > 1 else "torch.empty, as it comes",
+                          "in_read_tbps": self.d_in.tbps, "out_write_tbps": self.d_out.tbps}
+        if self.first_out is not None:
+            self.placement["first_allocation_in_read_tbps"] = round(ctx.stream_rate(self.first_in.data_ptr(), B * self.npix_in // 16 * 16, capi.PLACE_READ, stream), 2)
+            self.placement["first_allocation_out_write_tbps"] = round(ctx.stream_rate(self.first_out.data_ptr(), B * self.npix_out * 4, capi.PLACE_WRITE, stream), 2)
         if world == 1:
             ctx.synth_frames(self.d_in.data_ptr(), 0, B, self.npix_in, synth.SEED, stream)
         else:
@@ -546,17 +554,16 @@ class Workload:
         self.levels, self.d_levels = 4, []
         self.d_dI, self.d_abs = [], []
         def out_floats(count, tag):  # the other output arrays: placed like the base output
-            (t, rep, _), = pick_placements(ctx, [(count * 4, capi.PLACE_WRITE)], min(K, 4), dev, stream)
-            if rep["tbps"]:
-                self.placement[tag] = rep
-            return t.view(torch.float32)
+            b = Buf(ctx, count * 4, capi.PLACE_WRITE, min(K, 4), dev)
+            if b.tbps:
+                self.placement[tag + "_write_tbps"] = b.tbps
+            return b
 
         if wl in ("pyramid", "dso"):
             self.d_levels = [out_floats(B * (self.out_w >> l) * (self.out_h >> l), "level%d" % l) for l in range(1, self.levels)]
         if wl == "dso":  # per level: (I, dx, dy) triples + absSquaredGrad
             self.d_dI = [out_floats(B * (self.out_w >> l) * (self.out_h >> l) * 3, "dI%d" % l) for l in range(self.levels)]
             self.d_abs = [out_floats(B * (self.out_w >> l) * (self.out_h >> l), "abs%d" % l) for l in range(self.levels)]
-        torch.cuda.empty_cache()
         self.flags = capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED | (capi.RECTIFY if rect else 0)
         self.tuned = None
         if tune and wl in ("fused", "seq50k") and args.kernel == "auto" and not (args.no_tune or args.fpb or args.tile_rows or args.tile_cols or args.nbuf):
@@ -589,6 +596,9 @@ class Workload:
             self.ctx.process_batch(self.d_in.data_ptr(), self.d_out.data_ptr(), self.B, self.flags, self.stream)
 
     def free(self):
+        for b in [self.d_in, self.d_out, self.first_in, self.first_out] + self.d_levels + self.d_dI + self.d_abs:
+            if b is not None:
+                b.free()
         self.d_in = self.d_out = self.first_in = self.first_out = None
         self.d_levels, self.d_dI, self.d_abs = [], [], []
         self.ctx.close()
@@ -649,21 +659,20 @@ class Workload:
         return {"elapsed": elapsed, "steps": steps, "kstat": kstat, "per_rank_kernel_ms": per_rank, "clocks": clocks}
 
     def timed_on_first_allocation(self, steps, warmup):
-        """The same launch on the buffers a caller gets who takes the first allocation as it comes (kept by pick_placement when another
-        candidate won): what the placement is worth, in the same process.  -> kernel ms (mean) or None if the first allocations won."""
+        """The same launch on the buffers a caller gets who takes the first allocations of a fresh device as they come (torch.empty, made
+        before anything else): what the placement is worth, in the same process.  -> kernel ms (mean), or None if none were kept."""
         from mono_dataset_code_amd import synth
 
         if self.first_in is None and self.first_out is None:
             return None
         keep = (self.d_in, self.d_out)
-        if self.first_in is not None:
-            self.ctx.synth_frames(self.first_in.data_ptr(), 0, self.B, self.npix_in, synth.SEED, self.stream)
-            self.d_in = self.first_in
-        if self.first_out is not None:
-            self.d_out = self.first_out.view(torch.float32)
+        self.ctx.synth_frames(self.first_in.data_ptr(), 0, self.B, self.npix_in, synth.SEED, self.stream)
+        self.d_in, self.d_out = self.first_in, self.first_out
         self.preroll()
         t = self.timed(steps, warmup)
         self.d_in, self.d_out = keep
+        self.first_in.free()
+        self.first_out.free()
         self.first_in = self.first_out = None
         torch.cuda.empty_cache()
         return t["kstat"][0]
@@ -674,15 +683,15 @@ class Workload:
         if not (args.dump_dir and args.dump_frames > 0):
             return
         n = min(args.dump_frames, self.B)
-        np.save(os.path.join(args.dump_dir, "rank%d_out.npy" % rank), self.d_out[: n * self.npix_out].cpu().numpy().reshape(n, self.npix_out))
+        np.save(os.path.join(args.dump_dir, "rank%d_out.npy" % rank), self.d_out.read(0, n * self.npix_out, np.float32).reshape(n, self.npix_out))
         np.save(os.path.join(args.dump_dir, "rank%d_idx.npy" % rank), np.asarray(self.mine[:n], dtype=np.int64))
-        np.save(os.path.join(args.dump_dir, "rank%d_in_head.npy" % rank), self.d_in.view(self.B, self.npix_in)[:n, :64].cpu().numpy())
+        np.save(os.path.join(args.dump_dir, "rank%d_in_head.npy" % rank), np.stack([self.d_in.read(i * self.npix_in, 64, np.uint8) for i in range(n)]))
 
     def ceiling(self):
         """Same-box yardstick: the traffic mix of this launch as a linear stream, no arithmetic (rank 0)."""
         ctx, B, stream = self.ctx, self.B, self.stream
-        wbytes = min(self.alg_write * B, self.d_out.numel() * 4)
-        rbytes = min(self.alg_read * B, self.d_in.numel()) // 16 * 16
+        wbytes = min(self.alg_write * B, self.d_out.nbytes)
+        rbytes = min(self.alg_read * B, self.d_in.nbytes) // 16 * 16
         reps = 12
         best = None
         for blocks, span in ((4096, 0), (16384, 0), (65536, 0), (4096, 1), (16384, 1), (65536, 1)):
@@ -733,23 +742,23 @@ class Workload:
         checked = spot_frames(self.B, fpb, max(2, nframes))
         npi, npo = self.npix_in, self.npix_out
         for f in checked:
-            raw = self.d_in[f * npi:(f + 1) * npi].cpu().numpy()
+            raw = self.d_in.read(f * npi, npi, np.uint8)
             assert np.array_equal(raw, synth.noise_frames(int(self.mine[f]), 1, npi)[0]), "frame %d is not global frame %d" % (f, self.mine[f])
             if R is not None:
                 want = R.get_image(rfov, rphoto, raw, self.rect, True, True, True)
             else:
                 want = O.get_image(raw, IN_W, IN_H, self.out_w, self.out_h, ginv, vinv, True, True, rx, ry, self.rect, True, True, True)
-            bad += bits_differ(want, self.d_out[f * npo:(f + 1) * npo].cpu().numpy())
+            bad += bits_differ(want, self.d_out.read(f * npo * 4, npo, np.float32))
             src, cw, ch = want, self.out_w, self.out_h
             for l in range(self.levels if self.d_levels else 1):
                 if l > 0:
                     src = O.pyramid_level(src, cw, ch)
                     cw, ch = cw // 2, ch // 2
-                    bad += bits_differ(src, self.d_levels[l - 1][f * cw * ch:(f + 1) * cw * ch].cpu().numpy())
+                    bad += bits_differ(src, self.d_levels[l - 1].read(f * cw * ch * 4, cw * ch, np.float32))
                 if self.d_dI:
                     w_dI, w_abs = O.gradients(src, cw, ch)
-                    bad += bits_differ(w_dI.reshape(-1), self.d_dI[l][f * cw * ch * 3:(f + 1) * cw * ch * 3].cpu().numpy())
-                    bad += bits_differ(w_abs, self.d_abs[l][f * cw * ch:(f + 1) * cw * ch].cpu().numpy())
+                    bad += bits_differ(w_dI.reshape(-1), self.d_dI[l].read(f * cw * ch * 12, cw * ch * 3, np.float32))
+                    bad += bits_differ(w_abs, self.d_abs[l].read(f * cw * ch * 4, cw * ch, np.float32))
         out = {"frames_checked": len(checked), "frames": checked, "levels_checked": 1 + len(self.d_levels), "mismatching_pixels": bad,
                "against": "oracle/_ref/libmdc_ref.so (the reference's own sources compiled here, its own tables from the same calibration files)"
                           if R is not None else "oracle/liboracle.so (C restatement, pinned to the reference build by tests/test_oracle_vs_ref.py)"}
@@ -841,8 +850,8 @@ def main():
     first_ms = H.timed_on_first_allocation(args.steps, args.warmup) if D.world == 1 else None
     if D.rank == 0:
         head["roofline"]["placement"] = {
-            "buffers": "chosen among %d allocations each by a linear pass (config.placement); a stream's rate depends on the allocation "
-                       "it runs on (profiles/r05_experiments/05_*, 06_*)" % max(1, args.placement_candidates),
+            "buffers": "from mdc_device_alloc_fast (config.placement): a stream's rate depends on the allocation it runs on -- 5.3 to 6.9 TB/s for "
+                       "a linear write (profiles/r05_experiments/05_*, 06_*)",
             "kernel_ms_on_first_allocation": round(first_ms, 4) if first_ms else None,
             "frac_on_first_allocation": round(H.frac_of(first_ms), 4) if first_ms else None}
     devices = D.devices() if D.active else [{"rank": 0, "device": D.gpu}]

@@ -85,6 +85,37 @@ class DeviceOutputs(C.Structure):
         return o
 
 
+class DeviceBuffer:
+    """Device memory from mdc_device_alloc_fast (include/mdc_hip.h): the fastest of `candidates` ranges for a linear write (outputs) or read
+    (input frames) pass.  data_ptr() for the *_device entry points, read() for a copy back."""
+
+    def __init__(self, ctx, nbytes, kind=0, candidates=8):
+        self._ctx, self.nbytes = ctx, int(nbytes)
+        p, r = C.c_void_p(), C.c_double(0)
+        ctx._chk(ctx._L.mdc_device_alloc_fast(ctx._h, self.nbytes, kind, candidates, C.byref(p), C.byref(r)))
+        self._p, self.tbps = p.value, r.value
+
+    def data_ptr(self):
+        return self._p
+
+    def read(self, offset_bytes, count, dtype):
+        out = np.empty(count, dtype)
+        assert offset_bytes + out.nbytes <= self.nbytes
+        self._ctx._chk(self._ctx._L.mdc_copy_to_host(self._ctx._h, out.ctypes.data_as(C.c_void_p), self._p + offset_bytes, out.nbytes))
+        return out
+
+    def free(self):
+        if getattr(self, "_p", None):
+            self._ctx._L.mdc_device_free(self._ctx._h, C.c_void_p(self._p))
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # interpreter shutdown
+            pass
+
+
 class TuneResult(C.Structure):
     _fields_ = [("tile_w", C.c_int), ("tile_h", C.c_int), ("frames_per_block", C.c_int), ("ms", C.c_float), ("candidates", C.c_int)]
 
