@@ -86,6 +86,15 @@ for stage in "$@"; do
       timeout 600 python tools/alloc_probe.py ${ALLOC_ARGS:-32 5} > "$OUT/alloc_probe.txt" 2>&1; grep -av amdgpu.ids "$OUT/alloc_probe.txt" | tail -70 ;;
     probe)   # why the same launch ran 8 % apart within one process: launch time against clocks / idle gaps / placement
       timeout 300 python tools/clock_probe.py ${PROBE_ARGS:-12 4 3} > "$OUT/clock_probe.txt" 2>&1; grep -a "===\|^A \|^B \|plan:\|idle snapshot" -A0 "$OUT/clock_probe.txt" | tail -8 ;;
+    bench_each)  # every workload in its own process (which one faults?)
+      for wl in fused unmap pyramid dso seq50k; do
+        timeout 300 python3 bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > "$OUT/bench_each_$wl.json" 2> "$OUT/bench_each_$wl.err"; echo "$wl rc=$?"
+        tail -c 300 "$OUT/bench_each_$wl.err" | grep -a "fault\|Error\|error" ; python3 -c "
+import json,sys
+try:
+    d=json.loads([l for l in open('$OUT/bench_each_$wl.json') if l.startswith('{')][-1]); print('  frac', d['roofline']['frac'], d['config']['placement'], d['parity']['mismatching_pixels'])
+except Exception as e: print('  no line', e)"
+      done ;;
     bench_driver)  # exactly what the driver runs at round end
       ( time timeout 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver.json" 2> "$OUT/bench_driver.err" ) 2>&1 | grep real; tail -c 400 "$OUT/bench_driver.err"
       python3 - "$OUT/bench_driver.json" <<'PY'
