@@ -564,6 +564,10 @@ class Workload:
         if wl == "dso":  # per level: (I, dx, dy) triples + absSquaredGrad
             self.d_dI = [out_floats(B * (self.out_w >> l) * (self.out_h >> l) * 3, "dI%d" % l) for l in range(self.levels)]
             self.d_abs = [out_floats(B * (self.out_w >> l) * (self.out_h >> l), "abs%d" % l) for l in range(self.levels)]
+        if os.environ.get("MDC_BENCH_DEBUG_BUFFERS"):  # where every buffer lies (a GPU memory fault names an address)
+            for name, b in [("in", self.d_in), ("out", self.d_out)] + [("level%d" % (i + 1), b) for i, b in enumerate(self.d_levels)] + \
+                    [("dI%d" % i, b) for i, b in enumerate(self.d_dI)] + [("abs%d" % i, b) for i, b in enumerate(self.d_abs)]:
+                sys.stderr.write("buffer %-7s 0x%x .. 0x%x (%d bytes, %s)\n" % (name, b.data_ptr(), b.data_ptr() + b.nbytes, b.nbytes, "torch" if b.t is not None else "mdc_device_alloc_fast"))
         self.flags = capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED | (capi.RECTIFY if rect else 0)
         self.tuned = None
         if tune and wl in ("fused", "seq50k") and args.kernel == "auto" and not (args.no_tune or args.fpb or args.tile_rows or args.tile_cols or args.nbuf):
