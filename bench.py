@@ -445,6 +445,10 @@ class Buf:
         else:
             self.d = capi.DeviceBuffer(ctx, self.nbytes, kind, candidates)
             self.tbps = round(self.d.tbps, 2)
+        if os.environ.get("MDC_BENCH_DEBUG_BUFFERS"):
+            torch.cuda.synchronize()
+            sys.stderr.write("alloc %d bytes kind %d -> 0x%x (%s, %s TB/s)\n" % (self.nbytes, kind, self.data_ptr(), "torch" if self.t is not None else "fast", self.tbps))
+            sys.stderr.flush()
 
     def data_ptr(self):
         return self.t.data_ptr() if self.t is not None else self.d.data_ptr()
