@@ -645,6 +645,8 @@ int mdc_device_alloc_fast(mdc_ctx* c, size_t bytes, int kind, int candidates, vo
       break;  // out of memory for another candidate: the ones we have compete
     }
     cand.push_back(p);
+    static const bool trace = getenv("MDC_ALLOC_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "mdc_device_alloc_fast: candidate %d of %d for %zu bytes (kind %d) at %p\n", k, n, bytes, kind, p);
     double r = 0.0;
     if (n > 1 && (rc = stream_rate(c, p, bytes / 16 * 16, kind, nullptr, &r)) != MDC_OK) break;
     rate.push_back(r);
