@@ -565,28 +565,34 @@ void* vmm_alloc(int device, size_t bytes, size_t chunk) {
   const size_t n = (size + piece - 1) / piece, total = n * piece;
   void* va = nullptr;
   if (hipMemAddressReserve(&va, total, gran, nullptr, 0) != hipSuccess) return nullptr;
-  size_t mapped = 0;
+  // order as in the calls' documentation examples: create every piece, map every piece, set the access of the whole range, and only
+  // then drop the handles (the mappings keep the memory).  Releasing each handle right after its hipMemMap, before hipMemSetAccess,
+  // produced intermittent GPU memory faults in the first kernel that touched the range.
+  std::vector<hipMemGenericAllocationHandle_t> handles;
   bool ok = true;
-  for (; mapped < n && ok; mapped++) {
+  for (size_t k = 0; k < n && ok; k++) {
     hipMemGenericAllocationHandle_t h;
-    if (hipMemCreate(&h, piece, &prop, 0) != hipSuccess) {
+    ok = hipMemCreate(&h, piece, &prop, 0) == hipSuccess;
+    if (ok) handles.push_back(h);
+  }
+  size_t mapped = 0;
+  for (; mapped < handles.size() && ok; mapped++)
+    if (hipMemMap(static_cast<char*>(va) + mapped * piece, piece, 0, handles[mapped], 0) != hipSuccess) {
       ok = false;
       break;
     }
-    ok = hipMemMap(static_cast<char*>(va) + mapped * piece, piece, 0, h, 0) == hipSuccess;
-    (void)hipMemRelease(h);  // a mapping keeps the memory; an unmapped handle is gone with this
-    if (!ok) break;
-  }
   hipMemAccessDesc acc = {};
   acc.location = prop.location;
   acc.flags = hipMemAccessFlagsProtReadWrite;
   if (ok) ok = hipMemSetAccess(va, total, &acc, 1) == hipSuccess;
+  for (hipMemGenericAllocationHandle_t h : handles) (void)hipMemRelease(h);
   if (!ok) {
     (void)hipGetLastError();
     for (size_t k = 0; k < mapped; k++) (void)hipMemUnmap(static_cast<char*>(va) + k * piece, piece);
     (void)hipMemAddressFree(va, total);
     return nullptr;
   }
+  (void)hipDeviceSynchronize();
   std::lock_guard<std::mutex> lk(g_vmm_mu);
   vmm_ranges()[va] = VmmRange{total, piece};
   return va;

@@ -997,3 +997,26 @@ def test_placement_aware_allocation(setups, torch_cuda):
     assert p.value and rate.value == 0.0
     L.mdc_device_free(s.ctx.handle, p)
     assert L.mdc_device_alloc_fast(s.ctx.handle, 1 << 20, 7, 4, ctypes.byref(p), None) != 0
+
+
+def test_placement_aware_allocation_soak(setups, torch_cuda):
+    """mdc_device_alloc_fast over and over with sizes that make one-piece and many-piece virtual-memory-management candidates and plain
+    ones, every returned range written and read over its whole length at once: no GPU memory fault, no leak (free memory comes back)."""
+    import ctypes
+
+    from mono_dataset_code_amd import capi
+
+    torch = torch_cuda
+    s = setups("small_explicit")
+    L = capi.hip_lib()
+    free0 = torch.cuda.mem_get_info()[0]
+    sizes = [640 << 20, (2560 << 20), 300 << 20, (1 << 30) + (2 << 20), 7 * (1 << 30) + 4096 * 3, 503316480]
+    for it in range(18):
+        nb = sizes[it % len(sizes)]
+        p, rate = ctypes.c_void_p(), ctypes.c_double(0)
+        assert L.mdc_device_alloc_fast(s.ctx.handle, nb, it & 1, 4, ctypes.byref(p), ctypes.byref(rate)) == 0, s.ctx.last_error()
+        assert s.ctx.stream_rate(p.value, nb // 16 * 16, capi.PLACE_WRITE) > 0.5
+        assert s.ctx.stream_rate(p.value, nb // 16 * 16, capi.PLACE_READ) > 0.5
+        L.mdc_device_free(s.ctx.handle, p)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] > free0 - (1 << 30)
