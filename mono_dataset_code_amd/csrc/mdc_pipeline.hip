@@ -644,8 +644,9 @@ int mdc_device_alloc_fast(mdc_ctx* c, size_t bytes, int kind, int candidates, vo
   for (int k = 0; k < n; k++) {
     // the candidates: a range of 1-GiB pieces made with the virtual memory management calls, one made in one piece, then plain hipMalloc
     void* p = nullptr;
-    if (n > 1 && k == 0) p = vmm_alloc(c->device, bytes, (size_t)1 << 30);
-    else if (n > 1 && k == 1) p = vmm_alloc(c->device, bytes, 0);
+    static const bool use_vmm = getenv("MDC_ALLOC_VMM") != nullptr;  // experiment only: see the note above vmm_alloc
+    if (use_vmm && n > 1 && k == 0) p = vmm_alloc(c->device, bytes, (size_t)1 << 30);
+    else if (use_vmm && n > 1 && k == 1) p = vmm_alloc(c->device, bytes, 0);
     if (!p && hipMalloc(&p, std::max<size_t>(bytes, 1)) != hipSuccess) {
       (void)hipGetLastError();
       break;  // out of memory for another candidate: the ones we have compete
