@@ -431,8 +431,8 @@ def spot_frames(B, fpb, n):
 
 class Buf:
     """A device buffer of the bench: memory from the library's placement-aware allocator (mdc_device_alloc_fast: the fastest of K candidate
-    ranges -- hipMalloc'ed ones and ranges made with HIP's virtual memory management -- for a linear write / read pass), or, with
-    --placement-candidates 1 and for buffers below 256 MiB, a plain torch allocation."""
+    hipMalloc'ed ranges for a linear write / read pass), or, with --placement-candidates 1 and for buffers below 256 MiB, a plain torch
+    allocation."""
 
     def __init__(self, ctx, nbytes, kind, candidates, dev, plain=False):
         from mono_dataset_code_amd import capi

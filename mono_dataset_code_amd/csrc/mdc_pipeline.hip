@@ -540,82 +540,6 @@ int stream_rate(mdc_ctx* c, void* p, size_t bytes, int kind, hipStream_t s, doub
 }
 }  // namespace
 
-namespace {
-// Ranges built with HIP's virtual memory management (hipMemCreate + hipMemMap) -- candidates of mdc_device_alloc_fast beside plain
-// hipMalloc: on a device with little else allocated they are consistently the fastest memory for a write stream (6.8-6.9 TB/s against
-// 5.3-6.6 for hipMalloc'ed ranges, profiles/r05_experiments/06_*, 07_*).  ptr -> (total bytes, bytes per mapped chunk), for the free.
-struct VmmRange {
-  size_t total, chunk;
-};
-std::mutex g_vmm_mu;
-std::map<void*, VmmRange>& vmm_ranges() {
-  static std::map<void*, VmmRange>* m = new std::map<void*, VmmRange>();  // never destroyed: frees may come at any time of process exit
-  return *m;
-}
-// chunk = 0: one physical allocation for the whole range, else pieces of `chunk` bytes created one after the other
-void* vmm_alloc(int device, size_t bytes, size_t chunk) {
-  hipMemAllocationProp prop = {};
-  prop.type = hipMemAllocationTypePinned;
-  prop.location.type = hipMemLocationTypeDevice;
-  prop.location.id = device;
-  size_t gran = 0;
-  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) return nullptr;
-  const size_t size = (std::max<size_t>(bytes, 1) + gran - 1) / gran * gran;
-  const size_t piece = chunk ? (std::min(chunk, size) + gran - 1) / gran * gran : size;
-  const size_t n = (size + piece - 1) / piece, total = n * piece;
-  void* va = nullptr;
-  if (hipMemAddressReserve(&va, total, gran, nullptr, 0) != hipSuccess) return nullptr;
-  // order as in the calls' documentation examples: create every piece, map every piece, set the access of the whole range, and only
-  // then drop the handles (the mappings keep the memory).  Releasing each handle right after its hipMemMap, before hipMemSetAccess,
-  // produced intermittent GPU memory faults in the first kernel that touched the range.
-  std::vector<hipMemGenericAllocationHandle_t> handles;
-  bool ok = true;
-  for (size_t k = 0; k < n && ok; k++) {
-    hipMemGenericAllocationHandle_t h;
-    ok = hipMemCreate(&h, piece, &prop, 0) == hipSuccess;
-    if (ok) handles.push_back(h);
-  }
-  size_t mapped = 0;
-  for (; mapped < handles.size() && ok; mapped++)
-    if (hipMemMap(static_cast<char*>(va) + mapped * piece, piece, 0, handles[mapped], 0) != hipSuccess) {
-      ok = false;
-      break;
-    }
-  hipMemAccessDesc acc = {};
-  acc.location = prop.location;
-  acc.flags = hipMemAccessFlagsProtReadWrite;
-  if (ok) ok = hipMemSetAccess(va, total, &acc, 1) == hipSuccess;
-  for (hipMemGenericAllocationHandle_t h : handles) (void)hipMemRelease(h);
-  if (!ok) {
-    (void)hipGetLastError();
-    for (size_t k = 0; k < mapped; k++) (void)hipMemUnmap(static_cast<char*>(va) + k * piece, piece);
-    (void)hipMemAddressFree(va, total);
-    return nullptr;
-  }
-  (void)hipDeviceSynchronize();
-  std::lock_guard<std::mutex> lk(g_vmm_mu);
-  vmm_ranges()[va] = VmmRange{total, piece};
-  return va;
-}
-// true if p was one of ours (and is gone now)
-bool vmm_free(void* p) {
-  VmmRange r;
-  {
-    std::lock_guard<std::mutex> lk(g_vmm_mu);
-    auto it = vmm_ranges().find(p);
-    if (it == vmm_ranges().end()) return false;
-    r = it->second;
-    vmm_ranges().erase(it);
-  }
-  for (size_t off = 0; off < r.total; off += r.chunk) (void)hipMemUnmap(static_cast<char*>(p) + off, r.chunk);
-  (void)hipMemAddressFree(p, r.total);
-  return true;
-}
-void free_any(void* p) {
-  if (p && !vmm_free(p)) (void)hipFree(p);
-}
-}  // namespace
-
 int mdc_stream_rate_device(mdc_ctx* c, void* d_ptr, size_t bytes, int kind, void* stream, double* tbps) try {
   if (!c) return MDC_ERR_ARG;
   if (!d_ptr || !tbps || bytes < 16 || (kind != MDC_PLACE_WRITE && kind != MDC_PLACE_READ) || (reinterpret_cast<uintptr_t>(d_ptr) & 15) != 0)
@@ -642,18 +566,15 @@ int mdc_device_alloc_fast(mdc_ctx* c, size_t bytes, int kind, int candidates, vo
   std::vector<double> rate;
   int rc = MDC_OK;
   for (int k = 0; k < n; k++) {
-    // the candidates: a range of 1-GiB pieces made with the virtual memory management calls, one made in one piece, then plain hipMalloc
+    // (candidates are plain hipMalloc ranges.  Ranges made with the virtual-memory-management calls -- hipMemCreate + hipMemMap -- were
+    // the fastest memory of all on an otherwise empty device, 6.8-6.9 TB/s for a linear write, but candidates of that kind that are mapped,
+    // probed, unmapped and released in a row ended in intermittent GPU memory faults: profiles/r05_experiments/07_*; not used)
     void* p = nullptr;
-    static const bool use_vmm = getenv("MDC_ALLOC_VMM") != nullptr;  // experiment only: see the note above vmm_alloc
-    if (use_vmm && n > 1 && k == 0) p = vmm_alloc(c->device, bytes, (size_t)1 << 30);
-    else if (use_vmm && n > 1 && k == 1) p = vmm_alloc(c->device, bytes, 0);
-    if (!p && hipMalloc(&p, std::max<size_t>(bytes, 1)) != hipSuccess) {
+    if (hipMalloc(&p, std::max<size_t>(bytes, 1)) != hipSuccess) {
       (void)hipGetLastError();
       break;  // out of memory for another candidate: the ones we have compete
     }
     cand.push_back(p);
-    static const bool trace = getenv("MDC_ALLOC_TRACE") != nullptr;
-    if (trace) fprintf(stderr, "mdc_device_alloc_fast: candidate %d of %d for %zu bytes (kind %d) at %p\n", k, n, bytes, kind, p);
     double r = 0.0;
     if (n > 1 && (rc = stream_rate(c, p, bytes / 16 * 16, kind, nullptr, &r)) != MDC_OK) break;
     rate.push_back(r);
@@ -662,7 +583,7 @@ int mdc_device_alloc_fast(mdc_ctx* c, size_t bytes, int kind, int candidates, vo
   for (size_t k = 1; k < rate.size(); k++)
     if (rate[k] > rate[best]) best = k;
   for (size_t k = 0; k < cand.size(); k++)
-    if (rc != MDC_OK || k != best) free_any(cand[k]);
+    if (rc != MDC_OK || k != best) (void)hipFree(cand[k]);
   if (rc != MDC_OK) return rc;
   if (cand.empty()) return fail(c, MDC_ERR_HIP, "mdc_device_alloc_fast: out of device memory for %zu bytes", bytes);
   *d_ptr = cand[best];
@@ -673,7 +594,7 @@ int mdc_device_alloc_fast(mdc_ctx* c, size_t bytes, int kind, int candidates, vo
 void mdc_device_free(mdc_ctx* c, void* d_ptr) {
   if (!c || !d_ptr) return;
   DeviceGuard dg(c->device);
-  free_any(d_ptr);
+  (void)hipFree(d_ptr);
 }
 
 int mdc_copy_to_host(mdc_ctx* c, void* dst, const void* d_src, size_t bytes) try {
