@@ -83,9 +83,9 @@ def parse():
     p.add_argument("--preroll-windows", type=int, default=5)
     p.add_argument("--preroll-tol", type=float, default=0.01)
     p.add_argument("--placement-candidates", type=int, default=8,
-                   help="buffers are chosen among this many allocations by a linear read / write pass over each (mdc_stream_rate_device): on "
-                        "MI355X a stream's rate depends on the allocation it runs on by up to 24 %% (profiles/r05_experiments/05_*, 06_*); "
-                        "1 = take the first allocation as it comes")
+                   help="the headline's frame and result buffers are chosen among this many allocations each by timing the launch itself on them "
+                        "(mdc_tune_placement_device): on MI355X the time of one launch depends on the allocations it runs on by up to 9 %% "
+                        "(profiles/r05_experiments/05_*, 08_*); 1 = take the first allocations as they come")
     p.add_argument("--no-again", action="store_true", help="do not time the headline a second time after the secondary workloads")
     p.add_argument("--parity-frames", type=int, default=16, help="frames of the benchmarked launch compared with the oracle")
     p.add_argument("--frames", type=int, default=0,
@@ -430,41 +430,22 @@ def spot_frames(B, fpb, n):
 
 
 class Buf:
-    """A device buffer of the bench: memory from the library's placement-aware allocator (mdc_device_alloc_fast: the fastest of K candidate
-    hipMalloc'ed ranges for a linear write / read pass), or, with --placement-candidates 1 and for buffers below 256 MiB, a plain torch
-    allocation."""
+    """A device buffer of the bench (a torch allocation: hipMalloc through PyTorch's allocator) with byte-offset reads."""
 
-    def __init__(self, ctx, nbytes, kind, candidates, dev, plain=False):
-        from mono_dataset_code_amd import capi
-
+    def __init__(self, nbytes, dev, tensor=None):
         self.nbytes = int(nbytes)
-        self.t = self.d = None
-        if plain or candidates <= 1 or nbytes < (256 << 20):
-            self.t = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
-            self.tbps = None
-        else:
-            self.d = capi.DeviceBuffer(ctx, self.nbytes, kind, candidates)
-            self.tbps = round(self.d.tbps, 2)
-        if os.environ.get("MDC_BENCH_DEBUG_BUFFERS"):
-            torch.cuda.synchronize()
-            sys.stderr.write("alloc %d bytes kind %d -> 0x%x (%s, %s TB/s)\n" % (self.nbytes, kind, self.data_ptr(), "torch" if self.t is not None else "fast", self.tbps))
-            sys.stderr.flush()
+        self.t = tensor if tensor is not None else torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
 
     def data_ptr(self):
-        return self.t.data_ptr() if self.t is not None else self.d.data_ptr()
+        return self.t.data_ptr()
 
     def read(self, offset_bytes, count, dtype):
         """count elements of dtype from byte offset, as a numpy array"""
-        if self.t is not None:
-            nb = count * np.dtype(dtype).itemsize
-            return self.t[offset_bytes:offset_bytes + nb].cpu().numpy().view(dtype)
-        return self.d.read(offset_bytes, count, dtype)
+        nb = count * np.dtype(dtype).itemsize
+        return self.t[offset_bytes:offset_bytes + nb].cpu().numpy().view(dtype)
 
     def free(self):
         self.t = None
-        if self.d is not None:
-            self.d.free()
-            self.d = None
 
 
 class Workload:
@@ -537,31 +518,30 @@ class Workload:
         tstream = D.stream()
         torch.cuda.set_stream(tstream)
         self.stream = stream = tstream.cuda_stream
-        K = max(1, args.placement_candidates)
-        # what a caller gets who takes the first allocations of a fresh device as they come: kept for the headline, timed beside it
+        # Buffers.  The headline's: K candidate allocations for the frames and K for the results, the launch itself timed on them
+        # (mdc_tune_placement_device) further down, once the frames exist; the first allocations of the process -- what a caller gets who
+        # takes them as they come -- are candidate 0 of each and are timed beside the chosen ones (timed_on_first_allocation).
+        K = max(1, args.placement_candidates) if (keep_first and wl == "fused" and world == 1) else 1
+        in_bytes, out_bytes = B * self.npix_in, B * self.npix_out * 4
+        free_b = torch.cuda.mem_get_info(dev)[0]
+        K = max(1, min(K, int(free_b * 0.45 // (in_bytes + out_bytes))))
+        cand_in, cand_out = [], []
+        for _ in range(K):  # frames, results, frames, results, ...: candidates 0 are the first two allocations of the process
+            cand_in.append(Buf(in_bytes, dev))
+            cand_out.append(Buf(out_bytes, dev))
+        self.d_in, self.d_out = cand_in[0], cand_out[0]
         self.first_in = self.first_out = None
-        if keep_first and wl == "fused" and world == 1 and K > 1:
-            self.first_in = Buf(ctx, B * self.npix_in, capi.PLACE_READ, 1, dev, plain=True)
-            self.first_out = Buf(ctx, B * self.npix_out * 4, capi.PLACE_WRITE, 1, dev, plain=True)
-        self.d_in = Buf(ctx, B * self.npix_in, capi.PLACE_READ, K, dev)
-        self.d_out = Buf(ctx, B * self.npix_out * 4, capi.PLACE_WRITE, K, dev)
-        self.placement = {"allocator": "mdc_device_alloc_fast: the fastest of %d candidate ranges by a linear pass" % K if K > 1 else "torch.empty, as it comes",
-                          "in_read_tbps": self.d_in.tbps, "out_write_tbps": self.d_out.tbps}
-        if self.first_out is not None:
-            self.placement["first_allocation_in_read_tbps"] = round(ctx.stream_rate(self.first_in.data_ptr(), B * self.npix_in // 16 * 16, capi.PLACE_READ, stream), 2)
-            self.placement["first_allocation_out_write_tbps"] = round(ctx.stream_rate(self.first_out.data_ptr(), B * self.npix_out * 4, capi.PLACE_WRITE, stream), 2)
+        self.placement = {"how": "first allocations, as they come"}
         if world == 1:
-            ctx.synth_frames(self.d_in.data_ptr(), 0, B, self.npix_in, synth.SEED, stream)
+            for b_ in cand_in:
+                ctx.synth_frames(b_.data_ptr(), 0, B, self.npix_in, synth.SEED, stream)
         else:
             for i, f in enumerate(mine):  # local frame i = global frame rank + i * world
                 ctx.synth_frames(self.d_in.data_ptr() + i * self.npix_in, int(f), 1, self.npix_in, synth.SEED, stream)
         self.levels, self.d_levels = 4, []
         self.d_dI, self.d_abs = [], []
-        def out_floats(count, tag):  # the other output arrays: placed like the base output
-            b = Buf(ctx, count * 4, capi.PLACE_WRITE, min(K, 4), dev)
-            if b.tbps:
-                self.placement[tag + "_write_tbps"] = b.tbps
-            return b
+        def out_floats(count, tag):
+            return Buf(count * 4, dev)
 
         if wl in ("pyramid", "dso"):
             self.d_levels = [out_floats(B * (self.out_w >> l) * (self.out_h >> l), "level%d" % l) for l in range(1, self.levels)]
@@ -571,7 +551,7 @@ class Workload:
         if os.environ.get("MDC_BENCH_DEBUG_BUFFERS"):  # where every buffer lies (a GPU memory fault names an address)
             for name, b in [("in", self.d_in), ("out", self.d_out)] + [("level%d" % (i + 1), b) for i, b in enumerate(self.d_levels)] + \
                     [("dI%d" % i, b) for i, b in enumerate(self.d_dI)] + [("abs%d" % i, b) for i, b in enumerate(self.d_abs)]:
-                sys.stderr.write("buffer %-7s 0x%x .. 0x%x (%d bytes, %s)\n" % (name, b.data_ptr(), b.data_ptr() + b.nbytes, b.nbytes, "torch" if b.t is not None else "mdc_device_alloc_fast"))
+                sys.stderr.write("buffer %-7s 0x%x .. 0x%x (%d bytes, %s)\n" % (name, b.data_ptr(), b.data_ptr() + b.nbytes, b.nbytes, "torch.empty"))
         self.flags = capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED | (capi.RECTIFY if rect else 0)
         self.tuned = None
         if tune and wl in ("fused", "seq50k") and args.kernel == "auto" and not (args.no_tune or args.fpb or args.tile_rows or args.tile_cols or args.nbuf):
@@ -580,6 +560,23 @@ class Workload:
             self.tuned = {"tile": [t.tile_w, t.tile_h], "frames_per_workgroup": t.frames_per_block, "candidates": t.candidates,
                           "ms_on_%d_frames" % min(B, 4096): round(t.ms, 4)}
             self.info = ctx.info()
+        if K > 1:  # (after the plan is chosen: the launch that is timed on the candidates is the one the bench times)
+            torch.cuda.synchronize()
+            bi, bo, ms_in, ms_out = ctx.tune_placement([b_.data_ptr() for b_ in cand_in], [b_.data_ptr() for b_ in cand_out], B, self.flags, stream)
+            self.d_in, self.d_out = cand_in[bi], cand_out[bo]
+            self.first_in, self.first_out = cand_in[0], cand_out[0]
+            self.placement = {"how": "mdc_tune_placement_device: the launch timed on %d candidate allocations each for frames and results" % K,
+                              "ms_per_result_candidate_with_frames_0": [round(x, 4) for x in ms_out], "picked_result": bo,
+                              "ms_per_frame_candidate_with_picked_result": [round(x, 4) for x in ms_in], "picked_frames": bi}
+            for k, b_ in enumerate(cand_in):
+                if k not in (0, bi):
+                    b_.free()
+            for k, b_ in enumerate(cand_out):
+                if k not in (0, bo):
+                    b_.free()
+            if bi == 0 and bo == 0:
+                self.first_in = self.first_out = None  # the first allocations won: nothing to time beside
+            torch.cuda.empty_cache()
         self.kernel_name = ctx.describe_launch(self.flags, self.levels if wl in ("pyramid", "dso") else 0)
         if wl == "dso":
             self.kernel_name += " + gradients_levels_kernel"
@@ -674,13 +671,13 @@ class Workload:
         if self.first_in is None and self.first_out is None:
             return None
         keep = (self.d_in, self.d_out)
-        self.ctx.synth_frames(self.first_in.data_ptr(), 0, self.B, self.npix_in, synth.SEED, self.stream)
         self.d_in, self.d_out = self.first_in, self.first_out
         self.preroll()
         t = self.timed(steps, warmup)
         self.d_in, self.d_out = keep
-        self.first_in.free()
-        self.first_out.free()
+        for b_ in (self.first_in, self.first_out):
+            if b_ is not keep[0] and b_ is not keep[1]:
+                b_.free()
         self.first_in = self.first_out = None
         torch.cuda.empty_cache()
         return t["kstat"][0]
@@ -858,8 +855,8 @@ def main():
     first_ms = H.timed_on_first_allocation(args.steps, args.warmup) if D.world == 1 else None
     if D.rank == 0:
         head["roofline"]["placement"] = {
-            "buffers": "from mdc_device_alloc_fast (config.placement): a stream's rate depends on the allocation it runs on -- 5.3 to 6.9 TB/s for "
-                       "a linear write (profiles/r05_experiments/05_*, 06_*)",
+            "buffers": "chosen by mdc_tune_placement_device (config.placement): the time of one launch depends on the allocations it runs on, "
+                       "1.48 to 1.61 ms in one process (profiles/r05_experiments/05_*, 08_*)",
             "kernel_ms_on_first_allocation": round(first_ms, 4) if first_ms else None,
             "frac_on_first_allocation": round(H.frac_of(first_ms), 4) if first_ms else None}
     devices = D.devices() if D.active else [{"rank": 0, "device": D.gpu}]

@@ -293,18 +293,17 @@ MDC_API int mdc_process_jpeg_frames_host_to_device(mdc_ctx* ctx, const void* con
 MDC_API int mdc_process_jpeg_streams_host_to_device(mdc_ctx* ctx, const void* const* streams, const int64_t* stream_bytes, int64_t nframes,
                                                     unsigned flags, const mdc_device_outputs* out, const int64_t* frame_index, int* status);
 MDC_API int mdc_device_alloc(mdc_ctx* ctx, size_t bytes, void** d_ptr); /* device memory on the context's GPU (hipMalloc) */
-/* PLACEMENT-AWARE allocation.  On MI355X the rate a kernel reaches on a buffer is a property of the ALLOCATION (of the physical pages
- * behind it), not only of the kernel: a linear stream of nontemporal stores runs at 6.4-6.9 TB/s into some hipMalloc'ed ranges and at
- * 5.3-5.6 TB/s into others of the same size in the same process (24 % apart; reads: a few per cent) -- and this path's kernels, which
- * write two thirds of their bytes, follow: 1.48 vs 1.61 ms for the same launch (profiles/r05_experiments/05_*, 06_*).
- * mdc_device_alloc_fast allocates up to `candidates` ranges of `bytes`, times a linear pass over each (mdc_stream_rate_device: writes
- * for MDC_PLACE_WRITE -- output buffers --, reads for MDC_PLACE_READ -- input frames), keeps the fastest and frees the others; *tbps
- * (optional) = the winner's rate.  Buffers below 256 MiB (a probe would measure the Infinity Cache) and candidates <= 1 are plain
- * allocations.  Blocking, ~1 ms per candidate and 5 GB.  The contents of the returned range are unspecified.
- * mdc_stream_rate_device: the probe alone on a caller's own device range (any allocator's): MDC_PLACE_WRITE OVERWRITES it. */
-enum { MDC_PLACE_WRITE = 0, MDC_PLACE_READ = 1 };
-MDC_API int mdc_device_alloc_fast(mdc_ctx* ctx, size_t bytes, int kind, int candidates, void** d_ptr, double* tbps);
-MDC_API int mdc_stream_rate_device(mdc_ctx* ctx, void* d_ptr, size_t bytes, int kind, void* stream, double* tbps);
+/* BUFFER PLACEMENT by measurement.  On MI355X the time of one and the same launch depends on the ALLOCATIONS it runs on -- on the
+ * physical pages behind the caller's frame and result buffers: 1.48 to 1.61 ms for the headline launch (4096 frames) between pairs of
+ * hipMalloc'ed buffers of one process on one device, stable for the life of the buffers, and not predicted by a linear write or read pass
+ * over them (profiles/r05_experiments/05_*, 06_*, 08_*).  A caller that allocates its frame / result buffers once (a sequence, a ring)
+ * can allocate a few candidates and let the context time the real pass on them, as mdc_tune_device does for tile shapes:
+ * mdc_tune_placement_device runs the fused pass of `flags` over nframes frames on (d_in[0], d_out[k]) for every output candidate, then on
+ * (d_in[k], d_out[best]) for every input candidate (2 untimed + 5 timed launches each, median), and returns the fastest of each;
+ * ms_in / ms_out (optional, n_in / n_out floats) = the medians.  Every input candidate must hold the same frames.  The caller frees the
+ * losers.  Blocking.  The outputs' contents afterwards: results of the pass (every candidate was written). */
+MDC_API int mdc_tune_placement_device(mdc_ctx* ctx, const uint8_t* const* d_in, int n_in, float* const* d_out, int n_out, int64_t nframes,
+                                      unsigned flags, void* stream, int* best_in, int* best_out, float* ms_in, float* ms_out);
 MDC_API void mdc_device_free(mdc_ctx* ctx, void* d_ptr);
 MDC_API int mdc_copy_to_host(mdc_ctx* ctx, void* dst, const void* d_src, size_t bytes); /* blocking device -> host copy */
 

@@ -24,14 +24,13 @@ OPT_PREFETCH_STREAMS = 13
 OPT_ZERO_COPY = 14
 OPT_TAIL_TAPER = 15
 ORDER_BANDS, ORDER_ROWS, ORDER_IDENTITY, ORDER_BLOCKS2D = 0, 1, 2, 3
-PLACE_WRITE, PLACE_READ = 0, 1
 OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/mdc_hip.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = [
     "mdc_create", "mdc_destroy", "mdc_device_count", "mdc_device_pci_bus_id", "mdc_last_error", "mdc_build_flags", "mdc_code_id", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
     "mdc_set_remap", "mdc_unmap_host", "mdc_undistort_host_f32", "mdc_undistort_host_u8", "mdc_process_host",
-    "mdc_process_frames_host_to_device", "mdc_process_jpeg_frames_host_to_device", "mdc_process_jpeg_streams_host_to_device", "mdc_device_alloc", "mdc_device_alloc_fast", "mdc_stream_rate_device", "mdc_device_free", "mdc_copy_to_host",
+    "mdc_process_frames_host_to_device", "mdc_process_jpeg_frames_host_to_device", "mdc_process_jpeg_streams_host_to_device", "mdc_device_alloc", "mdc_tune_placement_device", "mdc_device_free", "mdc_copy_to_host",
     "mdc_host_alloc", "mdc_host_free", "mdc_process_frames_host", "mdc_process_jpeg_frames_host", "mdc_jpeg_idct_batch_device", "mdc_process_jpeg_streams_host", "mdc_jpeg_huffman_batch_device",
     "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
     "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device",
@@ -83,37 +82,6 @@ class DeviceOutputs(C.Structure):
         for i, p in enumerate(abs2):
             o.abs_squared_grad[i] = p
         return o
-
-
-class DeviceBuffer:
-    """Device memory from mdc_device_alloc_fast (include/mdc_hip.h): the fastest of `candidates` ranges for a linear write (outputs) or read
-    (input frames) pass.  data_ptr() for the *_device entry points, read() for a copy back."""
-
-    def __init__(self, ctx, nbytes, kind=0, candidates=8):
-        self._ctx, self.nbytes = ctx, int(nbytes)
-        p, r = C.c_void_p(), C.c_double(0)
-        ctx._chk(ctx._L.mdc_device_alloc_fast(ctx._h, self.nbytes, kind, candidates, C.byref(p), C.byref(r)))
-        self._p, self.tbps = p.value, r.value
-
-    def data_ptr(self):
-        return self._p
-
-    def read(self, offset_bytes, count, dtype):
-        out = np.empty(count, dtype)
-        assert offset_bytes + out.nbytes <= self.nbytes
-        self._ctx._chk(self._ctx._L.mdc_copy_to_host(self._ctx._h, out.ctypes.data_as(C.c_void_p), self._p + offset_bytes, out.nbytes))
-        return out
-
-    def free(self):
-        if getattr(self, "_p", None):
-            self._ctx._L.mdc_device_free(self._ctx._h, C.c_void_p(self._p))
-            self._p = None
-
-    def __del__(self):
-        try:
-            self.free()
-        except Exception:  # interpreter shutdown
-            pass
 
 
 class TuneResult(C.Structure):
@@ -207,8 +175,8 @@ def hip_lib():
             L.mdc_process_jpeg_streams_host_to_device.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_int64), _i64, C.c_uint, C.POINTER(DeviceOutputs),
                                                                   C.POINTER(C.c_int64), C.POINTER(C.c_int)]
             L.mdc_device_alloc.argtypes = [_vp, _sz, C.POINTER(_vp)]
-            L.mdc_device_alloc_fast.argtypes = [_vp, _sz, _i, _i, C.POINTER(_vp), C.POINTER(C.c_double)]
-            L.mdc_stream_rate_device.argtypes = [_vp, _vp, _sz, _i, _vp, C.POINTER(C.c_double)]
+            L.mdc_tune_placement_device.argtypes = [_vp, C.POINTER(_vp), _i, C.POINTER(_vp), _i, _i64, C.c_uint, _vp, C.POINTER(_i), C.POINTER(_i),
+                                                    C.POINTER(C.c_float), C.POINTER(C.c_float)]
             L.mdc_device_free.argtypes = [_vp, _vp]
             L.mdc_device_free.restype = None
             L.mdc_copy_to_host.argtypes = [_vp, _vp, _vp, _sz]
@@ -573,11 +541,15 @@ class Context:
     def synchronize(self):
         self._chk(self._L.mdc_synchronize(self._h))
 
-    def stream_rate(self, d_ptr, nbytes, kind, stream=0):
-        """TB/s of a linear pass over a device range (kind PLACE_WRITE overwrites it, PLACE_READ reads it): include/mdc_hip.h."""
-        r = C.c_double(0)
-        self._chk(self._L.mdc_stream_rate_device(self._h, d_ptr, nbytes, kind, stream if stream else None, C.byref(r)))
-        return r.value
+    def tune_placement(self, d_ins, d_outs, nframes, flags, stream=0):
+        """Which of the candidate input / output buffers (device addresses) does the fused pass run fastest on?  include/mdc_hip.h:
+        mdc_tune_placement_device.  -> (best input index, best output index, ms per input candidate, ms per output candidate)"""
+        ni, no = len(d_ins), len(d_outs)
+        a, b = (_vp * ni)(*d_ins), (_vp * no)(*d_outs)
+        bi, bo = _i(0), _i(0)
+        mi, mo = (C.c_float * ni)(), (C.c_float * no)()
+        self._chk(self._L.mdc_tune_placement_device(self._h, a, ni, b, no, nframes, flags, stream if stream else None, C.byref(bi), C.byref(bo), mi, mo))
+        return bi.value, bo.value, [float(x) for x in mi], [float(x) for x in mo]
 
     def pci_bus_id(self):
         buf = C.create_string_buffer(32)

@@ -493,104 +493,6 @@ int mdc_device_alloc(mdc_ctx* c, size_t bytes, void** d_ptr) try {
   return MDC_OK;
 } MDC_CATCH(c)
 
-namespace {
-// linear passes for mdc_stream_rate_device: nontemporal dword stores / 16-byte loads, grid-stride, 65536 workgroups of 256
-__global__ __launch_bounds__(256) void stream_write_kernel(float* __restrict__ p, unsigned long long n) {
-  const unsigned long long T = (unsigned long long)gridDim.x * 256;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += T) __builtin_nontemporal_store(0.f, p + i);
-}
-typedef uint32_t probe_u32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void stream_read_kernel(const probe_u32x4* __restrict__ p, unsigned long long n, uint32_t* __restrict__ sink) {
-  const unsigned long long T = (unsigned long long)gridDim.x * 256;
-  uint32_t x = 0;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += T) {
-    const probe_u32x4 v = __builtin_nontemporal_load(p + i);
-    x ^= v.x ^ v.y ^ v.z ^ v.w;
-  }
-  if (x == 0x9e3779b9u && sink) *sink = x;  // keeps the loads alive; practically never taken
-}
-
-// median of three timed passes (after one untimed) over [p, p + bytes); lock and device guard held by the caller
-int stream_rate(mdc_ctx* c, void* p, size_t bytes, int kind, hipStream_t s, double* tbps) {
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  MDC_HIP(c, hipEventCreate(&e0));
-  if (hipEventCreate(&e1) != hipSuccess) {
-    (void)hipEventDestroy(e0);
-    return fail(c, MDC_ERR_HIP, "hipEventCreate failed");
-  }
-  float ms[3] = {0, 0, 0};
-  hipError_t e = hipSuccess;
-  for (int k = 0; k < 4 && e == hipSuccess; k++) {
-    if (k) e = hipEventRecord(e0, s);
-    if (e == hipSuccess) {
-      if (kind == MDC_PLACE_READ) stream_read_kernel<<<65536, 256, 0, s>>>(static_cast<const probe_u32x4*>(p), bytes / 16, c->d_vcal_max);
-      else stream_write_kernel<<<65536, 256, 0, s>>>(static_cast<float*>(p), bytes / 4);
-      e = hipGetLastError();
-    }
-    if (k && e == hipSuccess) e = hipEventRecord(e1, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (k && e == hipSuccess) e = hipEventElapsedTime(&ms[k - 1], e0, e1);
-  }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  MDC_HIP(c, e);
-  std::sort(ms, ms + 3);
-  *tbps = ms[1] > 0 ? (double)bytes / (ms[1] * 1e-3) / 1e12 : 0.0;
-  return MDC_OK;
-}
-}  // namespace
-
-int mdc_stream_rate_device(mdc_ctx* c, void* d_ptr, size_t bytes, int kind, void* stream, double* tbps) try {
-  if (!c) return MDC_ERR_ARG;
-  if (!d_ptr || !tbps || bytes < 16 || (kind != MDC_PLACE_WRITE && kind != MDC_PLACE_READ) || (reinterpret_cast<uintptr_t>(d_ptr) & 15) != 0)
-    return fail(c, MDC_ERR_ARG, "mdc_stream_rate_device: bad argument (a 16-byte aligned device range expected)");
-  ReadLock lk(c->mu);
-  DeviceGuard dg(c->device);
-  return stream_rate(c, d_ptr, bytes, kind, (hipStream_t)stream, tbps);
-} MDC_CATCH(c)
-
-int mdc_device_alloc_fast(mdc_ctx* c, size_t bytes, int kind, int candidates, void** d_ptr, double* tbps) try {
-  if (!c) return MDC_ERR_ARG;
-  if (!d_ptr || (kind != MDC_PLACE_WRITE && kind != MDC_PLACE_READ)) return fail(c, MDC_ERR_ARG, "mdc_device_alloc_fast: bad argument");
-  *d_ptr = nullptr;
-  if (tbps) *tbps = 0.0;
-  ReadLock lk(c->mu);
-  DeviceGuard dg(c->device);
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-  // candidates are all held at once (a freed range would come straight back): never more than half of the free memory
-  int n = std::max(1, std::min(candidates, 16));
-  if (bytes > 0) n = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, free_b / 2 / bytes));
-  if (bytes < ((size_t)256 << 20)) n = 1;  // a pass over less than the Infinity Cache says nothing about the memory behind it
-  std::vector<void*> cand;
-  std::vector<double> rate;
-  int rc = MDC_OK;
-  for (int k = 0; k < n; k++) {
-    // (candidates are plain hipMalloc ranges.  Ranges made with the virtual-memory-management calls -- hipMemCreate + hipMemMap -- were
-    // the fastest memory of all on an otherwise empty device, 6.8-6.9 TB/s for a linear write, but candidates of that kind that are mapped,
-    // probed, unmapped and released in a row ended in intermittent GPU memory faults: profiles/r05_experiments/07_*; not used)
-    void* p = nullptr;
-    if (hipMalloc(&p, std::max<size_t>(bytes, 1)) != hipSuccess) {
-      (void)hipGetLastError();
-      break;  // out of memory for another candidate: the ones we have compete
-    }
-    cand.push_back(p);
-    double r = 0.0;
-    if (n > 1 && (rc = stream_rate(c, p, bytes / 16 * 16, kind, nullptr, &r)) != MDC_OK) break;
-    rate.push_back(r);
-  }
-  size_t best = 0;
-  for (size_t k = 1; k < rate.size(); k++)
-    if (rate[k] > rate[best]) best = k;
-  for (size_t k = 0; k < cand.size(); k++)
-    if (rc != MDC_OK || k != best) (void)hipFree(cand[k]);
-  if (rc != MDC_OK) return rc;
-  if (cand.empty()) return fail(c, MDC_ERR_HIP, "mdc_device_alloc_fast: out of device memory for %zu bytes", bytes);
-  *d_ptr = cand[best];
-  if (tbps && !rate.empty()) *tbps = rate[best];
-  return MDC_OK;
-} MDC_CATCH(c)
-
 void mdc_device_free(mdc_ctx* c, void* d_ptr) {
   if (!c || !d_ptr) return;
   DeviceGuard dg(c->device);

@@ -969,54 +969,31 @@ def test_error_codes(setups):
         c.set_remap(np.array([5.0], np.float32), np.array([500.0], np.float32), 16, 16, 1, 1)
 
 
-def test_placement_aware_allocation(setups, torch_cuda):
-    """mdc_stream_rate_device / mdc_device_alloc_fast (include/mdc_hip.h): the linear-pass probe gives a plausible rate for writes and
-    reads on a caller's range, the allocator returns a usable range that is at least as fast as the slowest of its candidates, small
-    requests are plain allocations, bad arguments are refused."""
+def test_tune_placement_picks_among_candidate_buffers(setups, oracle, torch_cuda):
+    """mdc_tune_placement_device (include/mdc_hip.h): the fused pass timed on candidate frame / result buffers; the indices returned are
+    valid, every candidate has a time, every result candidate holds the pass's results afterwards (bit-exact), bad arguments are refused."""
     import ctypes
 
-    from mono_dataset_code_amd import capi
+    from mono_dataset_code_amd import capi, synth
 
     torch = torch_cuda
-    s = setups("small_explicit")
-    L = capi.hip_lib()
-    n = 1 << 30
-    t = torch.empty(n, dtype=torch.uint8, device="cuda")
-    w = s.ctx.stream_rate(t.data_ptr(), n, capi.PLACE_WRITE)
-    r = s.ctx.stream_rate(t.data_ptr(), n, capi.PLACE_READ)
-    assert 1.0 < w < 9.0 and 1.0 < r < 9.0, (w, r)  # TB/s on an MI355X (8 TB/s peak; a 1-GB pass is partly served by the Infinity Cache)
-    assert int(t[:4096].sum()) == 0  # the write pass stores zeros over the whole range
+    s = setups("full_1280_to_640")
+    n, npix, nout = 48, s.W * s.H, s.w * s.h
+    st = torch.cuda.current_stream().cuda_stream
+    flags = capi.RECTIFY | capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED
+    ins = [torch.empty(n * npix, dtype=torch.uint8, device="cuda") for _ in range(3)]
+    outs = [torch.full((n * nout,), -5.0, dtype=torch.float32, device="cuda") for _ in range(4)]
+    for t in ins:
+        s.ctx.synth_frames(t.data_ptr(), 11, n, npix, synth.SEED, st)
+    bi, bo, ms_in, ms_out = s.ctx.tune_placement([t.data_ptr() for t in ins], [t.data_ptr() for t in outs], n, flags, st)
+    assert 0 <= bi < 3 and 0 <= bo < 4 and len(ms_in) == 3 and len(ms_out) == 4
+    assert all(0 < x < 50 for x in ms_in + ms_out) and ms_out[bo] == min(ms_out) and ms_in[bi] == min(ms_in)
+    frames = ins[0].view(n, npix)[:2].cpu().numpy()
+    for t in outs:  # every result candidate was written by the pass
+        got = t.view(n, nout)[:2].cpu().numpy()
+        for f in range(2):
+            assert bits_equal(got[f], s.want(oracle, frames[f], 1, 1, 1, 1))
     with pytest.raises(capi.MdcError):
-        s.ctx.stream_rate(t.data_ptr() + 4, n - 16, capi.PLACE_READ)  # unaligned
-    p, rate = ctypes.c_void_p(), ctypes.c_double(0)
-    assert L.mdc_device_alloc_fast(s.ctx.handle, 2 << 30, capi.PLACE_WRITE, 4, ctypes.byref(p), ctypes.byref(rate)) == 0
-    assert p.value and 1.0 < rate.value < 9.0
-    assert abs(s.ctx.stream_rate(p.value, 2 << 30, capi.PLACE_WRITE) / rate.value - 1) < 0.2  # the rate is the range's own, again
-    L.mdc_device_free(s.ctx.handle, p)
-    assert L.mdc_device_alloc_fast(s.ctx.handle, 1 << 20, capi.PLACE_READ, 4, ctypes.byref(p), ctypes.byref(rate)) == 0  # small: plain, no probe
-    assert p.value and rate.value == 0.0
-    L.mdc_device_free(s.ctx.handle, p)
-    assert L.mdc_device_alloc_fast(s.ctx.handle, 1 << 20, 7, 4, ctypes.byref(p), None) != 0
-
-
-def test_placement_aware_allocation_soak(setups, torch_cuda):
-    """mdc_device_alloc_fast over and over with sizes that make one-piece and many-piece virtual-memory-management candidates and plain
-    ones, every returned range written and read over its whole length at once: no GPU memory fault, no leak (free memory comes back)."""
-    import ctypes
-
-    from mono_dataset_code_amd import capi
-
-    torch = torch_cuda
-    s = setups("small_explicit")
-    L = capi.hip_lib()
-    free0 = torch.cuda.mem_get_info()[0]
-    sizes = [640 << 20, (2560 << 20), 300 << 20, (1 << 30) + (2 << 20), 7 * (1 << 30) + 4096 * 3, 503316480]
-    for it in range(18):
-        nb = sizes[it % len(sizes)]
-        p, rate = ctypes.c_void_p(), ctypes.c_double(0)
-        assert L.mdc_device_alloc_fast(s.ctx.handle, nb, it & 1, 4, ctypes.byref(p), ctypes.byref(rate)) == 0, s.ctx.last_error()
-        assert s.ctx.stream_rate(p.value, nb // 16 * 16, capi.PLACE_WRITE) > 0.5
-        assert s.ctx.stream_rate(p.value, nb // 16 * 16, capi.PLACE_READ) > 0.5
-        L.mdc_device_free(s.ctx.handle, p)
-    torch.cuda.synchronize()
-    assert torch.cuda.mem_get_info()[0] > free0 - (1 << 30)
+        s.ctx.tune_placement([], [outs[0].data_ptr()], n, flags, st)
+    with pytest.raises(capi.MdcError):
+        s.ctx.tune_placement([ins[0].data_ptr()], [0], n, flags, st)
