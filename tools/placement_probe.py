@@ -44,13 +44,13 @@ def main():
     rb, wb = int(info.src_bbox_bytes) * FRAMES // 16 * 16, OUT_BYTES
 
     places = []  # (name, in_ptr, out_ptr, keepalive)
-    for k in range(3):
+    for k in range(6):
         a = torch.empty(IN_BYTES, dtype=torch.uint8, device=dev)
         b = torch.empty(OUT_BYTES, dtype=torch.uint8, device=dev)
         places.append(("fresh pair %d" % k, a.data_ptr(), b.data_ptr(), (a, b)))
     arena = torch.empty(24 * GiB, dtype=torch.uint8, device=dev)
     base = (arena.data_ptr() + (1 << 21) - 1) >> 21 << 21  # 2-MiB aligned
-    for delta in (0, 4096, (1 << 20) + 4096, 1 << 30):
+    for delta in (0, (1 << 20) + 4096):
         places.append(("arena: in +0, out +8 GiB + %d" % delta, base, base + 8 * GiB + delta, None))
     huge_in = torch.empty(50000 * NPI, dtype=torch.uint8, device=dev)
     huge_out = torch.empty(50000 * NPO * 4, dtype=torch.uint8, device=dev)
@@ -69,6 +69,23 @@ def main():
         assert B.mdcb_chunked_alloc(0, chunk, n, 1, C.byref(p)) == 0
         return p.value
 
+    # physically contiguous ranges (hipExtMallocWithFlags(hipDeviceMallocContiguous)): the largest page-table fragments there are
+    path = [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][0]
+    hip = C.CDLL(path)
+    hip.hipExtMallocWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+
+    def contiguous(nbytes):
+        p = C.c_void_p()
+        rc = hip.hipExtMallocWithFlags(C.byref(p), nbytes, 0x4)
+        return p.value if rc == 0 else None
+
+    for k in range(int(os.environ.get("PLACE_CONTIG", "4"))):
+        ci, co = contiguous(IN_BYTES), contiguous(OUT_BYTES)
+        if ci and co:
+            places.append(("contiguous pair %d" % k, ci, co, None))
+            if k == 0:
+                places.append(("contiguous input 0, fresh output 0", ci, places[0][2], None))
+                places.append(("fresh input 0, contiguous output 0", places[0][1], co, None))
     v_in, v_out = vmm(IN_BYTES, 256 << 20), vmm(OUT_BYTES, 256 << 20)
     v_in1, v_out1 = vmm(IN_BYTES, 1 << 30), vmm(OUT_BYTES, 1 << 30)
     places.append(("VMM output (256-MiB chunks), fresh input 0", places[0][1], v_out, None))
