@@ -82,7 +82,7 @@ def parse():
     p.add_argument("--preroll-window-s", type=float, default=0.05)
     p.add_argument("--preroll-windows", type=int, default=5)
     p.add_argument("--preroll-tol", type=float, default=0.01)
-    p.add_argument("--placement-candidates", type=int, default=8,
+    p.add_argument("--placement-candidates", type=int, default=6,
                    help="the headline's frame and result buffers are chosen among this many allocations each by timing the launch itself on them "
                         "(mdc_tune_placement_device): on MI355X the time of one launch depends on the allocations it runs on by up to 9 %% "
                         "(profiles/r05_experiments/05_*, 08_*); 1 = take the first allocations as they come")
@@ -562,12 +562,12 @@ class Workload:
             self.info = ctx.info()
         if K > 1:  # (after the plan is chosen: the launch that is timed on the candidates is the one the bench times)
             torch.cuda.synchronize()
-            bi, bo, ms_in, ms_out = ctx.tune_placement([b_.data_ptr() for b_ in cand_in], [b_.data_ptr() for b_ in cand_out], B, self.flags, stream)
+            bi, bo, ms = ctx.tune_placement([b_.data_ptr() for b_ in cand_in], [b_.data_ptr() for b_ in cand_out], B, self.flags, stream)
             self.d_in, self.d_out = cand_in[bi], cand_out[bo]
             self.first_in, self.first_out = cand_in[0], cand_out[0]
-            self.placement = {"how": "mdc_tune_placement_device: the launch timed on %d candidate allocations each for frames and results" % K,
-                              "ms_per_result_candidate_with_frames_0": [round(x, 4) for x in ms_out], "picked_result": bo,
-                              "ms_per_frame_candidate_with_picked_result": [round(x, 4) for x in ms_in], "picked_frames": bi}
+            self.placement = {"how": "mdc_tune_placement_device: the launch timed on every pair of %d candidate allocations for the frames and %d for the "
+                                     "results (allocated frames 0, results 0, frames 1, ...)" % (K, K),
+                              "ms_frames_i_results_j": [[round(x, 4) for x in row] for row in ms], "picked_frames": bi, "picked_results": bo}
             for k, b_ in enumerate(cand_in):
                 if k not in (0, bi):
                     b_.free()

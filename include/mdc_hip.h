@@ -294,16 +294,16 @@ MDC_API int mdc_process_jpeg_streams_host_to_device(mdc_ctx* ctx, const void* co
                                                     unsigned flags, const mdc_device_outputs* out, const int64_t* frame_index, int* status);
 MDC_API int mdc_device_alloc(mdc_ctx* ctx, size_t bytes, void** d_ptr); /* device memory on the context's GPU (hipMalloc) */
 /* BUFFER PLACEMENT by measurement.  On MI355X the time of one and the same launch depends on the ALLOCATIONS it runs on -- on the
- * physical pages behind the caller's frame and result buffers: 1.48 to 1.61 ms for the headline launch (4096 frames) between pairs of
- * hipMalloc'ed buffers of one process on one device, stable for the life of the buffers, and not predicted by a linear write or read pass
- * over them (profiles/r05_experiments/05_*, 06_*, 08_*).  A caller that allocates its frame / result buffers once (a sequence, a ring)
- * can allocate a few candidates and let the context time the real pass on them, as mdc_tune_device does for tile shapes:
- * mdc_tune_placement_device runs the fused pass of `flags` over nframes frames on (d_in[0], d_out[k]) for every output candidate, then on
- * (d_in[k], d_out[best]) for every input candidate (2 untimed + 5 timed launches each, median), and returns the fastest of each;
- * ms_in / ms_out (optional, n_in / n_out floats) = the medians.  Every input candidate must hold the same frames.  The caller frees the
- * losers.  Blocking.  The outputs' contents afterwards: results of the pass (every candidate was written). */
+ * physical pages behind the caller's frame and result buffers, and on the PAIR of them: 1.48 to 1.63 ms for the headline launch (4096
+ * frames) between pairs of hipMalloc'ed buffers of one process on one device, stable for the life of the buffers, not changed by offsets
+ * inside an allocation and not predicted by a linear write or read pass over them (profiles/r05_experiments/05_*, 06_*, 08_*, 09_*).
+ * A caller that allocates its frame / result buffers once (a sequence, a ring) can allocate a few candidates and let the context time the
+ * real pass on them, as mdc_tune_device does for tile shapes: mdc_tune_placement_device runs the fused pass of `flags` over nframes
+ * frames on every pair (d_in[i], d_out[j]) -- 2 untimed + 5 timed launches each, median -- and returns the fastest pair; ms (optional,
+ * n_in * n_out floats, ms[i * n_out + j]) = the medians.  n_in * n_out <= 256.  Every input candidate must hold the same frames.  The
+ * caller frees the losers.  Blocking, ~10 launches' time per pair.  Afterwards every output candidate holds the results of the pass. */
 MDC_API int mdc_tune_placement_device(mdc_ctx* ctx, const uint8_t* const* d_in, int n_in, float* const* d_out, int n_out, int64_t nframes,
-                                      unsigned flags, void* stream, int* best_in, int* best_out, float* ms_in, float* ms_out);
+                                      unsigned flags, void* stream, int* best_in, int* best_out, float* ms);
 MDC_API void mdc_device_free(mdc_ctx* ctx, void* d_ptr);
 MDC_API int mdc_copy_to_host(mdc_ctx* ctx, void* dst, const void* d_src, size_t bytes); /* blocking device -> host copy */
 

@@ -176,7 +176,7 @@ def hip_lib():
                                                                   C.POINTER(C.c_int64), C.POINTER(C.c_int)]
             L.mdc_device_alloc.argtypes = [_vp, _sz, C.POINTER(_vp)]
             L.mdc_tune_placement_device.argtypes = [_vp, C.POINTER(_vp), _i, C.POINTER(_vp), _i, _i64, C.c_uint, _vp, C.POINTER(_i), C.POINTER(_i),
-                                                    C.POINTER(C.c_float), C.POINTER(C.c_float)]
+                                                    C.POINTER(C.c_float)]
             L.mdc_device_free.argtypes = [_vp, _vp]
             L.mdc_device_free.restype = None
             L.mdc_copy_to_host.argtypes = [_vp, _vp, _vp, _sz]
@@ -542,14 +542,14 @@ class Context:
         self._chk(self._L.mdc_synchronize(self._h))
 
     def tune_placement(self, d_ins, d_outs, nframes, flags, stream=0):
-        """Which of the candidate input / output buffers (device addresses) does the fused pass run fastest on?  include/mdc_hip.h:
-        mdc_tune_placement_device.  -> (best input index, best output index, ms per input candidate, ms per output candidate)"""
+        """Which PAIR of the candidate input / output buffers (device addresses) does the fused pass run fastest on?  include/mdc_hip.h:
+        mdc_tune_placement_device.  -> (best input index, best output index, ms[i][j] for input i with output j)"""
         ni, no = len(d_ins), len(d_outs)
-        a, b = (_vp * ni)(*d_ins), (_vp * no)(*d_outs)
+        a, b = (_vp * max(ni, 1))(*d_ins), (_vp * max(no, 1))(*d_outs)
         bi, bo = _i(0), _i(0)
-        mi, mo = (C.c_float * ni)(), (C.c_float * no)()
-        self._chk(self._L.mdc_tune_placement_device(self._h, a, ni, b, no, nframes, flags, stream if stream else None, C.byref(bi), C.byref(bo), mi, mo))
-        return bi.value, bo.value, [float(x) for x in mi], [float(x) for x in mo]
+        ms = (C.c_float * max(ni * no, 1))()
+        self._chk(self._L.mdc_tune_placement_device(self._h, a, ni, b, no, nframes, flags, stream if stream else None, C.byref(bi), C.byref(bo), ms))
+        return bi.value, bo.value, [[float(ms[i * no + j]) for j in range(no)] for i in range(ni)]
 
     def pci_bus_id(self):
         buf = C.create_string_buffer(32)

@@ -1021,9 +1021,9 @@ int mdc_tune_device(mdc_ctx* c, const uint8_t* d_in, float* d_out, int64_t nfram
 
 // Which of the caller's candidate buffers does the pass run fastest on?  (include/mdc_hip.h)
 int mdc_tune_placement_device(mdc_ctx* c, const uint8_t* const* d_in, int n_in, float* const* d_out, int n_out, int64_t nframes, unsigned flags,
-                              void* stream, int* best_in, int* best_out, float* ms_in, float* ms_out) try {
+                              void* stream, int* best_in, int* best_out, float* ms_out) try {
   if (!c) return MDC_ERR_ARG;
-  if (!d_in || !d_out || n_in < 1 || n_out < 1 || nframes <= 0 || !best_in || !best_out)
+  if (!d_in || !d_out || n_in < 1 || n_out < 1 || (int64_t)n_in * n_out > 256 || nframes <= 0 || !best_in || !best_out)
     return fail(c, MDC_ERR_ARG, "mdc_tune_placement_device: bad argument");
   for (int k = 0; k < n_in; k++)
     if (!d_in[k]) return fail(c, MDC_ERR_ARG, "mdc_tune_placement_device: input candidate %d is NULL", k);
@@ -1038,40 +1038,27 @@ int mdc_tune_placement_device(mdc_ctx* c, const uint8_t* const* d_in, int n_in, 
     (void)hipEventDestroy(e0);
     return fail(c, MDC_ERR_HIP, "hipEventCreate failed");
   }
-  int rc = MDC_OK;
-  auto median_ms = [&](const uint8_t* in, float* out, float* result) {
-    float ms[5] = {0, 0, 0, 0, 0};
-    for (int k = 0; k < 7 && rc == MDC_OK; k++) {  // 2 warm-up launches, 5 timed
-      bool ok = k < 2 || hipEventRecord(e0, s) == hipSuccess;
-      if (ok) rc = enqueue_process(c, in, out, nframes, flags, s);
-      if (rc != MDC_OK) break;
-      if (k >= 2) ok = ok && hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms[k - 2], e0, e1) == hipSuccess;
-      if (!ok) rc = fail(c, MDC_ERR_HIP, "mdc_tune_placement_device: timing a launch failed");
-    }
-    std::sort(ms, ms + 5);
-    *result = ms[2];
-  };
-  int bo = 0, bi = 0;
+  int rc = MDC_OK, bi = 0, bo = 0;
   float best = 1e30f;
-  for (int k = 0; k < n_out && rc == MDC_OK; k++) {
-    float t = 0.f;
-    median_ms(d_in[0], d_out[k], &t);
-    if (ms_out) ms_out[k] = t;
-    if (rc == MDC_OK && t < best) {
-      best = t;
-      bo = k;
+  for (int i = 0; i < n_in && rc == MDC_OK; i++)
+    for (int j = 0; j < n_out && rc == MDC_OK; j++) {
+      float ms[5] = {0, 0, 0, 0, 0};
+      for (int k = 0; k < 7 && rc == MDC_OK; k++) {  // 2 warm-up launches, 5 timed
+        bool ok = k < 2 || hipEventRecord(e0, s) == hipSuccess;
+        if (ok) rc = enqueue_process(c, d_in[i], d_out[j], nframes, flags, s);
+        if (rc != MDC_OK) break;
+        if (k >= 2) ok = ok && hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms[k - 2], e0, e1) == hipSuccess;
+        if (!ok) rc = fail(c, MDC_ERR_HIP, "mdc_tune_placement_device: timing a launch failed");
+      }
+      if (rc != MDC_OK) break;
+      std::sort(ms, ms + 5);
+      if (ms_out) ms_out[(size_t)i * n_out + j] = ms[2];
+      if (ms[2] < best) {
+        best = ms[2];
+        bi = i;
+        bo = j;
+      }
     }
-  }
-  best = 1e30f;
-  for (int k = 0; k < n_in && rc == MDC_OK; k++) {
-    float t = 0.f;
-    median_ms(d_in[k], d_out[bo], &t);
-    if (ms_in) ms_in[k] = t;
-    if (rc == MDC_OK && t < best) {
-      best = t;
-      bi = k;
-    }
-  }
   (void)hipStreamSynchronize(s);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);

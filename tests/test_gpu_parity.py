@@ -985,9 +985,10 @@ def test_tune_placement_picks_among_candidate_buffers(setups, oracle, torch_cuda
     outs = [torch.full((n * nout,), -5.0, dtype=torch.float32, device="cuda") for _ in range(4)]
     for t in ins:
         s.ctx.synth_frames(t.data_ptr(), 11, n, npix, synth.SEED, st)
-    bi, bo, ms_in, ms_out = s.ctx.tune_placement([t.data_ptr() for t in ins], [t.data_ptr() for t in outs], n, flags, st)
-    assert 0 <= bi < 3 and 0 <= bo < 4 and len(ms_in) == 3 and len(ms_out) == 4
-    assert all(0 < x < 50 for x in ms_in + ms_out) and ms_out[bo] == min(ms_out) and ms_in[bi] == min(ms_in)
+    bi, bo, ms = s.ctx.tune_placement([t.data_ptr() for t in ins], [t.data_ptr() for t in outs], n, flags, st)
+    assert 0 <= bi < 3 and 0 <= bo < 4 and len(ms) == 3 and all(len(r) == 4 for r in ms)
+    flat = [x for r in ms for x in r]
+    assert all(0 < x < 50 for x in flat) and ms[bi][bo] == min(flat)
     frames = ins[0].view(n, npix)[:2].cpu().numpy()
     for t in outs:  # every result candidate was written by the pass
         got = t.view(n, nout)[:2].cpu().numpy()
