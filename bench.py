@@ -521,7 +521,7 @@ class Workload:
         # Buffers.  The headline's: K candidate allocations for the frames and K for the results, the launch itself timed on them
         # (mdc_tune_placement_device) further down, once the frames exist; the first allocations of the process -- what a caller gets who
         # takes them as they come -- are candidate 0 of each and are timed beside the chosen ones (timed_on_first_allocation).
-        K = max(1, args.placement_candidates) if (keep_first and wl == "fused" and world == 1) else 1
+        K = max(1, args.placement_candidates) if wl in ("fused", "unmap", "seq50k") else 1  # (the pass mdc_tune_placement_device times: no pyramid / gradient outputs)
         in_bytes, out_bytes = B * self.npix_in, B * self.npix_out * 4
         free_b = torch.cuda.mem_get_info(dev)[0]
         K = max(1, min(K, int(free_b * 0.45 // (in_bytes + out_bytes))))
@@ -532,12 +532,12 @@ class Workload:
         self.d_in, self.d_out = cand_in[0], cand_out[0]
         self.first_in = self.first_out = None
         self.placement = {"how": "first allocations, as they come"}
-        if world == 1:
-            for b_ in cand_in:
+        for b_ in cand_in:
+            if world == 1:
                 ctx.synth_frames(b_.data_ptr(), 0, B, self.npix_in, synth.SEED, stream)
-        else:
-            for i, f in enumerate(mine):  # local frame i = global frame rank + i * world
-                ctx.synth_frames(self.d_in.data_ptr() + i * self.npix_in, int(f), 1, self.npix_in, synth.SEED, stream)
+            else:
+                for i, f in enumerate(mine):  # local frame i = global frame rank + i * world
+                    ctx.synth_frames(b_.data_ptr() + i * self.npix_in, int(f), 1, self.npix_in, synth.SEED, stream)
         self.levels, self.d_levels = 4, []
         self.d_dI, self.d_abs = [], []
         def out_floats(count, tag):
@@ -564,15 +564,15 @@ class Workload:
             torch.cuda.synchronize()
             bi, bo, ms = ctx.tune_placement([b_.data_ptr() for b_ in cand_in], [b_.data_ptr() for b_ in cand_out], B, self.flags, stream)
             self.d_in, self.d_out = cand_in[bi], cand_out[bo]
-            self.first_in, self.first_out = cand_in[0], cand_out[0]
+            self.first_in, self.first_out = (cand_in[0], cand_out[0]) if (keep_first and world == 1) else (None, None)
             self.placement = {"how": "mdc_tune_placement_device: the launch timed on every pair of %d candidate allocations for the frames and %d for the "
                                      "results (allocated frames 0, results 0, frames 1, ...)" % (K, K),
                               "ms_frames_i_results_j": [[round(x, 4) for x in row] for row in ms], "picked_frames": bi, "picked_results": bo}
             for k, b_ in enumerate(cand_in):
-                if k not in (0, bi):
+                if k != bi and b_ is not self.first_in:
                     b_.free()
             for k, b_ in enumerate(cand_out):
-                if k not in (0, bo):
+                if k != bo and b_ is not self.first_out:
                     b_.free()
             if bi == 0 and bo == 0:
                 self.first_in = self.first_out = None  # the first allocations won: nothing to time beside
@@ -881,7 +881,7 @@ def main():
                                  "algorithmic_bytes_per_frame": rf["algorithmic_bytes_per_frame"],
                                  "traffic": rf["traffic"], "traffic_source": rf["traffic_source"],
                                  "launches_per_step": rf.get("launches_per_step"), "per_rank_frac": rf.get("per_rank_frac"),
-                                 "plan": r["config"]["plan"], "preroll": r["config"]["preroll"], "parity": r["parity"]}
+                                 "plan": r["config"]["plan"], "placement": r["config"]["placement"], "preroll": r["config"]["preroll"], "parity": r["parity"]}
     # ---- the headline AGAIN: same context, same buffers, same plan, after everything else ran ------------------------------
     # (the same launch was timed 8 % apart within one process; both figures are printed, they must agree)
     again = None
