@@ -169,6 +169,11 @@ def gpu_clock_snapshot(index=0):
                     out[name + "_mhz"] = int(line.split(":")[1].strip().lower().split("mhz")[0])
         except (OSError, ValueError, IndexError):
             pass
+    for name in ("current_memory_partition", "current_compute_partition", "mem_info_vram_total", "mem_info_vram_vendor"):  # NPS1 / SPX ...: how HBM is interleaved
+        try:
+            out[name.replace("current_", "").replace("mem_info_", "")] = open(os.path.join(d, name)).read().strip()
+        except OSError:
+            pass
     for name in ("gpu_busy_percent", "mem_busy_percent"):
         try:
             out[name] = int(open(os.path.join(d, name)).read())
