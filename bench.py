@@ -86,6 +86,7 @@ def parse():
                    help="the headline's frame and result buffers are chosen among this many allocations each by timing the launch itself on them "
                         "(mdc_tune_placement_device): on MI355X the time of one launch depends on the allocations it runs on by up to 9 %% "
                         "(profiles/r05_experiments/05_*, 08_*); 1 = take the first allocations as they come")
+    p.add_argument("--placement-spread-gb", type=float, default=28.0, help="spacer allocation between successive candidate pairs (given back before timing)")
     p.add_argument("--no-again", action="store_true", help="do not time the headline a second time after the secondary workloads")
     p.add_argument("--parity-frames", type=int, default=16, help="frames of the benchmarked launch compared with the oracle")
     p.add_argument("--frames", type=int, default=0,
@@ -530,10 +531,24 @@ class Workload:
         in_bytes, out_bytes = B * self.npix_in, B * self.npix_out * 4
         free_b = torch.cuda.mem_get_info(dev)[0]
         K = max(1, min(K, int(free_b * 0.45 // (in_bytes + out_bytes))))
-        cand_in, cand_out = [], []
-        for _ in range(K):  # frames, results, frames, results, ...: candidates 0 are the first two allocations of the process
+        cand_in, cand_out, spacers = [], [], []
+        # candidates SPREAD over the device's memory: whether a pair is fast or slow goes with where its two buffers lie (two classes of
+        # memory, a pair from the same class is slow: profiles/r05_experiments/10_*), and neighbouring allocations are mostly of one class
+        # (on some GPUs the first 60 GB are) -- a spacer allocation between successive candidate pairs, given back before anything is timed
+        spacer_bytes = 0
+        if K > 1:
+            room = free_b * 0.85 - K * (in_bytes + out_bytes)
+            spacer_bytes = int(max(0, min(args.placement_spread_gb * 1e9, room / max(K - 1, 1)))) // (1 << 21) * (1 << 21)
+        for k in range(K):  # frames, results, (spacer,) frames, results, ...: candidates 0 are the first two allocations of the process
             cand_in.append(Buf(in_bytes, dev))
             cand_out.append(Buf(out_bytes, dev))
+            if spacer_bytes and k + 1 < K:
+                try:
+                    spacers.append(torch.empty(spacer_bytes, dtype=torch.uint8, device=dev))
+                except RuntimeError:
+                    spacer_bytes = 0
+        del spacers
+        torch.cuda.empty_cache()
         self.d_in, self.d_out = cand_in[0], cand_out[0]
         self.first_in = self.first_out = None
         self.placement = {"how": "first allocations, as they come"}
@@ -571,7 +586,7 @@ class Workload:
             self.d_in, self.d_out = cand_in[bi], cand_out[bo]
             self.first_in, self.first_out = (cand_in[0], cand_out[0]) if (keep_first and world == 1) else (None, None)
             self.placement = {"how": "mdc_tune_placement_device: the launch timed on every pair of %d candidate allocations for the frames and %d for the "
-                                     "results (allocated frames 0, results 0, frames 1, ...)" % (K, K),
+                                     "results (allocated frames 0, results 0, [%.0f-GB spacer,] frames 1, ...)" % (K, K, spacer_bytes / 1e9),
                               "ms_frames_i_results_j": [[round(x, 4) for x in row] for row in ms], "picked_frames": bi, "picked_results": bo}
             for k, b_ in enumerate(cand_in):
                 if k != bi and b_ is not self.first_in:
