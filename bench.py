@@ -85,7 +85,7 @@ def parse():
     p.add_argument("--placement-candidates", type=int, default=6,
                    help="the headline's frame and result buffers are chosen among this many allocations each by timing the launch itself on them "
                         "(mdc_tune_placement_device): on MI355X the time of one launch depends on the allocations it runs on by up to 9 %% "
-                        "(profiles/r05_experiments/05_*, 08_*); 1 = take the first allocations as they come")
+                        "(profiles/r05_experiments/05_*, 08_*, 10_*); 1 = take the first allocations as they come")
     p.add_argument("--placement-spread-gb", type=float, default=28.0, help="spacer allocation between successive candidate pairs (given back before timing)")
     p.add_argument("--no-again", action="store_true", help="do not time the headline a second time after the secondary workloads")
     p.add_argument("--parity-frames", type=int, default=16, help="frames of the benchmarked launch compared with the oracle")
@@ -876,7 +876,7 @@ def main():
     if D.rank == 0:
         head["roofline"]["placement"] = {
             "buffers": "chosen by mdc_tune_placement_device (config.placement): the time of one launch depends on the allocations it runs on, "
-                       "1.48 to 1.61 ms in one process (profiles/r05_experiments/05_*, 08_*)",
+                       "1.48 to 1.61 ms in one process (profiles/r05_experiments/05_*, 08_*, 10_*)",
             "kernel_ms_on_first_allocation": round(first_ms, 4) if first_ms else None,
             "frac_on_first_allocation": round(H.frac_of(first_ms), 4) if first_ms else None}
     devices = D.devices() if D.active else [{"rank": 0, "device": D.gpu}]
