@@ -12,7 +12,10 @@ TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 5 --preroll-s 0.3 --preroll-max-s 2 --no-cpu-baseline --no-ceiling --no-secondary $*"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 5 --preroll-s 0.3 --preroll-max-s 2 --no-cpu-baseline --no-ceiling --no-secondary --placement-candidates 1 $*"
+# --placement-candidates 1: the profiled run takes the first allocations as they come.  bench.py's search over candidate buffer pairs
+# (mdc_tune_placement_device: 36 pairs x 7 launches of the SAME kernel, most of them on slow pairs) would be averaged into rocprof's per-kernel
+# statistics; the profiled run's own bench line (bench_under_profiler.json) is the one its average must agree with.
 # The tuner's trial launches (3 shapes x 4 frames-per-workgroup settings) would be averaged into the per-kernel statistics: pick the
 # plan first, unprofiled, then profile a run that is told that plan and launches nothing else.
 PLAN=$($BENCH --steps 2 --warmup 1 --preroll-s 0.05 --preroll-max-s 0.05 2> /dev/null | python3 -c "
