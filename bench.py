@@ -527,7 +527,7 @@ class Workload:
         # Buffers.  The headline's: K candidate allocations for the frames and K for the results, the launch itself timed on them
         # (mdc_tune_placement_device) further down, once the frames exist; the first allocations of the process -- what a caller gets who
         # takes them as they come -- are candidate 0 of each and are timed beside the chosen ones (timed_on_first_allocation).
-        K = max(1, args.placement_candidates) if wl in ("fused", "unmap", "seq50k") else 1  # (the pass mdc_tune_placement_device times: no pyramid / gradient outputs)
+        K = max(1, args.placement_candidates)
         in_bytes, out_bytes = B * self.npix_in, B * self.npix_out * 4
         free_b = torch.cuda.mem_get_info(dev)[0]
         K = max(1, min(K, int(free_b * 0.45 // (in_bytes + out_bytes))))
@@ -582,11 +582,15 @@ class Workload:
             self.info = ctx.info()
         if K > 1:  # (after the plan is chosen: the launch that is timed on the candidates is the one the bench times)
             torch.cuda.synchronize()
-            bi, bo, ms = ctx.tune_placement([b_.data_ptr() for b_ in cand_in], [b_.data_ptr() for b_ in cand_out], B, self.flags, stream)
+            if wl in ("pyramid", "dso"):  # (levels / gradient images: mdc_tune_placement_device times the plain pass -- the step itself, from here)
+                bi, bo, ms = self.time_step_on_pairs(cand_in, cand_out)
+            else:
+                bi, bo, ms = ctx.tune_placement([b_.data_ptr() for b_ in cand_in], [b_.data_ptr() for b_ in cand_out], B, self.flags, stream)
             self.d_in, self.d_out = cand_in[bi], cand_out[bo]
             self.first_in, self.first_out = (cand_in[0], cand_out[0]) if (keep_first and world == 1) else (None, None)
-            self.placement = {"how": "mdc_tune_placement_device: the launch timed on every pair of %d candidate allocations for the frames and %d for the "
-                                     "results (allocated frames 0, results 0, [%.0f-GB spacer,] frames 1, ...)" % (K, K, spacer_bytes / 1e9),
+            self.placement = {"how": "%s timed on every pair of %d candidate allocations for the frames and %d for the (base) "
+                                     "results (allocated frames 0, results 0, [%.0f-GB spacer,] frames 1, ...)" % (
+                                         "the step" if wl in ("pyramid", "dso") else "mdc_tune_placement_device: the launch", K, K, spacer_bytes / 1e9),
                               "ms_frames_i_results_j": [[round(x, 4) for x in row] for row in ms], "picked_frames": bi, "picked_results": bo}
             for k, b_ in enumerate(cand_in):
                 if k != bi and b_ is not self.first_in:
@@ -614,6 +618,26 @@ class Workload:
             if wl == "dso":  # + 3 + 1 floats per pixel of every level (the levels' re-read by the gradient launch is not algorithmic)
                 self.alg_write += 16 * sum((self.out_w >> l) * (self.out_h >> l) for l in range(self.levels))
         self.alg_frame = self.alg_read + self.alg_write
+
+    def time_step_on_pairs(self, cand_in, cand_out):
+        """what mdc_tune_placement_device does for the plain pass, for a step with more outputs (levels, gradient images, in their own fixed
+        buffers): 2 untimed + 3 timed steps on every (frames, base results) pair -> (best frames index, best results index, ms[i][j])"""
+        ms = [[0.0] * len(cand_out) for _ in cand_in]
+        best = (1e30, 0, 0)
+        for i, bi_ in enumerate(cand_in):
+            for j, bo_ in enumerate(cand_out):
+                self.d_in, self.d_out = bi_, bo_
+                for _ in range(2):
+                    self.step()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    self.step()
+                e1.record()
+                torch.cuda.synchronize()
+                ms[i][j] = e0.elapsed_time(e1) / 3
+                best = min(best, (ms[i][j], i, j))
+        return best[1], best[2], ms
 
     def step(self):
         if self.wl == "dso":  # base + levels + gradient images in one call (chunks chosen by the library)
