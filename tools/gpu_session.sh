@@ -84,6 +84,8 @@ for stage in "$@"; do
       grep -a "torch.empty\|Error\|error" "$OUT/alloc_probe_expandable.txt" | tail -5 ;;
     alloc)   # linear write / read rate per allocation (does the rate depend on where a buffer lies?)
       timeout 600 python tools/alloc_probe.py ${ALLOC_ARGS:-32 5} > "$OUT/alloc_probe.txt" 2>&1; grep -av amdgpu.ids "$OUT/alloc_probe.txt" | tail -70 ;;
+    classmap)  # which pieces of the device's memory are slow with which (tools/class_map.py)
+      timeout 600 python tools/class_map.py ${CLASS_ARGS:-200 1} > "$OUT/class_map.txt" 2>&1; grep -av amdgpu.ids "$OUT/class_map.txt" | tail -60 ;;
     probe)   # why the same launch ran 8 % apart within one process: launch time against clocks / idle gaps / placement
       timeout 300 python tools/clock_probe.py ${PROBE_ARGS:-12 4 3} > "$OUT/clock_probe.txt" 2>&1; grep -a "===\|^A \|^B \|plan:\|idle snapshot" -A0 "$OUT/clock_probe.txt" | tail -8 ;;
     bench_each)  # every workload in its own process (which one faults?)
