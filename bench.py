@@ -531,6 +531,8 @@ class Workload:
         in_bytes, out_bytes = B * self.npix_in, B * self.npix_out * 4
         free_b = torch.cuda.mem_get_info(dev)[0]
         K = max(1, min(K, int(free_b * 0.45 // (in_bytes + out_bytes))))
+        if in_bytes + out_bytes < (2 << 30) or (D.active and D.backend != "nccl"):
+            K = 1  # test-sized batches (they fit the Infinity Cache), ranks sharing one GPU over gloo: buffers as they come
         cand_in, cand_out, spacers = [], [], []
         # candidates SPREAD over the device's memory: whether a pair is fast or slow goes with where its two buffers lie (two classes of
         # memory, a pair from the same class is slow: profiles/r05_experiments/10_*), and neighbouring allocations are mostly of one class
