@@ -608,6 +608,35 @@ class Workload:
                 self.tuned = {"tile": [t.tile_w, t.tile_h], "frames_per_workgroup": t.frames_per_block, "candidates": t.candidates,
                               "ms_on_%d_frames" % min(B, 4096): round(t.ms, 4)}
                 self.info = ctx.info()
+        if K > 1 and wl in ("pyramid", "dso"):
+            # the step's other large outputs, one after the other: candidates for level 1, and for the DSO step the level-0 gradient images
+            # (15.7 + 5.2 MB of the 35 MB a frame), each chosen by timing the step with everything else fixed
+            targets = [("level1", self.d_levels, 0)] + ([("dI0", self.d_dI, 0), ("abs0", self.d_abs, 0)] if wl == "dso" else [])
+            for tag, lst, idx in targets:
+                nb = lst[idx].nbytes
+                kk = max(1, min(4, int(torch.cuda.mem_get_info(dev)[0] * 0.5 // nb)))
+                if nb < (512 << 20) or kk < 2:
+                    continue
+                cands = [lst[idx]] + [Buf(nb, dev) for _ in range(kk - 1)]
+                times = []
+                for c_ in cands:
+                    lst[idx] = c_
+                    for _ in range(2):
+                        self.step()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        self.step()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    times.append(e0.elapsed_time(e1) / 3)
+                best = int(np.argmin(times))
+                lst[idx] = cands[best]
+                for k, c_ in enumerate(cands):
+                    if k != best:
+                        c_.free()
+                self.placement["ms_per_%s_candidate" % tag] = [round(x, 4) for x in times]
+            torch.cuda.empty_cache()
         self.kernel_name = ctx.describe_launch(self.flags, self.levels if wl in ("pyramid", "dso") else 0)
         if wl == "dso":
             self.kernel_name += " + gradients_levels_kernel"
