@@ -239,3 +239,23 @@ def test_bench_over_rccl_on_real_devices(tmp_path, oracle):
                       "0.3", "--no-cpu-baseline"], timeout=1200)
         assert seq["scaling"] == "strong" and seq["config"]["sequence_frames"] == 96 * n and seq["parity"]["mismatching_pixels"] == 0
         assert seq["ranks"]["rccl_ranks"] == n and len(seq["roofline"]["per_rank_frac"]) == n
+
+
+@pytest.mark.gpu
+def test_bench_chooses_its_buffers_by_measurement():
+    """bench.py allocates candidate frame / result buffers (spread by spacer allocations), has mdc_tune_placement_device time the launch on every
+    pair, runs on the fastest, and reports the matrix, the pair and the figure on the first allocations of the process beside the headline."""
+    out = _bench(["--steps", "4", "--warmup", "1", "--frames", "1024", "--placement-candidates", "3", "--placement-spread-gb", "2", "--preroll-s", "0.05",
+                  "--preroll-max-s", "0.3", "--no-cpu-baseline", "--no-secondary"])
+    pl = out["config"]["placement"]
+    m = pl["ms_frames_i_results_j"]
+    assert len(m) == 3 and all(len(r) == 3 for r in m) and all(0 < x < 20 for r in m for x in r)
+    assert m[pl["picked_frames"]][pl["picked_results"]] == min(x for r in m for x in r)
+    assert out["parity"]["mismatching_pixels"] == 0 and out["parity"]["frames_checked"] == 16
+    rp = out["roofline"]["placement"]
+    if (pl["picked_frames"], pl["picked_results"]) != (0, 0):
+        assert rp["frac_on_first_allocation"] and 0.2 < rp["frac_on_first_allocation"] < 0.9
+    assert 0.2 < out["roofline"]["frac"] < 0.9
+    plain = _bench(["--steps", "4", "--warmup", "1", "--frames", "1024", "--placement-candidates", "1", "--preroll-s", "0.05", "--preroll-max-s", "0.3",
+                    "--no-cpu-baseline", "--no-secondary"])
+    assert plain["config"]["placement"] == {"how": "first allocations, as they come"} and plain["parity"]["mismatching_pixels"] == 0
