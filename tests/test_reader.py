@@ -615,6 +615,24 @@ def test_reader_gpu_jpeg_stages_agree_on_damaged_and_mixed_files(tmp_path, capfd
         for i in range(len(blobs)):
             if ok0[i]:
                 assert bits_equal(results[stage][0][i], results[0][0][i]), (stage, i)
+    # getImagesDevice over the same folder: the same images at the same positions, the same failures (valid[i] = 0, the position
+    # untouched), in every stage -- damaged streams take the host decoder and go up as one frame, undecodable ones are refused
+    import torch
+
+    npo = results[0][0].shape[1]
+    for stage in (2, 1, 0):
+        r = capi.DatasetReader(d)
+        r.set_gpu_jpeg(stage)
+        d_base = torch.full((len(blobs), npo), -9.0, dtype=torch.float32, device="cuda")
+        valid, n = r.get_images_device(0, len(blobs), 1, 1, 1, 1, capi.DeviceOutputs.make(d_base.data_ptr()))
+        r.close()
+        got = d_base.cpu().numpy()
+        assert n == results[0][2] and (valid == ok0).all(), (stage, valid, ok0)
+        for i in range(len(blobs)):
+            if ok0[i]:
+                assert bits_equal(got[i], results[0][0][i]), (stage, i)
+            else:
+                assert (got[i] == -9.0).all(), (stage, i)
 
 
 def test_reader_gpu_jpeg_on_and_off_give_the_same_images(tmp_path):
