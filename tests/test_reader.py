@@ -910,3 +910,30 @@ def test_process_frames_host_to_device_with_frame_index(tmp_path, oracle):
     with pytest.raises(capi.MdcError):
         ctx.process_frames_host_to_device(raws[:1], flags, capi.DeviceOutputs.make(1), [-1])
     ctx.close()
+
+
+@pytest.mark.parametrize("fmt", ["png", "jpg"])
+def test_get_images_device_longer_than_the_ring(tmp_path, fmt):
+    """getImagesDevice over more frames than a lane's page-locked ring holds, with both lanes of the output device at work (the second
+    context is made at the first call): ring slots are re-used while the pool decodes ahead; every position equals getImages'."""
+    import torch
+
+    from mono_dataset_code_amd import capi
+
+    h, w = 64, 80
+    n = 700
+    frames = [textured(h, w, s % 37) for s in range(n)]
+    make_sequence(str(tmp_path), frames, True, fmt)
+    r = capi.DatasetReader(str(tmp_path))
+    want, ok, got = r.get_images(0, n, 1, 1, 1, 0)
+    assert got == n and ok.all()
+    for threads in (0, 3):
+        r.set_threads(threads)
+        d_base = torch.full((n, r.out_w * r.out_h), -3.0, dtype=torch.float32, device="cuda")
+        valid, got_d = r.get_images_device(0, n, 1, 1, 1, 0, capi.DeviceOutputs.make(d_base.data_ptr()))
+        assert got_d == n and valid.all(), r.last_error()
+        assert bits_equal(d_base.cpu().numpy(), want), (fmt, threads)
+    assert len(r.device_stats()) == 2  # the twin lane exists now; getImages keeps using one
+    want2, ok2, got2 = r.get_images(10, 50, 1, 1, 1, 0)
+    assert got2 == 50 and bits_equal(want2, want[10:60])
+    r.close()
