@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised soak of the reader's JPEG path (stage 2: Huffman decoding on the device, three-stream pipeline, slab pool, results
 made ahead): for SECONDS seconds random getImages ranges (1..700 frames, all four switch combinations that rectify or not) and
-random getImage walks (runs in order, jumps, switch changes) on a zipped sequence of 700 small JPEGs, every result compared bit
+random getImagesDevice ranges (results, box levels and gradient images left in device arrays; two lanes on the device) and random getImage walks
+(runs in order, jumps, switch changes) on a zipped sequence of 700 small JPEGs, every result compared bit
 for bit with the host-decoded path (stage 0, lookahead off) computed once.  usage: python tools/reader_soak.py [seconds] [seed]"""
 import os
 import sys
@@ -40,12 +41,51 @@ def same(a, b):
     return np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+import torch  # noqa: E402
+
 r = capi.DatasetReader(d)
+OW, OH = r.out_w, r.out_h
+dev_calls = 0
+d_arrays = {}  # rectified? -> device arrays for the whole sequence
+
+
+def device_arrays(rect):
+    if rect not in d_arrays:
+        w0, h0 = (OW, OH) if rect else (W, H)
+        dims = [(w0 >> l, h0 >> l) for l in range(3)]
+        d_arrays[rect] = (torch.zeros((N, w0 * h0), dtype=torch.float32, device="cuda"),
+                          [torch.zeros((N, a * b), dtype=torch.float32, device="cuda") for a, b in dims[1:]],
+                          [torch.zeros((N, a * b * 3), dtype=torch.float32, device="cuda") for a, b in dims],
+                          [torch.zeros((N, a * b), dtype=torch.float32, device="cuda") for a, b in dims], dims)
+    return d_arrays[rect]
+
+
 calls = frames_done = singles = 0
 t0 = time.time()
 while time.time() - t0 < SECONDS:
     sw = SWITCHES[rng.integers(len(SWITCHES))]
-    if rng.random() < 0.5:
+    u0 = rng.random()
+    if u0 < 0.25:  # getImagesDevice: positions 0..count-1 of the arrays hold frames first..first+count-1
+        count = int(rng.choice([1, 63, 64, 65, 129, 256, 257, 511, 700, int(rng.integers(1, 701))]))
+        first = int(rng.integers(0, N - count + 1))
+        base, lv, dI, ab, dims = device_arrays(sw[0])
+        base.fill_(-1.0)
+        with_levels = rng.random() < 0.5
+        outs = capi.DeviceOutputs.make(base.data_ptr(), 3, [t.data_ptr() for t in lv], [t.data_ptr() for t in dI], [t.data_ptr() for t in ab]) if with_levels \
+            else capi.DeviceOutputs.make(base.data_ptr())
+        valid, n = r.get_images_device(first, count, *sw, outs)
+        assert n == count and valid.all(), (first, count, sw, n, r.last_error())
+        assert same(base[:count].cpu().numpy(), want[sw][first:first + count]), ("getImagesDevice", first, count, sw)
+        if with_levels:  # level 1 of a few frames: the box filter of the base, bit for bit (0.25f * (((a + b) + c) + d))
+            for f in (0, count - 1):
+                b0 = want[sw][first + f].reshape(dims[0][1], dims[0][0])
+                l1 = np.float32(0.25) * (((b0[0::2, 0::2][:dims[1][1], :dims[1][0]] + b0[0::2, 1::2][:dims[1][1], :dims[1][0]]) + b0[1::2, 0::2][:dims[1][1], :dims[1][0]]) + b0[1::2, 1::2][:dims[1][1], :dims[1][0]])
+                g = lv[0][f].cpu().numpy().reshape(dims[1][1], dims[1][0])
+                nan = np.isnan(l1)
+                assert np.array_equal(nan, np.isnan(g)) and np.array_equal(l1[~nan].view(np.uint32), g[~nan].view(np.uint32)), ("level 1", first, f)
+        dev_calls += 1
+        frames_done += count
+    elif u0 < 0.6:
         count = int(rng.choice([1, 2, 63, 64, 65, 128, 255, 256, 257, 300, 512, 513, 700, int(rng.integers(1, 701))]))
         first = int(rng.integers(0, N - count + 1))
         imgs, ok, n = r.get_images(first, count, *sw)
@@ -68,5 +108,5 @@ while time.time() - t0 < SECONDS:
             else:
                 sw = SWITCHES[rng.integers(len(SWITCHES))]
 r.close()
-print("READER_SOAK ok: %.0f s, %d getImages calls (%d frames), %d getImage calls, every result bit-identical to the host-decoded path"
-      % (time.time() - t0, calls, frames_done, singles))
+print("READER_SOAK ok: %.0f s, %d getImages + %d getImagesDevice calls (%d frames), %d getImage calls, every result bit-identical to the host-decoded path"
+      % (time.time() - t0, calls, dev_calls, frames_done, singles))
