@@ -277,7 +277,8 @@ MDC_API int mdc_jpeg_huffman_batch_device(mdc_ctx* ctx, const void* d_streams, i
  * block this replaces for callers that keep working on the device.
  * `out` describes device arrays for a whole sequence; frame i of the call lands at position frame_index[i] of every array
  * (frame_index == NULL: position i).  Same bytes as the host-output call followed by a copy up.  Blocking: on return the
- * results are complete in device memory.  status as for mdc_process_jpeg_streams_host (the arrays' entries of a frame with
+ * results are complete in device memory.  The calls run on streams of the context's own: work of the caller's streams that still
+ * touches the arrays (a fill, a consumer of the previous results) must have finished before the call.  status as for mdc_process_jpeg_streams_host (the arrays' entries of a frame with
  * status != 0 are not results).  mdc_device_alloc / _free / mdc_copy_to_host: for callers without a HIP toolchain of their own. */
 typedef struct mdc_device_outputs {
   float* base;                /* positions x (w x h) floats: the processed frames (rectified size with MDC_RECTIFY); required */

@@ -624,6 +624,7 @@ def test_reader_gpu_jpeg_stages_agree_on_damaged_and_mixed_files(tmp_path, capfd
         r = capi.DatasetReader(d)
         r.set_gpu_jpeg(stage)
         d_base = torch.full((len(blobs), npo), -9.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
         valid, n = r.get_images_device(0, len(blobs), 1, 1, 1, 1, capi.DeviceOutputs.make(d_base.data_ptr()))
         r.close()
         got = d_base.cpu().numpy()
@@ -850,6 +851,7 @@ def test_get_images_device_equals_get_images(tmp_path, oracle, fmt, stage):
         assert got == count and ok.all()
         npo = ow * oh if fl[0] else w * h
         d_base = torch.full((count, npo), -3.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()  # (the call runs on the reader's own streams)
         outs = capi.DeviceOutputs.make(d_base.data_ptr())
         valid, got_d = r.get_images_device(first, count, *fl, outs)
         assert got_d == count and valid.all(), r.last_error()
@@ -861,6 +863,7 @@ def test_get_images_device_equals_get_images(tmp_path, oracle, fmt, stage):
     d_lv = [torch.zeros((count, a * b), dtype=torch.float32, device="cuda") for a, b in dims[1:]]
     d_dI = [torch.zeros((count, a * b * 3), dtype=torch.float32, device="cuda") for a, b in dims]
     d_ab = [torch.zeros((count, a * b), dtype=torch.float32, device="cuda") for a, b in dims]
+    torch.cuda.synchronize()
     outs = capi.DeviceOutputs.make(d_base.data_ptr(), 4, [t.data_ptr() for t in d_lv], [t.data_ptr() for t in d_dI], [t.data_ptr() for t in d_ab])
     valid, got_d = r.get_images_device(0, count, *fl, outs)
     assert got_d == count and valid.all(), r.last_error()
@@ -930,6 +933,7 @@ def test_get_images_device_longer_than_the_ring(tmp_path, fmt):
     for threads in (0, 3):
         r.set_threads(threads)
         d_base = torch.full((n, r.out_w * r.out_h), -3.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
         valid, got_d = r.get_images_device(0, n, 1, 1, 1, 0, capi.DeviceOutputs.make(d_base.data_ptr()))
         assert got_d == n and valid.all(), r.last_error()
         assert bits_equal(d_base.cpu().numpy(), want), (fmt, threads)

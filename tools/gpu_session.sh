@@ -144,6 +144,11 @@ PY
       MDC_DEVICES=0,0 timeout 200 python tools/reader_soak.py ${SOAK_S:-40} 2 > "$OUT/reader_soak_two_lanes.txt" 2>&1; grep -av amdgpu.ids "$OUT/reader_soak_two_lanes.txt" | tail -3
       timeout 300 python tools/soak.py 60 > "$OUT/soak.txt" 2>&1; tail -2 "$OUT/soak.txt"
       timeout 400 bash tools/soak_threads.sh 800 > "$OUT/thread_soak.txt" 2>&1; tail -4 "$OUT/thread_soak.txt" ;;
+    soak_device)  # the reader soak with getImagesDevice as most of the mix, seeds 1..3, default lanes and MDC_DEVICES=0,0
+      for seed in 1 2 3; do
+        SOAK_DEVICE_SHARE=0.8 timeout 200 python tools/reader_soak.py ${SOAK_S:-30} $seed > "$OUT/reader_soak_device_$seed.txt" 2>&1; grep -a "MISMATCH\|position\|READER_SOAK\|Error" "$OUT/reader_soak_device_$seed.txt" | cut -c1-400
+      done
+      MDC_DEVICES=0,0 SOAK_DEVICE_SHARE=0.8 timeout 200 python tools/reader_soak.py ${SOAK_S:-30} 4 > "$OUT/reader_soak_device_two_lanes.txt" 2>&1; grep -a "MISMATCH\|position\|READER_SOAK\|Error" "$OUT/reader_soak_device_two_lanes.txt" | cut -c1-400 ;;
     reader_device)  # getImagesDevice on a zipped JPEG sequence: lanes per device / frames per pipeline chunk (RATE_ENVS="A=1 B=2;A=3")
       MDC_RATE_ONLY=device MDC_RATE_KINDS=${KINDS:-zip_jpg} MDC_RATE_ENVS="${RATE_ENVS:-MDC_DEVICES=0,0}" timeout 900 python tools/reader_rate.py ${N:-1024} > "$OUT/reader_device_rates.txt" 2>&1
       grep -a "^==\|^--\|READER_RATE reader\|READER_RATE device [0-9]" "$OUT/reader_device_rates.txt" | cut -c1-200 ;;
