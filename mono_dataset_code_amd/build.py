@@ -44,6 +44,7 @@ HOST_FLAGS = ["-O2", "-std=c++11", "-ffp-contract=off", "-fPIC", "-shared", "-fv
 HOST_EXPORT_MAP = os.path.join(HOST, "mdc_host_exports.map")
 # what still leaks through -fvisibility=hidden (libstdc++ template instantiations are declared with default visibility): made local
 EXPORT_MAP = os.path.join(CSRC, "mdc_exports.map")
+RECIPE = os.path.abspath(__file__)  # (the flags and mdc_code_id()'s rule live here: a changed recipe relinks, objects are redone by their own rule)
 
 
 def _stale(target, deps):
@@ -76,15 +77,48 @@ def eigen_include():
     return EIGEN_STUB
 
 
+def code_text(src):
+    """C / C++ source without its comments and blank space at line ends (string and character literals kept as they are):
+    what the compiler sees of it, so that an edited comment does not make a measured build a different one."""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if c == "/" and i + 1 < n and src[i + 1] == "/":
+            while i < n and src[i] != "\n":
+                if src[i] == "\\" and i + 1 < n and src[i + 1] == "\n":  # a continued // comment
+                    i += 1
+                i += 1
+        elif c == "/" and i + 1 < n and src[i + 1] == "*":
+            j = src.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        elif c in "\"'":
+            j = i + 1
+            while j < n and src[j] != c:
+                j += 2 if src[j] == "\\" else 1
+            out.append(src[i:j + 1])
+            i = j + 1
+        elif c in " \t\r\f\v":  # a run of blanks outside literals is one blank
+            if not out or out[-1] != " ":
+                out.append(" ")
+            i += 1
+        else:
+            out.append(c)
+            i += 1
+    lines = [l.strip() for l in "".join(out).split("\n")]
+    return "\n".join(l for l in lines if l)
+
+
 def code_id(defines=()):
-    """16 hex digits over everything the kernels are made of: sources, shared headers, compile flags, -D list, compiler version."""
+    """16 hex digits over everything the kernels are made of: sources and shared headers (comments and spacing aside), compile
+    flags, -D list, compiler version."""
     import hashlib
 
     h = hashlib.sha256()
     for path in sorted(HIP_DEPS):
         h.update(os.path.basename(path).encode() + b"\0")
-        with open(path, "rb") as f:
-            h.update(f.read())
+        with open(path, "r", encoding="utf-8", errors="surrogateescape") as f:
+            h.update(code_text(f.read()).encode("utf-8", "surrogateescape"))
     h.update(" ".join(HIP_FLAGS + sorted(defines)).encode())
     try:
         h.update(subprocess.run([hipcc(), "--version"], stdout=subprocess.PIPE).stdout)
@@ -124,7 +158,7 @@ def _compile_link_hip(out, defines=(), objdir_tag="product"):
 
 
 def build_hip(force=False):
-    if force or _stale(LIB_HIP, HIP_DEPS):
+    if force or _stale(LIB_HIP, HIP_DEPS + [RECIPE]):
         if force:
             shutil.rmtree(os.path.join(PKG, "build", "product"), ignore_errors=True)
         _compile_link_hip(LIB_HIP)
@@ -196,7 +230,7 @@ def build_variant(name, defines):
     d = os.path.join(PKG, "variants")
     os.makedirs(d, exist_ok=True)
     out = os.path.join(d, "libmdc_hip_%s.so" % name)
-    if _stale(out, HIP_DEPS):
+    if _stale(out, HIP_DEPS + [RECIPE]):
         # MDC_DIAGNOSIS_BUILD: the licence for the wrong-result switches of csrc/mdc_build_config.h -- only ever set here,
         # for a library that lands under variants/ and reports itself through mdc_build_flags()
         diag = [] if name == "debug" else ["MDC_DIAGNOSIS_BUILD=1"]

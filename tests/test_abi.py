@@ -56,6 +56,16 @@ def test_exported_symbols_are_exactly_the_headers():
                 raise AssertionError("declaration without MDC_API: " + line)
 
 
+def test_code_id_ignores_comments_only():
+    """build.code_text: comments and spacing are not part of a build's identity; string literals and every token are."""
+    from mono_dataset_code_amd import build
+    a = 'int f() { return g("// no comment /* here */"); }  // why\n/* a block\n   of text */ int x = \'"\';\n'
+    b = '  int f() { return g("// no comment /* here */"); }\n\n int x = \'"\';   // another remark\n'
+    assert build.code_text(a) == build.code_text(b)
+    assert build.code_text(a) != build.code_text(a.replace("return g", "return h"))
+    assert build.code_text(a) != build.code_text(a.replace("no comment", "no  comment"))
+
+
 def test_code_id_names_the_build():
     """mdc_code_id(): the hash of sources + flags the library was made from == what the build recipe computes for the tree."""
     from mono_dataset_code_amd import build, capi
