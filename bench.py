@@ -822,7 +822,8 @@ class Workload:
             with quiet_stdout():
                 rfov = R.fov(os.path.join(self.calib_dir, "camera.txt"))
                 rphoto = R.photo(os.path.join(self.calib_dir, "pcalib.txt"), os.path.join(self.calib_dir, "vignette.png"), IN_W, IN_H)
-        bad = 0
+        bad = nan_bad = black_bad = 0
+        max_rel = 0.0
         fpb = int(getattr(self.info, "frames_per_block", 0) or (self.tuned or {}).get("frames_per_workgroup", 0) or 64)
         checked = spot_frames(self.B, fpb, max(2, nframes))
         npi, npo = self.npix_in, self.npix_out
@@ -833,7 +834,14 @@ class Workload:
                 want = R.get_image(rfov, rphoto, raw, self.rect, True, True, True)
             else:
                 want = O.get_image(raw, IN_W, IN_H, self.out_w, self.out_h, ginv, vinv, True, True, rx, ry, self.rect, True, True, True)
-            bad += bits_differ(want, self.d_out.read(f * npo * 4, npo, np.float32))
+            got = self.d_out.read(f * npo * 4, npo, np.float32)
+            bad += bits_differ(want, got)
+            # SURVEY.md 8(d)'s report for the base image, beside the bit count: NaN mask, exact zeros (black), relative error elsewhere
+            nan_bad += int(np.count_nonzero(np.isnan(want) != np.isnan(got)))
+            black_bad += int(np.count_nonzero((want == 0) != (got == 0)))
+            fin = np.isfinite(want) & (want != 0) & np.isfinite(got)
+            if fin.any():
+                max_rel = max(max_rel, float(np.max(np.abs((got[fin].astype(np.float64) - want[fin]) / want[fin]))))
             src, cw, ch = want, self.out_w, self.out_h
             for l in range(self.levels if self.d_levels else 1):
                 if l > 0:
@@ -845,6 +853,7 @@ class Workload:
                     bad += bits_differ(w_dI.reshape(-1), self.d_dI[l].read(f * cw * ch * 12, cw * ch * 3, np.float32))
                     bad += bits_differ(w_abs, self.d_abs[l].read(f * cw * ch * 4, cw * ch, np.float32))
         out = {"frames_checked": len(checked), "frames": checked, "levels_checked": 1 + len(self.d_levels), "mismatching_pixels": bad,
+               "nan_mask_mismatches": nan_bad, "black_pixel_mismatches": black_bad, "max_relative_error": max_rel,
                "against": "oracle/_ref/libmdc_ref.so (the reference's own sources compiled here, its own tables from the same calibration files)"
                           if R is not None else "oracle/liboracle.so (C restatement, pinned to the reference build by tests/test_oracle_vs_ref.py)"}
         if self.d_levels:

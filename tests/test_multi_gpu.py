@@ -252,6 +252,7 @@ def test_bench_chooses_its_buffers_by_measurement():
     assert len(m) == 3 and all(len(r) == 3 for r in m) and all(0 < x < 20 for r in m for x in r)
     assert m[pl["picked_frames"]][pl["picked_results"]] == min(x for r in m for x in r)
     assert out["parity"]["mismatching_pixels"] == 0 and out["parity"]["frames_checked"] == 16
+    assert (out["parity"]["nan_mask_mismatches"], out["parity"]["black_pixel_mismatches"], out["parity"]["max_relative_error"]) == (0, 0, 0.0)
     rp = out["roofline"]["placement"]
     if (pl["picked_frames"], pl["picked_results"]) != (0, 0):
         assert rp["frac_on_first_allocation"] and 0.2 < rp["frac_on_first_allocation"] < 0.9
