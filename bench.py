@@ -82,11 +82,13 @@ def parse():
     p.add_argument("--preroll-window-s", type=float, default=0.05)
     p.add_argument("--preroll-windows", type=int, default=5)
     p.add_argument("--preroll-tol", type=float, default=0.01)
-    p.add_argument("--placement-candidates", type=int, default=6,
-                   help="the headline's frame and result buffers are chosen among this many allocations each by timing the launch itself on them "
-                        "(mdc_tune_placement_device): on MI355X the time of one launch depends on the allocations it runs on by up to 9 %% "
-                        "(profiles/r05_experiments/05_*, 08_*, 10_*); 1 = take the first allocations as they come")
-    p.add_argument("--placement-spread-gb", type=float, default=28.0, help="spacer allocation between successive candidate pairs (given back before timing)")
+    p.add_argument("--placement", default="auto", choices=["auto", "first", "malloc", "vmm"],
+                   help="how the frame / result buffers of every workload are made: through the product's allocator, mdc_alloc_placed_device "
+                        "(include/mdc_hip.h).  On MI355X the time of one launch depends on the allocations it runs on by up to 9 %% "
+                        "(profiles/r05_experiments/05_*, 08_*, 10_*; DESIGN.md 6.1): auto = the library's default strategy, first = two plain "
+                        "allocations as they come, malloc = candidates + every pair timed, vmm = ranges assembled from classified physical pieces")
+    p.add_argument("--placement-candidates", type=int, default=0,
+                   help="malloc strategy: candidate allocations per buffer (0 = the library's default, 6; 1 = same as --placement first)")
     p.add_argument("--no-again", action="store_true", help="do not time the headline a second time after the secondary workloads")
     p.add_argument("--parity-frames", type=int, default=16, help="frames of the benchmarked launch compared with the oracle")
     p.add_argument("--frames", type=int, default=0,
@@ -436,19 +438,29 @@ def spot_frames(B, fpb, n):
 
 
 class Buf:
-    """A device buffer of the bench (a torch allocation: hipMalloc through PyTorch's allocator) with byte-offset reads."""
+    """A device buffer of the bench with byte-offset reads: either a torch allocation (hipMalloc through PyTorch's allocator: levels, gradient
+    images) or one half of a pair made by the product's allocator (mdc_alloc_placed_device: frames / base results)."""
 
-    def __init__(self, nbytes, dev, tensor=None):
+    def __init__(self, nbytes, dev=None, ptr=None, ctx=None):
         self.nbytes = int(nbytes)
-        self.t = tensor if tensor is not None else torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
+        self.ctx = ctx
+        self.t = None
+        if ptr is None:
+            self.t = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
+            self.ptr = self.t.data_ptr()
+        else:
+            self.ptr = int(ptr)
 
     def data_ptr(self):
-        return self.t.data_ptr()
+        return self.ptr
 
     def read(self, offset_bytes, count, dtype):
         """count elements of dtype from byte offset, as a numpy array"""
         nb = count * np.dtype(dtype).itemsize
-        return self.t[offset_bytes:offset_bytes + nb].cpu().numpy().view(dtype)
+        if self.t is not None:
+            return self.t[offset_bytes:offset_bytes + nb].cpu().numpy().view(dtype)
+        torch.cuda.synchronize()
+        return self.ctx.copy_to_host(self.ptr + offset_bytes, count, dtype)
 
     def free(self):
         self.t = None
@@ -459,7 +471,7 @@ class Workload:
     tuned plan, `step()` = one pass of the hot path over the shard.  Kept alive so that the SAME launch (same context, same
     buffers, same plan) can be timed again later in the process."""
 
-    def __init__(self, args, D, wl, frames, tune=True, keep_first=False):
+    def __init__(self, args, D, wl, frames, tune=True):
         from mono_dataset_code_amd import capi, shard, synth
 
         self.args, self.D, self.wl = args, D, wl
@@ -524,42 +536,25 @@ class Workload:
         tstream = D.stream()
         torch.cuda.set_stream(tstream)
         self.stream = stream = tstream.cuda_stream
-        # Buffers.  The headline's: K candidate allocations for the frames and K for the results, the launch itself timed on them
-        # (mdc_tune_placement_device) further down, once the frames exist; the first allocations of the process -- what a caller gets who
-        # takes them as they come -- are candidate 0 of each and are timed beside the chosen ones (timed_on_first_allocation).
-        K = max(1, args.placement_candidates)
-        in_bytes, out_bytes = B * self.npix_in, B * self.npix_out * 4
-        free_b = torch.cuda.mem_get_info(dev)[0]
-        K = max(1, min(K, int(free_b * 0.45 // (in_bytes + out_bytes))))
-        if in_bytes + out_bytes < (2 << 30) or (D.active and D.backend != "nccl"):
-            K = 1  # test-sized batches (they fit the Infinity Cache), ranks sharing one GPU over gloo: buffers as they come
-        cand_in, cand_out, spacers = [], [], []
-        # candidates SPREAD over the device's memory: whether a pair is fast or slow goes with where its two buffers lie (two classes of
-        # memory, a pair from the same class is slow: profiles/r05_experiments/10_*), and neighbouring allocations are mostly of one class
-        # (on some GPUs the first 60 GB are) -- a spacer allocation between successive candidate pairs, given back before anything is timed
-        spacer_bytes = 0
-        if K > 1:
-            room = free_b * 0.85 - K * (in_bytes + out_bytes)
-            spacer_bytes = int(max(0, min(args.placement_spread_gb * 1e9, room / max(K - 1, 1)))) // (1 << 21) * (1 << 21)
-        for k in range(K):  # frames, results, (spacer,) frames, results, ...: candidates 0 are the first two allocations of the process
-            cand_in.append(Buf(in_bytes, dev))
-            cand_out.append(Buf(out_bytes, dev))
-            if spacer_bytes and k + 1 < K:
-                try:
-                    spacers.append(torch.empty(spacer_bytes, dtype=torch.uint8, device=dev))
-                except RuntimeError:
-                    spacer_bytes = 0
-        del spacers
-        torch.cuda.empty_cache()
-        self.d_in, self.d_out = cand_in[0], cand_out[0]
-        self.first_in = self.first_out = None
-        self.placement = {"how": "first allocations, as they come"}
-        for b_ in cand_in:
-            if world == 1:
-                ctx.synth_frames(b_.data_ptr(), 0, B, self.npix_in, synth.SEED, stream)
-            else:
-                for i, f in enumerate(mine):  # local frame i = global frame rank + i * world
-                    ctx.synth_frames(b_.data_ptr() + i * self.npix_in, int(f), 1, self.npix_in, synth.SEED, stream)
+        # Buffers: the frames and the (base) results come from the PRODUCT's allocator (mdc_alloc_placed_device), which picks -- by timing the
+        # pass itself -- a pair of buffers the pass runs fast on; the bench has no search of its own.  What a caller gets who takes the first
+        # allocations as they come is the allocator's ms_first, printed beside (roofline.placement).
+        self.flags = capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED | (capi.RECTIFY if rect else 0)
+        strategy = {"auto": capi.PLACE_AUTO, "first": capi.PLACE_FIRST, "malloc": capi.PLACE_MALLOC, "vmm": capi.PLACE_VMM}[args.placement]
+        if args.placement_candidates == 1 or (D.active and D.backend != "nccl"):
+            strategy = capi.PLACE_FIRST  # (ranks sharing one GPU over gloo, the test mode: buffers as they come)
+        elif args.placement_candidates > 1:
+            os.environ["MDC_PLACE_CANDIDATES"] = str(args.placement_candidates)
+        torch.cuda.synchronize()
+        self.placed = ctx.alloc_placed(B, self.flags, strategy, stream)
+        self.d_in = Buf(self.placed.in_bytes, ptr=self.placed.d_in, ctx=ctx)
+        self.d_out = Buf(self.placed.out_bytes, ptr=self.placed.d_out, ctx=ctx)
+        self.placement = self.placed.describe()
+        if world == 1:
+            ctx.synth_frames(self.d_in.data_ptr(), 0, B, self.npix_in, synth.SEED, stream)
+        else:
+            for i, f in enumerate(mine):  # local frame i = global frame rank + i * world
+                ctx.synth_frames(self.d_in.data_ptr() + i * self.npix_in, int(f), 1, self.npix_in, synth.SEED, stream)
         self.levels, self.d_levels = 4, []
         self.d_dI, self.d_abs = [], []
         def out_floats(count, tag):
@@ -574,7 +569,6 @@ class Workload:
             for name, b in [("in", self.d_in), ("out", self.d_out)] + [("level%d" % (i + 1), b) for i, b in enumerate(self.d_levels)] + \
                     [("dI%d" % i, b) for i, b in enumerate(self.d_dI)] + [("abs%d" % i, b) for i, b in enumerate(self.d_abs)]:
                 sys.stderr.write("buffer %-7s 0x%x .. 0x%x (%d bytes, %s)\n" % (name, b.data_ptr(), b.data_ptr() + b.nbytes, b.nbytes, "torch.empty"))
-        self.flags = capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED | (capi.RECTIFY if rect else 0)
         self.tuned = None
         if tune and wl in ("fused", "seq50k") and args.kernel == "auto" and not (args.no_tune or args.fpb or args.tile_rows or args.tile_cols or args.nbuf):
             # plan selection by measurement, on (a part of) this rank's own batch; untimed set-up like the table build
@@ -582,61 +576,6 @@ class Workload:
             self.tuned = {"tile": [t.tile_w, t.tile_h], "frames_per_workgroup": t.frames_per_block, "candidates": t.candidates,
                           "ms_on_%d_frames" % min(B, 4096): round(t.ms, 4)}
             self.info = ctx.info()
-        if K > 1:  # (after the plan is chosen: the launch that is timed on the candidates is the one the bench times)
-            torch.cuda.synchronize()
-            if wl in ("pyramid", "dso"):  # (levels / gradient images: mdc_tune_placement_device times the plain pass -- the step itself, from here)
-                bi, bo, ms = self.time_step_on_pairs(cand_in, cand_out)
-            else:
-                bi, bo, ms = ctx.tune_placement([b_.data_ptr() for b_ in cand_in], [b_.data_ptr() for b_ in cand_out], B, self.flags, stream)
-            self.d_in, self.d_out = cand_in[bi], cand_out[bo]
-            self.first_in, self.first_out = (cand_in[0], cand_out[0]) if (keep_first and world == 1) else (None, None)
-            self.placement = {"how": "%s timed on every pair of %d candidate allocations for the frames and %d for the (base) "
-                                     "results (allocated frames 0, results 0, [%.0f-GB spacer,] frames 1, ...)" % (
-                                         "the step" if wl in ("pyramid", "dso") else "mdc_tune_placement_device: the launch", K, K, spacer_bytes / 1e9),
-                              "ms_frames_i_results_j": [[round(x, 4) for x in row] for row in ms], "picked_frames": bi, "picked_results": bo}
-            for k, b_ in enumerate(cand_in):
-                if k != bi and b_ is not self.first_in:
-                    b_.free()
-            for k, b_ in enumerate(cand_out):
-                if k != bo and b_ is not self.first_out:
-                    b_.free()
-            if bi == 0 and bo == 0:
-                self.first_in = self.first_out = None  # the first allocations won: nothing to time beside
-            torch.cuda.empty_cache()
-            if self.tuned is not None and (bi, bo) != (0, 0):  # the plan was measured on pair (0, 0): once more on the pair that is used
-                t = ctx.tune(self.d_in.data_ptr(), self.d_out.data_ptr(), min(B, 4096), self.flags, stream)
-                self.tuned = {"tile": [t.tile_w, t.tile_h], "frames_per_workgroup": t.frames_per_block, "candidates": t.candidates,
-                              "ms_on_%d_frames" % min(B, 4096): round(t.ms, 4)}
-                self.info = ctx.info()
-        if K > 1 and wl in ("pyramid", "dso"):
-            # the step's other large outputs, one after the other: candidates for level 1, and for the DSO step the level-0 gradient images
-            # (15.7 + 5.2 MB of the 35 MB a frame), each chosen by timing the step with everything else fixed
-            targets = [("level1", self.d_levels, 0)] + ([("dI0", self.d_dI, 0), ("abs0", self.d_abs, 0)] if wl == "dso" else [])
-            for tag, lst, idx in targets:
-                nb = lst[idx].nbytes
-                kk = max(1, min(4, int(torch.cuda.mem_get_info(dev)[0] * 0.5 // nb)))
-                if nb < (512 << 20) or kk < 2:
-                    continue
-                cands = [lst[idx]] + [Buf(nb, dev) for _ in range(kk - 1)]
-                times = []
-                for c_ in cands:
-                    lst[idx] = c_
-                    for _ in range(2):
-                        self.step()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(3):
-                        self.step()
-                    e1.record()
-                    torch.cuda.synchronize()
-                    times.append(e0.elapsed_time(e1) / 3)
-                best = int(np.argmin(times))
-                lst[idx] = cands[best]
-                for k, c_ in enumerate(cands):
-                    if k != best:
-                        c_.free()
-                self.placement["ms_per_%s_candidate" % tag] = [round(x, 4) for x in times]
-            torch.cuda.empty_cache()
         self.kernel_name = ctx.describe_launch(self.flags, self.levels if wl in ("pyramid", "dso") else 0)
         if wl == "dso":
             self.kernel_name += " + gradients_levels_kernel"
@@ -650,26 +589,6 @@ class Workload:
                 self.alg_write += 16 * sum((self.out_w >> l) * (self.out_h >> l) for l in range(self.levels))
         self.alg_frame = self.alg_read + self.alg_write
 
-    def time_step_on_pairs(self, cand_in, cand_out):
-        """what mdc_tune_placement_device does for the plain pass, for a step with more outputs (levels, gradient images, in their own fixed
-        buffers): 2 untimed + 3 timed steps on every (frames, base results) pair -> (best frames index, best results index, ms[i][j])"""
-        ms = [[0.0] * len(cand_out) for _ in cand_in]
-        best = (1e30, 0, 0)
-        for i, bi_ in enumerate(cand_in):
-            for j, bo_ in enumerate(cand_out):
-                self.d_in, self.d_out = bi_, bo_
-                for _ in range(2):
-                    self.step()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(3):
-                    self.step()
-                e1.record()
-                torch.cuda.synchronize()
-                ms[i][j] = e0.elapsed_time(e1) / 3
-                best = min(best, (ms[i][j], i, j))
-        return best[1], best[2], ms
-
     def step(self):
         if self.wl == "dso":  # base + levels + gradient images in one call (chunks chosen by the library)
             self.ctx.process_pyramid_gradients_batch(self.d_in.data_ptr(), self.d_out.data_ptr(), self.levels, [t.data_ptr() for t in self.d_levels],
@@ -681,11 +600,15 @@ class Workload:
             self.ctx.process_batch(self.d_in.data_ptr(), self.d_out.data_ptr(), self.B, self.flags, self.stream)
 
     def free(self):
-        for b in [self.d_in, self.d_out, self.first_in, self.first_out] + self.d_levels + self.d_dI + self.d_abs:
+        for b in self.d_levels + self.d_dI + self.d_abs:
             if b is not None:
                 b.free()
-        self.d_in = self.d_out = self.first_in = self.first_out = None
+        self.d_in = self.d_out = None
         self.d_levels, self.d_dI, self.d_abs = [], [], []
+        torch.cuda.synchronize()
+        if self.placed is not None:
+            self.ctx.free_placed(self.placed)
+            self.placed = None
         self.ctx.close()
         torch.cuda.empty_cache()
 
@@ -742,25 +665,6 @@ class Workload:
         kstat = [float(ktimes.mean()), float(np.median(ktimes)), float(ktimes.min())]
         per_rank = [[round(x, 4) for x in k] for k in D.gather(kstat)]
         return {"elapsed": elapsed, "steps": steps, "kstat": kstat, "per_rank_kernel_ms": per_rank, "clocks": clocks}
-
-    def timed_on_first_allocation(self, steps, warmup):
-        """The same launch on the buffers a caller gets who takes the first allocations of a fresh device as they come (torch.empty, made
-        before anything else): what the placement is worth, in the same process.  -> kernel ms (mean), or None if none were kept."""
-        from mono_dataset_code_amd import synth
-
-        if self.first_in is None and self.first_out is None:
-            return None
-        keep = (self.d_in, self.d_out)
-        self.d_in, self.d_out = self.first_in, self.first_out
-        self.preroll()
-        t = self.timed(steps, warmup)
-        self.d_in, self.d_out = keep
-        for b_ in (self.first_in, self.first_out):
-            if b_ is not keep[0] and b_ is not keep[1]:
-                b_.free()
-        self.first_in = self.first_out = None
-        torch.cuda.empty_cache()
-        return t["kstat"][0]
 
     def dump(self):
         """test hook: every rank hands out its first outputs (checked against the oracle per GLOBAL frame index)"""
@@ -939,16 +843,23 @@ def main():
     wl = args.workload
     do_ceiling = not args.no_ceiling
     clocks_idle = gpu_clock_snapshot(D.gpu)
-    H = Workload(args, D, wl, args.frames, keep_first=True)
+    H = Workload(args, D, wl, args.frames)
     head = measure(H, args.steps, args.warmup, do_ceiling, args.parity_frames, dump=True)
-    first_ms = H.timed_on_first_allocation(args.steps, args.warmup) if D.world == 1 else None
+    # every rank's buffers come from the product's allocator; its probe times (median of 5 launches of the pass over min(B, 4096) frames, on the
+    # built-in plan) on the pair it handed out and on the first two plain allocations of the device, per rank
+    place_all = D.gather([float(H.placed.ms_first), float(H.placed.ms_chosen), float(H.placed.strategy)])
     if D.rank == 0:
+        pf, pc = float(H.placed.ms_first), float(H.placed.ms_chosen)
         head["roofline"]["placement"] = {
-            "buffers": "chosen by mdc_tune_placement_device (config.placement): the time of one launch depends on the allocations it runs on, "
-                       "1.48 to 1.61 ms in one process (profiles/r05_experiments/05_*, 08_*, 10_*)",
-            "kernel_ms_on_first_allocation": round(first_ms, 4) if first_ms else None,
-            "frac_on_first_allocation": round(H.frac_of(first_ms), 4) if first_ms else None}
+            "buffers": "made by mdc_alloc_placed_device (libmdc_hip.so; config.placement says how): the time of one launch depends on the allocations it "
+                       "runs on, 1.48 to 1.61 ms in one process (profiles/r05_experiments/05_*, 08_*, 10_*; DESIGN.md 6.1)",
+            "probe_ms_on_first_allocations": round(pf, 4) if pf else None, "probe_ms_on_chosen_pair": round(pc, 4) if pc else None,
+            "frac_on_first_allocation": round(head["roofline"]["frac"] * pc / pf, 4) if pf and pc else None,
+            "frac_on_first_allocation_is": "frac x (probe on the chosen pair / probe on the first allocations): what a caller gets who takes two hipMalloc's as they come"}
     devices = D.devices() if D.active else [{"rank": 0, "device": D.gpu}]
+    for d_, pl in zip(devices, place_all):
+        d_["placement"] = {"strategy": capi.PLACE_NAMES.get(int(pl[2]), "?"), "probe_ms_on_first_allocations": round(pl[0], 4) or None,
+                           "probe_ms_on_chosen_pair": round(pl[1], 4) or None}
     # ---- the other BASELINE.json configs, timed in the same process (same box, same clocks) -------------------------
     # N = 1: configs[1] unMapImage, configs[4] pyramid, configs[3] as one 50,000-frame sequence on the one GPU.
     # N > 1: configs[3] as BASELINE.json words it -- the one sequence dealt round-robin over the ranks (strong scaling).

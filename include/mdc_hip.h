@@ -305,6 +305,39 @@ MDC_API int mdc_device_alloc(mdc_ctx* ctx, size_t bytes, void** d_ptr); /* devic
  * caller frees the losers.  Blocking, ~10 launches' time per pair.  Afterwards every output candidate holds the results of the pass. */
 MDC_API int mdc_tune_placement_device(mdc_ctx* ctx, const uint8_t* const* d_in, int n_in, float* const* d_out, int n_out, int64_t nframes,
                                       unsigned flags, void* stream, int* best_in, int* best_out, float* ms);
+/* The same as an ALLOCATOR: a frame buffer and a result buffer for `nframes` frames of the pass `flags` (sizes from the context's tables;
+ * in_bytes / out_bytes = 0: exactly that, larger values are honoured), made so that the pass runs fast on the pair -- what bench.py,
+ * libmdc_multi's callers (tests/native/multi_gpu_seq.cpp) and the reader's device-resident sequences use instead of two hipMalloc's.
+ * The context's tables for `flags` must be set (the pass itself is the probe: min(nframes, 4096) frames, 2 untimed + 5 timed launches per
+ * measurement, median).  Blocking; `stream` is used for the probes and is idle on return.  Strategies:
+ *   MDC_PLACE_FIRST   two hipMalloc's, as they come (no measurement; what AUTO does for pairs below 1 GiB, which live in the Infinity Cache);
+ *   MDC_PLACE_MALLOC  up to 6 x 6 hipMalloc'ed candidates spread over the device's memory by spacer allocations, every pair timed
+ *                     (mdc_tune_placement_device), the fastest kept, the rest freed; needs room for the candidates (else fewer, down to 1);
+ *   MDC_PLACE_VMM     both buffers assembled from 1-GiB physical pieces (hipMemCreate / hipMemMap), which are first sorted into memory classes
+ *                     by a timed linear stream against reference pieces: frames from one class, results from another.  Also fits pairs
+ *                     that leave no room for candidates (a 50,000-frame sequence).  Every address is mapped once and stays mapped until
+ *                     mdc_free_placed_device.
+ *   MDC_PLACE_AUTO    the library's default (MDC_PLACEMENT=first|malloc|vmm in the environment overrides it).
+ * ms_first = the probe on the first pair of plain allocations (what a caller gets who takes them as they come; 0 where not measured),
+ * ms_chosen = on the pair handed out.  Release with mdc_free_placed_device (waits for the device; never hipFree the pointers). */
+enum { MDC_PLACE_AUTO = 0, MDC_PLACE_FIRST = 1, MDC_PLACE_MALLOC = 2, MDC_PLACE_VMM = 3 };
+typedef struct mdc_placed_buffers {
+  uint8_t* d_in;            /* nframes frames (in_bytes) */
+  float* d_out;             /* nframes results (out_bytes) */
+  size_t in_bytes, out_bytes;
+  int64_t nframes, probe_frames;
+  int strategy;             /* the one that ran (never AUTO) */
+  int candidates_in, candidates_out, picked_in, picked_out; /* MALLOC: candidates made, pair kept */
+  float pair_ms[64];        /* MALLOC: probe time of frames candidate i on results candidate j at [i * candidates_out + j] */
+  int pieces, piece_mib;    /* VMM: physical pieces created, their size */
+  int class_count[3];       /* VMM: pieces per memory class (class of piece 0 / of the first piece fast with it / fast with both) */
+  float ms_first, ms_chosen;
+  char note[384];           /* one line for logs: what was done */
+  void* handle;             /* the allocator's own */
+} mdc_placed_buffers;
+MDC_API int mdc_alloc_placed_device(mdc_ctx* ctx, size_t in_bytes, size_t out_bytes, int64_t nframes, unsigned flags, int strategy, void* stream,
+                                    mdc_placed_buffers* out);
+MDC_API int mdc_free_placed_device(mdc_ctx* ctx, mdc_placed_buffers* buffers);
 MDC_API void mdc_device_free(mdc_ctx* ctx, void* d_ptr);
 MDC_API int mdc_copy_to_host(mdc_ctx* ctx, void* dst, const void* d_src, size_t bytes); /* blocking device -> host copy */
 

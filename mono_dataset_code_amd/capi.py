@@ -30,7 +30,7 @@ OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM = 0, -1, -2,
 HIP_SYMBOLS = [
     "mdc_create", "mdc_destroy", "mdc_device_count", "mdc_device_pci_bus_id", "mdc_last_error", "mdc_build_flags", "mdc_code_id", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
     "mdc_set_remap", "mdc_unmap_host", "mdc_undistort_host_f32", "mdc_undistort_host_u8", "mdc_process_host",
-    "mdc_process_frames_host_to_device", "mdc_process_jpeg_frames_host_to_device", "mdc_process_jpeg_streams_host_to_device", "mdc_device_alloc", "mdc_tune_placement_device", "mdc_device_free", "mdc_copy_to_host",
+    "mdc_process_frames_host_to_device", "mdc_process_jpeg_frames_host_to_device", "mdc_process_jpeg_streams_host_to_device", "mdc_device_alloc", "mdc_tune_placement_device", "mdc_alloc_placed_device", "mdc_free_placed_device", "mdc_device_free", "mdc_copy_to_host",
     "mdc_host_alloc", "mdc_host_free", "mdc_process_frames_host", "mdc_process_jpeg_frames_host", "mdc_jpeg_idct_batch_device", "mdc_process_jpeg_streams_host", "mdc_jpeg_huffman_batch_device",
     "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
     "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device",
@@ -51,6 +51,31 @@ HOST_SYMBOLS = [
     "mdch_decode_jpeg_record", "mdch_jpeg_stream", "mdch_image_alloc", "mdch_image_free",
     "mdch_image_pool_trim", "mdch_image_pool_idle_bytes",
 ]
+
+
+PLACE_AUTO, PLACE_FIRST, PLACE_MALLOC, PLACE_VMM = 0, 1, 2, 3
+PLACE_NAMES = {PLACE_AUTO: "auto", PLACE_FIRST: "first", PLACE_MALLOC: "malloc", PLACE_VMM: "vmm"}
+
+
+class PlacedBuffers(C.Structure):
+    """mdc_placed_buffers (include/mdc_hip.h)"""
+    _fields_ = [("d_in", C.c_void_p), ("d_out", C.c_void_p), ("in_bytes", C.c_size_t), ("out_bytes", C.c_size_t), ("nframes", C.c_int64),
+                ("probe_frames", C.c_int64), ("strategy", C.c_int), ("candidates_in", C.c_int), ("candidates_out", C.c_int), ("picked_in", C.c_int),
+                ("picked_out", C.c_int), ("pair_ms", C.c_float * 64), ("pieces", C.c_int), ("piece_mib", C.c_int), ("class_count", C.c_int * 3),
+                ("ms_first", C.c_float), ("ms_chosen", C.c_float), ("note", C.c_char * 384), ("handle", C.c_void_p)]
+
+    def describe(self):
+        """what was done, for a bench line / a log"""
+        d = {"strategy": PLACE_NAMES.get(self.strategy, str(self.strategy)), "how": self.note.decode(errors="replace"),
+             "probe_frames": int(self.probe_frames), "ms_on_first_allocations": round(float(self.ms_first), 4) or None,
+             "ms_on_chosen_pair": round(float(self.ms_chosen), 4) or None}
+        if self.strategy == PLACE_MALLOC and self.candidates_in > 1:
+            ki, ko = self.candidates_in, self.candidates_out
+            d["ms_frames_i_results_j"] = [[round(float(self.pair_ms[i * ko + j]), 4) for j in range(ko)] for i in range(ki)]
+            d["picked_frames"], d["picked_results"] = int(self.picked_in), int(self.picked_out)
+        if self.strategy == PLACE_VMM:
+            d["pieces"], d["piece_mib"], d["class_count"] = int(self.pieces), int(self.piece_mib), [int(x) for x in self.class_count]
+        return d
 
 
 class FovModel(C.Structure):
@@ -179,6 +204,9 @@ def hip_lib():
                                                     C.POINTER(C.c_float)]
             L.mdc_device_free.argtypes = [_vp, _vp]
             L.mdc_device_free.restype = None
+        if hasattr(L, "mdc_alloc_placed_device"):  # (absent from libraries built before round 6)
+            L.mdc_alloc_placed_device.argtypes = [_vp, _sz, _sz, _i64, C.c_uint, _i, _vp, C.POINTER(PlacedBuffers)]
+            L.mdc_free_placed_device.argtypes = [_vp, C.POINTER(PlacedBuffers)]
             L.mdc_copy_to_host.argtypes = [_vp, _vp, _vp, _sz]
         L.mdc_unmap_batch_device.argtypes = [_vp, _vp, _vp, _i64, C.c_uint, _vp]
         L.mdc_process_batch_device.argtypes = [_vp, _vp, _vp, _i64, C.c_uint, _vp]
@@ -550,6 +578,30 @@ class Context:
         ms = (C.c_float * max(ni * no, 1))()
         self._chk(self._L.mdc_tune_placement_device(self._h, a, ni, b, no, nframes, flags, stream if stream else None, C.byref(bi), C.byref(bo), ms))
         return bi.value, bo.value, [[float(ms[i * no + j]) for j in range(no)] for i in range(ni)]
+
+    def alloc_placed(self, nframes, flags, strategy=PLACE_AUTO, stream=0, in_bytes=0, out_bytes=0):
+        """A frame buffer and a result buffer for nframes frames of the pass `flags`, placed by measurement (include/mdc_hip.h:
+        mdc_alloc_placed_device).  -> PlacedBuffers; give it back with free_placed()."""
+        b = PlacedBuffers()
+        self._chk(self._L.mdc_alloc_placed_device(self._h, in_bytes, out_bytes, nframes, flags, strategy, stream if stream else None, C.byref(b)))
+        return b
+
+    def free_placed(self, b):
+        self._chk(self._L.mdc_free_placed_device(self._h, C.byref(b)))
+
+    def copy_to_host(self, d_src, count, dtype):
+        """count elements of dtype from device address d_src -> numpy array (mdc_copy_to_host: blocking)"""
+        out = np.empty(count, dtype=dtype)
+        self._chk(self._L.mdc_copy_to_host(self._h, _np_ptr(out), d_src, out.nbytes))
+        return out
+
+    def device_alloc(self, nbytes):
+        p = _vp()
+        self._chk(self._L.mdc_device_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def device_free(self, d_ptr):
+        self._L.mdc_device_free(self._h, d_ptr)
 
     def pci_bus_id(self):
         buf = C.create_string_buffer(32)

@@ -75,14 +75,21 @@ int main(int argc, char** argv) {
   const size_t npi = (size_t)W * H, npo = (size_t)w * h;
   std::vector<uint8_t*> d_in((size_t)n, (uint8_t*)0);
   std::vector<float*> d_out((size_t)n, (float*)0);
+  // every rank's frame / result buffers come from the product's allocator (mdc_alloc_placed_device, include/mdc_hip.h): a pair the pass
+  // runs fast on, found by timing the pass on this rank's device; the tables are in place (the probe needs them)
+  const unsigned flags = MDC_GAMMA | MDC_VIGNETTE | MDC_KILL_OVEREXPOSED | MDC_RECTIFY;
+  std::vector<mdc_placed_buffers> placed((size_t)n);
   for (int r = 0; r < n; r++) {
-    const size_t mine = (size_t)mdc_multi_frames_of_rank(m, total, r);
-    hipSetDevice(mdc_multi_device(m, r));
-    if (hipMalloc((void**)&d_in[(size_t)r], std::max<size_t>(1, mine * npi)) != hipSuccess ||
-        hipMalloc((void**)&d_out[(size_t)r], std::max<size_t>(1, mine * npo * sizeof(float))) != hipSuccess) {
-      std::fprintf(stderr, "hipMalloc failed on rank %d (%zu frames)\n", r, mine);
+    const long long mine = mdc_multi_frames_of_rank(m, total, r);
+    if (mine <= 0) continue;
+    if (mdc_alloc_placed_device(mdc_multi_ctx(m, r), 0, 0, mine, flags, MDC_PLACE_AUTO, mdc_multi_stream(m, r), &placed[(size_t)r]) != MDC_OK) {
+      std::fprintf(stderr, "mdc_alloc_placed_device failed on rank %d (%lld frames): %s\n", r, mine, mdc_last_error(mdc_multi_ctx(m, r)));
       return 8;
     }
+    d_in[(size_t)r] = placed[(size_t)r].d_in;
+    d_out[(size_t)r] = placed[(size_t)r].d_out;
+    std::printf("PLACEMENT rank %d device %d probe_ms_first %.4f probe_ms_chosen %.4f : %s\n", r, mdc_multi_device(m, r), placed[(size_t)r].ms_first,
+                placed[(size_t)r].ms_chosen, placed[(size_t)r].note);
   }
   // the synthetic sequence of SURVEY.md 8(d), sharded: local frame i of rank r is global frame r + i*N
   // (libmdc_bench.so, a test utility: the product libraries do not generate frames)
@@ -100,7 +107,6 @@ int main(int argc, char** argv) {
       std::fprintf(stderr, "rank %d: ncclCommCount = %d, expected %d\n", r, mdc_multi_comm_count(m, r), n);
       return 11;
     }
-  const unsigned flags = MDC_GAMMA | MDC_VIGNETTE | MDC_KILL_OVEREXPOSED | MDC_RECTIFY;
   for (int k = 0; k < 3; k++) CHECK(mdc_multi_process_sequence_device(m, d_in.data(), d_out.data(), total, flags));
   CHECK(mdc_multi_synchronize(m));
   const auto t0 = std::chrono::steady_clock::now();
@@ -122,11 +128,7 @@ int main(int argc, char** argv) {
       std::fwrite(host.data(), sizeof(float), host.size(), f);
       std::fclose(f);
     }
-  for (int r = 0; r < n; r++) {
-    hipSetDevice(mdc_multi_device(m, r));
-    hipFree(d_in[(size_t)r]);
-    hipFree(d_out[(size_t)r]);
-  }
+  for (int r = 0; r < n; r++) mdc_free_placed_device(mdc_multi_ctx(m, r), &placed[(size_t)r]);
   mdc_multi_destroy(m);
   return 0;
 }

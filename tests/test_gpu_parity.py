@@ -998,3 +998,50 @@ def test_tune_placement_picks_among_candidate_buffers(setups, oracle, torch_cuda
         s.ctx.tune_placement([], [outs[0].data_ptr()], n, flags, st)
     with pytest.raises(capi.MdcError):
         s.ctx.tune_placement([ins[0].data_ptr()], [0], n, flags, st)
+
+
+@pytest.mark.parametrize("strategy", ["first", "malloc", "vmm"])
+def test_alloc_placed_hands_out_working_buffers(setups, oracle, torch_cuda, strategy, monkeypatch):
+    """mdc_alloc_placed_device (include/mdc_hip.h): a frame buffer and a result buffer made by the product's allocator -- plain, chosen among timed
+    hipMalloc candidates, assembled from classified physical pieces -- hold the pass's bit-exact results like any other device memory, report what
+    was done, and can be given back and made again (a few rounds: the assembled ranges map and unmap physical pieces)."""
+    from mono_dataset_code_amd import capi, synth
+
+    torch = torch_cuda
+    s = setups("full_1280_to_640")
+    monkeypatch.setenv("MDC_PLACE_CANDIDATES", "2")
+    monkeypatch.setenv("MDC_PLACE_SPREAD_MB", "512")
+    monkeypatch.setenv("MDC_PLACE_PIECE_MIB", "64")
+    n, npix, nout = 600, s.W * s.H, s.w * s.h  # 0.79 GB of frames + 0.74 GB of results
+    st = torch.cuda.current_stream().cuda_stream
+    flags = capi.RECTIFY | capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED
+    which = {"first": capi.PLACE_FIRST, "malloc": capi.PLACE_MALLOC, "vmm": capi.PLACE_VMM}[strategy]
+    for rnd in range(3):
+        b = s.ctx.alloc_placed(n, flags, which, st)
+        d = b.describe()
+        assert b.strategy == which and b.d_in and b.d_out and b.in_bytes >= n * npix and b.out_bytes >= n * nout * 4 and d["how"]
+        if strategy == "malloc":
+            m = d["ms_frames_i_results_j"]
+            assert len(m) == 2 and all(0 < x < 50 for r in m for x in r) and m[d["picked_frames"]][d["picked_results"]] == min(x for r in m for x in r)
+            assert d["ms_on_first_allocations"] == m[0][0]
+        if strategy == "vmm":
+            assert d["pieces"] >= 12 + 12 and d["piece_mib"] == 64 and sum(d["class_count"]) == d["pieces"] and d["ms_on_chosen_pair"] > 0
+        s.ctx.synth_frames(b.d_in, 5 + rnd, n, npix, synth.SEED, st)
+        s.ctx.process_batch(b.d_in, b.d_out, n, flags, st)
+        torch.cuda.synchronize()
+        for f in (0, n // 2 + 1, n - 1):  # (frames that lie in different pieces of an assembled range)
+            raw = s.ctx.copy_to_host(b.d_in + f * npix, npix, np.uint8)
+            assert np.array_equal(raw, synth.noise_frames(5 + rnd + f, 1, npix)[0])
+            assert bits_equal(s.ctx.copy_to_host(b.d_out + f * nout * 4, nout, np.float32), s.want(oracle, raw, 1, 1, 1, 1))
+        s.ctx.free_placed(b)
+        assert not b.handle and not b.d_in
+        s.ctx.free_placed(b)  # giving back twice is harmless
+    small = s.ctx.alloc_placed(8, flags, capi.PLACE_AUTO, st)  # a pair that lives in the Infinity Cache: no search
+    assert small.strategy == capi.PLACE_FIRST
+    s.ctx.free_placed(small)
+    with pytest.raises(capi.MdcError):
+        s.ctx.alloc_placed(0, flags, which, st)
+    with pytest.raises(capi.MdcError):
+        s.ctx.alloc_placed(4, flags, which, st, in_bytes=100)  # smaller than four frames
+    with pytest.raises(capi.MdcError):
+        capi.Context(0).alloc_placed(4, flags, which, st)  # no tables: the pass cannot be probed

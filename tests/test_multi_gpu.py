@@ -242,21 +242,29 @@ def test_bench_over_rccl_on_real_devices(tmp_path, oracle):
 
 
 @pytest.mark.gpu
-def test_bench_chooses_its_buffers_by_measurement():
-    """bench.py allocates candidate frame / result buffers (spread by spacer allocations), has mdc_tune_placement_device time the launch on every
-    pair, runs on the fastest, and reports the matrix, the pair and the figure on the first allocations of the process beside the headline."""
-    out = _bench(["--steps", "4", "--warmup", "1", "--frames", "1024", "--placement-candidates", "3", "--placement-spread-gb", "2", "--preroll-s", "0.05",
-                  "--preroll-max-s", "0.3", "--no-cpu-baseline", "--no-secondary"])
+@pytest.mark.parametrize("strategy", ["malloc", "vmm"])
+def test_bench_takes_its_buffers_from_the_product_allocator(strategy):
+    """bench.py has no buffer search of its own: frames and results come from mdc_alloc_placed_device (libmdc_hip.so), whose report -- the
+    strategy, what it timed, the probe on the first allocations beside the probe on the pair handed out -- goes into the line."""
+    env = {"MDC_PLACE_SPREAD_MB": "2000", "MDC_PLACE_PIECE_MIB": "256"}
+    out = _bench(["--steps", "4", "--warmup", "1", "--frames", "1024", "--placement", strategy, "--placement-candidates", "3", "--preroll-s", "0.05",
+                  "--preroll-max-s", "0.3", "--no-cpu-baseline", "--no-secondary"], env=env)
     pl = out["config"]["placement"]
-    m = pl["ms_frames_i_results_j"]
-    assert len(m) == 3 and all(len(r) == 3 for r in m) and all(0 < x < 20 for r in m for x in r)
-    assert m[pl["picked_frames"]][pl["picked_results"]] == min(x for r in m for x in r)
+    assert pl["strategy"] == strategy and pl["probe_frames"] == 1024 and pl["ms_on_chosen_pair"] > 0
+    if strategy == "malloc":
+        m = pl["ms_frames_i_results_j"]
+        assert len(m) == 3 and all(len(r) == 3 for r in m) and all(0 < x < 20 for r in m for x in r)
+        assert m[pl["picked_frames"]][pl["picked_results"]] == min(x for r in m for x in r)
+    else:
+        assert sum(pl["class_count"]) == pl["pieces"] >= 11 and pl["piece_mib"] == 256
     assert out["parity"]["mismatching_pixels"] == 0 and out["parity"]["frames_checked"] == 16
     assert (out["parity"]["nan_mask_mismatches"], out["parity"]["black_pixel_mismatches"], out["parity"]["max_relative_error"]) == (0, 0, 0.0)  # SURVEY.md 8(d)
     rp = out["roofline"]["placement"]
-    if (pl["picked_frames"], pl["picked_results"]) != (0, 0):
-        assert rp["frac_on_first_allocation"] and 0.2 < rp["frac_on_first_allocation"] < 0.9
+    assert rp["probe_ms_on_chosen_pair"] == pl["ms_on_chosen_pair"]
+    if rp["probe_ms_on_first_allocations"]:
+        assert 0.2 < rp["frac_on_first_allocation"] < 0.9
+    assert out["ranks"]["devices"][0]["placement"]["strategy"] == strategy
     assert 0.2 < out["roofline"]["frac"] < 0.9
-    plain = _bench(["--steps", "4", "--warmup", "1", "--frames", "1024", "--placement-candidates", "1", "--preroll-s", "0.05", "--preroll-max-s", "0.3",
+    plain = _bench(["--steps", "4", "--warmup", "1", "--frames", "1024", "--placement", "first", "--preroll-s", "0.05", "--preroll-max-s", "0.3",
                     "--no-cpu-baseline", "--no-secondary"])
-    assert plain["config"]["placement"] == {"how": "first allocations, as they come"} and plain["parity"]["mismatching_pixels"] == 0
+    assert plain["config"]["placement"]["strategy"] == "first" and plain["parity"]["mismatching_pixels"] == 0
