@@ -31,6 +31,10 @@ MDC_API int mdcb_synth_frames_device(int device, uint8_t* d_out, int64_t first_f
 MDC_API int mdcb_ceiling_mix_device(int device, const void* d_read, int64_t read_bytes, float* d_write, int64_t write_bytes, int blocks, int span,
                             void* stream);
 
+/* A no-op kernel (`mdcb_marker_kernel`) on `stream`: bench.py --markers brackets its timed region with two of them, so that a rocprofv3
+ * kernel trace / counter collection of the run can be cut to the timed launches (tools/profile_round.py). */
+MDC_API int mdcb_marker_device(int device, int id, void* stream);
+
 /* Diagnosis (tools/mall_bracket.py): a device range of repeats * chunk_bytes virtual addresses that all map ONE physical
  * allocation of chunk_bytes (HIP virtual memory management; chunk_bytes must be a multiple of *out_granularity, which is
  * also returned on the -3 "not a whole number of pages" error).  Synchronous. */

@@ -110,6 +110,8 @@ enum { MDC_OPT_KERNEL = 1, MDC_OPT_FRAMES_PER_BLOCK = 2 /* frames a workgroup lo
           0 = automatic (on), 1 = on, 2 = off */,
        MDC_OPT_DEVICE_PIPELINE_CHUNK = 16 /* tuning: frames per chunk of the device-output pipeline (mdc_process_*_host_to_device:
           upload || decode || fused pass), 16..256; 0 = automatic (64, or MDC_PIPE_DEV_CHUNK in the environment) */,
+       MDC_OPT_DEVICE_PIPELINE_CHUNK_HINT = 17 /* the same as a HINT: what "automatic" means on this context where neither the option above
+          nor MDC_PIPE_DEV_CHUNK is set (the reader gives 128 to the contexts it runs two lanes on); 0 = no hint */,
        MDC_OPT_TAIL_TAPER = 15 /* tuning: a large launch of the tiled kernel ends on frame groups of 1/2, 1/4 and 1/8 of the
           frames per workgroup, so the slots that free up when its last long workgroups finish do not idle for a long
           workgroup's time: 0 = automatic (on), 1 = on, 2 = off */ };
@@ -508,8 +510,9 @@ typedef struct mdc_tune_result {
 MDC_API int mdc_tune_device(mdc_ctx* ctx, const uint8_t* d_in, float* d_out, int64_t nframes, unsigned flags, void* stream,
                     mdc_tune_result* result);
 
-/* Diagnostics: the kernel instantiation mdc_process_batch_device (pyramid_levels <= 1) or
- * mdc_process_pyramid_batch_device (pyramid_levels = its `levels`) launches for `flags` with the current tables and
+/* Diagnostics: the kernel instantiation mdc_process_batch_device (pyramid_levels 0 or 1),
+ * mdc_process_pyramid_batch_device (pyramid_levels = its `levels`) or mdc_undistort_batch_device_f32 (pyramid_levels = -1, flags
+ * ignored) launches for `flags` with the current tables and
  * options, spelt as rocprofv3 prints it without namespaces -- so a profile line can be matched to the kernel that ran.
  * (Measurement utilities -- the synthetic sequence generator, the linear-stream yardstick -- live in libmdc_bench.so,
  * include/mdc_bench.h: they are not part of this ABI.) */

@@ -23,6 +23,7 @@ OPT_PREFETCH_CHUNK = 12
 OPT_PREFETCH_STREAMS = 13
 OPT_ZERO_COPY = 14
 OPT_TAIL_TAPER = 15
+OPT_DEVICE_PIPELINE_CHUNK, OPT_DEVICE_PIPELINE_CHUNK_HINT = 16, 17
 ORDER_BANDS, ORDER_ROWS, ORDER_IDENTITY, ORDER_BLOCKS2D = 0, 1, 2, 3
 OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 
@@ -137,7 +138,7 @@ def _share_hip_runtime_with_torch():
 
 
 LIB_BENCH_PATH = os.path.join(_PKG, "libmdc_bench.so")
-BENCH_SYMBOLS = ["mdcb_synth_frames_device", "mdcb_ceiling_mix_device", "mdcb_alias_alloc", "mdcb_alias_free", "mdcb_chunked_alloc"]  # include/mdc_bench.h (not the product ABI)
+BENCH_SYMBOLS = ["mdcb_synth_frames_device", "mdcb_ceiling_mix_device", "mdcb_alias_alloc", "mdcb_alias_free", "mdcb_chunked_alloc", "mdcb_marker_device"]  # include/mdc_bench.h (not the product ABI)
 _bench = None
 
 
@@ -154,6 +155,7 @@ def bench_lib():
         L.mdcb_alias_alloc.argtypes = [_i, C.c_int64, _i, C.POINTER(_vp), C.POINTER(C.c_int64)]
         L.mdcb_alias_free.argtypes = [_i, _vp, C.c_int64, _i]
         L.mdcb_chunked_alloc.argtypes = [_i, C.c_int64, _i, _i, C.POINTER(_vp)]
+        L.mdcb_marker_device.argtypes = [_i, _i, _vp]
         _bench = L
     return _bench
 
@@ -612,6 +614,11 @@ class Context:
         buf = C.create_string_buffer(256)
         self._chk(self._L.mdc_describe_launch(self._h, flags, pyramid_levels, buf, 256))
         return buf.value.decode()
+
+    def marker(self, ident, stream=0):
+        """(bench utility, libmdc_bench.so) a no-op kernel named mdcb_marker_kernel on `stream`: a cut mark in a profiler's kernel trace"""
+        if bench_lib().mdcb_marker_device(self.device(), ident, stream if stream else None) != 0:
+            raise MdcError(-4, "mdcb_marker_device failed")
 
     def ceiling_mix(self, d_read, read_bytes, d_write, write_bytes, blocks=16384, span=0, stream=0):
         """(bench utility, libmdc_bench.so -- not part of the product ABI)"""

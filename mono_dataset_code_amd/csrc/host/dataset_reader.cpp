@@ -294,6 +294,7 @@ struct DatasetReader::State {
     if (lanes.empty() || !lanes[0].gpu) return;
     int have = 0;
     for (const Lane& ln : lanes) have += ln.device == lanes[0].device && ln.gpu ? 1 : 0;
+    bool made = false;
     for (; have < want; have++) {
       mdc_ctx* c = 0;
       if (mdc_create(lanes[0].device, &c) != MDC_OK || mdc_bind_objects(c, fov, photo) != MDC_OK) {
@@ -305,10 +306,14 @@ struct DatasetReader::State {
       ln.device = lanes[0].device;
       ln.twin = true;
       lanes.push_back(ln);
+      made = true;
     }
-    if (have >= 2)  // with a second call to hide a chunk's fill and drain behind, longer chunks win (Huffman: 5.3 us per frame at 128, 6.7 at 64)
+    // with a second call to hide a chunk's fill and drain behind, longer chunks win (Huffman: 5.3 us per frame at 128, 6.7 at 64).  Given ONCE,
+    // when a twin was made, and as a hint: a caller's own MDC_OPT_DEVICE_PIPELINE_CHUNK on the public context (getContext()) and
+    // MDC_PIPE_DEV_CHUNK in the environment both stay in force
+    if (made && have >= 2)
       for (Lane& ln : lanes)
-        if (ln.device == lanes[0].device && ln.gpu) (void)mdc_set_option(ln.gpu, MDC_OPT_DEVICE_PIPELINE_CHUNK, 128);
+        if (ln.device == lanes[0].device && ln.gpu) (void)mdc_set_option(ln.gpu, MDC_OPT_DEVICE_PIPELINE_CHUNK_HINT, 128);
   }
   void close_devices() {
     for (Lane& ln : lanes) {
@@ -653,14 +658,27 @@ void DatasetReader::getPrefetchStats(long* hits, long* misses) const {
   if (misses) *misses = s_->cache_misses;
 }
 
-int DatasetReader::getDeviceCount() const { return (int)s_->lanes.size(); }
+// Devices in use = the lanes getImages deals its range to (one per entry of MDC_DEVICES).  The twin contexts that getImagesDevice adds on a
+// device it already has a lane on are not devices of their own: their counters are folded into that lane's.
+int DatasetReader::getDeviceCount() const { return s_->host_lanes ? s_->host_lanes : (int)s_->lanes.size(); }
 void DatasetReader::getDeviceStats(int lane, int* device, long* frames, double* decoder_wait_s, double* gpu_call_s) const {
-  if (lane < 0 || lane >= (int)s_->lanes.size()) return;
+  if (lane < 0 || lane >= getDeviceCount()) return;
   const State::Lane& ln = s_->lanes[(size_t)lane];
+  long fr = ln.frames;
+  double tw = ln.t_wait, tg = ln.t_gpu;
+  bool first_of_device = true;
+  for (int k = 0; k < lane; k++) first_of_device = first_of_device && s_->lanes[(size_t)k].device != ln.device;
+  if (first_of_device)  // (MDC_DEVICES=0,0: two host lanes on one device -- the twins go to the first of them)
+    for (size_t k = (size_t)getDeviceCount(); k < s_->lanes.size(); k++)
+      if (s_->lanes[k].twin && s_->lanes[k].device == ln.device) {
+        fr += s_->lanes[k].frames;
+        tw += s_->lanes[k].t_wait;
+        tg += s_->lanes[k].t_gpu;
+      }
   if (device) *device = ln.device;
-  if (frames) *frames = ln.frames;
-  if (decoder_wait_s) *decoder_wait_s = ln.t_wait;
-  if (gpu_call_s) *gpu_call_s = ln.t_gpu;
+  if (frames) *frames = fr;
+  if (decoder_wait_s) *decoder_wait_s = tw;
+  if (gpu_call_s) *gpu_call_s = tg;
 }
 
 void DatasetReader::setDecodeThreads(int n) {
@@ -1103,9 +1121,11 @@ int DatasetReader::run_batch(int first, int count, bool rectify, bool removeGamm
   }
   // every lane runs to its end whatever happens in another one (an exception -- out of memory for a list of pointers -- ends
   // that lane's chunks with an error, not the process: a std::thread must not be left joinable, a lane's images must not leak)
-  auto run_lane = [&runs, &s](int l) {
+  auto run_lane = [&runs, &s](int l, bool helper_thread) {
     try {
-      if (l > 0) pin_thread_near_device(runs[(size_t)l].lane.gpu);  // a helper thread of this call: the caller's own thread (lane 0) keeps its affinity
+      // only a helper thread of this call is pinned near its GPU: the caller's own thread -- lane 0, and any lane that runs here because no
+      // thread could be made -- keeps the affinity the application gave it
+      if (helper_thread) pin_thread_near_device(runs[(size_t)l].lane.gpu);
       runs[(size_t)l].run();
     } catch (const std::exception& e) {
       runs[(size_t)l].drop_chunk_in_flight();
@@ -1120,15 +1140,15 @@ int DatasetReader::run_batch(int first, int count, bool rectify, bool removeGamm
   std::vector<std::thread> helpers;
   for (int l = 1; l < active; l++) {
     try {
-      helpers.emplace_back(run_lane, l);
+      helpers.emplace_back(run_lane, l, true);
     } catch (...) {  // no thread to be had: the lane's chunks run here, after lane 0's
       helpers.emplace_back();
     }
   }
-  run_lane(0);
+  run_lane(0, false);
   for (int l = 1; l < active; l++) {
     if (helpers[(size_t)(l - 1)].joinable()) helpers[(size_t)(l - 1)].join();
-    else run_lane(l);
+    else run_lane(l, false);
   }
   {  // `rec` dies with this call: no decode job may still point into it (a lane that ended early leaves some queued)
     std::unique_lock<std::mutex> lk(s.mu);

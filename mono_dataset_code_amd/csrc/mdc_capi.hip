@@ -522,6 +522,10 @@ int mdc_set_option(mdc_ctx* c, int option, int value) try {
       if (value != 0 && (value < 16 || value > 256)) return fail(c, MDC_ERR_ARG, "device pipeline chunk must be 0 (automatic) or 16..256 frames");
       c->opt_dev_chunk = value;
       return MDC_OK;
+    case MDC_OPT_DEVICE_PIPELINE_CHUNK_HINT:
+      if (value != 0 && (value < 16 || value > 256)) return fail(c, MDC_ERR_ARG, "device pipeline chunk hint must be 0 (none) or 16..256 frames");
+      c->opt_dev_chunk_hint = value;
+      return MDC_OK;
     case MDC_OPT_TAIL_TAPER:
       if (value < 0 || value > 2) return fail(c, MDC_ERR_ARG, "tail taper selector must be 0 (automatic), 1 (on) or 2 (off)");
       c->opt_taper = value;
@@ -1073,7 +1077,14 @@ int mdc_describe_launch(mdc_ctx* c, unsigned flags, int pyramid_levels, char* bu
   bool g, v, o;
   normalise(c, flags, g, v, o);
   char tmp[160];
-  if (!(flags & MDC_RECTIFY)) {
+  if (pyramid_levels == -1) {  // undistort<float> (mdc_undistort_batch_device_f32): its own plan, no LUT, no vignette
+    if (!c->valid_remap) return fail(c, MDC_ERR_STATE, "no remap set (UndistorterFOV invalid)");
+    const mdc_ctx::SrcPlan& p = c->plan[1];
+    if (p.tiled && c->opt_kernel != MDC_KERNEL_GATHER)
+      snprintf(tmp, sizeof tmp, "remap_tiled_kernel<false, %s, false, true, %d, %d, %d>", c->n_black > 0 ? "true" : "false", p.tile_w,
+               tile_threads(p.tile_w, p.tile_h), p.nbuf);
+    else snprintf(tmp, sizeof tmp, "remap_gather_f32_kernel");
+  } else if (!(flags & MDC_RECTIFY)) {
     const int fw = c->in_w > 0 ? c->in_w : c->rm_in_w, fh = c->in_h > 0 ? c->in_h : c->rm_in_h;
     snprintf(tmp, sizeof tmp, "%s<%s>", ((int64_t)fw * fh) % 4 == 0 ? "unmap_xpose_kernel" : "unmap_scalar_kernel", v ? "true" : "false");
   } else if (!c->valid_remap) {

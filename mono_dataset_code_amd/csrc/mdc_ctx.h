@@ -109,6 +109,7 @@ struct mdc_ctx {
   int opt_prefetch_streams = 0;  // MDC_OPT_PREFETCH_STREAMS: 0 = automatic (2), 1, 2
   int opt_prefetch_chunk = 0;  // MDC_OPT_PREFETCH_CHUNK: frames per prefetched chunk of the strip path; 0 = automatic, -1 = no prefetch
   int opt_dev_chunk = 0;   // MDC_OPT_DEVICE_PIPELINE_CHUNK: 0 = automatic
+  int opt_dev_chunk_hint = 0;  // MDC_OPT_DEVICE_PIPELINE_CHUNK_HINT: what automatic means here (below the option and the environment)
   int opt_two_stage = 0;   // MDC_OPT_TWO_STAGE: 0 = automatic (strip kernel by source pixels per output), 1 = strip kernel whenever
                            // plannable, 2 = never
 

@@ -163,6 +163,11 @@ int mdc_distort_points_host(mdc_ctx* c, const mdc_fov_model* model, float* x, fl
   ReadLock lk(c->mu);
   DeviceGuard dg(c->device);
   const size_t bytes = (size_t)n * sizeof(float);
+  // Results reach the caller's arrays only after everything succeeded: a failure half way (x copied back, y not) would leave a
+  // caller that falls back to its own loop (UndistorterFOV::distortCoordinates) distorting x a second time.  The landing buffers
+  // are declared BEFORE the slot lease: on an early return the lease's destructor drains the stream first (a copy into them may
+  // still be in flight), only then do they go away.
+  std::vector<float> hx((size_t)n), hy((size_t)n);
   SlotLease slot(c);
   if (!slot.s) return MDC_ERR_HIP;
   int rc = ensure_stage(c, slot.s, bytes, bytes);
@@ -173,9 +178,6 @@ int mdc_distort_points_host(mdc_ctx* c, const mdc_fov_model* model, float* x, fl
   MDC_HIP(c, hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, st));
   MDC_HIP(c, hipMemcpyAsync(dy, y, bytes, hipMemcpyHostToDevice, st));
   MDC_HIP(c, launch_distort_points(dx, dy, n, distort_model(model), st));
-  // Results reach the caller's arrays only after everything succeeded: a failure half way (x copied back, y not) would leave a
-  // caller that falls back to its own loop (UndistorterFOV::distortCoordinates) distorting x a second time.
-  std::vector<float> hx((size_t)n), hy((size_t)n);
   MDC_HIP(c, hipMemcpyAsync(hx.data(), dx, bytes, hipMemcpyDeviceToHost, st));
   MDC_HIP(c, hipMemcpyAsync(hy.data(), dy, bytes, hipMemcpyDeviceToHost, st));
   MDC_HIP(c, hipStreamSynchronize(st));

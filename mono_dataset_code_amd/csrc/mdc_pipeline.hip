@@ -144,11 +144,12 @@ struct PipelineCall {
     if (dev) {  // results stay in HBM: nothing to map, frames go up by copy; chunks of 64 frames (MDC_PIPE_DEV_CHUNK: 16..256) -- the
       // way out costs nothing now, and the Huffman launch's time per frame falls with the frames per launch (6.7 us at 64, 4.1 at 256)
       zc_in = zc_out = false;
-      static const int dev_chunk = [] {
+      static const int env_chunk = [] {
         const char* e = getenv("MDC_PIPE_DEV_CHUNK");
-        return e ? std::max(16, std::min(256, atoi(e))) : 64;
+        return e ? std::max(16, std::min(256, atoi(e))) : 0;
       }();
-      chunk = c->opt_dev_chunk ? c->opt_dev_chunk : dev_chunk;
+      // the caller's option, else the environment, else the context's hint (MDC_OPT_DEVICE_PIPELINE_CHUNK_HINT), else 64
+      chunk = c->opt_dev_chunk ? c->opt_dev_chunk : env_chunk ? env_chunk : c->opt_dev_chunk_hint ? c->opt_dev_chunk_hint : 64;
       return;
     }
     zc_out = nframes > 0 && !strm;

@@ -56,6 +56,15 @@ CAMERAS = {
     "pyr_whole_black": (("0.349153 0.436593 0.493140 0.499021 0.933271", "320 256", "full", "192 128"), 16),
     # BASELINE.json configs[4]: rectify 1280x1024 -> 1280x1024, the base of the 4-level pyramid (bench.py --workload pyramid)
     "full_1280_to_1280": (("0.349153 0.436593 0.493140 0.499021 0.933271", "1280 1024", "0.4 0.53 0.5 0.5 0", "1280 1024"), 16),
+    # full-size cameras beyond the bench's one: `crop`, `full` (black border outputs: the BLACK instantiations of the
+    # 1024-thread tiles), a pinhole (omega = 0), the wide lens of the public dataset's other camera (recalled, not in /root/reference:
+    # a representative synthetic line), and output sizes whose last tile column is ragged (752 = 5 x 128 + 112, 1000 = 7 x 128 + 104)
+    "full_1280_crop": (("0.349153 0.436593 0.493140 0.499021 0.933271", "1280 1024", "crop", "640 480"), 16),
+    "full_1280_full_black": (("0.349153 0.436593 0.493140 0.499021 0.933271", "1280 1024", "full", "640 480"), 16),
+    "full_1280_pinhole": (("0.5 0.6 0.5 0.5 0", "1280 1024", "crop", "640 480"), 8),
+    "full_1280_wide": (("0.535719 0.669567 0.493249 0.500409 0.897966", "1280 1024", "crop", "640 480"), 16),
+    "full_1280_to_752": (("0.349153 0.436593 0.493140 0.499021 0.933271", "1280 1024", "0.4 0.53 0.5 0.5 0", "752 480"), 16),
+    "full_1280_to_1000": (("0.535719 0.669567 0.493249 0.500409 0.897966", "1280 1024", "full", "1000 700"), 16),
     # magnifying remap (output larger than input)
     "upsample": (("0.349153 0.436593 0.493140 0.499021 0.5", "160 128", "crop", "320 256"), 16),
     # two-stage kernel cases: a magnifying 'full' remap made of whole 128x16 / 64x32 tiles with a wide black border (0.45-0.49

@@ -258,6 +258,86 @@ def test_full_size_flag_matrix_against_the_reference_build(name, calib_dirs, ref
     ctx.close()
 
 
+FULL_SIZE_CAMERAS = ["full_1280_crop", "full_1280_full_black", "full_1280_pinhole", "full_1280_wide", "full_1280_to_752", "full_1280_to_1000"]
+
+
+@pytest.mark.parametrize("name", FULL_SIZE_CAMERAS)
+def test_full_size_other_cameras_against_the_reference_build(name, calib_dirs, ref, torch_cuda):
+    """1280x1024 frames through cameras other than the bench's: `crop`, `full` (black outputs), a pinhole, a wide lens, ragged last tile
+    columns -- the output-K selection of src/FOVUndistorter.cpp:144-218 and the border rules of :235-251 at full size.  All 16 getImage
+    switch combinations x {noise, smooth + blobs, all-255, all-0} on the library's own plan, then the rectifying combinations again on the
+    128 x 32 and 128 x 16 tile plans set explicitly and on the plan mdc_tune_device picks, each against the REFERENCE BUILD bit for bit."""
+    from mono_dataset_code_amd import capi, synth
+
+    torch = torch_cuda
+    d = calib_dirs[name]
+    cam, pc, vg = os.path.join(d, "camera.txt"), os.path.join(d, "pcalib.txt"), os.path.join(d, "vignette.png")
+    rfov = ref.fov(cam)
+    W, H, w, h = rfov.dims()
+    assert (W, H) == (1280, 1024) and rfov.is_valid()
+    rphoto = ref.photo(pc, vg, W, H)
+    fov, photo = capi.UndistorterFOV(cam), capi.PhotometricUndistorter(pc, vg, W, H)
+    assert fov.has_gpu() and photo.has_gpu() and fov.dims() == (W, H, w, h)
+    ctx = capi.Context(0)
+    ctx.bind(fov, photo)
+    info = ctx.info()
+    if name == "full_1280_full_black":
+        assert info.n_black > 0  # the point of this camera
+    frames = np.stack(make_frames(W, H, n_noise=1))
+    n = len(frames)
+    d_in = torch.from_numpy(frames).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    wants = {}
+
+    def want(f, rect, g, v, o):
+        key = (f, rect, g, v, o)
+        if key not in wants:
+            wants[key] = ref.get_image(rfov, rphoto, frames[f].copy(), rect, g, v, o)
+        return wants[key]
+
+    def check(combos, tag):
+        for rect, g, v, o in combos:
+            flags = (capi.RECTIFY * rect) | (capi.GAMMA * g) | (capi.VIGNETTE * v) | (capi.KILL_OVEREXPOSED * o)
+            nout = w * h if rect else W * H
+            d_out = torch.full((n, nout), -7.0, dtype=torch.float32, device="cuda")
+            ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), n, flags, st)
+            torch.cuda.synchronize()
+            got = d_out.cpu().numpy()
+            for f in range(n):
+                assert bits_equal(got[f], want(f, rect, g, v, o)), (name, tag, f, rect, g, v, o)
+
+    check(list(itertools.product((0, 1), repeat=4)), "library plan %dx%d tiled=%d strip=%d" % (info.tile_w, info.tile_h, info.tiled, info.two_stage))
+    rectifying = [(1, 1, 1, 1), (1, 0, 0, 0), (1, 1, 0, 0), (1, 0, 0, 1)]
+    ran = []
+    for cols, rows in ((128, 32), (128, 16), (64, 32)):
+        ctx.set_option(capi.OPT_TILE_COLS, cols)
+        ctx.set_option(capi.OPT_TILE_ROWS, rows)
+        i2 = ctx.info()
+        if i2.tiled and (i2.tile_w, i2.tile_h) == (cols, rows) and not i2.two_stage:
+            ran.append((cols, rows))
+            check(rectifying, "plan %dx%d" % (cols, rows))
+    if name in ("full_1280_crop", "full_1280_full_black", "full_1280_to_752"):
+        assert (128, 32) in ran and (128, 16) in ran, ran  # the 2x-downscaling cameras take both headline shapes
+    ctx.set_option(capi.OPT_TILE_COLS, 0)
+    ctx.set_option(capi.OPT_TILE_ROWS, 0)
+    if ctx.info().tiled and not ctx.info().two_stage:
+        nb = 192  # the tuner wants a batch: noise frames, results checked on the first four (which are `frames`)
+        big = torch.empty(nb * W * H, dtype=torch.uint8, device="cuda")
+        big[:n * W * H] = d_in.view(-1)
+        ctx.synth_frames(big.data_ptr() + n * W * H, 100, nb - n, W * H, synth.SEED, st)
+        out = torch.empty(nb * w * h, dtype=torch.float32, device="cuda")
+        t = ctx.tune(big.data_ptr(), out.data_ptr(), nb, capi.RECTIFY | capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED, st)
+        assert t.candidates >= 1
+        ctx.process_batch(big.data_ptr(), out.data_ptr(), nb, capi.RECTIFY | capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED, st)
+        torch.cuda.synchronize()
+        got = out.view(nb, w * h)[:n].cpu().numpy()
+        for f in range(n):
+            assert bits_equal(got[f], want(f, 1, 1, 1, 1)), (name, "tuned plan %dx%d fpb %d" % (t.tile_w, t.tile_h, t.frames_per_block), f)
+        del big, out
+        check(rectifying, "tuned plan %dx%d" % (t.tile_w, t.tile_h))
+    ctx.close()
+
+
 def test_full_size_config_and_properties(setups, oracle, torch_cuda):
     """BASELINE.json configs[1]/[2] at full size: oracle on 3 frames, then
     size-independent properties on a 64-frame batch."""

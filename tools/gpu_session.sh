@@ -14,7 +14,7 @@
 #   bench            plain `python bench.py` (the driver's command) -> bench.json
 #   pyramid_alone    bench.py --workload pyramid in its own process (against the secondary entry of `bench`)
 #   bench2           `python bench.py --gpus 2` without torchrun (gloo, shared GPU)
-#   profile          tools/profile_bench.sh for the four workloads (rocprofv3 --stats + FETCH_SIZE / WRITE_SIZE passes)
+#   profile          tools/profile_round.py: rocprofv3 --kernel-trace --stats + FETCH_SIZE / WRITE_SIZE passes of bench.py's workloads, cut to the timed region
 #   pipe_trace       per-chunk time stamps of the JPEG-stream pipeline (upload / Huffman done / decoded / output) on a 256-frame getImages
 #   soak             reader soak (one lane, two lanes), tiled-kernel soak, 8-thread soak
 #   reader2          the reader's rates with two lanes on the one GPU (MDC_DEVICES=0,0)
@@ -130,12 +130,9 @@ PY
       MDC_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 20 --warmup 3 > "$OUT/bench_gpus2_gloo.json" 2> "$OUT/bench_gpus2_gloo.err"; echo "rc=$?"
       tail -c 1500 "$OUT/bench_gpus2_gloo.json"; echo
       timeout 120 python bench.py --gpus 8 > "$OUT/bench_gpus8_refused.txt" 2>&1; echo "--gpus 8 on this box: rc=$?"; tail -2 "$OUT/bench_gpus8_refused.txt" ;;
-    profile)
-      for wl in fused unmap pyramid seq50k; do
-        extra=""; [ $wl = unmap ] && extra="--frames 1024"
-        timeout 600 bash tools/profile_bench.sh ${TAG}_$wl --workload $wl $extra > "$OUT/profile_$wl.txt" 2>&1
-        tail -3 "$OUT/profile_$wl.txt"
-      done ;;
+    profile)  # the round's rocprofv3 evidence, one session of one build: tools/profile_round.py (PROFILE_WLS="fused unmap ...")
+      timeout ${PROFILE_TIMEOUT:-2400} python3 tools/profile_round.py ${PROFILE_TAG:-$TAG} ${PROFILE_WLS:-} > "$OUT/profile_round.txt" 2>&1
+      grep -av amdgpu.ids "$OUT/profile_round.txt" | tail -12 | cut -c1-400 ;;
     pipe_trace)
       MDC_TRACE_ENV=MDC_PIPE_TRACE=1 timeout 600 python tools/reader_trace.py 256 3 batch > "$OUT/pipe_trace.txt" 2>&1
       grep -a "chunks, ms since" "$OUT/pipe_trace.txt" | tail -3; grep -a "READER_RATE /\|READER_RATE r" "$OUT/pipe_trace.txt" | tail -2 ;;
@@ -196,6 +193,16 @@ for r in rows:
     print("%-62s calls %5s  avg %8.1f us  total %8.2f ms  %5.1f %%" % (m.group(0) if m else r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, 100 * float(r["TotalDurationNs"]) / tot))
 PY
       ;;
+    placed)  # the headline launch on buffers from the product's allocator, one strategy / setting per process (PLACED_CFGS="strategy:piece MiB:compose:rounds[:frames] ...")
+      for cfg in ${PLACED_CFGS:-first:0:0:1 malloc:0:0:1 vmm:1024:0:1 vmm:1024:1:1 vmm:1024:2:1 vmm:256:0:1 vmm:256:2:1 vmm:64:2:1}; do
+        IFS=: read -r strat piece comp rounds frames <<< "$cfg"
+        MDC_PLACE_PIECE_MIB=${piece:-1024} MDC_PLACE_COMPOSE=${comp:-0} timeout ${PLACED_TIMEOUT:-400} python tools/placed_probe.py $strat ${rounds:-1} ${frames:-4096} >> "$OUT/placed_probe.txt" 2>&1
+        echo "rc=$? ($cfg)" >> "$OUT/placed_probe.txt"
+      done
+      grep -a "PLACED\|rc=\|fault\|Error\|^   " "$OUT/placed_probe.txt" | cut -c1-420 ;;
+    power)   # power / clocks / launch time per library build (tools/power_ab.py; LIBS="lutrep16 fake1 ...")
+      libs=default; for l in ${LIBS:-lutrep16 lutrep8 fake1 fake2 skipstore skipload padvalu64}; do libs="$libs,mono_dataset_code_amd/variants/libmdc_hip_$l.so"; done
+      timeout 600 python tools/power_ab.py --libs "$libs" --rounds ${ROUNDS:-3} ${POWER_ARGS:-} > "$OUT/power_ab.txt" 2>&1; grep -av amdgpu.ids "$OUT/power_ab.txt" | tail -14 | cut -c1-330 ;;
     distort) timeout 300 python tools/distort_rate.py > "$OUT/distort_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/distort_rate.txt" | tail -5 ;;
     vcal)    timeout 600 python tools/vcal_rate.py > "$OUT/vcal_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/vcal_rate.txt" | tail -20 ;;
     *) echo "unknown stage $stage" ;;
