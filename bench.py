@@ -573,14 +573,24 @@ class Workload:
             ctx.unmap_batch(raw_ptr, self.d_in.data_ptr(), B, self.flags & ~capi.RECTIFY, stream)
         self.levels, self.d_levels = 4, []
         self.d_dI, self.d_abs = [], []
-        def out_floats(count, tag):
-            return Buf(count * 4, dev)
-
+        # the step's further outputs (config 5's levels, the DSO hand-off's gradient images): from the product's allocator too where the pair
+        # was assembled (mdc_alloc_striped_set_device: every buffer striped over the device's memory classes), else plain allocations
+        counts = []
         if wl in ("pyramid", "dso"):
-            self.d_levels = [out_floats(B * (self.out_w >> l) * (self.out_h >> l), "level%d" % l) for l in range(1, self.levels)]
+            counts += [B * (self.out_w >> l) * (self.out_h >> l) for l in range(1, self.levels)]
         if wl == "dso":  # per level: (I, dx, dy) triples + absSquaredGrad
-            self.d_dI = [out_floats(B * (self.out_w >> l) * (self.out_h >> l) * 3, "dI%d" % l) for l in range(self.levels)]
-            self.d_abs = [out_floats(B * (self.out_w >> l) * (self.out_h >> l), "abs%d" % l) for l in range(self.levels)]
+            counts += [B * (self.out_w >> l) * (self.out_h >> l) * 3 for l in range(self.levels)] + [B * (self.out_w >> l) * (self.out_h >> l) for l in range(self.levels)]
+        self.extra = None
+        if counts and self.placed.strategy == capi.PLACE_VMM:
+            self.extra = ctx.alloc_striped_set([4 * n_ for n_ in counts], stream)
+            bufs = [Buf(4 * n_, ptr=self.extra.d_ptr[k], ctx=ctx) for k, n_ in enumerate(counts)]
+            self.placement["further_outputs"] = self.extra.note.decode(errors="replace")
+        else:
+            bufs = [Buf(4 * n_, dev) for n_ in counts]
+        if wl in ("pyramid", "dso"):
+            self.d_levels = bufs[:self.levels - 1]
+        if wl == "dso":
+            self.d_dI, self.d_abs = bufs[self.levels - 1:2 * self.levels - 1], bufs[2 * self.levels - 1:]
         if os.environ.get("MDC_BENCH_DEBUG_BUFFERS"):  # where every buffer lies (a GPU memory fault names an address)
             for name, b in [("in", self.d_in), ("out", self.d_out)] + [("level%d" % (i + 1), b) for i, b in enumerate(self.d_levels)] + \
                     [("dI%d" % i, b) for i, b in enumerate(self.d_dI)] + [("abs%d" % i, b) for i, b in enumerate(self.d_abs)]:
@@ -624,6 +634,9 @@ class Workload:
         self.d_in = self.d_out = self.d_raw = None
         self.d_levels, self.d_dI, self.d_abs = [], [], []
         torch.cuda.synchronize()
+        if self.extra is not None:
+            self.ctx.free_striped_set(self.extra)
+            self.extra = None
         if self.placed is not None:
             self.ctx.free_placed(self.placed)
             self.placed = None

@@ -315,10 +315,10 @@ MDC_API int mdc_tune_placement_device(mdc_ctx* ctx, const uint8_t* const* d_in, 
  *   MDC_PLACE_FIRST   two hipMalloc's, as they come (no measurement; what AUTO does for pairs below 1 GiB, which live in the Infinity Cache);
  *   MDC_PLACE_MALLOC  up to 6 x 6 hipMalloc'ed candidates spread over the device's memory by spacer allocations, every pair timed
  *                     (mdc_tune_placement_device), the fastest kept, the rest freed; needs room for the candidates (else fewer, down to 1);
- *   MDC_PLACE_VMM     both buffers assembled from 1-GiB physical pieces (hipMemCreate / hipMemMap), which are first sorted into memory classes
- *                     by a timed linear stream against reference pieces: frames from one class, results from another.  Also fits pairs
- *                     that leave no room for candidates (a 50,000-frame sequence).  Every address is mapped once and stays mapped until
- *                     mdc_free_placed_device.
+ *   MDC_PLACE_VMM     both buffers assembled from 512-MiB physical pieces (hipMemCreate / hipMemMap), which are first sorted into the
+ *                     device's three memory classes by a timed linear stream against reference pieces; every buffer is then striped over
+ *                     all classes in equal shares (64-MiB stripes).  Also fits pairs that leave no room for candidates (a 50,000-frame
+ *                     sequence).  An address a kernel may know stays mapped until mdc_free_placed_device.
  *   MDC_PLACE_AUTO    the library's default (MDC_PLACEMENT=first|malloc|vmm in the environment overrides it).
  * ms_first = the probe on the first pair of plain allocations (what a caller gets who takes them as they come; 0 where not measured),
  * ms_chosen = on the pair handed out.  Release with mdc_free_placed_device (waits for the device; never hipFree the pointers). */
@@ -340,6 +340,23 @@ typedef struct mdc_placed_buffers {
 MDC_API int mdc_alloc_placed_device(mdc_ctx* ctx, size_t in_bytes, size_t out_bytes, int64_t nframes, unsigned flags, int strategy, void* stream,
                                     mdc_placed_buffers* out);
 MDC_API int mdc_free_placed_device(mdc_ctx* ctx, mdc_placed_buffers* buffers);
+/* The further buffers of a step that writes more than one result per frame -- the pyramid levels of mdc_process_pyramid_batch_device, the
+ * gradient images of mdc_process_pyramid_gradients_batch_device -- made the way MDC_PLACE_VMM makes the pair: n buffers of bytes[k], every
+ * one striped over the device's memory classes in equal shares (no probe pass, no tables needed).  Where the device has no virtual memory
+ * management (or MDC_PLACEMENT=first / malloc): n plain allocations, `strategy` says which.  Release with mdc_free_striped_set_device. */
+#define MDC_STRIPED_SET_MAX 16
+typedef struct mdc_striped_set {
+  int n;
+  void* d_ptr[MDC_STRIPED_SET_MAX];
+  size_t bytes[MDC_STRIPED_SET_MAX];
+  int strategy;            /* MDC_PLACE_VMM or MDC_PLACE_FIRST */
+  int pieces, piece_mib;
+  int class_count[3];
+  char note[384];
+  void* handle;
+} mdc_striped_set;
+MDC_API int mdc_alloc_striped_set_device(mdc_ctx* ctx, int n, const size_t* bytes, void* stream, mdc_striped_set* out);
+MDC_API int mdc_free_striped_set_device(mdc_ctx* ctx, mdc_striped_set* set);
 MDC_API void mdc_device_free(mdc_ctx* ctx, void* d_ptr);
 MDC_API int mdc_copy_to_host(mdc_ctx* ctx, void* dst, const void* d_src, size_t bytes); /* blocking device -> host copy */
 

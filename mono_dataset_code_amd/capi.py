@@ -31,7 +31,7 @@ OK, ERR_ARG, ERR_STATE, ERR_SIZE, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM = 0, -1, -2,
 HIP_SYMBOLS = [
     "mdc_create", "mdc_destroy", "mdc_device_count", "mdc_device_pci_bus_id", "mdc_last_error", "mdc_build_flags", "mdc_code_id", "mdc_get_info", "mdc_set_option", "mdc_set_photometric",
     "mdc_set_remap", "mdc_unmap_host", "mdc_undistort_host_f32", "mdc_undistort_host_u8", "mdc_process_host",
-    "mdc_process_frames_host_to_device", "mdc_process_jpeg_frames_host_to_device", "mdc_process_jpeg_streams_host_to_device", "mdc_device_alloc", "mdc_tune_placement_device", "mdc_alloc_placed_device", "mdc_free_placed_device", "mdc_device_free", "mdc_copy_to_host",
+    "mdc_process_frames_host_to_device", "mdc_process_jpeg_frames_host_to_device", "mdc_process_jpeg_streams_host_to_device", "mdc_device_alloc", "mdc_tune_placement_device", "mdc_alloc_placed_device", "mdc_free_placed_device", "mdc_alloc_striped_set_device", "mdc_free_striped_set_device", "mdc_device_free", "mdc_copy_to_host",
     "mdc_host_alloc", "mdc_host_free", "mdc_process_frames_host", "mdc_process_jpeg_frames_host", "mdc_jpeg_idct_batch_device", "mdc_process_jpeg_streams_host", "mdc_jpeg_huffman_batch_device",
     "mdc_unmap_batch_device", "mdc_process_batch_device", "mdc_undistort_batch_device_f32",
     "mdc_pyramid_batch_device", "mdc_process_pyramid_batch_device",
@@ -77,6 +77,12 @@ class PlacedBuffers(C.Structure):
         if self.strategy == PLACE_VMM:
             d["pieces"], d["piece_mib"], d["class_count"] = int(self.pieces), int(self.piece_mib), [int(x) for x in self.class_count]
         return d
+
+
+class StripedSet(C.Structure):
+    """mdc_striped_set (include/mdc_hip.h)"""
+    _fields_ = [("n", C.c_int), ("d_ptr", C.c_void_p * 16), ("bytes", C.c_size_t * 16), ("strategy", C.c_int), ("pieces", C.c_int), ("piece_mib", C.c_int),
+                ("class_count", C.c_int * 3), ("note", C.c_char * 384), ("handle", C.c_void_p)]
 
 
 class FovModel(C.Structure):
@@ -209,6 +215,8 @@ def hip_lib():
         if hasattr(L, "mdc_alloc_placed_device"):  # (absent from libraries built before round 6)
             L.mdc_alloc_placed_device.argtypes = [_vp, _sz, _sz, _i64, C.c_uint, _i, _vp, C.POINTER(PlacedBuffers)]
             L.mdc_free_placed_device.argtypes = [_vp, C.POINTER(PlacedBuffers)]
+            L.mdc_alloc_striped_set_device.argtypes = [_vp, _i, C.POINTER(_sz), _vp, C.POINTER(StripedSet)]
+            L.mdc_free_striped_set_device.argtypes = [_vp, C.POINTER(StripedSet)]
             L.mdc_copy_to_host.argtypes = [_vp, _vp, _vp, _sz]
         L.mdc_unmap_batch_device.argtypes = [_vp, _vp, _vp, _i64, C.c_uint, _vp]
         L.mdc_process_batch_device.argtypes = [_vp, _vp, _vp, _i64, C.c_uint, _vp]
@@ -590,6 +598,17 @@ class Context:
 
     def free_placed(self, b):
         self._chk(self._L.mdc_free_placed_device(self._h, C.byref(b)))
+
+    def alloc_striped_set(self, sizes, stream=0):
+        """len(sizes) device buffers, each striped over the device's memory classes (include/mdc_hip.h: mdc_alloc_striped_set_device)
+        -> StripedSet (d_ptr[k] = buffer k); give it back with free_striped_set()."""
+        b = StripedSet()
+        arr = (_sz * len(sizes))(*[int(x) for x in sizes])
+        self._chk(self._L.mdc_alloc_striped_set_device(self._h, len(sizes), arr, stream if stream else None, C.byref(b)))
+        return b
+
+    def free_striped_set(self, b):
+        self._chk(self._L.mdc_free_striped_set_device(self._h, C.byref(b)))
 
     def copy_to_host(self, d_src, count, dtype):
         """count elements of dtype from device address d_src -> numpy array (mdc_copy_to_host: blocking)"""

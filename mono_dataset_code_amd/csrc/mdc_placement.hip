@@ -67,15 +67,15 @@ struct Arena {
   // hipMalloc strategies
   void* m_in = nullptr;
   void* m_out = nullptr;
+  std::vector<void*> plain;  // a set's plain allocations
   // assembled ranges
   std::vector<hipMemGenericAllocationHandle_t> handles;
   size_t piece = 0;
   void* probe_va = nullptr;  // handles.size() pieces, creation order
-  size_t probe_mapped = 0;   // pieces mapped there
   void* in_va = nullptr;
-  size_t in_pieces = 0, in_mapped = 0;
   void* out_va = nullptr;
-  size_t out_pieces = 0, out_mapped = 0;
+  std::vector<std::pair<void*, size_t>> mapped;    // every hipMemMap that succeeded (address, size): undone one by one at the end
+  std::vector<std::pair<void*, size_t>> reserved;  // every hipMemAddressReserve
 };
 
 void release_arena(Arena* a) {
@@ -84,15 +84,11 @@ void release_arena(Arena* a) {
   (void)hipDeviceSynchronize();  // nothing may still touch a range that is about to lose its pages
   if (a->m_in) (void)hipFree(a->m_in);
   if (a->m_out) (void)hipFree(a->m_out);
-  auto unmap = [&](void* va, size_t mapped, size_t reserved) {
-    if (!va) return;
-    for (size_t k = 0; k < mapped; k++) (void)hipMemUnmap(static_cast<char*>(va) + k * a->piece, a->piece);
-    (void)hipMemAddressFree(va, reserved * a->piece);
-  };
-  unmap(a->in_va, a->in_mapped, a->in_pieces);
-  unmap(a->out_va, a->out_mapped, a->out_pieces);
-  unmap(a->probe_va, a->probe_mapped, a->handles.size());
-  for (hipMemGenericAllocationHandle_t h : a->handles) (void)hipMemRelease(h);  // after the last mapping is gone
+  for (void* p : a->plain) (void)hipFree(p);
+  for (size_t k = a->mapped.size(); k-- > 0;) (void)hipMemUnmap(a->mapped[k].first, a->mapped[k].second);
+  for (size_t k = a->reserved.size(); k-- > 0;) (void)hipMemAddressFree(a->reserved[k].first, a->reserved[k].second);
+  for (hipMemGenericAllocationHandle_t h : a->handles)
+    if (h) (void)hipMemRelease(h);  // after the last mapping is gone
   (void)hipDeviceSynchronize();
   delete a;
 }
@@ -240,6 +236,236 @@ int place_malloc(mdc_ctx* c, Arena* a, size_t in_bytes, size_t out_bytes, size_t
 }
 
 // ---- strategy: ranges assembled from classified physical pieces -----------------------------------------------------------
+// What the classes are (profiles/r06_experiments/02_*): a device's memory falls into THREE classes of a third of its size each (244 pieces
+// of 1 GiB: 86 / 84 / 74), handed out by the driver in runs of whole GiB -- the signature of the three ranks (stack IDs) of a 12-high
+// HBM3E stack selected by high physical address bits.  Ranks share a channel's data bus but have their own banks: the hundreds of
+// row-sized streams of a launch (a workgroup's output rows, its source windows) conflict in the banks of ONE rank far more often than
+// when they are spread over all three.  Hence the composition: EVERY range is striped over all classes in equal shares, in stripes
+// far smaller than the part of a range a launch works on at one time (measured: 0.66-0.67 of 8 TB/s for the headline against 0.63-0.64 for
+// the best pair of plain allocations and 0.58-0.60 for the first pair; frames in one class and results in another: 0.63).
+struct Range {
+  size_t bytes = 0, pieces = 0;
+  void* va = nullptr;
+  std::vector<size_t> piece_ids;
+};
+
+int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_t s, Events& ev, int* n_cls_out, int* pieces_out, int* piece_mib_out,
+                    char* note, size_t note_cap) {
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = c->device;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) {
+    (void)hipGetLastError();
+    return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: no virtual memory management on this device");
+  }
+  // pieces of 2 GiB ended in GPU memory faults (profiles/r06_experiments/02_*): 1 GiB at most
+  size_t piece = (size_t)std::min(1024, std::max(2, env_int(getenv("MDC_PLACE_PIECE_MIB"), 512))) << 20;
+  piece = (piece + gran - 1) / gran * gran;
+  a->piece = piece;
+  size_t need = 0;
+  for (Range& r : ranges) {
+    r.pieces = (r.bytes + piece - 1) / piece;
+    need += r.pieces;
+  }
+  const int compose = env_int(getenv("MDC_PLACE_COMPOSE"), 0);  // 0 = every range striped over all classes (the product), 1 = creation order,
+                                                                // no classification, 2 = range k in class k mod 3 (diagnosis: the r06 experiments)
+  size_t free_b = 0, total_b = 0;
+  MDC_HIP(c, hipMemGetInfo(&free_b, &total_b));
+  const size_t cap = (size_t)((double)free_b * 0.92 / (double)piece);  // pieces the device has room for
+  if (cap < need) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: %zu pieces of %zu MiB do not fit the device's free memory", need, piece >> 20);
+  const size_t max_pieces = compose == 1 ? need : std::min(cap, 4 * need + 24);
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  MDC_HIP(c, hipMemAddressReserve(&a->probe_va, max_pieces * piece, gran, nullptr, 0));
+  a->reserved.push_back({a->probe_va, max_pieces * piece});
+  auto probe_ptr = [&](size_t k) { return static_cast<char*>(a->probe_va) + k * piece; };
+  auto grow = [&](size_t upto) -> int {  // more pieces, mapped at the end of the probe range
+    const size_t from = a->handles.size();
+    while (a->handles.size() < upto) {
+      hipMemGenericAllocationHandle_t h;
+      if (hipMemCreate(&h, piece, &prop, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        break;
+      }
+      a->handles.push_back(h);
+      const size_t k = a->handles.size() - 1;
+      MDC_HIP(c, hipMemMap(probe_ptr(k), piece, 0, h, 0));
+      a->mapped.push_back({probe_ptr(k), piece});
+    }
+    if (a->handles.size() > from) MDC_HIP(c, hipMemSetAccess(probe_ptr(from), (a->handles.size() - from) * piece, &acc, 1));
+    return MDC_OK;
+  };
+  // ---- classes: 0 = the class of piece 0, 1 = the class of the first piece that is fast with piece 0, 2 = fast with both.
+  // t0[k] = a linear stream reading piece 0 and writing piece k; t1[k] = the same against the first piece of class 1.  A set of times is
+  // cut at its widest gap (if that is wide enough to be a gap at all).
+  std::vector<float> t0, t1;
+  std::vector<int> cls;
+  size_t ref1 = 0;
+  float gap[2] = {0.f, 0.f};
+  const size_t rd = piece / 2;  // 1 byte read : 2 bytes written, the path's ratio
+  auto cut_of = [](std::vector<float> v, float* rel) -> float {  // threshold between the fast and the slow cluster, or +inf
+    std::sort(v.begin(), v.end());
+    float best = 0.f, at = std::numeric_limits<float>::infinity();
+    for (size_t i = 1; i < v.size(); i++)
+      if (v[i] - v[i - 1] > best) best = v[i] - v[i - 1], at = 0.5f * (v[i] + v[i - 1]);
+    *rel = v.empty() || v[0] <= 0 ? 0.f : best / v[0];
+    return *rel > 0.025f ? at : std::numeric_limits<float>::infinity();
+  };
+  auto classify = [&]() -> int {
+    const size_t M = a->handles.size();
+    for (size_t k = t0.size(); k < M; k++) {
+      float ms = 0.f;
+      if (k > 0 && !time_stream(probe_ptr(0), rd, probe_ptr(k), piece, s, ev.e0, ev.e1, &ms)) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
+      t0.push_back(ms);
+    }
+    cls.assign(M, 0);
+    std::vector<float> v0(t0.begin() + 1, t0.end());
+    const float cut0 = cut_of(v0, &gap[0]);
+    std::vector<size_t> fast0;
+    for (size_t k = 1; k < M; k++)
+      if (t0[k] < cut0 && std::isfinite(cut0)) fast0.push_back(k);
+    if (fast0.empty()) return MDC_OK;  // one class as far as can be seen
+    if (!ref1) ref1 = fast0[0];
+    t1.resize(M, -1.f);
+    std::vector<float> v1;
+    for (size_t k : fast0) {
+      if (k == ref1) continue;
+      if (t1[k] < 0 && !time_stream(probe_ptr(ref1), rd, probe_ptr(k), piece, s, ev.e0, ev.e1, &t1[k])) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
+      v1.push_back(t1[k]);
+    }
+    const float cut1 = cut_of(v1, &gap[1]);
+    for (size_t k : fast0) cls[k] = (k == ref1 || !(t1[k] < cut1 && std::isfinite(cut1))) ? 1 : 2;
+    return MDC_OK;
+  };
+  int rc = grow(std::min(max_pieces, compose == 1 ? need : need + std::max<size_t>(need / 2, 6)));
+  if (rc != MDC_OK) return rc;
+  if (a->handles.size() < need) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: only %zu of %zu pieces of %zu MiB could be created", a->handles.size(), need, piece >> 20);
+  int n_cls[3] = {(int)a->handles.size(), 0, 0};
+  const size_t share = (need + 2) / 3;  // pieces wanted of every class
+  if (compose != 1) {
+    for (;;) {
+      if ((rc = classify()) != MDC_OK) return rc;
+      n_cls[0] = n_cls[1] = n_cls[2] = 0;
+      for (int k : cls) n_cls[k]++;
+      const bool balanced = (size_t)std::min(n_cls[0], std::min(n_cls[1], n_cls[2])) >= share;
+      if (balanced || a->handles.size() >= max_pieces) break;
+      const size_t before = a->handles.size();
+      if ((rc = grow(std::min(max_pieces, before + std::max<size_t>(need / 2, 8)))) != MDC_OK) return rc;
+      if (a->handles.size() == before) break;  // the device gave what it had
+    }
+    (void)hipStreamSynchronize(s);
+  }
+  const size_t M = a->handles.size();
+  cls.resize(M, 0);
+  // ---- which pieces make up which range
+  std::vector<size_t> by_cls[3];
+  for (size_t k = 0; k < M; k++) by_cls[cls[k]].push_back(k);
+  size_t at[3] = {0, 0, 0};
+  auto take = [&](int& turn) -> size_t {  // the next piece of class `turn`, or of the class after it that still has one
+    for (int q = 0; q < 3; q++) {
+      const int k = (turn + q) % 3;
+      if (at[k] < by_cls[k].size()) {
+        turn = (k + 1) % 3;
+        return by_cls[k][at[k]++];
+      }
+    }
+    return 0;
+  };
+  if (compose == 1) {
+    size_t next = 0;
+    for (Range& r : ranges)
+      for (size_t k = 0; k < r.pieces; k++) r.piece_ids.push_back(next++);
+  } else if (compose == 2) {  // diagnosis: a whole range in one class (range k: class k mod 3), the rest from wherever
+    for (size_t i = 0; i < ranges.size(); i++)
+      for (size_t k = 0; k < ranges[i].pieces; k++) {
+        int turn = (int)(i % 3);
+        ranges[i].piece_ids.push_back(take(turn));
+      }
+  } else {  // piece by piece round the classes, all ranges in step (range k starts at class k mod 3: a frame and its result lie at
+    std::vector<int> turn(ranges.size());  // about the same relative position of their ranges)
+    size_t longest = 0;
+    for (size_t i = 0; i < ranges.size(); i++) turn[i] = (int)(i % 3), longest = std::max(longest, ranges[i].pieces);
+    for (size_t k = 0; k < longest; k++)
+      for (size_t i = 0; i < ranges.size(); i++)
+        if (k < ranges[i].pieces) ranges[i].piece_ids.push_back(take(turn[i]));
+  }
+  // ---- the surplus goes back to the device before anything else is mapped (MDC_PLACE_KEEP_SURPLUS=1: stays mapped until the end).
+  // Only pieces no range uses are touched, after everything that ever ran on them has finished.
+  std::vector<char> used(M, 0);
+  for (const Range& r : ranges)
+    for (size_t id : r.piece_ids) used[id] = 1;
+  size_t returned = 0;
+  if (!env_int(getenv("MDC_PLACE_KEEP_SURPLUS"), 0)) {
+    MDC_HIP(c, hipDeviceSynchronize());
+    for (size_t k = 0; k < M; k++)
+      if (!used[k]) {
+        for (size_t q = 0; q < a->mapped.size(); q++)
+          if (a->mapped[q].first == (void*)probe_ptr(k)) {
+            (void)hipMemUnmap(a->mapped[q].first, a->mapped[q].second);
+            a->mapped.erase(a->mapped.begin() + (long)q);
+            break;
+          }
+        (void)hipMemRelease(a->handles[k]);
+        a->handles[k] = nullptr;
+        returned++;
+      }
+    MDC_HIP(c, hipDeviceSynchronize());
+  }
+  // ---- the ranges: every piece mapped a second time, in its final place (the probe mappings of the pieces in use stay: no address a
+  // kernel may still know is ever unmapped while the arena lives).  A range is made of STRIPES -- stripe t is sub-range (t / n) of the
+  // range's piece (t mod n), so consecutive stripes walk through all its pieces and their classes -- where hipMemMap takes an offset
+  // into a handle (ROCm 7 does); else of whole pieces.
+  size_t stripe = (size_t)std::max(0, env_int(getenv("MDC_PLACE_STRIPE_MIB"), 64)) << 20;
+  if (stripe == 0 || stripe >= piece || piece % stripe != 0 || stripe % gran != 0 || compose != 0) stripe = piece;
+  auto map_range = [&](Range& r, size_t st) -> hipError_t {
+    const size_t n = r.piece_ids.size(), per = piece / st;
+    for (size_t t = 0; t < n * per; t++) {
+      char* where = static_cast<char*>(r.va) + t * st;
+      const hipError_t e = hipMemMap(where, st, (t / n) * st, a->handles[r.piece_ids[t % n]], 0);
+      if (e != hipSuccess) return e;
+      a->mapped.push_back({where, st});
+    }
+    return hipSuccess;
+  };
+  for (Range& r : ranges) {
+    MDC_HIP(c, hipMemAddressReserve(&r.va, r.pieces * piece, gran, nullptr, 0));
+    a->reserved.push_back({r.va, r.pieces * piece});
+  }
+  if (stripe < piece) {  // (an offset the runtime refuses shows at the first stripe that has one)
+    const size_t before = a->mapped.size();
+    bool ok = true;
+    for (Range& r : ranges) ok = ok && map_range(r, stripe) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      while (a->mapped.size() > before) {
+        (void)hipMemUnmap(a->mapped.back().first, a->mapped.back().second);
+        a->mapped.pop_back();
+      }
+      stripe = piece;
+    }
+  }
+  if (stripe == piece)
+    for (Range& r : ranges) MDC_HIP(c, map_range(r, piece));
+  for (Range& r : ranges) MDC_HIP(c, hipMemSetAccess(r.va, r.pieces * piece, &acc, 1));
+  MDC_HIP(c, hipDeviceSynchronize());
+  for (int k = 0; k < 3; k++) n_cls_out[k] = n_cls[k];
+  *pieces_out = (int)M;
+  *piece_mib_out = (int)(piece >> 20);
+  int used_cls[3] = {0, 0, 0};
+  for (size_t k = 0; k < M; k++)
+    if (used[k]) used_cls[cls[k]]++;
+  snprintf(note, note_cap,
+           "assembled: %zu ranges from %zu pieces of %zu MiB (%zu created, %zu returned); memory classes by a timed read/write stream against reference "
+           "pieces: %d / %d / %d (gaps %.1f %%, %.1f %%), in use %d / %d / %d; %s",
+           ranges.size(), M - returned, piece >> 20, M, returned, n_cls[0], n_cls[1], n_cls[2], gap[0] * 100, gap[1] * 100, used_cls[0], used_cls[1], used_cls[2],
+           compose == 1 ? "creation order, no classification" : compose == 2 ? "a range in ONE class (diagnosis)" : "every range striped over the classes");
+  if (stripe < piece) snprintf(note + strlen(note), note_cap - strlen(note), ", stripes of %zu MiB", stripe >> 20);
+  return MDC_OK;
+}
+
 int place_vmm(mdc_ctx* c, Arena* a, size_t in_bytes, size_t out_bytes, size_t frame_in, int64_t probe_frames, unsigned flags, hipStream_t s,
               mdc_placed_buffers* r) {
   Events ev;
@@ -258,169 +484,20 @@ int place_vmm(mdc_ctx* c, Arena* a, size_t in_bytes, size_t out_bytes, size_t fr
     if (fi) (void)hipFree(fi);
     if (fo) (void)hipFree(fo);
   }
-  hipMemAllocationProp prop = {};
-  prop.type = hipMemAllocationTypePinned;
-  prop.location.type = hipMemLocationTypeDevice;
-  prop.location.id = c->device;
-  size_t gran = 0;
-  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0)
-    return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: no virtual memory management on this device");
-  size_t piece = (size_t)std::max(2, env_int(getenv("MDC_PLACE_PIECE_MIB"), 1024)) << 20;
-  piece = (piece + gran - 1) / gran * gran;
-  a->piece = piece;
-  const size_t n_in = (in_bytes + piece - 1) / piece, n_out = (out_bytes + piece - 1) / piece, need = n_in + n_out;
-  size_t free_b = 0, total_b = 0;
-  MDC_HIP(c, hipMemGetInfo(&free_b, &total_b));
-  const int compose = env_int(getenv("MDC_PLACE_COMPOSE"), 0);  // 0 = frames and results from different classes, 1 = creation order (no
-                                                        // classification), 2 = both ranges striped over all classes
-  // more pieces than needed, for the choice: twice the need + 4 where there is room (the surplus is returned at the end)
-  size_t M = std::min<size_t>(2 * need + 4, (size_t)((double)free_b * 0.9 / (double)piece));
-  if (compose == 1) M = std::min(M, need);
-  if (M < need) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: %zu + %zu bytes do not fit the device's free memory", in_bytes, out_bytes);
-  a->handles.reserve(M);
-  for (size_t k = 0; k < M; k++) {
-    hipMemGenericAllocationHandle_t h;
-    if (hipMemCreate(&h, piece, &prop, 0) != hipSuccess) {
-      (void)hipGetLastError();
-      break;
-    }
-    a->handles.push_back(h);
-  }
-  M = a->handles.size();
-  if (M < need) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: only %zu of %zu pieces of %zu MiB could be created", M, need, piece >> 20);
-  hipMemAccessDesc acc = {};
-  acc.location = prop.location;
-  acc.flags = hipMemAccessFlagsProtReadWrite;
-  MDC_HIP(c, hipMemAddressReserve(&a->probe_va, M * piece, gran, nullptr, 0));
-  for (size_t k = 0; k < M; k++) {
-    MDC_HIP(c, hipMemMap(static_cast<char*>(a->probe_va) + k * piece, piece, 0, a->handles[k], 0));
-    a->probe_mapped = k + 1;
-  }
-  MDC_HIP(c, hipMemSetAccess(a->probe_va, M * piece, &acc, 1));
-  auto probe_ptr = [&](size_t k) { return static_cast<char*>(a->probe_va) + k * piece; };
-
-  // ---- classes: 0 = the class of piece 0, 1 = the class of the first piece that is fast with piece 0, 2 = fast with both
-  std::vector<int> cls(M, 0);
-  int n_cls[3] = {(int)M, 0, 0};
-  float spread[2] = {0.f, 0.f};
-  if (compose != 1 && M >= 3) {
-    const size_t rd = piece / 2;  // 1 byte read : 2 bytes written, the path's ratio
-    auto split = [&](size_t ref, const std::vector<size_t>& members, std::vector<size_t>& slow, std::vector<size_t>& fast, float* rel) -> bool {
-      std::vector<float> t(members.size());
-      float lo = 1e30f, hi = 0.f;
-      for (size_t q = 0; q < members.size(); q++) {
-        if (!time_stream(probe_ptr(ref), rd, probe_ptr(members[q]), piece, s, ev.e0, ev.e1, &t[q])) return false;
-        lo = std::min(lo, t[q]);
-        hi = std::max(hi, t[q]);
-      }
-      *rel = lo > 0 ? (hi - lo) / lo : 0.f;
-      const float cut = 0.5f * (lo + hi);
-      for (size_t q = 0; q < members.size(); q++) ((*rel > 0.03f && t[q] > cut) ? slow : fast).push_back(members[q]);
-      return true;
-    };
-    std::vector<size_t> others, slow0, fast0;
-    for (size_t k = 1; k < M; k++) others.push_back(k);
-    if (!split(0, others, slow0, fast0, &spread[0])) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
-    n_cls[0] = 1 + (int)slow0.size();
-    if (!fast0.empty()) {
-      const size_t ref1 = fast0[0];
-      std::vector<size_t> rest(fast0.begin() + 1, fast0.end()), slow1, fast1;
-      if (!rest.empty() && !split(ref1, rest, slow1, fast1, &spread[1])) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
-      cls[ref1] = 1;
-      for (size_t k : slow1) cls[k] = 1;
-      for (size_t k : fast1) cls[k] = 2;
-      n_cls[1] = 1 + (int)slow1.size();
-      n_cls[2] = (int)fast1.size();
-    }
-    (void)hipStreamSynchronize(s);
-  }
-  // ---- which pieces make up which range
-  std::vector<size_t> by_cls[3];
-  for (size_t k = 0; k < M; k++) by_cls[cls[k]].push_back(k);
-  std::vector<size_t> pin, pout;
-  int cin = 0, cout = 0;
-  if (compose == 1 || n_cls[0] == (int)M) {  // creation order (no structure found: every piece is as good as any other)
-    for (size_t k = 0; k < n_in; k++) pin.push_back(k);
-    for (size_t k = 0; k < n_out; k++) pout.push_back(n_in + k);
-  } else if (compose == 2) {  // both ranges striped over the classes, piece by piece
-    size_t at[3] = {0, 0, 0};
-    int turn = 0;
-    auto take = [&]() -> size_t {
-      for (int q = 0; q < 3; q++) {
-        const int k = (turn + q) % 3;
-        if (at[k] < by_cls[k].size()) {
-          turn = (k + 1) % 3;
-          return by_cls[k][at[k]++];
-        }
-      }
-      return 0;
-    };
-    for (size_t k = 0; k < n_out; k++) pout.push_back(take());
-    for (size_t k = 0; k < n_in; k++) pin.push_back(take());
-  } else {
-    // frames <- class X, results <- class Y != X; what a class cannot cover comes from the third class, then from anywhere.
-    // The best (X, Y) covers the most pieces without putting the two ranges into one class.
-    size_t best_cov = 0;
-    for (int x = 0; x < 3; x++)
-      for (int y = 0; y < 3; y++) {
-        if (x == y) continue;
-        const int z = 3 - x - y;
-        const size_t a_in = std::min(n_in, by_cls[x].size()), a_out = std::min(n_out, by_cls[y].size());
-        const size_t cov = a_in + a_out + std::min((n_in - a_in) + (n_out - a_out), by_cls[z].size());
-        if (cov > best_cov) best_cov = cov, cin = x, cout = y;
-      }
-    size_t at[3] = {0, 0, 0};
-    auto take_from = [&](int k) -> long {
-      return at[k] < by_cls[k].size() ? (long)by_cls[k][at[k]++] : -1L;
-    };
-    const int cz = 3 - cin - cout;
-    for (size_t k = 0; k < n_out; k++) {
-      long p = take_from(cout);
-      if (p < 0) p = take_from(cz);
-      if (p < 0) p = take_from(cin);
-      pout.push_back((size_t)p);
-    }
-    for (size_t k = 0; k < n_in; k++) {
-      long p = take_from(cin);
-      if (p < 0) p = take_from(cz);
-      if (p < 0) p = take_from(cout);
-      pin.push_back((size_t)p);
-    }
-  }
-  // ---- the two ranges: every piece mapped a second time, in its final order (the probe mappings stay: nothing is ever unmapped
-  // while the arena lives)
-  a->in_pieces = n_in;
-  a->out_pieces = n_out;
-  MDC_HIP(c, hipMemAddressReserve(&a->in_va, n_in * piece, gran, nullptr, 0));
-  MDC_HIP(c, hipMemAddressReserve(&a->out_va, n_out * piece, gran, nullptr, 0));
-  for (size_t k = 0; k < n_in; k++) {
-    MDC_HIP(c, hipMemMap(static_cast<char*>(a->in_va) + k * piece, piece, 0, a->handles[pin[k]], 0));
-    a->in_mapped = k + 1;
-  }
-  for (size_t k = 0; k < n_out; k++) {
-    MDC_HIP(c, hipMemMap(static_cast<char*>(a->out_va) + k * piece, piece, 0, a->handles[pout[k]], 0));
-    a->out_mapped = k + 1;
-  }
-  MDC_HIP(c, hipMemSetAccess(a->in_va, n_in * piece, &acc, 1));
-  MDC_HIP(c, hipMemSetAccess(a->out_va, n_out * piece, &acc, 1));
+  std::vector<Range> ranges(2);
+  ranges[0].bytes = in_bytes;
+  ranges[1].bytes = out_bytes;
+  int rc = assemble_ranges(c, a, ranges, s, ev, r->class_count, &r->pieces, &r->piece_mib, r->note, sizeof r->note);
+  if (rc != MDC_OK) return rc;
+  a->in_va = ranges[0].va;
+  a->out_va = ranges[1].va;
   // the pass on the pair that is handed out
   if (!fill_noise(a->in_va, std::min(in_bytes, (size_t)probe_frames * frame_in) & ~(size_t)3, 0x1234u, s))
     return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: fill launch failed");
-  int rc = time_pass(c, (const uint8_t*)a->in_va, (float*)a->out_va, probe_frames, flags, s, ev.e0, ev.e1, &r->ms_chosen);
+  rc = time_pass(c, (const uint8_t*)a->in_va, (float*)a->out_va, probe_frames, flags, s, ev.e0, ev.e1, &r->ms_chosen);
   (void)hipStreamSynchronize(s);
   if (rc != MDC_OK) return rc;
-  int used[3] = {0, 0, 0}, used_out[3] = {0, 0, 0};
-  for (size_t p : pin) used[cls[p]]++;
-  for (size_t p : pout) used_out[cls[p]]++;
-  r->pieces = (int)M;
-  r->piece_mib = (int)(piece >> 20);
-  for (int k = 0; k < 3; k++) r->class_count[k] = n_cls[k];
   r->candidates_in = r->candidates_out = 1;
-  snprintf(r->note, sizeof r->note,
-           "assembled: %zu pieces of %zu MiB mapped once; classes by a timed read/write stream against a reference piece: %d / %d / %d "
-           "(spread %.1f %%, %.1f %%); frames <- %d+%d+%d pieces of classes 0/1/2, results <- %d+%d+%d%s",
-           M, piece >> 20, n_cls[0], n_cls[1], n_cls[2], spread[0] * 100, spread[1] * 100, used[0], used[1], used[2], used_out[0], used_out[1],
-           used_out[2], compose == 1 ? " (creation order)" : compose == 2 ? " (striped)" : "");
   return MDC_OK;
 }
 
@@ -488,6 +565,83 @@ int mdc_alloc_placed_device(mdc_ctx* c, size_t in_bytes, size_t out_bytes, int64
   out->handle = a;
   return MDC_OK;
 } MDC_CATCH(c)
+
+// Buffers of a step with more outputs than one result per frame (config 5's pyramid levels, the DSO hand-off's gradient images): every
+// one of them striped over the memory classes by the same machinery.
+int mdc_alloc_striped_set_device(mdc_ctx* c, int n, const size_t* bytes, void* stream, mdc_striped_set* out) try {
+  if (!c) return MDC_ERR_ARG;
+  if (!out || !bytes || n < 1 || n > MDC_STRIPED_SET_MAX) return fail(c, MDC_ERR_ARG, "mdc_alloc_striped_set_device: bad argument");
+  memset(out, 0, sizeof *out);
+  for (int k = 0; k < n; k++)
+    if (bytes[k] == 0) return fail(c, MDC_ERR_ARG, "mdc_alloc_striped_set_device: buffer %d has no size", k);
+  ReadLock lk(c->mu);
+  DeviceGuard dg(c->device);
+  Arena* a = new Arena();
+  a->device = c->device;
+  a->strategy = MDC_PLACE_VMM;
+  const char* e = getenv("MDC_PLACEMENT");
+  int rc = MDC_ERR_HIP;
+  if (!(e && (!strcmp(e, "first") || !strcmp(e, "malloc")))) {
+    Events ev;
+    // buffers below a piece's size share ONE range (each at a 2-MiB boundary): a range takes whole pieces
+    const size_t piece_guess = (size_t)std::min(1024, std::max(2, env_int(getenv("MDC_PLACE_PIECE_MIB"), 512))) << 20, align = (size_t)2 << 20;
+    std::vector<Range> ranges;
+    std::vector<std::pair<size_t, size_t>> where((size_t)n);  // buffer k = range index, offset
+    size_t small_total = 0;
+    long small_range = -1;
+    for (int k = 0; k < n; k++) {
+      if (bytes[k] >= piece_guess) {
+        where[(size_t)k] = {ranges.size(), 0};
+        ranges.push_back(Range());
+        ranges.back().bytes = bytes[k];
+      } else {
+        if (small_range < 0) {
+          small_range = (long)ranges.size();
+          ranges.push_back(Range());
+        }
+        where[(size_t)k] = {(size_t)small_range, small_total};
+        small_total += (bytes[k] + align - 1) / align * align;
+      }
+    }
+    if (small_range >= 0) ranges[(size_t)small_range].bytes = small_total;
+    rc = ev.make() ? assemble_ranges(c, a, ranges, (hipStream_t)stream, ev, out->class_count, &out->pieces, &out->piece_mib, out->note, sizeof out->note)
+                   : fail(c, MDC_ERR_HIP, "mdc_alloc_striped_set_device: hipEventCreate failed");
+    if (rc == MDC_OK)
+      for (int k = 0; k < n; k++) out->d_ptr[k] = static_cast<char*>(ranges[where[(size_t)k].first].va) + where[(size_t)k].second;
+  }
+  if (rc != MDC_OK) {  // no virtual memory management here (or switched off): plain allocations, as they come
+    release_arena(a);
+    a = new Arena();
+    a->device = c->device;
+    a->strategy = MDC_PLACE_FIRST;
+    rc = MDC_OK;
+    for (int k = 0; k < n && rc == MDC_OK; k++) {
+      void* p = nullptr;
+      if (hipMalloc(&p, bytes[k]) != hipSuccess) rc = fail(c, MDC_ERR_HIP, "mdc_alloc_striped_set_device: hipMalloc of %zu bytes failed", bytes[k]);
+      else a->plain.push_back(p), out->d_ptr[k] = p;
+    }
+    if (rc != MDC_OK) {
+      release_arena(a);
+      memset(out, 0, sizeof *out);
+      return rc;
+    }
+    snprintf(out->note, sizeof out->note, "plain allocations, as they come (hipMalloc)");
+  }
+  out->n = n;
+  for (int k = 0; k < n; k++) out->bytes[k] = bytes[k];
+  out->strategy = a->strategy;
+  out->handle = a;
+  return MDC_OK;
+} MDC_CATCH(c)
+
+int mdc_free_striped_set_device(mdc_ctx* c, mdc_striped_set* b) {
+  if (!c || !b) return MDC_ERR_ARG;
+  if (!b->handle) return MDC_OK;
+  Arena* a = static_cast<Arena*>(b->handle);
+  memset(b, 0, sizeof *b);
+  release_arena(a);
+  return MDC_OK;
+}
 
 int mdc_free_placed_device(mdc_ctx* c, mdc_placed_buffers* b) {
   if (!c || !b) return MDC_ERR_ARG;

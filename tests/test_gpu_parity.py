@@ -316,8 +316,9 @@ def test_full_size_other_cameras_against_the_reference_build(name, calib_dirs, r
         if i2.tiled and (i2.tile_w, i2.tile_h) == (cols, rows) and not i2.two_stage:
             ran.append((cols, rows))
             check(rectifying, "plan %dx%d" % (cols, rows))
-    if name in ("full_1280_crop", "full_1280_full_black", "full_1280_to_752"):
-        assert (128, 32) in ran and (128, 16) in ran, ran  # the 2x-downscaling cameras take both headline shapes
+    if name == "full_1280_to_752":  # the bench camera's K at another output size: both headline shapes plan (`crop` / `full` at 640 x 480
+        assert (128, 32) in ran and (128, 16) in ran, ran  # shrink 5.8 source pixels into one output: windows beyond any tile's LDS budget)
+    print("PLANS %s: library %dx%d tiled=%d strip=%d black=%d; explicit shapes that planned: %s" % (name, info.tile_w, info.tile_h, info.tiled, info.two_stage, info.n_black, ran))
     ctx.set_option(capi.OPT_TILE_COLS, 0)
     ctx.set_option(capi.OPT_TILE_ROWS, 0)
     if ctx.info().tiled and not ctx.info().two_stage:
@@ -1125,3 +1126,46 @@ def test_alloc_placed_hands_out_working_buffers(setups, oracle, torch_cuda, stra
         s.ctx.alloc_placed(4, flags, which, st, in_bytes=100)  # smaller than four frames
     with pytest.raises(capi.MdcError):
         capi.Context(0).alloc_placed(4, flags, which, st)  # no tables: the pass cannot be probed
+
+
+def test_striped_set_holds_a_pyramid_step(setups, oracle, torch_cuda, monkeypatch):
+    """mdc_alloc_striped_set_device: the further outputs of a step (config 5's levels) from the allocator -- large buffers as ranges of their own,
+    small ones sharing a range -- next to an assembled pair; the step's results on them equal the oracle's chain bit for bit; sets can be
+    made and given back repeatedly; bad arguments are refused."""
+    from mono_dataset_code_amd import capi, synth
+
+    torch = torch_cuda
+    s = setups("full_1280_to_1280")
+    monkeypatch.setenv("MDC_PLACE_PIECE_MIB", "64")
+    monkeypatch.setenv("MDC_PLACE_STRIPE_MIB", "16")
+    n, npix, nout = 96, s.W * s.H, s.w * s.h
+    st = torch.cuda.current_stream().cuda_stream
+    flags = capi.RECTIFY | capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED
+    for rnd in range(2):
+        pair = s.ctx.alloc_placed(n, flags, capi.PLACE_VMM, st)
+        sizes = [n * (s.w >> l) * (s.h >> l) * 4 for l in (1, 2, 3)]  # 126 MB (a range of its own), 31 MB and 8 MB (sharing one)
+        lv = s.ctx.alloc_striped_set(sizes, st)
+        assert lv.n == 3 and lv.strategy == capi.PLACE_VMM and all(lv.d_ptr[k] for k in range(3)) and b"striped" in lv.note
+        assert lv.d_ptr[2] - lv.d_ptr[1] == (sizes[1] + (2 << 20) - 1) // (2 << 20) * (2 << 20)  # the two small ones back to back at a 2-MiB boundary
+        s.ctx.synth_frames(pair.d_in, 40 + rnd, n, npix, synth.SEED, st)
+        s.ctx.process_pyramid_batch(pair.d_in, pair.d_out, 4, [lv.d_ptr[k] for k in range(3)], n, flags, st)
+        torch.cuda.synchronize()
+        for f in (0, n - 1):
+            raw = synth.noise_frames(40 + rnd + f, 1, npix)[0]
+            src, cw, ch = s.want(oracle, raw, 1, 1, 1, 1), s.w, s.h
+            assert bits_equal(s.ctx.copy_to_host(pair.d_out + f * nout * 4, nout, np.float32), src)
+            for l in range(3):
+                src = oracle.pyramid_level(src, cw, ch)
+                cw, ch = cw // 2, ch // 2
+                assert bits_equal(s.ctx.copy_to_host(lv.d_ptr[l] + f * cw * ch * 4, cw * ch, np.float32), src), (rnd, f, l + 1)
+        s.ctx.free_striped_set(lv)
+        s.ctx.free_placed(pair)
+        assert not lv.handle
+    with pytest.raises(capi.MdcError):
+        s.ctx.alloc_striped_set([], st)
+    with pytest.raises(capi.MdcError):
+        s.ctx.alloc_striped_set([1 << 20, 0], st)
+    monkeypatch.setenv("MDC_PLACEMENT", "first")  # switched off: plain allocations, said so
+    plain = s.ctx.alloc_striped_set([1 << 20, 3 << 20], st)
+    assert plain.strategy == capi.PLACE_FIRST and plain.d_ptr[0] and plain.d_ptr[1]
+    s.ctx.free_striped_set(plain)

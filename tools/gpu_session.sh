@@ -98,8 +98,8 @@ try:
 except Exception as e: print('  no line', e)"
       done ;;
     bench_driver)  # exactly what the driver runs at round end
-      ( time timeout 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver.json" 2> "$OUT/bench_driver.err" ) 2>&1 | grep real; tail -c 400 "$OUT/bench_driver.err"
-      python3 - "$OUT/bench_driver.json" <<'PY'
+      ( time timeout 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 ${BENCH_ARGS:-} > "$OUT/bench_driver${BENCH_TAG:-}.json" 2> "$OUT/bench_driver.err" ) 2>&1 | grep real; tail -c 400 "$OUT/bench_driver.err"
+      python3 - "$OUT/bench_driver${BENCH_TAG:-}.json" <<'PY'
 import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 r = d["roofline"]
@@ -193,10 +193,10 @@ for r in rows:
     print("%-62s calls %5s  avg %8.1f us  total %8.2f ms  %5.1f %%" % (m.group(0) if m else r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, 100 * float(r["TotalDurationNs"]) / tot))
 PY
       ;;
-    placed)  # the headline launch on buffers from the product's allocator, one strategy / setting per process (PLACED_CFGS="strategy:piece MiB:compose:rounds[:frames] ...")
+    placed)  # the headline launch on buffers from the product's allocator, one strategy / setting per process (PLACED_CFGS="strategy:piece MiB:compose:rounds[:frames[:stripe MiB]] ...")
       for cfg in ${PLACED_CFGS:-first:0:0:1 malloc:0:0:1 vmm:1024:0:1 vmm:1024:1:1 vmm:1024:2:1 vmm:256:0:1 vmm:256:2:1 vmm:64:2:1}; do
-        IFS=: read -r strat piece comp rounds frames <<< "$cfg"
-        MDC_PLACE_PIECE_MIB=${piece:-1024} MDC_PLACE_COMPOSE=${comp:-0} timeout ${PLACED_TIMEOUT:-400} python tools/placed_probe.py $strat ${rounds:-1} ${frames:-4096} >> "$OUT/placed_probe.txt" 2>&1
+        IFS=: read -r strat piece comp rounds frames stripe <<< "$cfg"
+        MDC_PLACE_PIECE_MIB=${piece:-1024} MDC_PLACE_COMPOSE=${comp:-0} MDC_PLACE_STRIPE_MIB=${stripe:-0} timeout ${PLACED_TIMEOUT:-400} python tools/placed_probe.py $strat ${rounds:-1} ${frames:-4096} >> "$OUT/placed_probe.txt" 2>&1
         echo "rc=$? ($cfg)" >> "$OUT/placed_probe.txt"
       done
       grep -a "PLACED\|rc=\|fault\|Error\|^   " "$OUT/placed_probe.txt" | cut -c1-420 ;;

@@ -66,6 +66,7 @@ def main():
                     help="diagnosis: replace the FOV remap by a distortion-free one of the same scale (no window overlap "
                          "from the bow); affine128 = output tile columns map to whole 128-byte source lines")
     ap.add_argument("--workload", default="fused", choices=["fused", "unmap"])
+    ap.add_argument("--placement", default="", help="frame / result buffers from the product's allocator (first | malloc | vmm | auto) instead of torch.empty")
     a = ap.parse_args()
     libs = [a.lib] if a.lib else a.libs.split(",")
     dev = torch.device("cuda", 0)
@@ -99,10 +100,37 @@ def main():
     st = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(st)
     s = st.cuda_stream
-    d_in = torch.empty(B * npi, dtype=torch.uint8, device=dev)
-    d_out = torch.empty(B * npo, dtype=torch.float32, device=dev)
-    ctxs[libs[0]][1].synth_frames(d_in.data_ptr(), 0, B, npi, synth.SEED, s)
     flags = 7 | (8 if a.workload == "fused" else 0)
+    if a.placement:
+        own = capi.Context(0)
+        own.import_tables(blob)
+        pb = own.alloc_placed(B, flags, {"first": capi.PLACE_FIRST, "malloc": capi.PLACE_MALLOC, "vmm": capi.PLACE_VMM, "auto": capi.PLACE_AUTO}[a.placement], s)
+        print("buffers:", pb.describe()["how"], "probe first / chosen", pb.ms_first, pb.ms_chosen)
+
+        class Ptr:  # the few tensor methods this script uses, on a raw device address
+            def __init__(self, ptr, n, dtype):
+                self.ptr, self.n, self.dtype = ptr, n, dtype
+
+            def data_ptr(self):
+                return self.ptr
+
+            def host(self):
+                return torch.from_numpy(own.copy_to_host(self.ptr, self.n, np.uint8 if self.dtype == torch.uint8 else np.float32))
+
+            def clone(self):
+                return self.host()
+
+            def view(self, dt):
+                return self.host().view(dt)
+
+            def zero_(self):
+                pass
+
+        d_in, d_out = Ptr(pb.d_in, B * npi, torch.uint8), Ptr(pb.d_out, B * npo, torch.float32)
+    else:
+        d_in = torch.empty(B * npi, dtype=torch.uint8, device=dev)
+        d_out = torch.empty(B * npo, dtype=torch.float32, device=dev)
+    ctxs[libs[0]][1].synth_frames(d_in.data_ptr(), 0, B, npi, synth.SEED, s)
     alg = (int(info.src_bbox_bytes) + npo * 4) if a.workload == "fused" else npi * 5
     kmap = {"tiled": capi.KERNEL_TILED, "gather": capi.KERNEL_GATHER, "auto": capi.KERNEL_AUTO}
     ints = lambda x: [int(v) for v in x.split(",")]  # noqa: E731
@@ -139,7 +167,7 @@ def main():
                     ref_out = d_out.clone()
                     same[v] = True
                 else:
-                    same[v] = bool(torch.equal(d_out.view(torch.int32), ref_out.view(torch.int32)))
+                    same[v] = bool(torch.equal(d_out.view(torch.int32), ref_out.view(torch.int32) if a.placement else ref_out.view(torch.int32)))
                 d_out.zero_()
             e0.record()
             for _ in range(a.iters):
