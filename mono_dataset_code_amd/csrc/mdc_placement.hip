@@ -23,7 +23,8 @@
 namespace mdc {
 namespace {
 
-constexpr int MDC_PLACE_DEFAULT = MDC_PLACE_MALLOC;  // what MDC_PLACE_AUTO means (DESIGN.md section 6.1 has the measurements behind it)
+constexpr int MDC_PLACE_DEFAULT = MDC_PLACE_VMM;  // what MDC_PLACE_AUTO means (DESIGN.md section 6.1 has the measurements behind it); falls back to
+                                                  // MDC_PLACE_MALLOC where the device has no virtual memory management
 
 __global__ __launch_bounds__(256) void placement_fill_kernel(uint32_t* __restrict__ p, size_t nwords, uint32_t seed) {
   // byte noise (a multiplicative hash per word): candidates are timed on frames that look like frames, not on zero pages
@@ -301,46 +302,74 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
   // ---- classes: 0 = the class of piece 0, 1 = the class of the first piece that is fast with piece 0, 2 = fast with both.
   // t0[k] = a linear stream reading piece 0 and writing piece k; t1[k] = the same against the first piece of class 1.  A set of times is
   // cut at its widest gap (if that is wide enough to be a gap at all).
-  std::vector<float> t0, t1;
-  std::vector<int> cls;
-  size_t ref1 = 0;
+  // The unit that is timed is a GROUP of consecutive pieces of 1 GiB in all (pieces made one after the other come out of the same block of
+  // the driver's): a stream over less than that partly lives in the 256-MiB Infinity Cache and the classes blur (clusters 3-4 % apart
+  // for 512-MiB units, noise for 256-MiB ones, against 5-9 % for 1 GiB: profiles/r06_experiments/02_*).
+  const size_t G = std::max<size_t>(1, ((size_t)1 << 30) / piece), group_bytes = G * piece;
+  std::vector<float> t0, t1;  // per group
+  std::vector<int> cls;       // per piece
+  size_t ref1 = 0;            // group
   float gap[2] = {0.f, 0.f};
-  const size_t rd = piece / 2;  // 1 byte read : 2 bytes written, the path's ratio
-  auto cut_of = [](std::vector<float> v, float* rel) -> float {  // threshold between the fast and the slow cluster, or +inf
-    std::sort(v.begin(), v.end());
-    float best = 0.f, at = std::numeric_limits<float>::infinity();
-    for (size_t i = 1; i < v.size(); i++)
-      if (v[i] - v[i - 1] > best) best = v[i] - v[i - 1], at = 0.5f * (v[i] + v[i - 1]);
-    *rel = v.empty() || v[0] <= 0 ? 0.f : best / v[0];
-    return *rel > 0.025f ? at : std::numeric_limits<float>::infinity();
+  const size_t rd = group_bytes / 2;  // 1 byte read : 2 bytes written, the path's ratio
+  auto group_ptr = [&](size_t g) { return probe_ptr(g * G); };
+  auto timed = [&](size_t ref, size_t g, float* ms) -> bool {  // the stream, once more if the figure is out of any class's range (a hiccup)
+    if (!time_stream(group_ptr(ref), rd, group_ptr(g), group_bytes, s, ev.e0, ev.e1, ms)) return false;
+    float lo = *ms;
+    for (float x : t0)
+      if (x > 0) lo = std::min(lo, x);
+    for (int again = 0; again < 2 && *ms > 1.12f * lo; again++)
+      if (!time_stream(group_ptr(ref), rd, group_ptr(g), group_bytes, s, ev.e0, ev.e1, ms)) return false;
+    return true;
+  };
+  // Two clusters of times (1-D 2-means from the extremes): a pair in one class runs 5-9 % slower than a pair across classes, the noise
+  // inside a cluster is ~1 %.  -> the threshold between them, or +inf when the set does not fall apart (means less than 3 % apart).
+  auto cut_of = [](const std::vector<float>& v, float* rel) -> float {
+    *rel = 0.f;
+    if (v.size() < 2) return std::numeric_limits<float>::infinity();
+    float lo = *std::min_element(v.begin(), v.end()), hi = *std::max_element(v.begin(), v.end());
+    for (int it = 0; it < 16; it++) {
+      double sl = 0, sh = 0;
+      size_t nl = 0, nh = 0;
+      const float mid = 0.5f * (lo + hi);
+      for (float x : v) (x < mid ? (sl += x, nl++) : (sh += x, nh++));
+      if (!nl || !nh) break;
+      lo = (float)(sl / nl);
+      hi = (float)(sh / nh);
+    }
+    *rel = lo > 0 ? (hi - lo) / lo : 0.f;
+    return *rel > 0.03f ? 0.5f * (lo + hi) : std::numeric_limits<float>::infinity();
   };
   auto classify = [&]() -> int {
-    const size_t M = a->handles.size();
-    for (size_t k = t0.size(); k < M; k++) {
+    const size_t NG = a->handles.size() / G;  // whole groups (grow() makes pieces in whole groups)
+    for (size_t g = t0.size(); g < NG; g++) {
       float ms = 0.f;
-      if (k > 0 && !time_stream(probe_ptr(0), rd, probe_ptr(k), piece, s, ev.e0, ev.e1, &ms)) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
+      if (g > 0 && !timed(0, g, &ms)) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
       t0.push_back(ms);
     }
-    cls.assign(M, 0);
+    std::vector<int> gcls(NG, 0);
+    cls.assign(a->handles.size(), 0);
+    if (NG < 2) return MDC_OK;
     std::vector<float> v0(t0.begin() + 1, t0.end());
     const float cut0 = cut_of(v0, &gap[0]);
     std::vector<size_t> fast0;
-    for (size_t k = 1; k < M; k++)
-      if (t0[k] < cut0 && std::isfinite(cut0)) fast0.push_back(k);
+    for (size_t g = 1; g < NG; g++)
+      if (std::isfinite(cut0) && t0[g] < cut0) fast0.push_back(g);
     if (fast0.empty()) return MDC_OK;  // one class as far as can be seen
     if (!ref1) ref1 = fast0[0];
-    t1.resize(M, -1.f);
+    t1.resize(NG, -1.f);
     std::vector<float> v1;
-    for (size_t k : fast0) {
-      if (k == ref1) continue;
-      if (t1[k] < 0 && !time_stream(probe_ptr(ref1), rd, probe_ptr(k), piece, s, ev.e0, ev.e1, &t1[k])) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
-      v1.push_back(t1[k]);
+    for (size_t g : fast0) {
+      if (g == ref1) continue;
+      if (t1[g] < 0 && !timed(ref1, g, &t1[g])) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
+      v1.push_back(t1[g]);
     }
     const float cut1 = cut_of(v1, &gap[1]);
-    for (size_t k : fast0) cls[k] = (k == ref1 || !(t1[k] < cut1 && std::isfinite(cut1))) ? 1 : 2;
+    for (size_t g : fast0) gcls[g] = (g == ref1 || !(std::isfinite(cut1) && t1[g] < cut1)) ? 1 : 2;
+    for (size_t k = 0; k < NG * G; k++) cls[k] = gcls[k / G];
     return MDC_OK;
   };
-  int rc = grow(std::min(max_pieces, compose == 1 ? need : need + std::max<size_t>(need / 2, 6)));
+  auto whole_groups = [&](size_t n) { return std::min(max_pieces / G * G, (n + G - 1) / G * G); };
+  int rc = grow(compose == 1 ? need : std::max(need, whole_groups(need + std::max<size_t>(need / 2, 6))));
   if (rc != MDC_OK) return rc;
   if (a->handles.size() < need) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: only %zu of %zu pieces of %zu MiB could be created", a->handles.size(), need, piece >> 20);
   int n_cls[3] = {(int)a->handles.size(), 0, 0};
@@ -350,10 +379,16 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
       if ((rc = classify()) != MDC_OK) return rc;
       n_cls[0] = n_cls[1] = n_cls[2] = 0;
       for (int k : cls) n_cls[k]++;
+      if (env_int(getenv("MDC_PLACE_DEBUG"), 0)) {
+        fprintf(stderr, "mdc placement: %zu pieces, classes %d / %d / %d, separation %.1f %% / %.1f %%; ms against piece 0:", a->handles.size(), n_cls[0], n_cls[1], n_cls[2],
+                gap[0] * 100, gap[1] * 100);
+        for (size_t k = 0; k < t0.size(); k++) fprintf(stderr, " %.4f", t0[k]);  // (per group of 1 GiB)
+        fprintf(stderr, "\n");
+      }
       const bool balanced = (size_t)std::min(n_cls[0], std::min(n_cls[1], n_cls[2])) >= share;
       if (balanced || a->handles.size() >= max_pieces) break;
       const size_t before = a->handles.size();
-      if ((rc = grow(std::min(max_pieces, before + std::max<size_t>(need / 2, 8)))) != MDC_OK) return rc;
+      if ((rc = grow(std::max(before, whole_groups(before + std::max<size_t>(need / 2, 8))))) != MDC_OK) return rc;
       if (a->handles.size() == before) break;  // the device gave what it had
     }
     (void)hipStreamSynchronize(s);
@@ -459,7 +494,7 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
     if (used[k]) used_cls[cls[k]]++;
   snprintf(note, note_cap,
            "assembled: %zu ranges from %zu pieces of %zu MiB (%zu created, %zu returned); memory classes by a timed read/write stream against reference "
-           "pieces: %d / %d / %d (gaps %.1f %%, %.1f %%), in use %d / %d / %d; %s",
+           "pieces: %d / %d / %d (clusters %.1f %%, %.1f %% apart), in use %d / %d / %d; %s",
            ranges.size(), M - returned, piece >> 20, M, returned, n_cls[0], n_cls[1], n_cls[2], gap[0] * 100, gap[1] * 100, used_cls[0], used_cls[1], used_cls[2],
            compose == 1 ? "creation order, no classification" : compose == 2 ? "a range in ONE class (diagnosis)" : "every range striped over the classes");
   if (stripe < piece) snprintf(note + strlen(note), note_cap - strlen(note), ", stripes of %zu MiB", stripe >> 20);
@@ -533,6 +568,7 @@ int mdc_alloc_placed_device(mdc_ctx* c, size_t in_bytes, size_t out_bytes, int64
   out->out_bytes = out_bytes;
   const int64_t probe_frames = std::min<int64_t>(nframes, 4096);
   out->probe_frames = probe_frames;
+  const bool asked_auto = strategy == MDC_PLACE_AUTO;
   if (strategy == MDC_PLACE_AUTO) {
     const char* e = getenv("MDC_PLACEMENT");
     if (e && !strcmp(e, "first")) strategy = MDC_PLACE_FIRST;
@@ -542,12 +578,25 @@ int mdc_alloc_placed_device(mdc_ctx* c, size_t in_bytes, size_t out_bytes, int64
     // batches that fit the 256-MiB Infinity Cache several times over do not see HBM placement: no search
     if (in_bytes + out_bytes < ((size_t)1 << 30)) strategy = MDC_PLACE_FIRST;
   }
+  const bool by_default = strategy == MDC_PLACE_DEFAULT && !getenv("MDC_PLACEMENT");
   Arena* a = new Arena();
   a->device = c->device;
   a->strategy = strategy;
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (strategy == MDC_PLACE_VMM) rc = place_vmm(c, a, in_bytes, out_bytes, frame_in, probe_frames, flags, s, out);
+  if (strategy == MDC_PLACE_VMM) {
+    rc = place_vmm(c, a, in_bytes, out_bytes, frame_in, probe_frames, flags, s, out);
+    if (rc != MDC_OK && by_default && asked_auto) {  // the library's own choice did not work here: candidates instead
+      release_arena(a);
+      a = new Arena();
+      a->device = c->device;
+      a->strategy = strategy = MDC_PLACE_MALLOC;
+      const int64_t nf = out->nframes, pf = out->probe_frames;
+      memset(out, 0, sizeof *out);
+      out->nframes = nf, out->probe_frames = pf, out->in_bytes = in_bytes, out->out_bytes = out_bytes;
+      rc = place_malloc(c, a, in_bytes, out_bytes, frame_in, probe_frames, flags, s, std::max(1, env_int(getenv("MDC_PLACE_CANDIDATES"), 6)), out);
+    }
+  }
   else if (strategy == MDC_PLACE_MALLOC) rc = place_malloc(c, a, in_bytes, out_bytes, frame_in, probe_frames, flags, s, std::max(1, env_int(getenv("MDC_PLACE_CANDIDATES"), 6)), out);
   else rc = place_first(c, a, in_bytes, out_bytes);
   if (rc != MDC_OK) {
