@@ -276,7 +276,10 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
   MDC_HIP(c, hipMemGetInfo(&free_b, &total_b));
   const size_t cap = (size_t)((double)free_b * 0.92 / (double)piece);  // pieces the device has room for
   if (cap < need) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: %zu pieces of %zu MiB do not fit the device's free memory", need, piece >> 20);
-  const size_t max_pieces = compose == 1 ? need : std::min(cap, 4 * need + 24);
+  // how far the scan for all three classes may go: on some devices the third class only shows after 125 GiB of allocations
+  // (profiles/r05_experiments/11_*); what is not used goes back at once
+  const size_t scan = ((size_t)std::max(0, env_int(getenv("MDC_PLACE_SCAN_GIB"), 160)) << 30) / piece;
+  const size_t max_pieces = compose == 1 ? need : std::min(cap, std::max(4 * need + 24, scan));
   hipMemAccessDesc acc = {};
   acc.location = prop.location;
   acc.flags = hipMemAccessFlagsProtReadWrite;
@@ -309,6 +312,7 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
   std::vector<float> t0, t1;  // per group
   std::vector<int> cls;       // per piece
   size_t ref1 = 0;            // group
+  bool ref1_set = false;
   float gap[2] = {0.f, 0.f};
   const size_t rd = group_bytes / 2;  // 1 byte read : 2 bytes written, the path's ratio
   auto group_ptr = [&](size_t g) { return probe_ptr(g * G); };
@@ -321,41 +325,69 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
       if (!time_stream(group_ptr(ref), rd, group_ptr(g), group_bytes, s, ev.e0, ev.e1, ms)) return false;
     return true;
   };
-  // Two clusters of times (1-D 2-means from the extremes): a pair in one class runs 5-9 % slower than a pair across classes, the noise
-  // inside a cluster is ~1 %.  -> the threshold between them, or +inf when the set does not fall apart (means less than 3 % apart).
-  auto cut_of = [](const std::vector<float>& v, float* rel) -> float {
+  // Two clusters of times: a pair in one class runs 5-9 % slower than a pair across classes, the noise inside a cluster is ~1 %.  The
+  // split of the sorted times that maximises the between-cluster variance (Otsu), neither side smaller than a tenth of the set (stray
+  // fast or slow measurements must not become a "class").  -> the threshold, or +inf when the means are less than 3 % apart.
+  auto cut_of = [](std::vector<float> v, float* rel) -> float {
     *rel = 0.f;
-    if (v.size() < 2) return std::numeric_limits<float>::infinity();
-    float lo = *std::min_element(v.begin(), v.end()), hi = *std::max_element(v.begin(), v.end());
-    for (int it = 0; it < 16; it++) {
-      double sl = 0, sh = 0;
-      size_t nl = 0, nh = 0;
-      const float mid = 0.5f * (lo + hi);
-      for (float x : v) (x < mid ? (sl += x, nl++) : (sh += x, nh++));
-      if (!nl || !nh) break;
-      lo = (float)(sl / nl);
-      hi = (float)(sh / nh);
+    const size_t n = v.size();
+    if (n < 2) return std::numeric_limits<float>::infinity();
+    std::sort(v.begin(), v.end());
+    std::vector<double> pre(n + 1, 0.0);
+    for (size_t i = 0; i < n; i++) pre[i + 1] = pre[i] + v[i];
+    const size_t minsz = std::max<size_t>(1, n / 10);
+    double best = -1;
+    size_t at = 0;
+    for (size_t i = minsz; i + minsz <= n; i++) {
+      const double m1 = pre[i] / i, m2 = (pre[n] - pre[i]) / (n - i), sc = (double)i * (n - i) * (m2 - m1) * (m2 - m1);
+      if (sc > best) best = sc, at = i;
     }
-    *rel = lo > 0 ? (hi - lo) / lo : 0.f;
-    return *rel > 0.03f ? 0.5f * (lo + hi) : std::numeric_limits<float>::infinity();
+    if (!at) return std::numeric_limits<float>::infinity();
+    const double m1 = pre[at] / at, m2 = (pre[n] - pre[at]) / (n - at);
+    *rel = m1 > 0 ? (float)((m2 - m1) / m1) : 0.f;
+    return *rel > 0.03f ? 0.5f * (v[at - 1] + v[at]) : std::numeric_limits<float>::infinity();
   };
+  size_t ref0 = 0;  // group
+  bool ref0_chosen = false;
   auto classify = [&]() -> int {
     const size_t NG = a->handles.size() / G;  // whole groups (grow() makes pieces in whole groups)
+    // The reference: one of the first three groups, the one that splits the first batch best.  A piece the driver put together from
+    // several blocks may straddle two classes; against such a reference everything looks half slow and nothing falls apart.
+    if (!ref0_chosen && NG >= 4) {
+      ref0_chosen = true;
+      float best_rel = -1.f;
+      std::vector<float> best_t;
+      for (size_t r = 0; r < 3; r++) {
+        std::vector<float> t(NG, 0.f), v;
+        for (size_t g = 0; g < NG; g++)
+          if (g != r) {
+            if (!timed(r, g, &t[g])) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
+            v.push_back(t[g]);
+          }
+        float rel = 0.f;
+        (void)cut_of(v, &rel);
+        if (rel > best_rel) best_rel = rel, ref0 = r, best_t = t;
+        if (rel > 0.05f) break;  // a clean split: this reference lies in one class
+      }
+      t0 = best_t;
+    }
     for (size_t g = t0.size(); g < NG; g++) {
       float ms = 0.f;
-      if (g > 0 && !timed(0, g, &ms)) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
+      if (g != ref0 && !timed(ref0, g, &ms)) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
       t0.push_back(ms);
     }
     std::vector<int> gcls(NG, 0);
     cls.assign(a->handles.size(), 0);
     if (NG < 2) return MDC_OK;
-    std::vector<float> v0(t0.begin() + 1, t0.end());
+    std::vector<float> v0;
+    for (size_t g = 0; g < NG; g++)
+      if (g != ref0) v0.push_back(t0[g]);
     const float cut0 = cut_of(v0, &gap[0]);
     std::vector<size_t> fast0;
-    for (size_t g = 1; g < NG; g++)
-      if (std::isfinite(cut0) && t0[g] < cut0) fast0.push_back(g);
+    for (size_t g = 0; g < NG; g++)
+      if (g != ref0 && std::isfinite(cut0) && t0[g] < cut0) fast0.push_back(g);
     if (fast0.empty()) return MDC_OK;  // one class as far as can be seen
-    if (!ref1) ref1 = fast0[0];
+    if (!ref1_set) ref1 = fast0[0], ref1_set = true;
     t1.resize(NG, -1.f);
     std::vector<float> v1;
     for (size_t g : fast0) {
