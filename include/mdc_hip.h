@@ -295,7 +295,9 @@ MDC_API int mdc_process_jpeg_frames_host_to_device(mdc_ctx* ctx, const void* con
                                                    int64_t nframes, unsigned flags, const mdc_device_outputs* out, const int64_t* frame_index);
 MDC_API int mdc_process_jpeg_streams_host_to_device(mdc_ctx* ctx, const void* const* streams, const int64_t* stream_bytes, int64_t nframes,
                                                     unsigned flags, const mdc_device_outputs* out, const int64_t* frame_index, int* status);
-MDC_API int mdc_device_alloc(mdc_ctx* ctx, size_t bytes, void** d_ptr); /* device memory on the context's GPU (hipMalloc) */
+MDC_API int mdc_device_alloc(mdc_ctx* ctx, size_t bytes, void** d_ptr); /* device memory on the context's GPU: hipMalloc; a GiB or more:
+   striped over the device's memory classes like mdc_alloc_striped_set_device's buffers (MDC_PLACEMENT=first: never).  Give it back with
+   mdc_device_free on the same context, never with hipFree; what is left when the context is destroyed goes with it. */
 /* BUFFER PLACEMENT by measurement.  On MI355X the time of one and the same launch depends on the ALLOCATIONS it runs on -- on the
  * physical pages behind the caller's frame and result buffers, and on the PAIR of them: 1.48 to 1.63 ms for the headline launch (4096
  * frames) between pairs of hipMalloc'ed buffers of one process on one device, stable for the life of the buffers, not changed by offsets

@@ -69,6 +69,9 @@
 #ifndef MDC_EXP_STRIP_NOSAMPLE
 #define MDC_EXP_STRIP_NOSAMPLE 0   // the strip kernel stores a register instead of sampling
 #endif
+#ifndef MDC_EXP_STRIP_FAKE_GRAD
+#define MDC_EXP_STRIP_FAKE_GRAD 0  // the strip kernel also writes level-0 gradient images -- the traffic, sample count and store shapes of a fused variant, not its values
+#endif
 #ifndef MDC_EXP_PAD_VALU
 #define MDC_EXP_PAD_VALU 0    // N dummy VALU instructions per wave and frame in the tiled kernel's loop (right results): the cost of one instruction
 #endif
@@ -82,7 +85,7 @@
 // MDC_EXP_HUFF_FAKE_STREAM (undefined): the Huffman kernels' refills read one of 64 words (what do the divergent stream loads cost?)
 // MDC_EXP_HUFF_NOSTORE (undefined): the Huffman kernels' write pass stores DC terms only (what do the scattered 2-byte stores cost?)
 
-#if (MDC_EXP_SKIP_STORE || MDC_EXP_SKIP_LOAD || MDC_EXP_FAKE_COMPUTE || MDC_EXP_STRIP_NOCONVERT || MDC_EXP_STRIP_NOSAMPLE || \
+#if (MDC_EXP_SKIP_STORE || MDC_EXP_SKIP_LOAD || MDC_EXP_FAKE_COMPUTE || MDC_EXP_STRIP_FAKE_GRAD || MDC_EXP_STRIP_NOCONVERT || MDC_EXP_STRIP_NOSAMPLE || \
      MDC_EXP_TIMING || MDC_EXP_PAD_VALU || defined(MDC_EXP_HUFF_ROUNDS) || defined(MDC_EXP_HUFF_NOSTORE) || defined(MDC_EXP_GRAD_FAKE_READ) || defined(MDC_EXP_HUFF_FAKE_STREAM) || defined(MDC_EXP_HUFF_VERIFY) || defined(MDC_EXP_HUFF_BAD_PROVISIONAL)) && !defined(MDC_DIAGNOSIS_BUILD)
 #error "a diagnosis switch (wrong results / device printf) is set: build through mono_dataset_code_amd/build.py:build_variant, which defines MDC_DIAGNOSIS_BUILD and writes to variants/"
 #endif
@@ -117,6 +120,7 @@ inline const char* build_flags_string() {
       MDC_CFG_ITEM(MDC_EXP_FAKE_COMPUTE, 0),
       MDC_CFG_ITEM(MDC_EXP_STRIP_NOCONVERT, 0),
       MDC_CFG_ITEM(MDC_EXP_STRIP_NOSAMPLE, 0),
+      MDC_CFG_ITEM(MDC_EXP_STRIP_FAKE_GRAD, 0),
       MDC_CFG_ITEM(MDC_EXP_TIMING, 0),
       MDC_CFG_ITEM(MDC_EXP_PAD_VALU, 0),
 #ifdef MDC_EXP_HUFF_ROUNDS

@@ -325,7 +325,14 @@ int enqueue_pyramid_gradients(mdc_ctx* c, const uint8_t* d_in, float* d_base, in
     float* base = d_base + (size_t)f0 * w0 * h0;
     float* pyr[3] = {levels > 1 ? lv[0] : nullptr, levels > 2 ? lv[1] : nullptr, levels > 3 ? lv[2] : nullptr};
     bool fused = false;
+#if MDC_EXP_STRIP_FAKE_GRAD  // diagnosis: the strip launch writes level 0's gradient images (traffic and shapes only), the gradient launch starts at level 1
+    g_fake_grad_dI = with_gradients ? d_dI[0] + (size_t)f0 * w0 * h0 * 3 : nullptr;
+    g_fake_grad_abs = with_gradients ? d_abs_squared_grad[0] + (size_t)f0 * w0 * h0 : nullptr;
+#endif
     int rc = enqueue_process(c, d_in + (size_t)f0 * npi, base, n, flags, s, levels > 1 ? pyr : nullptr, &fused);
+#if MDC_EXP_STRIP_FAKE_GRAD
+    g_fake_grad_dI = g_fake_grad_abs = nullptr;
+#endif
     if (rc != MDC_OK) return rc;
     const int first = fused ? std::min(levels, 4) : 1;
     const float* src = first == 1 ? base : lv[first - 2];
@@ -333,7 +340,12 @@ int enqueue_pyramid_gradients(mdc_ctx* c, const uint8_t* d_in, float* d_base, in
       MDC_HIP(c, launch_pyramid_level(src, lv[l - 1], lw[l - 1], lh[l - 1], n, s));
       src = lv[l - 1];
     }
-    for (int l0 = 0; l0 < levels && with_gradients; l0 += 4) {  // gradients: four levels per launch
+#if MDC_EXP_STRIP_FAKE_GRAD
+    constexpr int kGradFirst = 1;
+#else
+    constexpr int kGradFirst = 0;
+#endif
+    for (int l0 = kGradFirst; l0 < levels && with_gradients; l0 += 4) {  // gradients: four levels per launch
       const int nl = std::min(4, levels - l0);
       const float* gs[4];
       float *gd[4], *ga[4];
@@ -417,6 +429,20 @@ void mdc_destroy(mdc_ctx* c) {
     if (c->pipe_up_stream) (void)hipStreamSynchronize(c->pipe_up_stream);
     unpin_all(c);
     free_plan(c);
+    {  // striped buffers of mdc_device_alloc the caller never gave back: their arenas cannot be reached without the context
+      std::vector<void*> arenas;
+      {
+        std::lock_guard<std::mutex> lk(c->striped_mu);
+        for (auto& kv : c->striped) arenas.push_back(kv.second);
+        c->striped.clear();
+      }
+      for (void* a : arenas) {
+        mdc_striped_set set;
+        memset(&set, 0, sizeof set);
+        set.handle = a;
+        (void)mdc_free_striped_set_device(c, &set);
+      }
+    }
     void* ptrs[] = {c->d_luts, c->d_vinv, c->d_rx, c->d_ry, c->d_vcal_max, c->d_pipe_in[0], c->d_pipe_in[1], c->d_pipe_out[0], c->d_pipe_out[1],
                     c->d_pipe_rec[0], c->d_pipe_rec[1], c->d_pipe_strm[0], c->d_pipe_strm[1], c->d_pipe_status[0], c->d_pipe_status[1], c->d_pipe_seg[0], c->d_pipe_seg[1]};
     for (void* p : ptrs)

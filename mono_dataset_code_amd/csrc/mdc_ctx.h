@@ -145,6 +145,11 @@ struct mdc_ctx {
   int pipe_chunk_cap = 0;  // frames d_pipe_status / d_pipe_seg are sized for
   size_t pipe_in_cap = 0, pipe_out_cap = 0, pipe_rec_cap = 0, pipe_strm_cap = 0;
 
+  // mdc_device_alloc: buffers of a GiB or more are striped over the device's memory classes (mdc_placement.hip); what mdc_device_free
+  // must undo for them, by address
+  std::mutex striped_mu;
+  std::map<void*, void*> striped;  // device pointer -> the allocator's arena
+
   // vignetteCalib: bit pattern of the largest new vignette factor of ONE vignette step.  A ring of words, one per call:
   // steps that different threads put on different streams of one context never share a word.
   static constexpr int kVcalMaxWords = 256;

@@ -77,6 +77,10 @@ struct StripPlan {
   int nbuf;                  // u8 windows per wave: 1 or 2
   bool interleave;
 };
+#if MDC_EXP_STRIP_FAKE_GRAD
+extern float* g_fake_grad_dI;
+extern float* g_fake_grad_abs;
+#endif
 hipError_t launch_remap_strip_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const StripPlan& p, int64_t nframes, int fpb,
                                  hipStream_t s, float* d_l1 = nullptr, float* d_l2 = nullptr, float* d_l3 = nullptr);
 size_t strip_lds_bytes(int win_bytes, int nbuf, int waves);

@@ -413,6 +413,10 @@ struct PyramidOut {
   float* l1;  // nframes * (w/2)*(h/2), or nullptr
   float* l2;  // nframes * (w/4)*(h/4), or nullptr
   float* l3;  // nframes * (w/8)*(h/8), or nullptr
+#if MDC_EXP_STRIP_FAKE_GRAD
+  float* gI;  // diagnosis: level-0 (I, dx, dy) triples / absSquaredGrad written by the strip kernel with the traffic, the sample count
+  float* gA;  // and the store shapes a fused level-0 gradient would have -- NOT its values
+#endif
 };
 
 __device__ __forceinline__ float box4(float a, float b, float c, float d) { return 0.25f * (((a + b) + c) + d); }
@@ -977,6 +981,9 @@ __global__ __launch_bounds__(64 * W, ((PYR || P > 5 || NBUF > 2) ? MDC_EXP_STRIP
   const long long out_step = (long long)fstep * (out_bytes / 4);
   const uint8_t* src = in + (long long)f0 * in_bytes;
   float* dst = out + (long long)f0 * (out_bytes / 4);
+#if MDC_EXP_STRIP_FAKE_GRAD
+  float* s_gt = reinterpret_cast<float*>(smem + W * per_wave + kStripLutBytes) + wave * 384;  // wave-private [2][192] transpose scratch
+#endif
   const int last = nf - 1;
   const int rw = nch > 64 ? 2 : 1;  // DMA instructions per frame (wave-uniform)
   const uint32_t l1_bytes = out_bytes / 4, l2_bytes = out_bytes / 16, l3_bytes = out_bytes / 64;
@@ -1139,8 +1146,49 @@ __global__ __launch_bounds__(64 * W, ((PYR || P > 5 || NBUF > 2) ? MDC_EXP_STRIP
             if (res[u0 + u] != -1.2345e30f) continue;
 #endif
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[u0 + u]), ro, vo[h], (uint32_t)(4 * q + u0 + u) * row_bytes, kStoreAux);
+#if MDC_EXP_STRIP_FAKE_GRAD
+            if (py.gI) {  // the stores of a fused level-0 gradient: 192 wave-contiguous floats of triples through a wave-private transpose + absSquaredGrad
+              const uint32_t R = (uint32_t)(4 * q + u0 + u);
+              float* tt = s_gt + (R & 1u) * 192;
+              tt[3 * lane + 0] = res[u0 + u];
+              tt[3 * lane + 1] = res[u0 + u] * 0.5f;
+              tt[3 * lane + 2] = res[u0 + u] * 0.25f;
+              __builtin_amdgcn_wave_barrier();
+              const auto rg = MDC_FRAME_RSRC(uniform_ptr(py.gI + fa * (long long)(out_bytes / 4) * 3), out_bytes * 3u);
+              const uint32_t rowoff = (uint32_t)(((ty * 8 + (int)R) * a.out_w + tx * 128 + 64 * h) * 12);
+#pragma unroll
+              for (int k3 = 0; k3 < 3; k3++)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tt[k3 * 64 + lane]), rg, rowoff + (uint32_t)(k3 * 64 + lane) * 4u, 0, kStoreAux);
+              __builtin_amdgcn_wave_barrier();
+              const auto ra = MDC_FRAME_RSRC(uniform_ptr(py.gA + fa * (long long)(out_bytes / 4)), out_bytes);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[u0 + u] * res[u0 + u]), ra, vo[h], R * row_bytes, kStoreAux);
+            }
+#endif
           }
         }
+#if MDC_EXP_STRIP_FAKE_GRAD
+        if (py.gI && q == 0) {  // the halo's samples: 5 more sample slots per 16 outputs (2 x 128 halo row outputs + 16 halo column outputs per 1024)
+          float dummy = 0.f;
+#pragma unroll
+          for (int e = 0; e < (h == 0 ? 3 : 2); e++) {
+            uint32_t b0, b1;
+            asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(b0) : "v"(f_base), "v"(tap[8 * h + e]));
+            asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(b1) : "v"(f_base), "v"(tap[8 * h + e]));
+            lds_f32_ptr t0 = reinterpret_cast<lds_f32_ptr>((lds_u8_ptr)0 + b0);
+            lds_f32_ptr t1 = reinterpret_cast<lds_f32_ptr>((lds_u8_ptr)0 + b1);
+            Bilin bw;
+            float xxyy, omx;
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(xxyy) : "v"(fx[8 * h + e]), "v"(fy[8 * h + e]));
+            asm volatile("v_sub_f32 %0, 1.0, %1" : "=v"(omx) : "v"(fx[8 * h + e]));
+            bw.w11 = xxyy;
+            bw.w01 = fy[8 * h + e] - xxyy;
+            bw.w10 = fx[8 * h + e] - xxyy;
+            bw.w00 = (omx - fy[8 * h + e]) + xxyy;
+            dummy += bilin_sum(bw, t0[0], t0[1], t1[0], t1[1]);
+          }
+          if (dummy == -1.2345e30f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dummy), ro, vo[h], 0, kStoreAux);
+        }
+#endif
         if (PYR) {  // levels 1 and 2 of this column half / row quad, as pyramid_levels12
           float v1[2];
 #pragma unroll
@@ -1340,7 +1388,13 @@ static hipError_t launch_tiled_nt(const TiledLaunch& l) {
 }
 
 // ---- strip kernel: VIG x PYR x NBUF {1..4} x P {2, 3, 4, 5, 8}
-size_t strip_lds_bytes(int win_bytes, int nbuf, int waves) { return (size_t)waves * ((4 + nbuf) * win_bytes + kStripPad) + kStripLutBytes; }
+size_t strip_lds_bytes(int win_bytes, int nbuf, int waves) {
+  return (size_t)waves * ((4 + nbuf) * win_bytes + kStripPad) + kStripLutBytes
+#if MDC_EXP_STRIP_FAKE_GRAD
+         + (size_t)waves * 1536
+#endif
+      ;
+}
 template <bool VIG, bool PYR, int NBUF, int P>
 static hipError_t launch_strip_variant(const uint8_t* d_in, float* d_out, const RemapArgs& a, const StripPlan& p, const PyramidOut& py,
                                        int64_t nframes, int fpb, hipStream_t s) {
@@ -1367,11 +1421,19 @@ static hipError_t launch_strip_passes(const uint8_t* d_in, float* d_out, const R
   }
   return hipErrorInvalidValue;
 }
+#if MDC_EXP_STRIP_FAKE_GRAD
+float* g_fake_grad_dI = nullptr;  // diagnosis plumbing: set per launch by enqueue_pyramid_gradients (mdc_capi.hip)
+float* g_fake_grad_abs = nullptr;
+#endif
 hipError_t launch_remap_strip_u8(const uint8_t* d_in, float* d_out, const RemapArgs& a, const StripPlan& p, int64_t nframes, int fpb,
                                  hipStream_t s, float* d_l1, float* d_l2, float* d_l3) {
   if (nframes <= 0) return hipSuccess;
   if ((int64_t)a.in_w * a.in_h >= (int64_t)kOutside || (int64_t)a.out_w * (a.out_h + 8) * 4 >= 0xc0000000ll) return hipErrorInvalidValue;
+#if MDC_EXP_STRIP_FAKE_GRAD
+  const PyramidOut py{d_l1, d_l2, d_l3, g_fake_grad_dI, g_fake_grad_abs};
+#else
   const PyramidOut py{d_l1, d_l2, d_l3};
+#endif
   const bool pyr = d_l1 || d_l2 || d_l3;
 #define MDC_STRIP(V_, P_)                                                                                        \
   (p.nbuf == 1   ? launch_strip_passes<V_, P_, 1>(d_in, d_out, a, p, py, nframes, fpb, s)                          \
@@ -1389,7 +1451,9 @@ hipError_t launch_remap_tiled_u8(const uint8_t* d_in, float* d_out, const RemapA
   // frames are addressed through 32-bit buffer offsets
   if ((int64_t)a.in_w * a.in_h >= (int64_t)kOutside || (int64_t)a.out_w * a.out_h * 4 >= (int64_t)kOutside)
     return hipErrorInvalidValue;
-  const TiledLaunch l{d_in, d_out, a, p, PyramidOut{d_l1, d_l2, d_l3}, nframes, fpb, s};
+  PyramidOut tiled_py{};
+  tiled_py.l1 = d_l1, tiled_py.l2 = d_l2, tiled_py.l3 = d_l3;
+  const TiledLaunch l{d_in, d_out, a, p, tiled_py, nframes, fpb, s};
   if (a.vinv) return p.has_black ? launch_tiled_nt<true, true>(l) : launch_tiled_nt<true, false>(l);
   return p.has_black ? launch_tiled_nt<false, true>(l) : launch_tiled_nt<false, false>(l);
 }
@@ -1399,7 +1463,7 @@ hipError_t launch_remap_tiled_f32(const float* d_in, float* d_out, const RemapAr
   if (nframes <= 0) return hipSuccess;
   if ((int64_t)a.in_w * a.in_h * 4 >= (int64_t)kOutside || (int64_t)a.out_w * a.out_h * 4 >= (int64_t)kOutside)
     return hipErrorInvalidValue;
-  const TiledLaunch l{reinterpret_cast<const uint8_t*>(d_in), d_out, a, p, PyramidOut{nullptr, nullptr, nullptr}, nframes, fpb, s};
+  const TiledLaunch l{reinterpret_cast<const uint8_t*>(d_in), d_out, a, p, PyramidOut{}, nframes, fpb, s};
   return p.has_black ? launch_tiled_shape<false, true, false, true>(l) : launch_tiled_shape<false, false, false, true>(l);
 }
 

@@ -490,6 +490,22 @@ int mdc_device_alloc(mdc_ctx* c, size_t bytes, void** d_ptr) try {
   if (!d_ptr) return fail(c, MDC_ERR_ARG, "mdc_device_alloc: bad argument");
   *d_ptr = nullptr;
   DeviceGuard dg(c->device);
+  // a sequence-sized buffer (a GiB or more: results of getImagesDevice, a caller's frame store) is striped over the device's memory
+  // classes like the pairs of mdc_alloc_placed_device; small ones and devices without virtual memory
+  // management: hipMalloc
+  if (bytes >= ((size_t)1 << 30)) {
+    mdc_striped_set set;
+    const size_t one = bytes;
+    if (mdc_alloc_striped_set_device(c, 1, &one, nullptr, &set) == MDC_OK) {
+      if (set.strategy == MDC_PLACE_VMM) {
+        std::lock_guard<std::mutex> lk(c->striped_mu);
+        c->striped[set.d_ptr[0]] = set.handle;
+        *d_ptr = set.d_ptr[0];
+        return MDC_OK;
+      }
+      (void)mdc_free_striped_set_device(c, &set);  // (plain allocations: the ordinary path below owns those)
+    }
+  }
   MDC_HIP(c, hipMalloc(d_ptr, std::max<size_t>(bytes, 1)));
   return MDC_OK;
 } MDC_CATCH(c)
@@ -497,6 +513,22 @@ int mdc_device_alloc(mdc_ctx* c, size_t bytes, void** d_ptr) try {
 void mdc_device_free(mdc_ctx* c, void* d_ptr) {
   if (!c || !d_ptr) return;
   DeviceGuard dg(c->device);
+  void* arena = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(c->striped_mu);
+    auto it = c->striped.find(d_ptr);
+    if (it != c->striped.end()) {
+      arena = it->second;
+      c->striped.erase(it);
+    }
+  }
+  if (arena) {
+    mdc_striped_set set;
+    memset(&set, 0, sizeof set);
+    set.handle = arena;
+    (void)mdc_free_striped_set_device(c, &set);
+    return;
+  }
   (void)hipFree(d_ptr);
 }
 

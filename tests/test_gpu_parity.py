@@ -1169,3 +1169,27 @@ def test_striped_set_holds_a_pyramid_step(setups, oracle, torch_cuda, monkeypatc
     plain = s.ctx.alloc_striped_set([1 << 20, 3 << 20], st)
     assert plain.strategy == capi.PLACE_FIRST and plain.d_ptr[0] and plain.d_ptr[1]
     s.ctx.free_striped_set(plain)
+
+
+def test_device_alloc_stripes_large_buffers(setups, oracle, torch_cuda):
+    """mdc_device_alloc: a GiB or more comes striped over the device's memory classes (the same machinery as mdc_alloc_striped_set_device),
+    smaller buffers from hipMalloc; both hold results like any device memory and go back through mdc_device_free."""
+    from mono_dataset_code_amd import capi, synth
+
+    torch = torch_cuda
+    s = setups("full_1280_to_640")
+    n, npix, nout = 900, s.W * s.H, s.w * s.h  # 1.18 GB of frames, 1.11 GB of results
+    st = torch.cuda.current_stream().cuda_stream
+    flags = capi.RECTIFY | capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED
+    for rnd in range(2):
+        d_in, d_out, small = s.ctx.device_alloc(n * npix), s.ctx.device_alloc(n * nout * 4), s.ctx.device_alloc(4096)
+        assert d_in and d_out and small and len({d_in, d_out, small}) == 3
+        s.ctx.synth_frames(d_in, 70 + rnd, n, npix, synth.SEED, st)
+        s.ctx.process_batch(d_in, d_out, n, flags, st)
+        torch.cuda.synchronize()
+        for f in (0, n // 3, n - 1):
+            raw = s.ctx.copy_to_host(d_in + f * npix, npix, np.uint8)
+            assert np.array_equal(raw, synth.noise_frames(70 + rnd + f, 1, npix)[0])
+            assert bits_equal(s.ctx.copy_to_host(d_out + f * nout * 4, nout, np.float32), s.want(oracle, raw, 1, 1, 1, 1))
+        for p in (d_in, d_out, small):
+            s.ctx.device_free(p)

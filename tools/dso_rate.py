@@ -32,14 +32,40 @@ torch.cuda.set_stream(st)
 s = st.cuda_stream
 npi = 1280 * 1024
 dims = [(1280 >> l, 1024 >> l) for l in range(4)]
-d_in = torch.empty(n * npi, dtype=torch.uint8, device="cuda")
+PLACED = bool(os.environ.get("DSO_PLACED"))  # every buffer from the product's allocator (striped over the memory classes)
+
+
+class P:
+    """a device buffer by its address, with the two tensor methods this script uses"""
+
+    def __init__(self, ptr, count):
+        self.ptr, self.count = ptr, count
+
+    def data_ptr(self):
+        return self.ptr
+
+    def view(self, dt):
+        return torch.from_numpy(ctx.copy_to_host(self.ptr, self.count, np.int32))
+
+
+if PLACED:
+    pb = ctx.alloc_placed(n, 15, capi.PLACE_AUTO, s)
+    print("buffers:", pb.describe()["how"])
+    counts = [n * w * h for w, h in dims[1:]] + [n * w * h * 3 for w, h in dims] + [n * w * h for w, h in dims]
+    ss = ctx.alloc_striped_set([4 * x for x in counts], s)
+    ss2 = ctx.alloc_striped_set([4 * x for x in counts[3:]], s)  # (a set holds 16 buffers at most)
+    bufs = [P(ss.d_ptr[k], x) for k, x in enumerate(counts)] + [P(ss2.d_ptr[k], x) for k, x in enumerate(counts[3:])]
+    d_in, d_base = P(pb.d_in, n * npi // 4), P(pb.d_out, n * npi)
+    lv, dI, ab, dI2, ab2 = bufs[0:3], bufs[3:7], bufs[7:11], bufs[11:15], bufs[15:19]
+else:
+    d_in = torch.empty(n * npi, dtype=torch.uint8, device="cuda")
+    d_base = torch.empty(n * npi, dtype=torch.float32, device="cuda")
+    lv = [torch.empty(n * w * h, dtype=torch.float32, device="cuda") for w, h in dims[1:]]
+    dI = [torch.empty(n * w * h * 3, dtype=torch.float32, device="cuda") for w, h in dims]
+    ab = [torch.empty(n * w * h, dtype=torch.float32, device="cuda") for w, h in dims]
+    dI2 = [torch.empty_like(t) for t in dI]
+    ab2 = [torch.empty_like(t) for t in ab]
 ctx.synth_frames(d_in.data_ptr(), 0, n, npi, synth.SEED, s)
-d_base = torch.empty(n * npi, dtype=torch.float32, device="cuda")
-lv = [torch.empty(n * w * h, dtype=torch.float32, device="cuda") for w, h in dims[1:]]
-dI = [torch.empty(n * w * h * 3, dtype=torch.float32, device="cuda") for w, h in dims]
-ab = [torch.empty(n * w * h, dtype=torch.float32, device="cuda") for w, h in dims]
-dI2 = [torch.empty_like(t) for t in dI]
-ab2 = [torch.empty_like(t) for t in ab]
 
 
 def separate():
@@ -76,6 +102,7 @@ timeit(lambda: fused(0), reps=3)  # (the one-call path's own output buffers and 
 for chunk in (0, 8, 16, 24, 48, 96, 0):
     t = timeit(lambda: fused(chunk))
     print("one call, chunks of %4s frames (two launches per chunk)  : %8.3f ms  %7.1f frames/s  %.2f TB/s algorithmic" % (chunk or "auto", t, n / t * 1e3, alg * n / t / 1e9))
+torch.cuda.synchronize()
 same = all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(dI + ab, dI2 + ab2))
 print("one-call results == separate-launch results, bit for bit:", same)
 sys.exit(0 if same else 1)

@@ -203,6 +203,8 @@ PY
     power)   # power / clocks / launch time per library build (tools/power_ab.py; LIBS="lutrep16 fake1 ...")
       libs=default; for l in ${LIBS:-lutrep16 lutrep8 fake1 fake2 skipstore skipload padvalu64}; do libs="$libs,mono_dataset_code_amd/variants/libmdc_hip_$l.so"; done
       timeout 600 python tools/power_ab.py --libs "$libs" --rounds ${ROUNDS:-3} ${POWER_ARGS:-} > "$OUT/power_ab.txt" 2>&1; grep -av amdgpu.ids "$OUT/power_ab.txt" | tail -14 | cut -c1-330 ;;
+    pyramid_sweep)  # config 5: frames per prefetched chunk x streams (PYR_CHUNKS, PYR_STREAMS, PYR_PLACED=1: buffers from the product's allocator)
+      timeout 900 python tools/pyramid_sweep.py ${PYR_N:-1024} ${ROUNDS:-3} > "$OUT/pyramid_sweep${PYR_TAG:-}.txt" 2>&1; grep -av amdgpu.ids "$OUT/pyramid_sweep${PYR_TAG:-}.txt" | tail -24 ;;
     distort) timeout 300 python tools/distort_rate.py > "$OUT/distort_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/distort_rate.txt" | tail -5 ;;
     vcal)    timeout 600 python tools/vcal_rate.py > "$OUT/vcal_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/vcal_rate.txt" | tail -20 ;;
     *) echo "unknown stage $stage" ;;

@@ -35,7 +35,23 @@ s = st.cuda_stream
 npi = 1280 * 1024
 dims = [(1280 >> l, 1024 >> l) for l in range(4)]
 pairs = []
-for k in range(2):  # two (frames, base) pairs, a 40-GB spacer between them (given back)
+
+
+class P:  # a raw device address with the one tensor method this script uses
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def data_ptr(self):
+        return self.ptr
+
+
+if os.environ.get("PYR_PLACED"):  # every buffer from the product's allocator (mdc_alloc_placed_device + mdc_alloc_striped_set_device)
+    pb = ctx.alloc_placed(n, 15, capi.PLACE_AUTO, s)
+    ctx.synth_frames(pb.d_in, 0, n, npi, synth.SEED, s)
+    ss = ctx.alloc_striped_set([n * w * h * 4 for w, h in dims[1:]], s)
+    pairs.append((P(pb.d_in), P(pb.d_out), [P(ss.d_ptr[k]) for k in range(3)]))
+    print("buffers:", pb.describe()["how"])
+for k in range(0 if os.environ.get("PYR_PLACED") else 2):  # two (frames, base) pairs, a 40-GB spacer between them (given back)
     d_in = torch.empty(n * npi, dtype=torch.uint8, device="cuda")
     ctx.synth_frames(d_in.data_ptr(), 0, n, npi, synth.SEED, s)
     d_base = torch.empty(n * npi, dtype=torch.float32, device="cuda")
@@ -43,7 +59,8 @@ for k in range(2):  # two (frames, base) pairs, a 40-GB spacer between them (giv
     pairs.append((d_in, d_base, lv))
     if k == 0:
         spacer = torch.empty(40 << 30, dtype=torch.uint8, device="cuda")
-del spacer
+if not os.environ.get("PYR_PLACED"):
+    del spacer
 torch.cuda.empty_cache()
 ALG = 7593190  # bytes per frame
 
