@@ -319,8 +319,9 @@ MDC_API int mdc_tune_placement_device(mdc_ctx* ctx, const uint8_t* const* d_in, 
  *                     (mdc_tune_placement_device), the fastest kept, the rest freed; needs room for the candidates (else fewer, down to 1);
  *   MDC_PLACE_VMM     both buffers assembled from 512-MiB physical pieces (hipMemCreate / hipMemMap), which are first sorted into the
  *                     device's three memory classes by a timed linear stream against reference pieces; every buffer is then striped over
- *                     all classes in equal shares (64-MiB stripes).  Also fits pairs that leave no room for candidates (a 50,000-frame
- *                     sequence).  An address a kernel may know stays mapped until mdc_free_placed_device.
+ *                     all classes in equal shares, piece by piece.  Also fits pairs that leave no room for candidates (a 50,000-frame
+ *                     sequence).  An address a kernel may know stays mapped until mdc_free_placed_device; the address ranges themselves
+ *                     are never recycled within a process (ROCm 7.2 serves stale translations for a re-used range: DESIGN.md 6.1).
  *   MDC_PLACE_AUTO    the library's default (MDC_PLACEMENT=first|malloc|vmm in the environment overrides it).
  * ms_first = the probe on the first pair of plain allocations (what a caller gets who takes them as they come; 0 where not measured),
  * ms_chosen = on the pair handed out.  Release with mdc_free_placed_device (waits for the device; never hipFree the pointers). */

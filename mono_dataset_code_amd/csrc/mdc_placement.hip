@@ -87,7 +87,12 @@ void release_arena(Arena* a) {
   if (a->m_out) (void)hipFree(a->m_out);
   for (void* p : a->plain) (void)hipFree(p);
   for (size_t k = a->mapped.size(); k-- > 0;) (void)hipMemUnmap(a->mapped[k].first, a->mapped[k].second);
-  for (size_t k = a->reserved.size(); k-- > 0;) (void)hipMemAddressFree(a->reserved[k].first, a->reserved[k].second);
+  // The address ranges are NOT given back (hipMemAddressFree): ROCm 7.2 serves stale translations for a range that is reserved and
+  // mapped again after hipMemUnmap -- kernels then read and write the physical pages of the PREVIOUS mapping (tools/vmm_offset_check.hip:
+  // 650 of 768 pages wrong in the second round; with the reservations kept, none in any round; round 5's "intermittent memory faults"
+  // of churned candidates, profiles/r05_experiments/07_*, were this).  No address of an arena is ever mapped twice; what a process
+  // spends is address space only (tens of GiB per allocation of a 47-bit space: thousands of allocations), and when a reservation
+  // fails the allocator falls back to plain allocations.
   for (hipMemGenericAllocationHandle_t h : a->handles)
     if (h) (void)hipMemRelease(h);  // after the last mapping is gone
   (void)hipDeviceSynchronize();
@@ -241,9 +246,9 @@ int place_malloc(mdc_ctx* c, Arena* a, size_t in_bytes, size_t out_bytes, size_t
 // of 1 GiB: 86 / 84 / 74), handed out by the driver in runs of whole GiB -- the signature of the three ranks (stack IDs) of a 12-high
 // HBM3E stack selected by high physical address bits.  Ranks share a channel's data bus but have their own banks: the hundreds of
 // row-sized streams of a launch (a workgroup's output rows, its source windows) conflict in the banks of ONE rank far more often than
-// when they are spread over all three.  Hence the composition: EVERY range is striped over all classes in equal shares, in stripes
-// far smaller than the part of a range a launch works on at one time (measured: 0.66-0.67 of 8 TB/s for the headline against 0.63-0.64 for
-// the best pair of plain allocations and 0.58-0.60 for the first pair; frames in one class and results in another: 0.63).
+// when they are spread over all three.  Hence the composition: EVERY range is striped over all classes in equal shares, piece by piece
+// (512 MiB: less than the part of a range a launch works on at one time; measured: 0.66-0.67 of 8 TB/s for the headline against 0.63-0.64
+// for the best pair of plain allocations and 0.58-0.60 for the first pair; frames in one class and results in another: 0.63).
 struct Range {
   size_t bytes = 0, pieces = 0;
   void* va = nullptr;
@@ -283,11 +288,15 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
   hipMemAccessDesc acc = {};
   acc.location = prop.location;
   acc.flags = hipMemAccessFlagsProtReadWrite;
-  MDC_HIP(c, hipMemAddressReserve(&a->probe_va, max_pieces * piece, gran, nullptr, 0));
-  a->reserved.push_back({a->probe_va, max_pieces * piece});
-  auto probe_ptr = [&](size_t k) { return static_cast<char*>(a->probe_va) + k * piece; };
-  auto grow = [&](size_t upto) -> int {  // more pieces, mapped at the end of the probe range
+  std::vector<char*> piece_va;  // where piece k is mapped for the probes: batches of whole groups, every batch a reservation of its own
+  auto probe_ptr = [&](size_t k) { return piece_va[k]; };
+  auto grow = [&](size_t upto) -> int {  // more pieces, each mapped once for the probes
     const size_t from = a->handles.size();
+    if (upto <= from) return MDC_OK;
+    void* base = nullptr;
+    MDC_HIP(c, hipMemAddressReserve(&base, (upto - from) * piece, gran, nullptr, 0));
+    a->reserved.push_back({base, (upto - from) * piece});
+    if (!a->probe_va) a->probe_va = base;
     while (a->handles.size() < upto) {
       hipMemGenericAllocationHandle_t h;
       if (hipMemCreate(&h, piece, &prop, 0) != hipSuccess) {
@@ -295,11 +304,12 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
         break;
       }
       a->handles.push_back(h);
-      const size_t k = a->handles.size() - 1;
-      MDC_HIP(c, hipMemMap(probe_ptr(k), piece, 0, h, 0));
-      a->mapped.push_back({probe_ptr(k), piece});
+      char* at = static_cast<char*>(base) + (a->handles.size() - 1 - from) * piece;
+      piece_va.push_back(at);
+      MDC_HIP(c, hipMemMap(at, piece, 0, h, 0));
+      a->mapped.push_back({at, piece});
     }
-    if (a->handles.size() > from) MDC_HIP(c, hipMemSetAccess(probe_ptr(from), (a->handles.size() - from) * piece, &acc, 1));
+    if (a->handles.size() > from) MDC_HIP(c, hipMemSetAccess(base, (a->handles.size() - from) * piece, &acc, 1));
     return MDC_OK;
   };
   // ---- classes: 0 = the class of piece 0, 1 = the class of the first piece that is fast with piece 0, 2 = fast with both.
@@ -482,41 +492,18 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
     MDC_HIP(c, hipDeviceSynchronize());
   }
   // ---- the ranges: every piece mapped a second time, in its final place (the probe mappings of the pieces in use stay: no address a
-  // kernel may still know is ever unmapped while the arena lives).  A range is made of STRIPES -- stripe t is sub-range (t / n) of the
-  // range's piece (t mod n), so consecutive stripes walk through all its pieces and their classes -- where hipMemMap takes an offset
-  // into a handle (ROCm 7 does); else of whole pieces.
-  size_t stripe = (size_t)std::max(0, env_int(getenv("MDC_PLACE_STRIPE_MIB"), 64)) << 20;
-  if (stripe == 0 || stripe >= piece || piece % stripe != 0 || stripe % gran != 0 || compose != 0) stripe = piece;
-  auto map_range = [&](Range& r, size_t st) -> hipError_t {
-    const size_t n = r.piece_ids.size(), per = piece / st;
-    for (size_t t = 0; t < n * per; t++) {
-      char* where = static_cast<char*>(r.va) + t * st;
-      const hipError_t e = hipMemMap(where, st, (t / n) * st, a->handles[r.piece_ids[t % n]], 0);
-      if (e != hipSuccess) return e;
-      a->mapped.push_back({where, st});
-    }
-    return hipSuccess;
-  };
+  // kernel may still know is ever unmapped while the arena lives).  Whole pieces: hipMemMap refuses an offset into a handle
+  // (hipErrorInvalidValue on ROCm 7.2, as on CUDA), so a range's classes alternate piece by piece.
   for (Range& r : ranges) {
     MDC_HIP(c, hipMemAddressReserve(&r.va, r.pieces * piece, gran, nullptr, 0));
     a->reserved.push_back({r.va, r.pieces * piece});
-  }
-  if (stripe < piece) {  // (an offset the runtime refuses shows at the first stripe that has one)
-    const size_t before = a->mapped.size();
-    bool ok = true;
-    for (Range& r : ranges) ok = ok && map_range(r, stripe) == hipSuccess;
-    if (!ok) {
-      (void)hipGetLastError();
-      while (a->mapped.size() > before) {
-        (void)hipMemUnmap(a->mapped.back().first, a->mapped.back().second);
-        a->mapped.pop_back();
-      }
-      stripe = piece;
+    for (size_t t = 0; t < r.piece_ids.size(); t++) {
+      char* where = static_cast<char*>(r.va) + t * piece;
+      MDC_HIP(c, hipMemMap(where, piece, 0, a->handles[r.piece_ids[t]], 0));
+      a->mapped.push_back({where, piece});
     }
+    MDC_HIP(c, hipMemSetAccess(r.va, r.pieces * piece, &acc, 1));
   }
-  if (stripe == piece)
-    for (Range& r : ranges) MDC_HIP(c, map_range(r, piece));
-  for (Range& r : ranges) MDC_HIP(c, hipMemSetAccess(r.va, r.pieces * piece, &acc, 1));
   MDC_HIP(c, hipDeviceSynchronize());
   for (int k = 0; k < 3; k++) n_cls_out[k] = n_cls[k];
   *pieces_out = (int)M;
@@ -529,7 +516,6 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
            "pieces: %d / %d / %d (clusters %.1f %%, %.1f %% apart), in use %d / %d / %d; %s",
            ranges.size(), M - returned, piece >> 20, M, returned, n_cls[0], n_cls[1], n_cls[2], gap[0] * 100, gap[1] * 100, used_cls[0], used_cls[1], used_cls[2],
            compose == 1 ? "creation order, no classification" : compose == 2 ? "a range in ONE class (diagnosis)" : "every range striped over the classes");
-  if (stripe < piece) snprintf(note + strlen(note), note_cap - strlen(note), ", stripes of %zu MiB", stripe >> 20);
   return MDC_OK;
 }
 

@@ -1137,7 +1137,6 @@ def test_striped_set_holds_a_pyramid_step(setups, oracle, torch_cuda, monkeypatc
     torch = torch_cuda
     s = setups("full_1280_to_1280")
     monkeypatch.setenv("MDC_PLACE_PIECE_MIB", "64")
-    monkeypatch.setenv("MDC_PLACE_STRIPE_MIB", "16")
     n, npix, nout = 96, s.W * s.H, s.w * s.h
     st = torch.cuda.current_stream().cuda_stream
     flags = capi.RECTIFY | capi.GAMMA | capi.VIGNETTE | capi.KILL_OVEREXPOSED

@@ -193,10 +193,10 @@ for r in rows:
     print("%-62s calls %5s  avg %8.1f us  total %8.2f ms  %5.1f %%" % (m.group(0) if m else r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, 100 * float(r["TotalDurationNs"]) / tot))
 PY
       ;;
-    placed)  # the headline launch on buffers from the product's allocator, one strategy / setting per process (PLACED_CFGS="strategy:piece MiB:compose:rounds[:frames[:stripe MiB]] ...")
+    placed)  # the headline launch on buffers from the product's allocator, one strategy / setting per process (PLACED_CFGS="strategy:piece MiB:compose:rounds[:frames] ...")
       for cfg in ${PLACED_CFGS:-first:0:0:1 malloc:0:0:1 vmm:1024:0:1 vmm:1024:1:1 vmm:1024:2:1 vmm:256:0:1 vmm:256:2:1 vmm:64:2:1}; do
-        IFS=: read -r strat piece comp rounds frames stripe <<< "$cfg"
-        MDC_PLACE_PIECE_MIB=${piece:-1024} MDC_PLACE_COMPOSE=${comp:-0} MDC_PLACE_STRIPE_MIB=${stripe:-0} timeout ${PLACED_TIMEOUT:-400} python tools/placed_probe.py $strat ${rounds:-1} ${frames:-4096} >> "$OUT/placed_probe.txt" 2>&1
+        IFS=: read -r strat piece comp rounds frames <<< "$cfg"
+        MDC_PLACE_PIECE_MIB=${piece:-1024} MDC_PLACE_COMPOSE=${comp:-0} timeout ${PLACED_TIMEOUT:-400} python tools/placed_probe.py $strat ${rounds:-1} ${frames:-4096} >> "$OUT/placed_probe.txt" 2>&1
         echo "rc=$? ($cfg)" >> "$OUT/placed_probe.txt"
       done
       grep -a "PLACED\|rc=\|fault\|Error\|^   " "$OUT/placed_probe.txt" | cut -c1-420 ;;

@@ -46,7 +46,7 @@ def main():
     rx, ry = fov.remap()
     _, vinv = photo.vignette()
     ginv = photo.ginv()
-    knobs = " ".join("%s=%s" % (k, os.environ[k]) for k in ("MDC_PLACE_PIECE_MIB", "MDC_PLACE_COMPOSE", "MDC_PLACE_STRIPE_MIB", "MDC_PLACE_CANDIDATES", "MDC_PLACE_SPREAD_MB") if k in os.environ)
+    knobs = " ".join("%s=%s" % (k, os.environ[k]) for k in ("MDC_PLACE_PIECE_MIB", "MDC_PLACE_COMPOSE", "MDC_PLACE_CANDIDATES", "MDC_PLACE_SPREAD_MB") if k in os.environ)
     for rnd in range(ROUNDS):
         t0 = time.perf_counter()
         b = ctx.alloc_placed(FRAMES, flags, which, s)
