@@ -52,7 +52,13 @@ def main():
         b = ctx.alloc_placed(FRAMES, flags, which, s)
         t_alloc = time.perf_counter() - t0
         ctx.synth_frames(b.d_in, 0, FRAMES, NPI, synth.SEED, s)
-        if rnd == 0:
+        if rnd == 0 and os.environ.get("PROBE_SHAPE"):  # e.g. 128x16:128 -- a given plan instead of the tuner's
+            wh, fpb = os.environ["PROBE_SHAPE"].split(":")
+            ctx.set_option(capi.OPT_TILE_COLS, int(wh.split("x")[0]))
+            ctx.set_option(capi.OPT_TILE_ROWS, int(wh.split("x")[1]))
+            ctx.set_option(capi.OPT_FRAMES_PER_BLOCK, int(fpb))
+            plan = "%s fpb %s (given)" % (wh, fpb)
+        elif rnd == 0:
             t = ctx.tune(b.d_in, b.d_out, min(FRAMES, 4096), flags, s)
             plan = "%dx%d fpb %d" % (t.tile_w, t.tile_h, t.frames_per_block)
         t1 = time.perf_counter()
