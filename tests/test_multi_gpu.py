@@ -234,6 +234,9 @@ def test_bench_over_rccl_on_real_devices(tmp_path, oracle):
         assert len({d["pci"] for d in ranks["devices"]}) == n, ranks["devices"]  # N ranks, N different GPUs
         assert out["parity"]["mismatching_pixels"] == 0 and len(out["roofline"]["per_rank_frac"]) == n
         assert out["config"]["tables"] == "rank-0 build + one RCCL broadcast" and out["config"]["table_broadcast_ms"] > 0
+        # every rank allocates through the product's allocator on ITS device and says what it got
+        for d_ in ranks["devices"]:
+            assert d_["placement"]["strategy"] in ("first", "malloc", "vmm"), d_
         _check_rank_dumps(str(dump), n, 3, oracle)
         seq = _bench(["--gpus", str(n), "--steps", "3", "--warmup", "1", "--workload", "seq50k", "--frames", "96", "--preroll-s", "0.05", "--preroll-max-s",
                       "0.3", "--no-cpu-baseline"], timeout=1200)

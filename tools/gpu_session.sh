@@ -205,6 +205,14 @@ PY
       timeout 600 python tools/power_ab.py --libs "$libs" --rounds ${ROUNDS:-3} ${POWER_ARGS:-} > "$OUT/power_ab.txt" 2>&1; grep -av amdgpu.ids "$OUT/power_ab.txt" | tail -14 | cut -c1-330 ;;
     pyramid_sweep)  # config 5: frames per prefetched chunk x streams (PYR_CHUNKS, PYR_STREAMS, PYR_PLACED=1: buffers from the product's allocator)
       timeout 900 python tools/pyramid_sweep.py ${PYR_N:-1024} ${ROUNDS:-3} > "$OUT/pyramid_sweep${PYR_TAG:-}.txt" 2>&1; grep -av amdgpu.ids "$OUT/pyramid_sweep${PYR_TAG:-}.txt" | tail -24 ;;
+    vmm_check)  # hipMemMap with an offset; address ranges given back and re-used / kept / re-used after an ordinary hipMalloc + hipFree (tools/vmm_offset_check.hip)
+      ( echo "--- stripes of 64 MiB (an offset into the handle)"; tools/bin/vmm_offset_check 3 512 64 1
+        echo "--- whole pieces, address ranges given back and re-used"; tools/bin/vmm_offset_check 3 512 512 4
+        echo "--- whole pieces, address ranges kept (VMM_KEEP_VA=1)"; VMM_KEEP_VA=1 tools/bin/vmm_offset_check 3 512 512 5
+        echo "--- address ranges re-used, a hipMalloc + hipFree of 1 GiB between the rounds (VMM_CHURN=1)"; VMM_CHURN=1 tools/bin/vmm_offset_check 3 512 512 4
+        echo "--- 12 pieces, address ranges kept"; VMM_KEEP_VA=1 tools/bin/vmm_offset_check 12 512 512 4
+        echo "--- the allocator: ranges of the process after earlier ones were freed (tools/striped_alloc_check.py)"; python tools/striped_alloc_check.py 2>&1 | grep -a "frame\|^set\|ptr" | cut -c1-200 ) > "$OUT/vmm_offset_check.txt" 2>&1
+      grep -a "^---\|^round\|MISMATCH\|all pages\|refused\|BAD\|False" "$OUT/vmm_offset_check.txt" | cut -c1-200 | tail -30 ;;
     distort) timeout 300 python tools/distort_rate.py > "$OUT/distort_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/distort_rate.txt" | tail -5 ;;
     vcal)    timeout 600 python tools/vcal_rate.py > "$OUT/vcal_rate.txt" 2>&1; grep -av amdgpu.ids "$OUT/vcal_rate.txt" | tail -20 ;;
     *) echo "unknown stage $stage" ;;

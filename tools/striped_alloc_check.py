@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""mdc_device_alloc of a GiB or more and mdc_alloc_striped_set_device hand out ranges assembled from physical pieces: frames written by a kernel through such a
+range must come back through hipMemcpy, in every piece, after earlier ranges of the process were freed (the address-range hazard of
+tools/vmm_offset_check.hip).   python tools/striped_alloc_check.py"""
 import os, sys, tempfile
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--settle", type=float, default=0.3, help="seconds of untimed launches of a variant before its timed ones (0: the old behaviour, short bursts)")
     ap.add_argument("--fpb", default="0")
     ap.add_argument("--kernel", default="tiled")
     ap.add_argument("--libs", default="default", help="comma list of libmdc_hip builds ('default' = the in-tree one)")
@@ -161,6 +162,13 @@ def main():
             try_set(m, ctx, "OPT_WINDOW_BUFFERS", v[6])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), B, flags, s)
+            if r and a.settle > 0:  # back to steady clocks after the re-plan's idle gap (the ~30 ms after one run 8 % slow: r06 experiment 06)
+                import time
+                t_s = time.perf_counter()
+                while time.perf_counter() - t_s < a.settle:
+                    for _ in range(10):
+                        ctx.process_batch(d_in.data_ptr(), d_out.data_ptr(), B, flags, s)
+                    torch.cuda.synchronize()
             if r == 0:  # every variant's output against the first variant's, bit for bit (tuning variants must not change results)
                 torch.cuda.synchronize()
                 if ref_out is None:
