@@ -23,7 +23,7 @@ LIB_HOST = os.path.join(PKG, "libmdc_host.so")
 
 HIP_SOURCES = [os.path.join(CSRC, f) for f in ("mdc_kernels.hip", "mdc_vcal.hip", "mdc_jpeg.hip", "mdc_capi.hip", "mdc_plan.hip", "mdc_host_calls.hip",
                                                 "mdc_pipeline.hip", "mdc_placement.hip")]
-HIP_DEPS = HIP_SOURCES + [os.path.join(CSRC, "mdc_exports.map"), os.path.join(CSRC, "mdc_internal.h"), os.path.join(CSRC, "mdc_ctx.h"), os.path.join(CSRC, "mdc_build_config.h"), os.path.join(CSRC, "fov_point_model.h"), os.path.join(INC, "mdc_hip.h")]
+HIP_DEPS = HIP_SOURCES + [os.path.join(CSRC, "mdc_exports.map"), os.path.join(CSRC, "mdc_internal.h"), os.path.join(CSRC, "mdc_ctx.h"), os.path.join(CSRC, "mdc_build_config.h"), os.path.join(CSRC, "fov_point_model.h"), os.path.join(CSRC, "placement_classes.h"), os.path.join(INC, "mdc_hip.h")]
 HOST_SOURCES = [os.path.join(HOST, f) for f in (
     "fov_undistorter.cpp", "photometric_undistorter.cpp", "gray_png.cpp", "host_device.cpp", "mdc_host_capi.cpp",
     "image_codecs.cpp", "image_codecs_ext.cpp", "zip_reader.cpp", "image_pool.cpp", "dataset_reader.cpp")]

@@ -19,6 +19,7 @@
 // The reference call site this serves: the frame / result buffers a reader keeps for a sequence, src/BenchmarkDatasetReader.h:218-224
 // (internalTempBuffer and the ExposureImage blocks), here device-resident.
 #include "mdc_ctx.h"
+#include "placement_classes.h"
 
 namespace mdc {
 namespace {
@@ -321,8 +322,7 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
   const size_t G = std::max<size_t>(1, ((size_t)1 << 30) / piece), group_bytes = G * piece;
   std::vector<float> t0, t1;  // per group
   std::vector<int> cls;       // per piece
-  size_t ref1 = 0;            // group
-  bool ref1_set = false;
+  long ref1 = -1;             // group: the second reference (the first group that is fast with the first one)
   float gap[2] = {0.f, 0.f};
   const size_t rd = group_bytes / 2;  // 1 byte read : 2 bytes written, the path's ratio
   auto group_ptr = [&](size_t g) { return probe_ptr(g * G); };
@@ -334,28 +334,6 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
     for (int again = 0; again < 2 && *ms > 1.12f * lo; again++)
       if (!time_stream(group_ptr(ref), rd, group_ptr(g), group_bytes, s, ev.e0, ev.e1, ms)) return false;
     return true;
-  };
-  // Two clusters of times: a pair in one class runs 5-9 % slower than a pair across classes, the noise inside a cluster is ~1 %.  The
-  // split of the sorted times that maximises the between-cluster variance (Otsu), neither side smaller than a tenth of the set (stray
-  // fast or slow measurements must not become a "class").  -> the threshold, or +inf when the means are less than 3 % apart.
-  auto cut_of = [](std::vector<float> v, float* rel) -> float {
-    *rel = 0.f;
-    const size_t n = v.size();
-    if (n < 2) return std::numeric_limits<float>::infinity();
-    std::sort(v.begin(), v.end());
-    std::vector<double> pre(n + 1, 0.0);
-    for (size_t i = 0; i < n; i++) pre[i + 1] = pre[i] + v[i];
-    const size_t minsz = std::max<size_t>(1, n / 10);
-    double best = -1;
-    size_t at = 0;
-    for (size_t i = minsz; i + minsz <= n; i++) {
-      const double m1 = pre[i] / i, m2 = (pre[n] - pre[i]) / (n - i), sc = (double)i * (n - i) * (m2 - m1) * (m2 - m1);
-      if (sc > best) best = sc, at = i;
-    }
-    if (!at) return std::numeric_limits<float>::infinity();
-    const double m1 = pre[at] / at, m2 = (pre[n] - pre[at]) / (n - at);
-    *rel = m1 > 0 ? (float)((m2 - m1) / m1) : 0.f;
-    return *rel > 0.03f ? 0.5f * (v[at - 1] + v[at]) : std::numeric_limits<float>::infinity();
   };
   size_t ref0 = 0;  // group
   bool ref0_chosen = false;
@@ -375,7 +353,7 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
             v.push_back(t[g]);
           }
         float rel = 0.f;
-        (void)cut_of(v, &rel);
+        (void)placement_cut(v, &rel);
         if (rel > best_rel) best_rel = rel, ref0 = r, best_t = t;
         if (rel > 0.05f) break;  // a clean split: this reference lies in one class
       }
@@ -386,27 +364,16 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
       if (g != ref0 && !timed(ref0, g, &ms)) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
       t0.push_back(ms);
     }
-    std::vector<int> gcls(NG, 0);
     cls.assign(a->handles.size(), 0);
     if (NG < 2) return MDC_OK;
-    std::vector<float> v0;
-    for (size_t g = 0; g < NG; g++)
-      if (g != ref0) v0.push_back(t0[g]);
-    const float cut0 = cut_of(v0, &gap[0]);
-    std::vector<size_t> fast0;
-    for (size_t g = 0; g < NG; g++)
-      if (g != ref0 && std::isfinite(cut0) && t0[g] < cut0) fast0.push_back(g);
-    if (fast0.empty()) return MDC_OK;  // one class as far as can be seen
-    if (!ref1_set) ref1 = fast0[0], ref1_set = true;
-    t1.resize(NG, -1.f);
-    std::vector<float> v1;
-    for (size_t g : fast0) {
-      if (g == ref1) continue;
-      if (t1[g] < 0 && !timed(ref1, g, &t1[g])) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
-      v1.push_back(t1[g]);
+    std::vector<size_t> todo;
+    std::vector<int> gcls = placement_classes(t0, ref0, t1, &ref1, gap, &todo);  // which fast groups still need their time against the second reference
+    if (!todo.empty()) {
+      t1.resize(NG, -1.f);
+      for (size_t g : todo)
+        if (!timed((size_t)ref1, g, &t1[g])) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
+      gcls = placement_classes(t0, ref0, t1, &ref1, gap, nullptr);
     }
-    const float cut1 = cut_of(v1, &gap[1]);
-    for (size_t g : fast0) gcls[g] = (g == ref1 || !(std::isfinite(cut1) && t1[g] < cut1)) ? 1 : 2;
     for (size_t k = 0; k < NG * G; k++) cls[k] = gcls[k / G];
     return MDC_OK;
   };
@@ -461,13 +428,11 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
         int turn = (int)(i % 3);
         ranges[i].piece_ids.push_back(take(turn));
       }
-  } else {  // piece by piece round the classes, all ranges in step (range k starts at class k mod 3: a frame and its result lie at
-    std::vector<int> turn(ranges.size());  // about the same relative position of their ranges)
-    size_t longest = 0;
-    for (size_t i = 0; i < ranges.size(); i++) turn[i] = (int)(i % 3), longest = std::max(longest, ranges[i].pieces);
-    for (size_t k = 0; k < longest; k++)
-      for (size_t i = 0; i < ranges.size(); i++)
-        if (k < ranges[i].pieces) ranges[i].piece_ids.push_back(take(turn[i]));
+  } else {  // piece by piece round the classes, all ranges in step (placement_classes.h)
+    std::vector<size_t> want;
+    for (const Range& r : ranges) want.push_back(r.pieces);
+    const std::vector<std::vector<size_t>> ids = placement_compose(by_cls, want);
+    for (size_t i = 0; i < ranges.size(); i++) ranges[i].piece_ids = ids[i];
   }
   // ---- the surplus goes back to the device before anything else is mapped (MDC_PLACE_KEEP_SURPLUS=1: stays mapped until the end).
   // Only pieces no range uses are touched, after everything that ever ran on them has finished.
