@@ -283,8 +283,8 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
   const size_t cap = (size_t)((double)free_b * 0.92 / (double)piece);  // pieces the device has room for
   if (cap < need) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: %zu pieces of %zu MiB do not fit the device's free memory", need, piece >> 20);
   // how far the scan for all three classes may go: on some devices the third class only shows after 125 GiB of allocations
-  // (profiles/r05_experiments/11_*); what is not used goes back at once
-  const size_t scan = ((size_t)std::max(0, env_int(getenv("MDC_PLACE_SCAN_GIB"), 160)) << 30) / piece;
+  // (profiles/r05_experiments/11_*), on others 145 of the first 160 GiB are ONE class (session r06r); what is not used goes back at once
+  const size_t scan = ((size_t)std::max(0, env_int(getenv("MDC_PLACE_SCAN_GIB"), 256)) << 30) / piece;
   const size_t max_pieces = compose == 1 ? need : std::min(cap, std::max(4 * need + 24, scan));
   hipMemAccessDesc acc = {};
   acc.location = prop.location;
@@ -405,8 +405,38 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
   const size_t M = a->handles.size();
   cls.resize(M, 0);
   // ---- which pieces make up which range
+  // The pieces of a class, the surest first: a group whose time lies at its cluster's centre before one at its edge (a piece the driver
+  // put together from several blocks straddles two classes and shows an in-between time).
   std::vector<size_t> by_cls[3];
-  for (size_t k = 0; k < M; k++) by_cls[cls[k]].push_back(k);
+  {
+    const size_t NG = M / G;
+    std::vector<float> centre_t[3];
+    auto group_time = [&](size_t g) -> float {  // the time that decided the group's class
+      const int cg = cls[g * G];
+      if (cg == 0) return g < t0.size() ? t0[g] : 0.f;
+      return (g < t1.size() && t1[g] >= 0) ? t1[g] : -1.f;  // (the second reference itself: no time, sure by definition)
+    };
+    for (size_t g = 0; g < NG; g++)
+      if (g != ref0 && group_time(g) >= 0) centre_t[cls[g * G]].push_back(group_time(g));
+    float centre[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < 3; k++)
+      if (!centre_t[k].empty()) {
+        std::sort(centre_t[k].begin(), centre_t[k].end());
+        centre[k] = centre_t[k][centre_t[k].size() / 2];
+      }
+    std::vector<std::pair<float, size_t>> order[3];  // (distance from the centre, group)
+    for (size_t g = 0; g < NG; g++) {
+      const int cg = cls[g * G];
+      const float t = group_time(g);
+      order[cg].push_back({(g == ref0 || t < 0) ? 0.f : std::fabs(t - centre[cg]), g});
+    }
+    for (int k = 0; k < 3; k++) {
+      std::stable_sort(order[k].begin(), order[k].end(), [](const std::pair<float, size_t>& x, const std::pair<float, size_t>& y) { return x.first < y.first; });
+      for (const auto& e : order[k])
+        for (size_t q = 0; q < G; q++) by_cls[k].push_back(e.second * G + q);
+    }
+    for (size_t k = NG * G; k < M; k++) by_cls[cls[k]].push_back(k);  // (pieces beyond the last whole group: creation order, no classification)
+  }
   size_t at[3] = {0, 0, 0};
   auto take = [&](int& turn) -> size_t {  // the next piece of class `turn`, or of the class after it that still has one
     for (int q = 0; q < 3; q++) {
