@@ -30,7 +30,7 @@ def _bench_line(wl):
 
 def test_round_profiles_exist_for_every_workload():
     s = _summaries()
-    assert sorted(s) == sorted(WORKLOADS), sorted(s)
+    assert set(WORKLOADS) <= set(s), sorted(s)  # (+ e.g. fused_128x16: the headline on the plan the tuner did not pick that day)
     for wl in WORKLOADS:
         for suffix in ("kernel_stats.csv", "kernel_stats_whole_run.csv", "bench_under_profiler.json", "summary.json", "profiled_command.txt"):
             assert os.path.exists(os.path.join(PROF, "%s_%s_%s" % (TAG, wl, suffix))), (wl, suffix)

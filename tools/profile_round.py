@@ -64,14 +64,20 @@ def main():
     wls = sys.argv[2:] or ["fused", "unmap", "undistort_f32", "pyramid", "dso", "seq50k"]
     outdir = os.path.join(ROOT, "gpurun_out", tag + "_profiles")
     os.makedirs(outdir, exist_ok=True)
-    for wl in wls:
+    for spec in wls:
+        # "fused:128x16" = the workload on a given plan (tile columns x rows, 128 frames per workgroup) instead of the tuner's pick: the other
+        # instantiation a device may choose gets its own traffic entry; files are named <tag>_<workload>_<shape>_*
+        wl, _, shape = spec.partition(":")
         steps = STEPS.get(wl, 20)
-        scratch = os.path.join(ROOT, "gpurun_out", "%s_profile_scratch_%s" % (tag, wl))
+        name = wl + ("_" + shape if shape else "")
+        scratch = os.path.join(ROOT, "gpurun_out", "%s_profile_scratch_%s" % (tag, name))
         shutil.rmtree(scratch, ignore_errors=True)
         os.makedirs(scratch)
         bench = ["python3", os.path.join(ROOT, "bench.py"), "--workload", wl, "--steps", str(steps), "--warmup", "5", "--no-cpu-baseline", "--no-ceiling",
                  "--no-secondary", "--markers", "--parity-frames", "2"]
-        base = os.path.join(outdir, "%s_%s" % (tag, wl))
+        if shape:
+            bench += ["--tile-cols", shape.split("x")[0], "--tile-rows", shape.split("x")[1], "--fpb", "128"]
+        base = os.path.join(outdir, "%s_%s" % (tag, name))
         open(base + "_profiled_command.txt", "w").write(" ".join(bench).replace(ROOT + "/", "") + "\n  under: rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE --kernel-trace | "
                                                        "--pmc WRITE_SIZE --kernel-trace  (three runs; statistics cut to the dispatches between bench.py's two marker launches)\n")
         rc = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", scratch + "/stats", "--"] + bench, base + "_bench_under_profiler.json", scratch + "/stats.log")
@@ -145,7 +151,7 @@ def main():
         # start to the last end of the region, per step (the launches overlap, their sum is not the step's time)
         step_us = list(kernels.values())[0]["avg_us"] if single else span_ns / 1e3 / steps
         summary = {
-            "tag": tag, "workload": wl, "code_id": line.get("code_id"), "build_flags": line.get("build_flags"), "steps_timed": steps,
+            "tag": tag, "workload": wl, "plan_given": shape or None, "code_id": line.get("code_id"), "build_flags": line.get("build_flags"), "steps_timed": steps,
             "scope": scope, "command": " ".join(bench).replace(ROOT + "/", ""),
             "bench_line": {"kernel": rf["kernel"], "kernel_ms": rf["kernel_ms"], "kernel_ms_median": rf["kernel_ms_median"], "frac": rf["frac"],
                            "value": line["value"], "ms_per_step": line["ms_per_step"], "frames_per_launch": frames,
