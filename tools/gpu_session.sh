@@ -206,6 +206,7 @@ PY
     pyramid_sweep)  # config 5: frames per prefetched chunk x streams (PYR_CHUNKS, PYR_STREAMS, PYR_PLACED=1: buffers from the product's allocator)
       timeout 900 python tools/pyramid_sweep.py ${PYR_N:-1024} ${ROUNDS:-3} > "$OUT/pyramid_sweep${PYR_TAG:-}.txt" 2>&1; grep -av amdgpu.ids "$OUT/pyramid_sweep${PYR_TAG:-}.txt" | tail -24 ;;
     vmm_check)  # hipMemMap with an offset; address ranges given back and re-used / kept / re-used after an ordinary hipMalloc + hipFree (tools/vmm_offset_check.hip)
+      [ -x tools/bin/vmm_offset_check ] || { mkdir -p tools/bin; hipcc --offload-arch=gfx950 -O2 -o tools/bin/vmm_offset_check tools/vmm_offset_check.hip; }
       ( echo "--- stripes of 64 MiB (an offset into the handle)"; tools/bin/vmm_offset_check 3 512 64 1
         echo "--- whole pieces, address ranges given back and re-used"; tools/bin/vmm_offset_check 3 512 512 4
         echo "--- whole pieces, address ranges kept (VMM_KEEP_VA=1)"; VMM_KEEP_VA=1 tools/bin/vmm_offset_check 3 512 512 5
