@@ -336,33 +336,47 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
     return true;
   };
   size_t ref0 = 0;  // group
-  bool ref0_chosen = false;
+  size_t ref0_tried = 0, ref1_tried = 0;
+  float ref0_rel = -1.f, ref1_rel = -1.f;
+  std::vector<char> ref1_was(0);
   auto classify = [&]() -> int {
     const size_t NG = a->handles.size() / G;  // whole groups (grow() makes pieces in whole groups)
-    // The reference: one of the first three groups, the one that splits the first batch best.  A piece the driver put together from
-    // several blocks may straddle two classes; against such a reference everything looks half slow and nothing falls apart.
-    if (!ref0_chosen && NG >= 4) {
-      ref0_chosen = true;
-      float best_rel = -1.f;
-      std::vector<float> best_t;
-      for (size_t r = 0; r < 3; r++) {
-        std::vector<float> t(NG, 0.f), v;
-        for (size_t g = 0; g < NG; g++)
-          if (g != r) {
-            if (!timed(r, g, &t[g])) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
-            v.push_back(t[g]);
-          }
-        float rel = 0.f;
-        (void)placement_cut(v, &rel);
-        if (rel > best_rel) best_rel = rel, ref0 = r, best_t = t;
-        if (rel > 0.05f) break;  // a clean split: this reference lies in one class
-      }
-      t0 = best_t;
-    }
-    for (size_t g = t0.size(); g < NG; g++) {
+    // The reference: one of the first eight groups, the one that splits the groups seen so far best -- tried three per call until one
+    // splits them cleanly (clusters 5.5 % apart).  A group whose pieces the driver took from two blocks straddles two classes; against
+    // such a reference everything looks half slow and the split is weak or missing.
+    for (size_t g = t0.size(); g < NG; g++) {  // the groups that are new since the last call, against the reference of the moment
       float ms = 0.f;
       if (g != ref0 && !timed(ref0, g, &ms)) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
       t0.push_back(ms);
+    }
+    if (ref0_tried > 0) {  // how the reference of the moment splits what is there now
+      std::vector<float> v;
+      for (size_t g = 0; g < NG; g++)
+        if (g != ref0) v.push_back(t0[g]);
+      (void)placement_cut(v, &ref0_rel);
+    }
+    // (no structure at all -- everything seen so far is one class -- is no reason to doubt the reference: wait for more groups)
+    const bool doubt = ref0_tried == 0 || (ref0_rel >= 0.025f && ref0_rel < 0.055f);
+    for (int tries = 0; NG >= 4 && doubt && tries < 3 && ref0_rel < 0.055f && ref0_tried < std::min<size_t>(NG, 8); tries++) {
+      const size_t r = ref0_tried++;
+      std::vector<float> t(NG, 0.f), v;
+      for (size_t g = 0; g < NG; g++)
+        if (g != r) {
+          if (r == ref0 && g < t0.size() && t0[g] > 0) t[g] = t0[g];  // (already measured against this one)
+          else if (!timed(r, g, &t[g])) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
+          v.push_back(t[g]);
+        }
+      float rel = 0.f;
+      (void)placement_cut(v, &rel);
+      if (rel > ref0_rel || (r == ref0 && t0.size() < NG)) {
+        if (r != ref0) {  // another first reference: the second level starts over
+          t1.clear();
+          ref1 = -1;
+          ref1_tried = 0;
+          ref1_rel = -1.f;
+        }
+        ref0_rel = rel, ref0 = r, t0 = t;
+      }
     }
     cls.assign(a->handles.size(), 0);
     if (NG < 2) return MDC_OK;
@@ -373,6 +387,36 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
       for (size_t g : todo)
         if (!timed((size_t)ref1, g, &t1[g])) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
       gcls = placement_classes(t0, ref0, t1, &ref1, gap, nullptr);
+    }
+    // the second reference likewise: while the fast groups do not fall apart cleanly, another of them is tried (two per call, six in all)
+    std::vector<size_t> fast;
+    for (size_t g = 0; g < NG; g++)
+      if (gcls[g] != 0) fast.push_back(g);
+    ref1_rel = std::max(ref1_rel, gap[1]);
+    ref1_was.resize(NG, 0);
+    if (ref1 >= 0) ref1_was[(size_t)ref1] = 1;
+    for (int tries = 0; fast.size() >= 4 && tries < 2 && ref1_rel < 0.055f && ref1_tried < 6; tries++) {
+      long cand = -1;
+      for (size_t g : fast)
+        if (!ref1_was[g]) {
+          cand = (long)g;
+          break;
+        }
+      if (cand < 0) break;
+      ref1_was[(size_t)cand] = 1;
+      ref1_tried++;
+      std::vector<float> t(NG, -1.f), v;
+      for (size_t g : fast)
+        if ((long)g != cand) {
+          if (!timed((size_t)cand, g, &t[g])) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: timing a stream failed");
+          v.push_back(t[g]);
+        }
+      float rel = 0.f;
+      (void)placement_cut(v, &rel);
+      if (rel > ref1_rel) {
+        ref1_rel = rel, ref1 = cand, t1 = t;
+        gcls = placement_classes(t0, ref0, t1, &ref1, gap, nullptr);
+      }
     }
     for (size_t k = 0; k < NG * G; k++) cls[k] = gcls[k / G];
     return MDC_OK;
