@@ -21,8 +21,6 @@
 #include "mdc_ctx.h"
 #include "placement_classes.h"
 
-#include <functional>
-
 namespace mdc {
 namespace {
 
@@ -258,11 +256,8 @@ struct Range {
   std::vector<size_t> piece_ids;
 };
 
-// probe (optional): times what the caller will run on a candidate set of ranges (-> status, *ms); with it the allocator maps up to
-// MDC_PLACE_TRIES (3) different choices of pieces from the classified pool, one after the other, and keeps the fastest.
-typedef std::function<int(const std::vector<Range>&, float*)> RangeProbe;
 int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_t s, Events& ev, int* n_cls_out, int* pieces_out, int* piece_mib_out,
-                    char* note, size_t note_cap, const RangeProbe* probe = nullptr, float* probe_ms = nullptr) {
+                    char* note, size_t note_cap) {
   hipMemAllocationProp prop = {};
   prop.type = hipMemAllocationTypePinned;
   prop.location.type = hipMemLocationTypeDevice;
@@ -486,108 +481,35 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
     }
     for (size_t k = NG * G; k < M; k++) by_cls[cls[k]].push_back(k);  // (pieces beyond the last whole group: creation order, no classification)
   }
-  // One choice of pieces for all ranges.  `shift` (tries > 0) moves the window from which every class's pieces are taken by a share of
-  // the class's list, where the class has pieces to spare: another selection from the same pool.
-  auto choose = [&](int shift) {
-    std::vector<size_t> from[3];
-    for (int k = 0; k < 3; k++) {
-      const size_t n = by_cls[k].size(), per = std::min(n, (need + 2) / 3 + 1);
-      const size_t off = n > per ? std::min<size_t>((size_t)shift * per, n - per) : 0;
-      for (size_t q = 0; q < n; q++) from[k].push_back(by_cls[k][(off + q) % n]);
-    }
-    size_t at[3] = {0, 0, 0};
-    auto take = [&](int& turn) -> size_t {  // the next piece of class `turn`, or of the class after it that still has one
-      for (int q = 0; q < 3; q++) {
-        const int k = (turn + q) % 3;
-        if (at[k] < from[k].size()) {
-          turn = (k + 1) % 3;
-          return from[k][at[k]++];
-        }
+  size_t at[3] = {0, 0, 0};
+  auto take = [&](int& turn) -> size_t {  // the next piece of class `turn`, or of the class after it that still has one
+    for (int q = 0; q < 3; q++) {
+      const int k = (turn + q) % 3;
+      if (at[k] < by_cls[k].size()) {
+        turn = (k + 1) % 3;
+        return by_cls[k][at[k]++];
       }
-      return 0;
-    };
-    for (Range& r : ranges) r.piece_ids.clear();
-    if (compose == 1) {
-      size_t next = 0;
-      for (Range& r : ranges)
-        for (size_t k = 0; k < r.pieces; k++) r.piece_ids.push_back(next++);
-    } else if (compose == 2) {  // diagnosis: a whole range in one class (range k: class k mod 3), the rest from wherever
-      for (size_t i = 0; i < ranges.size(); i++)
-        for (size_t k = 0; k < ranges[i].pieces; k++) {
-          int turn = (int)(i % 3);
-          ranges[i].piece_ids.push_back(take(turn));
-        }
-    } else {  // piece by piece round the classes, all ranges in step (placement_classes.h)
-      std::vector<size_t> want;
-      for (const Range& r : ranges) want.push_back(r.pieces);
-      const std::vector<std::vector<size_t>> ids = placement_compose(from, want);
-      for (size_t i = 0; i < ranges.size(); i++) ranges[i].piece_ids = ids[i];
     }
+    return 0;
   };
-  // Every piece of a choice is mapped a second time, in its place in its range (the probe mappings stay; whole pieces: hipMemMap refuses
-  // an offset into a handle -- hipErrorInvalidValue on ROCm 7.2, as on CUDA -- so a range's classes alternate piece by piece).
-  typedef std::vector<std::pair<void*, size_t>> Maps;
-  auto map_choice = [&](Maps& maps) -> int {
-    for (Range& r : ranges) {
-      MDC_HIP(c, hipMemAddressReserve(&r.va, r.pieces * piece, gran, nullptr, 0));
-      a->reserved.push_back({r.va, r.pieces * piece});
-      for (size_t t = 0; t < r.piece_ids.size(); t++) {
-        char* where = static_cast<char*>(r.va) + t * piece;
-        MDC_HIP(c, hipMemMap(where, piece, 0, a->handles[r.piece_ids[t]], 0));
-        maps.push_back({where, piece});
+  if (compose == 1) {
+    size_t next = 0;
+    for (Range& r : ranges)
+      for (size_t k = 0; k < r.pieces; k++) r.piece_ids.push_back(next++);
+  } else if (compose == 2) {  // diagnosis: a whole range in one class (range k: class k mod 3), the rest from wherever
+    for (size_t i = 0; i < ranges.size(); i++)
+      for (size_t k = 0; k < ranges[i].pieces; k++) {
+        int turn = (int)(i % 3);
+        ranges[i].piece_ids.push_back(take(turn));
       }
-      MDC_HIP(c, hipMemSetAccess(r.va, r.pieces * piece, &acc, 1));
-    }
-    return MDC_OK;
-  };
-  auto unmap_choice = [&](Maps& maps) {  // (its addresses are never used again: nothing stale can be served for them)
-    (void)hipDeviceSynchronize();
-    for (size_t k = maps.size(); k-- > 0;) (void)hipMemUnmap(maps[k].first, maps[k].second);
-    maps.clear();
-  };
-  const int tries = (probe && compose == 0 && n_cls[0] != (int)M) ? std::max(1, std::min(8, env_int(getenv("MDC_PLACE_TRIES"), 3))) : 1;
-  Maps best_maps;
-  std::vector<Range> best_ranges;
-  float best_ms = std::numeric_limits<float>::infinity();
-  char tried[96] = "";
-  for (int t = 0; t < tries; t++) {
-    choose(t);
-    if (t > 0 && !best_ranges.empty()) {  // the same pieces as an earlier try (a small pool): nothing new to learn
-      bool same = true;
-      for (size_t i = 0; i < ranges.size(); i++) same = same && ranges[i].piece_ids == best_ranges[i].piece_ids;
-      if (same) break;
-    }
-    Maps maps;
-    rc = map_choice(maps);
-    if (rc != MDC_OK) {
-      unmap_choice(maps);
-      if (best_ranges.empty()) return rc;
-      break;  // (address space: keep what there is)
-    }
-    float ms = 0.f;
-    if (probe && tries > 1) {
-      rc = (*probe)(ranges, &ms);
-      if (rc != MDC_OK) {
-        unmap_choice(maps);
-        unmap_choice(best_maps);
-        return rc;
-      }
-      snprintf(tried + strlen(tried), sizeof tried - strlen(tried), "%s%.4f", t ? " / " : "", ms);
-    }
-    if (best_ranges.empty() || ms < best_ms) {
-      unmap_choice(best_maps);
-      best_maps.swap(maps);
-      best_ranges = ranges;
-      best_ms = ms;
-    } else {
-      unmap_choice(maps);
-    }
+  } else {  // piece by piece round the classes, all ranges in step (placement_classes.h)
+    std::vector<size_t> want;
+    for (const Range& r : ranges) want.push_back(r.pieces);
+    const std::vector<std::vector<size_t>> ids = placement_compose(by_cls, want);
+    for (size_t i = 0; i < ranges.size(); i++) ranges[i].piece_ids = ids[i];
   }
-  ranges = best_ranges;
-  if (probe_ms) *probe_ms = (tries > 1 && std::isfinite(best_ms)) ? best_ms : 0.f;
-  for (const auto& m : best_maps) a->mapped.push_back(m);
-  // ---- the surplus goes back to the device (MDC_PLACE_KEEP_SURPLUS=1: stays mapped until the end).  Only pieces no range uses are
-  // touched, after everything that ever ran on them has finished.
+  // ---- the surplus goes back to the device before anything else is mapped (MDC_PLACE_KEEP_SURPLUS=1: stays mapped until the end).
+  // Only pieces no range uses are touched, after everything that ever ran on them has finished.
   std::vector<char> used(M, 0);
   for (const Range& r : ranges)
     for (size_t id : r.piece_ids) used[id] = 1;
@@ -606,6 +528,20 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
         a->handles[k] = nullptr;
         returned++;
       }
+    MDC_HIP(c, hipDeviceSynchronize());
+  }
+  // ---- the ranges: every piece mapped a second time, in its final place (the probe mappings of the pieces in use stay: no address a
+  // kernel may still know is ever unmapped while the arena lives).  Whole pieces: hipMemMap refuses an offset into a handle
+  // (hipErrorInvalidValue on ROCm 7.2, as on CUDA), so a range's classes alternate piece by piece.
+  for (Range& r : ranges) {
+    MDC_HIP(c, hipMemAddressReserve(&r.va, r.pieces * piece, gran, nullptr, 0));
+    a->reserved.push_back({r.va, r.pieces * piece});
+    for (size_t t = 0; t < r.piece_ids.size(); t++) {
+      char* where = static_cast<char*>(r.va) + t * piece;
+      MDC_HIP(c, hipMemMap(where, piece, 0, a->handles[r.piece_ids[t]], 0));
+      a->mapped.push_back({where, piece});
+    }
+    MDC_HIP(c, hipMemSetAccess(r.va, r.pieces * piece, &acc, 1));
   }
   MDC_HIP(c, hipDeviceSynchronize());
   for (int k = 0; k < 3; k++) n_cls_out[k] = n_cls[k];
@@ -619,7 +555,6 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
            "pieces: %d / %d / %d (clusters %.1f %%, %.1f %% apart), in use %d / %d / %d; %s",
            ranges.size(), M - returned, piece >> 20, M, returned, n_cls[0], n_cls[1], n_cls[2], gap[0] * 100, gap[1] * 100, used_cls[0], used_cls[1], used_cls[2],
            compose == 1 ? "creation order, no classification" : compose == 2 ? "a range in ONE class (diagnosis)" : "every range striped over the classes");
-  if (tried[0]) snprintf(note + strlen(note), note_cap - strlen(note), "; the pass on %s choices of pieces: %s ms, fastest kept", tries > 2 ? "several" : "two", tried);
   return MDC_OK;
 }
 
@@ -644,24 +579,16 @@ int place_vmm(mdc_ctx* c, Arena* a, size_t in_bytes, size_t out_bytes, size_t fr
   std::vector<Range> ranges(2);
   ranges[0].bytes = in_bytes;
   ranges[1].bytes = out_bytes;
-  const size_t fill_bytes = std::min(in_bytes, (size_t)probe_frames * frame_in) & ~(size_t)3;
-  const RangeProbe pass_on = [&](const std::vector<Range>& rs, float* ms) -> int {  // the pass itself on a candidate pair
-    if (!fill_noise(rs[0].va, fill_bytes, 0x1234u, s)) return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: fill launch failed");
-    const int rc_ = time_pass(c, (const uint8_t*)rs[0].va, (float*)rs[1].va, probe_frames, flags, s, ev.e0, ev.e1, ms);
-    (void)hipStreamSynchronize(s);
-    return rc_;
-  };
-  float tried_ms = 0.f;
-  int rc = assemble_ranges(c, a, ranges, s, ev, r->class_count, &r->pieces, &r->piece_mib, r->note, sizeof r->note, &pass_on, &tried_ms);
+  int rc = assemble_ranges(c, a, ranges, s, ev, r->class_count, &r->pieces, &r->piece_mib, r->note, sizeof r->note);
   if (rc != MDC_OK) return rc;
   a->in_va = ranges[0].va;
   a->out_va = ranges[1].va;
-  if (tried_ms > 0) {
-    r->ms_chosen = tried_ms;
-  } else {  // (one choice only: the pass on the pair that is handed out)
-    rc = pass_on(ranges, &r->ms_chosen);
-    if (rc != MDC_OK) return rc;
-  }
+  // the pass on the pair that is handed out
+  if (!fill_noise(a->in_va, std::min(in_bytes, (size_t)probe_frames * frame_in) & ~(size_t)3, 0x1234u, s))
+    return fail(c, MDC_ERR_HIP, "mdc_alloc_placed_device: fill launch failed");
+  rc = time_pass(c, (const uint8_t*)a->in_va, (float*)a->out_va, probe_frames, flags, s, ev.e0, ev.e1, &r->ms_chosen);
+  (void)hipStreamSynchronize(s);
+  if (rc != MDC_OK) return rc;
   r->candidates_in = r->candidates_out = 1;
   return MDC_OK;
 }
