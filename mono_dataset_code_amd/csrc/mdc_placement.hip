@@ -353,7 +353,10 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
       std::vector<float> v;
       for (size_t g = 0; g < NG; g++)
         if (g != ref0) v.push_back(t0[g]);
-      (void)placement_cut(v, &ref0_rel);
+      const float cut = placement_cut(v, &ref0_rel);
+      size_t slow = 0;
+      for (float x : v) slow += (std::isfinite(cut) && x > cut) ? 1 : 0;
+      if (slow * 3 > v.size() * 2) ref0_rel *= 0.4f;  // (the same plausibility rule as for the candidates below)
     }
     // (no structure at all -- everything seen so far is one class -- is no reason to doubt the reference: wait for more groups)
     const bool doubt = ref0_tried == 0 || (ref0_rel >= 0.025f && ref0_rel < 0.055f);
@@ -367,7 +370,12 @@ int assemble_ranges(mdc_ctx* c, Arena* a, std::vector<Range>& ranges, hipStream_
           v.push_back(t[g]);
         }
       float rel = 0.f;
-      (void)placement_cut(v, &rel);
+      const float cut = placement_cut(v, &rel);
+      // A reference's own class is a third of the device: a split that puts more than two thirds of the groups into the slow cluster is
+      // an odd reference (a group of scattered pages that is slow with almost everything), however far apart its clusters are.
+      size_t slow = 0;
+      for (float x : v) slow += (std::isfinite(cut) && x > cut) ? 1 : 0;
+      if (slow * 3 > v.size() * 2) rel *= 0.4f;
       if (rel > ref0_rel || (r == ref0 && t0.size() < NG)) {
         if (r != ref0) {  // another first reference: the second level starts over
           t1.clear();
