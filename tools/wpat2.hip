@@ -1,8 +1,11 @@
 // Write-pattern microbenchmark, second take: the tile patterns of wpat.hip with compile-time tile shapes (no integer
 // division in the store loop -- wpat's tile kernel computes e / TW per store and may be VALU-bound rather than
 // memory-bound), plain and nontemporal stores, and the frame loop innermost or outermost.
-//   hipcc --offload-arch=gfx950 -O3 tools/wpat2.hip -o tools/bin/wpat2 && tools/bin/wpat2 [OW OH frames]
+//   hipcc --offload-arch=gfx950 -O3 tools/wpat2.hip -Iinclude -Lmono_dataset_code_amd -lmdc_hip -Wl,-rpath,'$ORIGIN/../../mono_dataset_code_amd' -o tools/bin/wpat2
+//   tools/bin/wpat2 [OW OH frames]          WPAT_PLACED=1: the buffer comes from the product's allocator (striped over the device's memory classes)
 #include <hip/hip_runtime.h>
+
+#include "mdc_hip.h"
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -54,7 +57,17 @@ int main(int argc, char** argv) {
   const int OW = argc > 1 ? atoi(argv[1]) : 640, OH = argc > 2 ? atoi(argv[2]) : 480, NF = argc > 3 ? atoi(argv[3]) : 4096;
   const size_t n = (size_t)OW * OH * NF;
   float* d;
-  CK(hipMalloc(&d, n * 4));
+  if (getenv("WPAT_PLACED")) {
+    mdc_ctx* ctx = nullptr;
+    if (mdc_create(0, &ctx) != MDC_OK) { printf("mdc_create: %s\n", mdc_last_error(nullptr)); return 1; }
+    size_t bytes[1] = {n * 4};
+    mdc_striped_set set;
+    if (mdc_alloc_striped_set_device(ctx, 1, bytes, nullptr, &set) != MDC_OK) { printf("allocator: %s\n", mdc_last_error(ctx)); return 1; }
+    d = (float*)set.d_ptr[0];
+    printf("buffer from the product's allocator: %s\n", set.note);
+  } else {
+    CK(hipMalloc(&d, n * 4));
+  }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -96,12 +109,11 @@ int main(int argc, char** argv) {
         }                                                                                                                           \
   } while (0)
   RUN(128, 32, 1024);
-  RUN(128, 32, 512);
   RUN(128, 16, 512);
-  RUN(64, 32, 512);
   RUN(128, 8, 256);
   RUN(128, 8, 64);
-  RUN(64, 16, 64);
-  RUN(64, 4, 256);
+  RUN(640, 4, 640);
+  RUN(640, 2, 640);
+  RUN(640, 8, 640);
   return 0;
 }
