@@ -9,6 +9,7 @@ Both land next to this file so they travel with the source tree to the GPU box.
 import os
 import shutil
 import subprocess
+import time
 import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
@@ -127,11 +128,23 @@ def code_id(defines=()):
     return h.hexdigest()[:16]
 
 
+def _linked_from(lib, defines=()):
+    """Does `lib` carry the identity of the sources as they are NOW?  (Modification times alone are fooled by an edit that lands while a
+    build is running: the objects are from before it, the library's time stamp from after.)"""
+    try:
+        with open(lib, "rb") as f:
+            return code_id(defines).encode() in f.read()
+    except OSError:
+        return False
+
+
 def _compile_link_hip(out, defines=(), objdir_tag="product"):
     """Every .hip translation unit -> its own object, in parallel (the kernels TU alone takes a minute), then one link.
     An object is redone when its source, a shared header or the -D list changed."""
     from concurrent.futures import ThreadPoolExecutor
 
+    started = time.time()
+    identity = code_id(defines)  # of the sources as the compilers are about to read them
     objdir = os.path.join(PKG, "build", objdir_tag)
     os.makedirs(objdir, exist_ok=True)
     flags = [f for f in HIP_FLAGS if f != "-shared"] + ["-I" + INC] + ["-D" + d for d in defines]
@@ -141,7 +154,7 @@ def _compile_link_hip(out, defines=(), objdir_tag="product"):
     jobs = []
     for src in HIP_SOURCES:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        if flags_changed or _stale(obj, [src] + headers):
+        if flags_changed or _stale(obj, [src] + headers) or not os.path.exists(out) or not _linked_from(out, defines):
             jobs.append([hipcc()] + flags + ["-c", src, "-o", obj])
     with ThreadPoolExecutor(max_workers=max(1, len(jobs))) as ex:
         list(ex.map(_run, jobs))
@@ -151,14 +164,17 @@ def _compile_link_hip(out, defines=(), objdir_tag="product"):
     # mdc_code_id(): the identity of this build (include/mdc_hip.h), a generated one-line translation unit
     idsrc = os.path.join(objdir, "mdc_code_id.cpp")
     with open(idsrc, "w") as f:
-        f.write('#include "mdc_hip.h"\nextern "C" const char* mdc_code_id(void) { return "%s"; }\n' % code_id(defines))
+        f.write('#include "mdc_hip.h"\nextern "C" const char* mdc_code_id(void) { return "%s"; }\n' % identity)
     idobj = idsrc + ".o"
     _run(["g++", "-O1", "-fPIC", "-fvisibility=hidden", "-I" + INC, "-c", idsrc, "-o", idobj])
     _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + EXPORT_MAP] + objs + [idobj, "-o", out])
+    if any(os.path.getmtime(d) > started for d in HIP_DEPS):
+        sys.stderr.write("mono_dataset_code_amd.build: a source changed while %s was being built; it is stamped %s and the next build redoes it\n"
+                         % (os.path.basename(out), identity))
 
 
 def build_hip(force=False):
-    if force or _stale(LIB_HIP, HIP_DEPS + [RECIPE]):
+    if force or _stale(LIB_HIP, HIP_DEPS + [RECIPE]) or not _linked_from(LIB_HIP):
         if force:
             shutil.rmtree(os.path.join(PKG, "build", "product"), ignore_errors=True)
         _compile_link_hip(LIB_HIP)
@@ -230,10 +246,10 @@ def build_variant(name, defines):
     d = os.path.join(PKG, "variants")
     os.makedirs(d, exist_ok=True)
     out = os.path.join(d, "libmdc_hip_%s.so" % name)
-    if _stale(out, HIP_DEPS + [RECIPE]):
+    diag = [] if name == "debug" else ["MDC_DIAGNOSIS_BUILD=1"]
+    if _stale(out, HIP_DEPS + [RECIPE]) or not _linked_from(out, diag + list(defines)):
         # MDC_DIAGNOSIS_BUILD: the licence for the wrong-result switches of csrc/mdc_build_config.h -- only ever set here,
         # for a library that lands under variants/ and reports itself through mdc_build_flags()
-        diag = [] if name == "debug" else ["MDC_DIAGNOSIS_BUILD=1"]
         _compile_link_hip(out, diag + list(defines), objdir_tag="variant_" + name)
     return out
 
